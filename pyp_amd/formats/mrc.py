@@ -42,7 +42,7 @@ def make_header(shape, dtype=np.float32, pixel_size=None, stats=None):
     h["xlen"], h["ylen"], h["zlen"] = nx * ps, ny * ps, nz * ps
     h["alpha"] = h["beta"] = h["gamma"] = 90.0
     h["mapc"], h["mapr"], h["maps"] = 1, 2, 3
-    h["map"] = b"MAP "
+    h["map"] = b"MAP"          # the reference strips the blank: "MAP" + NUL (mrc.py:381, :483)
     h["byteorder"] = _LITTLE_STAMP
     if stats is not None:
         h["amin"], h["amax"], h["amean"], h["rms"] = stats
