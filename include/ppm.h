@@ -1,0 +1,161 @@
+/* ppm.h — C ABI of libpypmatch.so: per-particle projection matching and Fourier-slice
+ * insertion on one MI355X (gfx950).  This is the drop-in boundary for the numerics PYP
+ * shells out to external binaries (none of which ship as source):
+ *
+ *   ppm_refine_batch      replaces the per-range `refine3d` process that
+ *                         src/pyp/refine/frealign/frealign.py:3918-3994 (mrefine_version)
+ *                         scripts and src/pyp/system/local_run.py:472-579 fans out; the
+ *                         `.par` twin is src/pyp/system/wrapper_functions.py:512-561.
+ *   ppm_insert_batch      replaces the per-range `reconstruct3d` process scripted at
+ *                         src/pyp/refine/frealign/frealign.py:1780-1824 (split_reconstruction).
+ *   ppm_accum_add /       replace `local_merge3d` (frealign.py:1878-1888): sum of dump pairs.
+ *   ppm_accum_download
+ *   ppm_finalize          replaces `merge3d` (frealign.py:2075-2093): FSC / part-FSC / SSNR table,
+ *                         Wiener-filtered map and the two half maps.
+ *   ppm_reference_create  is the "input reconstruction" preparation both binaries do at start-up
+ *                         (answer 4 of the refine3d script, frealign.py:3923).
+ *
+ * A parameter row is the 32-column `.cistem` row in file order
+ * (src/pyp/inout/metadata/cistem_star_file.py:596-628), held as doubles like the reference
+ * holds it in RAM (:716-727).  Angles in degrees, shifts in Angstrom (src/pyp/analysis/scores.py:693).
+ *
+ * Conventions: all functions return 0 on success, a negative errno-style code on failure and
+ * leave a message for ppm_last_error().  The caller owns every host buffer; the library owns
+ * device memory.  Handles are not thread-safe; different handles may be used from different
+ * threads.  No torch types cross this boundary.
+ */
+#ifndef PPM_H
+#define PPM_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PPM_NCOL 32 /* columns of a .cistem row */
+/* column indices inside a row (cistem_star_file.py:596-628) */
+enum {
+    PPM_POS = 0, PPM_PSI = 1, PPM_THETA = 2, PPM_PHI = 3, PPM_XSHIFT = 4, PPM_YSHIFT = 5,
+    PPM_DF1 = 6, PPM_DF2 = 7, PPM_ANGAST = 8, PPM_PSHIFT = 9, PPM_FILM = 10, PPM_OCC = 11,
+    PPM_LOGP = 12, PPM_SIGMA = 13, PPM_SCORE = 14, PPM_PIXEL = 15, PPM_VOLTAGE = 16,
+    PPM_CS = 17, PPM_AMP = 18, PPM_PIND = 26, PPM_TIND = 27
+};
+
+#define PPM_MAX_SHIFT_STEPS 8 /* half-width of the global-search shift window, in search-grid steps */
+#define PPM_MAX_TOP_HITS 64
+
+/* Refinement settings = the numeric answers of the refine3d prompt script
+ * (frealign.py:3918-3994; answer numbers as in SURVEY.md §9.1). */
+typedef struct ppm_refine_cfg {
+    int box;                  /* particle box edge N (power of two, 32..512) */
+    float pixel_size;         /* 15: Angstrom per pixel */
+    float molecular_mass_kda; /* 16 (kept for the log; not used by matching) */
+    float mask_radius;        /* 18: outer mask radius, Angstrom */
+    float res_low;            /* 19: low-resolution limit, Angstrom (0 = none) */
+    float res_high;           /* 20: high-resolution limit, Angstrom */
+    float res_signed_cc;      /* 21: rings at lower resolution than this are summed signed, the
+                                 rest by absolute value; 0 = all signed */
+    float search_mask_radius; /* 23: mask radius for the global search, Angstrom (0 = mask_radius) */
+    float res_search;         /* 24: resolution limit of the global search, Angstrom */
+    float angular_step;       /* 25: degrees */
+    int top_hits;             /* 26: global-search hits that get refined (the caller passes 20) */
+    float search_range_x;     /* 27: Angstrom, 0 = widest supported window */
+    float search_range_y;     /* 28 */
+    int global_search;        /* 36 */
+    int local_refine;         /* 37 */
+    int refine_psi, refine_theta, refine_phi, refine_x, refine_y; /* 38-42 */
+    int normalize;            /* 46: normalise particles */
+    int invert;               /* 47: invert contrast */
+    /* build-defined knobs (0 = default), DESIGN.md "search driver" */
+    float mask_falloff;       /* cosine edge width of the mask, Angstrom (default 20) */
+    int iters_hit;            /* compass iterations run on every hit (default 3) */
+    int iters_final;          /* further iterations on the best hit / on a local-only start (default 6) */
+    float local_angle_step;   /* first step of a local-only refinement, degrees (default 2.5) */
+    float local_shift_step;   /* same for shifts, pixels (default 2) */
+} ppm_refine_cfg;
+
+/* Reconstruction settings = numeric answers of the reconstruct3d script (frealign.py:1780-1824). */
+typedef struct ppm_recon_cfg {
+    int box;
+    float pixel_size;
+    float res_limit;        /* reconstruction resolution limit, Angstrom (caller passes 2*pixel) */
+    float score_weight_bfactor; /* "weighting factor" refine_bsc, A^2 per score unit; 0 = off */
+    float score_average;    /* mean SCORE used by the weighting (from <name>_stat.cistem or the rows) */
+    float score_threshold;  /* rows with SCORE below it are skipped (caller passes 0) */
+    int normalize;
+    int invert;
+    int split_by_pind;      /* 1: half = PIND parity, 0: half = POSITION_IN_STACK parity */
+    float mask_radius;      /* outer radius for the normalisation statistics, Angstrom */
+} ppm_recon_cfg;
+
+typedef struct ppm_final_cfg {
+    float molecular_mass_kda;
+    float inner_radius;     /* Angstrom */
+    float outer_radius;     /* Angstrom */
+    float mask_falloff;     /* Angstrom (default 10) */
+} ppm_final_cfg;
+
+#define PPM_STATS_COLS 7 /* shell, resolution A, ring radius, FSC, part-FSC, part-SSNR, rec-SSNR
+                            (src/pyp/postprocess/core.py:203-221; frealign.py:2559) */
+
+typedef struct ppm_ref ppm_ref_t;
+typedef struct ppm_accum ppm_accum_t;
+
+/* kernels whose device time the library accumulates when profiling is on */
+enum { PPM_K_PREP = 0, PPM_K_BANK = 1, PPM_K_GLOBAL = 2, PPM_K_TOPK = 3, PPM_K_LOCAL = 4,
+       PPM_K_INSERT = 5, PPM_K_FINAL = 6, PPM_K_COUNT = 7 };
+
+int ppm_init(int device);
+const char *ppm_last_error(void);
+const char *ppm_version(void);
+
+/* vol: n*n*n floats, x fastest. max_band_px: largest Fourier radius (pixels) any later call will
+ * use with this reference (<= n/2). */
+ppm_ref_t *ppm_reference_create(const float *vol, int n, float max_band_px);
+void ppm_reference_destroy(ppm_ref_t *ref);
+
+/* images: n_img * box * box floats. images_on_device != 0 means `images` is a device pointer.
+ * rows_in / rows_out: n_img * PPM_NCOL doubles (host).  Image i belongs to row i. */
+int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *images,
+                     int images_on_device, int n_img, const double *rows_in, double *rows_out);
+/* number of orientation evaluations per particle the last ppm_refine_batch performed
+ * (global grid, local) — for the roofline's algorithmic byte count */
+int ppm_refine_last_counts(ppm_ref_t *ref, long *n_global, long *n_local, long *samples_global,
+                           long *samples_local);
+
+/* symmetry: "C1", "Cn", "Dn", "T", "O", "I".  ext_device_buffer: NULL, or a device buffer of
+ * ppm_accum_floats(box) floats the caller allocated (e.g. a torch tensor, so that RCCL can
+ * reduce it in place); it must be zeroed by the caller. */
+size_t ppm_accum_floats(int box);
+ppm_accum_t *ppm_accum_create(int box, float pixel_size, const char *symmetry,
+                              void *ext_device_buffer);
+void ppm_accum_destroy(ppm_accum_t *acc);
+int ppm_insert_batch(ppm_accum_t *acc, const ppm_recon_cfg *cfg, const void *images,
+                     int images_on_device, int n_img, const double *rows);
+/* host copies of the accumulators: ppm_accum_floats(box) floats laid out
+ * [half 0..1][kz][ky][kx 0..box/2]{re, im, weight} */
+int ppm_accum_download(ppm_accum_t *acc, float *host);
+int ppm_accum_add(ppm_accum_t *acc, const float *host);
+long ppm_accum_count(ppm_accum_t *acc, int half); /* particles inserted so far */
+void ppm_accum_set_count(ppm_accum_t *acc, int half, long count);
+
+/* half1/half2/filtered: box^3 floats each (host).  stats: (box/2) * PPM_STATS_COLS doubles. */
+int ppm_finalize(ppm_accum_t *acc, const ppm_final_cfg *cfg, float *half1, float *half2,
+                 float *filtered, double *stats);
+
+/* device-time accounting with HIP events on the library's stream */
+void ppm_profile_enable(int on);
+void ppm_profile_reset(void);
+int ppm_profile_get(int kernel_id, double *total_ms, long *launches);
+
+/* device memory helpers for callers that keep the particle stack resident in HBM */
+void *ppm_device_alloc(size_t bytes);
+void ppm_device_free(void *p);
+int ppm_device_upload(void *dst, const void *src, size_t bytes);
+int ppm_device_sync(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PPM_H */

@@ -1,0 +1,871 @@
+/* ppm_oracle.c — CPU restatement of the projection-matching + Fourier-insertion path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under pyp_amd/ may import, link or execute this file;
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, as the checker.
+ *
+ * PARITY UNPINNED.  The arithmetic PYP runs on this path lives in binaries whose source is not in
+ * the reference checkout (git-LFS pointers: external/cistem2/{refine3d,reconstruct3d,merge3d},
+ * external/frealign_v9.11/bin/refine3d) and the reference's regression
+ * fixtures (tests/test_pyp.py:445-491) are absent, so no golden vector pins these numbers.
+ * What is restated here is the published FREALIGN / cisTEM method (Grigorieff 2007, 2016;
+ * Lyumkis et al. 2013; Grant, Rohou & Grigorieff 2018) on the call surface the reference does
+ * show: the refine3d answers (src/pyp/refine/frealign/frealign.py:3918-3994), the reconstruct3d
+ * answers (:1780-1824), merge3d (:2075-2093, table parsed at :2557-2567), the 32-column rows
+ * (src/pyp/inout/metadata/cistem_star_file.py:596-628), angles in degrees / shifts in Angstrom
+ * (src/pyp/analysis/scores.py:693) and the ZYZ Euler order phi -> theta -> psi
+ * (src/pyp/analysis/geometry/core.py:1186-1197).  The oracle is pinned instead by synthetic
+ * ground truth (tests/test_oracle_truth.py): poses recovered from projections of a known volume.
+ *
+ * Style: plain loops, double accumulators, no tricks.  The global-search correlation image is
+ * computed BOTH ways: by a zero-filled inverse 2-D FFT (mode 0, the textbook statement) and by
+ * the pruned direct transform over the shift window (mode 1, what the HIP kernel does).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/ppm.h"
+
+#define ORC_PI 3.14159265358979323846
+
+typedef struct { float re, im; } cpx;
+
+/* ------------------------------------------------------------------ FFT (radix-2, any 2^m) */
+#define ORC_MAXLOG 12
+static double *TWC[ORC_MAXLOG + 1], *TWS[ORC_MAXLOG + 1];
+static void fft_tables(void) {
+    /* twiddle tables for n = 2..4096, built once (call before any parallel region) */
+    if (TWC[1]) return;
+    for (int m = 1; m <= ORC_MAXLOG; m++) {
+        int n = 1 << m;
+        double *c = (double *)malloc(sizeof(double) * (n / 2)), *s = (double *)malloc(sizeof(double) * (n / 2));
+        for (int k = 0; k < n / 2; k++) { c[k] = cos(2.0 * ORC_PI * k / n); s[k] = sin(2.0 * ORC_PI * k / n); }
+        TWS[m] = s; TWC[m] = c;
+    }
+}
+
+static void fft1d(cpx *x, int n, int stride, int inverse) {
+    /* in-place iterative Cooley-Tukey on x[0], x[stride], ...; twiddles in double */
+    int j = 0, lg = 0;
+    while ((1 << lg) < n) lg++;
+    for (int i = 1; i < n; i++) {
+        int bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) { cpx t = x[i * stride]; x[i * stride] = x[j * stride]; x[j * stride] = t; }
+    }
+    const double *tc = TWC[lg], *ts = TWS[lg];
+    for (int len = 2; len <= n; len <<= 1) {
+        int q = n / len;
+        for (int i = 0; i < n; i += len) {
+            for (int k = 0; k < len / 2; k++) {
+                double wr = tc[k * q], wi = inverse ? ts[k * q] : -ts[k * q];
+                cpx *a = &x[(i + k) * stride], *b = &x[(i + k + len / 2) * stride];
+                double tr = b->re * wr - b->im * wi, ti = b->re * wi + b->im * wr;
+                double ar = a->re, ai = a->im;
+                a->re = (float)(ar + tr); a->im = (float)(ai + ti);
+                b->re = (float)(ar - tr); b->im = (float)(ai - ti);
+            }
+        }
+    }
+}
+
+static int is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+
+/* ------------------------------------------------------------------ derived geometry */
+typedef struct {
+    int N; double a;
+    double r_hi, r_lo, r_s, ring_signed;
+    int B, W, H;            /* band half-width, row width B+1, rows 2B+1 */
+    int Ns, step, RSx, RSy; /* global-search shift grid */
+    int n_theta, n_psi, n_dir, n_orient;
+    double dpsi;
+} geom_t;
+
+static int geom_init(geom_t *g, const ppm_refine_cfg *c) {
+    memset(g, 0, sizeof(*g));
+    g->N = c->box; g->a = c->pixel_size;
+    if (!is_pow2(g->N) || g->N < 16 || g->a <= 0 || c->res_high <= 0) return -1;
+    double na = g->N * g->a;
+    g->r_hi = na / c->res_high; if (g->r_hi > g->N / 2) g->r_hi = g->N / 2;
+    g->r_lo = c->res_low > 0 ? na / c->res_low : 0.0;
+    g->r_s = c->res_search > 0 ? na / c->res_search : g->r_hi; if (g->r_s > g->r_hi) g->r_s = g->r_hi;
+    g->ring_signed = c->res_signed_cc > 0 ? na / c->res_signed_cc : 1e30;
+    g->B = (int)ceil(g->r_hi) - 1; g->W = g->B + 1; g->H = 2 * g->B + 1;
+    int Bs = (int)ceil(g->r_s) - 1;
+    g->Ns = 2; while (g->Ns < 2 * (Bs + 1)) g->Ns <<= 1; if (g->Ns > g->N) g->Ns = g->N;
+    g->step = g->N / g->Ns;
+    double rx = c->search_range_x / g->a, ry = c->search_range_y / g->a;
+    g->RSx = rx > 0 ? (int)ceil(rx / g->step) : PPM_MAX_SHIFT_STEPS;
+    g->RSy = ry > 0 ? (int)ceil(ry / g->step) : PPM_MAX_SHIFT_STEPS;
+    if (g->RSx > PPM_MAX_SHIFT_STEPS) g->RSx = PPM_MAX_SHIFT_STEPS;
+    if (g->RSy > PPM_MAX_SHIFT_STEPS) g->RSy = PPM_MAX_SHIFT_STEPS;
+    double d = c->angular_step > 0 ? c->angular_step : 15.0;
+    g->n_theta = (int)floor(180.0 / d + 0.5) + 1;
+    g->n_psi = (int)floor(360.0 / d + 0.5); if (g->n_psi < 1) g->n_psi = 1;
+    g->dpsi = 360.0 / g->n_psi;
+    g->n_dir = 0;
+    for (int i = 0; i < g->n_theta; i++) {
+        double th = 180.0 * i / (g->n_theta - 1);
+        int np = (int)floor(360.0 * sin(th * ORC_PI / 180.0) / d + 0.5); if (np < 1) np = 1;
+        g->n_dir += np;
+    }
+    g->n_orient = g->n_dir * g->n_psi;
+    return 0;
+}
+
+/* direction list of the global grid: theta_i = 180 i/(n_theta-1), n_phi = max(1, round(360 sin(theta)/step)) */
+static void grid_direction(const geom_t *g, double dstep, int dir, double *theta, double *phi) {
+    int acc = 0;
+    for (int i = 0; i < g->n_theta; i++) {
+        double th = 180.0 * i / (g->n_theta - 1);
+        int np = (int)floor(360.0 * sin(th * ORC_PI / 180.0) / dstep + 0.5); if (np < 1) np = 1;
+        if (dir < acc + np) { *theta = th; *phi = 360.0 * (dir - acc) / np; return; }
+        acc += np;
+    }
+    *theta = 0; *phi = 0;
+}
+
+static void mat_mul3(const double *a, const double *b, double *c) {
+    double t[9];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+        double v = 0; for (int k = 0; k < 3; k++) v += a[i * 3 + k] * b[k * 3 + j];
+        t[i * 3 + j] = v;
+    }
+    memcpy(c, t, sizeof(t));
+}
+
+/* M = Rz(phi) Ry(theta) Rz(psi); first two columns (the image plane) */
+static void euler_cols(double psi, double theta, double phi, double m[6]) {
+    double ps = psi * ORC_PI / 180, th = theta * ORC_PI / 180, ph = phi * ORC_PI / 180;
+    double cps = cos(ps), sps = sin(ps), cth = cos(th), sth = sin(th), cph = cos(ph), sph = sin(ph);
+    m[0] = cph * cth * cps - sph * sps;  m[1] = -cph * cth * sps - sph * cps;  /* row x */
+    m[2] = sph * cth * cps + cph * sps;  m[3] = -sph * cth * sps + cph * cps;  /* row y */
+    m[4] = -sth * cps;                   m[5] = sth * sps;                     /* row z */
+}
+
+/* ------------------------------------------------------------------ reference cube */
+typedef struct { int N, B, CX, CY; cpx *cube; } oref_t;
+
+void *orc_reference_create(const float *vol, int n, float max_band_px) {
+    fft_tables();
+    if (!is_pow2(n) || max_band_px <= 0) return NULL;
+    if (max_band_px > n / 2) max_band_px = n / 2;
+    int B = (int)ceil(max_band_px) - 1;
+    size_t n3 = (size_t)n * n * n;
+    cpx *f = (cpx *)malloc(n3 * sizeof(cpx));
+    if (!f) return NULL;
+    /* pre-compensate the trilinear interpolation kernel: divide by sinc^2 along each axis
+     * (the real-space envelope that linear interpolation of the transform imposes) */
+    double *sc1 = (double *)malloc(n * sizeof(double));
+    for (int i = 0; i < n; i++) {
+        double u = ORC_PI * (double)(i - n / 2) / n, sv = fabs(u) < 1e-12 ? 1.0 : sin(u) / u;
+        sc1[i] = 1.0 / (sv * sv);
+    }
+    for (int z = 0; z < n; z++) for (int y = 0; y < n; y++) for (int x = 0; x < n; x++) {
+        size_t i = ((size_t)z * n + y) * n + x;
+        f[i].re = (float)(vol[i] * sc1[x] * sc1[y] * sc1[z]); f[i].im = 0;
+    }
+    free(sc1);
+    for (int z = 0; z < n; z++) for (int y = 0; y < n; y++) fft1d(f + ((size_t)z * n + y) * n, n, 1, 0);
+    for (int z = 0; z < n; z++) for (int x = 0; x < n; x++) fft1d(f + (size_t)z * n * n + x, n, n, 0);
+    for (int y = 0; y < n; y++) for (int x = 0; x < n; x++) fft1d(f + (size_t)y * n + x, n, n * n, 0);
+    oref_t *r = (oref_t *)calloc(1, sizeof(oref_t));
+    r->N = n; r->B = B; r->CX = B + 2; r->CY = 2 * B + 3;
+    r->cube = (cpx *)calloc((size_t)r->CX * r->CY * r->CY, sizeof(cpx));
+    double sc = 1.0 / n;
+    for (int z = -B - 1; z <= B + 1; z++) for (int y = -B - 1; y <= B + 1; y++) for (int x = 0; x <= B + 1; x++) {
+        int iz = ((z % n) + n) % n, iy = ((y % n) + n) % n, ix = x % n;
+        cpx v = f[((size_t)iz * n + iy) * n + ix];
+        double sg = ((x + y + z) & 1) ? -sc : sc;      /* origin at the box centre */
+        cpx *o = &r->cube[((size_t)(z + B + 1) * r->CY + (y + B + 1)) * r->CX + x];
+        o->re = (float)(v.re * sg); o->im = (float)(v.im * sg);
+    }
+    free(f);
+    return r;
+}
+
+void orc_reference_destroy(void *p) { oref_t *r = (oref_t *)p; if (r) { free(r->cube); free(r); } }
+
+/* trilinear sample of the cube at Fourier coordinate (X,Y,Z) */
+static void sample_cube(const oref_t *r, double X, double Y, double Z, double *ore, double *oim) {
+    int conj = 0;
+    if (X < 0) { X = -X; Y = -Y; Z = -Z; conj = 1; }
+    int x0 = (int)floor(X), y0 = (int)floor(Y), z0 = (int)floor(Z);
+    double fx = X - x0, fy = Y - y0, fz = Z - z0;
+    int off = r->B + 1;
+    double sr = 0, si = 0;
+    for (int dz = 0; dz < 2; dz++) for (int dy = 0; dy < 2; dy++) for (int dx = 0; dx < 2; dx++) {
+        double w = (dx ? fx : 1 - fx) * (dy ? fy : 1 - fy) * (dz ? fz : 1 - fz);
+        const cpx *v = &r->cube[((size_t)(z0 + dz + off) * r->CY + (y0 + dy + off)) * r->CX + (x0 + dx)];
+        sr += w * v->re; si += w * v->im;
+    }
+    *ore = sr; *oim = conj ? -si : si;
+}
+
+/* slice for one orientation into band layout [ky+B][kx], zero outside k^2 < rmax^2 */
+static void extract_slice(const oref_t *r, const geom_t *g, const double m[6], double rmax, cpx *out) {
+    double r2 = rmax * rmax;
+    for (int ky = -g->B; ky <= g->B; ky++) for (int kx = 0; kx <= g->B; kx++) {
+        cpx *o = &out[(size_t)(ky + g->B) * g->W + kx];
+        if ((double)kx * kx + (double)ky * ky >= r2) { o->re = o->im = 0; continue; }
+        double re, im;
+        sample_cube(r, m[0] * kx + m[1] * ky, m[2] * kx + m[3] * ky, m[4] * kx + m[5] * ky, &re, &im);
+        o->re = (float)re; o->im = (float)im;
+    }
+}
+
+/* ------------------------------------------------------------------ CTF */
+typedef struct { double lambda, cs, df1, df2, ast, extra, inv_na2; } ctf_t;
+
+static void ctf_init(ctf_t *c, const double *row, int N, double a) {
+    double v = row[PPM_VOLTAGE] * 1000.0;
+    c->lambda = 12.2639 / sqrt(v + 0.97845e-6 * v * v);
+    c->cs = row[PPM_CS] * 1e7;
+    c->df1 = row[PPM_DF1]; c->df2 = row[PPM_DF2];
+    c->ast = row[PPM_ANGAST] * ORC_PI / 180.0;
+    double w = row[PPM_AMP];
+    c->extra = row[PPM_PSHIFT] + atan(w / sqrt(1.0 - w * w));
+    c->inv_na2 = 1.0 / ((double)N * a * N * a);
+}
+
+static double ctf_eval(const ctf_t *c, int kx, int ky) {
+    double k2 = (double)kx * kx + (double)ky * ky;
+    if (k2 == 0) return -sin(c->extra);
+    double s2 = k2 * c->inv_na2;
+    double c2 = ((double)kx * kx - (double)ky * ky) / k2, s2a = 2.0 * kx * ky / k2;   /* cos 2phi, sin 2phi */
+    double df = 0.5 * (c->df1 + c->df2 + (c->df1 - c->df2) * (c2 * cos(2 * c->ast) + s2a * sin(2 * c->ast)));
+    double chi = ORC_PI * c->lambda * s2 * (df - 0.5 * c->cs * c->lambda * c->lambda * s2) + c->extra;
+    return -sin(chi);
+}
+
+/* ------------------------------------------------------------------ particle preprocessing */
+/* out: band layout [ky+B][kx] (zero outside k^2 < r_hi^2), whitened when `whiten`. */
+static void preprocess(const float *img, const geom_t *g, double mask_radius_A, double falloff_A,
+                       int normalize, int invert, int do_mask, int whiten, double rband, cpx *out,
+                       double *wring /* B+2 ring weights 1/sqrt(P_b), or NULL */) {
+    int N = g->N;
+    double Rm = mask_radius_A / g->a, w = falloff_A / g->a;
+    if (w < 1e-3) w = 1e-3;
+    double s1 = 0, s2 = 0; long cnt = 0;
+    for (int y = 0; y < N; y++) for (int x = 0; x < N; x++) {
+        double dx = x - N / 2, dy = y - N / 2;
+        if (dx * dx + dy * dy > Rm * Rm) { double v = img[y * N + x]; s1 += v; s2 += v * v; cnt++; }
+    }
+    if (cnt < 16) {
+        s1 = s2 = 0; cnt = (long)N * N;
+        for (int i = 0; i < N * N; i++) { s1 += img[i]; s2 += (double)img[i] * img[i]; }
+    }
+    double mu = s1 / cnt, var = s2 / cnt - mu * mu, sd = var > 0 ? sqrt(var) : 1.0;
+    double sgn = invert ? -1.0 : 1.0, sc = normalize ? 1.0 / sd : 1.0;
+    cpx *f = (cpx *)malloc((size_t)N * N * sizeof(cpx));
+    for (int y = 0; y < N; y++) for (int x = 0; x < N; x++) {
+        double dx = x - N / 2, dy = y - N / 2, rho = sqrt(dx * dx + dy * dy), m = 1.0;
+        if (do_mask) {
+            if (rho >= Rm + 0.5 * w) m = 0.0;
+            else if (rho > Rm - 0.5 * w) m = 0.5 * (1.0 + cos(ORC_PI * (rho - Rm + 0.5 * w) / w));
+        }
+        f[y * N + x].re = (float)((img[y * N + x] - mu) * sc * sgn * m);
+        f[y * N + x].im = 0;
+    }
+    for (int y = 0; y < N; y++) fft1d(f + (size_t)y * N, N, 1, 0);
+    for (int x = 0; x < N; x++) fft1d(f + x, N, N, 0);
+    double r2 = rband * rband, inv = 1.0 / N;
+    int nr = g->B + 2;
+    double *pw = (double *)calloc(nr, sizeof(double)), *pc = (double *)calloc(nr, sizeof(double));
+    for (int ky = -g->B; ky <= g->B; ky++) for (int kx = 0; kx <= g->B; kx++) {
+        cpx *o = &out[(size_t)(ky + g->B) * g->W + kx];
+        double k2 = (double)kx * kx + (double)ky * ky;
+        if (k2 >= r2 || k2 == 0) { o->re = o->im = 0; continue; }   /* DC dropped */
+        cpx v = f[(size_t)((ky + N) % N) * N + kx];
+        double sg = ((kx + ky) & 1) ? -inv : inv;
+        o->re = (float)(v.re * sg); o->im = (float)(v.im * sg);
+        int b = (int)floor(sqrt(k2));
+        double al = kx == 0 ? 1.0 : 2.0;
+        pw[b] += al * ((double)o->re * o->re + (double)o->im * o->im); pc[b] += al;
+    }
+    if (wring) for (int b = 0; b < nr; b++) {
+        double p = pc[b] > 0 ? pw[b] / pc[b] : 0;
+        wring[b] = (whiten && p > 0) ? 1.0 / sqrt(p) : (whiten ? 0.0 : 1.0);
+    }
+    if (whiten) {
+        for (int ky = -g->B; ky <= g->B; ky++) for (int kx = 0; kx <= g->B; kx++) {
+            cpx *o = &out[(size_t)(ky + g->B) * g->W + kx];
+            double k2 = (double)kx * kx + (double)ky * ky;
+            if (k2 >= r2 || k2 == 0) continue;
+            int b = (int)floor(sqrt(k2));
+            double p = pc[b] > 0 ? pw[b] / pc[b] : 0;
+            double s = p > 0 ? 1.0 / sqrt(p) : 0.0;
+            o->re = (float)(o->re * s); o->im = (float)(o->im * s);
+        }
+    }
+    free(pw); free(pc); free(f);
+}
+
+/* ------------------------------------------------------------------ local score */
+/* ring-wise weighted correlation of image I against CTF * slice * shift; signed below
+ * ring_signed, absolute above.  shifts in pixels. */
+static double score_local(const oref_t *r, const geom_t *g, const ctf_t *c, const cpx *I,
+                          const double *wr, double rmax, const double M[9], const double sh[2]) {
+    double m[6] = { M[0], M[1], M[3], M[4], M[6], M[7] };
+    int nr = g->B + 2;
+    double *A = (double *)calloc(nr, sizeof(double));
+    double sb = 0, sc = 0, rl2 = g->r_lo * g->r_lo, rh2 = rmax * rmax;
+    for (int ky = -g->B; ky <= g->B; ky++) for (int kx = 0; kx <= g->B; kx++) {
+        double k2 = (double)kx * kx + (double)ky * ky;
+        if (k2 >= rh2 || k2 < rl2 || k2 == 0) continue;
+        double pr, pi;
+        sample_cube(r, m[0] * kx + m[1] * ky, m[2] * kx + m[3] * ky, m[4] * kx + m[5] * ky, &pr, &pi);
+        int b = (int)floor(sqrt(k2));
+        double cv = ctf_eval(c, kx, ky) * wr[b];     /* the model gets the image's whitening filter too */
+        double ph = -2.0 * ORC_PI * (kx * sh[0] + ky * sh[1]) / g->N;
+        double cr = cos(ph), ci = sin(ph);
+        double mr = cv * (pr * cr - pi * ci), mi = cv * (pr * ci + pi * cr);
+        const cpx *iv = &I[(size_t)(ky + g->B) * g->W + kx];
+        double al = kx == 0 ? 1.0 : 2.0;
+        A[b] += al * (iv->re * mr + iv->im * mi);
+        sb += al * (mr * mr + mi * mi);
+        sc += al * ((double)iv->re * iv->re + (double)iv->im * iv->im);
+    }
+    double sa = 0;
+    for (int b = 0; b < nr; b++) sa += ((double)b <= g->ring_signed) ? A[b] : fabs(A[b]);
+    free(A);
+    return (sb > 0 && sc > 0) ? sa / sqrt(sb * sc) : 0.0;
+}
+
+/* ------------------------------------------------------------------ compass refinement */
+/* State: rotation matrix M = Rz(phi) Ry(theta) Rz(psi) (row-major 3x3), shifts in pixels, score f,
+ * current angular / shift steps.  The three rotational parameters are steps in the IMAGE frame
+ * (right-multiplication): 0 = in-plane (about image z; this IS psi), 1 / 2 = tilts about the image
+ * x / y axes.  They are decoupled at every theta, unlike (theta, phi).  When only one of theta / phi
+ * is free, that Euler angle itself is stepped (left-multiplication forms below). */
+typedef struct { double M[9], sh[2], f, ha, hs; } cstate_t;
+
+static void euler_full(double psi, double theta, double phi, double M[9]) {
+    double m[6]; euler_cols(psi, theta, phi, m);
+    double th = theta * ORC_PI / 180, ph = phi * ORC_PI / 180;
+    M[0] = m[0]; M[1] = m[1]; M[2] = cos(ph) * sin(th);
+    M[3] = m[2]; M[4] = m[3]; M[5] = sin(ph) * sin(th);
+    M[6] = m[4]; M[7] = m[5]; M[8] = cos(th);
+}
+
+static void angles_from_matrix(const double M[9], double *psi, double *theta, double *phi) {
+    double ct = M[8] > 1 ? 1 : (M[8] < -1 ? -1 : M[8]);
+    double st = sqrt(M[2] * M[2] + M[5] * M[5]);
+    if (st > 1e-7) {
+        *theta = atan2(st, ct) * 180 / ORC_PI;
+        *phi = atan2(M[5], M[2]) * 180 / ORC_PI;
+        *psi = atan2(M[7], -M[6]) * 180 / ORC_PI;
+    } else {               /* theta = 0 or 180: only psi +- phi is defined; put it all in psi */
+        *theta = ct > 0 ? 0.0 : 180.0; *phi = 0.0;
+        *psi = (ct > 0 ? atan2(M[3], M[0]) : atan2(-M[3], -M[0])) * 180 / ORC_PI;
+    }
+    if (*psi < 0) *psi += 360; if (*phi < 0) *phi += 360;
+}
+
+static void rot_step(const double M[9], int which, int tilt_frame, double hdeg, double out[9]) {
+    double h = hdeg * ORC_PI / 180, c = cos(h), s = sin(h), R[9], L[9], T[9];
+    if (which == 0) { double r[9] = { c, -s, 0, s, c, 0, 0, 0, 1 }; mat_mul3(M, r, out); return; }
+    if (tilt_frame) {
+        if (which == 1) { double r[9] = { 1, 0, 0, 0, c, -s, 0, s, c }; mat_mul3(M, r, out); }
+        else { double r[9] = { c, 0, s, 0, 1, 0, -s, 0, c }; mat_mul3(M, r, out); }
+        return;
+    }
+    if (which == 2) { double r[9] = { c, -s, 0, s, c, 0, 0, 0, 1 }; mat_mul3(r, M, out); return; }   /* phi += h */
+    /* theta += h: L = Rz(phi) Ry(h) Rz(-phi) */
+    double psi, th, ph; angles_from_matrix(M, &psi, &th, &ph);
+    double cp = cos(ph * ORC_PI / 180), sp = sin(ph * ORC_PI / 180);
+    double rz[9] = { cp, -sp, 0, sp, cp, 0, 0, 0, 1 }, rzt[9] = { cp, sp, 0, -sp, cp, 0, 0, 0, 1 }, ry[9] = { c, 0, s, 0, 1, 0, -s, 0, c };
+    mat_mul3(rz, ry, T); mat_mul3(T, rzt, L); mat_mul3(L, M, R); memcpy(out, R, sizeof(R));
+}
+
+static void compass_iter(const oref_t *r, const geom_t *g, const ctf_t *c, const cpx *I, const double *wr,
+                         double rmax, const int en[5], cstate_t *s, long *nevals) {
+    /* en[]: psi, theta, phi, x, y.  rotational slots: 0 <- psi; 1,2 <- tilts if both theta and phi are
+     * free, else slot 1 <- theta, slot 2 <- phi as Euler steps */
+    int tilt = en[1] && en[2];
+    int on[5] = { en[0], en[1], en[2], en[3], en[4] };
+    double fp[5], fm[5], d[5], Mq[9], shq[2];
+    int any = 0;
+    for (int i = 0; i < 5; i++) {
+        d[i] = 0; fp[i] = fm[i] = -1e300;
+        if (!on[i]) continue;
+        double h = i < 3 ? s->ha : s->hs;
+        for (int sg = 0; sg < 2; sg++) {
+            double hh = sg ? -h : h;
+            memcpy(Mq, s->M, sizeof(Mq)); shq[0] = s->sh[0]; shq[1] = s->sh[1];
+            if (i < 3) rot_step(s->M, i, tilt, hh, Mq); else shq[i - 3] += hh;
+            double v = score_local(r, g, c, I, wr, rmax, Mq, shq);
+            if (sg) fm[i] = v; else fp[i] = v;
+        }
+        *nevals += 2; any = 1;
+        double den = 2.0 * s->f - fp[i] - fm[i];
+        if (den > 1e-12) {
+            double t = 0.5 * h * (fp[i] - fm[i]) / den;
+            d[i] = t > h ? h : (t < -h ? -h : t);
+        } else {
+            double best = fp[i] > fm[i] ? fp[i] : fm[i];
+            d[i] = best > s->f ? (fp[i] > fm[i] ? h : -h) : 0.0;
+        }
+    }
+    if (any) {
+        double Mt[9], T[9];
+        memcpy(Mt, s->M, sizeof(Mt));
+        for (int i = 0; i < 3; i++) if (on[i] && d[i] != 0) { rot_step(Mt, i, tilt, d[i], T); memcpy(Mt, T, sizeof(T)); }
+        shq[0] = s->sh[0] + d[3]; shq[1] = s->sh[1] + d[4];
+        double ft = score_local(r, g, c, I, wr, rmax, Mt, shq); *nevals += 1;
+        int bi = -1, bs = 0; double fb = s->f;
+        for (int i = 0; i < 5; i++) {
+            if (!on[i]) continue;
+            if (fp[i] > fb) { fb = fp[i]; bi = i; bs = 1; }
+            if (fm[i] > fb) { fb = fm[i]; bi = i; bs = -1; }
+        }
+        if (ft > s->f && ft >= fb) { memcpy(s->M, Mt, sizeof(Mt)); s->sh[0] = shq[0]; s->sh[1] = shq[1]; s->f = ft; }
+        else if (bi >= 0) {
+            if (bi < 3) { rot_step(s->M, bi, tilt, bs * s->ha, T); memcpy(s->M, T, sizeof(T)); }
+            else s->sh[bi - 3] += bs * s->hs;
+            s->f = fb;
+        }
+    }
+    s->ha *= 0.5; s->hs *= 0.5;
+}
+
+/* ------------------------------------------------------------------ global search */
+typedef struct { double cc; int orient, sx, sy; } hit_t;
+
+/* correlation window of one orientation.  W = alpha * ctf * I (band r_lo..r_s), C2 = alpha * ctf^2,
+ * P = slice.  Returns max over the shift window of c(s)/sqrt(nP*nI).  mode 0: zero-filled Ns x Ns
+ * inverse FFT; mode 1: pruned direct transform. `conjP`: use conj(P) (orientation psi+180). */
+static double ccf_peak(const geom_t *g, const cpx *Wp, const float *C2, const cpx *P, int conjP,
+                       double nI, int mode, cpx *work, int *bsx, int *bsy) {
+    int B = g->B, Wd = g->W, Ns = g->Ns;
+    double nP = 0;
+    for (int i = 0; i < g->H * Wd; i++) nP += C2[i] * ((double)P[i].re * P[i].re + (double)P[i].im * P[i].im);
+    double best = -1e300; *bsx = *bsy = 0;
+    if (!(nP > 0 && nI > 0)) return 0.0;
+    if (mode == 0) {
+        memset(work, 0, (size_t)Ns * Ns * sizeof(cpx));
+        for (int ky = -B; ky <= B; ky++) for (int kx = 0; kx <= B; kx++) {
+            if (kx >= Ns / 2 || ky >= Ns / 2 || ky < -Ns / 2) continue;
+            size_t i = (size_t)(ky + B) * Wd + kx;
+            double pr = P[i].re, pi = conjP ? -P[i].im : P[i].im;
+            /* Q = W conj(P); W carries alpha (1 on kx = 0, 2 elsewhere): full plane = Q/alpha at k and conj at -k */
+            double qr = Wp[i].re * pr + Wp[i].im * pi, qi = Wp[i].im * pr - Wp[i].re * pi;
+            double al = kx == 0 ? 1.0 : 2.0;
+            qr /= al; qi /= al;
+            cpx *a = &work[(size_t)((ky + Ns) % Ns) * Ns + kx];
+            a->re += (float)qr; a->im += (float)qi;
+            if (kx > 0) { cpx *b = &work[(size_t)((-ky + Ns) % Ns) * Ns + (Ns - kx)]; b->re += (float)qr; b->im -= (float)qi; }
+        }
+        for (int y = 0; y < Ns; y++) fft1d(work + (size_t)y * Ns, Ns, 1, 1);
+        for (int x = 0; x < Ns; x++) fft1d(work + x, Ns, Ns, 1);
+        for (int sy = -g->RSy; sy <= g->RSy; sy++) for (int sx = -g->RSx; sx <= g->RSx; sx++) {
+            double v = work[(size_t)((sy + Ns) % Ns) * Ns + ((sx + Ns) % Ns)].re;
+            if (v > best) { best = v; *bsx = sx; *bsy = sy; }
+        }
+    } else {
+        /* separable pruned transform: G[kx][sy] = sum_ky Q e^{+i 2pi ky sy/Ns}, then the sum over kx */
+        int lg = 0; while ((1 << lg) < Ns) lg++;
+        const double *tc = TWC[lg], *ts = TWS[lg];
+        int nsy = 2 * g->RSy + 1;
+        double *G = (double *)calloc((size_t)2 * Wd * nsy, sizeof(double));
+        for (int ky = -B; ky <= B; ky++) for (int kx = 0; kx <= B; kx++) {
+            size_t i = (size_t)(ky + B) * Wd + kx;
+            if (C2[i] == 0) continue;
+            double pr = P[i].re, pi = conjP ? -P[i].im : P[i].im;
+            double qr = Wp[i].re * pr + Wp[i].im * pi, qi = Wp[i].im * pr - Wp[i].re * pi;
+            for (int sy = -g->RSy; sy <= g->RSy; sy++) {
+                int t = (((ky * sy) % Ns) + Ns) % Ns;
+                double c = t < Ns / 2 ? tc[t] : -tc[t - Ns / 2], s2 = t < Ns / 2 ? ts[t] : -ts[t - Ns / 2];
+                double *o = &G[((size_t)kx * nsy + (sy + g->RSy)) * 2];
+                o[0] += qr * c - qi * s2; o[1] += qr * s2 + qi * c;
+            }
+        }
+        for (int sy = -g->RSy; sy <= g->RSy; sy++) for (int sx = -g->RSx; sx <= g->RSx; sx++) {
+            double acc = 0;
+            for (int kx = 0; kx <= B; kx++) {
+                int t = (((kx * sx) % Ns) + Ns) % Ns;
+                double c = t < Ns / 2 ? tc[t] : -tc[t - Ns / 2], s2 = t < Ns / 2 ? ts[t] : -ts[t - Ns / 2];
+                const double *o = &G[((size_t)kx * nsy + (sy + g->RSy)) * 2];
+                acc += o[0] * c - o[1] * s2;
+            }
+            if (acc > best) { best = acc; *bsx = sx; *bsy = sy; }
+        }
+        free(G);
+    }
+    return best / sqrt(nP * nI);
+}
+
+/* ------------------------------------------------------------------ refine_batch */
+/* bank: optional caller-supplied slice bank (n_dir * n_psi/2 (or n_psi) slices at band r_s); built if NULL */
+int orc_refine_batch(void *refp, const ppm_refine_cfg *cfg, const float *images, int n_img,
+                     const double *rows_in, double *rows_out, int ccf_mode, long *eval_counts) {
+    fft_tables();
+    oref_t *r = (oref_t *)refp;
+    geom_t g;
+    if (!r || geom_init(&g, cfg)) return -22;
+    if (g.B > r->B || r->N != g.N) return -22;
+    int K = cfg->top_hits > 0 ? cfg->top_hits : 20; if (K > PPM_MAX_TOP_HITS) K = PPM_MAX_TOP_HITS;
+    int Tb = cfg->iters_hit > 0 ? cfg->iters_hit : 3, Tc = cfg->iters_final > 0 ? cfg->iters_final : 6;
+    double fall = cfg->mask_falloff > 0 ? cfg->mask_falloff : 20.0;
+    double dstep = cfg->angular_step > 0 ? cfg->angular_step : 15.0;
+    int en[5] = { cfg->refine_psi, cfg->refine_theta, cfg->refine_phi, cfg->refine_x, cfg->refine_y };
+    size_t nb = (size_t)g.H * g.W;
+    int half = (g.n_psi % 2 == 0);                 /* psi and psi+180 share a slice (conjugate) */
+    int npsi_store = half ? g.n_psi / 2 : g.n_psi;
+    cpx *bank = NULL;
+    if (cfg->global_search) {
+        bank = (cpx *)malloc((size_t)g.n_dir * npsi_store * nb * sizeof(cpx));
+        if (!bank) return -12;
+        for (int d = 0; d < g.n_dir; d++) {
+            double th, ph; grid_direction(&g, dstep, d, &th, &ph);
+            for (int k = 0; k < npsi_store; k++) {
+                double m[6]; euler_cols(k * g.dpsi, th, ph, m);
+                extract_slice(r, &g, m, g.r_s, bank + ((size_t)d * npsi_store + k) * nb);
+            }
+        }
+    }
+    long tot_g = 0, tot_l = 0;
+    int err = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : tot_g, tot_l)
+    for (int ip = 0; ip < n_img; ip++) {
+        const double *row = rows_in + (size_t)ip * PPM_NCOL;
+        double *out = rows_out + (size_t)ip * PPM_NCOL;
+        memcpy(out, row, PPM_NCOL * sizeof(double));
+        const float *img = images + (size_t)ip * g.N * g.N;
+        ctf_t c; ctf_init(&c, row, g.N, g.a);
+        cpx *I = (cpx *)malloc(nb * sizeof(cpx));
+        double *wr = (double *)malloc((g.B + 2) * sizeof(double)), *wrs = wr, *wrsown = NULL;
+        preprocess(img, &g, cfg->mask_radius, fall, cfg->normalize, cfg->invert, 1, 1, g.r_hi, I, wr);
+        long nev = 0;
+        cstate_t best; memset(&best, 0, sizeof(best));
+        if (cfg->global_search) {
+            cpx *Is = I, *Isown = NULL;
+            if (cfg->search_mask_radius > 0 && cfg->search_mask_radius != cfg->mask_radius) {
+                Isown = (cpx *)malloc(nb * sizeof(cpx)); wrsown = (double *)malloc((g.B + 2) * sizeof(double));
+                preprocess(img, &g, cfg->search_mask_radius, fall, cfg->normalize, cfg->invert, 1, 1, g.r_hi, Isown, wrsown);
+                Is = Isown; wrs = wrsown;
+            }
+            cpx *Wp = (cpx *)malloc(nb * sizeof(cpx)); float *C2 = (float *)malloc(nb * sizeof(float));
+            cpx *work = (cpx *)malloc((size_t)g.Ns * g.Ns * sizeof(cpx));
+            double nI = 0, rl2 = g.r_lo * g.r_lo, rs2 = g.r_s * g.r_s;
+            for (int ky = -g.B; ky <= g.B; ky++) for (int kx = 0; kx <= g.B; kx++) {
+                size_t i = (size_t)(ky + g.B) * g.W + kx;
+                double k2 = (double)kx * kx + (double)ky * ky;
+                if (k2 >= rs2 || k2 < rl2 || k2 == 0) { Wp[i].re = Wp[i].im = 0; C2[i] = 0; continue; }
+                double cv = ctf_eval(&c, kx, ky) * wrs[(int)floor(sqrt(k2))], al = kx == 0 ? 1.0 : 2.0;
+                Wp[i].re = (float)(al * cv * Is[i].re); Wp[i].im = (float)(al * cv * Is[i].im);
+                C2[i] = (float)(al * cv * cv);
+                nI += al * ((double)Is[i].re * Is[i].re + (double)Is[i].im * Is[i].im);
+            }
+            hit_t *hits = (hit_t *)malloc((size_t)g.n_orient * sizeof(hit_t));
+            for (int d = 0; d < g.n_dir; d++) for (int k = 0; k < g.n_psi; k++) {
+                int ks = half ? k % npsi_store : k, cj = half ? (k >= npsi_store) : 0;
+                hit_t *h = &hits[d * g.n_psi + k];
+                h->orient = d * g.n_psi + k;
+                h->cc = ccf_peak(&g, Wp, C2, bank + ((size_t)d * npsi_store + ks) * nb, cj, nI, ccf_mode, work, &h->sx, &h->sy);
+            }
+            tot_g += g.n_orient;
+            /* top-K by cc, ties -> lower orientation index */
+            int Kk = K < g.n_orient ? K : g.n_orient;
+            for (int a = 0; a < Kk; a++) {
+                int bi = a;
+                for (int b2 = a + 1; b2 < g.n_orient; b2++)
+                    if (hits[b2].cc > hits[bi].cc || (hits[b2].cc == hits[bi].cc && hits[b2].orient < hits[bi].orient)) bi = b2;
+                hit_t t = hits[a]; hits[a] = hits[bi]; hits[bi] = t;
+            }
+            int have = 0;
+            for (int a = 0; a < Kk; a++) {
+                cstate_t s;
+                double th, ph; grid_direction(&g, dstep, hits[a].orient / g.n_psi, &th, &ph);
+                euler_full((hits[a].orient % g.n_psi) * g.dpsi, th, ph, s.M);
+                s.sh[0] = hits[a].sx * g.step; s.sh[1] = hits[a].sy * g.step;
+                s.ha = 0.5 * dstep; s.hs = g.step;
+                if (cfg->local_refine) {
+                    s.f = score_local(r, &g, &c, I, wr, g.r_s, s.M, s.sh); nev++;
+                    for (int t = 0; t < Tb; t++) compass_iter(r, &g, &c, I, wr, g.r_s, en, &s, &nev);
+                } else s.f = hits[a].cc;
+                if (!have || s.f > best.f) { best = s; have = 1; }
+            }
+            if (cfg->local_refine) {       /* the best hit continues at the full band */
+                best.f = score_local(r, &g, &c, I, wr, g.r_hi, best.M, best.sh); nev++;
+                for (int t = 0; t < Tc; t++) compass_iter(r, &g, &c, I, wr, g.r_hi, en, &best, &nev);
+            }
+            free(hits); free(work); free(Wp); free(C2); free(Isown); free(wrsown);
+        } else {
+            euler_full(row[PPM_PSI], row[PPM_THETA], row[PPM_PHI], best.M);
+            best.sh[0] = row[PPM_XSHIFT] / g.a; best.sh[1] = row[PPM_YSHIFT] / g.a;
+            best.ha = cfg->local_angle_step > 0 ? cfg->local_angle_step : 2.5;
+            best.hs = cfg->local_shift_step > 0 ? cfg->local_shift_step : 2.0;
+            best.f = score_local(r, &g, &c, I, wr, g.r_hi, best.M, best.sh); nev++;
+            if (cfg->local_refine) for (int t = 0; t < Tb + Tc; t++) compass_iter(r, &g, &c, I, wr, g.r_hi, en, &best, &nev);
+        }
+        tot_l += nev;
+        angles_from_matrix(best.M, &out[PPM_PSI], &out[PPM_THETA], &out[PPM_PHI]);
+        out[PPM_XSHIFT] = best.sh[0] * g.a; out[PPM_YSHIFT] = best.sh[1] * g.a;
+        double cc = best.f, res = 1.0 - cc * cc; if (res < 1e-6) res = 1e-6;
+        out[PPM_SCORE] = 100.0 * cc;
+        out[PPM_SIGMA] = sqrt(res);
+        out[PPM_LOGP] = -0.5 * (ORC_PI * 0.5 * (g.r_hi * g.r_hi - g.r_lo * g.r_lo)) * log(res);
+        free(I); free(wr);
+    }
+    free(bank);
+    if (eval_counts) { eval_counts[0] = n_img ? tot_g / n_img : 0; eval_counts[1] = n_img ? tot_l / n_img : 0; }
+    return err;
+}
+
+/* score of given poses (no search): used by parity tests of the local-score kernel */
+int orc_score_batch(void *refp, const ppm_refine_cfg *cfg, const float *images, int n_img,
+                    const double *rows, double *scores) {
+    fft_tables();
+    oref_t *r = (oref_t *)refp; geom_t g;
+    if (!r || geom_init(&g, cfg) || g.B > r->B) return -22;
+    double fall = cfg->mask_falloff > 0 ? cfg->mask_falloff : 20.0;
+    size_t nb = (size_t)g.H * g.W;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int ip = 0; ip < n_img; ip++) {
+        const double *row = rows + (size_t)ip * PPM_NCOL;
+        ctf_t c; ctf_init(&c, row, g.N, g.a);
+        cpx *I = (cpx *)malloc(nb * sizeof(cpx));
+        double *wr = (double *)malloc((g.B + 2) * sizeof(double));
+        preprocess(images + (size_t)ip * g.N * g.N, &g, cfg->mask_radius, fall, cfg->normalize, cfg->invert, 1, 1, g.r_hi, I, wr);
+        double M[9], sh[2] = { row[PPM_XSHIFT] / g.a, row[PPM_YSHIFT] / g.a };
+        euler_full(row[PPM_PSI], row[PPM_THETA], row[PPM_PHI], M);
+        scores[ip] = score_local(r, &g, &c, I, wr, g.r_hi, M, sh);
+        free(I); free(wr);
+    }
+    return 0;
+}
+
+/* preprocessed (whitened, masked) band spectrum of one image: [2B+1][B+1] complex, for kernel tests */
+int orc_preprocess(const ppm_refine_cfg *cfg, const float *img, float mask_radius, float *out_band, double *out_wring) {
+    fft_tables();
+    geom_t g; if (geom_init(&g, cfg)) return -22;
+    double fall = cfg->mask_falloff > 0 ? cfg->mask_falloff : 20.0;
+    preprocess(img, &g, mask_radius, fall, cfg->normalize, cfg->invert, 1, 1, g.r_hi, (cpx *)out_band, out_wring);
+    return 0;
+}
+
+int orc_band_dims(const ppm_refine_cfg *cfg, int *B, int *n_orient, int *Ns, int *step, int *RSx, int *RSy) {
+    geom_t g; if (geom_init(&g, cfg)) return -22;
+    *B = g.B; *n_orient = g.n_orient; *Ns = g.Ns; *step = g.step; *RSx = g.RSx; *RSy = g.RSy;
+    return 0;
+}
+
+/* one reference slice at (psi,theta,phi), band layout, for kernel tests */
+int orc_extract_slice(void *refp, const ppm_refine_cfg *cfg, double psi, double theta, double phi, float *out_band) {
+    oref_t *r = (oref_t *)refp; geom_t g;
+    if (!r || geom_init(&g, cfg) || g.B > r->B) return -22;
+    double m[6]; euler_cols(psi, theta, phi, m);
+    extract_slice(r, &g, m, g.r_hi, (cpx *)out_band);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ symmetry operators */
+static void mat_mul(const double *a, const double *b, double *c) {
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+        double s = 0; for (int k = 0; k < 3; k++) s += a[i * 3 + k] * b[k * 3 + j];
+        c[i * 3 + j] = s;
+    }
+}
+static void rot_axis(const double ax[3], double deg, double *m) {
+    double n = sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+    double x = ax[0] / n, y = ax[1] / n, z = ax[2] / n, t = deg * ORC_PI / 180, c = cos(t), s = sin(t), C = 1 - c;
+    double r[9] = { c + x * x * C, x * y * C - z * s, x * z * C + y * s, y * x * C + z * s, c + y * y * C, y * z * C - x * s,
+                    z * x * C - y * s, z * y * C + x * s, c + z * z * C };
+    memcpy(m, r, sizeof(r));
+}
+/* closure of a generator set; returns count (<= 60) */
+static int sym_group(const double *gens, int ngen, double *ops) {
+    int n = 1; double I3[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 }; memcpy(ops, I3, sizeof(I3));
+    for (int grew = 1; grew;) {
+        grew = 0;
+        for (int i = 0; i < n && n < 60; i++) for (int j = 0; j < ngen && n < 60; j++) {
+            double c[9]; mat_mul(ops + i * 9, gens + j * 9, c);
+            int found = 0;
+            for (int k = 0; k < n && !found; k++) {
+                double d = 0; for (int q = 0; q < 9; q++) d += fabs(ops[k * 9 + q] - c[q]);
+                if (d < 1e-6) found = 1;
+            }
+            if (!found) { memcpy(ops + n * 9, c, sizeof(c)); n++; grew = 1; }
+        }
+    }
+    return n;
+}
+int orc_symmetry_ops(const char *sym, double *ops /* 60*9 */) {
+    double gens[3 * 9]; int ng = 0;
+    double z[3] = { 0, 0, 1 }, x[3] = { 1, 0, 0 }, d111[3] = { 1, 1, 1 };
+    char t = sym[0] >= 'a' ? sym[0] - 32 : sym[0];
+    int n = atoi(sym + 1);
+    if (t == 'C' && n >= 1) { rot_axis(z, 360.0 / n, gens); ng = 1; }
+    else if (t == 'D' && n >= 1) { rot_axis(z, 360.0 / n, gens); rot_axis(x, 180, gens + 9); ng = 2; }
+    else if (t == 'T') { rot_axis(z, 180, gens); rot_axis(d111, 120, gens + 9); ng = 2; }
+    else if (t == 'O') { rot_axis(z, 90, gens); rot_axis(d111, 120, gens + 9); ng = 2; }
+    else if (t == 'I') {
+        double phi = (1 + sqrt(5.0)) / 2, a5[3] = { 0, 1, phi };   /* 2-fold axes on x,y,z; 5-fold on (0,1,phi) */
+        rot_axis(z, 180, gens); rot_axis(d111, 120, gens + 9); rot_axis(a5, 72, gens + 18); ng = 3;
+    } else return -22;
+    return sym_group(gens, ng, ops);
+}
+
+/* ------------------------------------------------------------------ Fourier insertion */
+/* acc: [2][N][N][N/2+1][3] floats {re, im, weight}; kz,ky stored at index k + N/2 */
+int orc_insert_batch(float *acc, long *counts, const ppm_recon_cfg *cfg, const char *symmetry,
+                     const float *images, int n_img, const double *rows) {
+    fft_tables();
+    int N = cfg->box; double a = cfg->pixel_size;
+    if (!is_pow2(N) || a <= 0) return -22;
+    double ops[60 * 9]; int nsym = orc_symmetry_ops(symmetry && symmetry[0] ? symmetry : "C1", ops);
+    if (nsym < 1) return -22;
+    ppm_refine_cfg rc; memset(&rc, 0, sizeof(rc));
+    rc.box = N; rc.pixel_size = (float)a; rc.res_high = cfg->res_limit > 0 ? cfg->res_limit : (float)(2 * a);
+    rc.angular_step = 15;
+    geom_t g; if (geom_init(&g, &rc)) return -22;
+    size_t nb = (size_t)g.H * g.W, NX = N / 2 + 1, half_sz = (size_t)N * N * NX * 3;
+    cpx *I = (cpx *)malloc(nb * sizeof(cpx));
+    for (int ip = 0; ip < n_img; ip++) {
+        const double *row = rows + (size_t)ip * PPM_NCOL;
+        if (!(row[PPM_OCC] > 0) || row[PPM_SCORE] < cfg->score_threshold) continue;
+        long key = cfg->split_by_pind ? (long)row[PPM_PIND] : (long)row[PPM_POS];
+        int h = (int)(((key % 2) + 2) % 2);   /* odd keys -> half index 1, even -> 0 */
+        float *A = acc + (size_t)h * half_sz;
+        counts[h]++;
+        preprocess(images + (size_t)ip * N * N, &g, cfg->mask_radius, 20.0, cfg->normalize, cfg->invert, 0, 0, g.r_hi, I, NULL);
+        ctf_t c; ctf_init(&c, row, N, a);
+        double m[6]; euler_cols(row[PPM_PSI], row[PPM_THETA], row[PPM_PHI], m);
+        double sx = row[PPM_XSHIFT] / a, sy = row[PPM_YSHIFT] / a, na2 = (double)N * a * N * a;
+        for (int ky = -g.B; ky <= g.B; ky++) for (int kx = 0; kx <= g.B; kx++) {
+            double k2 = (double)kx * kx + (double)ky * ky;
+            if (k2 >= g.r_hi * g.r_hi || k2 == 0) continue;
+            double cv = ctf_eval(&c, kx, ky);
+            double w = row[PPM_OCC] / 100.0;
+            if (cfg->score_weight_bfactor != 0)
+                w *= exp(-0.25 * cfg->score_weight_bfactor * (cfg->score_average - row[PPM_SCORE]) * k2 / na2);
+            double ph = 2.0 * ORC_PI * (kx * sx + ky * sy) / N, cr = cos(ph), ci = sin(ph);
+            const cpx *iv = &I[(size_t)(ky + g.B) * g.W + kx];
+            double vr = w * cv * (iv->re * cr - iv->im * ci), vi = w * cv * (iv->re * ci + iv->im * cr), vw = w * cv * cv;
+            double X0 = m[0] * kx + m[1] * ky, Y0 = m[2] * kx + m[3] * ky, Z0 = m[4] * kx + m[5] * ky;
+            for (int s = 0; s < nsym; s++) {
+                const double *S = ops + s * 9;
+                double X = S[0] * X0 + S[1] * Y0 + S[2] * Z0, Y = S[3] * X0 + S[4] * Y0 + S[5] * Z0, Z = S[6] * X0 + S[7] * Y0 + S[8] * Z0;
+                double ur = vr, ui = vi;
+                if (X < 0) { X = -X; Y = -Y; Z = -Z; ui = -ui; }
+                int x0 = (int)floor(X), y0 = (int)floor(Y), z0 = (int)floor(Z);
+                double fx = X - x0, fy = Y - y0, fz = Z - z0;
+                for (int dz = 0; dz < 2; dz++) for (int dy = 0; dy < 2; dy++) for (int dx = 0; dx < 2; dx++) {
+                    int xi = x0 + dx, yi = y0 + dy + N / 2, zi = z0 + dz + N / 2;
+                    if (xi > N / 2 || yi < 0 || yi >= N || zi < 0 || zi >= N) continue;
+                    double wt = (dx ? fx : 1 - fx) * (dy ? fy : 1 - fy) * (dz ? fz : 1 - fz);
+                    float *v = A + (((size_t)zi * N + yi) * NX + xi) * 3;
+                    v[0] += (float)(wt * ur); v[1] += (float)(wt * ui); v[2] += (float)(wt * vw);
+                }
+            }
+        }
+    }
+    free(I);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ merge + finalise */
+static void ifft3_centered_real(cpx *f, int N, float *out) {
+    /* f: full N^3 complex spectrum in FFT order (already carrying the centre phase); out = Re(IFFT)/N^2 */
+    for (int z = 0; z < N; z++) for (int y = 0; y < N; y++) fft1d(f + ((size_t)z * N + y) * N, N, 1, 1);
+    for (int z = 0; z < N; z++) for (int x = 0; x < N; x++) fft1d(f + (size_t)z * N * N + x, N, N, 1);
+    for (int y = 0; y < N; y++) for (int x = 0; x < N; x++) fft1d(f + (size_t)y * N + x, N, N * N, 1);
+    double sc = 1.0 / ((double)N * N);
+    for (size_t i = 0; i < (size_t)N * N * N; i++) out[i] = (float)(f[i].re * sc);
+}
+
+int orc_finalize(const float *acc_in, int N, double a, const ppm_final_cfg *cfg,
+                 float *half1, float *half2, float *filt, double *stats) {
+    fft_tables();
+    if (!is_pow2(N)) return -22;
+    size_t NX = N / 2 + 1, half_sz = (size_t)N * N * NX * 3, n3 = (size_t)N * N * N;
+    float *acc = (float *)malloc(2 * half_sz * sizeof(float));
+    memcpy(acc, acc_in, 2 * half_sz * sizeof(float));
+    /* kx = 0 plane holds both Friedel mates: fold them together */
+    for (int h = 0; h < 2; h++) {
+        float *A = acc + h * half_sz; const float *S = acc_in + h * half_sz;
+        for (int z = -N / 2 + 1; z < N / 2; z++) for (int y = -N / 2 + 1; y < N / 2; y++) {
+            float *v = A + (((size_t)(z + N / 2) * N + (y + N / 2)) * NX) * 3;
+            const float *m = S + (((size_t)(-z + N / 2) * N + (-y + N / 2)) * NX) * 3;
+            v[0] += m[0]; v[1] -= m[1]; v[2] += m[2];
+        }
+    }
+    int ns = N / 2;
+    double *sden = (double *)calloc(2 * ns + 2, sizeof(double)), *scnt = (double *)calloc(ns + 1, sizeof(double));
+    double *sdt = (double *)calloc(ns + 1, sizeof(double));
+    for (int z = -N / 2; z < N / 2; z++) for (int y = -N / 2; y < N / 2; y++) for (int x = 0; x <= N / 2; x++) {
+        int b = (int)floor(sqrt((double)x * x + y * y + z * z) + 0.5);
+        if (b >= ns) continue;
+        size_t i = (((size_t)(z + N / 2) * N + (y + N / 2)) * NX + x) * 3;
+        double al = x == 0 ? 1.0 : 2.0;
+        sden[b] += al * acc[i + 2]; sden[ns + 1 + b] += al * acc[half_sz + i + 2]; scnt[b] += al;
+        sdt[b] += al * (acc[i + 2] + acc[half_sz + i + 2]);
+    }
+    double *c12 = (double *)calloc(ns + 1, sizeof(double)), *c11 = (double *)calloc(ns + 1, sizeof(double)), *c22 = (double *)calloc(ns + 1, sizeof(double));
+    for (int z = -N / 2; z < N / 2; z++) for (int y = -N / 2; y < N / 2; y++) for (int x = 0; x <= N / 2; x++) {
+        int b = (int)floor(sqrt((double)x * x + y * y + z * z) + 0.5);
+        if (b >= ns) continue;
+        size_t i = (((size_t)(z + N / 2) * N + (y + N / 2)) * NX + x) * 3;
+        double e1 = 1e-3 * sden[b] / scnt[b] + 1e-20, e2 = 1e-3 * sden[ns + 1 + b] / scnt[b] + 1e-20;
+        double d1 = acc[i + 2] + e1, d2 = acc[half_sz + i + 2] + e2;
+        double ar = acc[i] / d1, ai = acc[i + 1] / d1, br = acc[half_sz + i] / d2, bi = acc[half_sz + i + 1] / d2;
+        double al = x == 0 ? 1.0 : 2.0;
+        c12[b] += al * (ar * br + ai * bi); c11[b] += al * (ar * ar + ai * ai); c22[b] += al * (br * br + bi * bi);
+    }
+    double vfrac = cfg->molecular_mass_kda > 0 ? (cfg->molecular_mass_kda * 1000.0 / 0.81) / pow(N * a, 3.0) : 1.0;
+    if (vfrac > 1) vfrac = 1; if (vfrac < 1e-6) vfrac = 1e-6;
+    double *kap = (double *)calloc(ns + 1, sizeof(double));
+    for (int b = 0; b < ns; b++) {
+        double fsc = (c11[b] > 0 && c22[b] > 0) ? c12[b] / sqrt(c11[b] * c22[b]) : 0.0;
+        double fc = fsc < 0 ? 0 : (fsc > 0.999 ? 0.999 : fsc);
+        double rec = 2.0 * fc / (1.0 - fc), md = scnt[b] > 0 ? sdt[b] / scnt[b] : 0;
+        kap[b] = b == 0 ? 1e-20 : md / (rec > 1e-6 ? rec : 1e-6);
+        if (b >= 1 && stats) {
+            double *s = stats + (size_t)(b - 1) * PPM_STATS_COLS;
+            s[0] = b; s[1] = N * a / b; s[2] = b / (N * a); s[3] = fsc;
+            s[4] = fc / (fc + vfrac * (1 - fc)); s[5] = md > 0 ? rec / md / vfrac : 0; s[6] = rec;
+        }
+    }
+    cpx *f = (cpx *)malloc(n3 * sizeof(cpx));
+    float *outs[3] = { half1, half2, filt };
+    double rout = cfg->outer_radius / a, rin = cfg->inner_radius / a, fo = (cfg->mask_falloff > 0 ? cfg->mask_falloff : 10.0) / a;
+    for (int which = 0; which < 3; which++) {
+        if (!outs[which]) continue;
+        memset(f, 0, n3 * sizeof(cpx));
+        for (int z = -N / 2; z < N / 2; z++) for (int y = -N / 2; y < N / 2; y++) for (int x = 0; x <= N / 2; x++) {
+            int b = (int)floor(sqrt((double)x * x + y * y + z * z) + 0.5);
+            if (b >= ns) continue;
+            size_t i = (((size_t)(z + N / 2) * N + (y + N / 2)) * NX + x) * 3;
+            double nr, ni, dn;
+            if (which < 2) { nr = acc[which * half_sz + i]; ni = acc[which * half_sz + i + 1]; dn = acc[which * half_sz + i + 2]; }
+            else { nr = acc[i] + acc[half_sz + i]; ni = acc[i + 1] + acc[half_sz + i + 1]; dn = acc[i + 2] + acc[half_sz + i + 2]; }
+            double d = dn + kap[b], sg = ((x + y + z) & 1) ? -1.0 : 1.0;
+            double vr = sg * nr / d, vi = sg * ni / d;
+            int ix = x % N, iy = (y + N) % N, iz = (z + N) % N;
+            cpx *o = &f[((size_t)iz * N + iy) * N + ix]; o->re = (float)vr; o->im = (float)vi;
+            if (x > 0 && x < N / 2) {
+                cpx *q = &f[((size_t)((N - iz) % N) * N + ((N - iy) % N)) * N + (N - ix)];
+                q->re = (float)vr; q->im = (float)-vi;
+            }
+        }
+        ifft3_centered_real(f, N, outs[which]);
+        for (int z = 0; z < N; z++) for (int y = 0; y < N; y++) for (int x = 0; x < N; x++) {
+            double dx = x - N / 2, dy = y - N / 2, dz = z - N / 2, g3 = 1.0;
+            double t[3] = { dx / N, dy / N, dz / N };
+            for (int q = 0; q < 3; q++) { double u = ORC_PI * t[q], sv = fabs(u) < 1e-9 ? 1.0 : sin(u) / u; g3 *= sv * sv; }
+            double rho = sqrt(dx * dx + dy * dy + dz * dz), m = 1.0;
+            if (rout > 0) {
+                if (rho >= rout + 0.5 * fo) m = 0; else if (rho > rout - 0.5 * fo) m = 0.5 * (1 + cos(ORC_PI * (rho - rout + 0.5 * fo) / fo));
+            }
+            if (rin > 0 && rho < rin) m = 0;
+            size_t i = ((size_t)z * N + y) * N + x;
+            outs[which][i] = (float)(outs[which][i] / g3 * m);
+        }
+    }
+    free(f); free(kap); free(c12); free(c11); free(c22); free(sden); free(scnt); free(sdt); free(acc);
+    return 0;
+}

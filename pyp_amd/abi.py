@@ -1,0 +1,47 @@
+"""ctypes mirror of the structs in include/ppm.h (field order and types must match exactly)."""
+import ctypes as C
+
+NCOL = 32
+STATS_COLS = 7
+K_NAMES = ("prep", "bank", "global", "topk", "local", "insert", "final")
+
+
+class RefineCfg(C.Structure):
+    _fields_ = [
+        ("box", C.c_int), ("pixel_size", C.c_float), ("molecular_mass_kda", C.c_float),
+        ("mask_radius", C.c_float), ("res_low", C.c_float), ("res_high", C.c_float),
+        ("res_signed_cc", C.c_float), ("search_mask_radius", C.c_float), ("res_search", C.c_float),
+        ("angular_step", C.c_float), ("top_hits", C.c_int), ("search_range_x", C.c_float),
+        ("search_range_y", C.c_float), ("global_search", C.c_int), ("local_refine", C.c_int),
+        ("refine_psi", C.c_int), ("refine_theta", C.c_int), ("refine_phi", C.c_int),
+        ("refine_x", C.c_int), ("refine_y", C.c_int), ("normalize", C.c_int), ("invert", C.c_int),
+        ("mask_falloff", C.c_float), ("iters_hit", C.c_int), ("iters_final", C.c_int),
+        ("local_angle_step", C.c_float), ("local_shift_step", C.c_float),
+    ]
+
+    @classmethod
+    def make(cls, **kw):
+        d = dict(molecular_mass_kda=0.0, res_low=0.0, res_signed_cc=0.0, search_mask_radius=0.0, res_search=0.0,
+                 angular_step=15.0, top_hits=20, search_range_x=0.0, search_range_y=0.0, global_search=1,
+                 local_refine=1, refine_psi=1, refine_theta=1, refine_phi=1, refine_x=1, refine_y=1, normalize=1,
+                 invert=0, mask_falloff=0.0, iters_hit=0, iters_final=0, local_angle_step=0.0, local_shift_step=0.0)
+        d.update(kw)
+        for req in ("box", "pixel_size", "mask_radius", "res_high"):
+            if req not in d:
+                raise ValueError(f"ERROR: RefineCfg needs {req}")
+        if not d["res_search"]:
+            d["res_search"] = d["res_high"]
+        return cls(**d)
+
+
+class ReconCfg(C.Structure):
+    _fields_ = [
+        ("box", C.c_int), ("pixel_size", C.c_float), ("res_limit", C.c_float),
+        ("score_weight_bfactor", C.c_float), ("score_average", C.c_float), ("score_threshold", C.c_float),
+        ("normalize", C.c_int), ("invert", C.c_int), ("split_by_pind", C.c_int), ("mask_radius", C.c_float),
+    ]
+
+
+class FinalCfg(C.Structure):
+    _fields_ = [("molecular_mass_kda", C.c_float), ("inner_radius", C.c_float), ("outer_radius", C.c_float),
+                ("mask_falloff", C.c_float)]

@@ -1,0 +1,240 @@
+"""Deterministic synthetic particle stacks with known poses.
+
+Test/benchmark input generator, independent of both the HIP kernels and the CPU oracle: it
+projects a phantom with torch tensor ops (works on CPU and on `cuda`) using a 2x zero-padded
+Fourier volume and trilinear interpolation, applies the CTF, shifts, adds white noise and
+normalises like the reference normalises extracted boxes (background outside the particle
+radius -> mean 0 / sigma 1, src/pyp/analysis/image.py:406-417).  Rows are shaped like the
+reference's from-scratch `.cistem` rows (src/pyp/inout/metadata/core.py:1324-1608).
+"""
+import math
+
+import numpy as np
+import torch
+
+from .formats import cistem
+
+SEED_VOLUME, SEED_POSES, SEED_NOISE = 20240501, 20240502, 20240503
+
+
+def phantom(n, seed=SEED_VOLUME, n_blobs=40, n_atoms=None):
+    """Protein-like phantom, (n,n,n) float32: `n_blobs` broad Gaussian blobs (domain-scale density)
+    plus a cloud of point-like "atoms" blurred to ~1 px so that the spectrum does not die at high
+    resolution, all inside radius 0.35 n, low-passed at 0.45 cycles/pixel."""
+    rng = np.random.default_rng(seed)
+    ax = np.arange(n, dtype=np.float32) - n // 2
+    z, y, x = np.meshgrid(ax, ax, ax, indexing="ij")
+    v = np.zeros((n, n, n), dtype=np.float32)
+    centres = []
+    for _ in range(n_blobs):
+        while True:
+            c = rng.uniform(-0.35 * n, 0.35 * n, 3)
+            if np.linalg.norm(c) <= 0.35 * n:
+                break
+        s = rng.uniform(3.0, 8.0) * n / 256.0
+        s = max(s, 1.2)
+        amp = rng.uniform(0.5, 1.5)
+        centres.append((c, s))
+        v += amp * np.exp(-((x - c[0]) ** 2 + (y - c[1]) ** 2 + (z - c[2]) ** 2) / (2 * s * s)).astype(np.float32)
+    # atoms: scattered around the blob centres, nearest-voxel deposition, Gaussian blur in Fourier space
+    if n_atoms is None:
+        n_atoms = 60 * n
+    a = np.zeros((n, n, n), dtype=np.float32)
+    which = rng.integers(0, n_blobs, n_atoms)
+    for i in range(n_atoms):
+        c, s = centres[which[i]]
+        p = c + rng.normal(0, 1.5 * s, 3)
+        if np.linalg.norm(p) > 0.35 * n:
+            continue
+        q = np.rint(p).astype(int) + n // 2
+        a[q[2], q[1], q[0]] += rng.uniform(0.5, 1.5)
+    k = np.fft.fftfreq(n)
+    kz, ky, kx = np.meshgrid(k, k, k, indexing="ij")
+    k2 = kx ** 2 + ky ** 2 + kz ** 2
+    f = np.fft.fftn(v) + 3.0 * np.fft.fftn(a) * np.exp(-2 * (np.pi ** 2) * k2 * 0.9 ** 2)
+    f[np.sqrt(k2) > 0.45] = 0
+    return np.real(np.fft.ifftn(f)).astype(np.float32)
+
+
+def euler_matrix(psi, theta, phi):
+    """M = Rz(phi) Ry(theta) Rz(psi) (degrees): image-plane coordinates -> reference coordinates
+    ("rotates the reference by PHI -> THETA -> PSI", src/pyp/analysis/geometry/core.py:1186-1187)."""
+    ps, th, ph = np.radians(psi), np.radians(theta), np.radians(phi)
+    c, s = np.cos, np.sin
+    return np.array([
+        [c(ph) * c(th) * c(ps) - s(ph) * s(ps), -c(ph) * c(th) * s(ps) - s(ph) * c(ps), c(ph) * s(th)],
+        [s(ph) * c(th) * c(ps) + c(ph) * s(ps), -s(ph) * c(th) * s(ps) + c(ph) * c(ps), s(ph) * s(th)],
+        [-s(th) * c(ps), s(th) * s(ps), c(th)]])
+
+
+def pyp_matrix(psi, theta, phi):
+    """The matrix written out at analysis/geometry/core.py:1194-1197 (its "left-handed" form) =
+    euler_matrix(-psi, -theta, -phi) element-wise... kept for the convention golden test."""
+    ps, th, ph = np.radians(psi), np.radians(theta), np.radians(phi)
+    c, s = np.cos, np.sin
+    return np.array([
+        [c(ph) * c(th) * c(ps) - s(ph) * s(ps), c(ph) * c(th) * s(ps) + s(ph) * c(ps), -c(ph) * s(th)],
+        [-s(ph) * c(th) * c(ps) - c(ph) * s(ps), -s(ph) * c(th) * s(ps) + c(ph) * c(ps), s(ph) * s(th)],
+        [s(th) * c(ps), s(th) * s(ps), c(th)]])
+
+
+def angles_from_pyp_matrix(m):
+    """(psi, theta, phi) in [0,360) from the matrix above; restates get_degrees_from_matrix
+    (analysis/geometry/core.py:211-234)."""
+    eps = np.nextafter(0, 1)
+    if m[2, 2] < 1 - eps:
+        if m[2, 2] > -1 + eps:
+            theta = math.acos(m[2, 2])
+            st = math.sin(theta)
+            psi = math.atan2(m[2, 1] / st, m[2, 0] / st)
+            phi = math.atan2(m[1, 2] / st, -m[0, 2] / st)
+        else:
+            theta, phi, psi = math.pi, math.atan2(-m[0, 1], -m[0, 0]), 0.0
+    else:
+        theta, phi, psi = 0.0, math.atan2(m[0, 1], m[0, 0]), 0.0
+    out = np.degrees([psi, theta, phi])
+    return tuple(np.where(out < 0, out + 360.0, out))
+
+
+def ctf_image(n, pixel, df1, df2, angast_deg, kv, cs_mm, amp, phase_shift, device):
+    """CTF on the centred full grid (ky, kx in -n/2..n/2-1); tensors of shape (M,) broadcast to (M,n,n)."""
+    k = torch.arange(-n // 2, n // 2, device=device, dtype=torch.float32)
+    ky, kx = torch.meshgrid(k, k, indexing="ij")
+    v = kv * 1000.0
+    lam = 12.2639 / math.sqrt(v + 0.97845e-6 * v * v)
+    s2 = (kx * kx + ky * ky) / (n * pixel) ** 2
+    ang = torch.atan2(ky, kx)
+    df1, df2, ast = (torch.as_tensor(t, device=device, dtype=torch.float32).view(-1, 1, 1) for t in (df1, df2, np.radians(angast_deg)))
+    df = 0.5 * (df1 + df2 + (df1 - df2) * torch.cos(2 * (ang - ast)))
+    chi = math.pi * lam * s2 * (df - 0.5 * cs_mm * 1e7 * lam * lam * s2) + phase_shift + math.atan(amp / math.sqrt(1 - amp * amp))
+    return -torch.sin(chi)
+
+
+class Projector:
+    """Fourier-slice projector over a 2x padded volume (torch)."""
+
+    def __init__(self, vol, device="cpu"):
+        self.n = n = vol.shape[0]
+        self.device = torch.device(device)
+        p = 2 * n
+        v = torch.zeros((p, p, p), dtype=torch.float32, device=self.device)
+        o = (p - n) // 2
+        v[o:o + n, o:o + n, o:o + n] = torch.as_tensor(vol, device=self.device)
+        f = torch.fft.fftshift(torch.fft.fftn(torch.fft.ifftshift(v)))      # centred spectrum, origin at p/2
+        self.f = f.to(torch.complex64)
+        self.p = p
+        k = torch.arange(-n // 2, n // 2, device=self.device, dtype=torch.float32)
+        self.ky, self.kx = torch.meshgrid(k, k, indexing="ij")
+
+    def spectra(self, mats):
+        """mats: (M,3,3) rotation matrices -> (M,n,n) complex centred projection spectra (unnormalised FFT2)."""
+        m = torch.as_tensor(np.asarray(mats), device=self.device, dtype=torch.float32)
+        p, f = self.p, self.f
+        kx, ky = self.kx[None], self.ky[None]
+        X = 2 * (m[:, 0, 0, None, None] * kx + m[:, 0, 1, None, None] * ky) + p // 2
+        Y = 2 * (m[:, 1, 0, None, None] * kx + m[:, 1, 1, None, None] * ky) + p // 2
+        Z = 2 * (m[:, 2, 0, None, None] * kx + m[:, 2, 1, None, None] * ky) + p // 2
+        x0, y0, z0 = X.floor(), Y.floor(), Z.floor()
+        fx, fy, fz = X - x0, Y - y0, Z - z0
+        out = torch.zeros(X.shape, dtype=torch.complex64, device=self.device)
+        flat = f.reshape(-1)
+        for dz in (0, 1):
+            for dy in (0, 1):
+                for dx in (0, 1):
+                    xi, yi, zi = (x0 + dx).long(), (y0 + dy).long(), (z0 + dz).long()
+                    ok = (xi >= 0) & (xi < p) & (yi >= 0) & (yi < p) & (zi >= 0) & (zi < p)
+                    idx = (zi.clamp(0, p - 1) * p + yi.clamp(0, p - 1)) * p + xi.clamp(0, p - 1)
+                    w = (fx if dx else 1 - fx) * (fy if dy else 1 - fy) * (fz if dz else 1 - fz)
+                    out += torch.where(ok, w, torch.zeros_like(w)) * flat[idx]
+        return out
+
+
+def make_dataset(n, m, pixel=1.0, snr=0.05, seed_poses=SEED_POSES, seed_noise=SEED_NOISE, vol=None,
+                 device="cpu", batch=64, particle_rad_frac=0.32, shift_sigma=2.0, shift_clip=6.0,
+                 kv=300.0, cs_mm=2.7, amp=0.07, unique=None):
+    """Return (vol, stack (m,n,n) float32 torch tensor on `device`, rows (m,32) float64 with the TRUE poses).
+
+    unique: if set (< m), only that many distinct clean projections are computed and reused cyclically with
+    fresh noise — used by bench.py to fill a 100k-particle stack quickly; every particle is still a distinct image."""
+    if vol is None:
+        vol = phantom(n)
+    rng = np.random.default_rng(seed_poses)
+    u = m if unique is None else min(unique, m)
+    psi, phi = rng.uniform(0, 360, u), rng.uniform(0, 360, u)
+    theta = np.degrees(np.arccos(rng.uniform(-1, 1, u)))
+    sh = np.clip(rng.normal(0, shift_sigma, (u, 2)), -shift_clip, shift_clip)
+    df1 = rng.uniform(8000, 24000, u)
+    df2 = df1 + rng.uniform(-300, 300, u)
+    ast = rng.uniform(0, 180, u)
+    rows = cistem.default_rows(m, pixel, kv, cs_mm, amp)
+    rep = np.arange(m) % u
+    C = cistem.COL
+    rows[:, C["PSI"]], rows[:, C["THETA"]], rows[:, C["PHI"]] = psi[rep], theta[rep], phi[rep]
+    rows[:, C["X_SHIFT"]], rows[:, C["Y_SHIFT"]] = sh[rep, 0] * pixel, sh[rep, 1] * pixel
+    rows[:, C["DEFOCUS_1"]], rows[:, C["DEFOCUS_2"]], rows[:, C["DEFOCUS_ANGLE"]] = df1[rep], df2[rep], ast[rep]
+
+    dev = torch.device(device)
+    proj = Projector(vol, dev)
+    k = torch.arange(-n // 2, n // 2, device=dev, dtype=torch.float32)
+    ky, kx = torch.meshgrid(k, k, indexing="ij")
+    clean = torch.empty((u, n, n), dtype=torch.float32, device=dev)
+    for b0 in range(0, u, batch):
+        b1 = min(u, b0 + batch)
+        mats = np.stack([euler_matrix(psi[i], theta[i], phi[i]) for i in range(b0, b1)])
+        spec = proj.spectra(mats)
+        ctf = ctf_image(n, pixel, df1[b0:b1], df2[b0:b1], ast[b0:b1], kv, cs_mm, amp, 0.0, dev)
+        sx = torch.as_tensor(sh[b0:b1, 0], device=dev, dtype=torch.float32).view(-1, 1, 1)
+        sy = torch.as_tensor(sh[b0:b1, 1], device=dev, dtype=torch.float32).view(-1, 1, 1)
+        ramp = torch.exp(-2j * math.pi * (kx[None] * sx + ky[None] * sy) / n)
+        spec = spec * ctf * ramp
+        img = torch.fft.fftshift(torch.fft.ifft2(torch.fft.ifftshift(spec, dim=(-2, -1))), dim=(-2, -1)).real
+        clean[b0:b1] = img
+    sig_var = clean.var(dim=(-2, -1), keepdim=True).mean()
+    noise_sd = float(torch.sqrt(sig_var / snr)) if snr > 0 else 0.0
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed_noise)
+    stack = torch.empty((m, n, n), dtype=torch.float32, device=dev)
+    rad = particle_rad_frac * n
+    bg = ((kx * kx + ky * ky) > rad * rad)
+    for b0 in range(0, m, 1024):
+        b1 = min(m, b0 + 1024)
+        idx = torch.as_tensor(rep[b0:b1], device=dev)
+        x = clean[idx]
+        if noise_sd > 0:
+            x = x + noise_sd * torch.randn(x.shape, generator=gen, device=dev)
+        # cryo-EM convention: protein is dark -> invert? we keep positive-density-is-positive and
+        # the callers pass invert = no.
+        mu = x[:, bg].mean(dim=1).view(-1, 1, 1)
+        sd = x[:, bg].std(dim=1, unbiased=False).view(-1, 1, 1)
+        stack[b0:b1] = (x - mu) / sd
+    return vol, stack, rows
+
+
+def perturb_rows(rows, angle_sigma=2.0, shift_sigma_px=1.0, pixel=1.0, seed=7):
+    """Copy of `rows` with Gaussian perturbations of the poses (config 1: local refinement start)."""
+    rng = np.random.default_rng(seed)
+    r = rows.copy()
+    C = cistem.COL
+    for c in ("PSI", "THETA", "PHI"):
+        r[:, C[c]] += rng.normal(0, angle_sigma, len(r))
+    for c in ("X_SHIFT", "Y_SHIFT"):
+        r[:, C[c]] += rng.normal(0, shift_sigma_px * pixel, len(r))
+    return r
+
+
+def angular_error_deg(rows_a, rows_b):
+    """Geodesic angle (degrees) between the rotations of two row sets."""
+    C = cistem.COL
+    out = np.empty(len(rows_a))
+    for i in range(len(rows_a)):
+        ma = euler_matrix(rows_a[i, C["PSI"]], rows_a[i, C["THETA"]], rows_a[i, C["PHI"]])
+        mb = euler_matrix(rows_b[i, C["PSI"]], rows_b[i, C["THETA"]], rows_b[i, C["PHI"]])
+        t = (np.trace(ma.T @ mb) - 1.0) / 2.0
+        out[i] = np.degrees(np.arccos(np.clip(t, -1.0, 1.0)))
+    return out
+
+
+def shift_error_px(rows_a, rows_b, pixel=1.0):
+    C = cistem.COL
+    d = rows_a[:, [C["X_SHIFT"], C["Y_SHIFT"]]] - rows_b[:, [C["X_SHIFT"], C["Y_SHIFT"]]]
+    return np.sqrt((d ** 2).sum(axis=1)) / pixel
