@@ -1,0 +1,176 @@
+// ppm_geom.h — host-side derived geometry of a refinement call (band limits, shift grid,
+// orientation grid, ring-ordered sample list).  Plain C++, no device code.
+//
+// The quantities restate the numeric answers of the refine3d prompt script
+// (src/pyp/refine/frealign/frealign.py:3918-3994) in Fourier-pixel units; the grid is the
+// build-defined global grid of SURVEY.md §8a K6 (theta = 0..180 step D, n_phi = round(360 sin(theta)/D)).
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ppm.h"
+
+namespace ppm {
+
+constexpr double kPi = 3.14159265358979323846;
+
+struct Geom {
+    int N = 0;
+    double a = 0;
+    double r_hi = 0, r_lo = 0, r_s = 0, ring_signed = 0;
+    int B = 0, W = 0, H = 0;      // full band: half-width, row width B+1, rows 2B+1
+    int Bs = 0, Hs = 0;           // search band
+    int Ns = 0, step = 0, RSx = 0, RSy = 0;
+    int n_theta = 0, n_psi = 0, n_dir = 0, n_orient = 0, npsi_store = 0, half = 0;
+    double dpsi = 0, dstep = 0;
+};
+
+inline bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+
+inline int n_phi_at(double theta_deg, double dstep) {
+    int np = (int)std::floor(360.0 * std::sin(theta_deg * kPi / 180.0) / dstep + 0.5);
+    return np < 1 ? 1 : np;
+}
+
+inline bool geom_init(Geom &g, const ppm_refine_cfg &c, std::string &err) {
+    g = Geom();
+    g.N = c.box; g.a = c.pixel_size;
+    if (!is_pow2(g.N) || g.N < 32 || g.N > 512) { err = "box size must be a power of two in 32..512"; return false; }
+    if (!(g.a > 0) || !(c.res_high > 0)) { err = "pixel size and high-resolution limit must be positive"; return false; }
+    double na = g.N * g.a;
+    g.r_hi = na / c.res_high; if (g.r_hi > g.N / 2) g.r_hi = g.N / 2;
+    g.r_lo = c.res_low > 0 ? na / c.res_low : 0.0;
+    g.r_s = c.res_search > 0 ? na / c.res_search : g.r_hi; if (g.r_s > g.r_hi) g.r_s = g.r_hi;
+    g.ring_signed = c.res_signed_cc > 0 ? na / c.res_signed_cc : 1e30;
+    g.B = (int)std::ceil(g.r_hi) - 1; g.W = g.B + 1; g.H = 2 * g.B + 1;
+    g.Bs = (int)std::ceil(g.r_s) - 1; g.Hs = 2 * g.Bs + 1;
+    if (g.B < 2) { err = "resolution limits leave fewer than 3 Fourier pixels"; return false; }
+    g.Ns = 2; while (g.Ns < 2 * (g.Bs + 1)) g.Ns <<= 1; if (g.Ns > g.N) g.Ns = g.N;
+    g.step = g.N / g.Ns;
+    double rx = c.search_range_x / g.a, ry = c.search_range_y / g.a;
+    g.RSx = rx > 0 ? (int)std::ceil(rx / g.step) : PPM_MAX_SHIFT_STEPS;
+    g.RSy = ry > 0 ? (int)std::ceil(ry / g.step) : PPM_MAX_SHIFT_STEPS;
+    if (g.RSx > PPM_MAX_SHIFT_STEPS) g.RSx = PPM_MAX_SHIFT_STEPS;
+    if (g.RSy > PPM_MAX_SHIFT_STEPS) g.RSy = PPM_MAX_SHIFT_STEPS;
+    g.dstep = c.angular_step > 0 ? c.angular_step : 15.0;
+    g.n_theta = (int)std::floor(180.0 / g.dstep + 0.5) + 1;
+    if (g.n_theta < 2) g.n_theta = 2;
+    g.n_psi = (int)std::floor(360.0 / g.dstep + 0.5); if (g.n_psi < 1) g.n_psi = 1;
+    g.dpsi = 360.0 / g.n_psi;
+    g.n_dir = 0;
+    for (int i = 0; i < g.n_theta; i++) g.n_dir += n_phi_at(180.0 * i / (g.n_theta - 1), g.dstep);
+    g.n_orient = g.n_dir * g.n_psi;
+    g.half = (g.n_psi % 2 == 0);
+    g.npsi_store = g.half ? g.n_psi / 2 : g.n_psi;
+    return true;
+}
+
+inline void grid_direction(const Geom &g, int dir, double &theta, double &phi) {
+    int acc = 0;
+    for (int i = 0; i < g.n_theta; i++) {
+        double th = 180.0 * i / (g.n_theta - 1);
+        int np = n_phi_at(th, g.dstep);
+        if (dir < acc + np) { theta = th; phi = 360.0 * (dir - acc) / np; return; }
+        acc += np;
+    }
+    theta = phi = 0;
+}
+
+// M = Rz(phi) Ry(theta) Rz(psi), row-major 3x3 ("rotates the reference by PHI -> THETA -> PSI",
+// src/pyp/analysis/geometry/core.py:1186-1187)
+inline void euler_matrix(double psi, double theta, double phi, double M[9]) {
+    double ps = psi * kPi / 180, th = theta * kPi / 180, ph = phi * kPi / 180;
+    double cps = std::cos(ps), sps = std::sin(ps), cth = std::cos(th), sth = std::sin(th), cph = std::cos(ph), sph = std::sin(ph);
+    M[0] = cph * cth * cps - sph * sps; M[1] = -cph * cth * sps - sph * cps; M[2] = cph * sth;
+    M[3] = sph * cth * cps + cph * sps; M[4] = -sph * cth * sps + cph * cps; M[5] = sph * sth;
+    M[6] = -sth * cps;                  M[7] = sth * sps;                    M[8] = cth;
+}
+
+// Ring-ordered sample list of the half plane kx >= 0, 0 < k^2 < r_hi^2, ring = floor(|k|); every
+// ring padded to a multiple of 16 samples with weightless dummies so that a 16-lane group never
+// straddles two rings.  Packed: kx (9 bits) | ky+256 (10 bits) << 9 | alpha (2 bits) << 19 | ring << 21.
+struct SampleList {
+    std::vector<uint32_t> packed;
+    std::vector<int> ring_off;   // ring_off[b] = first sample of ring b; size B+3
+    std::vector<int> smap;       // (ky+B)*W + kx -> sample index or -1
+};
+
+inline uint32_t pack_sample(int kx, int ky, int alpha, int ring) {
+    return (uint32_t)kx | ((uint32_t)(ky + 256) << 9) | ((uint32_t)alpha << 19) | ((uint32_t)ring << 21);
+}
+
+inline void build_samples(const Geom &g, SampleList &sl) {
+    int B = g.B, W = g.W;
+    std::vector<std::vector<uint32_t>> rings(B + 2);
+    std::vector<std::vector<int>> cells(B + 2);
+    double r2 = g.r_hi * g.r_hi;
+    for (int ky = -B; ky <= B; ky++) for (int kx = 0; kx <= B; kx++) {
+        double k2 = (double)kx * kx + (double)ky * ky;
+        if (k2 >= r2 || k2 == 0) continue;
+        int b = (int)std::floor(std::sqrt(k2));
+        rings[b].push_back(pack_sample(kx, ky, kx == 0 ? 1 : 2, b));
+        cells[b].push_back((ky + B) * W + kx);
+    }
+    sl.packed.clear(); sl.ring_off.assign(B + 3, 0); sl.smap.assign((size_t)g.H * W, -1);
+    for (int b = 0; b <= B + 1; b++) {
+        sl.ring_off[b] = (int)sl.packed.size();
+        for (size_t i = 0; i < rings[b].size(); i++) {
+            sl.smap[cells[b][i]] = (int)sl.packed.size();
+            sl.packed.push_back(rings[b][i]);
+        }
+        while (sl.packed.size() % 16) sl.packed.push_back(pack_sample(0, 0, 0, b));
+    }
+    sl.ring_off[B + 2] = (int)sl.packed.size();
+}
+
+// Point-group operators (row-major 3x3 each); "C1","Cn","Dn","T","O","I"
+inline void mat_mul3(const double *a, const double *b, double *c) {
+    double t[9];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+        double v = 0; for (int k = 0; k < 3; k++) v += a[i * 3 + k] * b[k * 3 + j];
+        t[i * 3 + j] = v;
+    }
+    std::memcpy(c, t, sizeof(t));
+}
+inline void rot_axis(const double ax[3], double deg, double *m) {
+    double n = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+    double x = ax[0] / n, y = ax[1] / n, z = ax[2] / n, t = deg * kPi / 180, c = std::cos(t), s = std::sin(t), C = 1 - c;
+    double r[9] = { c + x * x * C, x * y * C - z * s, x * z * C + y * s, y * x * C + z * s, c + y * y * C, y * z * C - x * s,
+                    z * x * C - y * s, z * y * C + x * s, c + z * z * C };
+    std::memcpy(m, r, sizeof(r));
+}
+inline int symmetry_ops(const char *sym, std::vector<double> &ops) {
+    double gens[27]; int ng = 0;
+    double z[3] = { 0, 0, 1 }, x[3] = { 1, 0, 0 }, d111[3] = { 1, 1, 1 };
+    if (!sym || !sym[0]) sym = "C1";
+    char t = sym[0] >= 'a' ? sym[0] - 32 : sym[0];
+    int n = std::atoi(sym + 1);
+    if (t == 'C' && n >= 1) { rot_axis(z, 360.0 / n, gens); ng = 1; }
+    else if (t == 'D' && n >= 1) { rot_axis(z, 360.0 / n, gens); rot_axis(x, 180, gens + 9); ng = 2; }
+    else if (t == 'T') { rot_axis(z, 180, gens); rot_axis(d111, 120, gens + 9); ng = 2; }
+    else if (t == 'O') { rot_axis(z, 90, gens); rot_axis(d111, 120, gens + 9); ng = 2; }
+    else if (t == 'I') {
+        double phi = (1 + std::sqrt(5.0)) / 2, a5[3] = { 0, 1, phi };
+        rot_axis(z, 180, gens); rot_axis(d111, 120, gens + 9); rot_axis(a5, 72, gens + 18); ng = 3;
+    } else return -1;
+    ops.assign(9, 0.0); ops[0] = ops[4] = ops[8] = 1.0;
+    int cnt = 1;
+    for (bool grew = true; grew;) {
+        grew = false;
+        for (int i = 0; i < cnt && cnt < 60; i++) for (int j = 0; j < ng && cnt < 60; j++) {
+            double c[9]; mat_mul3(&ops[i * 9], gens + j * 9, c);
+            bool found = false;
+            for (int k = 0; k < cnt && !found; k++) {
+                double d = 0; for (int q = 0; q < 9; q++) d += std::fabs(ops[k * 9 + q] - c[q]);
+                if (d < 1e-6) found = true;
+            }
+            if (!found) { ops.insert(ops.end(), c, c + 9); cnt++; grew = true; }
+        }
+    }
+    return cnt;
+}
+
+}  // namespace ppm

@@ -1,0 +1,387 @@
+// ppm_kernels.h — the HIP kernels of libpypmatch (gfx950 / CDNA4, wave64).
+//
+//   k_fft_lines      batched strided 1-D complex FFT through LDS (3-D transforms of volumes)
+//   k_ref_load/crop  reference preparation (sinc^2 pre-compensation, centring, band-limited cube)
+//   k_prep           per-particle pre-processing: normalise, mask, 2-D real FFT in LDS (two rows
+//                    packed per complex transform, band-limited columns), ring whitening, CTF tables
+//   k_bank           central slices of the global-search grid (shared by all particles)
+//   k_global         pruned correlation image of every (particle, orientation): lane = kx, rows
+//                    stream over ky, wavefront-shuffle reduction of the shift window, top-K hits
+//   k_local          ring-wise weighted correlation at arbitrary poses + compass refinement
+//   k_insert         CTF-weighted trilinear scatter-add into the half-map accumulators
+//   finalise         shell statistics, Wiener division, mask and gridding correction
+#pragma once
+#include "ppm_dev.h"
+
+namespace ppm {
+
+// ---------------------------------------------------------------------------------- 3-D FFT passes
+struct FftLinesP {
+    float2 *data; const float2 *tw;
+    int n, logn, inverse, line_major, L;
+    long nlines, inner, inner_stride, outer_stride, elem_stride;
+};
+
+__global__ void __launch_bounds__(256) k_fft_lines(FftLinesP P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *buf = (float2 *)smem;
+    const int tid = threadIdx.x, n = P.n;
+    long l0 = (long)blockIdx.x * P.L;
+    int nl = (int)((P.nlines - l0) < P.L ? (P.nlines - l0) : P.L);
+    if (nl <= 0) return;
+    for (int i = tid; i < nl * n; i += 256) {
+        int line, e;
+        if (P.line_major) { line = i % nl; e = i / nl; } else { line = i / n; e = i % n; }
+        long l = l0 + line;
+        long base = (l / P.inner) * P.outer_stride + (l % P.inner) * P.inner_stride;
+        buf[line * n + bitrev(e, P.logn)] = P.data[base + e * P.elem_stride];
+    }
+    lds_fft(buf, n, P.logn, nl, n, P.inverse != 0, P.tw, tid, 256);
+    for (int i = tid; i < nl * n; i += 256) {
+        int line, e;
+        if (P.line_major) { line = i % nl; e = i / nl; } else { line = i / n; e = i % n; }
+        long l = l0 + line;
+        long base = (l / P.inner) * P.outer_stride + (l % P.inner) * P.inner_stride;
+        P.data[base + e * P.elem_stride] = buf[line * n + e];
+    }
+}
+
+// ---------------------------------------------------------------------------------- reference
+__global__ void k_ref_load(const float *__restrict__ vol, float2 *__restrict__ f, int n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, n3 = (size_t)n * n * n;
+    if (i >= n3) return;
+    int x = (int)(i % n), y = (int)((i / n) % n), z = (int)(i / ((size_t)n * n));
+    float g = 1.f;
+    int c[3] = { x, y, z };
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        float u = kPiF * (float)(c[q] - n / 2) / (float)n;
+        float sv = fabsf(u) < 1e-6f ? 1.f : sinf(u) / u;
+        g *= 1.f / (sv * sv);
+    }
+    f[i] = make_float2(vol[i] * g, 0.f);
+}
+
+__global__ void k_ref_crop(const float2 *__restrict__ f, float2 *__restrict__ cube, int n, int B, int CX, int CY) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, tot = (size_t)CX * CY * CY;
+    if (i >= tot) return;
+    int x = (int)(i % CX), y = (int)((i / CX) % CY) - (B + 1), z = (int)(i / ((size_t)CX * CY)) - (B + 1);
+    int iz = ((z % n) + n) % n, iy = ((y % n) + n) % n, ix = x % n;
+    float2 v = f[((size_t)iz * n + iy) * n + ix];
+    float sg = (((x + y + z) & 1) ? -1.f : 1.f) / (float)n;
+    cube[i] = make_float2(v.x * sg, v.y * sg);
+}
+
+// ---------------------------------------------------------------------------------- pre-processing
+struct PrepP {
+    const float *images; const double *rows; const float2 *tw;
+    int N, logN, B, W, H;
+    float r_hi2, Rm, wfall, a;
+    int normalize, invert, do_mask, whiten;
+    int nc, nchunks, L;
+    float2 *band;  // [n][H*W] unscaled band spectrum (scratch; the final result for insertion)
+    float *wring;  // [n][B+2] ring weights 1/sqrt(mean power), may be null
+    // ring-ordered list outputs (may be null)
+    const uint32_t *samples; int S_pad; float2 *Il; float *cw;
+    // search-layout outputs (may be null): [n][Hs*64]
+    float2 *Wp; float *C2; float *nI; int Bs, Hs; float r_s2, r_lo2;
+};
+
+__global__ void __launch_bounds__(256) k_prep(PrepP P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, N = P.N, B = P.B, W = P.W, H = P.H;
+    const int p = blockIdx.x;
+    const int TS = N + 1;                             // padded line stride of T (bank spread)
+    float2 *T = (float2 *)smem;                       // [nc][N+1]
+    float2 *Wk = T + (size_t)P.nc * TS;               // [L][N]
+    float *ringpw = (float *)(Wk + (size_t)P.L * N);  // [B+2]
+    float *ringpc = ringpw + (B + 2);                 // [B+2]
+    double *red = (double *)(((uintptr_t)(ringpc + (B + 2)) + 15) & ~(uintptr_t)15);  // [4*4]
+    float *stat = (float *)(red + 16);                // mu, scale
+    const float *img = P.images + (size_t)p * N * N;
+
+    // ---- statistics of the background (outside the mask radius); whole image if that is empty
+    double s1 = 0, s2 = 0, cnt = 0, t1 = 0, t2 = 0;
+    const float Rm2 = P.Rm * P.Rm;
+    for (int i = tid; i < N * N; i += 256) {
+        int x = i & (N - 1), y = i >> P.logN;
+        float dx = (float)(x - N / 2), dy = (float)(y - N / 2), v = img[i];
+        t1 += v; t2 += (double)v * v;
+        if (dx * dx + dy * dy > Rm2) { s1 += v; s2 += (double)v * v; cnt += 1.0; }
+    }
+    s1 = wave_sum_d(s1); s2 = wave_sum_d(s2); cnt = wave_sum_d(cnt); t1 = wave_sum_d(t1); t2 = wave_sum_d(t2);
+    if ((tid & 63) == 0) { int w = tid >> 6; red[w * 4] = s1; red[w * 4 + 1] = s2; red[w * 4 + 2] = cnt; red[w * 4 + 3] = t1; }
+    __syncthreads();
+    if (tid == 0) {
+        double a1 = 0, a2 = 0, ac = 0, b1 = 0;
+        for (int w = 0; w < 4; w++) { a1 += red[w * 4]; a2 += red[w * 4 + 1]; ac += red[w * 4 + 2]; b1 += red[w * 4 + 3]; }
+        red[0] = a1; red[1] = a2; red[2] = ac; red[3] = b1;
+    }
+    __syncthreads();
+    {
+        double a1 = red[0], a2 = red[1], ac = red[2], b1 = red[3];
+        __syncthreads();
+        if ((tid & 63) == 0) red[4 + (tid >> 6)] = t2;
+        __syncthreads();
+        if (tid == 0) {
+            double b2 = red[4] + red[5] + red[6] + red[7];
+            if (ac < 16) { a1 = b1; a2 = b2; ac = (double)N * N; }
+            double mu = a1 / ac, var = a2 / ac - mu * mu, sd = var > 0 ? sqrt(var) : 1.0;
+            stat[0] = (float)mu;
+            stat[1] = (float)((P.normalize ? 1.0 / sd : 1.0) * (P.invert ? -1.0 : 1.0));
+        }
+        __syncthreads();
+    }
+    const float mu = stat[0], sc = stat[1];
+    for (int i = tid; i < 2 * (B + 2); i += 256) ringpw[i] = 0.f;
+
+    const float wf = P.wfall < 1e-3f ? 1e-3f : P.wfall;
+    float2 *bandp = P.band + (size_t)p * H * W;
+    for (int ch = 0; ch < P.nchunks; ch++) {
+        const int c0 = ch * P.nc, ncol = (W - c0) < P.nc ? (W - c0) : P.nc;
+        // ---- row pass: two real rows per complex transform
+        for (int y0 = 0; y0 < N; y0 += 2 * P.L) {
+            __syncthreads();
+            for (int i = tid; i < P.L * N; i += 256) {
+                int l = i >> P.logN, x = i & (N - 1);
+                int ya = y0 + 2 * l, yb = ya + 1;
+                float va = (img[ya * N + x] - mu) * sc, vb = (img[yb * N + x] - mu) * sc;
+                if (P.do_mask) {
+                    float dx = (float)(x - N / 2);
+                    float ra = sqrtf(dx * dx + (float)((ya - N / 2) * (ya - N / 2)));
+                    float rb = sqrtf(dx * dx + (float)((yb - N / 2) * (yb - N / 2)));
+                    float ma = ra >= P.Rm + 0.5f * wf ? 0.f : (ra > P.Rm - 0.5f * wf ? 0.5f * (1.f + cosf(kPiF * (ra - P.Rm + 0.5f * wf) / wf)) : 1.f);
+                    float mb = rb >= P.Rm + 0.5f * wf ? 0.f : (rb > P.Rm - 0.5f * wf ? 0.5f * (1.f + cosf(kPiF * (rb - P.Rm + 0.5f * wf) / wf)) : 1.f);
+                    va *= ma; vb *= mb;
+                }
+                Wk[l * N + bitrev(x, P.logN)] = make_float2(va, vb);
+            }
+            lds_fft(Wk, N, P.logN, P.L, N, false, P.tw, tid, 256);
+            for (int i = tid; i < P.L * ncol; i += 256) {
+                int l = i / ncol, c = i - l * ncol, kx = c0 + c;
+                float2 z = Wk[l * N + kx], zc = Wk[l * N + ((N - kx) & (N - 1))];
+                float2 xa = make_float2(0.5f * (z.x + zc.x), 0.5f * (z.y - zc.y));
+                float2 d = make_float2(z.x - zc.x, z.y + zc.y);
+                float2 xb = make_float2(0.5f * d.y, -0.5f * d.x);
+                int ya = y0 + 2 * l;
+                T[c * TS + bitrev(ya, P.logN)] = xa;
+                T[c * TS + bitrev(ya + 1, P.logN)] = xb;
+            }
+        }
+        // ---- column pass
+        lds_fft(T, N, P.logN, ncol, TS, false, P.tw, tid, 256);
+        const float invN = 1.f / (float)N;
+        for (int i = tid; i < ncol * H; i += 256) {
+            int c = i % ncol, row = i / ncol, ky = row - B, kx = c0 + c;
+            float k2 = (float)(kx * kx + ky * ky);
+            float2 o = make_float2(0.f, 0.f);
+            if (k2 < P.r_hi2 && k2 > 0.f) {
+                float2 v = T[c * TS + ((ky + N) & (N - 1))];
+                float sg = ((kx + ky) & 1) ? -invN : invN;
+                o = make_float2(v.x * sg, v.y * sg);
+                int b = (int)floorf(sqrtf(k2));
+                float al = kx == 0 ? 1.f : 2.f;
+                atomicAdd(&ringpw[b], al * (o.x * o.x + o.y * o.y));
+                atomicAdd(&ringpc[b], al);
+            }
+            bandp[row * W + kx] = o;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- ring weights (re-using ringpw as the weight table)
+    for (int b = tid; b < B + 2; b += 256) {
+        float pw = ringpc[b] > 0.f ? ringpw[b] / ringpc[b] : 0.f;
+        float wgt = P.whiten ? (pw > 0.f ? rsqrtf(pw) : 0.f) : 1.f;
+        ringpw[b] = wgt;
+        if (P.wring) P.wring[(size_t)p * (B + 2) + b] = wgt;
+    }
+    __syncthreads();
+    CtfP ctf = ctf_from_row(P.rows + (size_t)p * PPM_NCOL, N, (double)P.a);
+    if (P.Il) {
+        float2 *Ilp = P.Il + (size_t)p * P.S_pad;
+        float *cwp = P.cw + (size_t)p * P.S_pad;
+        for (int s = tid; s < P.S_pad; s += 256) {
+            int kx, ky, al, ring;
+            unpack_sample(P.samples[s], kx, ky, al, ring);
+            float2 v = make_float2(0.f, 0.f); float c = 0.f;
+            if (al) {
+                float wgt = ringpw[ring];
+                float2 u = bandp[(ky + B) * W + kx];
+                v = make_float2(u.x * wgt, u.y * wgt);
+                c = ctf_eval(ctf, kx, ky) * wgt;
+            }
+            Ilp[s] = v; cwp[s] = c;
+        }
+    }
+    if (P.Wp) {
+        float2 *Wpp = P.Wp + (size_t)p * P.Hs * 64;
+        float *C2p = P.C2 + (size_t)p * P.Hs * 64;
+        float ni = 0.f;
+        for (int i = tid; i < P.Hs * 64; i += 256) {
+            int kx = i & 63, ky = (i >> 6) - P.Bs;
+            float k2 = (float)(kx * kx + ky * ky);
+            float2 wv = make_float2(0.f, 0.f); float c2 = 0.f;
+            if (kx <= P.Bs && k2 < P.r_s2 && k2 >= P.r_lo2 && k2 > 0.f) {
+                int b = (int)floorf(sqrtf(k2));
+                float wgt = ringpw[b], al = kx == 0 ? 1.f : 2.f;
+                float2 u = bandp[(ky + B) * W + kx];
+                float2 v = make_float2(u.x * wgt, u.y * wgt);
+                float c = ctf_eval(ctf, kx, ky) * wgt;
+                wv = make_float2(al * c * v.x, al * c * v.y);
+                c2 = al * c * c;
+                ni += al * (v.x * v.x + v.y * v.y);
+            }
+            Wpp[i] = wv; C2p[i] = c2;
+        }
+        ni = wave_sum(ni);
+        __syncthreads();
+        if ((tid & 63) == 0) stat[2 + (tid >> 6)] = ni;
+        __syncthreads();
+        if (tid == 0) P.nI[p] = stat[2] + stat[3] + stat[4] + stat[5];
+    }
+}
+
+// ---------------------------------------------------------------------------------- slice bank
+struct BankP { CubeView cv; const float *mats; float2 *bank; int nslices, Bs, Hs; float r_s2; };
+
+__global__ void __launch_bounds__(256) k_bank(BankP P) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, per = (size_t)P.Hs * 64;
+    if (i >= per * P.nslices) return;
+    int sl = (int)(i / per), r = (int)(i - (size_t)sl * per);
+    int kx = r & 63, ky = (r >> 6) - P.Bs;
+    float k2 = (float)(kx * kx + ky * ky);
+    float2 v = make_float2(0.f, 0.f);
+    if (kx <= P.Bs && k2 < P.r_s2) {
+        const float *m = P.mats + (size_t)sl * 6;
+        float fx = (float)kx, fy = (float)ky;
+        v = sample_cube(P.cv, m[0] * fx + m[1] * fy, m[2] * fx + m[3] * fy, m[4] * fx + m[5] * fy);
+    }
+    P.bank[i] = v;
+}
+
+// ---------------------------------------------------------------------------------- global search
+struct Hit { float cc; int orient; int sx, sy; };
+
+struct GlobP {
+    const float2 *bank; const float2 *Wp; const float *C2; const float *nI; const float2 *twN;  // twN: Ns-entry table e^{2 pi i t/Ns}
+    float *cc; int *sh;   // [n][n_orient] scratch scores and packed shifts
+    Hit *hits;            // [n][K]
+    int Bs, Hs, Ns, RSx, RSy, n_dir, n_psi, npsi_store, n_orient, K;
+};
+
+// Block = one particle, 16 waves.  The particle's CTF-weighted spectrum W and CTF^2 table sit in LDS;
+// each wave streams whole slices from the bank: lane = kx, loop over ky.  Per loaded slice sample it
+// forms Q = W conj(P) (orientation psi) and W P (psi + 180) and accumulates the partial transforms
+// G[kx][sy] for the 2R+1 rows of the shift window; the sum over kx is a wavefront reduction.
+constexpr int global_threads(int R) { return R <= 3 ? 1024 : 512; }   // wider windows need > 128 VGPRs
+
+template <int R, bool HALF>
+__global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
+    constexpr int NT = global_threads(R), NW = NT / 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = blockIdx.x;
+    const int Hs = P.Hs, Bs = P.Bs, Ns = P.Ns, nsamp = Hs * 64;
+    float2 *Wl = (float2 *)smem;
+    float *C2l = (float *)(Wl + nsamp);
+    {
+        const float2 *src = P.Wp + (size_t)p * nsamp; const float *src2 = P.C2 + (size_t)p * nsamp;
+        for (int i = tid; i < nsamp; i += NT) { Wl[i] = src[i]; C2l[i] = src2[i]; }
+    }
+    __syncthreads();
+    const float nI = P.nI[p];
+    // per-lane x twiddles e^{+2 pi i kx j / Ns}
+    float txc[R + 1], txs[R + 1];
+#pragma unroll
+    for (int j = 0; j <= R; j++) {
+        float2 t = P.twN[(lane * j) & (Ns - 1)];
+        txc[j] = t.x; txs[j] = t.y;
+    }
+    const int nslices = P.n_dir * P.npsi_store;
+    float *ccp = P.cc + (size_t)p * P.n_orient; int *shp = P.sh + (size_t)p * P.n_orient;
+    for (int sl = wave; sl < nslices; sl += NW) {
+        const float2 *Pp = P.bank + (size_t)sl * nsamp;
+        float2 g1[2 * R + 1], g2[2 * R + 1];
+#pragma unroll
+        for (int j = 0; j < 2 * R + 1; j++) { g1[j] = make_float2(0.f, 0.f); g2[j] = make_float2(0.f, 0.f); }
+        float nP = 0.f;
+        for (int row = 0; row < Hs; row++) {
+            const int ky = row - Bs;
+            float2 pv = Pp[row * 64 + lane];
+            float2 wv = Wl[row * 64 + lane];
+            float c2 = C2l[row * 64 + lane];
+            float a = wv.x * pv.x, b = wv.y * pv.y, c = wv.y * pv.x, d = wv.x * pv.y;
+            float2 q1 = make_float2(a + b, c - d);   // W conj(P)
+            float2 q2 = make_float2(a - b, c + d);   // W P
+            nP += c2 * (pv.x * pv.x + pv.y * pv.y);
+            g1[R].x += q1.x; g1[R].y += q1.y;
+            if (HALF) { g2[R].x += q2.x; g2[R].y += q2.y; }
+#pragma unroll
+            for (int j = 1; j <= R; j++) {
+                float2 t = P.twN[(ky * j) & (Ns - 1)];   // wave-uniform
+                g1[R + j].x += q1.x * t.x - q1.y * t.y; g1[R + j].y += q1.x * t.y + q1.y * t.x;
+                g1[R - j].x += q1.x * t.x + q1.y * t.y; g1[R - j].y += q1.y * t.x - q1.x * t.y;
+                if (HALF) {
+                    g2[R + j].x += q2.x * t.x - q2.y * t.y; g2[R + j].y += q2.x * t.y + q2.y * t.x;
+                    g2[R - j].x += q2.x * t.x + q2.y * t.y; g2[R - j].y += q2.y * t.x - q2.x * t.y;
+                }
+            }
+        }
+        nP = wave_sum(nP);
+        const float inv = (nP > 0.f && nI > 0.f) ? rsqrtf(nP * nI) : 0.f;
+        const int dir = sl / P.npsi_store, ks = sl - dir * P.npsi_store;
+#pragma unroll
+        for (int e = 0; e < (HALF ? 2 : 1); e++) {
+            float best = -3.0e38f; int bsx = 0, bsy = 0;
+#pragma unroll
+            for (int iy = 0; iy < 2 * R + 1; iy++) {
+                float2 g = e ? g2[iy] : g1[iy];
+#pragma unroll
+                for (int ix = 0; ix < 2 * R + 1; ix++) {
+                    const int j = ix - R, ja = j < 0 ? -j : j;
+                    float v = j >= 0 ? (g.x * txc[ja] - g.y * txs[ja]) : (g.x * txc[ja] + g.y * txs[ja]);
+                    v = wave_sum(v);
+                    bool ok = (ja <= P.RSx) && ((iy - R < 0 ? R - iy : iy - R) <= P.RSy);
+                    if (ok && v > best) { best = v; bsx = j; bsy = iy - R; }
+                }
+            }
+            if (lane == 0) {
+                int o = dir * P.n_psi + ks + e * P.npsi_store;
+                ccp[o] = best * inv;
+                shp[o] = (bsx & 0xffff) | (bsy << 16);
+            }
+        }
+    }
+    // ---- top-K of this particle's scores (ties -> lower orientation index); winners so far are kept
+    // in an LDS exclusion list so that the score array is only ever read
+    __threadfence_block();
+    __syncthreads();
+    float *rv = (float *)smem; int *ri = (int *)(rv + 16); int *won = ri + 16;   // W table no longer needed
+    for (int k = 0; k < P.K; k++) {
+        float bv = -3.0e38f; int bi = 0x7fffffff;
+        for (int o = tid; o < P.n_orient; o += NT) {
+            float v = ccp[o];
+            bool taken = false;
+            for (int q = 0; q < k; q++) taken |= (won[q] == o);
+            if (!taken && (v > bv || (v == bv && o < bi))) { bv = v; bi = o; }
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            float ov = __shfl_xor(bv, m, 64); int oi = __shfl_xor(bi, m, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { rv[wave] = bv; ri[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < NW; w++) if (rv[w] > bv || (rv[w] == bv && ri[w] < bi)) { bv = rv[w]; bi = ri[w]; }
+            Hit h; h.cc = bv; h.orient = bi;
+            int sv = shp[bi];
+            h.sx = (int)(short)(sv & 0xffff); h.sy = sv >> 16;
+            P.hits[(size_t)p * P.K + k] = h;
+            won[k] = bi;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace ppm

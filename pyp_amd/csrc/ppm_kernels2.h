@@ -1,0 +1,415 @@
+// ppm_kernels2.h — local refinement, Fourier insertion and finalisation kernels (gfx950).
+#pragma once
+#include "ppm_kernels.h"
+
+namespace ppm {
+
+// ---------------------------------------------------------------------------------- local refinement
+// One refinement trajectory.  M = Rz(phi) Ry(theta) Rz(psi) row-major; shifts in pixels.
+struct LState { double M[9]; double sh[2]; double f, ha, hs; int particle; int pad; };
+
+__device__ inline void d_mat_mul3(const double *a, const double *b, double *c) {
+    double t[9];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+        double v = 0; for (int k = 0; k < 3; k++) v += a[i * 3 + k] * b[k * 3 + j];
+        t[i * 3 + j] = v;
+    }
+    for (int i = 0; i < 9; i++) c[i] = t[i];
+}
+
+__device__ inline void d_euler(double psi, double theta, double phi, double *M) {
+    const double d2r = 3.14159265358979323846 / 180.0;
+    double cps = cos(psi * d2r), sps = sin(psi * d2r), cth = cos(theta * d2r), sth = sin(theta * d2r), cph = cos(phi * d2r), sph = sin(phi * d2r);
+    M[0] = cph * cth * cps - sph * sps; M[1] = -cph * cth * sps - sph * cps; M[2] = cph * sth;
+    M[3] = sph * cth * cps + cph * sps; M[4] = -sph * cth * sps + cph * cps; M[5] = sph * sth;
+    M[6] = -sth * cps;                  M[7] = sth * sps;                    M[8] = cth;
+}
+
+__device__ inline void d_angles(const double *M, double &psi, double &theta, double &phi) {
+    const double r2d = 180.0 / 3.14159265358979323846;
+    double ct = M[8] > 1 ? 1 : (M[8] < -1 ? -1 : M[8]);
+    double st = sqrt(M[2] * M[2] + M[5] * M[5]);
+    if (st > 1e-7) {
+        theta = atan2(st, ct) * r2d; phi = atan2(M[5], M[2]) * r2d; psi = atan2(M[7], -M[6]) * r2d;
+    } else {
+        theta = ct > 0 ? 0.0 : 180.0; phi = 0.0;
+        psi = (ct > 0 ? atan2(M[3], M[0]) : atan2(-M[3], -M[0])) * r2d;
+    }
+    if (psi < 0) psi += 360;
+    if (phi < 0) phi += 360;
+}
+
+// which: 0 = in-plane (psi), 1 / 2 = tilt about image x / y when tilt_frame, else theta / phi Euler steps
+__device__ inline void d_rot_step(const double *M, int which, int tilt_frame, double hdeg, double *out) {
+    double h = hdeg * 3.14159265358979323846 / 180.0, c = cos(h), s = sin(h);
+    if (which == 0) { double r[9] = { c, -s, 0, s, c, 0, 0, 0, 1 }; d_mat_mul3(M, r, out); return; }
+    if (tilt_frame) {
+        if (which == 1) { double r[9] = { 1, 0, 0, 0, c, -s, 0, s, c }; d_mat_mul3(M, r, out); }
+        else { double r[9] = { c, 0, s, 0, 1, 0, -s, 0, c }; d_mat_mul3(M, r, out); }
+        return;
+    }
+    if (which == 2) { double r[9] = { c, -s, 0, s, c, 0, 0, 0, 1 }; d_mat_mul3(r, M, out); return; }
+    double psi, th, ph; d_angles(M, psi, th, ph);
+    double cp = cos(ph * 3.14159265358979323846 / 180.0), sp = sin(ph * 3.14159265358979323846 / 180.0);
+    double rz[9] = { cp, -sp, 0, sp, cp, 0, 0, 0, 1 }, rzt[9] = { cp, sp, 0, -sp, cp, 0, 0, 0, 1 }, ry[9] = { c, 0, s, 0, 1, 0, -s, 0, c };
+    double T[9], L[9];
+    d_mat_mul3(rz, ry, T); d_mat_mul3(T, rzt, L); d_mat_mul3(L, M, out);
+}
+
+struct LocalP {
+    CubeView cv; const uint32_t *samples; const float2 *Il; const float *cw;
+    int S_pad, S_used, nrings, N;
+    float rmax2, rlo2, ring_signed;
+    LState *states; int T, rescore; int en[5];
+};
+
+constexpr int kMaxCand = 11;
+
+// Block = one trajectory, 256 threads.  A compass iteration scores up to 10 neighbouring poses in one
+// sweep over the ring-ordered samples (image value and CTF weight loaded once per sample), then one
+// trial pose.  Ring sums: 16-lane shuffle reduction (a 16-lane group never straddles a ring), then
+// one LDS atomic per group.
+__global__ void __launch_bounds__(256) k_local(LocalP P) {
+    __shared__ float cand[kMaxCand][8];
+    __shared__ float ringA[kMaxCand][260];
+    __shared__ float sumB[kMaxCand];
+    __shared__ float sumC;
+    __shared__ double score[kMaxCand];
+    __shared__ LState st;
+    __shared__ double sfp[5], sfm[5], sd[5], sMt[9], sshq[2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid == 0) st = P.states[blockIdx.x];
+    __syncthreads();
+    const int part = st.particle;
+    const float2 *Il = P.Il + (size_t)part * P.S_pad;
+    const float *cw = P.cw + (size_t)part * P.S_pad;
+    const float invN = 1.0f / (float)P.N;
+    const int tilt = P.en[1] && P.en[2];
+
+    auto evaluate = [&](int ncand) {
+        for (int i = tid; i < ncand * 260; i += 256) (&ringA[0][0])[i] = 0.f;
+        if (tid < kMaxCand) sumB[tid] = 0.f;
+        if (tid == 0) sumC = 0.f;
+        __syncthreads();
+        float accC = 0.f;
+        for (int s0 = 0; s0 < P.S_used; s0 += 256) {
+            const int s = s0 + tid;
+            int kx = 0, ky = 0, al = 0, ring = 0;
+            float2 iv = make_float2(0.f, 0.f); float c = 0.f;
+            if (s < P.S_used) {
+                unpack_sample(P.samples[s], kx, ky, al, ring);
+                float k2 = (float)(kx * kx + ky * ky);
+                if (!(k2 < P.rmax2 && k2 >= P.rlo2)) al = 0;
+                iv = Il[s]; c = cw[s];
+            }
+            const float fal = (float)al, fkx = (float)kx, fky = (float)ky;
+            accC += fal * (iv.x * iv.x + iv.y * iv.y);
+            for (int q = 0; q < ncand; q++) {
+                const float *m = cand[q];
+                float2 pv = sample_cube(P.cv, m[0] * fkx + m[1] * fky, m[2] * fkx + m[3] * fky, m[4] * fkx + m[5] * fky);
+                float rev = -(fkx * m[6] + fky * m[7]) * invN;     // phase in revolutions
+                rev -= floorf(rev);
+                float sn = __sinf(6.283185307179586f * rev), cs = __cosf(6.283185307179586f * rev);
+                float mr = c * (pv.x * cs - pv.y * sn), mi = c * (pv.x * sn + pv.y * cs);
+                float av = fal * (iv.x * mr + iv.y * mi);
+                float bv = fal * (mr * mr + mi * mi);
+                av = group16_sum(av);
+                bv = group16_sum(bv);
+                if ((lane & 15) == 0) { atomicAdd(&ringA[q][ring], av); atomicAdd(&sumB[q], bv); }
+            }
+        }
+        accC = wave_sum(accC);
+        if (lane == 0) atomicAdd(&sumC, accC);
+        __syncthreads();
+        if (tid < ncand) {
+            double sa = 0;
+            for (int b = 0; b < P.nrings; b++) { float a = ringA[tid][b]; sa += ((float)b <= P.ring_signed) ? (double)a : fabs((double)a); }
+            double sb = sumB[tid], sc = sumC;
+            score[tid] = (sb > 0 && sc > 0) ? sa / sqrt(sb * sc) : 0.0;
+        }
+        __syncthreads();
+    };
+    auto set_cand = [&](int q, const double *M, const double *sh) {
+        cand[q][0] = (float)M[0]; cand[q][1] = (float)M[1]; cand[q][2] = (float)M[3]; cand[q][3] = (float)M[4];
+        cand[q][4] = (float)M[6]; cand[q][5] = (float)M[7]; cand[q][6] = (float)sh[0]; cand[q][7] = (float)sh[1];
+    };
+
+    if (P.rescore) {
+        if (tid == 0) set_cand(0, st.M, st.sh);
+        __syncthreads();
+        evaluate(1);
+        if (tid == 0) st.f = score[0];
+        __syncthreads();
+    }
+    for (int it = 0; it < P.T; it++) {
+        // ---- neighbours: candidate 2i = +h on parameter i, 2i+1 = -h
+        int ncand = 0;
+        if (tid == 0) {
+            int q = 0;
+            for (int i = 0; i < 5; i++) {
+                if (!P.en[i]) continue;
+                double h = i < 3 ? st.ha : st.hs;
+                for (int sg = 0; sg < 2; sg++) {
+                    double Mq[9], shq[2] = { st.sh[0], st.sh[1] };
+                    for (int k = 0; k < 9; k++) Mq[k] = st.M[k];
+                    double hh = sg ? -h : h;
+                    if (i < 3) d_rot_step(st.M, i, tilt, hh, Mq); else shq[i - 3] += hh;
+                    set_cand(q++, Mq, shq);
+                }
+            }
+        }
+        for (int i = 0; i < 5; i++) ncand += P.en[i] ? 2 : 0;
+        __syncthreads();
+        if (ncand > 0) {
+            evaluate(ncand);
+            if (tid == 0) {
+                int q = 0;
+                for (int i = 0; i < 5; i++) {
+                    sd[i] = 0; sfp[i] = sfm[i] = -1e300;
+                    if (!P.en[i]) continue;
+                    double h = i < 3 ? st.ha : st.hs;
+                    sfp[i] = score[q]; sfm[i] = score[q + 1]; q += 2;
+                    double den = 2.0 * st.f - sfp[i] - sfm[i];
+                    if (den > 1e-12) {
+                        double t = 0.5 * h * (sfp[i] - sfm[i]) / den;
+                        sd[i] = t > h ? h : (t < -h ? -h : t);
+                    } else {
+                        double best = sfp[i] > sfm[i] ? sfp[i] : sfm[i];
+                        sd[i] = best > st.f ? (sfp[i] > sfm[i] ? h : -h) : 0.0;
+                    }
+                }
+                double T9[9];
+                for (int k = 0; k < 9; k++) sMt[k] = st.M[k];
+                for (int i = 0; i < 3; i++) if (P.en[i] && sd[i] != 0) { d_rot_step(sMt, i, tilt, sd[i], T9); for (int k = 0; k < 9; k++) sMt[k] = T9[k]; }
+                sshq[0] = st.sh[0] + sd[3]; sshq[1] = st.sh[1] + sd[4];
+                set_cand(0, sMt, sshq);
+            }
+            __syncthreads();
+            evaluate(1);
+            if (tid == 0) {
+                double ft = score[0];
+                int bi = -1, bs = 0; double fb = st.f;
+                for (int i = 0; i < 5; i++) {
+                    if (!P.en[i]) continue;
+                    if (sfp[i] > fb) { fb = sfp[i]; bi = i; bs = 1; }
+                    if (sfm[i] > fb) { fb = sfm[i]; bi = i; bs = -1; }
+                }
+                if (ft > st.f && ft >= fb) {
+                    for (int k = 0; k < 9; k++) st.M[k] = sMt[k];
+                    st.sh[0] = sshq[0]; st.sh[1] = sshq[1]; st.f = ft;
+                } else if (bi >= 0) {
+                    if (bi < 3) { double T9[9]; d_rot_step(st.M, bi, tilt, bs * st.ha, T9); for (int k = 0; k < 9; k++) st.M[k] = T9[k]; }
+                    else st.sh[bi - 3] += bs * st.hs;
+                    st.f = fb;
+                }
+            }
+        }
+        if (tid == 0) { st.ha *= 0.5; st.hs *= 0.5; }
+        __syncthreads();
+    }
+    if (tid == 0) P.states[blockIdx.x] = st;
+}
+
+// states from global-search hits: one thread per (particle, hit)
+__global__ void k_states_from_hits(const Hit *hits, LState *states, int n, int K, const double *dir_theta,
+                                   const double *dir_phi, int n_psi, double dpsi, int step, double ha0, double hs0) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * K) return;
+    Hit h = hits[i];
+    LState s;
+    int dir = h.orient / n_psi, k = h.orient - dir * n_psi;
+    d_euler(k * dpsi, dir_theta[dir], dir_phi[dir], s.M);
+    s.sh[0] = (double)(h.sx * step); s.sh[1] = (double)(h.sy * step);
+    s.f = h.cc; s.ha = ha0; s.hs = hs0; s.particle = i / K; s.pad = 0;
+    states[i] = s;
+}
+
+__global__ void k_states_from_rows(const double *rows, LState *states, int n, double a, double ha0, double hs0) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double *r = rows + (size_t)i * PPM_NCOL;
+    LState s;
+    d_euler(r[PPM_PSI], r[PPM_THETA], r[PPM_PHI], s.M);
+    s.sh[0] = r[PPM_XSHIFT] / a; s.sh[1] = r[PPM_YSHIFT] / a;
+    s.f = 0; s.ha = ha0; s.hs = hs0; s.particle = i; s.pad = 0;
+    states[i] = s;
+}
+
+// best of K trajectories per particle (first wins ties)
+__global__ void k_select_best(const LState *in, LState *out, int n, int K) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int b = 0;
+    for (int k = 1; k < K; k++) if (in[(size_t)i * K + k].f > in[(size_t)i * K + b].f) b = k;
+    out[i] = in[(size_t)i * K + b];
+}
+
+__global__ void k_rows_out(const LState *states, const double *rows_in, double *rows_out, int n, double a,
+                           double r_hi, double r_lo) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const LState &s = states[i];
+    double *o = rows_out + (size_t)i * PPM_NCOL;
+    const double *r = rows_in + (size_t)i * PPM_NCOL;
+    for (int c = 0; c < PPM_NCOL; c++) o[c] = r[c];
+    double psi, th, ph; d_angles(s.M, psi, th, ph);
+    o[PPM_PSI] = psi; o[PPM_THETA] = th; o[PPM_PHI] = ph;
+    o[PPM_XSHIFT] = s.sh[0] * a; o[PPM_YSHIFT] = s.sh[1] * a;
+    double cc = s.f, res = 1.0 - cc * cc; if (res < 1e-6) res = 1e-6;
+    o[PPM_SCORE] = 100.0 * cc;
+    o[PPM_SIGMA] = sqrt(res);
+    o[PPM_LOGP] = -0.5 * (3.14159265358979323846 * 0.5 * (r_hi * r_hi - r_lo * r_lo)) * log(res);
+}
+
+// ---------------------------------------------------------------------------------- Fourier insertion
+struct InsertP {
+    const float2 *band; const double *rows; const float *symops; int nsym;
+    float *acc;   // [2][N][N][N/2+1][3]
+    int N, B, W, H, n_img;
+    float r2, a, bfac, score_avg, score_thr;
+    int split_by_pind;
+    unsigned long long *counts;  // [2]
+};
+
+// grid: (ceil(H*W/256), n_img).  Thread = one Fourier sample of one particle; 8 taps x 3 float atomics
+// per symmetry operator.  Voxel layout {re, im, weight} keeps a tap's three adds in one 12-byte cell.
+__global__ void __launch_bounds__(256) k_insert(InsertP P) {
+    const int p = blockIdx.y, N = P.N, B = P.B, W = P.W;
+    const double *row = P.rows + (size_t)p * PPM_NCOL;
+    const double occ = row[PPM_OCC], scr = row[PPM_SCORE];
+    if (!(occ > 0) || scr < (double)P.score_thr) return;          // uniform over the block
+    long key = P.split_by_pind ? (long)row[PPM_PIND] : (long)row[PPM_POS];
+    const int h = (int)(((key % 2) + 2) % 2);
+    __shared__ CtfP ctf; __shared__ float m_s[6]; __shared__ float sh_s[2];
+    if (threadIdx.x == 0) {
+        ctf = ctf_from_row(row, N, (double)P.a);
+        double M[9]; d_euler(row[PPM_PSI], row[PPM_THETA], row[PPM_PHI], M);
+        m_s[0] = (float)M[0]; m_s[1] = (float)M[1]; m_s[2] = (float)M[3]; m_s[3] = (float)M[4]; m_s[4] = (float)M[6]; m_s[5] = (float)M[7];
+        sh_s[0] = (float)(row[PPM_XSHIFT] / (double)P.a); sh_s[1] = (float)(row[PPM_YSHIFT] / (double)P.a);
+        if (blockIdx.x == 0) atomicAdd(&P.counts[h], 1ull);
+    }
+    __syncthreads();
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P.H * W) return;
+    const int kx = idx % W, ky = idx / W - B;
+    const float k2 = (float)(kx * kx + ky * ky);
+    if (!(k2 < P.r2) || k2 == 0.f) return;
+    const float sx = sh_s[0], sy = sh_s[1];
+    const float cv = ctf_eval(ctf, kx, ky);
+    float w = (float)(occ / 100.0);
+    if (P.bfac != 0.f) w *= expf(-0.25f * P.bfac * (P.score_avg - (float)scr) * k2 * ctf.inv_na2);
+    float rev = (kx * sx + ky * sy) / (float)N; rev -= floorf(rev);
+    float sn = __sinf(6.283185307179586f * rev), cs = __cosf(6.283185307179586f * rev);
+    const float2 iv = P.band[((size_t)p * P.H + (ky + B)) * W + kx];
+    const float vr = w * cv * (iv.x * cs - iv.y * sn), vi = w * cv * (iv.x * sn + iv.y * cs), vw = w * cv * cv;
+    const float X0 = m_s[0] * kx + m_s[1] * ky, Y0 = m_s[2] * kx + m_s[3] * ky, Z0 = m_s[4] * kx + m_s[5] * ky;
+    const size_t NX = N / 2 + 1;
+    float *A = P.acc + (size_t)h * N * N * NX * 3;
+    for (int s = 0; s < P.nsym; s++) {
+        const float *S = P.symops + s * 9;
+        float X = S[0] * X0 + S[1] * Y0 + S[2] * Z0, Y = S[3] * X0 + S[4] * Y0 + S[5] * Z0, Z = S[6] * X0 + S[7] * Y0 + S[8] * Z0;
+        float ui = vi;
+        if (X < 0.f) { X = -X; Y = -Y; Z = -Z; ui = -ui; }
+        float xf = floorf(X), yf = floorf(Y), zf = floorf(Z);
+        float fx = X - xf, fy = Y - yf, fz = Z - zf;
+        int x0 = (int)xf, y0 = (int)yf + N / 2, z0 = (int)zf + N / 2;
+#pragma unroll
+        for (int dz = 0; dz < 2; dz++)
+#pragma unroll
+            for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+                for (int dx = 0; dx < 2; dx++) {
+                    int xi = x0 + dx, yi = y0 + dy, zi = z0 + dz;
+                    if (xi > N / 2 || yi < 0 || yi >= N || zi < 0 || zi >= N) continue;
+                    float wt = (dx ? fx : 1.f - fx) * (dy ? fy : 1.f - fy) * (dz ? fz : 1.f - fz);
+                    float *v = A + (((size_t)zi * N + yi) * NX + xi) * 3;
+                    atomicAdd(v, wt * vr); atomicAdd(v + 1, wt * ui); atomicAdd(v + 2, wt * vw);
+                }
+    }
+}
+
+// ---------------------------------------------------------------------------------- finalisation
+// kx = 0 plane: fold Friedel mates together (reads `src`, writes `dst`)
+__global__ void k_fold_plane(const float *__restrict__ src, float *__restrict__ dst, int N) {
+    size_t NX = N / 2 + 1, half_sz = (size_t)N * N * NX * 3;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)2 * N * N) return;
+    int h = (int)(i / ((size_t)N * N)); int r = (int)(i % ((size_t)N * N));
+    int yi = r % N, zi = r / N, y = yi - N / 2, z = zi - N / 2;
+    if (y == -N / 2 || z == -N / 2) return;
+    const float *m = src + h * half_sz + (((size_t)(-z + N / 2) * N + (-y + N / 2)) * NX) * 3;
+    const float *v = src + h * half_sz + (((size_t)zi * N + yi) * NX) * 3;
+    float *o = dst + h * half_sz + (((size_t)zi * N + yi) * NX) * 3;
+    o[0] = v[0] + m[0]; o[1] = v[1] - m[1]; o[2] = v[2] + m[2];
+}
+
+// pass 1: shell sums of the weights.  sums: [4][ns] = den1, den2, count, den1+den2
+__global__ void k_shell_den(const float *__restrict__ acc, double *sums, int N) {
+    size_t NX = N / 2 + 1, tot = (size_t)N * N * NX, half_sz = tot * 3;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= tot) return;
+    int x = (int)(i % NX), y = (int)((i / NX) % N) - N / 2, z = (int)(i / (NX * N)) - N / 2;
+    int ns = N / 2, b = (int)floorf(sqrtf((float)(x * x + y * y + z * z)) + 0.5f);
+    if (b >= ns) return;
+    double al = x == 0 ? 1.0 : 2.0;
+    double d1 = acc[i * 3 + 2], d2 = acc[half_sz + i * 3 + 2];
+    atomicAdd(&sums[b], al * d1); atomicAdd(&sums[ns + b], al * d2); atomicAdd(&sums[2 * ns + b], al); atomicAdd(&sums[3 * ns + b], al * (d1 + d2));
+}
+
+// pass 2: FSC sums between the two halves.  fsc: [3][ns] = c12, c11, c22
+__global__ void k_shell_fsc(const float *__restrict__ acc, const double *sums, double *fsc, int N) {
+    size_t NX = N / 2 + 1, tot = (size_t)N * N * NX, half_sz = tot * 3;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= tot) return;
+    int x = (int)(i % NX), y = (int)((i / NX) % N) - N / 2, z = (int)(i / (NX * N)) - N / 2;
+    int ns = N / 2, b = (int)floorf(sqrtf((float)(x * x + y * y + z * z)) + 0.5f);
+    if (b >= ns) return;
+    double cnt = sums[2 * ns + b];
+    double e1 = 1e-3 * sums[b] / cnt + 1e-20, e2 = 1e-3 * sums[ns + b] / cnt + 1e-20;
+    double d1 = acc[i * 3 + 2] + e1, d2 = acc[half_sz + i * 3 + 2] + e2;
+    double ar = acc[i * 3] / d1, ai = acc[i * 3 + 1] / d1, br = acc[half_sz + i * 3] / d2, bi = acc[half_sz + i * 3 + 1] / d2;
+    double al = x == 0 ? 1.0 : 2.0;
+    atomicAdd(&fsc[b], al * (ar * br + ai * bi)); atomicAdd(&fsc[ns + b], al * (ar * ar + ai * ai)); atomicAdd(&fsc[2 * ns + b], al * (br * br + bi * bi));
+}
+
+// Wiener division into a full N^3 complex spectrum in FFT order (which: 0/1 = half maps, 2 = sum)
+__global__ void k_wiener(const float *__restrict__ acc, const double *kappa, float2 *f, int N, int which) {
+    size_t NX = N / 2 + 1, tot = (size_t)N * N * NX, half_sz = tot * 3;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= tot) return;
+    int x = (int)(i % NX), y = (int)((i / NX) % N) - N / 2, z = (int)(i / (NX * N)) - N / 2;
+    int ns = N / 2, b = (int)floorf(sqrtf((float)(x * x + y * y + z * z)) + 0.5f);
+    if (b >= ns) return;
+    double nr, ni, dn;
+    if (which < 2) { nr = acc[which * half_sz + i * 3]; ni = acc[which * half_sz + i * 3 + 1]; dn = acc[which * half_sz + i * 3 + 2]; }
+    else { nr = (double)acc[i * 3] + acc[half_sz + i * 3]; ni = (double)acc[i * 3 + 1] + acc[half_sz + i * 3 + 1]; dn = (double)acc[i * 3 + 2] + acc[half_sz + i * 3 + 2]; }
+    double d = dn + kappa[b], sg = ((x + y + z) & 1) ? -1.0 : 1.0;
+    float vr = (float)(sg * nr / d), vi = (float)(sg * ni / d);
+    int ix = x % N, iy = (y + N) % N, iz = (z + N) % N;
+    f[((size_t)iz * N + iy) * N + ix] = make_float2(vr, vi);
+    if (x > 0 && x < N / 2) f[((size_t)((N - iz) % N) * N + ((N - iy) % N)) * N + (N - ix)] = make_float2(vr, -vi);
+}
+
+__global__ void k_map_post(const float2 *__restrict__ f, float *__restrict__ out, int N, float rout, float rin, float fo) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, n3 = (size_t)N * N * N;
+    if (i >= n3) return;
+    int x = (int)(i % N), y = (int)((i / N) % N), z = (int)(i / ((size_t)N * N));
+    float dx = (float)(x - N / 2), dy = (float)(y - N / 2), dz = (float)(z - N / 2);
+    float g3 = 1.f, t[3] = { dx / N, dy / N, dz / N };
+#pragma unroll
+    for (int q = 0; q < 3; q++) { float u = kPiF * t[q], sv = fabsf(u) < 1e-6f ? 1.f : sinf(u) / u; g3 *= sv * sv; }
+    float rho = sqrtf(dx * dx + dy * dy + dz * dz), m = 1.f;
+    if (rout > 0.f) {
+        if (rho >= rout + 0.5f * fo) m = 0.f;
+        else if (rho > rout - 0.5f * fo) m = 0.5f * (1.f + cosf(kPiF * (rho - rout + 0.5f * fo) / fo));
+    }
+    if (rin > 0.f && rho < rin) m = 0.f;
+    out[i] = f[i].x / ((float)N * (float)N) / g3 * m;
+}
+
+__global__ void k_axpy(float *__restrict__ y, const float *__restrict__ x, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] += x[i];
+}
+
+}  // namespace ppm

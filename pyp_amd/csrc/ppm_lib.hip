@@ -1,0 +1,616 @@
+// ppm_lib.hip — C-ABI entry points of libpypmatch.so (include/ppm.h) for MI355X (gfx950).
+// Host glue only: workspace management, launch sequencing on one HIP stream, event timing.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/ppm.h"
+#include "ppm_geom.h"
+#include "ppm_kernels2.h"
+
+using namespace ppm;
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string &msg) { g_err = "ERROR: " + msg; return code; }
+
+#define HIPCHK(call)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            g_err = std::string("ERROR: HIP: ") + hipGetErrorString(e_) + " at " #call;        \
+            return -5;                                                                        \
+        }                                                                                     \
+    } while (0)
+#define HIPCHKP(call)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            g_err = std::string("ERROR: HIP: ") + hipGetErrorString(e_) + " at " #call;        \
+            return nullptr;                                                                   \
+        }                                                                                     \
+    } while (0)
+
+struct Ctx {
+    bool inited = false;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    float2 *tw[10] = { nullptr };   // tw[m]: table for n = 2^m, m = 1..9
+    bool prof_on = false;
+    double prof_ms[PPM_K_COUNT] = { 0 };
+    long prof_n[PPM_K_COUNT] = { 0 };
+    struct Pending { int id; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> pool;
+} g;
+
+hipEvent_t ev_get() {
+    if (!g.pool.empty()) { hipEvent_t e = g.pool.back(); g.pool.pop_back(); return e; }
+    hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+void prof_flush() {
+    for (auto &p : g.pending) {
+        (void)hipEventSynchronize(p.b);
+        float ms = 0; (void)hipEventElapsedTime(&ms, p.a, p.b);
+        g.prof_ms[p.id] += ms; g.prof_n[p.id] += 1;
+        g.pool.push_back(p.a); g.pool.push_back(p.b);
+    }
+    g.pending.clear();
+}
+struct ProfScope {
+    int id; hipEvent_t a = nullptr;
+    explicit ProfScope(int id_) : id(id_) { if (g.prof_on) { a = ev_get(); (void)hipEventRecord(a, g.stream); } }
+    ~ProfScope() { if (a) { hipEvent_t b = ev_get(); (void)hipEventRecord(b, g.stream); g.pending.push_back({ id, a, b }); } }
+};
+
+int ilog2(int n) { int l = 0; while ((1 << l) < n) l++; return l; }
+
+int ensure_tw(int n) {
+    int m = ilog2(n);
+    if (m < 1 || m > 9) return fail(-22, "FFT length out of range");
+    if (g.tw[m]) return 0;
+    std::vector<float2> t(n / 2);
+    for (int k = 0; k < n / 2; k++) t[k] = make_float2((float)std::cos(2.0 * kPi * k / n), (float)std::sin(2.0 * kPi * k / n));
+    HIPCHK(hipMalloc(&g.tw[m], sizeof(float2) * (n / 2)));
+    HIPCHK(hipMemcpy(g.tw[m], t.data(), sizeof(float2) * (n / 2), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// 3-D FFT of an n^3 complex array in place (three strided passes through LDS)
+int fft3d(float2 *d, int n, bool inverse) {
+    if (int rc = ensure_tw(n)) return rc;
+    int logn = ilog2(n);
+    const int L = std::max(1, std::min(16, 8192 / n));
+    long nlines = (long)n * n;
+    for (int pass = 0; pass < 3; pass++) {
+        FftLinesP P;
+        P.data = d; P.tw = g.tw[logn]; P.n = n; P.logn = logn; P.inverse = inverse ? 1 : 0; P.L = L; P.nlines = nlines;
+        if (pass == 0) { P.inner = nlines; P.inner_stride = n; P.outer_stride = 0; P.elem_stride = 1; P.line_major = 0; }
+        else if (pass == 1) { P.inner = n; P.inner_stride = 1; P.outer_stride = (long)n * n; P.elem_stride = n; P.line_major = 1; }
+        else { P.inner = nlines; P.inner_stride = 1; P.outer_stride = 0; P.elem_stride = (long)n * n; P.line_major = 1; }
+        unsigned blocks = (unsigned)((nlines + L - 1) / L);
+        hipLaunchKernelGGL(k_fft_lines, dim3(blocks), dim3(256), (size_t)L * n * sizeof(float2), g.stream, P);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr; size_t cap = 0;
+    int ensure(size_t n) {
+        if (n <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        HIPCHK(hipMalloc(&p, n * sizeof(T)));
+        cap = n;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+}  // namespace
+
+struct ppm_ref {
+    int N = 0, B = 0, CX = 0, CY = 0;
+    float2 *cube = nullptr;
+    // workspaces (grown on demand, reused across calls)
+    DevBuf<double> rows_in, rows_out, dir_theta, dir_phi;
+    DevBuf<float> images, wring, cw, C2, nI, cc, mats;
+    DevBuf<float2> band, Il, Wp, bank, twN;
+    DevBuf<int> sh;
+    DevBuf<uint32_t> samples;
+    DevBuf<Hit> hits;
+    DevBuf<LState> states, states2;
+    std::string bank_key;
+    long last_counts[4] = { 0, 0, 0, 0 };
+};
+
+struct ppm_accum {
+    int N = 0; float pixel = 1.f;
+    float *acc = nullptr; bool external = false;
+    std::vector<double> symops; int nsym = 1;
+    float *d_sym = nullptr;
+    unsigned long long *d_counts = nullptr;
+    long counts[2] = { 0, 0 };
+    DevBuf<double> rows; DevBuf<float> images; DevBuf<float2> band;
+};
+
+// ------------------------------------------------------------------------------ pre-processing launch
+static int launch_prep(const float *d_images, const double *d_rows, int n_img, const Geom &gm, float Rm_px, float fall_px,
+                       int normalize, int invert, int do_mask, int whiten, float2 *band, float *wring,
+                       const uint32_t *samples, int S_pad, float2 *Il, float *cw, float2 *Wp, float *C2, float *nI) {
+    if (int rc = ensure_tw(gm.N)) return rc;
+    PrepP P;
+    P.images = d_images; P.rows = d_rows; P.tw = g.tw[ilog2(gm.N)];
+    P.N = gm.N; P.logN = ilog2(gm.N); P.B = gm.B; P.W = gm.W; P.H = gm.H;
+    P.r_hi2 = (float)(gm.r_hi * gm.r_hi); P.Rm = Rm_px; P.wfall = fall_px; P.a = (float)gm.a;
+    P.normalize = normalize; P.invert = invert; P.do_mask = do_mask; P.whiten = whiten;
+    P.nc = std::min(gm.W, (int)(139264 / ((gm.N + 1) * sizeof(float2))));
+    P.nchunks = (gm.W + P.nc - 1) / P.nc;
+    P.L = std::max(1, 2048 / gm.N);
+    P.band = band; P.wring = wring; P.samples = samples; P.S_pad = S_pad; P.Il = Il; P.cw = cw;
+    P.Wp = Wp; P.C2 = C2; P.nI = nI; P.Bs = gm.Bs; P.Hs = gm.Hs;
+    P.r_s2 = (float)(gm.r_s * gm.r_s); P.r_lo2 = (float)(gm.r_lo * gm.r_lo);
+    size_t lds = (size_t)P.nc * (gm.N + 1) * sizeof(float2) + (size_t)P.L * gm.N * sizeof(float2) + 2 * (gm.B + 2) * sizeof(float) + 16 + 16 * sizeof(double) + 8 * sizeof(float);
+    if (lds > 160 * 1024) return fail(-12, "pre-processing kernel needs more than 160 KB of LDS");
+    static bool attr_set = false;
+    if (!attr_set) { HIPCHK(hipFuncSetAttribute((const void *)k_prep, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
+    ProfScope ps(PPM_K_PREP);
+    hipLaunchKernelGGL(k_prep, dim3(n_img), dim3(256), lds, g.stream, P);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+template <int R>
+static int launch_global_r(const GlobP &P, int n_img, bool half, size_t lds) {
+    if (half) {
+        static bool set = false;
+        if (!set) { HIPCHK(hipFuncSetAttribute((const void *)k_global<R, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; }
+        hipLaunchKernelGGL((k_global<R, true>), dim3(n_img), dim3(global_threads(R)), lds, g.stream, P);
+    } else {
+        static bool set = false;
+        if (!set) { HIPCHK(hipFuncSetAttribute((const void *)k_global<R, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; }
+        hipLaunchKernelGGL((k_global<R, false>), dim3(n_img), dim3(global_threads(R)), lds, g.stream, P);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int launch_global(const GlobP &P, int n_img, bool half, int R) {
+    size_t lds = (size_t)P.Hs * 64 * (sizeof(float2) + sizeof(float));
+    if (lds < 1024) lds = 1024;
+    ProfScope ps(PPM_K_GLOBAL);
+    switch (R) {
+        case 1: return launch_global_r<1>(P, n_img, half, lds);
+        case 2: return launch_global_r<2>(P, n_img, half, lds);
+        case 3: return launch_global_r<3>(P, n_img, half, lds);
+        case 4: return launch_global_r<4>(P, n_img, half, lds);
+        case 5: return launch_global_r<5>(P, n_img, half, lds);
+        case 6: return launch_global_r<6>(P, n_img, half, lds);
+        case 7: return launch_global_r<7>(P, n_img, half, lds);
+        default: return launch_global_r<8>(P, n_img, half, lds);
+    }
+}
+
+
+extern "C" {
+
+const char *ppm_last_error(void) { return g_err.c_str(); }
+const char *ppm_version(void) { return "pypmatch 0.1 (gfx950)"; }
+
+int ppm_init(int device) {
+    if (g.inited && g.device == device) return 0;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(-19, "no HIP device visible; libpypmatch has no CPU path");
+    if (device < 0 || device >= count) return fail(-22, "device index out of range");
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
+        return fail(-19, std::string("device is ") + prop.gcnArchName + ", libpypmatch is built for gfx950 only");
+    if (!g.stream) HIPCHK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    g.device = device; g.inited = true;
+    return 0;
+}
+
+void ppm_profile_enable(int on) { g.prof_on = on != 0; }
+void ppm_profile_reset(void) { prof_flush(); for (int i = 0; i < PPM_K_COUNT; i++) { g.prof_ms[i] = 0; g.prof_n[i] = 0; } }
+int ppm_profile_get(int id, double *ms, long *n) {
+    if (id < 0 || id >= PPM_K_COUNT) return fail(-22, "bad kernel id");
+    prof_flush();
+    if (ms) *ms = g.prof_ms[id];
+    if (n) *n = g.prof_n[id];
+    return 0;
+}
+
+void *ppm_device_alloc(size_t bytes) { void *p = nullptr; if (hipMalloc(&p, bytes) != hipSuccess) { g_err = "ERROR: device allocation failed"; return nullptr; } return p; }
+void ppm_device_free(void *p) { if (p) (void)hipFree(p); }
+int ppm_device_upload(void *dst, const void *src, size_t bytes) { HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return 0; }
+int ppm_device_sync(void) { if (g.stream) HIPCHK(hipStreamSynchronize(g.stream)); HIPCHK(hipDeviceSynchronize()); return 0; }
+
+// ------------------------------------------------------------------------------ reference
+ppm_ref_t *ppm_reference_create(const float *vol, int n, float max_band_px) {
+    if (!g.inited) { fail(-1, "ppm_init has not been called"); return nullptr; }
+    if (!vol || !is_pow2(n) || n < 32 || n > 512 || !(max_band_px > 0)) { fail(-22, "reference volume must be a power-of-two cube (32..512) and the band positive"); return nullptr; }
+    if (max_band_px > n / 2) max_band_px = (float)(n / 2);
+    int B = (int)std::ceil(max_band_px) - 1;
+    size_t n3 = (size_t)n * n * n;
+    float *d_vol = nullptr; float2 *d_f = nullptr;
+    HIPCHKP(hipMalloc(&d_vol, n3 * sizeof(float)));
+    HIPCHKP(hipMalloc(&d_f, n3 * sizeof(float2)));
+    HIPCHKP(hipMemcpy(d_vol, vol, n3 * sizeof(float), hipMemcpyHostToDevice));
+    ppm_ref *r = new ppm_ref();
+    r->N = n; r->B = B; r->CX = B + 2; r->CY = 2 * B + 3;
+    size_t cube_n = (size_t)r->CX * r->CY * r->CY;
+    if (hipMalloc(&r->cube, cube_n * sizeof(float2)) != hipSuccess) { fail(-12, "out of device memory for the reference cube"); delete r; return nullptr; }
+    {
+        ProfScope ps(PPM_K_BANK);
+        hipLaunchKernelGGL(k_ref_load, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, g.stream, d_vol, d_f, n);
+        if (fft3d(d_f, n, false)) { delete r; return nullptr; }
+        hipLaunchKernelGGL(k_ref_crop, dim3((unsigned)((cube_n + 255) / 256)), dim3(256), 0, g.stream, d_f, r->cube, n, B, r->CX, r->CY);
+    }
+    HIPCHKP(hipStreamSynchronize(g.stream));
+    HIPCHKP(hipGetLastError());
+    (void)hipFree(d_vol); (void)hipFree(d_f);
+    return r;
+}
+
+void ppm_reference_destroy(ppm_ref_t *r) {
+    if (!r) return;
+    if (r->cube) (void)hipFree(r->cube);
+    r->rows_in.release(); r->rows_out.release(); r->dir_theta.release(); r->dir_phi.release();
+    r->images.release(); r->wring.release(); r->cw.release(); r->C2.release(); r->nI.release(); r->cc.release(); r->mats.release();
+    r->band.release(); r->Il.release(); r->Wp.release(); r->bank.release(); r->twN.release(); r->sh.release(); r->samples.release();
+    r->hits.release(); r->states.release(); r->states2.release();
+    delete r;
+}
+
+// ------------------------------------------------------------------------------ refine
+int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *images, int images_on_device,
+                     int n_img, const double *rows_in, double *rows_out) {
+    if (!g.inited) return fail(-1, "ppm_init has not been called");
+    if (!ref || !cfg || !images || !rows_in || !rows_out) return fail(-22, "null argument");
+    if (n_img <= 0) return 0;
+    Geom gm; std::string err;
+    if (!geom_init(gm, *cfg, err)) return fail(-22, err);
+    if (gm.N != ref->N) return fail(-22, "particle box differs from the reference box");
+    if (gm.B > ref->B) return fail(-22, "high-resolution limit exceeds the band the reference was prepared for");
+    if (cfg->global_search && gm.Bs + 1 > 64)
+        return fail(-22, "global search band wider than 64 Fourier pixels is not supported; lower the 'resolution limit for search'");
+    if (!cfg->global_search && !cfg->local_refine) { /* score only */ }
+    int K = cfg->top_hits > 0 ? cfg->top_hits : 20;
+    if (K > PPM_MAX_TOP_HITS) K = PPM_MAX_TOP_HITS;
+    if (K > gm.n_orient) K = gm.n_orient;
+    const int Tb = cfg->iters_hit > 0 ? cfg->iters_hit : 3, Tc = cfg->iters_final > 0 ? cfg->iters_final : 6;
+    const double fall = cfg->mask_falloff > 0 ? cfg->mask_falloff : 20.0;
+    const float fall_px = (float)(fall / gm.a), Rm_px = (float)(cfg->mask_radius / gm.a);
+    const bool sep_search = cfg->global_search && cfg->search_mask_radius > 0 && cfg->search_mask_radius != cfg->mask_radius;
+
+    SampleList sl; build_samples(gm, sl);
+    const int S_pad = (int)sl.packed.size();
+    const int nrings = gm.B + 2;
+    int ring_s = (int)std::ceil(gm.r_s); if (ring_s > gm.B + 1) ring_s = gm.B + 1;
+    const int S_search = sl.ring_off[ring_s];
+    if (int rc = ref->samples.ensure(S_pad)) return rc;
+    HIPCHK(hipMemcpyAsync(ref->samples.p, sl.packed.data(), S_pad * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
+
+    const size_t NN = (size_t)gm.N * gm.N, HW = (size_t)gm.H * gm.W, HS = (size_t)gm.Hs * 64;
+    const int nslices = gm.n_dir * gm.npsi_store;
+    // chunk so that the scratch stays well inside HBM
+    size_t per = NN * 4 + HW * 8 + (size_t)S_pad * 12 + 2 * PPM_NCOL * 8 + (gm.B + 2) * 4;
+    if (cfg->global_search) per += HS * 12 + (size_t)gm.n_orient * 8 + (size_t)K * (sizeof(Hit) + sizeof(LState)) + sizeof(LState);
+    int CH = (int)std::min<size_t>((size_t)n_img, std::max<size_t>(64, ((size_t)3 << 30) / per));
+    CH = std::min(CH, 8192);
+
+    if (int rc = ref->rows_in.ensure((size_t)CH * PPM_NCOL)) return rc;
+    if (int rc = ref->rows_out.ensure((size_t)CH * PPM_NCOL)) return rc;
+    if (!images_on_device) if (int rc = ref->images.ensure((size_t)CH * NN)) return rc;
+    if (int rc = ref->band.ensure((size_t)CH * HW)) return rc;
+    if (int rc = ref->wring.ensure((size_t)CH * (gm.B + 2))) return rc;
+    if (int rc = ref->Il.ensure((size_t)CH * S_pad)) return rc;
+    if (int rc = ref->cw.ensure((size_t)CH * S_pad)) return rc;
+    if (int rc = ref->states2.ensure(CH)) return rc;
+    CubeView cv; cv.cube = ref->cube; cv.CX = ref->CX; cv.CY = ref->CY; cv.off = ref->B + 1;
+
+    if (cfg->global_search) {
+        if (int rc = ref->Wp.ensure((size_t)CH * HS)) return rc;
+        if (int rc = ref->C2.ensure((size_t)CH * HS)) return rc;
+        if (int rc = ref->nI.ensure(CH)) return rc;
+        if (int rc = ref->cc.ensure((size_t)CH * gm.n_orient)) return rc;
+        if (int rc = ref->sh.ensure((size_t)CH * gm.n_orient)) return rc;
+        if (int rc = ref->hits.ensure((size_t)CH * K)) return rc;
+        if (int rc = ref->states.ensure((size_t)CH * K)) return rc;
+        // slice bank, twiddles and direction tables: rebuilt only when the grid / band changes
+        char key[160];
+        std::snprintf(key, sizeof(key), "%d/%.6f/%.6f/%d/%d", gm.N, gm.r_s, gm.dstep, gm.Ns, gm.npsi_store);
+        if (ref->bank_key != key) {
+            std::vector<float> mats((size_t)nslices * 6);
+            std::vector<double> dth(gm.n_dir), dph(gm.n_dir);
+            for (int d = 0; d < gm.n_dir; d++) {
+                grid_direction(gm, d, dth[d], dph[d]);
+                for (int k = 0; k < gm.npsi_store; k++) {
+                    double M[9]; euler_matrix(k * gm.dpsi, dth[d], dph[d], M);
+                    float *m = &mats[((size_t)d * gm.npsi_store + k) * 6];
+                    m[0] = (float)M[0]; m[1] = (float)M[1]; m[2] = (float)M[3]; m[3] = (float)M[4]; m[4] = (float)M[6]; m[5] = (float)M[7];
+                }
+            }
+            std::vector<float2> tw(gm.Ns);
+            for (int t = 0; t < gm.Ns; t++) tw[t] = make_float2((float)std::cos(2.0 * kPi * t / gm.Ns), (float)std::sin(2.0 * kPi * t / gm.Ns));
+            if (int rc = ref->mats.ensure(mats.size())) return rc;
+            if (int rc = ref->dir_theta.ensure(gm.n_dir)) return rc;
+            if (int rc = ref->dir_phi.ensure(gm.n_dir)) return rc;
+            if (int rc = ref->twN.ensure(gm.Ns)) return rc;
+            if (int rc = ref->bank.ensure((size_t)nslices * HS)) return rc;
+            HIPCHK(hipMemcpyAsync(ref->mats.p, mats.data(), mats.size() * sizeof(float), hipMemcpyHostToDevice, g.stream));
+            HIPCHK(hipMemcpyAsync(ref->dir_theta.p, dth.data(), dth.size() * sizeof(double), hipMemcpyHostToDevice, g.stream));
+            HIPCHK(hipMemcpyAsync(ref->dir_phi.p, dph.data(), dph.size() * sizeof(double), hipMemcpyHostToDevice, g.stream));
+            HIPCHK(hipMemcpyAsync(ref->twN.p, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice, g.stream));
+            BankP BP; BP.cv = cv; BP.mats = ref->mats.p; BP.bank = ref->bank.p; BP.nslices = nslices; BP.Bs = gm.Bs; BP.Hs = gm.Hs;
+            BP.r_s2 = (float)(gm.r_s * gm.r_s);
+            {
+                ProfScope ps(PPM_K_BANK);
+                size_t tot = (size_t)nslices * HS;
+                hipLaunchKernelGGL(k_bank, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, g.stream, BP);
+            }
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(g.stream));   // host vectors go out of scope
+            ref->bank_key = key;
+        }
+    }
+    HIPCHK(hipStreamSynchronize(g.stream));
+
+    LocalP LP;
+    LP.cv = cv; LP.samples = ref->samples.p; LP.Il = ref->Il.p; LP.cw = ref->cw.p; LP.S_pad = S_pad; LP.nrings = nrings; LP.N = gm.N;
+    LP.rlo2 = (float)(gm.r_lo * gm.r_lo); LP.ring_signed = (float)std::min(gm.ring_signed, 1e30);
+    LP.en[0] = cfg->refine_psi; LP.en[1] = cfg->refine_theta; LP.en[2] = cfg->refine_phi; LP.en[3] = cfg->refine_x; LP.en[4] = cfg->refine_y;
+
+    long n_local_evals = 0;
+    const int ncand = 2 * ((cfg->refine_psi != 0) + (cfg->refine_theta != 0) + (cfg->refine_phi != 0) + (cfg->refine_x != 0) + (cfg->refine_y != 0));
+    for (int c0 = 0; c0 < n_img; c0 += CH) {
+        const int nb = std::min(CH, n_img - c0);
+        HIPCHK(hipMemcpyAsync(ref->rows_in.p, rows_in + (size_t)c0 * PPM_NCOL, (size_t)nb * PPM_NCOL * sizeof(double), hipMemcpyHostToDevice, g.stream));
+        const float *d_img;
+        if (images_on_device) d_img = (const float *)images + (size_t)c0 * NN;
+        else {
+            HIPCHK(hipMemcpyAsync(ref->images.p, (const float *)images + (size_t)c0 * NN, (size_t)nb * NN * sizeof(float), hipMemcpyHostToDevice, g.stream));
+            d_img = ref->images.p;
+        }
+        // refinement spectra (+ search tables when the same mask serves both)
+        if (int rc = launch_prep(d_img, ref->rows_in.p, nb, gm, Rm_px, fall_px, cfg->normalize, cfg->invert, 1, 1, ref->band.p, ref->wring.p,
+                                 ref->samples.p, S_pad, ref->Il.p, ref->cw.p,
+                                 (cfg->global_search && !sep_search) ? ref->Wp.p : nullptr, ref->C2.p, ref->nI.p)) return rc;
+        if (sep_search)
+            if (int rc = launch_prep(d_img, ref->rows_in.p, nb, gm, (float)(cfg->search_mask_radius / gm.a), fall_px, cfg->normalize, cfg->invert, 1, 1,
+                                     ref->band.p, nullptr, nullptr, 0, nullptr, nullptr, ref->Wp.p, ref->C2.p, ref->nI.p)) return rc;
+        LState *final_states = ref->states2.p;
+        if (cfg->global_search) {
+            GlobP GP;
+            GP.bank = ref->bank.p; GP.Wp = ref->Wp.p; GP.C2 = ref->C2.p; GP.nI = ref->nI.p; GP.twN = ref->twN.p;
+            GP.cc = ref->cc.p; GP.sh = ref->sh.p; GP.hits = ref->hits.p;
+            GP.Bs = gm.Bs; GP.Hs = gm.Hs; GP.Ns = gm.Ns; GP.RSx = gm.RSx; GP.RSy = gm.RSy;
+            GP.n_dir = gm.n_dir; GP.n_psi = gm.n_psi; GP.npsi_store = gm.npsi_store; GP.n_orient = gm.n_orient; GP.K = K;
+            if (int rc = launch_global(GP, nb, gm.half != 0, std::max(gm.RSx, gm.RSy))) return rc;
+            {
+                ProfScope ps(PPM_K_TOPK);
+                hipLaunchKernelGGL(k_states_from_hits, dim3((nb * K + 255) / 256), dim3(256), 0, g.stream, ref->hits.p, ref->states.p, nb, K,
+                                   ref->dir_theta.p, ref->dir_phi.p, gm.n_psi, gm.dpsi, gm.step, 0.5 * gm.dstep, (double)gm.step);
+            }
+            if (cfg->local_refine) {
+                LP.states = ref->states.p; LP.T = Tb; LP.rescore = 1; LP.S_used = S_search; LP.rmax2 = (float)(gm.r_s * gm.r_s);
+                ProfScope ps(PPM_K_LOCAL);
+                hipLaunchKernelGGL(k_local, dim3(nb * K), dim3(256), 0, g.stream, LP);
+                n_local_evals += (long)K * (1 + (long)Tb * (ncand + 1));
+            }
+            {
+                ProfScope ps(PPM_K_TOPK);
+                hipLaunchKernelGGL(k_select_best, dim3((nb + 255) / 256), dim3(256), 0, g.stream, ref->states.p, ref->states2.p, nb, K);
+            }
+            if (cfg->local_refine) {
+                LP.states = ref->states2.p; LP.T = Tc; LP.rescore = 1; LP.S_used = S_pad; LP.rmax2 = (float)(gm.r_hi * gm.r_hi);
+                ProfScope ps(PPM_K_LOCAL);
+                hipLaunchKernelGGL(k_local, dim3(nb), dim3(256), 0, g.stream, LP);
+            }
+        } else {
+            double ha0 = cfg->local_angle_step > 0 ? cfg->local_angle_step : 2.5, hs0 = cfg->local_shift_step > 0 ? cfg->local_shift_step : 2.0;
+            hipLaunchKernelGGL(k_states_from_rows, dim3((nb + 255) / 256), dim3(256), 0, g.stream, ref->rows_in.p, ref->states2.p, nb, gm.a, ha0, hs0);
+            LP.states = ref->states2.p; LP.T = cfg->local_refine ? Tb + Tc : 0; LP.rescore = 1; LP.S_used = S_pad; LP.rmax2 = (float)(gm.r_hi * gm.r_hi);
+            ProfScope ps(PPM_K_LOCAL);
+            hipLaunchKernelGGL(k_local, dim3(nb), dim3(256), 0, g.stream, LP);
+        }
+        hipLaunchKernelGGL(k_rows_out, dim3((nb + 255) / 256), dim3(256), 0, g.stream, final_states, ref->rows_in.p, ref->rows_out.p, nb, gm.a, gm.r_hi, gm.r_lo);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(rows_out + (size_t)c0 * PPM_NCOL, ref->rows_out.p, (size_t)nb * PPM_NCOL * sizeof(double), hipMemcpyDeviceToHost, g.stream));
+        HIPCHK(hipStreamSynchronize(g.stream));
+    }
+    // evaluation counts per particle, for the roofline's algorithmic bytes
+    long nl;
+    if (cfg->global_search) nl = cfg->local_refine ? (long)K * (1 + (long)Tb * (ncand + 1)) + 1 + (long)Tc * (ncand + 1) : 0;
+    else nl = 1 + (cfg->local_refine ? (long)(Tb + Tc) * (ncand + 1) : 0);
+    ref->last_counts[0] = cfg->global_search ? gm.n_orient : 0;
+    ref->last_counts[1] = nl;
+    ref->last_counts[2] = (long)std::floor(kPi * gm.r_s * gm.r_s / 2);
+    ref->last_counts[3] = (long)std::floor(kPi * gm.r_hi * gm.r_hi / 2);
+    (void)n_local_evals;
+    return 0;
+}
+
+int ppm_refine_last_counts(ppm_ref_t *ref, long *n_global, long *n_local, long *samples_global, long *samples_local) {
+    if (!ref) return fail(-22, "null reference");
+    if (n_global) *n_global = ref->last_counts[0];
+    if (n_local) *n_local = ref->last_counts[1];
+    if (samples_global) *samples_global = ref->last_counts[2];
+    if (samples_local) *samples_local = ref->last_counts[3];
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ reconstruction
+size_t ppm_accum_floats(int box) { return (size_t)2 * box * box * (box / 2 + 1) * 3; }
+
+ppm_accum_t *ppm_accum_create(int box, float pixel_size, const char *symmetry, void *ext) {
+    if (!g.inited) { fail(-1, "ppm_init has not been called"); return nullptr; }
+    if (!is_pow2(box) || box < 32 || box > 512 || !(pixel_size > 0)) { fail(-22, "box must be a power of two in 32..512 and the pixel size positive"); return nullptr; }
+    ppm_accum *a = new ppm_accum();
+    a->N = box; a->pixel = pixel_size;
+    a->nsym = symmetry_ops(symmetry, a->symops);
+    if (a->nsym < 1) { fail(-22, std::string("unknown symmetry symbol '") + (symmetry ? symmetry : "") + "'"); delete a; return nullptr; }
+    size_t nf = ppm_accum_floats(box);
+    if (ext) { a->acc = (float *)ext; a->external = true; }
+    else {
+        if (hipMalloc(&a->acc, nf * sizeof(float)) != hipSuccess) { fail(-12, "out of device memory for the accumulators"); delete a; return nullptr; }
+        (void)hipMemset(a->acc, 0, nf * sizeof(float));
+    }
+    std::vector<float> s(a->symops.begin(), a->symops.end());
+    HIPCHKP(hipMalloc(&a->d_sym, s.size() * sizeof(float)));
+    HIPCHKP(hipMemcpy(a->d_sym, s.data(), s.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHKP(hipMalloc(&a->d_counts, 2 * sizeof(unsigned long long)));
+    HIPCHKP(hipMemset(a->d_counts, 0, 2 * sizeof(unsigned long long)));
+    return a;
+}
+
+void ppm_accum_destroy(ppm_accum_t *a) {
+    if (!a) return;
+    if (a->acc && !a->external) (void)hipFree(a->acc);
+    if (a->d_sym) (void)hipFree(a->d_sym);
+    if (a->d_counts) (void)hipFree(a->d_counts);
+    a->rows.release(); a->images.release(); a->band.release();
+    delete a;
+}
+
+int ppm_insert_batch(ppm_accum_t *a, const ppm_recon_cfg *cfg, const void *images, int images_on_device, int n_img, const double *rows) {
+    if (!g.inited) return fail(-1, "ppm_init has not been called");
+    if (!a || !cfg || !images || !rows) return fail(-22, "null argument");
+    if (cfg->box != a->N) return fail(-22, "box differs from the accumulator's");
+    if (n_img <= 0) return 0;
+    ppm_refine_cfg rc; std::memset(&rc, 0, sizeof(rc));
+    rc.box = a->N; rc.pixel_size = cfg->pixel_size; rc.res_high = cfg->res_limit > 0 ? cfg->res_limit : 2.f * cfg->pixel_size; rc.angular_step = 15.f;
+    Geom gm; std::string err;
+    if (!geom_init(gm, rc, err)) return fail(-22, err);
+    const size_t NN = (size_t)gm.N * gm.N, HW = (size_t)gm.H * gm.W;
+    int CH = (int)std::min<size_t>((size_t)n_img, std::max<size_t>(32, ((size_t)2 << 30) / (NN * 4 + HW * 8)));
+    if (int r = a->rows.ensure((size_t)CH * PPM_NCOL)) return r;
+    if (!images_on_device) if (int r = a->images.ensure((size_t)CH * NN)) return r;
+    if (int r = a->band.ensure((size_t)CH * HW)) return r;
+    for (int c0 = 0; c0 < n_img; c0 += CH) {
+        const int nb = std::min(CH, n_img - c0);
+        HIPCHK(hipMemcpyAsync(a->rows.p, rows + (size_t)c0 * PPM_NCOL, (size_t)nb * PPM_NCOL * sizeof(double), hipMemcpyHostToDevice, g.stream));
+        const float *d_img;
+        if (images_on_device) d_img = (const float *)images + (size_t)c0 * NN;
+        else {
+            HIPCHK(hipMemcpyAsync(a->images.p, (const float *)images + (size_t)c0 * NN, (size_t)nb * NN * sizeof(float), hipMemcpyHostToDevice, g.stream));
+            d_img = a->images.p;
+        }
+        if (int r = launch_prep(d_img, a->rows.p, nb, gm, cfg->mask_radius / cfg->pixel_size, 1.f, cfg->normalize, cfg->invert, 0, 0,
+                                a->band.p, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr)) return r;
+        InsertP IP;
+        IP.band = a->band.p; IP.rows = a->rows.p; IP.symops = a->d_sym; IP.nsym = a->nsym; IP.acc = a->acc;
+        IP.N = gm.N; IP.B = gm.B; IP.W = gm.W; IP.H = gm.H; IP.n_img = nb;
+        IP.r2 = (float)(gm.r_hi * gm.r_hi); IP.a = cfg->pixel_size; IP.bfac = cfg->score_weight_bfactor; IP.score_avg = cfg->score_average;
+        IP.score_thr = cfg->score_threshold; IP.split_by_pind = cfg->split_by_pind; IP.counts = a->d_counts;
+        {
+            ProfScope ps(PPM_K_INSERT);
+            hipLaunchKernelGGL(k_insert, dim3((unsigned)((HW + 255) / 256), nb), dim3(256), 0, g.stream, IP);
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(g.stream));
+    }
+    unsigned long long c[2];
+    HIPCHK(hipMemcpy(c, a->d_counts, sizeof(c), hipMemcpyDeviceToHost));
+    a->counts[0] = (long)c[0]; a->counts[1] = (long)c[1];
+    return 0;
+}
+
+long ppm_accum_count(ppm_accum_t *a, int half) { return (a && (half == 0 || half == 1)) ? a->counts[half] : -1; }
+void ppm_accum_set_count(ppm_accum_t *a, int half, long count) {
+    if (!a || (half != 0 && half != 1)) return;
+    a->counts[half] = count;
+    unsigned long long c = (unsigned long long)count;
+    (void)hipMemcpy(a->d_counts + half, &c, sizeof(c), hipMemcpyHostToDevice);
+}
+
+int ppm_accum_download(ppm_accum_t *a, float *host) {
+    if (!a || !host) return fail(-22, "null argument");
+    HIPCHK(hipStreamSynchronize(g.stream));
+    HIPCHK(hipMemcpy(host, a->acc, ppm_accum_floats(a->N) * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int ppm_accum_add(ppm_accum_t *a, const float *host) {
+    if (!a || !host) return fail(-22, "null argument");
+    size_t nf = ppm_accum_floats(a->N);
+    float *tmp = nullptr;
+    HIPCHK(hipMalloc(&tmp, nf * sizeof(float)));
+    HIPCHK(hipMemcpy(tmp, host, nf * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_axpy, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, g.stream, a->acc, tmp, nf);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(g.stream));
+    (void)hipFree(tmp);
+    return 0;
+}
+
+int ppm_finalize(ppm_accum_t *a, const ppm_final_cfg *cfg, float *half1, float *half2, float *filtered, double *stats) {
+    if (!g.inited) return fail(-1, "ppm_init has not been called");
+    if (!a || !cfg) return fail(-22, "null argument");
+    const int N = a->N, ns = N / 2;
+    const double px = a->pixel;
+    const size_t nf = ppm_accum_floats(N), n3 = (size_t)N * N * N, tot = (size_t)N * N * (N / 2 + 1);
+    float *tmp = nullptr; double *d_s = nullptr; float2 *d_f = nullptr; float *d_out = nullptr;
+    HIPCHK(hipMalloc(&tmp, nf * sizeof(float)));
+    HIPCHK(hipMalloc(&d_s, 8 * ns * sizeof(double)));
+    HIPCHK(hipMemset(d_s, 0, 8 * ns * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(tmp, a->acc, nf * sizeof(float), hipMemcpyDeviceToDevice, g.stream));
+    ProfScope *ps = new ProfScope(PPM_K_FINAL);
+    hipLaunchKernelGGL(k_fold_plane, dim3((unsigned)(((size_t)2 * N * N + 255) / 256)), dim3(256), 0, g.stream, a->acc, tmp, N);
+    hipLaunchKernelGGL(k_shell_den, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, g.stream, tmp, d_s, N);
+    hipLaunchKernelGGL(k_shell_fsc, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, g.stream, tmp, d_s, d_s + 4 * ns, N);
+    delete ps;
+    std::vector<double> hs(8 * ns);
+    HIPCHK(hipMemcpyAsync(hs.data(), d_s, 8 * ns * sizeof(double), hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    double vfrac = cfg->molecular_mass_kda > 0 ? (cfg->molecular_mass_kda * 1000.0 / 0.81) / std::pow(N * px, 3.0) : 1.0;
+    vfrac = std::min(1.0, std::max(1e-6, vfrac));
+    std::vector<double> kap(ns);
+    for (int b = 0; b < ns; b++) {
+        double c12 = hs[4 * ns + b], c11 = hs[5 * ns + b], c22 = hs[6 * ns + b], cnt = hs[2 * ns + b], sdt = hs[3 * ns + b];
+        double fsc = (c11 > 0 && c22 > 0) ? c12 / std::sqrt(c11 * c22) : 0.0;
+        double fc = fsc < 0 ? 0 : (fsc > 0.999 ? 0.999 : fsc);
+        double rec = 2.0 * fc / (1.0 - fc), md = cnt > 0 ? sdt / cnt : 0;
+        kap[b] = b == 0 ? 1e-20 : md / (rec > 1e-6 ? rec : 1e-6);
+        if (b >= 1 && stats) {
+            double *s = stats + (size_t)(b - 1) * PPM_STATS_COLS;
+            s[0] = b; s[1] = N * px / b; s[2] = b / (N * px); s[3] = fsc;
+            s[4] = fc / (fc + vfrac * (1 - fc)); s[5] = md > 0 ? rec / md / vfrac : 0; s[6] = rec;
+        }
+    }
+    HIPCHK(hipMemcpy(d_s, kap.data(), ns * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&d_f, n3 * sizeof(float2)));
+    HIPCHK(hipMalloc(&d_out, n3 * sizeof(float)));
+    float *outs[3] = { half1, half2, filtered };
+    const float rout = (float)(cfg->outer_radius / px), rin = (float)(cfg->inner_radius / px);
+    const float fo = (float)((cfg->mask_falloff > 0 ? cfg->mask_falloff : 10.0) / px);
+    for (int which = 0; which < 3; which++) {
+        if (!outs[which]) continue;
+        {
+            ProfScope p2(PPM_K_FINAL);
+            HIPCHK(hipMemsetAsync(d_f, 0, n3 * sizeof(float2), g.stream));
+            hipLaunchKernelGGL(k_wiener, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, g.stream, tmp, d_s, d_f, N, which);
+            if (int rc = fft3d(d_f, N, true)) return rc;
+            hipLaunchKernelGGL(k_map_post, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, g.stream, d_f, d_out, N, rout, rin, fo);
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(outs[which], d_out, n3 * sizeof(float), hipMemcpyDeviceToHost, g.stream));
+        HIPCHK(hipStreamSynchronize(g.stream));
+    }
+    (void)hipFree(tmp); (void)hipFree(d_s); (void)hipFree(d_f); (void)hipFree(d_out);
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,144 @@
+"""Host-side objects over the C ABI: Reference (prepared 3-D reference), refine(), Accumulator
+(half-map accumulators + finalise).  Mirrors what the refine3d / reconstruct3d / merge3d processes
+do between reading their inputs and writing their outputs."""
+import ctypes as C
+
+import numpy as np
+
+from . import lib
+from .abi import NCOL, STATS_COLS, K_NAMES, FinalCfg, ReconCfg, RefineCfg  # noqa: F401
+
+
+def _images_arg(images, n_img, box):
+    """numpy array (host) or an object with data_ptr() on the GPU (torch tensor) -> (pointer, on_device, keepalive)."""
+    if hasattr(images, "data_ptr") and hasattr(images, "is_cuda"):
+        if not images.is_cuda:
+            images = images.numpy()
+        else:
+            if str(images.dtype) != "torch.float32" or not images.is_contiguous():
+                raise ValueError("ERROR: device image stack must be contiguous float32")
+            if images.numel() != n_img * box * box:
+                raise ValueError("ERROR: image stack size does not match the rows")
+            return C.c_void_p(images.data_ptr()), 1, images
+    a = np.ascontiguousarray(images, dtype=np.float32)
+    if a.size != n_img * box * box:
+        raise ValueError("ERROR: image stack size does not match the rows")
+    return lib.ptr(a), 0, a
+
+
+class Reference:
+    """3-D reference prepared for projection matching up to `max_band_px` Fourier pixels."""
+
+    def __init__(self, vol, max_band_px=None, device=0):
+        lib.init(device)
+        vol = np.ascontiguousarray(vol, dtype=np.float32)
+        if vol.ndim != 3 or len(set(vol.shape)) != 1:
+            raise ValueError("ERROR: reference must be a cubic volume")
+        self.n = vol.shape[0]
+        band = self.n / 2 if max_band_px is None else float(max_band_px)
+        self.h = lib.load().ppm_reference_create(lib.ptr(vol), self.n, band)
+        if not self.h:
+            raise lib.PpmError(lib.last_error())
+
+    def refine(self, cfg, images, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.float64)
+        if rows.ndim != 2 or rows.shape[1] != NCOL:
+            raise ValueError("ERROR: rows must be (M, 32)")
+        out = np.empty_like(rows)
+        p, on_dev, keep = _images_arg(images, len(rows), cfg.box)
+        lib.check(lib.load().ppm_refine_batch(self.h, C.byref(cfg), p, on_dev, len(rows), lib.ptr(rows), lib.ptr(out)))
+        del keep
+        return out
+
+    def last_counts(self):
+        v = [C.c_long() for _ in range(4)]
+        lib.check(lib.load().ppm_refine_last_counts(self.h, *[C.byref(x) for x in v]))
+        return dict(zip(("n_global", "n_local", "samples_global", "samples_local"), [x.value for x in v]))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.load().ppm_reference_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Accumulator:
+    """The two half-map accumulators of a reconstruction ({re, im, weight} per Fourier voxel)."""
+
+    def __init__(self, box, pixel_size, symmetry="C1", device=0, ext_tensor=None):
+        lib.init(device)
+        self.box, self.pixel = int(box), float(pixel_size)
+        self.nfloats = int(lib.load().ppm_accum_floats(self.box))
+        self._ext = ext_tensor
+        ext = None
+        if ext_tensor is not None:
+            if ext_tensor.numel() != self.nfloats or not ext_tensor.is_cuda or not ext_tensor.is_contiguous():
+                raise ValueError("ERROR: external accumulator tensor has the wrong size or is not on the GPU")
+            ext = C.c_void_p(ext_tensor.data_ptr())
+        self.h = lib.load().ppm_accum_create(self.box, self.pixel, symmetry.encode(), ext)
+        if not self.h:
+            raise lib.PpmError(lib.last_error())
+
+    def insert(self, cfg, images, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.float64)
+        p, on_dev, keep = _images_arg(images, len(rows), self.box)
+        lib.check(lib.load().ppm_insert_batch(self.h, C.byref(cfg), p, on_dev, len(rows), lib.ptr(rows)))
+        del keep
+
+    def counts(self):
+        return [int(lib.load().ppm_accum_count(self.h, 0)), int(lib.load().ppm_accum_count(self.h, 1))]
+
+    def set_counts(self, c0, c1):
+        lib.load().ppm_accum_set_count(self.h, 0, int(c0))
+        lib.load().ppm_accum_set_count(self.h, 1, int(c1))
+
+    def download(self):
+        a = np.empty(self.nfloats, dtype=np.float32)
+        lib.check(lib.load().ppm_accum_download(self.h, lib.ptr(a)))
+        return a
+
+    def add(self, host):
+        a = np.ascontiguousarray(host, dtype=np.float32)
+        if a.size != self.nfloats:
+            raise ValueError("ERROR: dump has the wrong size for this box")
+        lib.check(lib.load().ppm_accum_add(self.h, lib.ptr(a)))
+
+    def finalize(self, fcfg):
+        n = self.box
+        h1 = np.empty((n, n, n), dtype=np.float32)
+        h2 = np.empty_like(h1)
+        fl = np.empty_like(h1)
+        stats = np.zeros((n // 2 - 1, STATS_COLS), dtype=np.float64)
+        lib.check(lib.load().ppm_finalize(self.h, C.byref(fcfg), lib.ptr(h1), lib.ptr(h2), lib.ptr(fl), lib.ptr(stats)))
+        return h1, h2, fl, stats
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.load().ppm_accum_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def profile(enable=True, reset=True):
+    lib.load().ppm_profile_enable(1 if enable else 0)
+    if reset:
+        lib.load().ppm_profile_reset()
+
+
+def profile_report():
+    out = {}
+    for i, name in enumerate(K_NAMES):
+        ms, n = C.c_double(), C.c_long()
+        lib.check(lib.load().ppm_profile_get(i, C.byref(ms), C.byref(n)))
+        out[name] = {"ms": ms.value, "launches": n.value}
+    return out
