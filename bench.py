@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""bench.py — particles/s of per-particle projection matching (BASELINE.json metric) on N MI355X.
+
+A "step" is one pass of the hot path (pre-processing FFT + CTF tables, global grid search,
+top-hit + final local refinement: one ppm_refine_batch call) over the rank's synthetic
+particle stack, which is resident in HBM before the timed region starts.
+
+Workload at N=1 = BASELINE.json configs[1]: "SPA global search: 100k 256^2 particles,
+15 deg angular step, 1 MI355X" (search band r = 64 Fourier px).  Particles
+shard across ranks with no data-path collective (weak scaling: --particles is per GPU).
+
+Contract: python bench.py --gpus N --steps K --warmup W   (torchrun launches N ranks for N > 1)
+prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--particles", type=int, default=100000, help="particles per GPU per step (resident stack)")
+    ap.add_argument("--box", type=int, default=256)
+    ap.add_argument("--band", type=float, default=64.0, help="search / refinement band limit, Fourier pixels")
+    ap.add_argument("--angular-step", type=float, default=15.0)
+    ap.add_argument("--unique", type=int, default=512, help="distinct clean projections (each particle gets fresh noise)")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target wall time of the CPU oracle sample (0 = skip)")
+    ap.add_argument("--no-cpu", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        print("ERROR: bench.py needs a GPU (the product path has no CPU fallback)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from pyp_amd import host, synth
+    from pyp_amd.abi import RefineCfg
+
+    N, M, px = a.box, a.particles, 1.0
+    dev = torch.device("cuda", local)
+    # ---- synthetic inputs: phantom, poses, CTF, SNR 0.05; rank r gets its own poses/noise
+    vol = synth.phantom(N)
+    _, stack, rows = synth.make_dataset(N, M, pixel=px, snr=0.05, vol=vol, device=dev, unique=min(a.unique, M),
+                                        seed_poses=synth.SEED_POSES + rank, seed_noise=synth.SEED_NOISE + rank, batch=32)
+    torch.cuda.synchronize()
+    res = px * N / a.band
+    cfg = RefineCfg.make(box=N, pixel_size=px, mask_radius=0.32 * N * px, res_high=res, res_search=res, res_low=0.0,
+                         angular_step=a.angular_step, top_hits=20, search_range_x=6.0 * px, search_range_y=6.0 * px,
+                         res_signed_cc=30.0, molecular_mass_kda=500.0)
+    t0 = time.time()
+    ref = host.Reference(vol, N / 2, device=local)
+    t_refprep = time.time() - t0
+    start_rows = synth.cistem.default_rows(M, px, 300.0, 2.7, 0.07)      # from-scratch rows: the search ignores the poses
+    for c in ("DEFOCUS_1", "DEFOCUS_2", "DEFOCUS_ANGLE"):
+        start_rows[:, synth.cistem.COL[c]] = rows[:, synth.cistem.COL[c]]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        host.lib.load().ppm_device_sync()
+
+    out = None
+    for _ in range(a.warmup):
+        out = ref.refine(cfg, stack, start_rows)
+    host.profile(True, True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = ref.refine(cfg, stack, start_rows)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    prof = host.profile_report()
+    host.profile(False, False)
+    counts = ref.last_counts()
+
+    if rank == 0:
+        total = world * M * a.steps
+        value = total / dt
+        # ---- roofline of the dominant kernel: algorithmic bytes per launch / measured launch time
+        S_g, S_l = counts["samples_global"], counts["samples_local"]
+        launches_g = max(prof["global"]["launches"], 1)
+        per_launch_particles = M * a.steps / launches_g
+        bytes_g = per_launch_particles * counts["n_global"] * 8.0 * S_g
+        ms_g = prof["global"]["ms"] / launches_g
+        # local refinement: hits refine at the search band, the final trajectory at the full band
+        bytes_l_total = M * a.steps * counts["n_local"] * 8.0 * S_l
+        ms_l_total = max(prof["local"]["ms"], 1e-9)
+        dom = "global" if prof["global"]["ms"] >= prof["local"]["ms"] else "local"
+        if dom == "global":
+            achieved = bytes_g / (ms_g * 1e-3) / 1e9
+            kname, kms = "k_global", ms_g
+        else:
+            achieved = bytes_l_total / (ms_l_total * 1e-3) / 1e9
+            kname, kms = "k_local", ms_l_total / max(prof["local"]["launches"], 1)
+        b_pm = 4.0 * N * N + (counts["n_global"] * 8.0 * S_g + counts["n_local"] * 8.0 * S_l) + 128
+        roof = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(achieved / 8000.0, 4), "traffic": None, "avg_launch_ms": round(kms, 3),
+                "path_bytes_per_particle": b_pm, "path_achieved_GBps": round(b_pm * M * a.steps / dt / 1e9 * 1.0, 1),
+                "path_frac": round(b_pm * M * a.steps / dt / 8e12, 4)}
+        # ---- accuracy of what was timed (vs the synthetic ground truth), first 2000 particles
+        k = min(M, 2000)
+        ang = synth.angular_error_deg(out[:k], rows[:k])
+        shf = synth.shift_error_px(out[:k], rows[:k], px)
+        line = {
+            "metric": "particles/sec projection-matching, 256^2 box", "value": round(value, 1), "unit": "particles/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "SPA global search: %dk %d^2 particles/GPU, %g deg angular step, band r=%g px, top-20 hits refined"
+                       % (M // 1000, N, a.angular_step, a.band), "particles_per_gpu": M, "box": N, "orientations": counts["n_global"],
+                       "local_evaluations": counts["n_local"], "parallelism": "particle-sharded x%d" % world},
+            "roofline": roof,
+            "kernels_ms": {k2: round(v["ms"], 2) for k2, v in prof.items() if v["launches"]},
+            "reference_prep_s": round(t_refprep, 3),
+            "accuracy_vs_truth": {"median_deg": round(float(np.median(ang)), 3), "frac_within_2deg": round(float((ang < 2).mean()), 3),
+                                  "median_shift_px": round(float(np.median(shf)), 3)},
+        }
+        if not a.no_cpu and a.cpu_seconds > 0:
+            line["cpu_baseline"] = cpu_baseline(vol, stack, start_rows, cfg, N, a.cpu_seconds)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(vol, stack, start_rows, cfg, N, seconds):
+    """The CPU oracle (kind "port": the reference binaries are absent) on a bounded sample of
+    the SAME stack, all host cores via OpenMP, reference preparation excluded like on the GPU side."""
+    from oracle import oracle
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    t0 = time.time()
+    oref = oracle.Reference(vol, N / 2)
+    t_prep = time.time() - t0
+    n = cores
+    imgs = stack[:max(4 * cores, 8)].cpu().numpy()
+    t0 = time.time()
+    oracle.refine_batch(oref, cfg, imgs[:n], start_rows[:n], ccf_mode=1)
+    t1 = time.time() - t0
+    rate = n / t1
+    if t1 < 0.5 * seconds and len(imgs) > n:     # extend the sample towards the time budget
+        n2 = int(min(len(imgs), max(n, rate * seconds)))
+        n2 = max(cores, (n2 // cores) * cores)
+        t0 = time.time()
+        oracle.refine_batch(oref, cfg, imgs[:n2], start_rows[:n2], ccf_mode=1)
+        t1 = time.time() - t0
+        n = n2
+        rate = n / t1
+    return {"value": round(rate, 3), "unit": "particles/s", "cores": cores, "kind": "port",
+            "sample": "%d particles of the same stack, %.1f s wall, OpenMP over particles; reference prep %.1f s excluded" % (n, t1, t_prep)}
+
+
+if __name__ == "__main__":
+    main()

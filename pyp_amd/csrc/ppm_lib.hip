@@ -156,7 +156,7 @@ static int launch_prep(const float *d_images, const double *d_rows, int n_img, c
     P.normalize = normalize; P.invert = invert; P.do_mask = do_mask; P.whiten = whiten;
     P.nc = std::min(gm.W, (int)(139264 / ((gm.N + 1) * sizeof(float2))));
     P.nchunks = (gm.W + P.nc - 1) / P.nc;
-    P.L = std::max(1, 2048 / gm.N);
+    P.L = std::max(1, std::min(2048 / gm.N, gm.N / 2));
     P.band = band; P.wring = wring; P.samples = samples; P.S_pad = S_pad; P.Il = Il; P.cw = cw;
     P.Wp = Wp; P.C2 = C2; P.nI = nI; P.Bs = gm.Bs; P.Hs = gm.Hs;
     P.r_s2 = (float)(gm.r_s * gm.r_s); P.r_lo2 = (float)(gm.r_lo * gm.r_lo);
@@ -496,6 +496,7 @@ int ppm_insert_batch(ppm_accum_t *a, const ppm_recon_cfg *cfg, const void *image
     if (!geom_init(gm, rc, err)) return fail(-22, err);
     const size_t NN = (size_t)gm.N * gm.N, HW = (size_t)gm.H * gm.W;
     int CH = (int)std::min<size_t>((size_t)n_img, std::max<size_t>(32, ((size_t)2 << 30) / (NN * 4 + HW * 8)));
+    CH = std::min(CH, 32768);   // grid.y limit
     if (int r = a->rows.ensure((size_t)CH * PPM_NCOL)) return r;
     if (!images_on_device) if (int r = a->images.ensure((size_t)CH * NN)) return r;
     if (int r = a->band.ensure((size_t)CH * HW)) return r;

@@ -1,0 +1,189 @@
+"""Parity of the HIP path (through the C ABI, libpypmatch.so) with the CPU oracle on identical
+seeded inputs.  Tolerances: BASELINE.json states 0.1 deg / 0.5 px for poses; scores and maps are
+compared to float32 round-off (stated per test).  Run on the GPU box:  pytest -m gpu"""
+import numpy as np
+import pytest
+
+from pyp_amd import synth
+from pyp_amd.abi import FinalCfg, ReconCfg, RefineCfg
+
+pytestmark = pytest.mark.gpu
+
+ANG_TOL_DEG, SHIFT_TOL_PX = 0.1, 0.5       # BASELINE.json north_star
+
+
+@pytest.fixture(scope="module")
+def H():
+    from pyp_amd import host
+    return host
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+def dataset(n, m, px, snr):
+    vol, stack, rows = synth.make_dataset(n, m, pixel=px, snr=snr)
+    return vol, stack.numpy(), rows
+
+
+def cfg_for(n, px, **kw):
+    base = dict(box=n, pixel_size=px, mask_radius=0.4 * n * px, res_high=px * n / (0.375 * n), res_search=px * n / (0.16 * n),
+                search_range_x=6 * px, search_range_y=6 * px, res_signed_cc=30.0)
+    base.update(kw)
+    return RefineCfg.make(**base)
+
+
+@pytest.fixture(scope="module")
+def d64(H, O):
+    vol, imgs, rows = dataset(64, 24, 2.0, 0.1)
+    return vol, imgs, rows, H.Reference(vol, 32), O.Reference(vol, 32)
+
+
+def test_score_at_given_poses_matches_oracle(d64, H, O):
+    vol, imgs, rows, g, o = d64
+    for kw in (dict(), dict(res_signed_cc=0.0), dict(res_low=60.0), dict(invert=1), dict(normalize=0)):
+        c = cfg_for(64, 2.0, global_search=0, local_refine=0, **kw)
+        want = O.score_batch(o, c, imgs, rows)
+        got = g.refine(c, imgs, rows)[:, 14] / 100.0
+        assert np.abs(want - got).max() < 2e-5, kw                       # float32 round-off of a normalised sum
+
+
+def test_local_refinement_matches_oracle(d64, H, O):
+    vol, imgs, rows, g, o = d64
+    start = synth.perturb_rows(rows, 2.0, 1.0, 2.0)
+    c = cfg_for(64, 2.0, global_search=0)
+    want, _ = O.refine_batch(o, c, imgs, start)
+    got = g.refine(c, imgs, start)
+    assert synth.angular_error_deg(want, got).max() < ANG_TOL_DEG
+    assert synth.shift_error_px(want, got, 2.0).max() < SHIFT_TOL_PX
+    assert np.abs(want[:, 14] - got[:, 14]).max() < 0.01                 # SCORE is 100 x cc
+    untouched = [0] + list(range(6, 12)) + list(range(15, 32))
+    assert np.array_equal(got[:, untouched], start[:, untouched])
+
+
+def test_global_grid_search_matches_oracle_exactly(d64, H, O):
+    vol, imgs, rows, g, o = d64
+    c = cfg_for(64, 2.0, local_refine=0)
+    want, _ = O.refine_batch(o, c, imgs, rows)
+    got = g.refine(c, imgs, rows)
+    assert synth.angular_error_deg(want, got).max() < 1e-4               # same grid point
+    assert np.array_equal(np.round(want[:, 4:6] / 2.0), np.round(got[:, 4:6] / 2.0))   # same integer shift
+    assert np.abs(want[:, 14] - got[:, 14]).max() < 0.01
+
+
+@pytest.mark.parametrize("n,px,m,step", [(64, 2.0, 24, 15.0), (128, 1.5, 8, 15.0), (64, 2.0, 6, 20.0), (32, 3.0, 6, 30.0)])
+def test_full_refinement_matches_oracle(H, O, n, px, m, step):
+    vol, imgs, rows = dataset(n, m, px, 0.1)
+    g, o = H.Reference(vol, n / 2), O.Reference(vol, n / 2)
+    c = cfg_for(n, px, angular_step=step)
+    want, counts = O.refine_batch(o, c, imgs, rows)
+    got = g.refine(c, imgs, rows)
+    lc = g.last_counts()
+    assert lc["n_global"] == counts[0] and lc["n_local"] == counts[1]
+    ang, shf = synth.angular_error_deg(want, got), synth.shift_error_px(want, got, px)
+    assert ang.max() < ANG_TOL_DEG and shf.max() < SHIFT_TOL_PX
+
+
+def test_odd_psi_count_and_wide_shift_window(d64, H, O):
+    vol, imgs, rows, g, o = d64
+    c = cfg_for(64, 2.0, angular_step=24.0, search_range_x=0.0, search_range_y=10.0)    # n_psi = 15 (no conjugate pairing), RSx = 8
+    want, _ = O.refine_batch(o, c, imgs[:6], rows[:6])
+    got = g.refine(c, imgs[:6], rows[:6])
+    assert synth.angular_error_deg(want, got).max() < ANG_TOL_DEG
+    assert synth.shift_error_px(want, got, 2.0).max() < SHIFT_TOL_PX
+
+
+def test_separate_search_mask_and_frozen_parameters(d64, H, O):
+    vol, imgs, rows, g, o = d64
+    c = cfg_for(64, 2.0, search_mask_radius=1.5 * 0.32 * 64 * 2.0, refine_x=0, refine_y=0)
+    want, _ = O.refine_batch(o, c, imgs[:6], rows[:6])
+    got = g.refine(c, imgs[:6], rows[:6])
+    assert synth.angular_error_deg(want, got).max() < ANG_TOL_DEG
+    assert np.allclose(want[:, 4:6], got[:, 4:6], atol=1e-6)
+
+
+def test_device_resident_stack_equals_host_stack(d64, H):
+    import torch
+    vol, imgs, rows, g, o = d64
+    c = cfg_for(64, 2.0)
+    a = g.refine(c, imgs[:8], rows[:8])
+    b = g.refine(c, torch.as_tensor(imgs[:8]).cuda(), rows[:8])
+    assert synth.angular_error_deg(a, b).max() < 1e-2 and np.abs(a[:, 14] - b[:, 14]).max() < 1e-2
+
+
+def test_errors_are_loud(d64, H):
+    from pyp_amd import lib
+    vol, imgs, rows, g, o = d64
+    with pytest.raises(lib.PpmError, match="ERROR"):
+        g.refine(cfg_for(128, 2.0), np.zeros((1, 128, 128), np.float32), rows[:1])          # box mismatch
+    with pytest.raises(lib.PpmError, match="ERROR"):
+        g.refine(RefineCfg.make(box=64, pixel_size=2.0, mask_radius=40, res_high=-1.0), imgs[:1], rows[:1])
+    with pytest.raises(lib.PpmError, match="ERROR"):
+        H.Accumulator(64, 2.0, "Q5")
+    with pytest.raises(ValueError):
+        H.Reference(np.zeros((32, 32, 16), np.float32))
+
+
+@pytest.mark.parametrize("sym", ["C1", "D2", "O"])
+def test_insertion_and_finalise_match_oracle(H, O, sym):
+    n, px, m = 64, 2.0, 40
+    vol, imgs, rows = dataset(n, m, px, 0.2)
+    rows[:, 14] = np.linspace(5, 35, m)
+    rows[3, 11] = 0.0                                                   # one rejected particle
+    rc = ReconCfg(box=n, pixel_size=px, res_limit=2 * px, score_weight_bfactor=2.0, score_average=20.0, score_threshold=0.0,
+                  normalize=1, invert=0, split_by_pind=1, mask_radius=0.4 * n * px)
+    acc = np.zeros(O.accum_floats(n), dtype=np.float32)
+    counts = np.zeros(2, dtype=np.int64)
+    O.insert_batch(acc, counts, rc, sym, imgs, rows)
+    ga = H.Accumulator(n, px, sym)
+    ga.insert(rc, imgs[:25], rows[:25])
+    ga.insert(rc, imgs[25:], rows[25:])                                 # ragged second batch
+    assert ga.counts() == list(counts)
+    got = ga.download()
+    assert np.linalg.norm(got - acc) / np.linalg.norm(acc) < 1e-4       # float atomics: order-dependent round-off
+    fc = FinalCfg(molecular_mass_kda=300.0, inner_radius=0.0, outer_radius=0.45 * n * px, mask_falloff=0.0)
+    w1, w2, wf, ws = O.finalize(acc, n, px, fc)
+    g1, g2, gf, gs = ga.finalize(fc)
+    for a, b in ((w1, g1), (w2, g2), (wf, gf)):
+        assert np.linalg.norm(a - b) / np.linalg.norm(a) < 1e-4
+    assert np.abs(ws[:, 3:5] - gs[:, 3:5]).max() < 1e-4                  # FSC, part-FSC
+
+
+def test_accumulator_sum_is_linear(H, O):
+    """merge = sum of dumps: inserting two halves of a stack separately and adding equals inserting all (local_merge3d)."""
+    n, px = 32, 3.0
+    vol, imgs, rows = dataset(n, 20, px, 0.2)
+    rc = ReconCfg(box=n, pixel_size=px, res_limit=2 * px, normalize=1, mask_radius=0.4 * n * px)
+    a, b, c = H.Accumulator(n, px), H.Accumulator(n, px), H.Accumulator(n, px)
+    a.insert(rc, imgs[:10], rows[:10]); b.insert(rc, imgs[10:], rows[10:]); c.insert(rc, imgs, rows)
+    a.add(b.download())
+    x, y = a.download(), c.download()
+    assert np.linalg.norm(x - y) / np.linalg.norm(y) < 1e-5
+
+
+def test_full_size_properties_256(H):
+    """BASELINE.json size (256^2, band 64 px): size-independent properties instead of the (slow) oracle."""
+    n, px, m = 256, 1.0, 48
+    vol, stack, rows = synth.make_dataset(n, m, pixel=px, snr=0.05)
+    imgs = stack.numpy()
+    g = H.Reference(vol, n / 2)
+    c = RefineCfg.make(box=n, pixel_size=px, mask_radius=0.32 * n * px, res_high=4.0, res_search=4.0, search_range_x=6.0,
+                       search_range_y=6.0, res_signed_cc=30.0)
+    out = g.refine(c, imgs, rows)
+    ang = synth.angular_error_deg(out, rows)
+    assert np.median(ang) < 1.5 and (ang < 5).mean() > 0.9                # recovers the true poses from scratch
+    # idempotence: a local refinement started at the refined poses stays there
+    c2 = RefineCfg.make(box=n, pixel_size=px, mask_radius=0.32 * n * px, res_high=4.0, global_search=0, res_signed_cc=30.0,
+                        local_angle_step=0.2, local_shift_step=0.2)
+    again = g.refine(c2, imgs, out)
+    assert np.median(synth.angular_error_deg(again, out)) < 0.1
+    assert (again[:, 14] >= out[:, 14] - 1e-3).all()
+    # in-plane rotation covariance: rotating the image by 90 deg (exact on the grid) adds 90 deg to psi
+    rot = np.ascontiguousarray(np.rot90(imgs[:8], k=1, axes=(1, 2)))
+    # our rot90 of an even box moves the centre by one pixel; compare poses up to that shift
+    o2 = g.refine(c, rot, rows[:8])
+    d = synth.angular_error_deg(o2, out[:8])
+    assert np.median(np.abs(d - 90.0)) < 2.0

@@ -1,0 +1,114 @@
+"""CPU tests of the oracle itself (oracle/ppm_oracle.c): it has no reference arithmetic to be pinned to
+(parity unpinned), so it is pinned by synthetic ground truth and internal consistency."""
+import numpy as np
+import pytest
+
+from pyp_amd import synth
+from pyp_amd.abi import FinalCfg, ReconCfg, RefineCfg
+from oracle import oracle
+
+N, PX = 64, 2.0
+
+
+@pytest.fixture(scope="module")
+def data():
+    vol, stack, rows = synth.make_dataset(N, 12, pixel=PX, snr=0)
+    return vol, stack.numpy(), rows, oracle.Reference(vol, N / 2)
+
+
+def cfg_for(**kw):
+    base = dict(box=N, pixel_size=PX, mask_radius=0.4 * N * PX, res_high=PX * N / 24.0, res_search=PX * N / 10.0,
+                search_range_x=12.0, search_range_y=12.0)
+    base.update(kw)
+    return RefineCfg.make(**base)
+
+
+def test_grid_matches_survey_count():
+    d = oracle.band_dims(cfg_for(angular_step=15.0))
+    assert d["n_orient"] == 184 * 24          # 184 directions x 24 in-plane
+    assert d["B"] == 23 and d["Ns"] == 32 and d["step"] == 2
+
+
+def test_global_search_recovers_true_poses_noise_free(data):
+    vol, imgs, rows, ref = data
+    out, counts = oracle.refine_batch(ref, cfg_for(), imgs, rows)
+    ang = synth.angular_error_deg(out, rows)
+    shf = synth.shift_error_px(out, rows, PX)
+    assert counts[0] == 4416
+    assert np.median(ang) < 0.5 and ang.max() < 1.5          # 1 Fourier pixel at the band edge = 2.4 deg
+    assert shf.max() < 0.15
+    assert (out[:, 14] > 50).all()
+
+
+def test_fft_and_pruned_correlation_agree(data):
+    vol, imgs, rows, ref = data
+    c = cfg_for(local_refine=0)
+    a, _ = oracle.refine_batch(ref, c, imgs[:4], rows[:4], ccf_mode=0)
+    b, _ = oracle.refine_batch(ref, c, imgs[:4], rows[:4], ccf_mode=1)
+    assert np.array_equal(a[:, 1:6], b[:, 1:6])
+    assert np.allclose(a[:, 14], b[:, 14], atol=1e-3)
+
+
+def test_local_refinement_converges_from_perturbed_start(data):
+    vol, imgs, rows, ref = data
+    start = synth.perturb_rows(rows, 2.0, 1.0, PX)
+    out, counts = oracle.refine_batch(ref, cfg_for(global_search=0), imgs, start)
+    assert counts[0] == 0 and counts[1] == 1 + 9 * 11
+    assert np.median(synth.angular_error_deg(out, rows)) < 0.5
+    assert synth.angular_error_deg(out, rows).max() < synth.angular_error_deg(start, rows).max()
+    assert synth.shift_error_px(out, rows, PX).max() < 0.2
+
+
+def test_refine_flags_freeze_parameters(data):
+    vol, imgs, rows, ref = data
+    start = synth.perturb_rows(rows, 1.0, 0.5, PX)
+    out, _ = oracle.refine_batch(ref, cfg_for(global_search=0, refine_x=0, refine_y=0), imgs[:3], start[:3])
+    assert np.allclose(out[:, 4:6], start[:3, 4:6], atol=1e-9)
+    out, _ = oracle.refine_batch(ref, cfg_for(global_search=0, refine_psi=0, refine_theta=0, refine_phi=0), imgs[:3], start[:3])
+    assert synth.angular_error_deg(out, start[:3]).max() < 1e-5
+
+
+def test_signed_cc_limit_changes_score_only_above_limit(data):
+    vol, imgs, rows, ref = data
+    s_all = oracle.score_batch(ref, cfg_for(), imgs[:3], rows[:3])
+    s_abs = oracle.score_batch(ref, cfg_for(res_signed_cc=30.0), imgs[:3], rows[:3])
+    assert (s_abs >= s_all - 1e-12).all()      # |ring sums| can only raise the numerator
+
+
+def test_symmetry_groups_have_the_right_order():
+    for sym, n in (("C1", 1), ("C7", 7), ("D7", 14), ("T", 12), ("O", 24), ("I", 60)):
+        ops = oracle.symmetry_ops(sym)
+        assert len(ops) == n
+        for m in ops:
+            assert np.allclose(m @ m.T, np.eye(3), atol=1e-9) and np.isclose(np.linalg.det(m), 1.0)
+    with pytest.raises(ValueError):
+        oracle.symmetry_ops("X9")
+
+
+def test_reconstruction_reproduces_the_phantom():
+    n = 32
+    vol, stack, rows = synth.make_dataset(n, 400, pixel=PX, snr=0)
+    acc = np.zeros(oracle.accum_floats(n), dtype=np.float32)
+    counts = np.zeros(2, dtype=np.int64)
+    rc = ReconCfg(box=n, pixel_size=PX, res_limit=2 * PX, normalize=0, invert=0, split_by_pind=0, mask_radius=0.4 * n * PX)
+    oracle.insert_batch(acc, counts, rc, "C1", stack.numpy(), rows)
+    assert list(counts) == [200, 200]
+    h1, h2, fl, stats = oracle.finalize(acc, n, PX, FinalCfg(outer_radius=0.45 * n * PX))
+
+    def cc(a, b):
+        a, b = a - a.mean(), b - b.mean()
+        return float((a * b).sum() / np.sqrt((a * a).sum() * (b * b).sum()))
+    assert cc(fl, vol) > 0.97 and cc(h1, h2) > 0.99
+    assert stats.shape == (n // 2 - 1, 7) and (stats[:10, 3] > 0.95).all()
+    assert np.allclose(stats[:, 1], n * PX / stats[:, 0])
+
+
+def test_zero_occupancy_rows_are_skipped():
+    n = 32
+    vol, stack, rows = synth.make_dataset(n, 6, pixel=PX, snr=0)
+    rows[:, 11] = [100, 0, 100, 0, 100, 100]
+    acc = np.zeros(oracle.accum_floats(n), dtype=np.float32)
+    counts = np.zeros(2, dtype=np.int64)
+    rc = ReconCfg(box=n, pixel_size=PX, res_limit=2 * PX, mask_radius=0.4 * n * PX)
+    oracle.insert_batch(acc, counts, rc, "C1", stack.numpy(), rows)
+    assert counts.sum() == 4
