@@ -1,0 +1,297 @@
+"""Drop-in `refine3d`, `reconstruct3d`, `local_merge3d`, `merge3d`: same stdin answer scripts, same
+input / output files, same log sentinels as the binaries PYP finds in external/cistem2/
+(src/pyp/system/utils.py:227-235), computing on the GPU through libpypmatch.
+
+Failure contract: print a line containing ERROR, exit non-zero, create no output file.
+Sentinels the caller greps: "Reconstruct3D: Normal termination" (frealign.py:4970), the table between
+"Rec_SSNR" and "Merge3D: Normal termination" (frealign.py:2557-2567).
+"""
+import os
+import struct
+import sys
+import time
+
+import numpy as np
+
+from ..abi import FinalCfg, ReconCfg, RefineCfg
+from ..formats import cistem, mrc, parfile
+from . import prompts
+
+C = cistem.COL
+DUMP_MAGIC = b"PPMDUMP1"
+
+
+def _die(msg):
+    if "ERROR" not in msg:
+        msg = "ERROR: " + msg
+    print(msg, flush=True)
+    sys.exit(1)
+
+
+def _unsupported(d, keys, prog):
+    for k, bad in keys:
+        if d.get(k) == bad:
+            _die(f"ERROR: {prog}: option '{k}' = {d[k]} is not supported by this build")
+
+
+def _select(rows, first, last):
+    pos = rows[:, C["POSITION_IN_STACK"]]
+    sel = np.where((pos >= first) & (pos <= last))[0]
+    if len(sel) == 0:
+        _die(f"ERROR: no rows with POSITION_IN_STACK in {first}..{last}")
+    return sel
+
+
+def _load_images(stack_path, positions, box_expected=None):
+    mm = mrc.mmap(stack_path)
+    if positions.max() > mm.shape[0] or positions.min() < 1:
+        _die(f"ERROR: {stack_path}: stack has {mm.shape[0]} images, rows ask for {int(positions.max())}")
+    if mm.shape[1] != mm.shape[2]:
+        _die(f"ERROR: {stack_path}: particle images must be square")
+    imgs = np.ascontiguousarray(mm[positions.astype(np.int64) - 1], dtype=np.float32)
+    return imgs
+
+
+def _ssnr_weighted_reference(vol, stats_path, pixel):
+    """'use statistics' = yes: figure-of-merit weighting of the reference rings,
+    w = sqrt(2 pFSC / (1 + pFSC)) from the part-FSC column of statistics_rNN.txt (7 columns,
+    src/pyp/postprocess/core.py:203-221)."""
+    st = np.loadtxt(stats_path, comments=["C"], ndmin=2)
+    if st.shape[1] < 5 or len(st) < 2:
+        _die(f"ERROR: {stats_path}: statistics file needs 7 columns")
+    n = vol.shape[0]
+    res, pfsc = st[:, 1], np.clip(st[:, 4], 0.0, 1.0)
+    w_tab = np.sqrt(2 * pfsc / (1 + pfsc))
+    f = np.fft.rfftn(vol)
+    kz, ky = np.fft.fftfreq(n) * n, np.fft.fftfreq(n) * n
+    kx = np.arange(n // 2 + 1)
+    k = np.sqrt(kz[:, None, None] ** 2 + ky[None, :, None] ** 2 + kx[None, None, :] ** 2)
+    s = k / (n * pixel)
+    order = np.argsort(1.0 / res)
+    w = np.interp(s, (1.0 / res)[order], w_tab[order], left=1.0, right=float(w_tab[order][-1]))
+    return np.fft.irfftn(f * w, s=vol.shape).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------------ refine3d
+def refine3d_main(argv=None, stdin=None):
+    t0 = time.time()
+    try:
+        d = prompts.parse_refine3d(prompts.read_answers(stdin or sys.stdin))
+    except prompts.PromptError as e:
+        _die(str(e))
+    print("\n        **   Welcome to Refine3D (MI355X / libpypmatch)   **\n")
+    for k, v in d.items():
+        print(f"{k:28s}: {v}")
+    _unsupported(d, [("use_priors", True), ("calc_match", True), ("mask_2d", True), ("refine_defocus", True),
+                     ("exclude_edges", True), ("normalize_reference", True), ("threshold_reference", True)], "refine3d")
+    if abs(d["padding"] - 1.0) > 1e-6:
+        _die("ERROR: refine3d: only padding factor 1 is supported")
+    if any(abs(d[k]) > 0 for k in ("focus_x", "focus_y", "focus_z", "focus_r")):
+        _die("ERROR: refine3d: focus masks are not supported")
+    for p in (d["stack"], d["input_params"], d["reference"]):
+        if not os.path.exists(p):
+            _die(f"ERROR: refine3d: input file {p} does not exist")
+    px = d["pixel_size"]
+    if d["surface"] == "par":
+        par, version, ext, _, _ = parfile.read(d["input_params"])
+        if version not in (parfile.NEW, parfile.FREALIGNX):
+            _die("ERROR: refine3d: only NEW / FREALIGNX parameter files are supported")
+        rows = parfile.par_to_cistem(par, version, px, d["voltage"], d["cs"], d["amplitude_contrast"])
+    else:
+        rows = cistem.read_parameters(d["input_params"])
+    sel = _select(rows, d["first"], d["last"])
+    rin = rows[sel]
+    imgs = _load_images(d["stack"], rin[:, C["POSITION_IN_STACK"]])
+    box = imgs.shape[1]
+    vol = mrc.read(d["reference"]).astype(np.float32)
+    if vol.shape != (box, box, box):
+        _die(f"ERROR: refine3d: reference is {vol.shape}, particles are {box}^2")
+    if d["use_statistics"]:
+        if not os.path.exists(d["statistics"]):
+            _die(f"ERROR: refine3d: statistics file {d['statistics']} does not exist")
+        vol = _ssnr_weighted_reference(vol, d["statistics"], px)
+    cfg = RefineCfg.make(
+        box=box, pixel_size=px, molecular_mass_kda=d["molecular_mass"], mask_radius=d["outer_radius"], res_low=d["res_low"],
+        res_high=d["res_high"], res_signed_cc=d["res_signed_cc"], search_mask_radius=d["search_mask_radius"],
+        res_search=d["res_search"], angular_step=d["angular_step"], top_hits=d["top_hits"], search_range_x=d["search_range_x"],
+        search_range_y=d["search_range_y"], global_search=int(d["global_search"]), local_refine=int(d["local_refine"]),
+        refine_psi=int(d["refine_psi"]), refine_theta=int(d["refine_theta"]), refine_phi=int(d["refine_phi"]),
+        refine_x=int(d["refine_x"]), refine_y=int(d["refine_y"]), normalize=int(d["normalize"]), invert=int(d["invert"]))
+    from .. import host, lib
+    try:
+        ref = host.Reference(vol, box / 2, device=int(os.environ.get("PPM_DEVICE", "0")))
+        rout = ref.refine(cfg, imgs, rin)
+    except (lib.PpmError, ValueError) as e:
+        _die(str(e))
+    changes = rout - rin
+    changes[:, C["POSITION_IN_STACK"]] = rin[:, C["POSITION_IN_STACK"]]
+    if d["surface"] == "par":
+        parfile.write(d["output_params"], parfile.cistem_to_par(rout, version, change=changes[:, C["SCORE"]]), version=version)
+    else:
+        cistem.write_parameters(d["output_params"], rout)
+        if d["output_changes"] not in ("/dev/null", "null"):
+            cistem.write_parameters(d["output_changes"], changes)
+    print("\n   NO     PSI   THETA     PHI       SHX       SHY     SCORE   CHANGE")
+    for r, c in zip(rout[:50], changes[:50]):
+        print("%7d%8.2f%8.2f%8.2f%10.2f%10.2f%10.4f%9.4f" % (r[0], r[1], r[2], r[3], r[4], r[5], r[C["SCORE"]], c[C["SCORE"]]))
+    print(f"\nRefined {len(rout)} particles in {time.time() - t0:.1f} s; mean score {rout[:, C['SCORE']].mean():.4f}")
+    print("\nRefine3D: Normal termination\n", flush=True)
+    return 0
+
+
+# ------------------------------------------------------------------------------------------ dumps
+def write_dump(path, box, pixel, count, data):
+    tmp = path + ".tmp%d" % os.getpid()
+    with open(tmp, "wb") as f:
+        f.write(DUMP_MAGIC + struct.pack("<ifq", box, pixel, count))
+        f.write(np.ascontiguousarray(data, dtype="<f4").tobytes())
+    os.replace(tmp, path)
+
+
+def read_dump(path):
+    with open(path, "rb") as f:
+        head = f.read(24)
+        if len(head) < 24 or head[:8] != DUMP_MAGIC:
+            _die(f"ERROR: {path} is not a libpypmatch dump file")
+        box, pixel, count = struct.unpack("<ifq", head[8:])
+        n = box * box * (box // 2 + 1) * 3
+        data = np.fromfile(f, dtype="<f4", count=n)
+    if data.size != n:
+        _die(f"ERROR: {path}: dump file is truncated")
+    return box, pixel, count, data
+
+
+# ------------------------------------------------------------------------------------------ reconstruct3d
+def reconstruct3d_main(argv=None, stdin=None):
+    t0 = time.time()
+    try:
+        d = prompts.parse_reconstruct3d(prompts.read_answers(stdin or sys.stdin))
+    except prompts.PromptError as e:
+        _die(str(e))
+    print("\n        **   Welcome to Reconstruct3D (MI355X / libpypmatch)   **\n")
+    for k, v in d.items():
+        print(f"{k:28s}: {v}")
+    _unsupported(d, [("dose_weighting", True), ("crop", True), ("center_mass", True), ("likelihood_blurring", True),
+                     ("threshold_reference", True), ("exclude_edges", True), ("split_even_odd", False), ("dump", False)], "reconstruct3d")
+    if abs(d["padding"] - 1.0) > 1e-6:
+        _die("ERROR: reconstruct3d: only padding factor 1 is supported")
+    if not d["input_params"].endswith(".cistem"):
+        _die("ERROR: reconstruct3d: input parameters must be a .cistem file")
+    for p in (d["stack"], d["input_params"]):
+        if not os.path.exists(p):
+            _die(f"ERROR: reconstruct3d: input file {p} does not exist")
+    rows = cistem.read_parameters(d["input_params"])
+    sel = _select(rows, d["first"], d["last"])
+    rin = rows[sel].copy()
+    px = d["pixel_size"]
+    used = rin[:, C["OCCUPANCY"]] > 0
+    if d["adjust_scores"] and used.sum() > 10:
+        # score vs defocus regression, removed before thresholding / weighting
+        df = 0.5 * (rin[used, C["DEFOCUS_1"]] + rin[used, C["DEFOCUS_2"]])
+        sc = rin[used, C["SCORE"]]
+        if df.std() > 0:
+            slope = np.polyfit(df, sc, 1)[0]
+            rin[:, C["SCORE"]] -= slope * (0.5 * (rin[:, C["DEFOCUS_1"]] + rin[:, C["DEFOCUS_2"]]) - df.mean())
+    if d["global_stats"] not in ("null", "") and os.path.exists(d["global_stats"]):
+        score_avg = float(cistem.read_parameters(d["global_stats"])[0, C["SCORE"]])
+    else:
+        score_avg = float(rin[used, C["SCORE"]].mean()) if used.any() else 0.0
+    imgs = _load_images(d["stack"], rin[:, C["POSITION_IN_STACK"]])
+    box = imgs.shape[1]
+    rc = ReconCfg(box=box, pixel_size=px, res_limit=d["res_limit"], score_weight_bfactor=d["score_bfactor"] if d["score_weighting"] else 0.0,
+                  score_average=score_avg, score_threshold=d["score_threshold"], normalize=int(d["normalize"]), invert=int(d["invert"]),
+                  split_by_pind=int(d["per_particle_splitting"]), mask_radius=d["outer_radius"])
+    from .. import host, lib
+    try:
+        acc = host.Accumulator(box, px, d["symmetry"], device=int(os.environ.get("PPM_DEVICE", "0")))
+        acc.insert(rc, imgs, rin)
+        data = acc.download()
+        counts = acc.counts()
+    except (lib.PpmError, ValueError) as e:
+        _die(str(e))
+    half = data.size // 2
+    write_dump(d["dump_1"], box, px, counts[1], data[half:])      # odd keys  -> map 1
+    write_dump(d["dump_2"], box, px, counts[0], data[:half])      # even keys -> map 2
+    with open(d["res_file"], "w") as f:
+        f.write("C Reconstruct3D (libpypmatch): particles %d..%d, inserted %d + %d\n" % (d["first"], d["last"], counts[1], counts[0]))
+    print(f"\nInserted {counts[0] + counts[1]} of {len(rin)} particles in {time.time() - t0:.1f} s")
+    print("\nNormal termination, intermediate files dumped")
+    print("\nReconstruct3D: Normal termination\n", flush=True)
+    return 0
+
+
+def _sum_dumps(seed1, seed2, n):
+    tot = None
+    box = pixel = None
+    counts = [0, 0]
+    for k in range(1, n + 1):
+        for h, seed in ((0, seed1), (1, seed2)):
+            p = prompts.dump_name(seed, k)
+            if not os.path.exists(p):
+                _die(f"ERROR: dump file {p} does not exist")
+            b, px, cnt, data = read_dump(p)
+            if box is None:
+                box, pixel = b, px
+                tot = [np.zeros_like(data, dtype=np.float64), np.zeros_like(data, dtype=np.float64)]
+            if b != box:
+                _die(f"ERROR: dump file {p} has box {b}, expected {box}")
+            tot[h] += data
+            counts[h] += cnt
+    return box, pixel, counts, tot
+
+
+def local_merge3d_main(argv=None, stdin=None):
+    try:
+        d = prompts.parse_local_merge3d(prompts.read_answers(stdin or sys.stdin))
+    except prompts.PromptError as e:
+        _die(str(e))
+    print("\n        **   Welcome to LocalMerge3D (libpypmatch)   **\n")
+    box, pixel, counts, tot = _sum_dumps(d["dump_seed_1"], d["dump_seed_2"], d["n_dumps"])
+    write_dump(d["out_dump_1"], box, pixel, counts[0], tot[0].astype(np.float32))
+    write_dump(d["out_dump_2"], box, pixel, counts[1], tot[1].astype(np.float32))
+    print(f"Merged {d['n_dumps']} dump pairs ({counts[0]} + {counts[1]} particles)")
+    print("\nLocalMerge3D: Normal termination\n", flush=True)
+    return 0
+
+
+def format_stats_table(stats):
+    """Rows in the fixed widths the caller slices with numpy.genfromtxt(delimiter=[5,8,10,10,10,10,10])
+    (frealign.py:2559): shell, resolution, ring radius, FSC, part-FSC, part-SSNR, rec-SSNR."""
+    lines = []
+    for s in stats:
+        lines.append("%5d%8.2f%10.4f%10.4f%10.4f%10.4f%10.2f" % (int(s[0]), s[1], s[2], s[3], s[4], min(s[5], 99999.0), min(s[6], 999999.0)))
+    return lines
+
+
+def merge3d_main(argv=None, stdin=None):
+    t0 = time.time()
+    try:
+        d = prompts.parse_merge3d(prompts.read_answers(stdin or sys.stdin))
+    except prompts.PromptError as e:
+        _die(str(e))
+    print("\n        **   Welcome to Merge3D (MI355X / libpypmatch)   **\n")
+    for k, v in d.items():
+        print(f"{k:28s}: {v}")
+    box, pixel, counts, tot = _sum_dumps(d["dump_seed_1"], d["dump_seed_2"], d["n_dumps"])
+    from .. import host, lib
+    try:
+        acc = host.Accumulator(box, pixel, "C1", device=int(os.environ.get("PPM_DEVICE", "0")))
+        acc.add(np.concatenate([tot[1], tot[0]]).astype(np.float32))      # dump 1 = odd keys = half index 1
+        acc.set_counts(counts[1], counts[0])
+        fc = FinalCfg(molecular_mass_kda=d["molecular_mass"], inner_radius=d["inner_radius"], outer_radius=d["outer_radius"], mask_falloff=0.0)
+        h_even, h_odd, filt, stats = acc.finalize(fc)
+    except (lib.PpmError, ValueError) as e:
+        _die(str(e))
+    mrc.write(h_odd, d["half1"], pixel_size=pixel)
+    mrc.write(h_even, d["half2"], pixel_size=pixel)
+    mrc.write(filt, d["filtered"], pixel_size=pixel)
+    with open(d["statistics"], "w") as f:
+        f.write("C  NO.   RESOL  RING RAD       FSC  Part_FSC Part_SSNR  Rec_SSNR\n")
+        for s in stats:
+            f.write("%14.5f%14.5f%14.5f%14.5f%14.5f%14.5f%14.5f\n" % tuple(s))
+    print(f"\nParticles: {counts[0]} (map 1) + {counts[1]} (map 2); finalised in {time.time() - t0:.1f} s\n")
+    print("   NO.   RESOL  RING RAD       FSC  Part_FSC Part_SSNR  Rec_SSNR")
+    for line in format_stats_table(stats):
+        print(line)
+    print("\n\nMerge3D: Normal termination\n", flush=True)
+    return 0

@@ -1,0 +1,237 @@
+"""CPU tests of the call surface: positional answer scripts exactly as PYP writes them
+(src/pyp/refine/frealign/frealign.py:3918-3994, :1780-1824, :1878-1888, :2075-2093;
+src/pyp/system/wrapper_functions.py:512-561), dump files, log table format, error behaviour."""
+import io
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from pyp_amd.surface import cli, prompts
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+REFINE_CISTEM = """../ds_stack.mrc
+name_r01.cistem
+null
+name_r01.mrc
+statistics_r01.txt
+no
+no
+name_r01_match.mrc_0000001_0000143
+name_r01_0000001_0000143.cistem
+name_r01_0000001_0000143_changes.cistem
+D7
+1
+143
+1
+4.32
+700
+0
+85
+100.0
+8
+30.0
+8.0
+127.5
+8
+20.0
+20
+0.0
+0.0
+0
+0
+0
+0
+500
+50.0
+1
+yes
+no
+yes
+yes
+yes
+yes
+yes
+no
+no
+no
+no
+no
+no
+no
+no
+eot
+"""
+
+# verbatim from src/pyp/system/wrapper_functions.py:512-561
+REFINE_PAR = """../spr_frames_00_04_stack.mrc
+spr_frames_00_04_r01_08.par
+spr_frames_00_04_r01_07.mrc
+statistics_r01.txt
+yes
+spr_frames_00_04_r01_08_match.mrc_0000001_0000027
+spr_frames_00_04_r01_08.par_0000001_0000027
+/dev/null
+O
+1
+27
+1.08
+300.0
+2.7
+0.07
+400.0
+65
+100.0
+3.0
+30.0
+8
+97.5
+3.0
+200
+20
+0
+0
+0
+0
+0
+0
+500.0
+50.0
+1
+no
+yes
+yes
+yes
+yes
+yes
+yes
+no
+no
+no
+no
+"""
+
+RECON = """/scratch/ds_stack.mrc
+name_r01_used.cistem
+null
+name_r01.mrc
+name_r01_map1.mrc
+name_r01_map2.mrc
+output.mrc
+name_r01_n1.res
+C1
+1
+5000
+1.08
+700
+0
+138.24
+2.16
+0
+2.0
+no
+0
+-1
+{dose}
+0
+1
+1
+no
+yes
+no
+no
+no
+yes
+yes
+no
+no
+no
+yes
+/scratch/name_r01_map1_n1.mrc
+/scratch/name_r01_map2_n1.mrc
+1
+"""
+
+
+def test_refine3d_cistem_script():
+    d = prompts.parse_refine3d(prompts.read_answers(io.StringIO(REFINE_CISTEM)))
+    assert d["surface"] == "cistem" and d["symmetry"] == "D7" and (d["first"], d["last"]) == (1, 143)
+    assert d["pixel_size"] == 4.32 and d["outer_radius"] == 85 and d["res_high"] == 8 and d["res_search"] == 8
+    assert d["angular_step"] == 20.0 and d["top_hits"] == 20 and d["global_search"] and not d["local_refine"]
+    assert d["refine_psi"] and d["refine_y"] and not d["invert"] and d["search_mask_radius"] == 127.5
+    assert d["output_params"] == "name_r01_0000001_0000143.cistem"
+
+
+def test_refine3d_par_script_verbatim_from_reference():
+    d = prompts.parse_refine3d(prompts.read_answers(io.StringIO(REFINE_PAR)))
+    assert d["surface"] == "par" and d["symmetry"] == "O" and (d["first"], d["last"]) == (1, 27)
+    assert (d["pixel_size"], d["voltage"], d["cs"], d["amplitude_contrast"]) == (1.08, 300.0, 2.7, 0.07)
+    assert d["outer_radius"] == 65 and d["res_high"] == 3.0 and d["res_signed_cc"] == 30.0 and d["angular_step"] == 200
+    assert not d["global_search"] and d["local_refine"] and d["use_statistics"] and d["output_changes"] == "/dev/null"
+
+
+def test_reconstruct3d_script_with_and_without_dose_weighting():
+    d = prompts.parse_reconstruct3d(prompts.read_answers(io.StringIO(RECON.format(dose="no"))))
+    assert not d["dose_weighting"] and d["res_limit"] == 2.16 and d["score_bfactor"] == 2.0 and d["threads"] == 1
+    assert d["dump_1"].endswith("_map1_n1.mrc") and d["split_even_odd"] and d["per_particle_splitting"] and d["adjust_scores"]
+    d = prompts.parse_reconstruct3d(prompts.read_answers(io.StringIO(RECON.format(dose="yes\n/scratch/not_provided\nyes\n0.5\n4.0"))))
+    assert d["dose_weighting"] and d["dose_fraction"] == 0.5 and d["dump_2"].endswith("_map2_n1.mrc") and d["threads"] == 1
+
+
+def test_short_or_bad_scripts_raise():
+    with pytest.raises(prompts.PromptError, match="ERROR"):
+        prompts.parse_refine3d(["a.mrc", "b.cistem"])
+    bad = REFINE_CISTEM.replace("\nyes\nno\nyes\nyes", "\nmaybe\nno\nyes\nyes", 1)
+    with pytest.raises(prompts.PromptError, match="yes or no"):
+        prompts.parse_refine3d(prompts.read_answers(io.StringIO(bad)))
+    with pytest.raises(prompts.PromptError):
+        prompts.parse_merge3d(["a", "b", "c", "d", "700", "0", "x", "s1", "s2", "3"])
+
+
+def test_dump_roundtrip_and_names(tmp_path):
+    assert prompts.dump_name("/s/ds_r01_map1_n.mrc", 12) == "/s/ds_r01_map1_n12.mrc"
+    data = np.arange(32 * 32 * 17 * 3, dtype=np.float32)
+    p = str(tmp_path / "x_map1_n1.mrc")
+    cli.write_dump(p, 32, 1.5, 77, data)
+    box, px, cnt, back = cli.read_dump(p)
+    assert (box, px, cnt) == (32, 1.5, 77) and np.array_equal(back, data)
+
+
+def test_local_merge3d_sums_dumps(tmp_path, capsys):
+    for k in (1, 2, 3):
+        cli.write_dump(str(tmp_path / f"t_map1_n{k}.mrc"), 32, 2.0, 10 * k, np.full(32 * 32 * 17 * 3, float(k), np.float32))
+        cli.write_dump(str(tmp_path / f"t_map2_n{k}.mrc"), 32, 2.0, k, np.full(32 * 32 * 17 * 3, 0.5 * k, np.float32))
+    script = "\n".join([str(tmp_path / "o_map1_n1.mrc"), str(tmp_path / "o_map2_n1.mrc"), str(tmp_path / "t_map1_n.mrc"),
+                        str(tmp_path / "t_map2_n.mrc"), "3"]) + "\n"
+    assert cli.local_merge3d_main(stdin=io.StringIO(script)) == 0
+    assert "LocalMerge3D: Normal termination" in capsys.readouterr().out
+    b, px, cnt, d = cli.read_dump(str(tmp_path / "o_map1_n1.mrc"))
+    assert cnt == 60 and np.all(d == 6.0)
+    b, px, cnt, d = cli.read_dump(str(tmp_path / "o_map2_n1.mrc"))
+    assert cnt == 6 and np.all(d == 3.0)
+
+
+def test_merge_log_table_parses_like_the_caller(tmp_path):
+    """Replays the slicing of src/pyp/refine/frealign/frealign.py:2557-2567 on our log text."""
+    from io import StringIO
+    stats = np.array([[b, 64.0 / b, b / 64.0, 1.0 - 0.01 * b, 0.99, 12.5, 300.0 / b] for b in range(1, 32)])
+    log = "blah\n   NO.   RESOL  RING RAD       FSC  Part_FSC Part_SSNR  Rec_SSNR\n" + "\n".join(cli.format_stats_table(stats)) + "\n\n\nMerge3D: Normal termination\n"
+    A = log
+    Afsc = A[A.find("Rec_SSNR") + 9: A.find("Merge3D: Normal termination") - 3]
+    widths = [5, 8, 10, 10, 10, 10, 10]
+    rows = len(Afsc.split("\n"))
+    cur = np.genfromtxt(StringIO(Afsc), delimiter=widths).reshape((rows, len(widths)))[:, list(range(1, 4, 2))].astype("float")
+    assert rows == 31
+    assert np.allclose(cur[:, 0], np.round(stats[:, 1], 2)) and np.allclose(cur[:, 1], np.round(stats[:, 3], 4))
+
+
+def test_executables_fail_loudly_without_inputs(tmp_path):
+    """Non-zero exit, a line containing ERROR, and no output file (SURVEY.md §8b 'Errors')."""
+    script = REFINE_CISTEM.replace("name_r01_0000001_0000143.cistem", str(tmp_path / "out.cistem"))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bin", "refine3d")], input=script, capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode != 0 and "ERROR" in r.stdout and not (tmp_path / "out.cistem").exists()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bin", "merge3d")], input="a\nb\n", capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode != 0 and "ERROR" in r.stdout
