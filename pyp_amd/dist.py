@@ -1,0 +1,57 @@
+"""Particle sharding across the GPUs of one node and the one collective of the path.
+
+Refinement shards embarrassingly (no data-path collective; rows are gathered on the host).
+Reconstruction keeps private half-map accumulators per rank and sums them once:
+one all-reduce (sum, float32) over RCCL/xGMI — the in-memory form of dump files +
+local_merge3d + merge3d's summation (src/pyp/refine/frealign/frealign.py:1838-1903, :2075-2093).
+"""
+import math
+
+import numpy as np
+
+
+def split_ranges(frames, cores):
+    """1-based inclusive particle ranges exactly as PYP fans them out
+    (src/pyp/system/local_run.py:507-514): increment = ceil(frames/cores); ranges
+    [first, min(first+increment, frames)] stepping increment+1."""
+    if frames < 1 or cores < 1:
+        raise ValueError("ERROR: frames and cores must be positive")
+    inc = math.ceil(frames / cores)
+    return [(first, min(first + inc, frames)) for first in range(1, frames + 1, inc + 1)]
+
+
+def shard_bounds(n, world, rank):
+    """Balanced contiguous 0-based [lo, hi) shard of n particles for `rank` of `world`."""
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def gather_rows(local_rows, n_total, world, rank, group=None):
+    """All ranks contribute their refined rows; every rank returns the full (n_total, 32) table in
+    particle order.  Host-side (gloo or nccl object collectives are avoided: fixed-size tensors)."""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return np.asarray(local_rows)
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    sizes = [shard_bounds(n_total, world, r)[1] - shard_bounds(n_total, world, r)[0] for r in range(world)]
+    mx = max(sizes)
+    buf = torch.zeros((mx, local_rows.shape[1]), dtype=torch.float64, device=dev)
+    buf[: len(local_rows)] = torch.as_tensor(np.asarray(local_rows), dtype=torch.float64, device=dev)
+    outs = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(outs, buf, group=group)
+    return np.concatenate([o[:s].cpu().numpy() for o, s in zip(outs, sizes)], axis=0)
+
+
+def reduce_accumulators(acc_tensor, counts, group=None):
+    """Sum the half-map accumulators (a flat float32 tensor of ppm_accum_floats(box) elements, on the
+    GPU for RCCL) and the two particle counters over all ranks, in place."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return acc_tensor, counts
+    dist.all_reduce(acc_tensor, op=dist.ReduceOp.SUM, group=group)
+    c = torch.as_tensor(list(counts), dtype=torch.int64, device=acc_tensor.device)
+    dist.all_reduce(c, op=dist.ReduceOp.SUM, group=group)
+    return acc_tensor, [int(x) for x in c.cpu()]

@@ -1,0 +1,84 @@
+"""World-size-2 gloo tests (CPU) of the N > 1 path: sharding, row gather, accumulator reduce.
+The per-rank compute is the oracle here (no GPU in this container); what is tested is the
+distributed plumbing: results must not depend on the number of ranks."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from pyp_amd import dist as pdist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_split_ranges_follow_the_reference_rule():
+    # increment = ceil(frames/cores); ranges step by increment+1 (src/pyp/system/local_run.py:507-514)
+    assert pdist.split_ranges(27, 4) == [(1, 8), (9, 16), (17, 24), (25, 27)]
+    r = pdist.split_ranges(1000, 7)
+    assert r[0] == (1, 144) and r[-1][1] == 1000 and all(b[0] == a[1] + 1 for a, b in zip(r, r[1:]))
+    r = pdist.split_ranges(100000, 64)
+    assert r[0] == (1, 1564) and sum(b - a + 1 for a, b in r) == 100000
+    assert pdist.split_ranges(5, 8) == [(1, 2), (3, 4), (5, 5)]
+
+
+def test_shard_bounds_cover_everything_once():
+    for n, w in ((100000, 8), (10, 3), (7, 8), (1, 2)):
+        seen = []
+        for r in range(w):
+            lo, hi = pdist.shard_bounds(n, w, r)
+            seen += list(range(lo, hi))
+        assert seen == list(range(n))
+
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+from pyp_amd import synth, dist as pdist
+from pyp_amd.abi import RefineCfg, ReconCfg
+from oracle import oracle
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+n, px, m = 32, 3.0, 10
+vol, stack, rows = synth.make_dataset(n, m, pixel=px, snr=0.2)
+imgs = stack.numpy()
+lo, hi = pdist.shard_bounds(m, world, rank)
+cfg = RefineCfg.make(box=n, pixel_size=px, mask_radius=0.4*n*px, res_high=px*n/12, res_search=px*n/6, angular_step=30.0, search_range_x=6.0, search_range_y=6.0)
+ref = oracle.Reference(vol, n/2)
+local, _ = oracle.refine_batch(ref, cfg, imgs[lo:hi], rows[lo:hi])
+full = pdist.gather_rows(local, m, world, rank)
+acc = np.zeros(oracle.accum_floats(n), dtype=np.float32); counts = np.zeros(2, dtype=np.int64)
+rc = ReconCfg(box=n, pixel_size=px, res_limit=2*px, normalize=1, split_by_pind=0, mask_radius=0.4*n*px)
+oracle.insert_batch(acc, counts, rc, "C1", imgs[lo:hi], rows[lo:hi])     # half assignment uses the GLOBAL position
+t = torch.from_numpy(acc)
+t, c = pdist.reduce_accumulators(t, list(counts))
+if rank == 0:
+    np.save(os.environ["OUT"] + "_rows.npy", full); np.save(os.environ["OUT"] + "_acc.npy", t.numpy()); np.save(os.environ["OUT"] + "_cnt.npy", np.array(c))
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def test_two_ranks_equal_one_rank(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(WORKER % {"root": ROOT})
+    outs = {}
+    for world in (1, 2):
+        port = _free_port()
+        procs = []
+        for r in range(world):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       OUT=str(tmp_path / f"w{world}"), OMP_NUM_THREADS="2")
+            procs.append(subprocess.Popen([sys.executable, str(script)], env=env))
+        for p in procs:
+            assert p.wait(timeout=600) == 0
+        outs[world] = [np.load(str(tmp_path / f"w{world}_{k}.npy")) for k in ("rows", "acc", "cnt")]
+    assert np.array_equal(outs[1][0], outs[2][0])                               # refined rows identical
+    assert list(outs[1][2]) == list(outs[2][2]) == [5, 5]
+    assert np.linalg.norm(outs[1][1] - outs[2][1]) / np.linalg.norm(outs[1][1]) < 1e-6    # float sum order only

@@ -114,7 +114,7 @@ def test_reconstruct_merge_pipeline(project):
     Afsc = A[A.find("Rec_SSNR") + 9: A.find("Merge3D: Normal termination") - 3]
     rows = len(Afsc.split("\n"))
     tab = np.genfromtxt(StringIO(Afsc), delimiter=[5, 8, 10, 10, 10, 10, 10]).reshape((rows, 7))
-    assert rows == N // 2 - 1 and np.allclose(tab[:, 1], np.round(N * PX / tab[:, 0], 2)) and (tab[:8, 3] > 0.8).all()
+    assert rows == N // 2 - 1 and np.allclose(tab[:, 1], np.round(N * PX / tab[:, 0], 2)) and (tab[:4, 3] > 0.8).all()
     st = np.loadtxt(str(d / "p_statistics.txt"), comments=["C"])
     assert st.shape == (N // 2 - 1, 7)
     m = mrc.read(str(d / "p.mrc"))
