@@ -267,31 +267,68 @@ struct GlobP {
     const float2 *bank; const float2 *Wp; const float *C2; const float *nI; const float2 *twN;  // twN: Ns-entry table e^{2 pi i t/Ns}
     float *cc; int *sh;   // [n][n_orient] scratch scores and packed shifts
     Hit *hits;            // [n][K]
-    int Bs, Hs, Ns, RSx, RSy, n_dir, n_psi, npsi_store, n_orient, K;
+    int Bs, Hs, HsP, Ns, RSx, RSy, n_dir, n_psi, npsi_store, n_orient, K;
 };
 
-// Block = one particle, 16 waves.  The particle's CTF-weighted spectrum W and CTF^2 table sit in LDS;
-// each wave streams whole slices from the bank: lane = kx, loop over ky.  Per loaded slice sample it
-// forms Q = W conj(P) (orientation psi) and W P (psi + 180) and accumulates the partial transforms
-// G[kx][sy] for the 2R+1 rows of the shift window; the sum over kx is a wavefront reduction.
-constexpr int global_threads(int R) { return R <= 3 ? 1024 : 512; }   // wider windows need > 128 VGPRs
+// Row twiddles e^{+2 pi i ky j / Ns}, [row][j-1]: wave-uniform, so they are fetched with scalar loads.
+constexpr int kRowTwRows = 128;
+__constant__ float2 c_rowtw[kRowTwRows * PPM_MAX_SHIFT_STEPS];
 
+constexpr int global_threads(int R) { return R <= 3 ? 1024 : 512; }   // wider windows need > 128 VGPRs
+constexpr int global_unroll(int R) { return R <= 3 ? 8 : 4; }         // rows in flight per wave (prefetch depth)
+
+// pairwise halving step of a cross-lane reduction: afterwards lanes with (lane & m) == 0 carry the
+// partial sum of `a`, the others that of `b`
+__device__ __forceinline__ float halve_pair(float a, float b, int lane, int m) {
+    const bool hi = (lane & m) != 0;
+    float send = hi ? a : b, keep = hi ? b : a;
+    return keep + __shfl_xor(send, m, 64);
+}
+
+// Sums NV per-lane values over the 64 lanes in 6 halving stages (NV + NV/2 + ... shuffles instead of
+// 6 NV).  Returns one register: lane l holds the total of value index bitrev6(l) (if that is < NV <= 64).
+template <int NV>
+__device__ __forceinline__ float reduce_halving(float (&v)[NV], int lane) {
+    static_assert(NV <= 64, "one output register");
+    constexpr int n1 = (NV + 1) / 2, n2 = (n1 + 1) / 2, n3 = (n2 + 1) / 2, n4 = (n3 + 1) / 2, n5 = (n4 + 1) / 2;
+    float a1[n1], a2[n2], a3[n3], a4[n4], a5[n5];
+#pragma unroll
+    for (int i = 0; i < n1; i++) a1[i] = halve_pair(v[2 * i], (2 * i + 1 < NV) ? v[2 * i + 1] : 0.f, lane, 32);
+#pragma unroll
+    for (int i = 0; i < n2; i++) a2[i] = halve_pair(a1[2 * i], (2 * i + 1 < n1) ? a1[2 * i + 1] : 0.f, lane, 16);
+#pragma unroll
+    for (int i = 0; i < n3; i++) a3[i] = halve_pair(a2[2 * i], (2 * i + 1 < n2) ? a2[2 * i + 1] : 0.f, lane, 8);
+#pragma unroll
+    for (int i = 0; i < n4; i++) a4[i] = halve_pair(a3[2 * i], (2 * i + 1 < n3) ? a3[2 * i + 1] : 0.f, lane, 4);
+#pragma unroll
+    for (int i = 0; i < n5; i++) a5[i] = halve_pair(a4[2 * i], (2 * i + 1 < n4) ? a4[2 * i + 1] : 0.f, lane, 2);
+    return halve_pair(a5[0], (n5 > 1) ? a5[1] : 0.f, lane, 1);
+}
+
+// Block = one particle.  The particle's CTF-weighted spectrum W and CTF^2 table sit in LDS for the whole
+// orientation loop; each wave streams whole slices of the bank: lane = kx, rows = ky, U rows prefetched
+// ahead.  Per slice sample: Q1 = W conj(P) (orientation psi) and Q2 = W P (psi + 180 deg).  The
+// partial transforms over ky are accumulated as U_j = sum Q cos(2 pi ky j/Ns), V_j = sum Q sin(...)
+// (4 FMA per j instead of 8: G(+-j) = U +- iV is formed once per slice); the sum over kx of the shift
+// window is a wavefront halving reduction.
 template <int R, bool HALF>
 __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
-    constexpr int NT = global_threads(R), NW = NT / 64;
+    constexpr int NT = global_threads(R), NW = NT / 64, U = global_unroll(R), NS = 2 * R + 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = blockIdx.x;
-    const int Hs = P.Hs, Bs = P.Bs, Ns = P.Ns, nsamp = Hs * 64;
+    const int Hs = P.Hs, HsP = P.HsP, Ns = P.Ns, nsamp = Hs * 64, nsampP = HsP * 64;
     float2 *Wl = (float2 *)smem;
-    float *C2l = (float *)(Wl + nsamp);
+    float *C2l = (float *)(Wl + nsampP);
     {
         const float2 *src = P.Wp + (size_t)p * nsamp; const float *src2 = P.C2 + (size_t)p * nsamp;
-        for (int i = tid; i < nsamp; i += NT) { Wl[i] = src[i]; C2l[i] = src2[i]; }
+        for (int i = tid; i < nsampP; i += NT) {
+            Wl[i] = i < nsamp ? src[i] : make_float2(0.f, 0.f);
+            C2l[i] = i < nsamp ? src2[i] : 0.f;
+        }
     }
     __syncthreads();
     const float nI = P.nI[p];
-    // per-lane x twiddles e^{+2 pi i kx j / Ns}
-    float txc[R + 1], txs[R + 1];
+    float txc[R + 1], txs[R + 1];      // per-lane x twiddles e^{+2 pi i kx j / Ns}
 #pragma unroll
     for (int j = 0; j <= R; j++) {
         float2 t = P.twN[(lane * j) & (Ns - 1)];
@@ -300,49 +337,103 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
     const int nslices = P.n_dir * P.npsi_store;
     float *ccp = P.cc + (size_t)p * P.n_orient; int *shp = P.sh + (size_t)p * P.n_orient;
     for (int sl = wave; sl < nslices; sl += NW) {
-        const float2 *Pp = P.bank + (size_t)sl * nsamp;
-        float2 g1[2 * R + 1], g2[2 * R + 1];
+        const float2 *Pp = P.bank + (size_t)sl * nsampP + lane;
+        float s1x = 0.f, s1y = 0.f, s2x = 0.f, s2y = 0.f, nP = 0.f;
+        float u1x[R], u1y[R], v1x[R], v1y[R], u2x[R], u2y[R], v2x[R], v2y[R];
 #pragma unroll
-        for (int j = 0; j < 2 * R + 1; j++) { g1[j] = make_float2(0.f, 0.f); g2[j] = make_float2(0.f, 0.f); }
-        float nP = 0.f;
-        for (int row = 0; row < Hs; row++) {
-            const int ky = row - Bs;
-            float2 pv = Pp[row * 64 + lane];
-            float2 wv = Wl[row * 64 + lane];
-            float c2 = C2l[row * 64 + lane];
-            float a = wv.x * pv.x, b = wv.y * pv.y, c = wv.y * pv.x, d = wv.x * pv.y;
-            float2 q1 = make_float2(a + b, c - d);   // W conj(P)
-            float2 q2 = make_float2(a - b, c + d);   // W P
-            nP += c2 * (pv.x * pv.x + pv.y * pv.y);
-            g1[R].x += q1.x; g1[R].y += q1.y;
-            if (HALF) { g2[R].x += q2.x; g2[R].y += q2.y; }
+        for (int j = 0; j < R; j++) { u1x[j] = u1y[j] = v1x[j] = v1y[j] = u2x[j] = u2y[j] = v2x[j] = v2y[j] = 0.f; }
+        float2 pv[U], pn[U];
 #pragma unroll
-            for (int j = 1; j <= R; j++) {
-                float2 t = P.twN[(ky * j) & (Ns - 1)];   // wave-uniform
-                g1[R + j].x += q1.x * t.x - q1.y * t.y; g1[R + j].y += q1.x * t.y + q1.y * t.x;
-                g1[R - j].x += q1.x * t.x + q1.y * t.y; g1[R - j].y += q1.y * t.x - q1.x * t.y;
-                if (HALF) {
-                    g2[R + j].x += q2.x * t.x - q2.y * t.y; g2[R + j].y += q2.x * t.y + q2.y * t.x;
-                    g2[R - j].x += q2.x * t.x + q2.y * t.y; g2[R - j].y += q2.y * t.x - q2.x * t.y;
+        for (int u = 0; u < U; u++) pv[u] = Pp[u * 64];
+        for (int row0 = 0; row0 < HsP; row0 += U) {
+            if (row0 + U < HsP) {
+#pragma unroll
+                for (int u = 0; u < U; u++) pn[u] = Pp[(row0 + U + u) * 64];
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int row = row0 + u;
+                const float2 wv = Wl[row * 64 + lane];
+                const float c2 = C2l[row * 64 + lane];
+                const float px = pv[u].x, py = pv[u].y;
+                const float a = wv.x * px, b = wv.y * py, c = wv.y * px, d = wv.x * py;
+                const float q1x = a + b, q1y = c - d;      // W conj(P)
+                const float q2x = a - b, q2y = c + d;      // W P
+                nP = fmaf(c2, fmaf(px, px, py * py), nP);
+                s1x += q1x; s1y += q1y;
+                if (HALF) { s2x += q2x; s2y += q2y; }
+#pragma unroll
+                for (int j = 0; j < R; j++) {
+                    const float2 t = c_rowtw[row * PPM_MAX_SHIFT_STEPS + j];     // wave-uniform -> SGPRs
+                    u1x[j] = fmaf(q1x, t.x, u1x[j]); u1y[j] = fmaf(q1y, t.x, u1y[j]);
+                    v1x[j] = fmaf(q1x, t.y, v1x[j]); v1y[j] = fmaf(q1y, t.y, v1y[j]);
+                    if (HALF) {
+                        u2x[j] = fmaf(q2x, t.x, u2x[j]); u2y[j] = fmaf(q2y, t.x, u2y[j]);
+                        v2x[j] = fmaf(q2x, t.y, v2x[j]); v2y[j] = fmaf(q2y, t.y, v2y[j]);
+                    }
                 }
             }
+#pragma unroll
+            for (int u = 0; u < U; u++) pv[u] = pn[u];
         }
         nP = wave_sum(nP);
         const float inv = (nP > 0.f && nI > 0.f) ? rsqrtf(nP * nI) : 0.f;
         const int dir = sl / P.npsi_store, ks = sl - dir * P.npsi_store;
 #pragma unroll
         for (int e = 0; e < (HALF ? 2 : 1); e++) {
+            // G[iy] = U + iV for iy > R, U - iV for iy < R; value(iy, ix) = Re(G[iy] e^{+2 pi i kx (ix-R)/Ns})
             float best = -3.0e38f; int bsx = 0, bsy = 0;
+            if constexpr (NS * NS <= 64) {
+                float val[NS * NS];
 #pragma unroll
-            for (int iy = 0; iy < 2 * R + 1; iy++) {
-                float2 g = e ? g2[iy] : g1[iy];
+                for (int iy = 0; iy < NS; iy++) {
+                    const int jy = iy - R, ja = jy < 0 ? -jy : jy;
+                    float gx, gy;
+                    if (jy == 0) { gx = e ? s2x : s1x; gy = e ? s2y : s1y; }
+                    else {
+                        const float ux = e ? u2x[ja - 1] : u1x[ja - 1], uy = e ? u2y[ja - 1] : u1y[ja - 1];
+                        const float vx = e ? v2x[ja - 1] : v1x[ja - 1], vy = e ? v2y[ja - 1] : v1y[ja - 1];
+                        gx = jy > 0 ? ux - vy : ux + vy; gy = jy > 0 ? uy + vx : uy - vx;
+                    }
+                    val[iy * NS + R] = gx;
 #pragma unroll
-                for (int ix = 0; ix < 2 * R + 1; ix++) {
-                    const int j = ix - R, ja = j < 0 ? -j : j;
-                    float v = j >= 0 ? (g.x * txc[ja] - g.y * txs[ja]) : (g.x * txc[ja] + g.y * txs[ja]);
-                    v = wave_sum(v);
-                    bool ok = (ja <= P.RSx) && ((iy - R < 0 ? R - iy : iy - R) <= P.RSy);
-                    if (ok && v > best) { best = v; bsx = j; bsy = iy - R; }
+                    for (int j = 1; j <= R; j++) {
+                        const float pc = gx * txc[j], qs = gy * txs[j];
+                        val[iy * NS + R + j] = pc - qs;
+                        val[iy * NS + R - j] = pc + qs;
+                    }
+                }
+                const float tot = reduce_halving<NS * NS>(val, lane);
+                const int vi = (int)(__brev((unsigned)lane) >> 26);            // the value index this lane ended up with
+                const int iy = vi / NS, ix = vi - iy * NS;
+                const int ay = iy - R < 0 ? R - iy : iy - R, ax = ix - R < 0 ? R - ix : ix - R;
+                float cand = (vi < NS * NS && ax <= P.RSx && ay <= P.RSy) ? tot : -3.0e38f;
+                int ci = vi;
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) {     // arg-max over lanes; ties -> lower (sy, sx) index like the oracle's scan order
+                    float ov = __shfl_xor(cand, m, 64); int oi = __shfl_xor(ci, m, 64);
+                    if (ov > cand || (ov == cand && oi < ci)) { cand = ov; ci = oi; }
+                }
+                best = cand; bsy = ci / NS - R; bsx = ci - (ci / NS) * NS - R;
+            } else {
+#pragma unroll
+                for (int iy = 0; iy < NS; iy++) {
+                    const int jy = iy - R, ja = jy < 0 ? -jy : jy;
+                    float gx, gy;
+                    if (jy == 0) { gx = e ? s2x : s1x; gy = e ? s2y : s1y; }
+                    else {
+                        const float ux = e ? u2x[ja - 1] : u1x[ja - 1], uy = e ? u2y[ja - 1] : u1y[ja - 1];
+                        const float vx = e ? v2x[ja - 1] : v1x[ja - 1], vy = e ? v2y[ja - 1] : v1y[ja - 1];
+                        gx = jy > 0 ? ux - vy : ux + vy; gy = jy > 0 ? uy + vx : uy - vx;
+                    }
+#pragma unroll
+                    for (int ix = 0; ix < NS; ix++) {
+                        const int j = ix - R, jx = j < 0 ? -j : j;
+                        float v = j >= 0 ? (gx * txc[jx] - gy * txs[jx]) : (gx * txc[jx] + gy * txs[jx]);
+                        v = wave_sum(v);
+                        bool ok = (jx <= P.RSx) && (ja <= P.RSy);
+                        if (ok && v > best) { best = v; bsx = j; bsy = jy; }
+                    }
                 }
             }
             if (lane == 0) {

@@ -186,7 +186,7 @@ static int launch_global_r(const GlobP &P, int n_img, bool half, size_t lds) {
 }
 
 static int launch_global(const GlobP &P, int n_img, bool half, int R) {
-    size_t lds = (size_t)P.Hs * 64 * (sizeof(float2) + sizeof(float));
+    size_t lds = (size_t)P.HsP * 64 * (sizeof(float2) + sizeof(float));
     if (lds < 1024) lds = 1024;
     ProfScope ps(PPM_K_GLOBAL);
     switch (R) {
@@ -304,6 +304,9 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
     HIPCHK(hipMemcpyAsync(ref->samples.p, sl.packed.data(), S_pad * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
 
     const size_t NN = (size_t)gm.N * gm.N, HW = (size_t)gm.H * gm.W, HS = (size_t)gm.Hs * 64;
+    const int Rwin = std::max(gm.RSx, gm.RSy);
+    const int HsP = ((gm.Hs + global_unroll(Rwin) - 1) / global_unroll(Rwin)) * global_unroll(Rwin);   // bank rows per slice (zero padded)
+    const size_t HSP = (size_t)HsP * 64;
     const int nslices = gm.n_dir * gm.npsi_store;
     // chunk so that the scratch stays well inside HBM
     size_t per = NN * 4 + HW * 8 + (size_t)S_pad * 12 + 2 * PPM_NCOL * 8 + (gm.B + 2) * 4;
@@ -331,7 +334,7 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
         if (int rc = ref->states.ensure((size_t)CH * K)) return rc;
         // slice bank, twiddles and direction tables: rebuilt only when the grid / band changes
         char key[160];
-        std::snprintf(key, sizeof(key), "%d/%.6f/%.6f/%d/%d", gm.N, gm.r_s, gm.dstep, gm.Ns, gm.npsi_store);
+        std::snprintf(key, sizeof(key), "%d/%.6f/%.6f/%d/%d/%d", gm.N, gm.r_s, gm.dstep, gm.Ns, gm.npsi_store, HsP);
         if (ref->bank_key != key) {
             std::vector<float> mats((size_t)nslices * 6);
             std::vector<double> dth(gm.n_dir), dph(gm.n_dir);
@@ -349,16 +352,25 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
             if (int rc = ref->dir_theta.ensure(gm.n_dir)) return rc;
             if (int rc = ref->dir_phi.ensure(gm.n_dir)) return rc;
             if (int rc = ref->twN.ensure(gm.Ns)) return rc;
-            if (int rc = ref->bank.ensure((size_t)nslices * HS)) return rc;
+            if (int rc = ref->bank.ensure((size_t)nslices * HSP)) return rc;
             HIPCHK(hipMemcpyAsync(ref->mats.p, mats.data(), mats.size() * sizeof(float), hipMemcpyHostToDevice, g.stream));
             HIPCHK(hipMemcpyAsync(ref->dir_theta.p, dth.data(), dth.size() * sizeof(double), hipMemcpyHostToDevice, g.stream));
             HIPCHK(hipMemcpyAsync(ref->dir_phi.p, dph.data(), dph.size() * sizeof(double), hipMemcpyHostToDevice, g.stream));
             HIPCHK(hipMemcpyAsync(ref->twN.p, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice, g.stream));
-            BankP BP; BP.cv = cv; BP.mats = ref->mats.p; BP.bank = ref->bank.p; BP.nslices = nslices; BP.Bs = gm.Bs; BP.Hs = gm.Hs;
+            // row twiddles of the shift window -> __constant__ (scalar loads in k_global)
+            {
+                std::vector<float2> rt((size_t)kRowTwRows * PPM_MAX_SHIFT_STEPS, make_float2(1.f, 0.f));
+                for (int row = 0; row < HsP && row < kRowTwRows; row++) for (int j = 1; j <= PPM_MAX_SHIFT_STEPS; j++) {
+                    int t = (((row - gm.Bs) * j) % gm.Ns + gm.Ns) % gm.Ns;
+                    rt[(size_t)row * PPM_MAX_SHIFT_STEPS + j - 1] = make_float2((float)std::cos(2.0 * kPi * t / gm.Ns), (float)std::sin(2.0 * kPi * t / gm.Ns));
+                }
+                HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_rowtw), rt.data(), rt.size() * sizeof(float2)));
+            }
+            BankP BP; BP.cv = cv; BP.mats = ref->mats.p; BP.bank = ref->bank.p; BP.nslices = nslices; BP.Bs = gm.Bs; BP.Hs = HsP;
             BP.r_s2 = (float)(gm.r_s * gm.r_s);
             {
                 ProfScope ps(PPM_K_BANK);
-                size_t tot = (size_t)nslices * HS;
+                size_t tot = (size_t)nslices * HSP;
                 hipLaunchKernelGGL(k_bank, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, g.stream, BP);
             }
             HIPCHK(hipGetLastError());
@@ -396,9 +408,9 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
             GlobP GP;
             GP.bank = ref->bank.p; GP.Wp = ref->Wp.p; GP.C2 = ref->C2.p; GP.nI = ref->nI.p; GP.twN = ref->twN.p;
             GP.cc = ref->cc.p; GP.sh = ref->sh.p; GP.hits = ref->hits.p;
-            GP.Bs = gm.Bs; GP.Hs = gm.Hs; GP.Ns = gm.Ns; GP.RSx = gm.RSx; GP.RSy = gm.RSy;
+            GP.Bs = gm.Bs; GP.Hs = gm.Hs; GP.HsP = HsP; GP.Ns = gm.Ns; GP.RSx = gm.RSx; GP.RSy = gm.RSy;
             GP.n_dir = gm.n_dir; GP.n_psi = gm.n_psi; GP.npsi_store = gm.npsi_store; GP.n_orient = gm.n_orient; GP.K = K;
-            if (int rc = launch_global(GP, nb, gm.half != 0, std::max(gm.RSx, gm.RSy))) return rc;
+            if (int rc = launch_global(GP, nb, gm.half != 0, Rwin)) return rc;
             {
                 ProfScope ps(PPM_K_TOPK);
                 hipLaunchKernelGGL(k_states_from_hits, dim3((nb * K + 255) / 256), dim3(256), 0, g.stream, ref->hits.p, ref->states.p, nb, K,
