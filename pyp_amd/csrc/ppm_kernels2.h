@@ -63,14 +63,29 @@ struct LocalP {
     LState *states; int T, rescore; int en[5];
 };
 
-constexpr int kMaxCand = 11;
+constexpr int kMaxCand = 11;   // scores produced per sweep: 2 per free parameter, or 1 (trial / rescore)
+constexpr int kMaxGroup = 8;   // gathers per sweep: 6 angular neighbours + the centre (shared by the 4 shift neighbours)
 
-// Block = one trajectory, 256 threads.  A compass iteration scores up to 10 neighbouring poses in one
-// sweep over the ring-ordered samples (image value and CTF weight loaded once per sample), then one
-// trial pose.  Ring sums: 16-lane shuffle reduction (a 16-lane group never straddles a ring), then
-// one LDS atomic per group.
-__global__ void __launch_bounds__(256) k_local(LocalP P) {
-    __shared__ float cand[kMaxCand][8];
+// sum over aligned groups of 16 lanes with DPP only (quad swaps, then half-row and row mirrors);
+// every lane of the group ends up with the total
+__device__ __forceinline__ float group16_sum_dpp(float v) {
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xF, 0xF, true));   // row_mirror
+    return v;
+}
+
+// A sweep evaluates `ng` gather groups; group g = one rotation (6 floats) with nv[g] shift variants, the
+// scores of which go to consecutive slots starting at slot0[g].
+struct SweepPlan { float m[kMaxGroup][6]; float sh[kMaxCand][2]; int nv[kMaxGroup]; int slot0[kMaxGroup]; int ng, nslots; };
+
+// Block = one trajectory, 256 threads.  A compass iteration scores the neighbouring poses in one sweep
+// over the ring-ordered samples (image value and CTF weight loaded once per sample; the four shift
+// neighbours reuse the centre's interpolated slice value), then one trial pose.  Ring sums: 16-lane DPP
+// reduction (a 16-lane group never straddles a ring), then one LDS atomic per group.
+__global__ void __launch_bounds__(256, 4) k_local(LocalP P) {
+    __shared__ SweepPlan plan;
     __shared__ float ringA[kMaxCand][260];
     __shared__ float sumB[kMaxCand];
     __shared__ float sumC;
@@ -86,8 +101,9 @@ __global__ void __launch_bounds__(256) k_local(LocalP P) {
     const float invN = 1.0f / (float)P.N;
     const int tilt = P.en[1] && P.en[2];
 
-    auto evaluate = [&](int ncand) {
-        for (int i = tid; i < ncand * 260; i += 256) (&ringA[0][0])[i] = 0.f;
+    auto sweep = [&]() {
+        const int nslots = plan.nslots, ng = plan.ng;
+        for (int i = tid; i < nslots * 260; i += 256) (&ringA[0][0])[i] = 0.f;
         if (tid < kMaxCand) sumB[tid] = 0.f;
         if (tid == 0) sumC = 0.f;
         __syncthreads();
@@ -104,24 +120,28 @@ __global__ void __launch_bounds__(256) k_local(LocalP P) {
             }
             const float fal = (float)al, fkx = (float)kx, fky = (float)ky;
             accC += fal * (iv.x * iv.x + iv.y * iv.y);
-            for (int q = 0; q < ncand; q++) {
-                const float *m = cand[q];
+            const float ax = fal * iv.x, ay = fal * iv.y;
+            for (int g = 0; g < ng; g++) {
+                const float *m = plan.m[g];
                 float2 pv = sample_cube(P.cv, m[0] * fkx + m[1] * fky, m[2] * fkx + m[3] * fky, m[4] * fkx + m[5] * fky);
-                float rev = -(fkx * m[6] + fky * m[7]) * invN;     // phase in revolutions
-                rev -= floorf(rev);
-                float sn = __sinf(6.283185307179586f * rev), cs = __cosf(6.283185307179586f * rev);
-                float mr = c * (pv.x * cs - pv.y * sn), mi = c * (pv.x * sn + pv.y * cs);
-                float av = fal * (iv.x * mr + iv.y * mi);
-                float bv = fal * (mr * mr + mi * mi);
-                av = group16_sum(av);
-                bv = group16_sum(bv);
-                if ((lane & 15) == 0) { atomicAdd(&ringA[q][ring], av); atomicAdd(&sumB[q], bv); }
+                pv.x *= c; pv.y *= c;
+                float bv = group16_sum_dpp(fal * (pv.x * pv.x + pv.y * pv.y));     // |m|^2 does not depend on the shift
+                const int nv = plan.nv[g], q0 = plan.slot0[g];
+                for (int v = 0; v < nv; v++) {
+                    const int q = q0 + v;
+                    float rev = -(fkx * plan.sh[q][0] + fky * plan.sh[q][1]) * invN;     // phase in revolutions
+                    rev -= floorf(rev);
+                    float sn = __sinf(6.283185307179586f * rev), cs = __cosf(6.283185307179586f * rev);
+                    float mr = pv.x * cs - pv.y * sn, mi = pv.x * sn + pv.y * cs;
+                    float av = group16_sum_dpp(ax * mr + ay * mi);
+                    if ((lane & 15) == 0) { atomicAdd(&ringA[q][ring], av); atomicAdd(&sumB[q], bv); }
+                }
             }
         }
         accC = wave_sum(accC);
         if (lane == 0) atomicAdd(&sumC, accC);
         __syncthreads();
-        if (tid < ncand) {
+        if (tid < nslots) {
             double sa = 0;
             for (int b = 0; b < P.nrings; b++) { float a = ringA[tid][b]; sa += ((float)b <= P.ring_signed) ? (double)a : fabs((double)a); }
             double sb = sumB[tid], sc = sumC;
@@ -129,39 +149,56 @@ __global__ void __launch_bounds__(256) k_local(LocalP P) {
         }
         __syncthreads();
     };
-    auto set_cand = [&](int q, const double *M, const double *sh) {
-        cand[q][0] = (float)M[0]; cand[q][1] = (float)M[1]; cand[q][2] = (float)M[3]; cand[q][3] = (float)M[4];
-        cand[q][4] = (float)M[6]; cand[q][5] = (float)M[7]; cand[q][6] = (float)sh[0]; cand[q][7] = (float)sh[1];
+    auto set_rot = [&](int g, const double *M) {
+        plan.m[g][0] = (float)M[0]; plan.m[g][1] = (float)M[1]; plan.m[g][2] = (float)M[3];
+        plan.m[g][3] = (float)M[4]; plan.m[g][4] = (float)M[6]; plan.m[g][5] = (float)M[7];
+    };
+    auto single = [&](const double *M, const double *sh) {      // plan for one pose
+        set_rot(0, M); plan.sh[0][0] = (float)sh[0]; plan.sh[0][1] = (float)sh[1];
+        plan.nv[0] = 1; plan.slot0[0] = 0; plan.ng = 1; plan.nslots = 1;
     };
 
     if (P.rescore) {
-        if (tid == 0) set_cand(0, st.M, st.sh);
+        if (tid == 0) single(st.M, st.sh);
         __syncthreads();
-        evaluate(1);
+        sweep();
         if (tid == 0) st.f = score[0];
         __syncthreads();
     }
+    int nfree = 0;
+    for (int i = 0; i < 5; i++) nfree += P.en[i] ? 1 : 0;
     for (int it = 0; it < P.T; it++) {
-        // ---- neighbours: candidate 2i = +h on parameter i, 2i+1 = -h
-        int ncand = 0;
+        // ---- neighbours: slot 2i = +h on free parameter i (in order psi, theta, phi, x, y), 2i+1 = -h
         if (tid == 0) {
-            int q = 0;
-            for (int i = 0; i < 5; i++) {
+            int q = 0, g = 0;
+            for (int i = 0; i < 3; i++) {
                 if (!P.en[i]) continue;
-                double h = i < 3 ? st.ha : st.hs;
                 for (int sg = 0; sg < 2; sg++) {
-                    double Mq[9], shq[2] = { st.sh[0], st.sh[1] };
-                    for (int k = 0; k < 9; k++) Mq[k] = st.M[k];
-                    double hh = sg ? -h : h;
-                    if (i < 3) d_rot_step(st.M, i, tilt, hh, Mq); else shq[i - 3] += hh;
-                    set_cand(q++, Mq, shq);
+                    double Mq[9];
+                    d_rot_step(st.M, i, tilt, sg ? -st.ha : st.ha, Mq);
+                    set_rot(g, Mq); plan.nv[g] = 1; plan.slot0[g] = q;
+                    plan.sh[q][0] = (float)st.sh[0]; plan.sh[q][1] = (float)st.sh[1];
+                    g++; q++;
                 }
             }
+            if (P.en[3] || P.en[4]) {
+                set_rot(g, st.M); plan.slot0[g] = q; int nv = 0;
+                for (int i = 3; i < 5; i++) {
+                    if (!P.en[i]) continue;
+                    for (int sg = 0; sg < 2; sg++) {
+                        double shq[2] = { st.sh[0], st.sh[1] };
+                        shq[i - 3] += sg ? -st.hs : st.hs;
+                        plan.sh[q][0] = (float)shq[0]; plan.sh[q][1] = (float)shq[1];
+                        q++; nv++;
+                    }
+                }
+                plan.nv[g] = nv; g++;
+            }
+            plan.ng = g; plan.nslots = q;
         }
-        for (int i = 0; i < 5; i++) ncand += P.en[i] ? 2 : 0;
         __syncthreads();
-        if (ncand > 0) {
-            evaluate(ncand);
+        if (nfree > 0) {
+            sweep();
             if (tid == 0) {
                 int q = 0;
                 for (int i = 0; i < 5; i++) {
@@ -182,10 +219,10 @@ __global__ void __launch_bounds__(256) k_local(LocalP P) {
                 for (int k = 0; k < 9; k++) sMt[k] = st.M[k];
                 for (int i = 0; i < 3; i++) if (P.en[i] && sd[i] != 0) { d_rot_step(sMt, i, tilt, sd[i], T9); for (int k = 0; k < 9; k++) sMt[k] = T9[k]; }
                 sshq[0] = st.sh[0] + sd[3]; sshq[1] = st.sh[1] + sd[4];
-                set_cand(0, sMt, sshq);
+                single(sMt, sshq);
             }
             __syncthreads();
-            evaluate(1);
+            sweep();
             if (tid == 0) {
                 double ft = score[0];
                 int bi = -1, bs = 0; double fb = st.f;
