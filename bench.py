@@ -100,26 +100,31 @@ def main():
     if rank == 0:
         total = world * M * a.steps
         value = total / dt
-        # ---- roofline of the dominant kernel: algorithmic bytes per launch / measured launch time
-        S_g, S_l = counts["samples_global"], counts["samples_local"]
+        # ---- roofline of the dominant kernel: algorithmic bytes per launch / measured launch time (HIP events
+        # recorded by the library on its own stream around every launch).  SURVEY.md §8(d) streaming model:
+        # 8 S(r) bytes per orientation evaluated (+ 4 N^2 + 128 per particle for the whole path).
+        S_g = counts["samples_global"]
         launches_g = max(prof["global"]["launches"], 1)
         per_launch_particles = M * a.steps / launches_g
         bytes_g = per_launch_particles * counts["n_global"] * 8.0 * S_g
         ms_g = prof["global"]["ms"] / launches_g
-        # local refinement: hits refine at the search band, the final trajectory at the full band
-        bytes_l_total = M * a.steps * counts["n_local"] * 8.0 * S_l
+        bytes_l_total = M * a.steps * 8.0 * counts["samples_local"]          # samples_local = sum over local evaluations
         ms_l_total = max(prof["local"]["ms"], 1e-9)
         dom = "global" if prof["global"]["ms"] >= prof["local"]["ms"] else "local"
         if dom == "global":
             achieved = bytes_g / (ms_g * 1e-3) / 1e9
-            kname, kms = "k_global", ms_g
+            kname, kms, kbytes = "k_global", ms_g, bytes_g
         else:
+            nl = max(prof["local"]["launches"], 1)
             achieved = bytes_l_total / (ms_l_total * 1e-3) / 1e9
-            kname, kms = "k_local", ms_l_total / max(prof["local"]["launches"], 1)
-        b_pm = 4.0 * N * N + (counts["n_global"] * 8.0 * S_g + counts["n_local"] * 8.0 * S_l) + 128
+            kname, kms, kbytes = "k_local", ms_l_total / nl, bytes_l_total / nl
+        b_pm = 4.0 * N * N + counts["n_global"] * 8.0 * S_g + 8.0 * counts["samples_local"] + 128
         roof = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 4), "traffic": None, "avg_launch_ms": round(kms, 3),
-                "path_bytes_per_particle": b_pm, "path_achieved_GBps": round(b_pm * M * a.steps / dt / 1e9 * 1.0, 1),
+                "algorithmic_bytes_per_launch": kbytes,
+                "note": "streaming-model bytes (8 S(r) per orientation); the slice bank is served from L2 / Infinity Cache and each "
+                        "stored slice serves psi and psi+180, so frac can exceed the HBM-only ceiling; the kernel is fp32-VALU bound",
+                "path_bytes_per_particle": b_pm, "path_achieved_GBps": round(b_pm * M * a.steps / dt / 1e9, 1),
                 "path_frac": round(b_pm * M * a.steps / dt / 8e12, 4)}
         # ---- accuracy of what was timed (vs the synthetic ground truth), first 2000 particles
         k = min(M, 2000)

@@ -73,6 +73,9 @@ typedef struct ppm_refine_cfg {
     int iters_final;          /* further iterations on the best hit / on a local-only start (default 6) */
     float local_angle_step;   /* first step of a local-only refinement, degrees (default 2.5) */
     float local_shift_step;   /* same for shifts, pixels (default 2) */
+    float band_factor;        /* frequency marching: a compass iteration whose largest probe displacement is d pixels
+                                 (mask radius x angular step in radians, or the shift step) scores only rings below
+                                 band_factor * N / (2 pi d), capped by the stage's band.  0 = default 3, < 0 = off */
 } ppm_refine_cfg;
 
 /* Reconstruction settings = numeric answers of the reconstruct3d script (frealign.py:1780-1824). */
@@ -119,8 +122,9 @@ void ppm_reference_destroy(ppm_ref_t *ref);
  * rows_in / rows_out: n_img * PPM_NCOL doubles (host).  Image i belongs to row i. */
 int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *images,
                      int images_on_device, int n_img, const double *rows_in, double *rows_out);
-/* number of orientation evaluations per particle the last ppm_refine_batch performed
- * (global grid, local) — for the roofline's algorithmic byte count */
+/* per particle, for the roofline's algorithmic byte count: orientations of the global grid, local score
+ * evaluations, in-band samples S(r_search) of one grid orientation, and the in-band sample counts summed
+ * over all local evaluations (frequency marching makes early ones cheaper) */
 int ppm_refine_last_counts(ppm_ref_t *ref, long *n_global, long *n_local, long *samples_global,
                            long *samples_local);
 

@@ -81,7 +81,7 @@ def refine_batch(ref, cfg, images, rows, ccf_mode=1):
     images = np.ascontiguousarray(images, dtype=np.float32)
     rows = np.ascontiguousarray(rows, dtype=np.float64)
     out = np.empty_like(rows)
-    counts = np.zeros(2, dtype=np.int64)
+    counts = np.zeros(3, dtype=np.int64)      # orientations, local score evaluations, local sample-evaluations (per particle)
     rc = lib().orc_refine_batch(ref.h, C.byref(cfg), _p(images), len(rows), _p(rows), _p(out), int(ccf_mode), _p(counts))
     if rc:
         raise RuntimeError(f"oracle: refine_batch failed ({rc})")

@@ -381,52 +381,73 @@ static void rot_step(const double M[9], int which, int tilt_frame, double hdeg, 
     mat_mul3(rz, ry, T); mat_mul3(T, rzt, L); mat_mul3(L, M, R); memcpy(out, R, sizeof(R));
 }
 
+/* band of one compass iteration (frequency marching): rings whose phase moves by more than about
+ * band_factor radians under the iteration's largest probe displacement carry no usable gradient */
+static double iter_band(const geom_t *g, double rm_px, double bf, const int en[5], double ha, double hs, double rcap) {
+    if (bf < 0) return rcap;
+    double d = 0;
+    if (en[0] || en[1] || en[2]) d = rm_px * ha * ORC_PI / 180.0;
+    if ((en[3] || en[4]) && hs > d) d = hs;
+    if (!(d > 0)) return rcap;
+    double rit = bf * g->N / (2.0 * ORC_PI * d);
+    if (rit < 4.0) rit = 4.0;
+    return rit < rcap ? rit : rcap;
+}
+
 static void compass_iter(const oref_t *r, const geom_t *g, const ctf_t *c, const cpx *I, const double *wr,
-                         double rmax, const int en[5], cstate_t *s, long *nevals) {
+                         double rcap, double rm_px, double bf, const int en[5], cstate_t *s, long *nevals, double *sevals) {
     /* en[]: psi, theta, phi, x, y.  rotational slots: 0 <- psi; 1,2 <- tilts if both theta and phi are
-     * free, else slot 1 <- theta, slot 2 <- phi as Euler steps */
+     * free, else slot 1 <- theta, slot 2 <- phi as Euler steps.  Every score of one iteration (centre,
+     * 2 per free parameter, trial) is taken at the iteration's band. */
     int tilt = en[1] && en[2];
     int on[5] = { en[0], en[1], en[2], en[3], en[4] };
     double fp[5], fm[5], d[5], Mq[9], shq[2];
-    int any = 0;
-    for (int i = 0; i < 5; i++) {
-        d[i] = 0; fp[i] = fm[i] = -1e300;
-        if (!on[i]) continue;
-        double h = i < 3 ? s->ha : s->hs;
-        for (int sg = 0; sg < 2; sg++) {
-            double hh = sg ? -h : h;
-            memcpy(Mq, s->M, sizeof(Mq)); shq[0] = s->sh[0]; shq[1] = s->sh[1];
-            if (i < 3) rot_step(s->M, i, tilt, hh, Mq); else shq[i - 3] += hh;
-            double v = score_local(r, g, c, I, wr, rmax, Mq, shq);
-            if (sg) fm[i] = v; else fp[i] = v;
-        }
-        *nevals += 2; any = 1;
-        double den = 2.0 * s->f - fp[i] - fm[i];
-        if (den > 1e-12) {
-            double t = 0.5 * h * (fp[i] - fm[i]) / den;
-            d[i] = t > h ? h : (t < -h ? -h : t);
-        } else {
-            double best = fp[i] > fm[i] ? fp[i] : fm[i];
-            d[i] = best > s->f ? (fp[i] > fm[i] ? h : -h) : 0.0;
-        }
-    }
-    if (any) {
-        double Mt[9], T[9];
-        memcpy(Mt, s->M, sizeof(Mt));
-        for (int i = 0; i < 3; i++) if (on[i] && d[i] != 0) { rot_step(Mt, i, tilt, d[i], T); memcpy(Mt, T, sizeof(T)); }
-        shq[0] = s->sh[0] + d[3]; shq[1] = s->sh[1] + d[4];
-        double ft = score_local(r, g, c, I, wr, rmax, Mt, shq); *nevals += 1;
-        int bi = -1, bs = 0; double fb = s->f;
+    int any = 0, nfree = 0;
+    for (int i = 0; i < 5; i++) nfree += on[i] ? 1 : 0;
+    if (nfree) {
+        double rmax = iter_band(g, rm_px, bf, en, s->ha, s->hs, rcap);
+        double sper = floor(ORC_PI * rmax * rmax / 2);
+        double f0 = score_local(r, g, c, I, wr, rmax, s->M, s->sh); *nevals += 1; *sevals += sper;
         for (int i = 0; i < 5; i++) {
+            d[i] = 0; fp[i] = fm[i] = -1e300;
             if (!on[i]) continue;
-            if (fp[i] > fb) { fb = fp[i]; bi = i; bs = 1; }
-            if (fm[i] > fb) { fb = fm[i]; bi = i; bs = -1; }
+            double h = i < 3 ? s->ha : s->hs;
+            for (int sg = 0; sg < 2; sg++) {
+                double hh = sg ? -h : h;
+                memcpy(Mq, s->M, sizeof(Mq)); shq[0] = s->sh[0]; shq[1] = s->sh[1];
+                if (i < 3) rot_step(s->M, i, tilt, hh, Mq); else shq[i - 3] += hh;
+                double v = score_local(r, g, c, I, wr, rmax, Mq, shq);
+                if (sg) fm[i] = v; else fp[i] = v;
+            }
+            *nevals += 2; *sevals += 2 * sper; any = 1;
+            double den = 2.0 * f0 - fp[i] - fm[i];
+            if (den > 1e-12) {
+                double t = 0.5 * h * (fp[i] - fm[i]) / den;
+                d[i] = t > h ? h : (t < -h ? -h : t);
+            } else {
+                double best = fp[i] > fm[i] ? fp[i] : fm[i];
+                d[i] = best > f0 ? (fp[i] > fm[i] ? h : -h) : 0.0;
+            }
         }
-        if (ft > s->f && ft >= fb) { memcpy(s->M, Mt, sizeof(Mt)); s->sh[0] = shq[0]; s->sh[1] = shq[1]; s->f = ft; }
-        else if (bi >= 0) {
-            if (bi < 3) { rot_step(s->M, bi, tilt, bs * s->ha, T); memcpy(s->M, T, sizeof(T)); }
-            else s->sh[bi - 3] += bs * s->hs;
-            s->f = fb;
+        if (any) {
+            double Mt[9], T[9];
+            memcpy(Mt, s->M, sizeof(Mt));
+            for (int i = 0; i < 3; i++) if (on[i] && d[i] != 0) { rot_step(Mt, i, tilt, d[i], T); memcpy(Mt, T, sizeof(T)); }
+            shq[0] = s->sh[0] + d[3]; shq[1] = s->sh[1] + d[4];
+            double ft = score_local(r, g, c, I, wr, rmax, Mt, shq); *nevals += 1; *sevals += sper;
+            int bi = -1, bs = 0; double fb = f0;
+            for (int i = 0; i < 5; i++) {
+                if (!on[i]) continue;
+                if (fp[i] > fb) { fb = fp[i]; bi = i; bs = 1; }
+                if (fm[i] > fb) { fb = fm[i]; bi = i; bs = -1; }
+            }
+            s->f = f0;
+            if (ft > f0 && ft >= fb) { memcpy(s->M, Mt, sizeof(Mt)); s->sh[0] = shq[0]; s->sh[1] = shq[1]; s->f = ft; }
+            else if (bi >= 0) {
+                if (bi < 3) { rot_step(s->M, bi, tilt, bs * s->ha, T); memcpy(s->M, T, sizeof(T)); }
+                else s->sh[bi - 3] += bs * s->hs;
+                s->f = fb;
+            }
         }
     }
     s->ha *= 0.5; s->hs *= 0.5;
@@ -512,6 +533,7 @@ int orc_refine_batch(void *refp, const ppm_refine_cfg *cfg, const float *images,
     double fall = cfg->mask_falloff > 0 ? cfg->mask_falloff : 20.0;
     double dstep = cfg->angular_step > 0 ? cfg->angular_step : 15.0;
     int en[5] = { cfg->refine_psi, cfg->refine_theta, cfg->refine_phi, cfg->refine_x, cfg->refine_y };
+    const double bf = cfg->band_factor == 0 ? 3.0 : cfg->band_factor, rm_px = cfg->mask_radius / g.a;
     size_t nb = (size_t)g.H * g.W;
     int half = (g.n_psi % 2 == 0);                 /* psi and psi+180 share a slice (conjugate) */
     int npsi_store = half ? g.n_psi / 2 : g.n_psi;
@@ -528,8 +550,9 @@ int orc_refine_batch(void *refp, const ppm_refine_cfg *cfg, const float *images,
         }
     }
     long tot_g = 0, tot_l = 0;
+    double tot_s = 0;
     int err = 0;
-#pragma omp parallel for schedule(dynamic, 1) reduction(+ : tot_g, tot_l)
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : tot_g, tot_l, tot_s)
     for (int ip = 0; ip < n_img; ip++) {
         const double *row = rows_in + (size_t)ip * PPM_NCOL;
         double *out = rows_out + (size_t)ip * PPM_NCOL;
@@ -539,7 +562,7 @@ int orc_refine_batch(void *refp, const ppm_refine_cfg *cfg, const float *images,
         cpx *I = (cpx *)malloc(nb * sizeof(cpx));
         double *wr = (double *)malloc((g.B + 2) * sizeof(double)), *wrs = wr, *wrsown = NULL;
         preprocess(img, &g, cfg->mask_radius, fall, cfg->normalize, cfg->invert, 1, 1, g.r_hi, I, wr);
-        long nev = 0;
+        long nev = 0; double sev = 0;
         cstate_t best; memset(&best, 0, sizeof(best));
         if (cfg->global_search) {
             cpx *Is = I, *Isown = NULL;
@@ -584,14 +607,13 @@ int orc_refine_batch(void *refp, const ppm_refine_cfg *cfg, const float *images,
                 s.sh[0] = hits[a].sx * g.step; s.sh[1] = hits[a].sy * g.step;
                 s.ha = 0.5 * dstep; s.hs = g.step;
                 if (cfg->local_refine) {
-                    s.f = score_local(r, &g, &c, I, wr, g.r_s, s.M, s.sh); nev++;
-                    for (int t = 0; t < Tb; t++) compass_iter(r, &g, &c, I, wr, g.r_s, en, &s, &nev);
+                    for (int t = 0; t < Tb; t++) compass_iter(r, &g, &c, I, wr, g.r_s, rm_px, bf, en, &s, &nev, &sev);
                 } else s.f = hits[a].cc;
                 if (!have || s.f > best.f) { best = s; have = 1; }
             }
             if (cfg->local_refine) {       /* the best hit continues at the full band */
-                best.f = score_local(r, &g, &c, I, wr, g.r_hi, best.M, best.sh); nev++;
-                for (int t = 0; t < Tc; t++) compass_iter(r, &g, &c, I, wr, g.r_hi, en, &best, &nev);
+                for (int t = 0; t < Tc; t++) compass_iter(r, &g, &c, I, wr, g.r_hi, rm_px, bf, en, &best, &nev, &sev);
+                best.f = score_local(r, &g, &c, I, wr, g.r_hi, best.M, best.sh); nev++; sev += floor(ORC_PI * g.r_hi * g.r_hi / 2);
             }
             free(hits); free(work); free(Wp); free(C2); free(Isown); free(wrsown);
         } else {
@@ -599,10 +621,10 @@ int orc_refine_batch(void *refp, const ppm_refine_cfg *cfg, const float *images,
             best.sh[0] = row[PPM_XSHIFT] / g.a; best.sh[1] = row[PPM_YSHIFT] / g.a;
             best.ha = cfg->local_angle_step > 0 ? cfg->local_angle_step : 2.5;
             best.hs = cfg->local_shift_step > 0 ? cfg->local_shift_step : 2.0;
-            best.f = score_local(r, &g, &c, I, wr, g.r_hi, best.M, best.sh); nev++;
-            if (cfg->local_refine) for (int t = 0; t < Tb + Tc; t++) compass_iter(r, &g, &c, I, wr, g.r_hi, en, &best, &nev);
+            if (cfg->local_refine) for (int t = 0; t < Tb + Tc; t++) compass_iter(r, &g, &c, I, wr, g.r_hi, rm_px, bf, en, &best, &nev, &sev);
+            best.f = score_local(r, &g, &c, I, wr, g.r_hi, best.M, best.sh); nev++; sev += floor(ORC_PI * g.r_hi * g.r_hi / 2);
         }
-        tot_l += nev;
+        tot_l += nev; tot_s += sev;
         angles_from_matrix(best.M, &out[PPM_PSI], &out[PPM_THETA], &out[PPM_PHI]);
         out[PPM_XSHIFT] = best.sh[0] * g.a; out[PPM_YSHIFT] = best.sh[1] * g.a;
         double cc = best.f, res = 1.0 - cc * cc; if (res < 1e-6) res = 1e-6;
@@ -612,7 +634,7 @@ int orc_refine_batch(void *refp, const ppm_refine_cfg *cfg, const float *images,
         free(I); free(wr);
     }
     free(bank);
-    if (eval_counts) { eval_counts[0] = n_img ? tot_g / n_img : 0; eval_counts[1] = n_img ? tot_l / n_img : 0; }
+    if (eval_counts) { eval_counts[0] = n_img ? tot_g / n_img : 0; eval_counts[1] = n_img ? tot_l / n_img : 0; eval_counts[2] = n_img ? (long)(tot_s / n_img) : 0; }
     return err;
 }
 

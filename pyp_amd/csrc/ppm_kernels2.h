@@ -56,15 +56,19 @@ __device__ inline void d_rot_step(const double *M, int which, int tilt_frame, do
     d_mat_mul3(rz, ry, T); d_mat_mul3(T, rzt, L); d_mat_mul3(L, M, out);
 }
 
+constexpr int kMaxIters = 24;
 struct LocalP {
     CubeView cv; const uint32_t *samples; const float2 *Il; const float *cw;
-    int S_pad, S_used, nrings, N;
-    float rmax2, rlo2, ring_signed;
-    LState *states; int T, rescore; int en[5];
+    int S_pad, nrings, N;
+    float rlo2, ring_signed;
+    LState *states; int T, final_rescore; int en[5];
+    // frequency marching: band (squared) and sample-list prefix of every iteration, and of the final score
+    float rmax2_it[kMaxIters]; int S_it[kMaxIters];
+    float rmax2_final; int S_final;
 };
 
-constexpr int kMaxCand = 11;   // scores produced per sweep: 2 per free parameter, or 1 (trial / rescore)
-constexpr int kMaxGroup = 8;   // gathers per sweep: 6 angular neighbours + the centre (shared by the 4 shift neighbours)
+constexpr int kMaxCand = 11;   // scores per sweep: 2 per free parameter + the centre, or 1 (trial / final score)
+constexpr int kMaxGroup = 7;   // gathers per sweep: 6 angular neighbours + the centre (shared with the 4 shift neighbours)
 
 // sum over aligned groups of 16 lanes with DPP only (quad swaps, then half-row and row mirrors);
 // every lane of the group ends up with the total
@@ -78,11 +82,12 @@ __device__ __forceinline__ float group16_sum_dpp(float v) {
 
 // A sweep evaluates `ng` gather groups; group g = one rotation (6 floats) with nv[g] shift variants, the
 // scores of which go to consecutive slots starting at slot0[g].
-struct SweepPlan { float m[kMaxGroup][6]; float sh[kMaxCand][2]; int nv[kMaxGroup]; int slot0[kMaxGroup]; int ng, nslots; };
+struct SweepPlan { float m[kMaxGroup][6]; float sh[kMaxCand][2]; int nv[kMaxGroup]; int slot0[kMaxGroup]; int ng, nslots, S_used; float rmax2; };
 
-// Block = one trajectory, 256 threads.  A compass iteration scores the neighbouring poses in one sweep
-// over the ring-ordered samples (image value and CTF weight loaded once per sample; the four shift
-// neighbours reuse the centre's interpolated slice value), then one trial pose.  Ring sums: 16-lane DPP
+// Block = one trajectory, 256 threads.  A compass iteration scores the centre and the neighbouring poses in
+// one sweep over the ring-ordered samples (image value and CTF weight loaded once per sample; the centre and
+// the four shift neighbours share one interpolated slice value), then one trial pose; all at the
+// iteration's band (frequency marching: a prefix of the ring-ordered list).  Ring sums: 16-lane DPP
 // reduction (a 16-lane group never straddles a ring), then one LDS atomic per group.
 __global__ void __launch_bounds__(256, 4) k_local(LocalP P) {
     __shared__ SweepPlan plan;
@@ -91,7 +96,7 @@ __global__ void __launch_bounds__(256, 4) k_local(LocalP P) {
     __shared__ float sumC;
     __shared__ double score[kMaxCand];
     __shared__ LState st;
-    __shared__ double sfp[5], sfm[5], sd[5], sMt[9], sshq[2];
+    __shared__ double sfp[5], sfm[5], sd[5], sMt[9], sshq[2], sf0;
     const int tid = threadIdx.x, lane = tid & 63;
     if (tid == 0) st = P.states[blockIdx.x];
     __syncthreads();
@@ -102,20 +107,21 @@ __global__ void __launch_bounds__(256, 4) k_local(LocalP P) {
     const int tilt = P.en[1] && P.en[2];
 
     auto sweep = [&]() {
-        const int nslots = plan.nslots, ng = plan.ng;
+        const int nslots = plan.nslots, ng = plan.ng, S_used = plan.S_used;
+        const float rmax2 = plan.rmax2;
         for (int i = tid; i < nslots * 260; i += 256) (&ringA[0][0])[i] = 0.f;
         if (tid < kMaxCand) sumB[tid] = 0.f;
         if (tid == 0) sumC = 0.f;
         __syncthreads();
         float accC = 0.f;
-        for (int s0 = 0; s0 < P.S_used; s0 += 256) {
+        for (int s0 = 0; s0 < S_used; s0 += 256) {
             const int s = s0 + tid;
             int kx = 0, ky = 0, al = 0, ring = 0;
             float2 iv = make_float2(0.f, 0.f); float c = 0.f;
-            if (s < P.S_used) {
+            if (s < S_used) {
                 unpack_sample(P.samples[s], kx, ky, al, ring);
                 float k2 = (float)(kx * kx + ky * ky);
-                if (!(k2 < P.rmax2 && k2 >= P.rlo2)) al = 0;
+                if (!(k2 < rmax2 && k2 >= P.rlo2)) al = 0;
                 iv = Il[s]; c = cw[s];
             }
             const float fal = (float)al, fkx = (float)kx, fky = (float)ky;
@@ -153,22 +159,15 @@ __global__ void __launch_bounds__(256, 4) k_local(LocalP P) {
         plan.m[g][0] = (float)M[0]; plan.m[g][1] = (float)M[1]; plan.m[g][2] = (float)M[3];
         plan.m[g][3] = (float)M[4]; plan.m[g][4] = (float)M[6]; plan.m[g][5] = (float)M[7];
     };
-    auto single = [&](const double *M, const double *sh) {      // plan for one pose
+    auto single = [&](const double *M, const double *sh) {      // plan for one pose (band fields are set by the caller)
         set_rot(0, M); plan.sh[0][0] = (float)sh[0]; plan.sh[0][1] = (float)sh[1];
         plan.nv[0] = 1; plan.slot0[0] = 0; plan.ng = 1; plan.nslots = 1;
     };
 
-    if (P.rescore) {
-        if (tid == 0) single(st.M, st.sh);
-        __syncthreads();
-        sweep();
-        if (tid == 0) st.f = score[0];
-        __syncthreads();
-    }
     int nfree = 0;
     for (int i = 0; i < 5; i++) nfree += P.en[i] ? 1 : 0;
     for (int it = 0; it < P.T; it++) {
-        // ---- neighbours: slot 2i = +h on free parameter i (in order psi, theta, phi, x, y), 2i+1 = -h
+        // ---- slots: 2 per free angle (+h, -h), then the centre, then 2 per free shift
         if (tid == 0) {
             int q = 0, g = 0;
             for (int i = 0; i < 3; i++) {
@@ -181,38 +180,43 @@ __global__ void __launch_bounds__(256, 4) k_local(LocalP P) {
                     g++; q++;
                 }
             }
-            if (P.en[3] || P.en[4]) {
-                set_rot(g, st.M); plan.slot0[g] = q; int nv = 0;
-                for (int i = 3; i < 5; i++) {
-                    if (!P.en[i]) continue;
-                    for (int sg = 0; sg < 2; sg++) {
-                        double shq[2] = { st.sh[0], st.sh[1] };
-                        shq[i - 3] += sg ? -st.hs : st.hs;
-                        plan.sh[q][0] = (float)shq[0]; plan.sh[q][1] = (float)shq[1];
-                        q++; nv++;
-                    }
+            set_rot(g, st.M); plan.slot0[g] = q;
+            plan.sh[q][0] = (float)st.sh[0]; plan.sh[q][1] = (float)st.sh[1];
+            q++;
+            int nv = 1;
+            for (int i = 3; i < 5; i++) {
+                if (!P.en[i]) continue;
+                for (int sg = 0; sg < 2; sg++) {
+                    double shq[2] = { st.sh[0], st.sh[1] };
+                    shq[i - 3] += sg ? -st.hs : st.hs;
+                    plan.sh[q][0] = (float)shq[0]; plan.sh[q][1] = (float)shq[1];
+                    q++; nv++;
                 }
-                plan.nv[g] = nv; g++;
             }
-            plan.ng = g; plan.nslots = q;
+            plan.nv[g] = nv; g++;
+            plan.ng = g; plan.nslots = q; plan.S_used = P.S_it[it]; plan.rmax2 = P.rmax2_it[it];
         }
         __syncthreads();
         if (nfree > 0) {
             sweep();
             if (tid == 0) {
-                int q = 0;
+                int q = 0, qc = 0;
+                for (int i = 0; i < 3; i++) qc += P.en[i] ? 2 : 0;
+                const double f0 = score[qc];
+                sf0 = f0;
                 for (int i = 0; i < 5; i++) {
                     sd[i] = 0; sfp[i] = sfm[i] = -1e300;
+                    if (i == 3) q = qc + 1;
                     if (!P.en[i]) continue;
                     double h = i < 3 ? st.ha : st.hs;
                     sfp[i] = score[q]; sfm[i] = score[q + 1]; q += 2;
-                    double den = 2.0 * st.f - sfp[i] - sfm[i];
+                    double den = 2.0 * f0 - sfp[i] - sfm[i];
                     if (den > 1e-12) {
                         double t = 0.5 * h * (sfp[i] - sfm[i]) / den;
                         sd[i] = t > h ? h : (t < -h ? -h : t);
                     } else {
                         double best = sfp[i] > sfm[i] ? sfp[i] : sfm[i];
-                        sd[i] = best > st.f ? (sfp[i] > sfm[i] ? h : -h) : 0.0;
+                        sd[i] = best > f0 ? (sfp[i] > sfm[i] ? h : -h) : 0.0;
                     }
                 }
                 double T9[9];
@@ -224,14 +228,15 @@ __global__ void __launch_bounds__(256, 4) k_local(LocalP P) {
             __syncthreads();
             sweep();
             if (tid == 0) {
-                double ft = score[0];
-                int bi = -1, bs = 0; double fb = st.f;
+                const double ft = score[0], f0 = sf0;
+                int bi = -1, bs = 0; double fb = f0;
                 for (int i = 0; i < 5; i++) {
                     if (!P.en[i]) continue;
                     if (sfp[i] > fb) { fb = sfp[i]; bi = i; bs = 1; }
                     if (sfm[i] > fb) { fb = sfm[i]; bi = i; bs = -1; }
                 }
-                if (ft > st.f && ft >= fb) {
+                st.f = f0;
+                if (ft > f0 && ft >= fb) {
                     for (int k = 0; k < 9; k++) st.M[k] = sMt[k];
                     st.sh[0] = sshq[0]; st.sh[1] = sshq[1]; st.f = ft;
                 } else if (bi >= 0) {
@@ -242,6 +247,13 @@ __global__ void __launch_bounds__(256, 4) k_local(LocalP P) {
             }
         }
         if (tid == 0) { st.ha *= 0.5; st.hs *= 0.5; }
+        __syncthreads();
+    }
+    if (P.final_rescore) {
+        if (tid == 0) { single(st.M, st.sh); plan.S_used = P.S_final; plan.rmax2 = P.rmax2_final; }
+        __syncthreads();
+        sweep();
+        if (tid == 0) st.f = score[0];
         __syncthreads();
     }
     if (tid == 0) P.states[blockIdx.x] = st;

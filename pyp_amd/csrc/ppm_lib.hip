@@ -299,7 +299,7 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
     const int S_pad = (int)sl.packed.size();
     const int nrings = gm.B + 2;
     int ring_s = (int)std::ceil(gm.r_s); if (ring_s > gm.B + 1) ring_s = gm.B + 1;
-    const int S_search = sl.ring_off[ring_s];
+    (void)ring_s;
     if (int rc = ref->samples.ensure(S_pad)) return rc;
     HIPCHK(hipMemcpyAsync(ref->samples.p, sl.packed.data(), S_pad * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
 
@@ -380,13 +380,39 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
     }
     HIPCHK(hipStreamSynchronize(g.stream));
 
+    // frequency marching: band of a compass iteration from its probe displacement (same rule as the oracle's iter_band)
+    const double bf = cfg->band_factor == 0 ? 3.0 : cfg->band_factor, rm_px = cfg->mask_radius / gm.a;
+    const bool any_ang = cfg->refine_psi || cfg->refine_theta || cfg->refine_phi, any_sh = cfg->refine_x || cfg->refine_y;
+    auto iter_band = [&](double ha, double hs, double rcap) {
+        if (bf < 0) return rcap;
+        double d = 0;
+        if (any_ang) d = rm_px * ha * kPi / 180.0;
+        if (any_sh && hs > d) d = hs;
+        if (!(d > 0)) return rcap;
+        double rit = bf * gm.N / (2.0 * kPi * d);
+        if (rit < 4.0) rit = 4.0;
+        return rit < rcap ? rit : rcap;
+    };
+    auto prefix_of = [&](double rband) { int rg = (int)std::ceil(rband); if (rg > gm.B + 1) rg = gm.B + 1; return sl.ring_off[rg]; };
+    double sample_evals = 0;   // in-band samples summed over all local score evaluations of one particle
     LocalP LP;
     LP.cv = cv; LP.samples = ref->samples.p; LP.Il = ref->Il.p; LP.cw = ref->cw.p; LP.S_pad = S_pad; LP.nrings = nrings; LP.N = gm.N;
     LP.rlo2 = (float)(gm.r_lo * gm.r_lo); LP.ring_signed = (float)std::min(gm.ring_signed, 1e30);
     LP.en[0] = cfg->refine_psi; LP.en[1] = cfg->refine_theta; LP.en[2] = cfg->refine_phi; LP.en[3] = cfg->refine_x; LP.en[4] = cfg->refine_y;
 
-    long n_local_evals = 0;
-    const int ncand = 2 * ((cfg->refine_psi != 0) + (cfg->refine_theta != 0) + (cfg->refine_phi != 0) + (cfg->refine_x != 0) + (cfg->refine_y != 0));
+    const int nfree = (cfg->refine_psi != 0) + (cfg->refine_theta != 0) + (cfg->refine_phi != 0) + (cfg->refine_x != 0) + (cfg->refine_y != 0);
+    const int per_iter = nfree ? 2 * nfree + 2 : 0;     // centre + 2 per free parameter + trial
+    if (Tb + Tc > kMaxIters) return fail(-22, "too many compass iterations requested");
+    auto fill_schedule = [&](double ha, double hs, int t0, int T, double rcap, double mult) {
+        for (int t = 0; t < T; t++) {
+            double rb = iter_band(ha, hs, rcap);
+            LP.rmax2_it[t] = (float)(rb * rb); LP.S_it[t] = prefix_of(rb);
+            sample_evals += mult * per_iter * std::floor(kPi * rb * rb / 2);
+            ha *= 0.5; hs *= 0.5;
+        }
+        (void)t0;
+    };
+    LP.rmax2_final = (float)(gm.r_hi * gm.r_hi); LP.S_final = S_pad;
     for (int c0 = 0; c0 < n_img; c0 += CH) {
         const int nb = std::min(CH, n_img - c0);
         HIPCHK(hipMemcpyAsync(ref->rows_in.p, rows_in + (size_t)c0 * PPM_NCOL, (size_t)nb * PPM_NCOL * sizeof(double), hipMemcpyHostToDevice, g.stream));
@@ -417,24 +443,30 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
                                    ref->dir_theta.p, ref->dir_phi.p, gm.n_psi, gm.dpsi, gm.step, 0.5 * gm.dstep, (double)gm.step);
             }
             if (cfg->local_refine) {
-                LP.states = ref->states.p; LP.T = Tb; LP.rescore = 1; LP.S_used = S_search; LP.rmax2 = (float)(gm.r_s * gm.r_s);
+                sample_evals = 0;
+                LP.states = ref->states.p; LP.T = Tb; LP.final_rescore = 0;
+                fill_schedule(0.5 * gm.dstep, (double)gm.step, 0, Tb, gm.r_s, (double)K);
                 ProfScope ps(PPM_K_LOCAL);
                 hipLaunchKernelGGL(k_local, dim3(nb * K), dim3(256), 0, g.stream, LP);
-                n_local_evals += (long)K * (1 + (long)Tb * (ncand + 1));
             }
             {
                 ProfScope ps(PPM_K_TOPK);
                 hipLaunchKernelGGL(k_select_best, dim3((nb + 255) / 256), dim3(256), 0, g.stream, ref->states.p, ref->states2.p, nb, K);
             }
             if (cfg->local_refine) {
-                LP.states = ref->states2.p; LP.T = Tc; LP.rescore = 1; LP.S_used = S_pad; LP.rmax2 = (float)(gm.r_hi * gm.r_hi);
+                LP.states = ref->states2.p; LP.T = Tc; LP.final_rescore = 1;
+                fill_schedule(0.5 * gm.dstep / (double)(1 << Tb), (double)gm.step / (double)(1 << Tb), Tb, Tc, gm.r_hi, 1.0);
+                sample_evals += std::floor(kPi * gm.r_hi * gm.r_hi / 2);
                 ProfScope ps(PPM_K_LOCAL);
                 hipLaunchKernelGGL(k_local, dim3(nb), dim3(256), 0, g.stream, LP);
             }
         } else {
             double ha0 = cfg->local_angle_step > 0 ? cfg->local_angle_step : 2.5, hs0 = cfg->local_shift_step > 0 ? cfg->local_shift_step : 2.0;
             hipLaunchKernelGGL(k_states_from_rows, dim3((nb + 255) / 256), dim3(256), 0, g.stream, ref->rows_in.p, ref->states2.p, nb, gm.a, ha0, hs0);
-            LP.states = ref->states2.p; LP.T = cfg->local_refine ? Tb + Tc : 0; LP.rescore = 1; LP.S_used = S_pad; LP.rmax2 = (float)(gm.r_hi * gm.r_hi);
+            sample_evals = 0;
+            LP.states = ref->states2.p; LP.T = cfg->local_refine ? Tb + Tc : 0; LP.final_rescore = 1;
+            fill_schedule(ha0, hs0, 0, LP.T, gm.r_hi, 1.0);
+            sample_evals += std::floor(kPi * gm.r_hi * gm.r_hi / 2);
             ProfScope ps(PPM_K_LOCAL);
             hipLaunchKernelGGL(k_local, dim3(nb), dim3(256), 0, g.stream, LP);
         }
@@ -445,13 +477,12 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
     }
     // evaluation counts per particle, for the roofline's algorithmic bytes
     long nl;
-    if (cfg->global_search) nl = cfg->local_refine ? (long)K * (1 + (long)Tb * (ncand + 1)) + 1 + (long)Tc * (ncand + 1) : 0;
-    else nl = 1 + (cfg->local_refine ? (long)(Tb + Tc) * (ncand + 1) : 0);
+    if (cfg->global_search) nl = cfg->local_refine ? (long)K * Tb * per_iter + (long)Tc * per_iter + 1 : 0;
+    else nl = 1 + (cfg->local_refine ? (long)(Tb + Tc) * per_iter : 0);
     ref->last_counts[0] = cfg->global_search ? gm.n_orient : 0;
     ref->last_counts[1] = nl;
     ref->last_counts[2] = (long)std::floor(kPi * gm.r_s * gm.r_s / 2);
-    ref->last_counts[3] = (long)std::floor(kPi * gm.r_hi * gm.r_hi / 2);
-    (void)n_local_evals;
+    ref->last_counts[3] = (long)sample_evals;      // sum over the local evaluations of their in-band sample counts
     return 0;
 }
 

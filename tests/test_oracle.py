@@ -53,7 +53,7 @@ def test_local_refinement_converges_from_perturbed_start(data):
     vol, imgs, rows, ref = data
     start = synth.perturb_rows(rows, 2.0, 1.0, PX)
     out, counts = oracle.refine_batch(ref, cfg_for(global_search=0), imgs, start)
-    assert counts[0] == 0 and counts[1] == 1 + 9 * 11
+    assert counts[0] == 0 and counts[1] == 9 * 12 + 1     # per iteration: centre + 2 x 5 neighbours + trial; one final score
     assert np.median(synth.angular_error_deg(out, rows)) < 0.5
     assert synth.angular_error_deg(out, rows).max() < synth.angular_error_deg(start, rows).max()
     assert synth.shift_error_px(out, rows, PX).max() < 0.2
