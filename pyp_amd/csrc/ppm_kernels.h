@@ -249,10 +249,12 @@ __global__ void __launch_bounds__(256) k_bank(BankP P) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, per = (size_t)P.Hs * 64;
     if (i >= per * P.nslices) return;
     int sl = (int)(i / per), r = (int)(i - (size_t)sl * per);
-    int kx = r & 63, ky = (r >> 6) - P.Bs;
+    // rows are stored in the paired order of k_global: row 0 = ky 0, row 1 = empty, row 2t = +t, row 2t+1 = -t
+    int kx = r & 63, rr = r >> 6, t = rr >> 1;
+    int ky = (rr & 1) ? -t : t;
     float k2 = (float)(kx * kx + ky * ky);
     float2 v = make_float2(0.f, 0.f);
-    if (kx <= P.Bs && k2 < P.r_s2) {
+    if (rr != 1 && t <= P.Bs && kx <= P.Bs && k2 < P.r_s2) {
         const float *m = P.mats + (size_t)sl * 6;
         float fx = (float)kx, fy = (float)ky;
         v = sample_cube(P.cv, m[0] * fx + m[1] * fy, m[2] * fx + m[3] * fy, m[4] * fx + m[5] * fy);
@@ -270,12 +272,12 @@ struct GlobP {
     int Bs, Hs, HsP, Ns, RSx, RSy, n_dir, n_psi, npsi_store, n_orient, K;
 };
 
-// Row twiddles e^{+2 pi i ky j / Ns}, [row][j-1]: wave-uniform, so they are fetched with scalar loads.
-constexpr int kRowTwRows = 128;
+// Pair twiddles e^{+2 pi i t j / Ns}, [t][j-1] for the row pair ky = +-t: wave-uniform, fetched with scalar loads.
+constexpr int kRowTwRows = 64;
 __constant__ float2 c_rowtw[kRowTwRows * PPM_MAX_SHIFT_STEPS];
 
 constexpr int global_threads(int R) { return R <= 3 ? 1024 : 512; }   // wider windows need > 128 VGPRs
-constexpr int global_unroll(int R) { return R <= 3 ? 8 : 4; }         // rows in flight per wave (prefetch depth)
+constexpr int global_unroll(int R) { return R <= 3 ? 8 : 4; }         // rows in flight per wave (prefetch depth), even
 
 // pairwise halving step of a cross-lane reduction: afterwards lanes with (lane & m) == 0 carry the
 // partial sum of `a`, the others that of `b`
@@ -306,24 +308,28 @@ __device__ __forceinline__ float reduce_halving(float (&v)[NV], int lane) {
 }
 
 // Block = one particle.  The particle's CTF-weighted spectrum W and CTF^2 table sit in LDS for the whole
-// orientation loop; each wave streams whole slices of the bank: lane = kx, rows = ky, U rows prefetched
-// ahead.  Per slice sample: Q1 = W conj(P) (orientation psi) and Q2 = W P (psi + 180 deg).  The
-// partial transforms over ky are accumulated as U_j = sum Q cos(2 pi ky j/Ns), V_j = sum Q sin(...)
-// (4 FMA per j instead of 8: G(+-j) = U +- iV is formed once per slice); the sum over kx of the shift
-// window is a wavefront halving reduction.
+// orientation loop; each wave streams whole slices of the bank: lane = kx, rows = ky in +-t pairs, U rows
+// prefetched ahead.  With P the slice sample, A = Re(P) W and Bq = Im(P) (Wy, -Wx): W conj(P) = A + Bq
+// (orientation psi) and W P = A - Bq (psi + 180 deg).  The transforms over ky use the even / odd parts of a
+// row pair: sum_ky Q e^{i 2 pi ky j/Ns} = sum_t (Q(+t) + Q(-t)) cos + i (Q(+t) - Q(-t)) sin, accumulated in the
+// (A, Bq) basis — 8 FMA per shift row j and row PAIR for both orientations — and recombined once per slice;
+// the sum over kx of the shift window is a wavefront halving reduction.
 template <int R, bool HALF>
 __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
     constexpr int NT = global_threads(R), NW = NT / 64, U = global_unroll(R), NS = 2 * R + 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = blockIdx.x;
-    const int Hs = P.Hs, HsP = P.HsP, Ns = P.Ns, nsamp = Hs * 64, nsampP = HsP * 64;
+    const int Hs = P.Hs, HsP = P.HsP, Bs = P.Bs, Ns = P.Ns, nsampP = HsP * 64;
     float2 *Wl = (float2 *)smem;
     float *C2l = (float *)(Wl + nsampP);
     {
-        const float2 *src = P.Wp + (size_t)p * nsamp; const float *src2 = P.C2 + (size_t)p * nsamp;
+        const float2 *src = P.Wp + (size_t)p * Hs * 64; const float *src2 = P.C2 + (size_t)p * Hs * 64;
         for (int i = tid; i < nsampP; i += NT) {
-            Wl[i] = i < nsamp ? src[i] : make_float2(0.f, 0.f);
-            C2l[i] = i < nsamp ? src2[i] : 0.f;
+            const int rr = i >> 6, t = rr >> 1, ky = (rr & 1) ? -t : t;
+            const bool ok = rr != 1 && t <= Bs;
+            const int srow = ky + Bs;
+            Wl[i] = ok ? src[srow * 64 + (i & 63)] : make_float2(0.f, 0.f);
+            C2l[i] = ok ? src2[srow * 64 + (i & 63)] : 0.f;
         }
     }
     __syncthreads();
@@ -338,10 +344,11 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
     float *ccp = P.cc + (size_t)p * P.n_orient; int *shp = P.sh + (size_t)p * P.n_orient;
     for (int sl = wave; sl < nslices; sl += NW) {
         const float2 *Pp = P.bank + (size_t)sl * nsampP + lane;
-        float s1x = 0.f, s1y = 0.f, s2x = 0.f, s2y = 0.f, nP = 0.f;
-        float u1x[R], u1y[R], v1x[R], v1y[R], u2x[R], u2y[R], v2x[R], v2y[R];
+        // accumulators: s* = sum over rows (shift row 0); per j: even part x cos (ua, ub), odd part x sin (va, vb)
+        float sax = 0.f, say = 0.f, sbx = 0.f, sby = 0.f, nP = 0.f;
+        float uax[R], uay[R], ubx[R], uby[R], vax[R], vay[R], vbx[R], vby[R];
 #pragma unroll
-        for (int j = 0; j < R; j++) { u1x[j] = u1y[j] = v1x[j] = v1y[j] = u2x[j] = u2y[j] = v2x[j] = v2y[j] = 0.f; }
+        for (int j = 0; j < R; j++) { uax[j] = uay[j] = ubx[j] = uby[j] = vax[j] = vay[j] = vbx[j] = vby[j] = 0.f; }
         float2 pv[U], pn[U];
 #pragma unroll
         for (int u = 0; u < U; u++) pv[u] = Pp[u * 64];
@@ -351,26 +358,26 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
                 for (int u = 0; u < U; u++) pn[u] = Pp[(row0 + U + u) * 64];
             }
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int row = row0 + u;
-                const float2 wv = Wl[row * 64 + lane];
-                const float c2 = C2l[row * 64 + lane];
-                const float px = pv[u].x, py = pv[u].y;
-                const float a = wv.x * px, b = wv.y * py, c = wv.y * px, d = wv.x * py;
-                const float q1x = a + b, q1y = c - d;      // W conj(P)
-                const float q2x = a - b, q2y = c + d;      // W P
-                nP = fmaf(c2, fmaf(px, px, py * py), nP);
-                s1x += q1x; s1y += q1y;
-                if (HALF) { s2x += q2x; s2y += q2y; }
+            for (int u = 0; u < U; u += 2) {
+                const int ra = row0 + u, rb = ra + 1, tp = ra >> 1;
+                const float2 wa = Wl[ra * 64 + lane], wb = Wl[rb * 64 + lane];
+                const float ca = C2l[ra * 64 + lane], cb = C2l[rb * 64 + lane];
+                const float pax = pv[u].x, pay = pv[u].y, pbx = pv[u + 1].x, pby = pv[u + 1].y;
+                nP = fmaf(ca, fmaf(pax, pax, pay * pay), nP);
+                nP = fmaf(cb, fmaf(pbx, pbx, pby * pby), nP);
+                // A = Re(P) W, Bq = Im(P) (Wy, -Wx) for both rows; even (+) and odd (-) parts of the pair
+                const float aax = pax * wa.x, aay = pax * wa.y, bax = pay * wa.y, bay = -pay * wa.x;
+                const float abx = pbx * wb.x, aby = pbx * wb.y, bbx = pby * wb.y, bby = -pby * wb.x;
+                const float asx = aax + abx, asy = aay + aby, adx = aax - abx, ady = aay - aby;
+                const float bsx = bax + bbx, bsy = bay + bby, bdx = bax - bbx, bdy = bay - bby;
+                sax += asx; say += asy; sbx += bsx; sby += bsy;
 #pragma unroll
                 for (int j = 0; j < R; j++) {
-                    const float2 t = c_rowtw[row * PPM_MAX_SHIFT_STEPS + j];     // wave-uniform -> SGPRs
-                    u1x[j] = fmaf(q1x, t.x, u1x[j]); u1y[j] = fmaf(q1y, t.x, u1y[j]);
-                    v1x[j] = fmaf(q1x, t.y, v1x[j]); v1y[j] = fmaf(q1y, t.y, v1y[j]);
-                    if (HALF) {
-                        u2x[j] = fmaf(q2x, t.x, u2x[j]); u2y[j] = fmaf(q2y, t.x, u2y[j]);
-                        v2x[j] = fmaf(q2x, t.y, v2x[j]); v2y[j] = fmaf(q2y, t.y, v2y[j]);
-                    }
+                    const float2 t = c_rowtw[tp * PPM_MAX_SHIFT_STEPS + j];     // wave-uniform -> SGPRs
+                    uax[j] = fmaf(asx, t.x, uax[j]); uay[j] = fmaf(asy, t.x, uay[j]);
+                    ubx[j] = fmaf(bsx, t.x, ubx[j]); uby[j] = fmaf(bsy, t.x, uby[j]);
+                    vax[j] = fmaf(adx, t.y, vax[j]); vay[j] = fmaf(ady, t.y, vay[j]);
+                    vbx[j] = fmaf(bdx, t.y, vbx[j]); vby[j] = fmaf(bdy, t.y, vby[j]);
                 }
             }
 #pragma unroll
@@ -381,18 +388,20 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
         const int dir = sl / P.npsi_store, ks = sl - dir * P.npsi_store;
 #pragma unroll
         for (int e = 0; e < (HALF ? 2 : 1); e++) {
-            // G[iy] = U + iV for iy > R, U - iV for iy < R; value(iy, ix) = Re(G[iy] e^{+2 pi i kx (ix-R)/Ns})
-            float best = -3.0e38f; int bsx = 0, bsy = 0;
+            // this orientation's Q = A + sg Bq: U = ua + sg ub, V = va + sg vb; G(+j) = U + iV, G(-j) = U - iV;
+            // value(iy, ix) = Re(G[iy] e^{+2 pi i kx (ix-R)/Ns})
+            const float sg = e ? -1.f : 1.f;
+            float best = -3.0e38f; int bsx_ = 0, bsy_ = 0;
             if constexpr (NS * NS <= 64) {
                 float val[NS * NS];
 #pragma unroll
                 for (int iy = 0; iy < NS; iy++) {
                     const int jy = iy - R, ja = jy < 0 ? -jy : jy;
                     float gx, gy;
-                    if (jy == 0) { gx = e ? s2x : s1x; gy = e ? s2y : s1y; }
+                    if (jy == 0) { gx = sax + sg * sbx; gy = say + sg * sby; }
                     else {
-                        const float ux = e ? u2x[ja - 1] : u1x[ja - 1], uy = e ? u2y[ja - 1] : u1y[ja - 1];
-                        const float vx = e ? v2x[ja - 1] : v1x[ja - 1], vy = e ? v2y[ja - 1] : v1y[ja - 1];
+                        const float ux = uax[ja - 1] + sg * ubx[ja - 1], uy = uay[ja - 1] + sg * uby[ja - 1];
+                        const float vx = vax[ja - 1] + sg * vbx[ja - 1], vy = vay[ja - 1] + sg * vby[ja - 1];
                         gx = jy > 0 ? ux - vy : ux + vy; gy = jy > 0 ? uy + vx : uy - vx;
                     }
                     val[iy * NS + R] = gx;
@@ -414,16 +423,16 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
                     float ov = __shfl_xor(cand, m, 64); int oi = __shfl_xor(ci, m, 64);
                     if (ov > cand || (ov == cand && oi < ci)) { cand = ov; ci = oi; }
                 }
-                best = cand; bsy = ci / NS - R; bsx = ci - (ci / NS) * NS - R;
+                best = cand; bsy_ = ci / NS - R; bsx_ = ci - (ci / NS) * NS - R;
             } else {
 #pragma unroll
                 for (int iy = 0; iy < NS; iy++) {
                     const int jy = iy - R, ja = jy < 0 ? -jy : jy;
                     float gx, gy;
-                    if (jy == 0) { gx = e ? s2x : s1x; gy = e ? s2y : s1y; }
+                    if (jy == 0) { gx = sax + sg * sbx; gy = say + sg * sby; }
                     else {
-                        const float ux = e ? u2x[ja - 1] : u1x[ja - 1], uy = e ? u2y[ja - 1] : u1y[ja - 1];
-                        const float vx = e ? v2x[ja - 1] : v1x[ja - 1], vy = e ? v2y[ja - 1] : v1y[ja - 1];
+                        const float ux = uax[ja - 1] + sg * ubx[ja - 1], uy = uay[ja - 1] + sg * uby[ja - 1];
+                        const float vx = vax[ja - 1] + sg * vbx[ja - 1], vy = vay[ja - 1] + sg * vby[ja - 1];
                         gx = jy > 0 ? ux - vy : ux + vy; gy = jy > 0 ? uy + vx : uy - vx;
                     }
 #pragma unroll
@@ -432,14 +441,14 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
                         float v = j >= 0 ? (gx * txc[jx] - gy * txs[jx]) : (gx * txc[jx] + gy * txs[jx]);
                         v = wave_sum(v);
                         bool ok = (jx <= P.RSx) && (ja <= P.RSy);
-                        if (ok && v > best) { best = v; bsx = j; bsy = jy; }
+                        if (ok && v > best) { best = v; bsx_ = j; bsy_ = jy; }
                     }
                 }
             }
             if (lane == 0) {
                 int o = dir * P.n_psi + ks + e * P.npsi_store;
                 ccp[o] = best * inv;
-                shp[o] = (bsx & 0xffff) | (bsy << 16);
+                shp[o] = (bsx_ & 0xffff) | (bsy_ << 16);
             }
         }
     }

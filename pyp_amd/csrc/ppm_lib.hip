@@ -305,7 +305,8 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
 
     const size_t NN = (size_t)gm.N * gm.N, HW = (size_t)gm.H * gm.W, HS = (size_t)gm.Hs * 64;
     const int Rwin = std::max(gm.RSx, gm.RSy);
-    const int HsP = ((gm.Hs + global_unroll(Rwin) - 1) / global_unroll(Rwin)) * global_unroll(Rwin);   // bank rows per slice (zero padded)
+    // bank rows per slice in the paired order of k_global: row 0 = ky 0, row 1 = empty, rows 2t / 2t+1 = ky +t / -t
+    const int HsP = ((2 * (gm.Bs + 1) + global_unroll(Rwin) - 1) / global_unroll(Rwin)) * global_unroll(Rwin);
     const size_t HSP = (size_t)HsP * 64;
     const int nslices = gm.n_dir * gm.npsi_store;
     // chunk so that the scratch stays well inside HBM
@@ -360,9 +361,9 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
             // row twiddles of the shift window -> __constant__ (scalar loads in k_global)
             {
                 std::vector<float2> rt((size_t)kRowTwRows * PPM_MAX_SHIFT_STEPS, make_float2(1.f, 0.f));
-                for (int row = 0; row < HsP && row < kRowTwRows; row++) for (int j = 1; j <= PPM_MAX_SHIFT_STEPS; j++) {
-                    int t = (((row - gm.Bs) * j) % gm.Ns + gm.Ns) % gm.Ns;
-                    rt[(size_t)row * PPM_MAX_SHIFT_STEPS + j - 1] = make_float2((float)std::cos(2.0 * kPi * t / gm.Ns), (float)std::sin(2.0 * kPi * t / gm.Ns));
+                for (int tp = 0; tp <= gm.Bs && tp < kRowTwRows; tp++) for (int j = 1; j <= PPM_MAX_SHIFT_STEPS; j++) {
+                    int t = ((tp * j) % gm.Ns + gm.Ns) % gm.Ns;
+                    rt[(size_t)tp * PPM_MAX_SHIFT_STEPS + j - 1] = make_float2((float)std::cos(2.0 * kPi * t / gm.Ns), (float)std::sin(2.0 * kPi * t / gm.Ns));
                 }
                 HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_rowtw), rt.data(), rt.size() * sizeof(float2)));
             }
