@@ -36,6 +36,9 @@ def parse():
     ap.add_argument("--unique", type=int, default=512, help="distinct clean projections (each particle gets fresh noise)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target wall time of the CPU oracle sample (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--workload", choices=["refine", "reconstruct"], default="refine",
+                    help="refine = BASELINE.json configs[1] (the headline metric); reconstruct = configs[2]: Fourier insertion into "
+                         "half-map accumulators + one all-reduce over the ranks")
     return ap.parse_args()
 
 
@@ -66,6 +69,8 @@ def main():
     cfg = RefineCfg.make(box=N, pixel_size=px, mask_radius=0.32 * N * px, res_high=res, res_search=res, res_low=0.0,
                          angular_step=a.angular_step, top_hits=20, search_range_x=6.0 * px, search_range_y=6.0 * px,
                          res_signed_cc=30.0, molecular_mass_kda=500.0)
+    if a.workload == "reconstruct":
+        return reconstruct_bench(a, rank, world, local, dev, vol, stack, rows, N, M, px)
     t0 = time.time()
     ref = host.Reference(vol, N / 2, device=local)
     t_refprep = time.time() - t0
@@ -119,8 +124,9 @@ def main():
             achieved = bytes_l_total / (ms_l_total * 1e-3) / 1e9
             kname, kms, kbytes = "k_local", ms_l_total / nl, bytes_l_total / nl
         b_pm = 4.0 * N * N + counts["n_global"] * 8.0 * S_g + 8.0 * counts["samples_local"] + 128
+        traffic, traffic_src = pmc_traffic(kname, per_launch_particles if dom == "global" else M * a.steps / max(prof["local"]["launches"], 1))
         roof = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 4), "traffic": None, "avg_launch_ms": round(kms, 3),
+                "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(kms, 3),
                 "algorithmic_bytes_per_launch": kbytes,
                 "note": "streaming-model bytes (8 S(r) per orientation); the slice bank is served from L2 / Infinity Cache and each "
                         "stored slice serves psi and psi+180, so frac can exceed the HBM-only ceiling; the kernel is fp32-VALU bound",
@@ -145,6 +151,95 @@ def main():
         }
         if not a.no_cpu and a.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(vol, stack, start_rows, cfg, N, a.cpu_seconds)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def pmc_traffic(kernel, particles_per_launch):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc summary (separate FETCH_SIZE and
+    WRITE_SIZE passes; units of 1 KB; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), scaled from
+    the profiled particle count to this launch.  None when no summary is committed."""
+    path = os.path.join(ROOT, "profiles", "r01_v3_pmc_summary_8k.json")
+    if not os.path.exists(path):
+        return None, None
+    d = json.load(open(path))
+    key = [k for k in d if kernel in k]
+    if not key or "FETCH_SIZE" not in d[key[0]] or "WRITE_SIZE" not in d[key[0]]:
+        return None, None
+    e = d[key[0]]
+    per_particle = (2.0 * e["FETCH_SIZE"]["sum"] + e["WRITE_SIZE"]["sum"]) * 1024.0 / 8000.0
+    return per_particle * particles_per_launch, "profiles/r01_v3_pmc_summary_8k.json (8000 particles, FETCH_SIZE x2 + WRITE_SIZE, KB)"
+
+
+def reconstruct_bench(a, rank, world, local, dev, vol, stack, rows, N, M, px):
+    """configs[2]: every rank inserts its particles into private accumulators (a torch tensor handed to the
+    library), then ONE all-reduce (sum, f32) over RCCL; finalisation on rank 0 is outside the timed region."""
+    import torch
+    import torch.distributed as dist
+    from pyp_amd import dist as pdist
+    from pyp_amd import host
+    from pyp_amd.abi import FinalCfg, ReconCfg
+    nfl = int(host.lib.load().ppm_accum_floats(N))
+    host.lib.init(local)
+    acc_t = torch.zeros(nfl, dtype=torch.float32, device=dev)
+    acc = host.Accumulator(N, px, "C1", device=local, ext_tensor=acc_t)
+    rows = rows.copy()
+    rows[:, 0] += rank * M                 # global positions: half assignment must not depend on the rank count
+    rc = ReconCfg(box=N, pixel_size=px, res_limit=2 * px, score_weight_bfactor=0.0, score_average=0.0, score_threshold=0.0,
+                  normalize=1, invert=0, split_by_pind=0, mask_radius=0.32 * N * px)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        host.lib.load().ppm_device_sync()
+
+    def step():
+        acc_t.zero_()
+        torch.cuda.synchronize()
+        acc.set_counts(0, 0)
+        acc.insert(rc, stack, rows)
+        return pdist.reduce_accumulators(acc_t, acc.counts())[1]
+
+    counts = None
+    for _ in range(a.warmup):
+        counts = step()
+    host.profile(True, True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        counts = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    prof = host.profile_report()
+    host.profile(False, False)
+    if rank == 0:
+        S = int(np.floor(np.pi * (N / 2) ** 2 / 2))
+        b_ins = 4.0 * N * N + S * 192.0
+        nl = max(prof["insert"]["launches"], 1)
+        ms = prof["insert"]["ms"] / nl
+        achieved = (M * a.steps / nl) * (S * 192.0) / (ms * 1e-3) / 1e9
+        acc.set_counts(counts[0], counts[1])
+        h1, h2, fl, stats = acc.finalize(FinalCfg(molecular_mass_kda=500.0, inner_radius=0.0, outer_radius=0.45 * N * px, mask_falloff=0.0))
+        cc = float(np.corrcoef(fl.ravel(), vol.ravel())[0, 1])
+        line = {"metric": "particles/sec Fourier insertion, 256^2 box", "value": round(world * M * a.steps / dt, 1), "unit": "particles/s",
+                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "3D reconstruction: Fourier-insert %dk %d^2 particles/GPU -> %d^3 half-maps, C1, one all-reduce"
+                           % (M // 1000, N, N), "particles_per_gpu": M, "box": N, "parallelism": "particle-sharded x%d" % world},
+                "roofline": {"bound": "hbm", "kernel": "k_insert", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+                             "frac": round(achieved / 8000.0, 4), "traffic": None, "avg_launch_ms": round(ms, 3),
+                             "note": "algorithmic bytes = S(N/2) x 8 taps x 12 B x 2 (read-modify-write) per particle; the practical ceiling "
+                                     "is the float-atomic rate (about 1.3 TB/s of added bytes = 0.33 of this figure)",
+                             "path_bytes_per_particle": b_ins},
+                "kernels_ms": {k2: round(v["ms"], 2) for k2, v in prof.items() if v["launches"]},
+                "map_cc_vs_truth": round(cc, 4), "fsc_at_half_nyquist": round(float(stats[N // 4 - 1, 3]), 4)}
         print(json.dumps(line))
     if world > 1:
         dist.barrier()
