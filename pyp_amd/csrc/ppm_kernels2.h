@@ -320,8 +320,11 @@ struct InsertP {
     unsigned long long *counts;  // [2]
 };
 
-// grid: (ceil(H*W/256), n_img).  Thread = one Fourier sample of one particle; 8 taps x 3 float atomics
-// per symmetry operator.  Voxel layout {re, im, weight} keeps a tap's three adds in one 12-byte cell.
+// grid: (ceil(H*W/256), n_img).  Thread = one Fourier sample of one particle and symmetry operator: 8 taps x
+// {re, im, weight}.  A tap pair (x0, x0+1) of one (y, z) row is 6 consecutive floats in the accumulator, so the
+// adds are issued TRANSPOSED: every wave stages its 64 x 4 row segments (base index + 6 values) in LDS and then
+// walks them 6 floats at a time, ~10.7 segments per wave-instruction.  One wave-instruction therefore produces
+// ~11 64-byte atomic requests instead of 64 (float atomics execute at the memory side, per 64-B request).
 __global__ void __launch_bounds__(256) k_insert(InsertP P) {
     const int p = blockIdx.y, N = P.N, B = P.B, W = P.W;
     const double *row = P.rows + (size_t)p * PPM_NCOL;
@@ -330,7 +333,10 @@ __global__ void __launch_bounds__(256) k_insert(InsertP P) {
     long key = P.split_by_pind ? (long)row[PPM_PIND] : (long)row[PPM_POS];
     const int h = (int)(((key % 2) + 2) % 2);
     __shared__ CtfP ctf; __shared__ float m_s[6]; __shared__ float sh_s[2];
-    if (threadIdx.x == 0) {
+    __shared__ int seg_base[4][256];          // [wave][lane * 4 + row]  -> float index of (x0, y, z).re, or -1
+    __shared__ float seg_val[4][256 * 6];     // [wave][(lane * 4 + row) * 6 + c]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) {
         ctf = ctf_from_row(row, N, (double)P.a);
         double M[9]; d_euler(row[PPM_PSI], row[PPM_THETA], row[PPM_PHI], M);
         m_s[0] = (float)M[0]; m_s[1] = (float)M[1]; m_s[2] = (float)M[3]; m_s[3] = (float)M[4]; m_s[4] = (float)M[6]; m_s[5] = (float)M[7];
@@ -338,42 +344,52 @@ __global__ void __launch_bounds__(256) k_insert(InsertP P) {
         if (blockIdx.x == 0) atomicAdd(&P.counts[h], 1ull);
     }
     __syncthreads();
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= P.H * W) return;
+    const int idx = blockIdx.x * 256 + tid;
     const int kx = idx % W, ky = idx / W - B;
     const float k2 = (float)(kx * kx + ky * ky);
-    if (!(k2 < P.r2) || k2 == 0.f) return;
-    const float sx = sh_s[0], sy = sh_s[1];
-    const float cv = ctf_eval(ctf, kx, ky);
-    float w = (float)(occ / 100.0);
-    if (P.bfac != 0.f) w *= expf(-0.25f * P.bfac * (P.score_avg - (float)scr) * k2 * ctf.inv_na2);
-    float rev = (kx * sx + ky * sy) / (float)N; rev -= floorf(rev);
-    float sn = __sinf(6.283185307179586f * rev), cs = __cosf(6.283185307179586f * rev);
-    const float2 iv = P.band[((size_t)p * P.H + (ky + B)) * W + kx];
-    const float vr = w * cv * (iv.x * cs - iv.y * sn), vi = w * cv * (iv.x * sn + iv.y * cs), vw = w * cv * cv;
-    const float X0 = m_s[0] * kx + m_s[1] * ky, Y0 = m_s[2] * kx + m_s[3] * ky, Z0 = m_s[4] * kx + m_s[5] * ky;
+    const bool live = idx < P.H * W && k2 < P.r2 && k2 != 0.f;
+    float vr = 0.f, vi = 0.f, vw = 0.f, X0 = 0.f, Y0 = 0.f, Z0 = 0.f;
+    if (live) {
+        const float cv = ctf_eval(ctf, kx, ky);
+        float w = (float)(occ / 100.0);
+        if (P.bfac != 0.f) w *= expf(-0.25f * P.bfac * (P.score_avg - (float)scr) * k2 * ctf.inv_na2);
+        float rev = (kx * sh_s[0] + ky * sh_s[1]) / (float)N; rev -= floorf(rev);
+        float sn = __sinf(6.283185307179586f * rev), cs = __cosf(6.283185307179586f * rev);
+        const float2 iv = P.band[((size_t)p * P.H + (ky + B)) * W + kx];
+        vr = w * cv * (iv.x * cs - iv.y * sn); vi = w * cv * (iv.x * sn + iv.y * cs); vw = w * cv * cv;
+        X0 = m_s[0] * kx + m_s[1] * ky; Y0 = m_s[2] * kx + m_s[3] * ky; Z0 = m_s[4] * kx + m_s[5] * ky;
+    }
     const size_t NX = N / 2 + 1;
     float *A = P.acc + (size_t)h * N * N * NX * 3;
+    int *sb = seg_base[wave]; float *sv = seg_val[wave];
     for (int s = 0; s < P.nsym; s++) {
         const float *S = P.symops + s * 9;
         float X = S[0] * X0 + S[1] * Y0 + S[2] * Z0, Y = S[3] * X0 + S[4] * Y0 + S[5] * Z0, Z = S[6] * X0 + S[7] * Y0 + S[8] * Z0;
         float ui = vi;
         if (X < 0.f) { X = -X; Y = -Y; Z = -Z; ui = -ui; }
-        float xf = floorf(X), yf = floorf(Y), zf = floorf(Z);
-        float fx = X - xf, fy = Y - yf, fz = Z - zf;
-        int x0 = (int)xf, y0 = (int)yf + N / 2, z0 = (int)zf + N / 2;
+        const float xf = floorf(X), yf = floorf(Y), zf = floorf(Z);
+        const float fx = X - xf, fy = Y - yf, fz = Z - zf;
+        const int x0 = (int)xf, y0 = (int)yf + N / 2, z0 = (int)zf + N / 2;
 #pragma unroll
-        for (int dz = 0; dz < 2; dz++)
-#pragma unroll
-            for (int dy = 0; dy < 2; dy++)
-#pragma unroll
-                for (int dx = 0; dx < 2; dx++) {
-                    int xi = x0 + dx, yi = y0 + dy, zi = z0 + dz;
-                    if (xi > N / 2 || yi < 0 || yi >= N || zi < 0 || zi >= N) continue;
-                    float wt = (dx ? fx : 1.f - fx) * (dy ? fy : 1.f - fy) * (dz ? fz : 1.f - fz);
-                    float *v = A + (((size_t)zi * N + yi) * NX + xi) * 3;
-                    atomicAdd(v, wt * vr); atomicAdd(v + 1, wt * ui); atomicAdd(v + 2, wt * vw);
-                }
+        for (int r = 0; r < 4; r++) {
+            const int dy = r & 1, dz = r >> 1, yi = y0 + dy, zi = z0 + dz;
+            const bool ok = live && yi >= 0 && yi < N && zi >= 0 && zi < N && x0 + 1 <= N / 2;
+            const float wyz = (dy ? fy : 1.f - fy) * (dz ? fz : 1.f - fz);
+            const float w0 = wyz * (1.f - fx), w1 = wyz * fx;
+            sb[lane * 4 + r] = ok ? (int)((((size_t)zi * N + yi) * NX + x0) * 3) : -1;
+            float *o = sv + (lane * 4 + r) * 6;
+            o[0] = w0 * vr; o[1] = w0 * ui; o[2] = w0 * vw; o[3] = w1 * vr; o[4] = w1 * ui; o[5] = w1 * vw;
+        }
+        // the wave is its own producer and consumer: LDS writes above are complete before the reads below
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0)
+#pragma unroll 4
+        for (int f = lane; f < 256 * 6; f += 64) {
+            const int seg = f / 6, c = f - seg * 6;
+            const int base = sb[seg];
+            if (base >= 0) atomicAdd(A + base + c, sv[f]);
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
