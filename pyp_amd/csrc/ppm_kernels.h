@@ -87,7 +87,10 @@ struct PrepP {
     float2 *Wp; float *C2; float *nI; int Bs, Hs; float r_s2, r_lo2;
 };
 
-__global__ void __launch_bounds__(256) k_prep(PrepP P) {
+constexpr int kPrepThreads = 1024;   // one block per CU (LDS-bound): 16 waves hide the LDS / barrier latency of the FFT stages
+
+__global__ void __launch_bounds__(kPrepThreads) k_prep(PrepP P) {
+    constexpr int PT = kPrepThreads, PW = PT / 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, N = P.N, B = P.B, W = P.W, H = P.H;
     const int p = blockIdx.x;
@@ -96,14 +99,14 @@ __global__ void __launch_bounds__(256) k_prep(PrepP P) {
     float2 *Wk = T + (size_t)P.nc * TS;               // [L][N]
     float *ringpw = (float *)(Wk + (size_t)P.L * N);  // [B+2]
     float *ringpc = ringpw + (B + 2);                 // [B+2]
-    double *red = (double *)(((uintptr_t)(ringpc + (B + 2)) + 15) & ~(uintptr_t)15);  // [4*4]
-    float *stat = (float *)(red + 16);                // mu, scale
+    double *red = (double *)(((uintptr_t)(ringpc + (B + 2)) + 15) & ~(uintptr_t)15);  // [PW*4 + PW]
+    float *stat = (float *)(red + PW * 5);            // mu, scale, nI partials
     const float *img = P.images + (size_t)p * N * N;
 
     // ---- statistics of the background (outside the mask radius); whole image if that is empty
     double s1 = 0, s2 = 0, cnt = 0, t1 = 0, t2 = 0;
     const float Rm2 = P.Rm * P.Rm;
-    for (int i = tid; i < N * N; i += 256) {
+    for (int i = tid; i < N * N; i += PT) {
         int x = i & (N - 1), y = i >> P.logN;
         float dx = (float)(x - N / 2), dy = (float)(y - N / 2), v = img[i];
         t1 += v; t2 += (double)v * v;
@@ -114,17 +117,18 @@ __global__ void __launch_bounds__(256) k_prep(PrepP P) {
     __syncthreads();
     if (tid == 0) {
         double a1 = 0, a2 = 0, ac = 0, b1 = 0;
-        for (int w = 0; w < 4; w++) { a1 += red[w * 4]; a2 += red[w * 4 + 1]; ac += red[w * 4 + 2]; b1 += red[w * 4 + 3]; }
+        for (int w = 0; w < PW; w++) { a1 += red[w * 4]; a2 += red[w * 4 + 1]; ac += red[w * 4 + 2]; b1 += red[w * 4 + 3]; }
         red[0] = a1; red[1] = a2; red[2] = ac; red[3] = b1;
     }
     __syncthreads();
     {
         double a1 = red[0], a2 = red[1], ac = red[2], b1 = red[3];
         __syncthreads();
-        if ((tid & 63) == 0) red[4 + (tid >> 6)] = t2;
+        if ((tid & 63) == 0) red[PW * 4 + (tid >> 6)] = t2;
         __syncthreads();
         if (tid == 0) {
-            double b2 = red[4] + red[5] + red[6] + red[7];
+            double b2 = 0;
+            for (int w = 0; w < PW; w++) b2 += red[PW * 4 + w];
             if (ac < 16) { a1 = b1; a2 = b2; ac = (double)N * N; }
             double mu = a1 / ac, var = a2 / ac - mu * mu, sd = var > 0 ? sqrt(var) : 1.0;
             stat[0] = (float)mu;
@@ -133,7 +137,7 @@ __global__ void __launch_bounds__(256) k_prep(PrepP P) {
         __syncthreads();
     }
     const float mu = stat[0], sc = stat[1];
-    for (int i = tid; i < 2 * (B + 2); i += 256) ringpw[i] = 0.f;
+    for (int i = tid; i < 2 * (B + 2); i += PT) ringpw[i] = 0.f;
 
     const float wf = P.wfall < 1e-3f ? 1e-3f : P.wfall;
     float2 *bandp = P.band + (size_t)p * H * W;
@@ -142,7 +146,7 @@ __global__ void __launch_bounds__(256) k_prep(PrepP P) {
         // ---- row pass: two real rows per complex transform
         for (int y0 = 0; y0 < N; y0 += 2 * P.L) {
             __syncthreads();
-            for (int i = tid; i < P.L * N; i += 256) {
+            for (int i = tid; i < P.L * N; i += PT) {
                 int l = i >> P.logN, x = i & (N - 1);
                 int ya = y0 + 2 * l, yb = ya + 1;
                 float va = (img[ya * N + x] - mu) * sc, vb = (img[yb * N + x] - mu) * sc;
@@ -156,8 +160,8 @@ __global__ void __launch_bounds__(256) k_prep(PrepP P) {
                 }
                 Wk[l * N + bitrev(x, P.logN)] = make_float2(va, vb);
             }
-            lds_fft(Wk, N, P.logN, P.L, N, false, P.tw, tid, 256);
-            for (int i = tid; i < P.L * ncol; i += 256) {
+            lds_fft(Wk, N, P.logN, P.L, N, false, P.tw, tid, PT);
+            for (int i = tid; i < P.L * ncol; i += PT) {
                 int l = i / ncol, c = i - l * ncol, kx = c0 + c;
                 float2 z = Wk[l * N + kx], zc = Wk[l * N + ((N - kx) & (N - 1))];
                 float2 xa = make_float2(0.5f * (z.x + zc.x), 0.5f * (z.y - zc.y));
@@ -169,9 +173,9 @@ __global__ void __launch_bounds__(256) k_prep(PrepP P) {
             }
         }
         // ---- column pass
-        lds_fft(T, N, P.logN, ncol, TS, false, P.tw, tid, 256);
+        lds_fft(T, N, P.logN, ncol, TS, false, P.tw, tid, PT);
         const float invN = 1.f / (float)N;
-        for (int i = tid; i < ncol * H; i += 256) {
+        for (int i = tid; i < ncol * H; i += PT) {
             int c = i % ncol, row = i / ncol, ky = row - B, kx = c0 + c;
             float k2 = (float)(kx * kx + ky * ky);
             float2 o = make_float2(0.f, 0.f);
@@ -190,7 +194,7 @@ __global__ void __launch_bounds__(256) k_prep(PrepP P) {
     __threadfence_block();
     __syncthreads();
     // ---- ring weights (re-using ringpw as the weight table)
-    for (int b = tid; b < B + 2; b += 256) {
+    for (int b = tid; b < B + 2; b += PT) {
         float pw = ringpc[b] > 0.f ? ringpw[b] / ringpc[b] : 0.f;
         float wgt = P.whiten ? (pw > 0.f ? rsqrtf(pw) : 0.f) : 1.f;
         ringpw[b] = wgt;
@@ -201,7 +205,7 @@ __global__ void __launch_bounds__(256) k_prep(PrepP P) {
     if (P.Il) {
         float2 *Ilp = P.Il + (size_t)p * P.S_pad;
         float *cwp = P.cw + (size_t)p * P.S_pad;
-        for (int s = tid; s < P.S_pad; s += 256) {
+        for (int s = tid; s < P.S_pad; s += PT) {
             int kx, ky, al, ring;
             unpack_sample(P.samples[s], kx, ky, al, ring);
             float2 v = make_float2(0.f, 0.f); float c = 0.f;
@@ -218,7 +222,7 @@ __global__ void __launch_bounds__(256) k_prep(PrepP P) {
         float2 *Wpp = P.Wp + (size_t)p * P.Hs * 64;
         float *C2p = P.C2 + (size_t)p * P.Hs * 64;
         float ni = 0.f;
-        for (int i = tid; i < P.Hs * 64; i += 256) {
+        for (int i = tid; i < P.Hs * 64; i += PT) {
             int kx = i & 63, ky = (i >> 6) - P.Bs;
             float k2 = (float)(kx * kx + ky * ky);
             float2 wv = make_float2(0.f, 0.f); float c2 = 0.f;
@@ -238,7 +242,7 @@ __global__ void __launch_bounds__(256) k_prep(PrepP P) {
         __syncthreads();
         if ((tid & 63) == 0) stat[2 + (tid >> 6)] = ni;
         __syncthreads();
-        if (tid == 0) P.nI[p] = stat[2] + stat[3] + stat[4] + stat[5];
+        if (tid == 0) { float t = 0.f; for (int w = 0; w < PW; w++) t += stat[2 + w]; P.nI[p] = t; }
     }
 }
 
@@ -318,7 +322,8 @@ template <int R, bool HALF>
 __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
     constexpr int NT = global_threads(R), NW = NT / 64, U = global_unroll(R), NS = 2 * R + 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, p = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: slice addresses stay in SGPRs
     const int Hs = P.Hs, HsP = P.HsP, Bs = P.Bs, Ns = P.Ns, nsampP = HsP * 64;
     float2 *Wl = (float2 *)smem;
     float *C2l = (float *)(Wl + nsampP);
@@ -343,7 +348,7 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
     const int nslices = P.n_dir * P.npsi_store;
     float *ccp = P.cc + (size_t)p * P.n_orient; int *shp = P.sh + (size_t)p * P.n_orient;
     for (int sl = wave; sl < nslices; sl += NW) {
-        const float2 *Pp = P.bank + (size_t)sl * nsampP + lane;
+        const float2 *Pp = P.bank + (size_t)sl * nsampP;          // wave-uniform base, lane added as a 32-bit offset
         // accumulators: s* = sum over rows (shift row 0); per j: even part x cos (ua, ub), odd part x sin (va, vb)
         float sax = 0.f, say = 0.f, sbx = 0.f, sby = 0.f, nP = 0.f;
         float uax[R], uay[R], ubx[R], uby[R], vax[R], vay[R], vbx[R], vby[R];
@@ -351,11 +356,12 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
         for (int j = 0; j < R; j++) { uax[j] = uay[j] = ubx[j] = uby[j] = vax[j] = vay[j] = vbx[j] = vby[j] = 0.f; }
         float2 pv[U], pn[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) pv[u] = Pp[u * 64];
+        for (int u = 0; u < U; u++) pv[u] = Pp[u * 64 + lane];
         for (int row0 = 0; row0 < HsP; row0 += U) {
             if (row0 + U < HsP) {
+                const float2 *nxt = Pp + (row0 + U) * 64;       // scalar base; the row offsets below fit the 12-bit immediate
 #pragma unroll
-                for (int u = 0; u < U; u++) pn[u] = Pp[(row0 + U + u) * 64];
+                for (int u = 0; u < U; u++) pn[u] = nxt[u * 64 + lane];
             }
 #pragma unroll
             for (int u = 0; u < U; u += 2) {

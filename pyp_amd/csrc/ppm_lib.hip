@@ -160,12 +160,12 @@ static int launch_prep(const float *d_images, const double *d_rows, int n_img, c
     P.band = band; P.wring = wring; P.samples = samples; P.S_pad = S_pad; P.Il = Il; P.cw = cw;
     P.Wp = Wp; P.C2 = C2; P.nI = nI; P.Bs = gm.Bs; P.Hs = gm.Hs;
     P.r_s2 = (float)(gm.r_s * gm.r_s); P.r_lo2 = (float)(gm.r_lo * gm.r_lo);
-    size_t lds = (size_t)P.nc * (gm.N + 1) * sizeof(float2) + (size_t)P.L * gm.N * sizeof(float2) + 2 * (gm.B + 2) * sizeof(float) + 16 + 16 * sizeof(double) + 8 * sizeof(float);
+    size_t lds = (size_t)P.nc * (gm.N + 1) * sizeof(float2) + (size_t)P.L * gm.N * sizeof(float2) + 2 * (gm.B + 2) * sizeof(float) + 16 + 5 * (kPrepThreads / 64) * sizeof(double) + (4 + kPrepThreads / 64) * sizeof(float);
     if (lds > 160 * 1024) return fail(-12, "pre-processing kernel needs more than 160 KB of LDS");
     static bool attr_set = false;
     if (!attr_set) { HIPCHK(hipFuncSetAttribute((const void *)k_prep, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
     ProfScope ps(PPM_K_PREP);
-    hipLaunchKernelGGL(k_prep, dim3(n_img), dim3(256), lds, g.stream, P);
+    hipLaunchKernelGGL(k_prep, dim3(n_img), dim3(kPrepThreads), lds, g.stream, P);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -314,6 +314,7 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
     if (cfg->global_search) per += HS * 12 + (size_t)gm.n_orient * 8 + (size_t)K * (sizeof(Hit) + sizeof(LState)) + sizeof(LState);
     int CH = (int)std::min<size_t>((size_t)n_img, std::max<size_t>(64, ((size_t)3 << 30) / per));
     CH = std::min(CH, 8192);
+    if (const char *e = std::getenv("PPM_CHUNK")) { int v = std::atoi(e); if (v > 0) CH = std::min(CH, v); }   // tests: force several chunks
 
     if (int rc = ref->rows_in.ensure((size_t)CH * PPM_NCOL)) return rc;
     if (int rc = ref->rows_out.ensure((size_t)CH * PPM_NCOL)) return rc;

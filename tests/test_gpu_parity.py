@@ -115,6 +115,18 @@ def test_device_resident_stack_equals_host_stack(d64, H):
     assert synth.angular_error_deg(a, b).max() < ANG_TOL_DEG and np.abs(a[:, 14] - b[:, 14]).max() < 5e-2
 
 
+def test_chunked_batches_and_empty_input(d64, H, monkeypatch):
+    """Ragged chunking (n not a multiple of the chunk) gives the same rows as one chunk; zero particles is a no-op."""
+    vol, imgs, rows, g, o = d64
+    c = cfg_for(64, 2.0)
+    whole = g.refine(c, imgs[:11], rows[:11])
+    monkeypatch.setenv("PPM_CHUNK", "4")
+    parts = g.refine(c, imgs[:11], rows[:11])
+    monkeypatch.delenv("PPM_CHUNK")
+    assert synth.angular_error_deg(whole, parts).max() < ANG_TOL_DEG and np.abs(whole[:, 14] - parts[:, 14]).max() < 5e-2
+    assert g.refine(c, np.zeros((0, 64, 64), np.float32), np.zeros((0, 32))).shape == (0, 32)
+
+
 def test_errors_are_loud(d64, H):
     from pyp_amd import lib
     vol, imgs, rows, g, o = d64
