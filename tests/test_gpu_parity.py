@@ -105,6 +105,29 @@ def test_separate_search_mask_and_frozen_parameters(d64, H, O):
     assert np.allclose(want[:, 4:6], got[:, 4:6], atol=1e-6)
 
 
+@pytest.mark.parametrize("flags", [dict(refine_phi=0), dict(refine_theta=0), dict(refine_psi=0, refine_x=0), dict(refine_theta=0, refine_phi=0)])
+def test_partial_refine_flags_match_oracle(d64, H, O, flags):
+    """theta-only / phi-only use Euler-angle steps instead of the image-frame tilts; frozen parameters stay put."""
+    vol, imgs, rows, g, o = d64
+    start = synth.perturb_rows(rows, 1.5, 0.7, 2.0, seed=11)
+    c = cfg_for(64, 2.0, global_search=0, **flags)
+    want, _ = O.refine_batch(o, c, imgs[:8], start[:8])
+    got = g.refine(c, imgs[:8], start[:8])
+    assert synth.angular_error_deg(want, got).max() < ANG_TOL_DEG
+    assert synth.shift_error_px(want, got, 2.0).max() < SHIFT_TOL_PX
+    if not c.refine_x:
+        assert np.allclose(got[:, 4], start[:8, 4], atol=1e-6)
+
+
+def test_frequency_marching_can_be_switched_off(d64, H, O):
+    vol, imgs, rows, g, o = d64
+    c = cfg_for(64, 2.0, band_factor=-1.0)
+    want, cw = O.refine_batch(o, c, imgs[:6], rows[:6])
+    got = g.refine(c, imgs[:6], rows[:6])
+    assert synth.angular_error_deg(want, got).max() < ANG_TOL_DEG
+    assert g.last_counts()["samples_local"] == cw[2]
+
+
 def test_device_resident_stack_equals_host_stack(d64, H):
     import torch
     vol, imgs, rows, g, o = d64
