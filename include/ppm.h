@@ -73,6 +73,9 @@ typedef struct ppm_refine_cfg {
     int iters_final;          /* further iterations on the best hit / on a local-only start (default 6) */
     float local_angle_step;   /* first step of a local-only refinement, degrees (default 2.5) */
     float local_shift_step;   /* same for shifts, pixels (default 2) */
+    char symmetry[8];         /* 11: point group of the reference ("C1", "C7", "D7", "T", "O", "I"; "" = C1).  The global grid
+                                 is restricted to phi < 360/n for Cn / Dn and theta <= 90 for Dn; T and I search the D2 unit they
+                                 contain, O the D4 unit.  Every pose found is symmetry-equivalent to the unrestricted optimum */
     float band_factor;        /* frequency marching: a compass iteration whose largest probe displacement is d pixels
                                  (mask radius x angular step in radians, or the shift step) scores only rings below
                                  band_factor * N / (2 pi d), capped by the stage's band.  0 = default 3, < 0 = off */

@@ -81,8 +81,21 @@ typedef struct {
     int B, W, H;            /* band half-width, row width B+1, rows 2B+1 */
     int Ns, step, RSx, RSy; /* global-search shift grid */
     int n_theta, n_psi, n_dir, n_orient;
-    double dpsi;
+    double dpsi, phi_max, theta_max;
 } geom_t;
+
+/* asymmetric unit of the global grid: phi < 360/n for Cn and Dn, theta <= 90 for Dn; T and I use the D2 unit they
+ * contain, O the D4 unit */
+static void sym_limits(const char *sym, double *phi_max, double *theta_max) {
+    *phi_max = 360.0; *theta_max = 180.0;
+    if (!sym || !sym[0]) return;
+    char t = sym[0] >= 'a' ? sym[0] - 32 : sym[0];
+    int n = atoi(sym + 1);
+    if (t == 'C' && n >= 1) { *phi_max = 360.0 / n; }
+    else if (t == 'D' && n >= 1) { *phi_max = 360.0 / n; *theta_max = 90.0; }
+    else if (t == 'T' || t == 'I') { *phi_max = 180.0; *theta_max = 90.0; }
+    else if (t == 'O') { *phi_max = 90.0; *theta_max = 90.0; }
+}
 
 static int geom_init(geom_t *g, const ppm_refine_cfg *c) {
     memset(g, 0, sizeof(*g));
@@ -103,13 +116,15 @@ static int geom_init(geom_t *g, const ppm_refine_cfg *c) {
     if (g->RSx > PPM_MAX_SHIFT_STEPS) g->RSx = PPM_MAX_SHIFT_STEPS;
     if (g->RSy > PPM_MAX_SHIFT_STEPS) g->RSy = PPM_MAX_SHIFT_STEPS;
     double d = c->angular_step > 0 ? c->angular_step : 15.0;
-    g->n_theta = (int)floor(180.0 / d + 0.5) + 1;
+    sym_limits(c->symmetry, &g->phi_max, &g->theta_max);
+    g->n_theta = (int)floor(g->theta_max / d + 0.5) + 1;
+    if (g->n_theta < 2) g->n_theta = 2;
     g->n_psi = (int)floor(360.0 / d + 0.5); if (g->n_psi < 1) g->n_psi = 1;
     g->dpsi = 360.0 / g->n_psi;
     g->n_dir = 0;
     for (int i = 0; i < g->n_theta; i++) {
-        double th = 180.0 * i / (g->n_theta - 1);
-        int np = (int)floor(360.0 * sin(th * ORC_PI / 180.0) / d + 0.5); if (np < 1) np = 1;
+        double th = g->theta_max * i / (g->n_theta - 1);
+        int np = (int)floor(g->phi_max * sin(th * ORC_PI / 180.0) / d + 0.5); if (np < 1) np = 1;
         g->n_dir += np;
     }
     g->n_orient = g->n_dir * g->n_psi;
@@ -120,9 +135,9 @@ static int geom_init(geom_t *g, const ppm_refine_cfg *c) {
 static void grid_direction(const geom_t *g, double dstep, int dir, double *theta, double *phi) {
     int acc = 0;
     for (int i = 0; i < g->n_theta; i++) {
-        double th = 180.0 * i / (g->n_theta - 1);
-        int np = (int)floor(360.0 * sin(th * ORC_PI / 180.0) / dstep + 0.5); if (np < 1) np = 1;
-        if (dir < acc + np) { *theta = th; *phi = 360.0 * (dir - acc) / np; return; }
+        double th = g->theta_max * i / (g->n_theta - 1);
+        int np = (int)floor(g->phi_max * sin(th * ORC_PI / 180.0) / dstep + 0.5); if (np < 1) np = 1;
+        if (dir < acc + np) { *theta = th; *phi = g->phi_max * (dir - acc) / np; return; }
         acc += np;
     }
     *theta = 0; *phi = 0;

@@ -25,13 +25,25 @@ struct Geom {
     int Bs = 0, Hs = 0;           // search band
     int Ns = 0, step = 0, RSx = 0, RSy = 0;
     int n_theta = 0, n_psi = 0, n_dir = 0, n_orient = 0, npsi_store = 0, half = 0;
-    double dpsi = 0, dstep = 0;
+    double dpsi = 0, dstep = 0, phi_max = 360, theta_max = 180;
 };
+
+// asymmetric unit of the global grid (include/ppm.h, field `symmetry`)
+inline void sym_limits(const char *sym, double &phi_max, double &theta_max) {
+    phi_max = 360.0; theta_max = 180.0;
+    if (!sym || !sym[0]) return;
+    char t = sym[0] >= 'a' ? sym[0] - 32 : sym[0];
+    int n = std::atoi(sym + 1);
+    if (t == 'C' && n >= 1) phi_max = 360.0 / n;
+    else if (t == 'D' && n >= 1) { phi_max = 360.0 / n; theta_max = 90.0; }
+    else if (t == 'T' || t == 'I') { phi_max = 180.0; theta_max = 90.0; }
+    else if (t == 'O') { phi_max = 90.0; theta_max = 90.0; }
+}
 
 inline bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 
-inline int n_phi_at(double theta_deg, double dstep) {
-    int np = (int)std::floor(360.0 * std::sin(theta_deg * kPi / 180.0) / dstep + 0.5);
+inline int n_phi_at(double theta_deg, double dstep, double phi_max = 360.0) {
+    int np = (int)std::floor(phi_max * std::sin(theta_deg * kPi / 180.0) / dstep + 0.5);
     return np < 1 ? 1 : np;
 }
 
@@ -56,12 +68,14 @@ inline bool geom_init(Geom &g, const ppm_refine_cfg &c, std::string &err) {
     if (g.RSx > PPM_MAX_SHIFT_STEPS) g.RSx = PPM_MAX_SHIFT_STEPS;
     if (g.RSy > PPM_MAX_SHIFT_STEPS) g.RSy = PPM_MAX_SHIFT_STEPS;
     g.dstep = c.angular_step > 0 ? c.angular_step : 15.0;
-    g.n_theta = (int)std::floor(180.0 / g.dstep + 0.5) + 1;
+    char symbuf[9]; std::memcpy(symbuf, c.symmetry, 8); symbuf[8] = 0;
+    sym_limits(symbuf, g.phi_max, g.theta_max);
+    g.n_theta = (int)std::floor(g.theta_max / g.dstep + 0.5) + 1;
     if (g.n_theta < 2) g.n_theta = 2;
     g.n_psi = (int)std::floor(360.0 / g.dstep + 0.5); if (g.n_psi < 1) g.n_psi = 1;
     g.dpsi = 360.0 / g.n_psi;
     g.n_dir = 0;
-    for (int i = 0; i < g.n_theta; i++) g.n_dir += n_phi_at(180.0 * i / (g.n_theta - 1), g.dstep);
+    for (int i = 0; i < g.n_theta; i++) g.n_dir += n_phi_at(g.theta_max * i / (g.n_theta - 1), g.dstep, g.phi_max);
     g.n_orient = g.n_dir * g.n_psi;
     g.half = (g.n_psi % 2 == 0);
     g.npsi_store = g.half ? g.n_psi / 2 : g.n_psi;
@@ -71,9 +85,9 @@ inline bool geom_init(Geom &g, const ppm_refine_cfg &c, std::string &err) {
 inline void grid_direction(const Geom &g, int dir, double &theta, double &phi) {
     int acc = 0;
     for (int i = 0; i < g.n_theta; i++) {
-        double th = 180.0 * i / (g.n_theta - 1);
-        int np = n_phi_at(th, g.dstep);
-        if (dir < acc + np) { theta = th; phi = 360.0 * (dir - acc) / np; return; }
+        double th = g.theta_max * i / (g.n_theta - 1);
+        int np = n_phi_at(th, g.dstep, g.phi_max);
+        if (dir < acc + np) { theta = th; phi = g.phi_max * (dir - acc) / np; return; }
         acc += np;
     }
     theta = phi = 0;

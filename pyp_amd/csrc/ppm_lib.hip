@@ -336,7 +336,7 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
         if (int rc = ref->states.ensure((size_t)CH * K)) return rc;
         // slice bank, twiddles and direction tables: rebuilt only when the grid / band changes
         char key[160];
-        std::snprintf(key, sizeof(key), "%d/%.6f/%.6f/%d/%d/%d", gm.N, gm.r_s, gm.dstep, gm.Ns, gm.npsi_store, HsP);
+        std::snprintf(key, sizeof(key), "%d/%.6f/%.6f/%d/%d/%d/%.3f/%.3f", gm.N, gm.r_s, gm.dstep, gm.Ns, gm.npsi_store, HsP, gm.phi_max, gm.theta_max);
         if (ref->bank_key != key) {
             std::vector<float> mats((size_t)nslices * 6);
             std::vector<double> dth(gm.n_dir), dph(gm.n_dir);

@@ -116,7 +116,8 @@ def refine3d_main(argv=None, stdin=None):
         res_search=d["res_search"], angular_step=d["angular_step"], top_hits=d["top_hits"], search_range_x=d["search_range_x"],
         search_range_y=d["search_range_y"], global_search=int(d["global_search"]), local_refine=int(d["local_refine"]),
         refine_psi=int(d["refine_psi"]), refine_theta=int(d["refine_theta"]), refine_phi=int(d["refine_phi"]),
-        refine_x=int(d["refine_x"]), refine_y=int(d["refine_y"]), normalize=int(d["normalize"]), invert=int(d["invert"]))
+        refine_x=int(d["refine_x"]), refine_y=int(d["refine_y"]), normalize=int(d["normalize"]), invert=int(d["invert"]),
+        symmetry=d["symmetry"][:7])
     from .. import host, lib
     try:
         ref = host.Reference(vol, box / 2, device=int(os.environ.get("PPM_DEVICE", "0")))

@@ -119,6 +119,16 @@ def test_partial_refine_flags_match_oracle(d64, H, O, flags):
         assert np.allclose(got[:, 4], start[:8, 4], atol=1e-6)
 
 
+@pytest.mark.parametrize("sym", ["C3", "D2", "O"])
+def test_symmetry_restricted_grid_matches_oracle(d64, H, O, sym):
+    vol, imgs, rows, g, o = d64
+    c = cfg_for(64, 2.0, symmetry=sym)
+    want, cw = O.refine_batch(o, c, imgs[:8], rows[:8])
+    got = g.refine(c, imgs[:8], rows[:8])
+    assert g.last_counts()["n_global"] == cw[0] < 4416
+    assert synth.angular_error_deg(want, got).max() < ANG_TOL_DEG
+
+
 def test_frequency_marching_can_be_switched_off(d64, H, O):
     vol, imgs, rows, g, o = d64
     c = cfg_for(64, 2.0, band_factor=-1.0)

@@ -112,3 +112,31 @@ def test_zero_occupancy_rows_are_skipped():
     rc = ReconCfg(box=n, pixel_size=PX, res_limit=2 * PX, mask_radius=0.4 * n * PX)
     oracle.insert_batch(acc, counts, rc, "C1", stack.numpy(), rows)
     assert counts.sum() == 4
+
+
+def _neg(a, axes):
+    for ax in axes:
+        a = np.roll(np.flip(a, axis=ax), 1, axis=ax)      # index i -> (N - i) % N keeps the centre N/2 fixed
+    return a
+
+
+def test_symmetry_restricted_grid_finds_an_equivalent_pose():
+    """D2 reference: the restricted grid (phi < 180, theta <= 90: a quarter of the orientations) returns poses that are
+    symmetry-equivalent to the truth."""
+    vol = synth.phantom(N)
+    vz, vx = _neg(vol, (1, 2)), _neg(vol, (0, 1))          # 180 deg about z: (x,y) -> (-x,-y); about x: (y,z) -> (-y,-z)
+    vsym = (vol + vz + vx + _neg(vz, (0, 1))) / 4.0
+    _, stack, rows = synth.make_dataset(N, 8, pixel=PX, snr=0, vol=vsym)
+    ref = oracle.Reference(vsym, N / 2)
+    full = oracle.band_dims(cfg_for())["n_orient"]
+    c = cfg_for(symmetry="D2")
+    assert oracle.band_dims(c)["n_orient"] < 0.3 * full
+    out, _ = oracle.refine_batch(ref, c, stack.numpy(), rows)
+    ops = oracle.symmetry_ops("D2")
+    C = synth.cistem.COL
+    for i in range(len(rows)):
+        mt = synth.euler_matrix(rows[i, C["PSI"]], rows[i, C["THETA"]], rows[i, C["PHI"]])
+        mo = synth.euler_matrix(out[i, C["PSI"]], out[i, C["THETA"]], out[i, C["PHI"]])
+        errs = [np.degrees(np.arccos(np.clip((np.trace((g @ mt).T @ mo) - 1) / 2, -1, 1))) for g in ops]
+        assert min(errs) < 1.5, (i, errs)
+        assert out[i, C["THETA"]] <= 90.0 + 10.0       # stays near the asymmetric unit (local refinement may step out a little)
