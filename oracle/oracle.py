@@ -40,6 +40,7 @@ def lib():
         L.orc_band_dims.argtypes = [C.c_void_p] + [C.c_void_p] * 6
         L.orc_extract_slice.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p]
         L.orc_symmetry_ops.argtypes = [C.c_char_p, C.c_void_p]
+        L.orc_fft1d.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.orc_insert_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_void_p]
         L.orc_finalize.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
@@ -71,7 +72,7 @@ class Reference:
 
 
 def band_dims(cfg):
-    v = [C.c_int() for _ in range(6)]
+    v = [C.c_int(), C.c_int(), C.c_int(), C.c_double(), C.c_int(), C.c_int()]
     if lib().orc_band_dims(C.byref(cfg), *[C.byref(x) for x in v]):
         raise ValueError("oracle: bad config")
     return dict(zip(("B", "n_orient", "Ns", "step", "RSx", "RSy"), [x.value for x in v]))
@@ -145,3 +146,11 @@ def finalize(acc, box, pixel, fcfg):
     if rc:
         raise RuntimeError(f"oracle: finalize failed ({rc})")
     return h1, h2, fl, stats
+
+
+def fft1d(x, inverse=False):
+    """The oracle's mixed-radix FFT on a complex vector (known-answer test against numpy.fft)."""
+    a = np.ascontiguousarray(x, dtype=np.complex64).copy()
+    if lib().orc_fft1d(_p(a), len(a), 1 if inverse else 0):
+        raise ValueError("oracle: unsupported FFT length")
+    return a

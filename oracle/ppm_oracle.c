@@ -32,54 +32,100 @@
 
 typedef struct { float re, im; } cpx;
 
-/* ------------------------------------------------------------------ FFT (radix-2, any 2^m) */
-#define ORC_MAXLOG 12
-static double *TWC[ORC_MAXLOG + 1], *TWS[ORC_MAXLOG + 1];
-static void fft_tables(void) {
-    /* twiddle tables for n = 2..4096, built once (call before any parallel region) */
-    if (TWC[1]) return;
-    for (int m = 1; m <= ORC_MAXLOG; m++) {
-        int n = 1 << m;
-        double *c = (double *)malloc(sizeof(double) * (n / 2)), *s = (double *)malloc(sizeof(double) * (n / 2));
-        for (int k = 0; k < n / 2; k++) { c[k] = cos(2.0 * ORC_PI * k / n); s[k] = sin(2.0 * ORC_PI * k / n); }
-        TWS[m] = s; TWC[m] = c;
+/* ------------------------------------------------------------------ FFT (mixed radix 2, 3, 4, 5) */
+/* Decimation in time over the factors of n (4s first, then 2, 3, 5): the input is permuted so that the
+ * r_m interleaved sub-sequences sit in consecutive blocks, then every stage combines r blocks of length L
+ * into one of length r L with the textbook r-point DFT and twiddles w^(q j), w = e^(-+2 pi i/(r L)).
+ * Twiddle and permutation tables are cached per length (built before any parallel region). */
+#define ORC_MAXN 4096
+typedef struct { int n, nfac, fac[16]; double *c, *s; int *perm; } fplan_t;
+static fplan_t *PLANS[ORC_MAXN + 1];
+
+static int fft_size_ok(int n) {
+    if (n < 2 || n > ORC_MAXN) return 0;
+    while (n % 2 == 0) n /= 2;
+    while (n % 3 == 0) n /= 3;
+    while (n % 5 == 0) n /= 5;
+    return n == 1;
+}
+
+static fplan_t *fft_plan(int n) {
+    if (PLANS[n]) return PLANS[n];
+    fplan_t *p = (fplan_t *)calloc(1, sizeof(fplan_t));
+    p->n = n;
+    int m = n;
+    while (m % 4 == 0) { p->fac[p->nfac++] = 4; m /= 4; }
+    while (m % 2 == 0) { p->fac[p->nfac++] = 2; m /= 2; }
+    while (m % 3 == 0) { p->fac[p->nfac++] = 3; m /= 3; }
+    while (m % 5 == 0) { p->fac[p->nfac++] = 5; m /= 5; }
+    p->c = (double *)malloc(sizeof(double) * n); p->s = (double *)malloc(sizeof(double) * n);
+    for (int k = 0; k < n; k++) { p->c[k] = cos(2.0 * ORC_PI * k / n); p->s[k] = sin(2.0 * ORC_PI * k / n); }
+    /* position of input sample i: P_m(i) = (i mod r_m) L_{m-1} + P_{m-1}(i div r_m) */
+    p->perm = (int *)malloc(sizeof(int) * n);
+    for (int i = 0; i < n; i++) {
+        int pos = 0, rem = i, L = n;
+        for (int st = p->nfac - 1; st >= 0; st--) { int r = p->fac[st]; L /= r; pos += (rem % r) * L; rem /= r; }
+        p->perm[i] = pos;
     }
+    PLANS[n] = p;
+    return p;
+}
+
+static void fft_tables(void) {
+    /* plans for every size the library accepts, built once (call before any parallel region) */
+    static int done = 0;
+    if (done) return;
+    for (int n = 2; n <= 1024; n++) if (fft_size_ok(n)) fft_plan(n);
+    done = 1;
 }
 
 static void fft1d(cpx *x, int n, int stride, int inverse) {
-    /* in-place iterative Cooley-Tukey on x[0], x[stride], ...; twiddles in double */
-    int j = 0, lg = 0;
-    while ((1 << lg) < n) lg++;
-    for (int i = 1; i < n; i++) {
-        int bit = n >> 1;
-        for (; j & bit; bit >>= 1) j ^= bit;
-        j ^= bit;
-        if (i < j) { cpx t = x[i * stride]; x[i * stride] = x[j * stride]; x[j * stride] = t; }
-    }
-    const double *tc = TWC[lg], *ts = TWS[lg];
-    for (int len = 2; len <= n; len <<= 1) {
-        int q = n / len;
-        for (int i = 0; i < n; i += len) {
-            for (int k = 0; k < len / 2; k++) {
-                double wr = tc[k * q], wi = inverse ? ts[k * q] : -ts[k * q];
-                cpx *a = &x[(i + k) * stride], *b = &x[(i + k + len / 2) * stride];
-                double tr = b->re * wr - b->im * wi, ti = b->re * wi + b->im * wr;
-                double ar = a->re, ai = a->im;
-                a->re = (float)(ar + tr); a->im = (float)(ai + ti);
-                b->re = (float)(ar - tr); b->im = (float)(ai - ti);
+    const fplan_t *p = PLANS[n];
+    double br[ORC_MAXN > 1024 ? 1024 : ORC_MAXN], bi[1024];
+    for (int i = 0; i < n; i++) { br[p->perm[i]] = x[i * stride].re; bi[p->perm[i]] = x[i * stride].im; }
+    int Lp = 1;
+    for (int st = 0; st < p->nfac; st++) {
+        const int r = p->fac[st], L = Lp * r, tws = n / L, rs = n / r;
+        for (int blk = 0; blk < n; blk += L) for (int j = 0; j < Lp; j++) {
+            double xr[5], xi[5];
+            for (int q = 0; q < r; q++) {
+                double vr = br[blk + q * Lp + j], vi = bi[blk + q * Lp + j];
+                int t = q * j * tws;                         /* < n */
+                double wr = p->c[t], wi = inverse ? p->s[t] : -p->s[t];
+                xr[q] = vr * wr - vi * wi; xi[q] = vr * wi + vi * wr;
+            }
+            for (int pp = 0; pp < r; pp++) {
+                double sr = 0, si = 0;
+                for (int q = 0; q < r; q++) {
+                    int t = ((pp * q) % r) * rs;
+                    double wr = p->c[t], wi = inverse ? p->s[t] : -p->s[t];
+                    sr += xr[q] * wr - xi[q] * wi; si += xr[q] * wi + xi[q] * wr;
+                }
+                br[blk + pp * Lp + j] = sr; bi[blk + pp * Lp + j] = si;
             }
         }
+        Lp = L;
     }
+    for (int i = 0; i < n; i++) { x[i * stride].re = (float)br[i]; x[i * stride].im = (float)bi[i]; }
+}
+
+/* exported for the FFT known-answer test (numpy.fft) */
+int orc_fft1d(float *data /* n interleaved complex */, int n, int inverse) {
+    fft_tables();
+    if (!fft_size_ok(n) || n > 1024) return -22;
+    fft1d((cpx *)data, n, 1, inverse);
+    return 0;
 }
 
 static int is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+static int box_ok(int n) { return n >= 16 && n <= 512 && n % 2 == 0 && fft_size_ok(n); }
 
 /* ------------------------------------------------------------------ derived geometry */
 typedef struct {
     int N; double a;
     double r_hi, r_lo, r_s, ring_signed;
     int B, W, H;            /* band half-width, row width B+1, rows 2B+1 */
-    int Ns, step, RSx, RSy; /* global-search shift grid */
+    int Ns, RSx, RSy; double step; /* global-search shift grid: Ns points over the box, step = N/Ns pixels */
     int n_theta, n_psi, n_dir, n_orient;
     double dpsi, phi_max, theta_max;
 } geom_t;
@@ -100,7 +146,7 @@ static void sym_limits(const char *sym, double *phi_max, double *theta_max) {
 static int geom_init(geom_t *g, const ppm_refine_cfg *c) {
     memset(g, 0, sizeof(*g));
     g->N = c->box; g->a = c->pixel_size;
-    if (!is_pow2(g->N) || g->N < 16 || g->a <= 0 || c->res_high <= 0) return -1;
+    if (!box_ok(g->N) || g->a <= 0 || c->res_high <= 0) return -1;
     double na = g->N * g->a;
     g->r_hi = na / c->res_high; if (g->r_hi > g->N / 2) g->r_hi = g->N / 2;
     g->r_lo = c->res_low > 0 ? na / c->res_low : 0.0;
@@ -108,8 +154,8 @@ static int geom_init(geom_t *g, const ppm_refine_cfg *c) {
     g->ring_signed = c->res_signed_cc > 0 ? na / c->res_signed_cc : 1e30;
     g->B = (int)ceil(g->r_hi) - 1; g->W = g->B + 1; g->H = 2 * g->B + 1;
     int Bs = (int)ceil(g->r_s) - 1;
-    g->Ns = 2; while (g->Ns < 2 * (Bs + 1)) g->Ns <<= 1; if (g->Ns > g->N) g->Ns = g->N;
-    g->step = g->N / g->Ns;
+    g->Ns = 2; while (g->Ns < 2 * (Bs + 1)) g->Ns <<= 1;
+    g->step = (double)g->N / g->Ns;
     double rx = c->search_range_x / g->a, ry = c->search_range_y / g->a;
     g->RSx = rx > 0 ? (int)ceil(rx / g->step) : PPM_MAX_SHIFT_STEPS;
     g->RSy = ry > 0 ? (int)ceil(ry / g->step) : PPM_MAX_SHIFT_STEPS;
@@ -166,7 +212,7 @@ typedef struct { int N, B, CX, CY; cpx *cube; } oref_t;
 
 void *orc_reference_create(const float *vol, int n, float max_band_px) {
     fft_tables();
-    if (!is_pow2(n) || max_band_px <= 0) return NULL;
+    if (!box_ok(n) || max_band_px <= 0) return NULL;
     if (max_band_px > n / 2) max_band_px = n / 2;
     int B = (int)ceil(max_band_px) - 1;
     size_t n3 = (size_t)n * n * n;
@@ -503,8 +549,7 @@ static double ccf_peak(const geom_t *g, const cpx *Wp, const float *C2, const cp
         }
     } else {
         /* separable pruned transform: G[kx][sy] = sum_ky Q e^{+i 2pi ky sy/Ns}, then the sum over kx */
-        int lg = 0; while ((1 << lg) < Ns) lg++;
-        const double *tc = TWC[lg], *ts = TWS[lg];
+        const double *tc = PLANS[Ns]->c, *ts = PLANS[Ns]->s;
         int nsy = 2 * g->RSy + 1;
         double *G = (double *)calloc((size_t)2 * Wd * nsy, sizeof(double));
         for (int ky = -B; ky <= B; ky++) for (int kx = 0; kx <= B; kx++) {
@@ -514,7 +559,7 @@ static double ccf_peak(const geom_t *g, const cpx *Wp, const float *C2, const cp
             double qr = Wp[i].re * pr + Wp[i].im * pi, qi = Wp[i].im * pr - Wp[i].re * pi;
             for (int sy = -g->RSy; sy <= g->RSy; sy++) {
                 int t = (((ky * sy) % Ns) + Ns) % Ns;
-                double c = t < Ns / 2 ? tc[t] : -tc[t - Ns / 2], s2 = t < Ns / 2 ? ts[t] : -ts[t - Ns / 2];
+                double c = tc[t], s2 = ts[t];
                 double *o = &G[((size_t)kx * nsy + (sy + g->RSy)) * 2];
                 o[0] += qr * c - qi * s2; o[1] += qr * s2 + qi * c;
             }
@@ -523,7 +568,7 @@ static double ccf_peak(const geom_t *g, const cpx *Wp, const float *C2, const cp
             double acc = 0;
             for (int kx = 0; kx <= B; kx++) {
                 int t = (((kx * sx) % Ns) + Ns) % Ns;
-                double c = t < Ns / 2 ? tc[t] : -tc[t - Ns / 2], s2 = t < Ns / 2 ? ts[t] : -ts[t - Ns / 2];
+                double c = tc[t], s2 = ts[t];
                 const double *o = &G[((size_t)kx * nsy + (sy + g->RSy)) * 2];
                 acc += o[0] * c - o[1] * s2;
             }
@@ -685,7 +730,7 @@ int orc_preprocess(const ppm_refine_cfg *cfg, const float *img, float mask_radiu
     return 0;
 }
 
-int orc_band_dims(const ppm_refine_cfg *cfg, int *B, int *n_orient, int *Ns, int *step, int *RSx, int *RSy) {
+int orc_band_dims(const ppm_refine_cfg *cfg, int *B, int *n_orient, int *Ns, double *step, int *RSx, int *RSy) {
     geom_t g; if (geom_init(&g, cfg)) return -22;
     *B = g.B; *n_orient = g.n_orient; *Ns = g.Ns; *step = g.step; *RSx = g.RSx; *RSy = g.RSy;
     return 0;
@@ -753,7 +798,7 @@ int orc_insert_batch(float *acc, long *counts, const ppm_recon_cfg *cfg, const c
                      const float *images, int n_img, const double *rows) {
     fft_tables();
     int N = cfg->box; double a = cfg->pixel_size;
-    if (!is_pow2(N) || a <= 0) return -22;
+    if (!box_ok(N) || a <= 0) return -22;
     double ops[60 * 9]; int nsym = orc_symmetry_ops(symmetry && symmetry[0] ? symmetry : "C1", ops);
     if (nsym < 1) return -22;
     ppm_refine_cfg rc; memset(&rc, 0, sizeof(rc));
@@ -818,7 +863,7 @@ static void ifft3_centered_real(cpx *f, int N, float *out) {
 int orc_finalize(const float *acc_in, int N, double a, const ppm_final_cfg *cfg,
                  float *half1, float *half2, float *filt, double *stats) {
     fft_tables();
-    if (!is_pow2(N)) return -22;
+    if (!box_ok(N)) return -22;
     size_t NX = N / 2 + 1, half_sz = (size_t)N * N * NX * 3, n3 = (size_t)N * N * N;
     float *acc = (float *)malloc(2 * half_sz * sizeof(float));
     memcpy(acc, acc_in, 2 * half_sz * sizeof(float));

@@ -11,7 +11,6 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 
-__device__ __forceinline__ unsigned bitrev(unsigned x, int logn) { return __brev(x) >> (32 - logn); }
 
 // wave64 all-lanes sum (every lane gets the total)
 __device__ __forceinline__ float wave_sum(float v) {
@@ -31,27 +30,60 @@ __device__ __forceinline__ float group16_sum(float v) {
     return v;
 }
 
-// In-place radix-2 decimation-in-time FFT of `nlines` lines of length n = 2^logn held in LDS.
-// Input must already sit in bit-reversed order; output is in natural order.  tw[k] =
-// (cos 2 pi k/n, sin 2 pi k/n), k < n/2 (global memory).  All threads of the block must call.
-__device__ inline void lds_fft(float2 *buf, int n, int logn, int nlines, int lstride, bool inverse,
-                               const float2 *__restrict__ tw, int tid, int nthr) {
-    const int half = n >> 1;
-    for (int s = 0; s < logn; s++) {
-        const int h = 1 << s, q = half >> s;
+// FFT plan of one length n = prod fac[] (factors 4, 2, 3, 5): tw[k] = (cos 2 pi k/n, sin 2 pi k/n), k < n;
+// perm[i] = LDS position of input sample i (digit-reversed staging), both in global memory.
+struct FftPlan { int n, nfac; int fac[12]; const float2 *tw; const unsigned short *perm; };
+
+// In-place mixed-radix decimation-in-time FFT of `nlines` lines of length n held in LDS.  Input must
+// already sit at the positions plan.perm gives; output is in natural order.  Every stage combines r
+// blocks of length Lp into one of length r Lp: twiddle w^(q j), then the r-point butterfly.  All threads of
+// the block must call.
+__device__ inline void lds_fft(float2 *buf, const FftPlan &pl, int nlines, int lstride, bool inverse, int tid, int nthr) {
+    const int n = pl.n;
+    const float sgn = inverse ? 1.f : -1.f;       // sign of the exponent
+    int Lp = 1;
+    for (int st = 0; st < pl.nfac; st++) {
+        const int r = pl.fac[st], L = Lp * r, m = n / r, tws = n / L;
         __syncthreads();
-        for (int i = tid; i < nlines * half; i += nthr) {
-            int line = i >> (logn - 1), j = i & (half - 1);
-            int k = j & (h - 1);
-            int base = ((j >> s) << (s + 1)) + k;
-            float2 w = tw[k * q];
-            if (!inverse) w.y = -w.y;
-            float2 *p = buf + line * lstride;
-            float2 a = p[base], b = p[base + h];
-            float2 t = cmul(b, w);
-            p[base] = cadd(a, t);
-            p[base + h] = csub(a, t);
+        for (int i = tid; i < nlines * m; i += nthr) {
+            const int line = i / m, t = i - line * m, blk = t / Lp, j = t - blk * Lp;
+            float2 *p = buf + line * lstride + blk * L + j;
+            float2 x[5];
+#pragma unroll
+            for (int q = 0; q < 5; q++) {
+                if (q < r) {
+                    float2 v = p[q * Lp];
+                    if (q > 0) { float2 w = pl.tw[q * j * tws]; w.y *= sgn; v = cmul(v, w); }
+                    x[q] = v;
+                }
+            }
+            if (r == 2) {
+                p[0] = cadd(x[0], x[1]); p[Lp] = csub(x[0], x[1]);
+            } else if (r == 4) {
+                float2 t0 = cadd(x[0], x[2]), t1 = csub(x[0], x[2]), t2 = cadd(x[1], x[3]), d = csub(x[1], x[3]);
+                float2 jd = make_float2(-sgn * d.y, sgn * d.x);      // (sgn i) d
+                p[0] = cadd(t0, t2); p[2 * Lp] = csub(t0, t2);
+                p[Lp] = cadd(t1, jd); p[3 * Lp] = csub(t1, jd);
+            } else if (r == 3) {
+                float2 sm = cadd(x[1], x[2]), d = csub(x[1], x[2]);
+                float2 h = make_float2(x[0].x - 0.5f * sm.x, x[0].y - 0.5f * sm.y);
+                const float c = 0.8660254037844386f * sgn;           // (sgn i sqrt(3)/2) d
+                float2 jd = make_float2(-c * d.y, c * d.x);
+                p[0] = cadd(x[0], sm); p[Lp] = cadd(h, jd); p[2 * Lp] = csub(h, jd);
+            } else {
+                const float c1 = 0.30901699437494745f, c2 = -0.8090169943749475f, s1 = 0.9510565162951535f, s2 = 0.5877852522924731f;
+                float2 a1 = cadd(x[1], x[4]), a2 = cadd(x[2], x[3]), b1 = csub(x[1], x[4]), b2 = csub(x[2], x[3]);
+                float2 t1 = make_float2(x[0].x + c1 * a1.x + c2 * a2.x, x[0].y + c1 * a1.y + c2 * a2.y);
+                float2 t2 = make_float2(x[0].x + c2 * a1.x + c1 * a2.x, x[0].y + c2 * a1.y + c1 * a2.y);
+                float2 u1 = make_float2(s1 * b1.x + s2 * b2.x, s1 * b1.y + s2 * b2.y);
+                float2 u2 = make_float2(s2 * b1.x - s1 * b2.x, s2 * b1.y - s1 * b2.y);
+                float2 j1 = make_float2(-sgn * u1.y, sgn * u1.x), j2 = make_float2(-sgn * u2.y, sgn * u2.x);   // (sgn i) u
+                p[0] = make_float2(x[0].x + a1.x + a2.x, x[0].y + a1.y + a2.y);
+                p[Lp] = cadd(t1, j1); p[4 * Lp] = csub(t1, j1);
+                p[2 * Lp] = cadd(t2, j2); p[3 * Lp] = csub(t2, j2);
+            }
         }
+        Lp = L;
     }
     __syncthreads();
 }

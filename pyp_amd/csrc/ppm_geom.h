@@ -23,7 +23,8 @@ struct Geom {
     double r_hi = 0, r_lo = 0, r_s = 0, ring_signed = 0;
     int B = 0, W = 0, H = 0;      // full band: half-width, row width B+1, rows 2B+1
     int Bs = 0, Hs = 0;           // search band
-    int Ns = 0, step = 0, RSx = 0, RSy = 0;
+    int Ns = 0, RSx = 0, RSy = 0;
+    double step = 0;              // global-search shift grid: Ns points over the box, step = N/Ns pixels
     int n_theta = 0, n_psi = 0, n_dir = 0, n_orient = 0, npsi_store = 0, half = 0;
     double dpsi = 0, dstep = 0, phi_max = 360, theta_max = 180;
 };
@@ -41,6 +42,29 @@ inline void sym_limits(const char *sym, double &phi_max, double &theta_max) {
 }
 
 inline bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+// box sizes the FFTs handle: even, 32..512, prime factors 2, 3, 5 only
+inline bool box_ok(int n) {
+    if (n < 32 || n > 512 || n % 2) return false;
+    while (n % 2 == 0) n /= 2;
+    while (n % 3 == 0) n /= 3;
+    while (n % 5 == 0) n /= 5;
+    return n == 1;
+}
+// factors (4s first, then 2, 3, 5) and the digit-reversal staging permutation of an FFT length
+inline void fft_factors(int n, std::vector<int> &fac, std::vector<unsigned short> &perm) {
+    fac.clear();
+    int m = n;
+    while (m % 4 == 0) { fac.push_back(4); m /= 4; }
+    while (m % 2 == 0) { fac.push_back(2); m /= 2; }
+    while (m % 3 == 0) { fac.push_back(3); m /= 3; }
+    while (m % 5 == 0) { fac.push_back(5); m /= 5; }
+    perm.resize(n);
+    for (int i = 0; i < n; i++) {
+        int pos = 0, rem = i, L = n;
+        for (int st = (int)fac.size() - 1; st >= 0; st--) { int r = fac[st]; L /= r; pos += (rem % r) * L; rem /= r; }
+        perm[i] = (unsigned short)pos;
+    }
+}
 
 inline int n_phi_at(double theta_deg, double dstep, double phi_max = 360.0) {
     int np = (int)std::floor(phi_max * std::sin(theta_deg * kPi / 180.0) / dstep + 0.5);
@@ -50,7 +74,7 @@ inline int n_phi_at(double theta_deg, double dstep, double phi_max = 360.0) {
 inline bool geom_init(Geom &g, const ppm_refine_cfg &c, std::string &err) {
     g = Geom();
     g.N = c.box; g.a = c.pixel_size;
-    if (!is_pow2(g.N) || g.N < 32 || g.N > 512) { err = "box size must be a power of two in 32..512"; return false; }
+    if (!box_ok(g.N)) { err = "box size must be even, 32..512, with prime factors 2, 3 and 5 only"; return false; }
     if (!(g.a > 0) || !(c.res_high > 0)) { err = "pixel size and high-resolution limit must be positive"; return false; }
     double na = g.N * g.a;
     g.r_hi = na / c.res_high; if (g.r_hi > g.N / 2) g.r_hi = g.N / 2;
@@ -60,8 +84,8 @@ inline bool geom_init(Geom &g, const ppm_refine_cfg &c, std::string &err) {
     g.B = (int)std::ceil(g.r_hi) - 1; g.W = g.B + 1; g.H = 2 * g.B + 1;
     g.Bs = (int)std::ceil(g.r_s) - 1; g.Hs = 2 * g.Bs + 1;
     if (g.B < 2) { err = "resolution limits leave fewer than 3 Fourier pixels"; return false; }
-    g.Ns = 2; while (g.Ns < 2 * (g.Bs + 1)) g.Ns <<= 1; if (g.Ns > g.N) g.Ns = g.N;
-    g.step = g.N / g.Ns;
+    g.Ns = 2; while (g.Ns < 2 * (g.Bs + 1)) g.Ns <<= 1;
+    g.step = (double)g.N / g.Ns;
     double rx = c.search_range_x / g.a, ry = c.search_range_y / g.a;
     g.RSx = rx > 0 ? (int)std::ceil(rx / g.step) : PPM_MAX_SHIFT_STEPS;
     g.RSy = ry > 0 ? (int)std::ceil(ry / g.step) : PPM_MAX_SHIFT_STEPS;

@@ -17,8 +17,8 @@ namespace ppm {
 
 // ---------------------------------------------------------------------------------- 3-D FFT passes
 struct FftLinesP {
-    float2 *data; const float2 *tw;
-    int n, logn, inverse, line_major, L;
+    float2 *data; FftPlan plan;
+    int n, inverse, line_major, L;
     long nlines, inner, inner_stride, outer_stride, elem_stride;
 };
 
@@ -34,9 +34,9 @@ __global__ void __launch_bounds__(256) k_fft_lines(FftLinesP P) {
         if (P.line_major) { line = i % nl; e = i / nl; } else { line = i / n; e = i % n; }
         long l = l0 + line;
         long base = (l / P.inner) * P.outer_stride + (l % P.inner) * P.inner_stride;
-        buf[line * n + bitrev(e, P.logn)] = P.data[base + e * P.elem_stride];
+        buf[line * n + P.plan.perm[e]] = P.data[base + e * P.elem_stride];
     }
-    lds_fft(buf, n, P.logn, nl, n, P.inverse != 0, P.tw, tid, 256);
+    lds_fft(buf, P.plan, nl, n, P.inverse != 0, tid, 256);
     for (int i = tid; i < nl * n; i += 256) {
         int line, e;
         if (P.line_major) { line = i % nl; e = i / nl; } else { line = i / n; e = i % n; }
@@ -74,8 +74,8 @@ __global__ void k_ref_crop(const float2 *__restrict__ f, float2 *__restrict__ cu
 
 // ---------------------------------------------------------------------------------- pre-processing
 struct PrepP {
-    const float *images; const double *rows; const float2 *tw;
-    int N, logN, B, W, H;
+    const float *images; const double *rows; FftPlan plan;
+    int N, B, W, H;
     float r_hi2, Rm, wfall, a;
     int normalize, invert, do_mask, whiten;
     int nc, nchunks, L;
@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(kPrepThreads) k_prep(PrepP P) {
     double s1 = 0, s2 = 0, cnt = 0, t1 = 0, t2 = 0;
     const float Rm2 = P.Rm * P.Rm;
     for (int i = tid; i < N * N; i += PT) {
-        int x = i & (N - 1), y = i >> P.logN;
+        int y = i / N, x = i - y * N;
         float dx = (float)(x - N / 2), dy = (float)(y - N / 2), v = img[i];
         t1 += v; t2 += (double)v * v;
         if (dx * dx + dy * dy > Rm2) { s1 += v; s2 += (double)v * v; cnt += 1.0; }
@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(kPrepThreads) k_prep(PrepP P) {
         for (int y0 = 0; y0 < N; y0 += 2 * P.L) {
             __syncthreads();
             for (int i = tid; i < P.L * N; i += PT) {
-                int l = i >> P.logN, x = i & (N - 1);
+                int l = i / N, x = i - l * N;
                 int ya = y0 + 2 * l, yb = ya + 1;
                 float va = (img[ya * N + x] - mu) * sc, vb = (img[yb * N + x] - mu) * sc;
                 if (P.do_mask) {
@@ -158,29 +158,29 @@ __global__ void __launch_bounds__(kPrepThreads) k_prep(PrepP P) {
                     float mb = rb >= P.Rm + 0.5f * wf ? 0.f : (rb > P.Rm - 0.5f * wf ? 0.5f * (1.f + cosf(kPiF * (rb - P.Rm + 0.5f * wf) / wf)) : 1.f);
                     va *= ma; vb *= mb;
                 }
-                Wk[l * N + bitrev(x, P.logN)] = make_float2(va, vb);
+                Wk[l * N + P.plan.perm[x]] = make_float2(va, vb);
             }
-            lds_fft(Wk, N, P.logN, P.L, N, false, P.tw, tid, PT);
+            lds_fft(Wk, P.plan, P.L, N, false, tid, PT);
             for (int i = tid; i < P.L * ncol; i += PT) {
                 int l = i / ncol, c = i - l * ncol, kx = c0 + c;
-                float2 z = Wk[l * N + kx], zc = Wk[l * N + ((N - kx) & (N - 1))];
+                float2 z = Wk[l * N + kx], zc = Wk[l * N + (kx ? N - kx : 0)];
                 float2 xa = make_float2(0.5f * (z.x + zc.x), 0.5f * (z.y - zc.y));
                 float2 d = make_float2(z.x - zc.x, z.y + zc.y);
                 float2 xb = make_float2(0.5f * d.y, -0.5f * d.x);
                 int ya = y0 + 2 * l;
-                T[c * TS + bitrev(ya, P.logN)] = xa;
-                T[c * TS + bitrev(ya + 1, P.logN)] = xb;
+                T[c * TS + P.plan.perm[ya]] = xa;
+                T[c * TS + P.plan.perm[ya + 1]] = xb;
             }
         }
         // ---- column pass
-        lds_fft(T, N, P.logN, ncol, TS, false, P.tw, tid, PT);
+        lds_fft(T, P.plan, ncol, TS, false, tid, PT);
         const float invN = 1.f / (float)N;
         for (int i = tid; i < ncol * H; i += PT) {
             int c = i % ncol, row = i / ncol, ky = row - B, kx = c0 + c;
             float k2 = (float)(kx * kx + ky * ky);
             float2 o = make_float2(0.f, 0.f);
             if (k2 < P.r_hi2 && k2 > 0.f) {
-                float2 v = T[c * TS + ((ky + N) & (N - 1))];
+                float2 v = T[c * TS + (ky < 0 ? ky + N : ky)];
                 float sg = ((kx + ky) & 1) ? -invN : invN;
                 o = make_float2(v.x * sg, v.y * sg);
                 int b = (int)floorf(sqrtf(k2));

@@ -261,14 +261,14 @@ __global__ void __launch_bounds__(256, 4) k_local(LocalP P) {
 
 // states from global-search hits: one thread per (particle, hit)
 __global__ void k_states_from_hits(const Hit *hits, LState *states, int n, int K, const double *dir_theta,
-                                   const double *dir_phi, int n_psi, double dpsi, int step, double ha0, double hs0) {
+                                   const double *dir_phi, int n_psi, double dpsi, double step, double ha0, double hs0) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n * K) return;
     Hit h = hits[i];
     LState s;
     int dir = h.orient / n_psi, k = h.orient - dir * n_psi;
     d_euler(k * dpsi, dir_theta[dir], dir_phi[dir], s.M);
-    s.sh[0] = (double)(h.sx * step); s.sh[1] = (double)(h.sy * step);
+    s.sh[0] = h.sx * step; s.sh[1] = h.sy * step;
     s.f = h.cc; s.ha = ha0; s.hs = hs0; s.particle = i / K; s.pad = 0;
     states[i] = s;
 }

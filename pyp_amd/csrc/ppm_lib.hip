@@ -43,7 +43,8 @@ struct Ctx {
     bool inited = false;
     int device = 0;
     hipStream_t stream = nullptr;
-    float2 *tw[10] = { nullptr };   // tw[m]: table for n = 2^m, m = 1..9
+    struct PlanDev { FftPlan plan; bool ready = false; };
+    PlanDev plans[513];             // FFT plans by length (tables live in device memory)
     bool prof_on = false;
     double prof_ms[PPM_K_COUNT] = { 0 };
     long prof_n[PPM_K_COUNT] = { 0 };
@@ -71,28 +72,36 @@ struct ProfScope {
     ~ProfScope() { if (a) { hipEvent_t b = ev_get(); (void)hipEventRecord(b, g.stream); g.pending.push_back({ id, a, b }); } }
 };
 
-int ilog2(int n) { int l = 0; while ((1 << l) < n) l++; return l; }
-
-int ensure_tw(int n) {
-    int m = ilog2(n);
-    if (m < 1 || m > 9) return fail(-22, "FFT length out of range");
-    if (g.tw[m]) return 0;
-    std::vector<float2> t(n / 2);
-    for (int k = 0; k < n / 2; k++) t[k] = make_float2((float)std::cos(2.0 * kPi * k / n), (float)std::sin(2.0 * kPi * k / n));
-    HIPCHK(hipMalloc(&g.tw[m], sizeof(float2) * (n / 2)));
-    HIPCHK(hipMemcpy(g.tw[m], t.data(), sizeof(float2) * (n / 2), hipMemcpyHostToDevice));
+int ensure_plan(int n) {
+    if (n < 2 || n > 512) return fail(-22, "FFT length out of range");
+    if (g.plans[n].ready) return 0;
+    std::vector<int> fac; std::vector<unsigned short> perm;
+    fft_factors(n, fac, perm);
+    int prod = 1; for (int f : fac) prod *= f;
+    if (prod != n || fac.size() > 12) return fail(-22, "FFT length must have prime factors 2, 3 and 5 only");
+    std::vector<float2> t(n);
+    for (int k = 0; k < n; k++) t[k] = make_float2((float)std::cos(2.0 * kPi * k / n), (float)std::sin(2.0 * kPi * k / n));
+    float2 *dtw = nullptr; unsigned short *dperm = nullptr;
+    HIPCHK(hipMalloc(&dtw, sizeof(float2) * n));
+    HIPCHK(hipMalloc(&dperm, sizeof(unsigned short) * n));
+    HIPCHK(hipMemcpy(dtw, t.data(), sizeof(float2) * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dperm, perm.data(), sizeof(unsigned short) * n, hipMemcpyHostToDevice));
+    FftPlan &p = g.plans[n].plan;
+    p.n = n; p.nfac = (int)fac.size(); for (size_t i = 0; i < fac.size(); i++) p.fac[i] = fac[i];
+    p.tw = dtw; p.perm = dperm;
+    g.plans[n].ready = true;
     return 0;
 }
 
 // 3-D FFT of an n^3 complex array in place (three strided passes through LDS)
 int fft3d(float2 *d, int n, bool inverse) {
-    if (int rc = ensure_tw(n)) return rc;
-    int logn = ilog2(n);
-    const int L = std::max(1, std::min(16, 8192 / n));
+    if (int rc = ensure_plan(n)) return rc;
+    int L = std::max(1, std::min(16, 8192 / n));
+    while (((long)n * n) % L) L--;
     long nlines = (long)n * n;
     for (int pass = 0; pass < 3; pass++) {
         FftLinesP P;
-        P.data = d; P.tw = g.tw[logn]; P.n = n; P.logn = logn; P.inverse = inverse ? 1 : 0; P.L = L; P.nlines = nlines;
+        P.data = d; P.plan = g.plans[n].plan; P.n = n; P.inverse = inverse ? 1 : 0; P.L = L; P.nlines = nlines;
         if (pass == 0) { P.inner = nlines; P.inner_stride = n; P.outer_stride = 0; P.elem_stride = 1; P.line_major = 0; }
         else if (pass == 1) { P.inner = n; P.inner_stride = 1; P.outer_stride = (long)n * n; P.elem_stride = n; P.line_major = 1; }
         else { P.inner = nlines; P.inner_stride = 1; P.outer_stride = 0; P.elem_stride = (long)n * n; P.line_major = 1; }
@@ -148,15 +157,16 @@ struct ppm_accum {
 static int launch_prep(const float *d_images, const double *d_rows, int n_img, const Geom &gm, float Rm_px, float fall_px,
                        int normalize, int invert, int do_mask, int whiten, float2 *band, float *wring,
                        const uint32_t *samples, int S_pad, float2 *Il, float *cw, float2 *Wp, float *C2, float *nI) {
-    if (int rc = ensure_tw(gm.N)) return rc;
+    if (int rc = ensure_plan(gm.N)) return rc;
     PrepP P;
-    P.images = d_images; P.rows = d_rows; P.tw = g.tw[ilog2(gm.N)];
-    P.N = gm.N; P.logN = ilog2(gm.N); P.B = gm.B; P.W = gm.W; P.H = gm.H;
+    P.images = d_images; P.rows = d_rows; P.plan = g.plans[gm.N].plan;
+    P.N = gm.N; P.B = gm.B; P.W = gm.W; P.H = gm.H;
     P.r_hi2 = (float)(gm.r_hi * gm.r_hi); P.Rm = Rm_px; P.wfall = fall_px; P.a = (float)gm.a;
     P.normalize = normalize; P.invert = invert; P.do_mask = do_mask; P.whiten = whiten;
     P.nc = std::min(gm.W, (int)(139264 / ((gm.N + 1) * sizeof(float2))));
     P.nchunks = (gm.W + P.nc - 1) / P.nc;
     P.L = std::max(1, std::min(2048 / gm.N, gm.N / 2));
+    while ((gm.N / 2) % P.L) P.L--;          // the row pass walks the image 2 L rows at a time
     P.band = band; P.wring = wring; P.samples = samples; P.S_pad = S_pad; P.Il = Il; P.cw = cw;
     P.Wp = Wp; P.C2 = C2; P.nI = nI; P.Bs = gm.Bs; P.Hs = gm.Hs;
     P.r_s2 = (float)(gm.r_s * gm.r_s); P.r_lo2 = (float)(gm.r_lo * gm.r_lo);
@@ -240,7 +250,7 @@ int ppm_device_sync(void) { if (g.stream) HIPCHK(hipStreamSynchronize(g.stream))
 // ------------------------------------------------------------------------------ reference
 ppm_ref_t *ppm_reference_create(const float *vol, int n, float max_band_px) {
     if (!g.inited) { fail(-1, "ppm_init has not been called"); return nullptr; }
-    if (!vol || !is_pow2(n) || n < 32 || n > 512 || !(max_band_px > 0)) { fail(-22, "reference volume must be a power-of-two cube (32..512) and the band positive"); return nullptr; }
+    if (!vol || !box_ok(n) || !(max_band_px > 0)) { fail(-22, "reference box must be even, 32..512, with prime factors 2, 3, 5, and the band positive"); return nullptr; }
     if (max_band_px > n / 2) max_band_px = (float)(n / 2);
     int B = (int)std::ceil(max_band_px) - 1;
     size_t n3 = (size_t)n * n * n;
@@ -442,12 +452,12 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
             {
                 ProfScope ps(PPM_K_TOPK);
                 hipLaunchKernelGGL(k_states_from_hits, dim3((nb * K + 255) / 256), dim3(256), 0, g.stream, ref->hits.p, ref->states.p, nb, K,
-                                   ref->dir_theta.p, ref->dir_phi.p, gm.n_psi, gm.dpsi, gm.step, 0.5 * gm.dstep, (double)gm.step);
+                                   ref->dir_theta.p, ref->dir_phi.p, gm.n_psi, gm.dpsi, gm.step, 0.5 * gm.dstep, gm.step);
             }
             if (cfg->local_refine) {
                 sample_evals = 0;
                 LP.states = ref->states.p; LP.T = Tb; LP.final_rescore = 0;
-                fill_schedule(0.5 * gm.dstep, (double)gm.step, 0, Tb, gm.r_s, (double)K);
+                fill_schedule(0.5 * gm.dstep, gm.step, 0, Tb, gm.r_s, (double)K);
                 ProfScope ps(PPM_K_LOCAL);
                 hipLaunchKernelGGL(k_local, dim3(nb * K), dim3(256), 0, g.stream, LP);
             }
@@ -457,7 +467,7 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
             }
             if (cfg->local_refine) {
                 LP.states = ref->states2.p; LP.T = Tc; LP.final_rescore = 1;
-                fill_schedule(0.5 * gm.dstep / (double)(1 << Tb), (double)gm.step / (double)(1 << Tb), Tb, Tc, gm.r_hi, 1.0);
+                fill_schedule(0.5 * gm.dstep / (double)(1 << Tb), gm.step / (double)(1 << Tb), Tb, Tc, gm.r_hi, 1.0);
                 sample_evals += std::floor(kPi * gm.r_hi * gm.r_hi / 2);
                 ProfScope ps(PPM_K_LOCAL);
                 hipLaunchKernelGGL(k_local, dim3(nb), dim3(256), 0, g.stream, LP);
@@ -502,7 +512,7 @@ size_t ppm_accum_floats(int box) { return (size_t)2 * box * box * (box / 2 + 1) 
 
 ppm_accum_t *ppm_accum_create(int box, float pixel_size, const char *symmetry, void *ext) {
     if (!g.inited) { fail(-1, "ppm_init has not been called"); return nullptr; }
-    if (!is_pow2(box) || box < 32 || box > 512 || !(pixel_size > 0)) { fail(-22, "box must be a power of two in 32..512 and the pixel size positive"); return nullptr; }
+    if (!box_ok(box) || !(pixel_size > 0)) { fail(-22, "box must be even, 32..512, with prime factors 2, 3, 5, and the pixel size positive"); return nullptr; }
     ppm_accum *a = new ppm_accum();
     a->N = box; a->pixel = pixel_size;
     a->nsym = symmetry_ops(symmetry, a->symops);

@@ -74,7 +74,8 @@ def test_global_grid_search_matches_oracle_exactly(d64, H, O):
     assert np.abs(want[:, 14] - got[:, 14]).max() < 0.01
 
 
-@pytest.mark.parametrize("n,px,m,step", [(64, 2.0, 24, 15.0), (128, 1.5, 8, 15.0), (64, 2.0, 6, 20.0), (32, 3.0, 6, 30.0)])
+@pytest.mark.parametrize("n,px,m,step", [(64, 2.0, 24, 15.0), (128, 1.5, 8, 15.0), (64, 2.0, 6, 20.0), (32, 3.0, 6, 30.0),
+                                          (96, 1.5, 6, 15.0), (80, 2.0, 6, 15.0), (48, 3.0, 6, 20.0)])   # 2^5 3, 2^4 5, 2^4 3: mixed-radix FFT
 def test_full_refinement_matches_oracle(H, O, n, px, m, step):
     vol, imgs, rows = dataset(n, m, px, 0.1)
     g, o = H.Reference(vol, n / 2), O.Reference(vol, n / 2)
@@ -196,6 +197,23 @@ def test_insertion_and_finalise_match_oracle(H, O, sym):
     for a, b in ((w1, g1), (w2, g2), (wf, gf)):
         assert np.linalg.norm(a - b) / np.linalg.norm(a) < 1e-4
     assert np.abs(ws[:, 3:5] - gs[:, 3:5]).max() < 1e-4                  # FSC, part-FSC
+
+
+def test_insertion_non_power_of_two_box(H, O):
+    n, px, m = 96, 1.5, 16
+    vol, imgs, rows = dataset(n, m, px, 0.2)
+    rc = ReconCfg(box=n, pixel_size=px, res_limit=2 * px, normalize=1, split_by_pind=0, mask_radius=0.4 * n * px)
+    acc = np.zeros(O.accum_floats(n), dtype=np.float32)
+    counts = np.zeros(2, dtype=np.int64)
+    O.insert_batch(acc, counts, rc, "C2", imgs, rows)
+    ga = H.Accumulator(n, px, "C2")
+    ga.insert(rc, imgs, rows)
+    assert np.linalg.norm(ga.download() - acc) / np.linalg.norm(acc) < 1e-4
+    fc = FinalCfg(molecular_mass_kda=200.0, inner_radius=0.0, outer_radius=0.45 * n * px, mask_falloff=0.0)
+    w = O.finalize(acc, n, px, fc)
+    g = ga.finalize(fc)
+    for a, b in zip(w[:3], g[:3]):
+        assert np.linalg.norm(a - b) / np.linalg.norm(a) < 1e-4
 
 
 def test_accumulator_sum_is_linear(H, O):

@@ -140,3 +140,23 @@ def test_symmetry_restricted_grid_finds_an_equivalent_pose():
         errs = [np.degrees(np.arccos(np.clip((np.trace((g @ mt).T @ mo) - 1) / 2, -1, 1))) for g in ops]
         assert min(errs) < 1.5, (i, errs)
         assert out[i, C["THETA"]] <= 90.0 + 10.0       # stays near the asymmetric unit (local refinement may step out a little)
+
+
+def test_mixed_radix_fft_matches_numpy():
+    rng = np.random.default_rng(3)
+    for n in (32, 48, 80, 96, 120, 160, 192, 240, 256, 320, 384, 480, 512):
+        x = (rng.normal(size=n) + 1j * rng.normal(size=n)).astype(np.complex64)
+        assert np.abs(oracle.fft1d(x) - np.fft.fft(x)).max() < 2e-5 * np.sqrt(n)
+        assert np.abs(oracle.fft1d(x, True) - np.fft.ifft(x) * n).max() < 2e-5 * np.sqrt(n)
+    with pytest.raises(ValueError):
+        oracle.fft1d(np.zeros(56, np.complex64))            # 7 is not a supported factor
+
+
+def test_non_power_of_two_boxes_recover_poses():
+    for n in (48, 96):
+        vol, stack, rows = synth.make_dataset(n, 6, pixel=PX, snr=0)
+        ref = oracle.Reference(vol, n / 2)
+        c = RefineCfg.make(box=n, pixel_size=PX, mask_radius=0.4 * n * PX, res_high=PX * n / (0.375 * n), res_search=PX * n / (0.16 * n),
+                           search_range_x=12.0, search_range_y=12.0)
+        out, _ = oracle.refine_batch(ref, c, stack.numpy(), rows)
+        assert synth.angular_error_deg(out, rows).max() < 1.5 and synth.shift_error_px(out, rows, PX).max() < 0.2
