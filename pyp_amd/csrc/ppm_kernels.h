@@ -277,8 +277,10 @@ struct GlobP {
 };
 
 // Pair twiddles e^{+2 pi i t j / Ns}, [t][j-1] for the row pair ky = +-t: wave-uniform, fetched with scalar loads.
+// Stored as {cos, cos, sin, sin} so that a scalar load delivers the two operand pairs of the packed FMAs as they are.
 constexpr int kRowTwRows = 64;
-__constant__ float2 c_rowtw[kRowTwRows * PPM_MAX_SHIFT_STEPS];
+__constant__ float4 c_rowtw[kRowTwRows * PPM_MAX_SHIFT_STEPS];
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 constexpr int global_threads(int R) { return R <= 3 ? 1024 : 512; }   // wider windows need > 128 VGPRs
 constexpr int global_unroll(int R) { return R <= 3 ? 8 : 4; }         // rows in flight per wave (prefetch depth), even
@@ -349,11 +351,13 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
     float *ccp = P.cc + (size_t)p * P.n_orient; int *shp = P.sh + (size_t)p * P.n_orient;
     for (int sl = wave; sl < nslices; sl += NW) {
         const float2 *Pp = P.bank + (size_t)sl * nsampP;          // wave-uniform base, lane added as a 32-bit offset
-        // accumulators: s* = sum over rows (shift row 0); per j: even part x cos (ua, ub), odd part x sin (va, vb)
-        float sax = 0.f, say = 0.f, sbx = 0.f, sby = 0.f, nP = 0.f;
-        float uax[R], uay[R], ubx[R], uby[R], vax[R], vay[R], vbx[R], vby[R];
+        // accumulators (packed re/im pairs): s* = sum over rows (shift row 0); per j: even part x cos (ua, ub),
+        // odd part x sin (va, vb)
+        v2f sa = { 0.f, 0.f }, sb = { 0.f, 0.f };
+        float nP = 0.f;
+        v2f ua[R], ub[R], va[R], vb[R];
 #pragma unroll
-        for (int j = 0; j < R; j++) { uax[j] = uay[j] = ubx[j] = uby[j] = vax[j] = vay[j] = vbx[j] = vby[j] = 0.f; }
+        for (int j = 0; j < R; j++) { ua[j] = ub[j] = va[j] = vb[j] = (v2f){ 0.f, 0.f }; }
         float2 pv[U], pn[U];
 #pragma unroll
         for (int u = 0; u < U; u++) pv[u] = Pp[u * 64 + lane];
@@ -372,22 +376,27 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
                 nP = fmaf(ca, fmaf(pax, pax, pay * pay), nP);
                 nP = fmaf(cb, fmaf(pbx, pbx, pby * pby), nP);
                 // A = Re(P) W, Bq = Im(P) (Wy, -Wx) for both rows; even (+) and odd (-) parts of the pair
-                const float aax = pax * wa.x, aay = pax * wa.y, bax = pay * wa.y, bay = -pay * wa.x;
-                const float abx = pbx * wb.x, aby = pbx * wb.y, bbx = pby * wb.y, bby = -pby * wb.x;
-                const float asx = aax + abx, asy = aay + aby, adx = aax - abx, ady = aay - aby;
-                const float bsx = bax + bbx, bsy = bay + bby, bdx = bax - bbx, bdy = bay - bby;
-                sax += asx; say += asy; sbx += bsx; sby += bsy;
+                const v2f wav = { wa.x, wa.y }, wbv = { wb.x, wb.y }, waq = { wa.y, -wa.x }, wbq = { wb.y, -wb.x };
+                const v2f aa = wav * pax, ab = wbv * pbx, ba = waq * pay, bb = wbq * pby;
+                const v2f as2 = aa + ab, ad2 = aa - ab, bs2 = ba + bb, bd2 = ba - bb;
+                sa += as2; sb += bs2;
 #pragma unroll
                 for (int j = 0; j < R; j++) {
-                    const float2 t = c_rowtw[tp * PPM_MAX_SHIFT_STEPS + j];     // wave-uniform -> SGPRs
-                    uax[j] = fmaf(asx, t.x, uax[j]); uay[j] = fmaf(asy, t.x, uay[j]);
-                    ubx[j] = fmaf(bsx, t.x, ubx[j]); uby[j] = fmaf(bsy, t.x, uby[j]);
-                    vax[j] = fmaf(adx, t.y, vax[j]); vay[j] = fmaf(ady, t.y, vay[j]);
-                    vbx[j] = fmaf(bdx, t.y, vbx[j]); vby[j] = fmaf(bdy, t.y, vby[j]);
+                    const float4 t = c_rowtw[tp * PPM_MAX_SHIFT_STEPS + j];     // wave-uniform -> SGPRs {c, c, s, s}
+                    const v2f tc = { t.x, t.y }, ts = { t.z, t.w };
+                    ua[j] += as2 * tc; ub[j] += bs2 * tc;
+                    va[j] += ad2 * ts; vb[j] += bd2 * ts;
                 }
             }
 #pragma unroll
             for (int u = 0; u < U; u++) pv[u] = pn[u];
+        }
+        const float sax = sa.x, say = sa.y, sbx = sb.x, sby = sb.y;
+        float uax[R], uay[R], ubx[R], uby[R], vax[R], vay[R], vbx[R], vby[R];
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            uax[j] = ua[j].x; uay[j] = ua[j].y; ubx[j] = ub[j].x; uby[j] = ub[j].y;
+            vax[j] = va[j].x; vay[j] = va[j].y; vbx[j] = vb[j].x; vby[j] = vb[j].y;
         }
         nP = wave_sum(nP);
         const float inv = (nP > 0.f && nI > 0.f) ? rsqrtf(nP * nI) : 0.f;

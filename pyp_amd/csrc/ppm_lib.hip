@@ -43,6 +43,7 @@ struct Ctx {
     bool inited = false;
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy = nullptr;     // uploads of the next chunk's images overlap the current chunk's kernels
     struct PlanDev { FftPlan plan; bool ready = false; };
     PlanDev plans[513];             // FFT plans by length (tables live in device memory)
     bool prof_on = false;
@@ -228,6 +229,7 @@ int ppm_init(int device) {
     if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
         return fail(-19, std::string("device is ") + prop.gcnArchName + ", libpypmatch is built for gfx950 only");
     if (!g.stream) HIPCHK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    if (!g.copy) HIPCHK(hipStreamCreateWithFlags(&g.copy, hipStreamNonBlocking));
     g.device = device; g.inited = true;
     return 0;
 }
@@ -328,7 +330,7 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
 
     if (int rc = ref->rows_in.ensure((size_t)CH * PPM_NCOL)) return rc;
     if (int rc = ref->rows_out.ensure((size_t)CH * PPM_NCOL)) return rc;
-    if (!images_on_device) if (int rc = ref->images.ensure((size_t)CH * NN)) return rc;
+    if (!images_on_device) if (int rc = ref->images.ensure((size_t)2 * CH * NN)) return rc;     // double-buffered staging
     if (int rc = ref->band.ensure((size_t)CH * HW)) return rc;
     if (int rc = ref->wring.ensure((size_t)CH * (gm.B + 2))) return rc;
     if (int rc = ref->Il.ensure((size_t)CH * S_pad)) return rc;
@@ -371,12 +373,13 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
             HIPCHK(hipMemcpyAsync(ref->twN.p, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice, g.stream));
             // row twiddles of the shift window -> __constant__ (scalar loads in k_global)
             {
-                std::vector<float2> rt((size_t)kRowTwRows * PPM_MAX_SHIFT_STEPS, make_float2(1.f, 0.f));
+                std::vector<float4> rt((size_t)kRowTwRows * PPM_MAX_SHIFT_STEPS, make_float4(1.f, 1.f, 0.f, 0.f));
                 for (int tp = 0; tp <= gm.Bs && tp < kRowTwRows; tp++) for (int j = 1; j <= PPM_MAX_SHIFT_STEPS; j++) {
                     int t = ((tp * j) % gm.Ns + gm.Ns) % gm.Ns;
-                    rt[(size_t)tp * PPM_MAX_SHIFT_STEPS + j - 1] = make_float2((float)std::cos(2.0 * kPi * t / gm.Ns), (float)std::sin(2.0 * kPi * t / gm.Ns));
+                    const float c = (float)std::cos(2.0 * kPi * t / gm.Ns), sn = (float)std::sin(2.0 * kPi * t / gm.Ns);
+                    rt[(size_t)tp * PPM_MAX_SHIFT_STEPS + j - 1] = make_float4(c, c, sn, sn);
                 }
-                HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_rowtw), rt.data(), rt.size() * sizeof(float2)));
+                HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_rowtw), rt.data(), rt.size() * sizeof(float4)));
             }
             BankP BP; BP.cv = cv; BP.mats = ref->mats.p; BP.bank = ref->bank.p; BP.nslices = nslices; BP.Bs = gm.Bs; BP.Hs = HsP;
             BP.r_s2 = (float)(gm.r_s * gm.r_s);
@@ -425,15 +428,14 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
         (void)t0;
     };
     LP.rmax2_final = (float)(gm.r_hi * gm.r_hi); LP.S_final = S_pad;
-    for (int c0 = 0; c0 < n_img; c0 += CH) {
+    if (!images_on_device) {        // first chunk's images
+        HIPCHK(hipMemcpyAsync(ref->images.p, images, (size_t)std::min(CH, n_img) * NN * sizeof(float), hipMemcpyHostToDevice, g.copy));
+        HIPCHK(hipStreamSynchronize(g.copy));
+    }
+    for (int c0 = 0, ci = 0; c0 < n_img; c0 += CH, ci++) {
         const int nb = std::min(CH, n_img - c0);
         HIPCHK(hipMemcpyAsync(ref->rows_in.p, rows_in + (size_t)c0 * PPM_NCOL, (size_t)nb * PPM_NCOL * sizeof(double), hipMemcpyHostToDevice, g.stream));
-        const float *d_img;
-        if (images_on_device) d_img = (const float *)images + (size_t)c0 * NN;
-        else {
-            HIPCHK(hipMemcpyAsync(ref->images.p, (const float *)images + (size_t)c0 * NN, (size_t)nb * NN * sizeof(float), hipMemcpyHostToDevice, g.stream));
-            d_img = ref->images.p;
-        }
+        const float *d_img = images_on_device ? (const float *)images + (size_t)c0 * NN : ref->images.p + (size_t)(ci & 1) * CH * NN;
         // refinement spectra (+ search tables when the same mask serves both)
         if (int rc = launch_prep(d_img, ref->rows_in.p, nb, gm, Rm_px, fall_px, cfg->normalize, cfg->invert, 1, 1, ref->band.p, ref->wring.p,
                                  ref->samples.p, S_pad, ref->Il.p, ref->cw.p,
@@ -484,8 +486,14 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
         }
         hipLaunchKernelGGL(k_rows_out, dim3((nb + 255) / 256), dim3(256), 0, g.stream, final_states, ref->rows_in.p, ref->rows_out.p, nb, gm.a, gm.r_hi, gm.r_lo);
         HIPCHK(hipGetLastError());
+        if (!images_on_device && c0 + CH < n_img) {     // next chunk's images travel while this chunk computes
+            const int nn = std::min(CH, n_img - (c0 + CH));
+            HIPCHK(hipMemcpyAsync(ref->images.p + (size_t)((ci + 1) & 1) * CH * NN, (const float *)images + (size_t)(c0 + CH) * NN,
+                                  (size_t)nn * NN * sizeof(float), hipMemcpyHostToDevice, g.copy));
+        }
         HIPCHK(hipMemcpyAsync(rows_out + (size_t)c0 * PPM_NCOL, ref->rows_out.p, (size_t)nb * PPM_NCOL * sizeof(double), hipMemcpyDeviceToHost, g.stream));
         HIPCHK(hipStreamSynchronize(g.stream));
+        HIPCHK(hipStreamSynchronize(g.copy));
     }
     // evaluation counts per particle, for the roofline's algorithmic bytes
     long nl;
@@ -553,17 +561,16 @@ int ppm_insert_batch(ppm_accum_t *a, const ppm_recon_cfg *cfg, const void *image
     int CH = (int)std::min<size_t>((size_t)n_img, std::max<size_t>(32, ((size_t)2 << 30) / (NN * 4 + HW * 8)));
     CH = std::min(CH, 32768);   // grid.y limit
     if (int r = a->rows.ensure((size_t)CH * PPM_NCOL)) return r;
-    if (!images_on_device) if (int r = a->images.ensure((size_t)CH * NN)) return r;
+    if (!images_on_device) if (int r = a->images.ensure((size_t)2 * CH * NN)) return r;       // double-buffered staging
     if (int r = a->band.ensure((size_t)CH * HW)) return r;
-    for (int c0 = 0; c0 < n_img; c0 += CH) {
+    if (!images_on_device) {
+        HIPCHK(hipMemcpyAsync(a->images.p, images, (size_t)std::min(CH, n_img) * NN * sizeof(float), hipMemcpyHostToDevice, g.copy));
+        HIPCHK(hipStreamSynchronize(g.copy));
+    }
+    for (int c0 = 0, ci = 0; c0 < n_img; c0 += CH, ci++) {
         const int nb = std::min(CH, n_img - c0);
         HIPCHK(hipMemcpyAsync(a->rows.p, rows + (size_t)c0 * PPM_NCOL, (size_t)nb * PPM_NCOL * sizeof(double), hipMemcpyHostToDevice, g.stream));
-        const float *d_img;
-        if (images_on_device) d_img = (const float *)images + (size_t)c0 * NN;
-        else {
-            HIPCHK(hipMemcpyAsync(a->images.p, (const float *)images + (size_t)c0 * NN, (size_t)nb * NN * sizeof(float), hipMemcpyHostToDevice, g.stream));
-            d_img = a->images.p;
-        }
+        const float *d_img = images_on_device ? (const float *)images + (size_t)c0 * NN : a->images.p + (size_t)(ci & 1) * CH * NN;
         if (int r = launch_prep(d_img, a->rows.p, nb, gm, cfg->mask_radius / cfg->pixel_size, 1.f, cfg->normalize, cfg->invert, 0, 0,
                                 a->band.p, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr)) return r;
         InsertP IP;
@@ -576,7 +583,13 @@ int ppm_insert_batch(ppm_accum_t *a, const ppm_recon_cfg *cfg, const void *image
             hipLaunchKernelGGL(k_insert, dim3((unsigned)((HW + 255) / 256), nb), dim3(256), 0, g.stream, IP);
         }
         HIPCHK(hipGetLastError());
+        if (!images_on_device && c0 + CH < n_img) {
+            const int nn = std::min(CH, n_img - (c0 + CH));
+            HIPCHK(hipMemcpyAsync(a->images.p + (size_t)((ci + 1) & 1) * CH * NN, (const float *)images + (size_t)(c0 + CH) * NN,
+                                  (size_t)nn * NN * sizeof(float), hipMemcpyHostToDevice, g.copy));
+        }
         HIPCHK(hipStreamSynchronize(g.stream));
+        HIPCHK(hipStreamSynchronize(g.copy));
     }
     unsigned long long c[2];
     HIPCHK(hipMemcpy(c, a->d_counts, sizeof(c), hipMemcpyDeviceToHost));
