@@ -132,6 +132,14 @@ def main():
                         "stored slice serves psi and psi+180, so frac can exceed the HBM-only ceiling; the kernel is fp32-VALU bound",
                 "path_bytes_per_particle": b_pm, "path_achieved_GBps": round(b_pm * M * a.steps / dt / 1e9, 1),
                 "path_frac": round(b_pm * M * a.steps / dt / 8e12, 4)}
+        if dom == "global":
+            # secondary: fp32 vector rate of k_global.  Per slice row pair and lane: 24 FMA (shift rows), 2 x 3 for the norm,
+            # 8 mul + 12 add for the (A, Bq) even/odd parts; plus ~800 ops per lane and slice for the window reduction.
+            R = 3
+            flops_slice = 64 * 64 * (2 * 8 * R + 12 + 20) + 64 * 800
+            flops = per_launch_particles * (counts["n_global"] / 2) * flops_slice
+            roof["k_global_fp32_TFLOPs"] = round(flops / (ms_g * 1e-3) / 1e12, 1)
+            roof["k_global_fp32_frac_of_157"] = round(flops / (ms_g * 1e-3) / 157.3e12, 3)
         # ---- accuracy of what was timed (vs the synthetic ground truth), first 2000 particles
         k = min(M, 2000)
         ang = synth.angular_error_deg(out[:k], rows[:k])

@@ -216,6 +216,45 @@ def test_insertion_non_power_of_two_box(H, O):
         assert np.linalg.norm(a - b) / np.linalg.norm(a) < 1e-4
 
 
+def test_external_accumulator_tensor_and_reduce(H, O):
+    """The accumulator can live in a caller-allocated torch tensor (what RCCL reduces in place)."""
+    import torch
+    from pyp_amd import dist as pdist
+    n, px = 32, 3.0
+    vol, imgs, rows = dataset(n, 12, px, 0.2)
+    rc = ReconCfg(box=n, pixel_size=px, res_limit=2 * px, normalize=1, mask_radius=0.4 * n * px)
+    own = H.Accumulator(n, px)
+    own.insert(rc, imgs, rows)
+    t = torch.zeros(own.nfloats, dtype=torch.float32, device="cuda")
+    ext = H.Accumulator(n, px, ext_tensor=t)
+    ext.insert(rc, imgs, rows)
+    a, b = own.download(), t.cpu().numpy()
+    assert np.linalg.norm(a - b) / np.linalg.norm(a) < 1e-5
+    t2, c2 = pdist.reduce_accumulators(t, ext.counts())           # single process: identity
+    assert c2 == ext.counts() and t2.data_ptr() == t.data_ptr()
+    with pytest.raises(ValueError):
+        H.Accumulator(n, px, ext_tensor=torch.zeros(7, device="cuda"))
+
+
+def test_largest_box_512_properties(H):
+    """N = 512 (the largest supported box): no oracle at this size; the true pose must outscore perturbed poses and a
+    local refinement from a perturbed start must move towards it."""
+    n, px, m = 512, 1.0, 4
+    vol = synth.phantom(n, n_blobs=6, n_atoms=4000)
+    _, stack, rows = synth.make_dataset(n, m, pixel=px, snr=0.1, vol=vol, device="cuda", batch=2)
+    g = H.Reference(vol, 128)
+    c = RefineCfg.make(box=n, pixel_size=px, mask_radius=0.32 * n * px, res_high=px * n / 100.0, global_search=0, local_refine=0,
+                       res_signed_cc=30.0)
+    s_true = g.refine(c, stack, rows)[:, 14]
+    pert = synth.perturb_rows(rows, 1.0, 1.0, px, seed=5)
+    s_pert = g.refine(c, stack, pert)[:, 14]
+    assert (s_true > s_pert).all() and (s_true > 5).all()
+    c.local_refine = 1
+    out = g.refine(c, stack, pert)
+    assert np.median(synth.angular_error_deg(out, rows)) < np.median(synth.angular_error_deg(pert, rows))
+    assert (out[:, 14] >= s_pert - 1e-3).all()
+
+
 def test_accumulator_sum_is_linear(H, O):
     """merge = sum of dumps: inserting two halves of a stack separately and adding equals inserting all (local_merge3d)."""
     n, px = 32, 3.0
