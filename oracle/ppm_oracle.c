@@ -689,8 +689,11 @@ int orc_refine_batch(void *refp, const ppm_refine_cfg *cfg, const float *images,
         out[PPM_XSHIFT] = best.sh[0] * g.a; out[PPM_YSHIFT] = best.sh[1] * g.a;
         double cc = best.f, res = 1.0 - cc * cc; if (res < 1e-6) res = 1e-6;
         out[PPM_SCORE] = 100.0 * cc;
+        /* whitened image against the best model: residual variance 1 - cc^2 per sample, n = in-band samples of the
+         * full plane; LogP = Gaussian log-likelihood at the maximum-likelihood sigma */
+        double nsamp = ORC_PI * (g.r_hi * g.r_hi - g.r_lo * g.r_lo);
         out[PPM_SIGMA] = sqrt(res);
-        out[PPM_LOGP] = -0.5 * (ORC_PI * 0.5 * (g.r_hi * g.r_hi - g.r_lo * g.r_lo)) * log(res);
+        out[PPM_LOGP] = -0.5 * nsamp * (log(2.0 * ORC_PI * res) + 1.0);
         free(I); free(wr);
     }
     free(bank);

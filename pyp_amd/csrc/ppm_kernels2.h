@@ -307,7 +307,7 @@ __global__ void k_rows_out(const LState *states, const double *rows_in, double *
     double cc = s.f, res = 1.0 - cc * cc; if (res < 1e-6) res = 1e-6;
     o[PPM_SCORE] = 100.0 * cc;
     o[PPM_SIGMA] = sqrt(res);
-    o[PPM_LOGP] = -0.5 * (3.14159265358979323846 * 0.5 * (r_hi * r_hi - r_lo * r_lo)) * log(res);
+    o[PPM_LOGP] = -0.5 * (3.14159265358979323846 * (r_hi * r_hi - r_lo * r_lo)) * (log(2.0 * 3.14159265358979323846 * res) + 1.0);
 }
 
 // ---------------------------------------------------------------------------------- Fourier insertion

@@ -21,6 +21,28 @@ C = cistem.COL
 DUMP_MAGIC = b"PPMDUMP1"
 
 
+class gpu_lock:
+    """PYP may still start `slurm_tasks` concurrent refine3d / reconstruct3d processes per node
+    (src/pyp/system/mpi.py:104); they are serialised per GPU with an advisory file lock so that one process at a
+    time owns the device memory (SURVEY.md §8b 'Threading')."""
+
+    def __init__(self, device):
+        self.path = os.path.join(os.environ.get("PPM_LOCK_DIR", "/tmp"), "pyp_amd_gpu%d.lock" % int(device))
+        self.f = None
+
+    def __enter__(self):
+        import fcntl
+        self.f = open(self.path, "w")
+        fcntl.flock(self.f, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *a):
+        import fcntl
+        fcntl.flock(self.f, fcntl.LOCK_UN)
+        self.f.close()
+        return False
+
+
 def _die(msg):
     if "ERROR" not in msg:
         msg = "ERROR: " + msg
@@ -119,9 +141,12 @@ def refine3d_main(argv=None, stdin=None):
         refine_x=int(d["refine_x"]), refine_y=int(d["refine_y"]), normalize=int(d["normalize"]), invert=int(d["invert"]),
         symmetry=d["symmetry"][:7])
     from .. import host, lib
+    dev = int(os.environ.get("PPM_DEVICE", "0"))
     try:
-        ref = host.Reference(vol, box / 2, device=int(os.environ.get("PPM_DEVICE", "0")))
-        rout = ref.refine(cfg, imgs, rin)
+        with gpu_lock(dev):
+            ref = host.Reference(vol, box / 2, device=dev)
+            rout = ref.refine(cfg, imgs, rin)
+            ref.close()
     except (lib.PpmError, ValueError) as e:
         _die(str(e))
     changes = rout - rin
@@ -203,11 +228,14 @@ def reconstruct3d_main(argv=None, stdin=None):
                   score_average=score_avg, score_threshold=d["score_threshold"], normalize=int(d["normalize"]), invert=int(d["invert"]),
                   split_by_pind=int(d["per_particle_splitting"]), mask_radius=d["outer_radius"])
     from .. import host, lib
+    dev = int(os.environ.get("PPM_DEVICE", "0"))
     try:
-        acc = host.Accumulator(box, px, d["symmetry"], device=int(os.environ.get("PPM_DEVICE", "0")))
-        acc.insert(rc, imgs, rin)
-        data = acc.download()
-        counts = acc.counts()
+        with gpu_lock(dev):
+            acc = host.Accumulator(box, px, d["symmetry"], device=dev)
+            acc.insert(rc, imgs, rin)
+            data = acc.download()
+            counts = acc.counts()
+            acc.close()
     except (lib.PpmError, ValueError) as e:
         _die(str(e))
     half = data.size // 2
@@ -275,12 +303,15 @@ def merge3d_main(argv=None, stdin=None):
         print(f"{k:28s}: {v}")
     box, pixel, counts, tot = _sum_dumps(d["dump_seed_1"], d["dump_seed_2"], d["n_dumps"])
     from .. import host, lib
+    dev = int(os.environ.get("PPM_DEVICE", "0"))
     try:
-        acc = host.Accumulator(box, pixel, "C1", device=int(os.environ.get("PPM_DEVICE", "0")))
-        acc.add(np.concatenate([tot[1], tot[0]]).astype(np.float32))      # dump 1 = odd keys = half index 1
-        acc.set_counts(counts[1], counts[0])
-        fc = FinalCfg(molecular_mass_kda=d["molecular_mass"], inner_radius=d["inner_radius"], outer_radius=d["outer_radius"], mask_falloff=0.0)
-        h_even, h_odd, filt, stats = acc.finalize(fc)
+        with gpu_lock(dev):
+            acc = host.Accumulator(box, pixel, "C1", device=dev)
+            acc.add(np.concatenate([tot[1], tot[0]]).astype(np.float32))      # dump 1 = odd keys = half index 1
+            acc.set_counts(counts[1], counts[0])
+            fc = FinalCfg(molecular_mass_kda=d["molecular_mass"], inner_radius=d["inner_radius"], outer_radius=d["outer_radius"], mask_falloff=0.0)
+            h_even, h_odd, filt, stats = acc.finalize(fc)
+            acc.close()
     except (lib.PpmError, ValueError) as e:
         _die(str(e))
     mrc.write(h_odd, d["half1"], pixel_size=pixel)

@@ -235,3 +235,19 @@ def test_executables_fail_loudly_without_inputs(tmp_path):
     assert r.returncode != 0 and "ERROR" in r.stdout and not (tmp_path / "out.cistem").exists()
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bin", "merge3d")], input="a\nb\n", capture_output=True, text=True, cwd=tmp_path)
     assert r.returncode != 0 and "ERROR" in r.stdout
+
+
+def test_gpu_lock_serialises_processes(tmp_path, monkeypatch):
+    """Two holders of the per-GPU lock never overlap (concurrent refine3d processes of one node)."""
+    import multiprocessing as mp
+    import time
+    monkeypatch.setenv("PPM_LOCK_DIR", str(tmp_path))
+
+    def worker(tag, out):
+        with cli.gpu_lock(0):
+            t0 = time.time(); time.sleep(0.3); out.put((tag, t0, time.time()))
+    q = mp.Queue()
+    ps = [mp.Process(target=worker, args=(i, q)) for i in range(2)]
+    [p.start() for p in ps]; [p.join() for p in ps]
+    a, b = sorted([q.get(), q.get()], key=lambda r: r[1])
+    assert b[1] >= a[2] - 1e-3
