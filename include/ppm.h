@@ -110,7 +110,7 @@ typedef struct ppm_accum ppm_accum_t;
 
 /* kernels whose device time the library accumulates when profiling is on */
 enum { PPM_K_PREP = 0, PPM_K_BANK = 1, PPM_K_GLOBAL = 2, PPM_K_TOPK = 3, PPM_K_LOCAL = 4,
-       PPM_K_INSERT = 5, PPM_K_FINAL = 6, PPM_K_COUNT = 7 };
+       PPM_K_INSERT = 5, PPM_K_FINAL = 6, PPM_K_EXTRACT = 7, PPM_K_COUNT = 8 };
 
 int ppm_init(int device);
 const char *ppm_last_error(void);
@@ -150,6 +150,18 @@ void ppm_accum_set_count(ppm_accum_t *acc, int half, long count);
 /* half1/half2/filtered: box^3 floats each (host).  stats: (box/2) * PPM_STATS_COLS doubles. */
 int ppm_finalize(ppm_accum_t *acc, const ppm_final_cfg *cfg, float *half1, float *half2,
                  float *filtered, double *stats);
+
+/* Particle extraction straight into a (resident) stack — the step before the path:
+ * crop `box` x `box` windows around the picked coordinates, fill what falls outside the micrograph with the mean
+ * of the inside part, replace empty boxes by white noise, subtract the background mean and divide by the background
+ * sigma (pixels farther than radius_px from the box centre).  Restates extract_particles_non_mpi
+ * (src/pyp/extract/core.py:447-506) and normalize_image / extract_background / fix_empty_particles_in_place
+ * (src/pyp/analysis/image.py:320-340, :406-417, :461-471).
+ * image: rows x cols floats (row-major); coords: m x 2 doubles {box[0] (column coordinate), box[1] (row coordinate)}
+ * in unbinned pixels; out: m * box * box floats. */
+int ppm_extract_boxes(const void *image, int image_on_device, int rows, int cols, const double *coords, int m,
+                      int box, double coordinate_binning, double radius_px, int normalize, int fix_empty,
+                      void *out, int out_on_device);
 
 /* device-time accounting with HIP events on the library's stream */
 void ppm_profile_enable(int on);

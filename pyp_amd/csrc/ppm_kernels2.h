@@ -472,6 +472,102 @@ __global__ void k_map_post(const float2 *__restrict__ f, float *__restrict__ out
     out[i] = f[i].x / ((float)N * (float)N) / g3 * m;
 }
 
+// ---------------------------------------------------------------------------------- particle extraction
+struct ExtractP {
+    const float *image; int rows, cols;
+    const double *coords; int box; double cbin; float radius2; int normalize, fix_empty;
+    float *out;
+};
+
+__device__ __forceinline__ unsigned hash32(unsigned x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
+
+// Block = one particle.  Window bounds exactly as the reference computes them (including its habit of dropping
+// the last row / column when the window touches the far edge); pass 1 = mean of the inside part, pass 2 =
+// emptiness probes + background statistics, pass 3 = write.  The micrograph window is re-read from L2.
+__global__ void __launch_bounds__(256) k_extract(ExtractP P) {
+    __shared__ double red[4][5];
+    __shared__ double s_fill, s_mu, s_sd;
+    __shared__ int s_empty;
+    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, box = P.box;
+    const double bx = P.coords[2 * p], by = P.coords[2 * p + 1];
+    int minx = 0, miny = 0, maxx = box, maxy = box;
+    int minX = (int)floor(by / P.cbin - floor(box / 2.0)), maxX = minX + box;
+    int minY = (int)floor(bx / P.cbin - floor(box / 2.0)), maxY = minY + box;
+    if (minX < 0) { minx = -minX; minX = 0; } else if (maxX >= P.rows) { maxx = box - (maxX - P.rows + 1); maxX = P.rows - 1; }
+    if (minY < 0) { miny = -minY; minY = 0; } else if (maxY >= P.cols) { maxy = box - (maxY - P.cols + 1); maxY = P.cols - 1; }
+    // python slices clamp: inside = image[minX:maxX, minY:maxY]
+    const int iX0 = minX < P.rows ? minX : P.rows, iX1 = maxX < P.rows ? (maxX > iX0 ? maxX : iX0) : P.rows;
+    const int iY0 = minY < P.cols ? minY : P.cols, iY1 = maxY < P.cols ? (maxY > iY0 ? maxY : iY0) : P.cols;
+    const int nX = iX1 - iX0, nY = iY1 - iY0;
+    const bool has_inside = nX > 0 && nY > 0;
+    auto raw_at = [&](int r, int c, float fill) -> float {       // raw[r][c]: the window pixel or the fill value
+        int ir = r - minx, ic = c - miny;
+        bool in = has_inside && r >= minx && r < maxx && c >= miny && c < maxy && ir < nX && ic < nY;
+        return in ? P.image[(size_t)(iX0 + ir) * P.cols + (iY0 + ic)] : fill;
+    };
+    auto block_sum = [&](double v, int slot) {
+        v = wave_sum_d(v);
+        if (lane == 0) red[wave][slot] = v;
+    };
+    // ---- pass 1: mean of the inside part
+    double s = 0;
+    if (has_inside) for (int i = tid; i < nX * nY; i += 256) s += P.image[(size_t)(iX0 + i / nY) * P.cols + (iY0 + i % nY)];
+    block_sum(s, 0);
+    __syncthreads();
+    if (tid == 0) s_fill = has_inside ? (red[0][0] + red[1][0] + red[2][0] + red[3][0]) / ((double)nX * nY) : 0.0;
+    __syncthreads();
+    const float fill = (float)s_fill;
+    // ---- pass 2: emptiness probes (three candidate "constant" values) + min/max
+    const int npx = box * box;
+    if (P.fix_empty) {
+        const float c0 = raw_at(0, 0, fill), c1 = raw_at(box / 2, box / 2, fill), c2 = fill;
+        double n0 = 0, n1 = 0, n2 = 0; float mn = 3e38f, mx = -3e38f;
+        for (int i = tid; i < npx; i += 256) {
+            float v = raw_at(i / box, i % box, fill);
+            n0 += v == c0; n1 += v == c1; n2 += v == c2; mn = fminf(mn, v); mx = fmaxf(mx, v);
+        }
+        for (int m = 32; m >= 1; m >>= 1) { mn = fminf(mn, __shfl_xor(mn, m, 64)); mx = fmaxf(mx, __shfl_xor(mx, m, 64)); }
+        __syncthreads();
+        block_sum(n0, 0); block_sum(n1, 1); block_sum(n2, 2); block_sum((double)mn, 3); block_sum((double)mx, 4);
+        __syncthreads();
+        if (tid == 0) {
+            double t0 = 0, t1 = 0, t2 = 0, gmn = 3e38, gmx = -3e38;
+            for (int w = 0; w < 4; w++) { t0 += red[w][0]; t1 += red[w][1]; t2 += red[w][2]; gmn = fmin(gmn, red[w][3]); gmx = fmax(gmx, red[w][4]); }
+            double most = fmax(t0, fmax(t1, t2));
+            s_empty = (gmn == gmx) || ((double)npx - most < 0.01 * npx);
+        }
+        __syncthreads();
+    } else { if (tid == 0) s_empty = 0; __syncthreads(); }
+    const bool empty = s_empty != 0;
+    auto value_at = [&](int i) -> float {       // the frame that gets normalised
+        if (!empty) return raw_at(i / box, i % box, fill);
+        unsigned h1 = hash32((unsigned)p * 2654435761u + (unsigned)i * 2u + 1u), h2 = hash32(h1 ^ 0x9e3779b9u);
+        float u1 = ((h1 >> 8) + 1) * (1.0f / 16777217.0f), u2 = (h2 >> 8) * (1.0f / 16777216.0f);
+        return sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);       // unit white noise instead of numpy's
+    };
+    // ---- background statistics (outside radius_px of the box centre)
+    double b1 = 0, b2 = 0, bc = 0;
+    if (P.normalize) {
+        for (int i = tid; i < npx; i += 256) {
+            int r = i / box - box / 2, c = i % box - box / 2;
+            if ((float)(r * r + c * c) > P.radius2) { double v = value_at(i); b1 += v; b2 += v * v; bc += 1; }
+        }
+    }
+    __syncthreads();
+    block_sum(b1, 0); block_sum(b2, 1); block_sum(bc, 2);
+    __syncthreads();
+    if (tid == 0) {
+        double a1 = 0, a2 = 0, ac = 0;
+        for (int w = 0; w < 4; w++) { a1 += red[w][0]; a2 += red[w][1]; ac += red[w][2]; }
+        double mu = ac > 0 ? a1 / ac : 0.0, var = ac > 0 ? a2 / ac - mu * mu : 0.0;
+        s_mu = P.normalize ? mu : 0.0; s_sd = (P.normalize && var > 0) ? sqrt(var) : 1.0;
+    }
+    __syncthreads();
+    const double mu = s_mu, isd = 1.0 / s_sd;
+    float *o = P.out + (size_t)p * npx;
+    for (int i = tid; i < npx; i += 256) o[i] = (float)(((double)value_at(i) - mu) * isd);
+}
+
 __global__ void k_axpy(float *__restrict__ y, const float *__restrict__ x, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] += x[i];

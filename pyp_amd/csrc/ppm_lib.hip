@@ -625,6 +625,36 @@ int ppm_accum_add(ppm_accum_t *a, const float *host) {
     return 0;
 }
 
+int ppm_extract_boxes(const void *image, int image_on_device, int rows, int cols, const double *coords, int m,
+                      int box, double coordinate_binning, double radius_px, int normalize, int fix_empty,
+                      void *out, int out_on_device) {
+    if (!g.inited) return fail(-1, "ppm_init has not been called");
+    if (!image || !coords || !out) return fail(-22, "null argument");
+    if (rows <= 0 || cols <= 0 || box < 2 || box > 4096 || !(coordinate_binning > 0)) return fail(-22, "bad extraction geometry");
+    if (m <= 0) return 0;
+    if (radius_px > box / 2.0) radius_px = box / 2.0;        // "Particle radius falls outside box" (image.py:323-331)
+    float *d_img = nullptr, *d_out = nullptr; double *d_xy = nullptr;
+    const size_t npix = (size_t)rows * cols, nout = (size_t)m * box * box;
+    if (image_on_device) d_img = (float *)image;
+    else { HIPCHK(hipMalloc(&d_img, npix * sizeof(float))); HIPCHK(hipMemcpy(d_img, image, npix * sizeof(float), hipMemcpyHostToDevice)); }
+    if (out_on_device) d_out = (float *)out; else HIPCHK(hipMalloc(&d_out, nout * sizeof(float)));
+    HIPCHK(hipMalloc(&d_xy, (size_t)m * 2 * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(d_xy, coords, (size_t)m * 2 * sizeof(double), hipMemcpyHostToDevice, g.stream));
+    ExtractP P; P.image = d_img; P.rows = rows; P.cols = cols; P.coords = d_xy; P.box = box; P.cbin = coordinate_binning;
+    P.radius2 = (float)(radius_px * radius_px); P.normalize = normalize; P.fix_empty = fix_empty; P.out = d_out;
+    {
+        ProfScope ps(PPM_K_EXTRACT);
+        hipLaunchKernelGGL(k_extract, dim3(m), dim3(256), 0, g.stream, P);
+    }
+    HIPCHK(hipGetLastError());
+    if (!out_on_device) HIPCHK(hipMemcpyAsync(out, d_out, nout * sizeof(float), hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    (void)hipFree(d_xy);
+    if (!image_on_device) (void)hipFree(d_img);
+    if (!out_on_device) (void)hipFree(d_out);
+    return 0;
+}
+
 int ppm_finalize(ppm_accum_t *a, const ppm_final_cfg *cfg, float *half1, float *half2, float *filtered, double *stats) {
     if (!g.inited) return fail(-1, "ppm_init has not been called");
     if (!a || !cfg) return fail(-22, "null argument");

@@ -129,6 +129,37 @@ class Accumulator:
             pass
 
 
+def extract_boxes(micrograph, coords, box, radius_A, pixel_size, coordinate_binning=1, normalize=True, fix_empty=True,
+                  out=None, device=0):
+    """Crop + normalise particle boxes (src/pyp/extract/core.py:447-506 with src/pyp/analysis/image.py:406-417).
+    micrograph: 2-D float32 numpy array or CUDA tensor; coords: (M, 2) of (box[0], box[1]) = (column, row) coordinates;
+    out: optional CUDA tensor (M, box, box) to fill in place (resident stack).  Returns the stack."""
+    lib.init(device)
+    coords = np.ascontiguousarray(coords, dtype=np.float64).reshape(-1, 2)
+    m = len(coords)
+    radius_px = float(radius_A) / (float(pixel_size) * float(coordinate_binning))
+    if hasattr(micrograph, "is_cuda") and micrograph.is_cuda:
+        if str(micrograph.dtype) != "torch.float32" or not micrograph.is_contiguous() or micrograph.dim() != 2:
+            raise ValueError("ERROR: device micrograph must be a contiguous 2-D float32 tensor")
+        ip, idev, rows, cols, keep = C.c_void_p(micrograph.data_ptr()), 1, micrograph.shape[0], micrograph.shape[1], micrograph
+    else:
+        a = np.ascontiguousarray(micrograph, dtype=np.float32)
+        if a.ndim != 2:
+            raise ValueError("ERROR: micrograph must be 2-D")
+        ip, idev, rows, cols, keep = lib.ptr(a), 0, a.shape[0], a.shape[1], a
+    if out is not None:
+        if not out.is_cuda or out.numel() != m * box * box or not out.is_contiguous():
+            raise ValueError("ERROR: output stack tensor has the wrong size or is not on the GPU")
+        op, odev, res = C.c_void_p(out.data_ptr()), 1, out
+    else:
+        res = np.empty((m, box, box), dtype=np.float32)
+        op, odev = lib.ptr(res), 0
+    lib.check(lib.load().ppm_extract_boxes(ip, idev, int(rows), int(cols), lib.ptr(coords), m, int(box), float(coordinate_binning),
+                                           radius_px, int(bool(normalize)), int(bool(fix_empty)), op, odev))
+    del keep
+    return res
+
+
 def profile(enable=True, reset=True):
     lib.load().ppm_profile_enable(1 if enable else 0)
     if reset:

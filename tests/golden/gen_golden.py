@@ -18,6 +18,7 @@ Reference entry points exercised:
   src/pyp/inout/image/mrc.py:537-560                   write / read / readHeaderFromFile
   src/pyp/analysis/geometry/core.py:211-234            get_degrees_from_matrix
   src/pyp/system/project_params.py:362-373             param() colon schedules
+  src/pyp/analysis/image.py:320-417                    extract_background / normalize_image
 """
 import json
 import os
@@ -169,6 +170,17 @@ def main():
 
     # ---- (5) per-iteration colon schedules -----------------------------------------------
     out["param_schedule"] = {s: [pp.param(s, it) for it in range(2, 8)] for s in ("8:7:6", "4", "20:10")}
+
+    # ---- (6) box normalisation of the extraction step (src/pyp/analysis/image.py:320-417) ---------
+    from pyp.analysis import image as rimg
+    boxes, outs, meta = [], [], []
+    for boxsize, radius, pixel, binning in ((16, 10.0, 2.0, 1), (24, 30.0, 1.5, 2), (16, 100.0, 2.0, 1), (32, 20.0, 1.0, 1)):
+        img = rng.normal(5.0, 2.0, (boxsize, boxsize))
+        res = rimg.normalize_image(img.copy(), radius, pixel, binning)
+        bg = rimg.extract_background(img.copy(), radius, pixel * binning)
+        boxes.append(img); outs.append(res); meta.append([boxsize, radius, pixel, binning, float(bg[0]), float(bg[1])])
+    np.savez(os.path.join(HERE, "normalize_image.npz"), **{f"in{i}": b for i, b in enumerate(boxes)}, **{f"out{i}": o for i, o in enumerate(outs)})
+    out["normalize_image"] = meta
 
     with open(os.path.join(HERE, "golden.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
