@@ -333,8 +333,9 @@ __global__ void __launch_bounds__(256) k_insert(InsertP P) {
     long key = P.split_by_pind ? (long)row[PPM_PIND] : (long)row[PPM_POS];
     const int h = (int)(((key % 2) + 2) % 2);
     __shared__ CtfP ctf; __shared__ float m_s[6]; __shared__ float sh_s[2];
-    __shared__ int seg_base[4][256];          // [wave][lane * 4 + row]  -> float index of (x0, y, z).re, or -1
-    __shared__ float seg_val[4][256 * 6];     // [wave][(lane * 4 + row) * 6 + c]
+    __shared__ int seg_base[4][256];          // [wave][row * 64 + lane]  -> float index of (x0, y, z).re, or -1
+    __shared__ float seg_val[4][256 * 6];     // [wave][(row * 64 + lane) * 6 + c]: neighbouring samples' segments of one
+                                              // (dy, dz) row are adjacent, so they tend to share 64-byte lines
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) {
         ctf = ctf_from_row(row, N, (double)P.a);
@@ -376,8 +377,8 @@ __global__ void __launch_bounds__(256) k_insert(InsertP P) {
             const bool ok = live && yi >= 0 && yi < N && zi >= 0 && zi < N && x0 + 1 <= N / 2;
             const float wyz = (dy ? fy : 1.f - fy) * (dz ? fz : 1.f - fz);
             const float w0 = wyz * (1.f - fx), w1 = wyz * fx;
-            sb[lane * 4 + r] = ok ? (int)((((size_t)zi * N + yi) * NX + x0) * 3) : -1;
-            float *o = sv + (lane * 4 + r) * 6;
+            sb[r * 64 + lane] = ok ? (int)((((size_t)zi * N + yi) * NX + x0) * 3) : -1;
+            float *o = sv + (r * 64 + lane) * 6;
             o[0] = w0 * vr; o[1] = w0 * ui; o[2] = w0 * vw; o[3] = w1 * vr; o[4] = w1 * ui; o[5] = w1 * vw;
         }
         // the wave is its own producer and consumer: LDS writes above are complete before the reads below
