@@ -57,7 +57,8 @@ typedef struct ppm_refine_cfg {
     float res_signed_cc;      /* 21: rings at lower resolution than this are summed signed, the
                                  rest by absolute value; 0 = all signed */
     float search_mask_radius; /* 23: mask radius for the global search, Angstrom (0 = mask_radius) */
-    float res_search;         /* 24: resolution limit of the global search, Angstrom */
+    float res_search;         /* 24: resolution limit of the global search, Angstrom; the grid search itself never uses more
+                                 than 64 Fourier pixels (the limit is lowered to that silently) */
     float angular_step;       /* 25: degrees */
     int top_hits;             /* 26: global-search hits that get refined (the caller passes 20) */
     float search_range_x;     /* 27: Angstrom, 0 = widest supported window */

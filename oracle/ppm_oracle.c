@@ -151,6 +151,7 @@ static int geom_init(geom_t *g, const ppm_refine_cfg *c) {
     g->r_hi = na / c->res_high; if (g->r_hi > g->N / 2) g->r_hi = g->N / 2;
     g->r_lo = c->res_low > 0 ? na / c->res_low : 0.0;
     g->r_s = c->res_search > 0 ? na / c->res_search : g->r_hi; if (g->r_s > g->r_hi) g->r_s = g->r_hi;
+    if (c->global_search && g->r_s > 64.0) g->r_s = 64.0;   /* the grid search never uses more than 64 Fourier pixels (ppm.h) */
     g->ring_signed = c->res_signed_cc > 0 ? na / c->res_signed_cc : 1e30;
     g->B = (int)ceil(g->r_hi) - 1; g->W = g->B + 1; g->H = 2 * g->B + 1;
     int Bs = (int)ceil(g->r_s) - 1;
@@ -208,6 +209,8 @@ static void euler_cols(double psi, double theta, double phi, double m[6]) {
 }
 
 /* ------------------------------------------------------------------ reference cube */
+/* K1: what refine3d does with answer 4 "input reconstruction" (frealign.py:3923) at padding 1 (answer 35, :3962);
+ * the sinc^2 pre-compensation is the real-space counterpart of trilinear interpolation in Fourier space. */
 typedef struct { int N, B, CX, CY; cpx *cube; } oref_t;
 
 void *orc_reference_create(const float *vol, int n, float max_band_px) {
@@ -279,6 +282,8 @@ static void extract_slice(const oref_t *r, const geom_t *g, const double m[6], d
 }
 
 /* ------------------------------------------------------------------ CTF */
+/* K3: from the row's DEFOCUS_1/2, DEFOCUS_ANGLE, PHASE_SHIFT, MICROSCOPE_VOLTAGE, MICROSCOPE_CS, AMPLITUDE_CONTRAST
+ * (cistem_star_file.py:596-628); the .par surface passes kV / Cs / contrast as answers (wrapper_functions.py:526-528). */
 typedef struct { double lambda, cs, df1, df2, ast, extra, inv_na2; } ctf_t;
 
 static void ctf_init(ctf_t *c, const double *row, int N, double a) {
@@ -303,6 +308,8 @@ static double ctf_eval(const ctf_t *c, int kx, int ky) {
 }
 
 /* ------------------------------------------------------------------ particle preprocessing */
+/* K2: answers 46 "normalize particles", 47 "invert contrast", 18 outer mask radius (frealign.py:3937, :3984-3988);
+ * the background statistics are those of the stack's own normalisation (analysis/image.py:406-417). */
 /* out: band layout [ky+B][kx] (zero outside k^2 < r_hi^2), whitened when `whiten`. */
 static void preprocess(const float *img, const geom_t *g, double mask_radius_A, double falloff_A,
                        int normalize, int invert, int do_mask, int whiten, double rband, cpx *out,
@@ -366,6 +373,8 @@ static void preprocess(const float *img, const geom_t *g, double mask_radius_A, 
 }
 
 /* ------------------------------------------------------------------ local score */
+/* K5: answers 19/20 low / high resolution limit and 21 "resolution limit for signed CC" (frealign.py:3939-3943);
+ * SCORE is reported x100 and clipped to 0..100 by the caller (align/core.py:1467). */
 /* ring-wise weighted correlation of image I against CTF * slice * shift; signed below
  * ring_signed, absolute above.  shifts in pixels. */
 static double score_local(const oref_t *r, const geom_t *g, const ctf_t *c, const cpx *I,
@@ -515,6 +524,8 @@ static void compass_iter(const oref_t *r, const geom_t *g, const ctf_t *c, const
 }
 
 /* ------------------------------------------------------------------ global search */
+/* K5/K6: answers 24 search resolution, 25 angular step, 26 top hits, 27/28 search range X/Y, 36/37 global / local
+ * (frealign.py:3949-3957, :3866-3871). */
 typedef struct { double cc; int orient, sx, sy; } hit_t;
 
 /* correlation window of one orientation.  W = alpha * ctf * I (band r_lo..r_s), C2 = alpha * ctf^2,
@@ -796,6 +807,8 @@ int orc_symmetry_ops(const char *sym, double *ops /* 60*9 */) {
 }
 
 /* ------------------------------------------------------------------ Fourier insertion */
+/* K7: the reconstruct3d answers (frealign.py:1780-1824): resolution limit, weighting factor refine_bsc, score
+ * threshold, normalise, invert, split even/odd, per-particle splitting by PIND (:1766, :1814-1815), symmetry (:1775-1778). */
 /* acc: [2][N][N][N/2+1][3] floats {re, im, weight}; kz,ky stored at index k + N/2 */
 int orc_insert_batch(float *acc, long *counts, const ppm_recon_cfg *cfg, const char *symmetry,
                      const float *images, int n_img, const double *rows) {
@@ -854,6 +867,8 @@ int orc_insert_batch(float *acc, long *counts, const ppm_recon_cfg *cfg, const c
 }
 
 /* ------------------------------------------------------------------ merge + finalise */
+/* K8: merge3d (frealign.py:2075-2093): half maps, filtered map, the 7 statistics columns consumed at :2557-2567
+ * and postprocess/core.py:203-221; particle volume from the 810 Da/nm^3 rule (docs/tutorials/tomo_empiar_10164.rst:289). */
 static void ifft3_centered_real(cpx *f, int N, float *out) {
     /* f: full N^3 complex spectrum in FFT order (already carrying the centre phase); out = Re(IFFT)/N^2 */
     for (int z = 0; z < N; z++) for (int y = 0; y < N; y++) fft1d(f + ((size_t)z * N + y) * N, N, 1, 1);

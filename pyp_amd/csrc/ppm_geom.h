@@ -80,6 +80,8 @@ inline bool geom_init(Geom &g, const ppm_refine_cfg &c, std::string &err) {
     g.r_hi = na / c.res_high; if (g.r_hi > g.N / 2) g.r_hi = g.N / 2;
     g.r_lo = c.res_low > 0 ? na / c.res_low : 0.0;
     g.r_s = c.res_search > 0 ? na / c.res_search : g.r_hi; if (g.r_s > g.r_hi) g.r_s = g.r_hi;
+    if (c.global_search && g.r_s > 64.0) g.r_s = 64.0;   // the grid-search kernel covers 64 Fourier pixels (lane = kx); finer
+                                                         // detail only enters through the refinement of the hits
     g.ring_signed = c.res_signed_cc > 0 ? na / c.res_signed_cc : 1e30;
     g.B = (int)std::ceil(g.r_hi) - 1; g.W = g.B + 1; g.H = 2 * g.B + 1;
     g.Bs = (int)std::ceil(g.r_s) - 1; g.Hs = 2 * g.Bs + 1;

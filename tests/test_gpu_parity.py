@@ -88,6 +88,19 @@ def test_full_refinement_matches_oracle(H, O, n, px, m, step):
     assert ang.max() < ANG_TOL_DEG and shf.max() < SHIFT_TOL_PX
 
 
+def test_wide_band_grid_search_is_capped_at_64_pixels(H, O):
+    """res_search beyond 64 Fourier pixels: the grid search runs at 64 px, the refinement at the full band (72 px)."""
+    n, px = 160, 1.0
+    vol, imgs, rows = dataset(n, 4, px, 0.1)
+    g, o = H.Reference(vol, n / 2), O.Reference(vol, n / 2)
+    c = RefineCfg.make(box=n, pixel_size=px, mask_radius=0.4 * n * px, res_high=px * n / 72.0, res_search=px * n / 72.0,
+                       angular_step=30.0, search_range_x=6.0, search_range_y=6.0, res_signed_cc=30.0)
+    assert O.band_dims(c)["Ns"] == 128
+    want, _ = O.refine_batch(o, c, imgs, rows)
+    got = g.refine(c, imgs, rows)
+    assert synth.angular_error_deg(want, got).max() < ANG_TOL_DEG and synth.shift_error_px(want, got, px).max() < SHIFT_TOL_PX
+
+
 def test_odd_psi_count_and_wide_shift_window(d64, H, O):
     vol, imgs, rows, g, o = d64
     c = cfg_for(64, 2.0, angular_step=24.0, search_range_x=0.0, search_range_y=10.0)    # n_psi = 15 (no conjugate pairing), RSx = 8
