@@ -23,12 +23,6 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
     return v;
 }
-// sum within aligned groups of 16 lanes
-__device__ __forceinline__ float group16_sum(float v) {
-#pragma unroll
-    for (int m = 8; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
-}
 
 // FFT plan of one length n = prod fac[] (factors 4, 2, 3, 5): tw[k] = (cos 2 pi k/n, sin 2 pi k/n), k < n;
 // perm[i] = LDS position of input sample i (digit-reversed staging), both in global memory.

@@ -41,7 +41,6 @@ inline void sym_limits(const char *sym, double &phi_max, double &theta_max) {
     else if (t == 'O') { phi_max = 90.0; theta_max = 90.0; }
 }
 
-inline bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 // box sizes the FFTs handle: even, 32..512, prime factors 2, 3, 5 only
 inline bool box_ok(int n) {
     if (n < 32 || n > 512 || n % 2) return false;
@@ -135,7 +134,6 @@ inline void euler_matrix(double psi, double theta, double phi, double M[9]) {
 struct SampleList {
     std::vector<uint32_t> packed;
     std::vector<int> ring_off;   // ring_off[b] = first sample of ring b; size B+3
-    std::vector<int> smap;       // (ky+B)*W + kx -> sample index or -1
 };
 
 inline uint32_t pack_sample(int kx, int ky, int alpha, int ring) {
@@ -143,24 +141,19 @@ inline uint32_t pack_sample(int kx, int ky, int alpha, int ring) {
 }
 
 inline void build_samples(const Geom &g, SampleList &sl) {
-    int B = g.B, W = g.W;
+    int B = g.B;
     std::vector<std::vector<uint32_t>> rings(B + 2);
-    std::vector<std::vector<int>> cells(B + 2);
     double r2 = g.r_hi * g.r_hi;
     for (int ky = -B; ky <= B; ky++) for (int kx = 0; kx <= B; kx++) {
         double k2 = (double)kx * kx + (double)ky * ky;
         if (k2 >= r2 || k2 == 0) continue;
         int b = (int)std::floor(std::sqrt(k2));
         rings[b].push_back(pack_sample(kx, ky, kx == 0 ? 1 : 2, b));
-        cells[b].push_back((ky + B) * W + kx);
     }
-    sl.packed.clear(); sl.ring_off.assign(B + 3, 0); sl.smap.assign((size_t)g.H * W, -1);
+    sl.packed.clear(); sl.ring_off.assign(B + 3, 0);
     for (int b = 0; b <= B + 1; b++) {
         sl.ring_off[b] = (int)sl.packed.size();
-        for (size_t i = 0; i < rings[b].size(); i++) {
-            sl.smap[cells[b][i]] = (int)sl.packed.size();
-            sl.packed.push_back(rings[b][i]);
-        }
+        for (size_t i = 0; i < rings[b].size(); i++) sl.packed.push_back(rings[b][i]);
         while (sl.packed.size() % 16) sl.packed.push_back(pack_sample(0, 0, 0, b));
     }
     sl.ring_off[B + 2] = (int)sl.packed.size();

@@ -68,8 +68,8 @@ def euler_matrix(psi, theta, phi):
 
 
 def pyp_matrix(psi, theta, phi):
-    """The matrix written out at analysis/geometry/core.py:1194-1197 (its "left-handed" form) =
-    euler_matrix(-psi, -theta, -phi) element-wise... kept for the convention golden test."""
+    """The matrix PYP writes out at analysis/geometry/core.py:1194-1197 (its "left-handed" form).  It equals
+    euler_matrix(-psi, -theta, -phi); kept for the convention golden test."""
     ps, th, ph = np.radians(psi), np.radians(theta), np.radians(phi)
     c, s = np.cos, np.sin
     return np.array([

@@ -280,6 +280,23 @@ def test_accumulator_sum_is_linear(H, O):
     assert np.linalg.norm(x - y) / np.linalg.norm(y) < 1e-5
 
 
+def test_baseline_size_256_matches_oracle(H, O):
+    """BASELINE.json configs[1] geometry (256^2 box, 15 deg, band 64 px, 20 hits) on a handful of particles against the
+    oracle itself (about a minute of CPU work on the GPU box's cores)."""
+    n, px, m = 256, 1.0, 6
+    vol, stack, rows = synth.make_dataset(n, m, pixel=px, snr=0.05)
+    imgs = stack.numpy()
+    c = RefineCfg.make(box=n, pixel_size=px, mask_radius=0.32 * n * px, res_high=4.0, res_search=4.0, search_range_x=6.0,
+                       search_range_y=6.0, res_signed_cc=30.0)
+    want, cw = O.refine_batch(O.Reference(vol, n / 2), c, imgs, rows)
+    g = H.Reference(vol, n / 2)
+    got = g.refine(c, imgs, rows)
+    lc = g.last_counts()
+    assert (lc["n_global"], lc["n_local"], lc["samples_local"]) == (cw[0], cw[1], cw[2]) and cw[0] == 4416
+    assert synth.angular_error_deg(want, got).max() < ANG_TOL_DEG and synth.shift_error_px(want, got, px).max() < SHIFT_TOL_PX
+    assert np.abs(want[:, 14] - got[:, 14]).max() < 0.02
+
+
 def test_full_size_properties_256(H):
     """BASELINE.json size (256^2, band 64 px): size-independent properties instead of the (slow) oracle."""
     n, px, m = 256, 1.0, 48
