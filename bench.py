@@ -169,7 +169,7 @@ def pmc_traffic(kernel, particles_per_launch):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc summary (separate FETCH_SIZE and
     WRITE_SIZE passes; units of 1 KB; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), scaled from
     the profiled particle count to this launch.  None when no summary is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_v3_pmc_summary_8k.json")
+    path = os.path.join(ROOT, "profiles", "r01_final_pmc_summary_8k.json")
     if not os.path.exists(path):
         return None, None
     d = json.load(open(path))
@@ -178,7 +178,7 @@ def pmc_traffic(kernel, particles_per_launch):
         return None, None
     e = d[key[0]]
     per_particle = (2.0 * e["FETCH_SIZE"]["sum"] + e["WRITE_SIZE"]["sum"]) * 1024.0 / 8000.0
-    return per_particle * particles_per_launch, "profiles/r01_v3_pmc_summary_8k.json (8000 particles, FETCH_SIZE x2 + WRITE_SIZE, KB)"
+    return per_particle * particles_per_launch, "profiles/r01_final_pmc_summary_8k.json (8000 particles, FETCH_SIZE x2 + WRITE_SIZE, KB)"
 
 
 def reconstruct_bench(a, rank, world, local, dev, vol, stack, rows, N, M, px):
@@ -243,8 +243,10 @@ def reconstruct_bench(a, rank, world, local, dev, vol, stack, rows, N, M, px):
                            % (M // 1000, N, N), "particles_per_gpu": M, "box": N, "parallelism": "particle-sharded x%d" % world},
                 "roofline": {"bound": "hbm", "kernel": "k_insert", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                              "frac": round(achieved / 8000.0, 4), "traffic": None, "avg_launch_ms": round(ms, 3),
-                             "note": "algorithmic bytes = S(N/2) x 8 taps x 12 B x 2 (read-modify-write) per particle; the practical ceiling "
-                                     "is the float-atomic rate (about 1.3 TB/s of added bytes = 0.33 of this figure)",
+                             "note": "algorithmic bytes = S(N/2) x 8 taps x 12 B x 2 (read-modify-write) per particle; float atomics execute at "
+                                     "the memory side per 64-byte request and the kernel issues about 149 k requests per particle "
+                                     "(TCC_EA0_ATOMIC, profiles/r01_final_pmc_reconstruct_20k.json) = 20 G requests/s, the chip's atomic "
+                                     "request rate (1.3 TB/s / 64 B), so this kernel sits on the atomic ceiling, not the HBM one",
                              "path_bytes_per_particle": b_ins},
                 "kernels_ms": {k2: round(v["ms"], 2) for k2, v in prof.items() if v["launches"]},
                 "map_cc_vs_truth": round(cc, 4), "fsc_at_half_nyquist": round(float(stats[N // 4 - 1, 3]), 4)}
