@@ -47,6 +47,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if "PPM_FORCE_DEVICE" in os.environ:          # rehearsal of the N > 1 path on a one-GPU box (with PPM_DIST_BACKEND=gloo)
+        local = int(os.environ["PPM_FORCE_DEVICE"])
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -54,7 +56,11 @@ def main():
         sys.exit(2)
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("PPM_DIST_BACKEND", "nccl")          # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     from pyp_amd import host, synth
     from pyp_amd.abi import RefineCfg
 
