@@ -70,8 +70,8 @@ typedef struct ppm_refine_cfg {
     int invert;               /* 47: invert contrast */
     /* build-defined knobs (0 = default), DESIGN.md "search driver" */
     float mask_falloff;       /* cosine edge width of the mask, Angstrom (default 20) */
-    int iters_hit;            /* compass iterations run on every hit (default 3) */
-    int iters_final;          /* further iterations on the best hit / on a local-only start (default 6) */
+    int iters_hit;            /* compass iterations run on every hit (default 2) */
+    int iters_final;          /* further iterations on the best hit / on a local-only start (default 7) */
     float local_angle_step;   /* first step of a local-only refinement, degrees (default 2.5) */
     float local_shift_step;   /* same for shifts, pixels (default 2) */
     char symmetry[8];         /* 11: point group of the reference ("C1", "C7", "D7", "T", "O", "I"; "" = C1).  The global grid

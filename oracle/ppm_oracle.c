@@ -600,7 +600,7 @@ int orc_refine_batch(void *refp, const ppm_refine_cfg *cfg, const float *images,
     if (!r || geom_init(&g, cfg)) return -22;
     if (g.B > r->B || r->N != g.N) return -22;
     int K = cfg->top_hits > 0 ? cfg->top_hits : 20; if (K > PPM_MAX_TOP_HITS) K = PPM_MAX_TOP_HITS;
-    int Tb = cfg->iters_hit > 0 ? cfg->iters_hit : 3, Tc = cfg->iters_final > 0 ? cfg->iters_final : 6;
+    int Tb = cfg->iters_hit > 0 ? cfg->iters_hit : 2, Tc = cfg->iters_final > 0 ? cfg->iters_final : 7;
     double fall = cfg->mask_falloff > 0 ? cfg->mask_falloff : 20.0;
     double dstep = cfg->angular_step > 0 ? cfg->angular_step : 15.0;
     int en[5] = { cfg->refine_psi, cfg->refine_theta, cfg->refine_phi, cfg->refine_x, cfg->refine_y };

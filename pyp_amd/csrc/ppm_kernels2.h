@@ -39,13 +39,20 @@ __device__ inline void d_angles(const double *M, double &psi, double &theta, dou
     if (phi < 0) phi += 360;
 }
 
-// which: 0 = in-plane (psi), 1 / 2 = tilt about image x / y when tilt_frame, else theta / phi Euler steps
+// which: 0 = in-plane (psi), 1 / 2 = tilt about image x / y when tilt_frame, else theta / phi Euler steps.
+// The three image-frame steps are right-multiplications by Rz / Rx / Ry: plain column mixes.
 __device__ inline void d_rot_step(const double *M, int which, int tilt_frame, double hdeg, double *out) {
-    double h = hdeg * 3.14159265358979323846 / 180.0, c = cos(h), s = sin(h);
-    if (which == 0) { double r[9] = { c, -s, 0, s, c, 0, 0, 0, 1 }; d_mat_mul3(M, r, out); return; }
-    if (tilt_frame) {
-        if (which == 1) { double r[9] = { 1, 0, 0, 0, c, -s, 0, s, c }; d_mat_mul3(M, r, out); }
-        else { double r[9] = { c, 0, s, 0, 1, 0, -s, 0, c }; d_mat_mul3(M, r, out); }
+    double s, c;
+    sincos(hdeg * 3.14159265358979323846 / 180.0, &s, &c);
+    if (which == 0 || tilt_frame) {
+        const int a = which == 0 ? 0 : (which == 1 ? 1 : 2), b = which == 0 ? 1 : (which == 1 ? 2 : 0), keep = 3 - a - b;
+        // M R with R rotating the (a, b) coordinate pair: out[:,a] = c M[:,a] + s M[:,b], out[:,b] = -s M[:,a] + c M[:,b]
+        for (int r = 0; r < 3; r++) {
+            const double ma = M[r * 3 + a], mb = M[r * 3 + b];
+            out[r * 3 + a] = ma * c + mb * s;
+            out[r * 3 + b] = mb * c - ma * s;
+            out[r * 3 + keep] = M[r * 3 + keep];
+        }
         return;
     }
     if (which == 2) { double r[9] = { c, -s, 0, s, c, 0, 0, 0, 1 }; d_mat_mul3(r, M, out); return; }
@@ -167,34 +174,40 @@ __global__ void __launch_bounds__(256, 4) k_local(LocalP P) {
     int nfree = 0;
     for (int i = 0; i < 5; i++) nfree += P.en[i] ? 1 : 0;
     for (int it = 0; it < P.T; it++) {
-        // ---- slots: 2 per free angle (+h, -h), then the centre, then 2 per free shift
-        if (tid == 0) {
-            int q = 0, g = 0;
-            for (int i = 0; i < 3; i++) {
-                if (!P.en[i]) continue;
-                for (int sg = 0; sg < 2; sg++) {
+        // ---- slots: 2 per free angle (+h, -h), then the centre, then 2 per free shift.  Lanes 0..5 build one angular
+        // neighbour each (the double-precision trig is the serial part of an iteration), lane 6 the centre group.
+        {
+            int nang = 0;
+            for (int i = 0; i < 3; i++) nang += P.en[i] ? 2 : 0;
+            if (tid < 6) {
+                const int i = tid >> 1, sg = tid & 1;
+                if (P.en[i]) {
+                    int g = 0;
+                    for (int k = 0; k < i; k++) g += P.en[k] ? 2 : 0;
+                    g += sg;
                     double Mq[9];
                     d_rot_step(st.M, i, tilt, sg ? -st.ha : st.ha, Mq);
-                    set_rot(g, Mq); plan.nv[g] = 1; plan.slot0[g] = q;
-                    plan.sh[q][0] = (float)st.sh[0]; plan.sh[q][1] = (float)st.sh[1];
-                    g++; q++;
+                    set_rot(g, Mq); plan.nv[g] = 1; plan.slot0[g] = g;
+                    plan.sh[g][0] = (float)st.sh[0]; plan.sh[g][1] = (float)st.sh[1];
                 }
-            }
-            set_rot(g, st.M); plan.slot0[g] = q;
-            plan.sh[q][0] = (float)st.sh[0]; plan.sh[q][1] = (float)st.sh[1];
-            q++;
-            int nv = 1;
-            for (int i = 3; i < 5; i++) {
-                if (!P.en[i]) continue;
-                for (int sg = 0; sg < 2; sg++) {
-                    double shq[2] = { st.sh[0], st.sh[1] };
-                    shq[i - 3] += sg ? -st.hs : st.hs;
-                    plan.sh[q][0] = (float)shq[0]; plan.sh[q][1] = (float)shq[1];
-                    q++; nv++;
+            } else if (tid == 6) {
+                int q = nang, g = nang;
+                set_rot(g, st.M); plan.slot0[g] = q;
+                plan.sh[q][0] = (float)st.sh[0]; plan.sh[q][1] = (float)st.sh[1];
+                q++;
+                int nv = 1;
+                for (int i = 3; i < 5; i++) {
+                    if (!P.en[i]) continue;
+                    for (int sg = 0; sg < 2; sg++) {
+                        double shq[2] = { st.sh[0], st.sh[1] };
+                        shq[i - 3] += sg ? -st.hs : st.hs;
+                        plan.sh[q][0] = (float)shq[0]; plan.sh[q][1] = (float)shq[1];
+                        q++; nv++;
+                    }
                 }
+                plan.nv[g] = nv;
+                plan.ng = g + 1; plan.nslots = q; plan.S_used = P.S_it[it]; plan.rmax2 = P.rmax2_it[it];
             }
-            plan.nv[g] = nv; g++;
-            plan.ng = g; plan.nslots = q; plan.S_used = P.S_it[it]; plan.rmax2 = P.rmax2_it[it];
         }
         __syncthreads();
         if (nfree > 0) {

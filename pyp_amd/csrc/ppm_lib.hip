@@ -302,7 +302,7 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
     int K = cfg->top_hits > 0 ? cfg->top_hits : 20;
     if (K > PPM_MAX_TOP_HITS) K = PPM_MAX_TOP_HITS;
     if (K > gm.n_orient) K = gm.n_orient;
-    const int Tb = cfg->iters_hit > 0 ? cfg->iters_hit : 3, Tc = cfg->iters_final > 0 ? cfg->iters_final : 6;
+    const int Tb = cfg->iters_hit > 0 ? cfg->iters_hit : 2, Tc = cfg->iters_final > 0 ? cfg->iters_final : 7;
     const double fall = cfg->mask_falloff > 0 ? cfg->mask_falloff : 20.0;
     const float fall_px = (float)(fall / gm.a), Rm_px = (float)(cfg->mask_radius / gm.a);
     const bool sep_search = cfg->global_search && cfg->search_mask_radius > 0 && cfg->search_mask_radius != cfg->mask_radius;
