@@ -140,6 +140,19 @@ __device__ __forceinline__ float ctf_eval(const CtfP &c, int kx, int ky) {
     return -sinf(chi);
 }
 
+// same CTF with the phase reduced to one revolution in fp32 and the hardware sine (v_sin_f32): chi itself carries an fp32
+// rounding of ~|chi| 6e-8, the hardware sine adds ~1e-6 absolute
+__device__ __forceinline__ float ctf_eval_fast(const CtfP &c, int kx, int ky) {
+    float k2 = (float)(kx * kx + ky * ky);
+    float s2 = k2 * c.inv_na2;
+    float ik2 = __frcp_rn(fmaxf(k2, 1.f));
+    float c2 = (float)(kx * kx - ky * ky) * ik2, s2p = (float)(2 * kx * ky) * ik2;
+    float df = 0.5f * (c.dsum + c.ddif * (c2 * c.c2a + s2p * c.s2a));
+    float chi = kPiF * c.lambda * s2 * (df - 0.5f * c.cs * c.lambda * c.lambda * s2) + c.extra;
+    float rev = chi * 0.15915494309189535f; rev -= floorf(rev);
+    return -__sinf(6.283185307179586f * rev);
+}
+
 __device__ __forceinline__ void unpack_sample(uint32_t u, int &kx, int &ky, int &alpha, int &ring) {
     kx = (int)(u & 511u);
     ky = (int)((u >> 9) & 1023u) - 256;

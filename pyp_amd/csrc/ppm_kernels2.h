@@ -407,6 +407,204 @@ __global__ void __launch_bounds__(256) k_insert(InsertP P) {
     }
 }
 
+// ---------------------------------------------------------------------------------- brick-binned insertion
+// No global atomics: the accumulator is cut into bricks of BE^3 voxels; one block owns one brick of one half-map,
+// keeps it in LDS, walks over the particles of the batch, finds the slice samples whose 8-tap footprint touches the
+// brick (plane / box rejection, then a candidate rectangle in the slice plane) and adds them with LDS atomics; the
+// brick is written back once, by its only owner (plain read-modify-write, deterministic up to the LDS add order).
+struct PartIns {       // per-particle constants, written by k_insert_params
+    float m[6];        // X = m0 kx + m1 ky, Y = m2 kx + m3 ky, Z = m4 kx + m5 ky
+    CtfP ctf;
+    float sx, sy, w0, wexp;   // shifts (px), occupancy weight, exponent coefficient of the score weighting (per k^2)
+    int half, valid;
+};
+
+// One work item = one brick x one slice of the batch's particles (heavy bricks near the origin are cut into more slices,
+// so that items carry about equal work; the host sorts them heavy-first).
+struct BrickItem { unsigned short bx, by, bz; unsigned char s, S; };
+
+struct InsertBrickP {
+    const float2 *band; const PartIns *pp; const float *symops; int nsym;
+    float *acc; int N, B, W, H, n_img;
+    const BrickItem *items;
+    const unsigned *maxima;   // [0] bits of max |band| component, [1] bits of max particle weight (floats >= 0, set by atomicMax)
+    float r2;
+};
+
+// max over the chunk of |re|, |im| of the band images (bits of a non-negative float compare like unsigned integers)
+__global__ void __launch_bounds__(256) k_band_absmax(const float2 *band, size_t n, unsigned *maxima) {
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float2 v = band[i];
+        m = fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y)));
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.f && m < 3.0e38f) atomicMax(maxima, __float_as_uint(m));
+}
+
+__global__ void k_insert_params(const double *rows, PartIns *pp, int n, int N, double a, double bfac, double score_avg,
+                                double score_thr, int split_by_pind, double r2, unsigned long long *counts, unsigned *maxima) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double *row = rows + (size_t)i * PPM_NCOL;
+    PartIns q;
+    const double occ = row[PPM_OCC], scr = row[PPM_SCORE];
+    q.valid = (occ > 0 && !(scr < score_thr)) ? 1 : 0;
+    long key = split_by_pind ? (long)row[PPM_PIND] : (long)row[PPM_POS];
+    q.half = (int)(((key % 2) + 2) % 2);
+    double M[9]; d_euler(row[PPM_PSI], row[PPM_THETA], row[PPM_PHI], M);
+    q.m[0] = (float)M[0]; q.m[1] = (float)M[1]; q.m[2] = (float)M[3]; q.m[3] = (float)M[4]; q.m[4] = (float)M[6]; q.m[5] = (float)M[7];
+    q.ctf = ctf_from_row(row, N, a);
+    q.sx = (float)(row[PPM_XSHIFT] / a); q.sy = (float)(row[PPM_YSHIFT] / a);
+    q.w0 = (float)(occ / 100.0);
+    q.wexp = (float)(-0.25 * bfac * (score_avg - scr)) * q.ctf.inv_na2;
+    pp[i] = q;
+    if (q.valid) {
+        atomicAdd(&counts[q.half], 1ull);
+        const float wmax = q.w0 * fmaxf(1.f, expf(q.wexp * (float)r2));
+        if (wmax > 0.f && wmax < 3.0e38f) atomicMax(maxima + 1, __float_as_uint(wmax));
+    }
+}
+
+// grid: (items, 2 halves), NW waves.  Each wave takes every NW-th (particle, operator) of the item's slice: plane-vs-box
+// rejection (wave-uniform), then 8x8 tiles of the candidate rectangle are TESTED (cheap: position only) and the hits
+// compacted into a per-wave LDS queue; full groups of 64 hits are EVALUATED (CTF, weights, phase, 8 taps).
+// The brick is accumulated in 64-bit FIXED POINT: on gfx950 a ds_add_f32 wave-instruction occupies the LDS for ~190
+// cycles (lanes are serialised), a ds_add_u64 for ~8 (scripts/micro/lds_atomic_bench.hip).  Every tap is rounded to a
+// 31-bit integer relative to the largest possible value of the chunk (max |band| x max weight, found on the device
+// beforehand), then summed exactly: the LDS part of the sum no longer depends on the order of the adds.
+template <int BE, int NW>
+__global__ void __launch_bounds__(NW * 64) k_insert_bricks(InsertBrickP P) {
+    extern __shared__ long long brick[];           // [BE][BE][BE][3]
+    __shared__ unsigned queue_s[NW][128];
+    // value scale 2^(30-e) with bound < 2^e, so |tap| < 2^30; likewise for the weight channel
+    float sv, sw;
+    {
+        int ev, ew;
+        const float bv = __uint_as_float(P.maxima[0]) * __uint_as_float(P.maxima[1]), bw = __uint_as_float(P.maxima[1]);
+        (void)frexpf(bv > 0.f ? bv : 1.f, &ev); (void)frexpf(bw > 0.f ? bw : 1.f, &ew);
+        sv = ldexpf(1.f, min(30 - ev, 120)); sw = ldexpf(1.f, min(30 - ew, 120));
+    }
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N = P.N, B = P.B, W = P.W;
+    const int h = blockIdx.y;
+    const BrickItem it = P.items[blockIdx.x];
+    // voxel COORDINATES covered by this brick: x in [x_lo, x_lo+BE), y, z likewise (stored index = coordinate + N/2)
+    const int x_lo = it.bx * BE, y_lo = it.by * BE - N / 2, z_lo = it.bz * BE - N / 2;
+    const int p_lo = (int)((long)P.n_img * it.s / it.S), p_hi = (int)((long)P.n_img * (it.s + 1) / it.S);
+    for (int i = tid; i < BE * BE * BE * 3; i += NW * 64) brick[i] = 0ll;
+    __syncthreads();
+    // sample positions Q whose floor() lies in [lo-1, lo+BE-1] touch the brick:  lo-1 <= Q < lo+BE
+    const float cx = x_lo - 1 + 0.5f * (BE + 1), cy = y_lo - 1 + 0.5f * (BE + 1), cz = z_lo - 1 + 0.5f * (BE + 1), hh = 0.5f * (BE + 1);
+    unsigned *queue = queue_s[wave];
+    int qn = 0;
+    bool touched = false;
+    const int i_hi = p_hi * P.nsym;
+    for (int idx = p_lo * P.nsym + wave; idx < i_hi; idx += NW) {
+        const int p = idx / P.nsym, so = idx - p * P.nsym;
+        const PartIns &q = P.pp[p];
+        if (!q.valid || q.half != h) continue;
+        const float *S = P.symops + so * 9;
+        // first two columns of S M
+        const float a0 = S[0] * q.m[0] + S[1] * q.m[2] + S[2] * q.m[4], a1 = S[0] * q.m[1] + S[1] * q.m[3] + S[2] * q.m[5];
+        const float b0 = S[3] * q.m[0] + S[4] * q.m[2] + S[5] * q.m[4], b1 = S[3] * q.m[1] + S[4] * q.m[3] + S[5] * q.m[5];
+        const float c0 = S[6] * q.m[0] + S[7] * q.m[2] + S[8] * q.m[4], c1 = S[6] * q.m[1] + S[7] * q.m[3] + S[8] * q.m[5];
+        // plane normal = col0 x col1; does the plane through the origin cut the box?
+        const float nx = b0 * c1 - c0 * b1, ny = c0 * a1 - a0 * c1, nz = a0 * b1 - b0 * a1;
+        if (fabsf(nx * cx + ny * cy + nz * cz) > (fabsf(nx) + fabsf(ny) + fabsf(nz)) * hh + 1e-3f) continue;
+        // EVALUATE one queued sample per lane
+        auto evaluate = [&](unsigned e, bool on) {
+            if (!on) return;
+            const int kx = (int)(e & 0xffffu), ky = (int)(e >> 16) - 512;
+            const float k2 = (float)(kx * kx + ky * ky);
+            float X = a0 * kx + a1 * ky, Y = b0 * kx + b1 * ky, Z = c0 * kx + c1 * ky;
+            const bool refl = X < 0.f;
+            if (refl) { X = -X; Y = -Y; Z = -Z; }
+            const float xf = floorf(X), yf = floorf(Y), zf = floorf(Z);
+            const int x0 = (int)xf - x_lo, y0 = (int)yf - y_lo, z0 = (int)zf - z_lo;      // brick-local base tap
+            const float fx = X - xf, fy = Y - yf, fz = Z - zf;
+            const float cv = ctf_eval_fast(q.ctf, kx, ky);
+            const float w = q.w0 * (q.wexp != 0.f ? expf(q.wexp * k2) : 1.f);
+            float rev = (kx * q.sx + ky * q.sy) / (float)N; rev -= floorf(rev);
+            const float sn = __sinf(6.283185307179586f * rev), cs = __cosf(6.283185307179586f * rev);
+            const float2 iv = P.band[((size_t)p * P.H + (ky + B)) * W + kx];
+            const float vr = sv * w * cv * (iv.x * cs - iv.y * sn), vw = sw * w * cv * cv;
+            float vi = sv * w * cv * (iv.x * sn + iv.y * cs);
+            if (refl) vi = -vi;
+#pragma unroll
+            for (int dz = 0; dz < 2; dz++)
+#pragma unroll
+                for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+                    for (int dx = 0; dx < 2; dx++) {
+                        const int xi = x0 + dx, yi = y0 + dy, zi = z0 + dz;
+                        if ((unsigned)xi >= (unsigned)BE || (unsigned)yi >= (unsigned)BE || (unsigned)zi >= (unsigned)BE) continue;
+                        const float wt = (dx ? fx : 1.f - fx) * (dy ? fy : 1.f - fy) * (dz ? fz : 1.f - fz);
+                        unsigned long long *v = (unsigned long long *)brick + ((zi * BE + yi) * BE + xi) * 3;
+                        atomicAdd(v, (unsigned long long)(long long)__float2int_rn(wt * vr));
+                        atomicAdd(v + 1, (unsigned long long)(long long)__float2int_rn(wt * vi));
+                        atomicAdd(v + 2, (unsigned long long)(long long)__float2int_rn(wt * vw));
+                    }
+        };
+        // candidate rectangle of (kx, ky) = (col0 . Q, col1 . Q) over the box, for Q = +P (sgn +1) and Q = -P (sgn -1)
+        const float ea = (fabsf(a0) + fabsf(b0) + fabsf(c0)) * hh, eb = (fabsf(a1) + fabsf(b1) + fabsf(c1)) * hh;
+        const float ka = a0 * cx + b0 * cy + c0 * cz, kb = a1 * cx + b1 * cy + c1 * cz;
+#pragma unroll 1
+        for (int sgn = 1; sgn >= -1; sgn -= 2) {
+            int kx0 = (int)floorf(sgn * ka - ea) - 1, kx1 = (int)ceilf(sgn * ka + ea) + 1;
+            int ky0 = (int)floorf(sgn * kb - eb) - 1, ky1 = (int)ceilf(sgn * kb + eb) + 1;
+            kx0 = kx0 < 0 ? 0 : kx0; kx1 = kx1 > B ? B : kx1; ky0 = ky0 < -B ? -B : ky0; ky1 = ky1 > B ? B : ky1;
+            if (kx1 < kx0 || ky1 < ky0) continue;
+#pragma unroll 1
+            for (int ty = ky0; ty <= ky1; ty += 8)
+#pragma unroll 1
+                for (int tx = kx0; tx <= kx1; tx += 8) {
+                    const int kx = tx + (lane & 7), ky = ty + (lane >> 3);
+                    const float k2 = (float)(kx * kx + ky * ky);
+                    float X = a0 * kx + a1 * ky, Y = b0 * kx + b1 * ky, Z = c0 * kx + c1 * ky;
+                    const bool refl = X < 0.f;
+                    if (refl) { X = -X; Y = -Y; Z = -Z; }
+                    const int x0 = (int)floorf(X) - x_lo, y0 = (int)floorf(Y) - y_lo, z0 = (int)floorf(Z) - z_lo;
+                    const bool hit = kx <= kx1 && ky <= ky1 && k2 < P.r2 && k2 != 0.f && refl == (sgn < 0) &&
+                                     (unsigned)(x0 + 1) <= (unsigned)BE && (unsigned)(y0 + 1) <= (unsigned)BE && (unsigned)(z0 + 1) <= (unsigned)BE;
+                    const unsigned long long m = __ballot(hit);
+                    if (m == 0ull) continue;
+                    if (hit) queue[qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (unsigned)kx | ((unsigned)(ky + 512) << 16);
+                    qn += __popcll(m);
+                    __builtin_amdgcn_wave_barrier();
+                    if (qn >= 64) {
+                        qn -= 64;
+                        evaluate(queue[qn + lane], true);
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    touched = true;
+                }
+        }
+        if (qn > 0) {              // the queue never crosses a (particle, operator): the rotation above is wave-uniform
+            evaluate(queue[lane], lane < qn);
+            __builtin_amdgcn_wave_barrier();
+            qn = 0;
+        }
+    }
+    const int any = __syncthreads_or(touched ? 1 : 0);
+    if (!any) return;
+    const size_t NX = N / 2 + 1;
+    float *A = P.acc + (size_t)h * N * N * NX * 3;
+    for (int i = tid; i < BE * BE * BE * 3; i += NW * 64) {       // BE*3 consecutive floats per (y, z) row of the brick
+        const long long vq = brick[i];
+        if (vq == 0ll) continue;
+        const int x3 = i % (BE * 3), yi = (i / (BE * 3)) % BE, zi = i / (BE * BE * 3);
+        const int gy = y_lo + yi + N / 2, gz = z_lo + zi + N / 2;
+        if (x_lo * 3 + x3 >= (int)NX * 3 || gy >= N || gz >= N) continue;
+        float *o = A + (((size_t)gz * N + gy) * NX + x_lo) * 3 + x3;
+        const float v = (float)((double)vq / (double)(i % 3 == 2 ? sw : sv));
+        if (it.S == 1) *o += v;          // sole owner of this brick in this launch
+        else atomicAdd(o, v);
+    }
+}
+
 // ---------------------------------------------------------------------------------- finalisation
 // kx = 0 plane: fold Friedel mates together (reads `src`, writes `dst`)
 __global__ void k_fold_plane(const float *__restrict__ src, float *__restrict__ dst, int N) {

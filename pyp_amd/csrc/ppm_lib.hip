@@ -150,9 +150,64 @@ struct ppm_accum {
     std::vector<double> symops; int nsym = 1;
     float *d_sym = nullptr;
     unsigned long long *d_counts = nullptr;
+    unsigned *d_max = nullptr;       // chunk maxima for the fixed-point scales of k_insert_bricks
     long counts[2] = { 0, 0 };
-    DevBuf<double> rows; DevBuf<float> images; DevBuf<float2> band;
+    DevBuf<double> rows; DevBuf<float> images; DevBuf<float2> band; DevBuf<PartIns> pp; DevBuf<BrickItem> items;
+    std::vector<float> brick_load; float load_r = -1.f; int n_items = 0, items_cap = -1;
 };
+
+// Work items of the brick insertion (k_insert_bricks): expected load of a brick = share of random slice planes that cut
+// its (expanded) box, estimated with a fixed set of normals; heavy bricks are cut into up to `cap` particle slices and the
+// items are sorted heavy-first.  Bricks wholly outside the band carry no item.
+static int build_brick_items(ppm_accum *a, const Geom &gm, int BE, int nb) {
+    const int N = gm.N, nbx = (N / 2 + 1 + BE - 1) / BE, nby = (N + BE - 1) / BE;
+    const float r = (float)gm.r_hi, hh = 0.5f * (BE + 1);
+    if (a->load_r != r || a->brick_load.empty()) {
+        const int NS = 192;
+        std::vector<float> nrm(NS * 3);
+        for (int i = 0; i < NS; i++) {          // Fibonacci sphere
+            double z = 1.0 - 2.0 * (i + 0.5) / NS, ph = i * 2.399963229728653, rr = std::sqrt(std::max(0.0, 1.0 - z * z));
+            nrm[i * 3] = (float)(rr * std::cos(ph)); nrm[i * 3 + 1] = (float)(rr * std::sin(ph)); nrm[i * 3 + 2] = (float)z;
+        }
+        a->brick_load.assign((size_t)nbx * nby * nby, -1.f);
+        for (int bz = 0; bz < nby; bz++) for (int by = 0; by < nby; by++) for (int bx = 0; bx < nbx; bx++) {
+            const int x_lo = bx * BE, y_lo = by * BE - N / 2, z_lo = bz * BE - N / 2;
+            const float dx = std::max(std::max((float)(x_lo - 1), -(float)(x_lo + BE)), 0.f), dy = std::max(std::max((float)(y_lo - 1), -(float)(y_lo + BE)), 0.f),
+                        dz = std::max(std::max((float)(z_lo - 1), -(float)(z_lo + BE)), 0.f);
+            if (dx * dx + dy * dy + dz * dz >= r * r) continue;
+            const float cx = x_lo - 1 + hh, cy = y_lo - 1 + hh, cz = z_lo - 1 + hh;
+            int cut = 0;
+            for (int i = 0; i < NS; i++) {
+                const float *n = &nrm[i * 3];
+                if (std::fabs(n[0] * cx + n[1] * cy + n[2] * cz) <= (std::fabs(n[0]) + std::fabs(n[1]) + std::fabs(n[2])) * hh) cut++;
+            }
+            a->brick_load[((size_t)bz * nby + by) * nbx + bx] = 0.02f + (float)cut / NS;
+        }
+        a->load_r = r; a->items_cap = -1;
+    }
+    static const int smax_env = getenv("PPM_BRICK_SLICES") ? atoi(getenv("PPM_BRICK_SLICES")) : 16;
+    const int cap = std::max(1, std::min(smax_env, nb / 128));
+    if (cap == a->items_cap) return 0;
+    struct Tmp { BrickItem it; float load; };
+    std::vector<Tmp> v;
+    for (int bz = 0; bz < nby; bz++) for (int by = 0; by < nby; by++) for (int bx = 0; bx < nbx; bx++) {
+        const float L = a->brick_load[((size_t)bz * nby + by) * nbx + bx];
+        if (L < 0.f) continue;
+        const int S = std::max(1, std::min(cap, (int)std::lround(L * smax_env)));
+        for (int sl = 0; sl < S; sl++) {
+            Tmp t; t.it.bx = (unsigned short)bx; t.it.by = (unsigned short)by; t.it.bz = (unsigned short)bz; t.it.s = (unsigned char)sl; t.it.S = (unsigned char)S;
+            t.load = L / S; v.push_back(t);
+        }
+    }
+    std::stable_sort(v.begin(), v.end(), [](const Tmp &x, const Tmp &y) { return x.load > y.load; });
+    std::vector<BrickItem> items(v.size());
+    for (size_t i = 0; i < v.size(); i++) items[i] = v[i].it;
+    if (int rc = a->items.ensure(items.size())) return rc;
+    HIPCHK(hipMemcpyAsync(a->items.p, items.data(), items.size() * sizeof(BrickItem), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    a->n_items = (int)items.size(); a->items_cap = cap;
+    return 0;
+}
 
 // ------------------------------------------------------------------------------ pre-processing launch
 static int launch_prep(const float *d_images, const double *d_rows, int n_img, const Geom &gm, float Rm_px, float fall_px,
@@ -536,6 +591,9 @@ ppm_accum_t *ppm_accum_create(int box, float pixel_size, const char *symmetry, v
     HIPCHKP(hipMemcpy(a->d_sym, s.data(), s.size() * sizeof(float), hipMemcpyHostToDevice));
     HIPCHKP(hipMalloc(&a->d_counts, 2 * sizeof(unsigned long long)));
     HIPCHKP(hipMemset(a->d_counts, 0, 2 * sizeof(unsigned long long)));
+    HIPCHKP(hipMalloc(&a->d_max, 2 * sizeof(unsigned)));
+    static bool attr_set = false;
+    if (!attr_set) { HIPCHKP(hipFuncSetAttribute((const void *)k_insert_bricks<16, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 16 * 16 * 3 * 8)); attr_set = true; }
     return a;
 }
 
@@ -544,7 +602,8 @@ void ppm_accum_destroy(ppm_accum_t *a) {
     if (a->acc && !a->external) (void)hipFree(a->acc);
     if (a->d_sym) (void)hipFree(a->d_sym);
     if (a->d_counts) (void)hipFree(a->d_counts);
-    a->rows.release(); a->images.release(); a->band.release();
+    if (a->d_max) (void)hipFree(a->d_max);
+    a->rows.release(); a->images.release(); a->band.release(); a->pp.release(); a->items.release();
     delete a;
 }
 
@@ -573,14 +632,24 @@ int ppm_insert_batch(ppm_accum_t *a, const ppm_recon_cfg *cfg, const void *image
         const float *d_img = images_on_device ? (const float *)images + (size_t)c0 * NN : a->images.p + (size_t)(ci & 1) * CH * NN;
         if (int r = launch_prep(d_img, a->rows.p, nb, gm, cfg->mask_radius / cfg->pixel_size, 1.f, cfg->normalize, cfg->invert, 0, 0,
                                 a->band.p, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr)) return r;
-        InsertP IP;
-        IP.band = a->band.p; IP.rows = a->rows.p; IP.symops = a->d_sym; IP.nsym = a->nsym; IP.acc = a->acc;
-        IP.N = gm.N; IP.B = gm.B; IP.W = gm.W; IP.H = gm.H; IP.n_img = nb;
-        IP.r2 = (float)(gm.r_hi * gm.r_hi); IP.a = cfg->pixel_size; IP.bfac = cfg->score_weight_bfactor; IP.score_avg = cfg->score_average;
-        IP.score_thr = cfg->score_threshold; IP.split_by_pind = cfg->split_by_pind; IP.counts = a->d_counts;
+        // per-particle constants and the chunk's value bounds, then one block per (brick, particle slice, half)
+        if (int r = a->pp.ensure(nb)) return r;
+        HIPCHK(hipMemsetAsync(a->d_max, 0, 2 * sizeof(unsigned), g.stream));
+        hipLaunchKernelGGL(k_insert_params, dim3((nb + 255) / 256), dim3(256), 0, g.stream, a->rows.p, a->pp.p, nb, gm.N, (double)cfg->pixel_size,
+                           (double)cfg->score_weight_bfactor, (double)cfg->score_average, (double)cfg->score_threshold, cfg->split_by_pind,
+                           gm.r_hi * gm.r_hi, a->d_counts, a->d_max);
+        hipLaunchKernelGGL(k_band_absmax, dim3(1024), dim3(256), 0, g.stream, a->band.p, (size_t)nb * HW, a->d_max);
+        const int BE = gm.N >= 128 ? 16 : 8;
+        if (int r = build_brick_items(a, gm, BE, nb)) return r;
+        InsertBrickP IP;
+        IP.band = a->band.p; IP.pp = a->pp.p; IP.symops = a->d_sym; IP.nsym = a->nsym; IP.acc = a->acc;
+        IP.N = gm.N; IP.B = gm.B; IP.W = gm.W; IP.H = gm.H; IP.n_img = nb; IP.items = a->items.p; IP.maxima = a->d_max;
+        IP.r2 = (float)(gm.r_hi * gm.r_hi);
         {
             ProfScope ps(PPM_K_INSERT);
-            hipLaunchKernelGGL(k_insert, dim3((unsigned)((HW + 255) / 256), nb), dim3(256), 0, g.stream, IP);
+            dim3 grid((unsigned)a->n_items, 2);
+            if (BE == 16) hipLaunchKernelGGL((k_insert_bricks<16, 16>), grid, dim3(1024), 16 * 16 * 16 * 3 * sizeof(long long), g.stream, IP);
+            else hipLaunchKernelGGL((k_insert_bricks<8, 4>), grid, dim3(256), 8 * 8 * 8 * 3 * sizeof(long long), g.stream, IP);
         }
         HIPCHK(hipGetLastError());
         if (!images_on_device && c0 + CH < n_img) {
