@@ -423,8 +423,11 @@ struct PartIns {       // per-particle constants, written by k_insert_params
 // so that items carry about equal work; the host sorts them heavy-first).
 struct BrickItem { unsigned short bx, by, bz; unsigned char s, S; };
 
+// one entry per (particle, symmetry operator): unit normal of the inserted slice plane; flag = half-map, or -1 if skipped
+struct CullEnt { float nx, ny, nz; int flag; };
+
 struct InsertBrickP {
-    const float2 *band; const PartIns *pp; const float *symops; int nsym;
+    const float2 *band; const PartIns *pp; const CullEnt *cull; const float *symops; int nsym;
     float *acc; int N, B, W, H, n_img;
     const BrickItem *items;
     const unsigned *maxima;   // [0] bits of max |band| component, [1] bits of max particle weight (floats >= 0, set by atomicMax)
@@ -443,8 +446,8 @@ __global__ void __launch_bounds__(256) k_band_absmax(const float2 *band, size_t 
     if ((threadIdx.x & 63) == 0 && m > 0.f && m < 3.0e38f) atomicMax(maxima, __float_as_uint(m));
 }
 
-__global__ void k_insert_params(const double *rows, PartIns *pp, int n, int N, double a, double bfac, double score_avg,
-                                double score_thr, int split_by_pind, double r2, unsigned long long *counts, unsigned *maxima) {
+__global__ void k_insert_params(const double *rows, PartIns *pp, CullEnt *cull, const float *symops, int nsym, int n, int N, double a, double bfac,
+                                double score_avg, double score_thr, int split_by_pind, double r2, unsigned long long *counts, unsigned *maxima) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const double *row = rows + (size_t)i * PPM_NCOL;
@@ -460,6 +463,14 @@ __global__ void k_insert_params(const double *rows, PartIns *pp, int n, int N, d
     q.w0 = (float)(occ / 100.0);
     q.wexp = (float)(-0.25 * bfac * (score_avg - scr)) * q.ctf.inv_na2;
     pp[i] = q;
+    for (int so = 0; so < nsym; so++) {
+        const float *S = symops + so * 9;
+        const float m2 = (float)M[2], m5 = (float)M[5], m8 = (float)M[8];
+        CullEnt c;
+        c.nx = S[0] * m2 + S[1] * m5 + S[2] * m8; c.ny = S[3] * m2 + S[4] * m5 + S[5] * m8; c.nz = S[6] * m2 + S[7] * m5 + S[8] * m8;
+        c.flag = q.valid ? q.half : -1;
+        cull[(size_t)i * nsym + so] = c;
+    }
     if (q.valid) {
         atomicAdd(&counts[q.half], 1ull);
         const float wmax = q.w0 * fmaxf(1.f, expf(q.wexp * (float)r2));
@@ -467,17 +478,23 @@ __global__ void k_insert_params(const double *rows, PartIns *pp, int n, int N, d
     }
 }
 
-// grid: (items, 2 halves), NW waves.  Each wave takes every NW-th (particle, operator) of the item's slice: plane-vs-box
-// rejection (wave-uniform), then 8x8 tiles of the candidate rectangle are TESTED (cheap: position only) and the hits
-// compacted into a per-wave LDS queue; full groups of 64 hits are EVALUATED (CTF, weights, phase, 8 taps).
+// grid: (items, 2 halves), NW waves.  Per round of up to CULL_CAP (particle, operator) entries of the item's slice:
+//   CULL  every thread tests entries (slice-plane normal vs the brick's expanded box) and the cutting ones are collected in
+//         a block-wide LDS list;
+//   WORK  waves pull cuts from that list (dynamic balance); for one cut, 8x8 tiles of the candidate rectangle in the slice
+//         are TESTED (position only), the hits compacted into a per-wave LDS queue, and full groups of 64 hits EVALUATED
+//         (CTF, weights, phase, 8 taps).
 // The brick is accumulated in 64-bit FIXED POINT: on gfx950 a ds_add_f32 wave-instruction occupies the LDS for ~190
 // cycles (lanes are serialised), a ds_add_u64 for ~8 (scripts/micro/lds_atomic_bench.hip).  Every tap is rounded to a
 // 31-bit integer relative to the largest possible value of the chunk (max |band| x max weight, found on the device
-// beforehand), then summed exactly: the LDS part of the sum no longer depends on the order of the adds.
+// beforehand), then summed exactly: the LDS part of the sum does not depend on the order of the adds.
+constexpr int CULL_CAP = 4096;
 template <int BE, int NW>
 __global__ void __launch_bounds__(NW * 64) k_insert_bricks(InsertBrickP P) {
     extern __shared__ long long brick[];           // [BE][BE][BE][3]
     __shared__ unsigned queue_s[NW][128];
+    __shared__ int cut_list[CULL_CAP];
+    __shared__ int n_cut, cut_head;
     // value scale 2^(30-e) with bound < 2^e, so |tap| < 2^30; likewise for the weight channel
     float sv, sw;
     {
@@ -501,19 +518,41 @@ __global__ void __launch_bounds__(NW * 64) k_insert_bricks(InsertBrickP P) {
     unsigned *queue = queue_s[wave];
     int qn = 0;
     bool touched = false;
-    const int i_hi = p_hi * P.nsym;
-    for (int idx = p_lo * P.nsym + wave; idx < i_hi; idx += NW) {
+    const int e_hi = p_hi * P.nsym;
+    for (int r0 = p_lo * P.nsym; r0 < e_hi; r0 += CULL_CAP) {
+    const int r1 = min(r0 + CULL_CAP, e_hi);
+    if (tid == 0) { n_cut = 0; cut_head = 0; }
+    __syncthreads();
+    for (int eb = r0; eb < r1; eb += NW * 64) {          // CULL
+        const int e = eb + tid;
+        bool cut = false;
+        if (e < r1) {
+            const CullEnt c = P.cull[e];
+            cut = c.flag == h && fabsf(c.nx * cx + c.ny * cy + c.nz * cz) <= (fabsf(c.nx) + fabsf(c.ny) + fabsf(c.nz)) * hh + 1e-3f;
+        }
+        const unsigned long long m = __ballot(cut);
+        if (m != 0ull) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&n_cut, (int)__popcll(m));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (cut) cut_list[base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = e;
+        }
+    }
+    __syncthreads();
+    const int nc = n_cut;
+    for (;;) {                                           // WORK
+        int ci = 0;
+        if (lane == 0) ci = atomicAdd(&cut_head, 1);
+        ci = __builtin_amdgcn_readfirstlane(ci);
+        if (ci >= nc) break;
+        const int idx = __builtin_amdgcn_readfirstlane(cut_list[ci]);
         const int p = idx / P.nsym, so = idx - p * P.nsym;
         const PartIns &q = P.pp[p];
-        if (!q.valid || q.half != h) continue;
         const float *S = P.symops + so * 9;
         // first two columns of S M
         const float a0 = S[0] * q.m[0] + S[1] * q.m[2] + S[2] * q.m[4], a1 = S[0] * q.m[1] + S[1] * q.m[3] + S[2] * q.m[5];
         const float b0 = S[3] * q.m[0] + S[4] * q.m[2] + S[5] * q.m[4], b1 = S[3] * q.m[1] + S[4] * q.m[3] + S[5] * q.m[5];
         const float c0 = S[6] * q.m[0] + S[7] * q.m[2] + S[8] * q.m[4], c1 = S[6] * q.m[1] + S[7] * q.m[3] + S[8] * q.m[5];
-        // plane normal = col0 x col1; does the plane through the origin cut the box?
-        const float nx = b0 * c1 - c0 * b1, ny = c0 * a1 - a0 * c1, nz = a0 * b1 - b0 * a1;
-        if (fabsf(nx * cx + ny * cy + nz * cz) > (fabsf(nx) + fabsf(ny) + fabsf(nz)) * hh + 1e-3f) continue;
         // EVALUATE one queued sample per lane
         auto evaluate = [&](unsigned e, bool on) {
             if (!on) return;
@@ -587,6 +626,8 @@ __global__ void __launch_bounds__(NW * 64) k_insert_bricks(InsertBrickP P) {
             __builtin_amdgcn_wave_barrier();
             qn = 0;
         }
+    }
+    __syncthreads();
     }
     const int any = __syncthreads_or(touched ? 1 : 0);
     if (!any) return;

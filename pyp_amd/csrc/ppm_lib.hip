@@ -152,7 +152,7 @@ struct ppm_accum {
     unsigned long long *d_counts = nullptr;
     unsigned *d_max = nullptr;       // chunk maxima for the fixed-point scales of k_insert_bricks
     long counts[2] = { 0, 0 };
-    DevBuf<double> rows; DevBuf<float> images; DevBuf<float2> band; DevBuf<PartIns> pp; DevBuf<BrickItem> items;
+    DevBuf<double> rows; DevBuf<float> images; DevBuf<float2> band; DevBuf<PartIns> pp; DevBuf<CullEnt> cull; DevBuf<BrickItem> items;
     std::vector<float> brick_load; float load_r = -1.f; int n_items = 0, items_cap = -1;
 };
 
@@ -186,7 +186,8 @@ static int build_brick_items(ppm_accum *a, const Geom &gm, int BE, int nb) {
         a->load_r = r; a->items_cap = -1;
     }
     static const int smax_env = getenv("PPM_BRICK_SLICES") ? atoi(getenv("PPM_BRICK_SLICES")) : 16;
-    const int cap = std::max(1, std::min(smax_env, nb / 128));
+    static const int minp_env = getenv("PPM_BRICK_MINP") ? atoi(getenv("PPM_BRICK_MINP")) : 512;
+    const int cap = std::max(1, std::min(smax_env, nb / std::max(1, minp_env)));
     if (cap == a->items_cap) return 0;
     struct Tmp { BrickItem it; float load; };
     std::vector<Tmp> v;
@@ -603,7 +604,7 @@ void ppm_accum_destroy(ppm_accum_t *a) {
     if (a->d_sym) (void)hipFree(a->d_sym);
     if (a->d_counts) (void)hipFree(a->d_counts);
     if (a->d_max) (void)hipFree(a->d_max);
-    a->rows.release(); a->images.release(); a->band.release(); a->pp.release(); a->items.release();
+    a->rows.release(); a->images.release(); a->band.release(); a->pp.release(); a->cull.release(); a->items.release();
     delete a;
 }
 
@@ -634,15 +635,16 @@ int ppm_insert_batch(ppm_accum_t *a, const ppm_recon_cfg *cfg, const void *image
                                 a->band.p, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr)) return r;
         // per-particle constants and the chunk's value bounds, then one block per (brick, particle slice, half)
         if (int r = a->pp.ensure(nb)) return r;
+        if (int r = a->cull.ensure((size_t)nb * a->nsym)) return r;
         HIPCHK(hipMemsetAsync(a->d_max, 0, 2 * sizeof(unsigned), g.stream));
-        hipLaunchKernelGGL(k_insert_params, dim3((nb + 255) / 256), dim3(256), 0, g.stream, a->rows.p, a->pp.p, nb, gm.N, (double)cfg->pixel_size,
+        hipLaunchKernelGGL(k_insert_params, dim3((nb + 255) / 256), dim3(256), 0, g.stream, a->rows.p, a->pp.p, a->cull.p, a->d_sym, a->nsym, nb, gm.N, (double)cfg->pixel_size,
                            (double)cfg->score_weight_bfactor, (double)cfg->score_average, (double)cfg->score_threshold, cfg->split_by_pind,
                            gm.r_hi * gm.r_hi, a->d_counts, a->d_max);
         hipLaunchKernelGGL(k_band_absmax, dim3(1024), dim3(256), 0, g.stream, a->band.p, (size_t)nb * HW, a->d_max);
         const int BE = gm.N >= 128 ? 16 : 8;
         if (int r = build_brick_items(a, gm, BE, nb)) return r;
         InsertBrickP IP;
-        IP.band = a->band.p; IP.pp = a->pp.p; IP.symops = a->d_sym; IP.nsym = a->nsym; IP.acc = a->acc;
+        IP.band = a->band.p; IP.pp = a->pp.p; IP.cull = a->cull.p; IP.symops = a->d_sym; IP.nsym = a->nsym; IP.acc = a->acc;
         IP.N = gm.N; IP.B = gm.B; IP.W = gm.W; IP.H = gm.H; IP.n_img = nb; IP.items = a->items.p; IP.maxima = a->d_max;
         IP.r2 = (float)(gm.r_hi * gm.r_hi);
         {
