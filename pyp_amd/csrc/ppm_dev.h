@@ -32,22 +32,32 @@ struct FftPlan { int n, nfac; int fac[12]; const float2 *tw; const unsigned shor
 // already sit at the positions plan.perm gives; output is in natural order.  Every stage combines r
 // blocks of length Lp into one of length r Lp: twiddle w^(q j), then the r-point butterfly.  All threads of
 // the block must call.
-__device__ inline void lds_fft(float2 *buf, const FftPlan &pl, int nlines, int lstride, bool inverse, int tid, int nthr) {
+// i / d for 0 <= i < 2^22 with inv = 1.0f / d (float quotient, one fix-up step)
+__device__ __forceinline__ int fast_div(int i, int d, float inv) {
+    int q = (int)((float)i * inv);
+    const int r = i - q * d;
+    return r < 0 ? q - 1 : (r >= d ? q + 1 : q);
+}
+
+// `tw` = the plan's twiddle table, or a copy of it the caller keeps in LDS (the per-stage global loads are what the
+// stages wait for otherwise).
+__device__ inline void lds_fft(float2 *buf, const FftPlan &pl, int nlines, int lstride, bool inverse, int tid, int nthr, const float2 *tw) {
     const int n = pl.n;
     const float sgn = inverse ? 1.f : -1.f;       // sign of the exponent
     int Lp = 1;
     for (int st = 0; st < pl.nfac; st++) {
         const int r = pl.fac[st], L = Lp * r, m = n / r, tws = n / L;
+        const float inv_m = 1.0f / (float)m, inv_Lp = 1.0f / (float)Lp;
         __syncthreads();
         for (int i = tid; i < nlines * m; i += nthr) {
-            const int line = i / m, t = i - line * m, blk = t / Lp, j = t - blk * Lp;
+            const int line = fast_div(i, m, inv_m), t = i - line * m, blk = fast_div(t, Lp, inv_Lp), j = t - blk * Lp;
             float2 *p = buf + line * lstride + blk * L + j;
             float2 x[5];
 #pragma unroll
             for (int q = 0; q < 5; q++) {
                 if (q < r) {
                     float2 v = p[q * Lp];
-                    if (q > 0) { float2 w = pl.tw[q * j * tws]; w.y *= sgn; v = cmul(v, w); }
+                    if (q > 0) { float2 w = tw[q * j * tws]; w.y *= sgn; v = cmul(v, w); }
                     x[q] = v;
                 }
             }
@@ -80,6 +90,9 @@ __device__ inline void lds_fft(float2 *buf, const FftPlan &pl, int nlines, int l
         Lp = L;
     }
     __syncthreads();
+}
+__device__ inline void lds_fft(float2 *buf, const FftPlan &pl, int nlines, int lstride, bool inverse, int tid, int nthr) {
+    lds_fft(buf, pl, nlines, lstride, inverse, tid, nthr, pl.tw);
 }
 
 // Trilinear sample of the band-limited reference cube at Fourier coordinate (X,Y,Z).

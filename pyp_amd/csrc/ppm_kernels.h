@@ -97,10 +97,16 @@ __global__ void __launch_bounds__(kPrepThreads) k_prep(PrepP P) {
     const int TS = N + 1;                             // padded line stride of T (bank spread)
     float2 *T = (float2 *)smem;                       // [nc][N+1]
     float2 *Wk = T + (size_t)P.nc * TS;               // [L][N]
-    float *ringpw = (float *)(Wk + (size_t)P.L * N);  // [B+2]
-    float *ringpc = ringpw + (B + 2);                 // [B+2]
-    double *red = (double *)(((uintptr_t)(ringpc + (B + 2)) + 15) & ~(uintptr_t)15);  // [PW*4 + PW]
-    float *stat = (float *)(red + PW * 5);            // mu, scale, nI partials
+    // ring power sums in 64-bit fixed point and integer counts: a ds_add_f32 costs ~190 LDS cycles per wave-instruction on
+    // gfx950, ds_add_u64 / ds_add_u32 ~8 / ~5 (scripts/micro/lds_atomic_bench.hip)
+    unsigned long long *ringq = (unsigned long long *)(Wk + (size_t)P.L * N);  // [B+2]
+    unsigned *ringc = (unsigned *)(ringq + (B + 2));  // [B+2]
+    float *ringpw = (float *)(ringc + (B + 2));       // [B+2] ring weights
+    double *red = (double *)(((uintptr_t)(ringpw + (B + 2)) + 15) & ~(uintptr_t)15);  // [PW*4 + PW]
+    float *stat = (float *)(red + PW * 5);            // mu, scale, fixed-point scale, nI partials
+    float2 *tw_s = (float2 *)(stat + 4 + PW);         // [N] twiddles and [N] staging positions of the FFT plan, kept in LDS
+    unsigned short *perm_s = (unsigned short *)(tw_s + N);
+    for (int i = tid; i < N; i += PT) { tw_s[i] = P.plan.tw[i]; perm_s[i] = P.plan.perm[i]; }
     const float *img = P.images + (size_t)p * N * N;
 
     // ---- statistics of the background (outside the mask radius); whole image if that is empty
@@ -133,11 +139,18 @@ __global__ void __launch_bounds__(kPrepThreads) k_prep(PrepP P) {
             double mu = a1 / ac, var = a2 / ac - mu * mu, sd = var > 0 ? sqrt(var) : 1.0;
             stat[0] = (float)mu;
             stat[1] = (float)((P.normalize ? 1.0 / sd : 1.0) * (P.invert ? -1.0 : 1.0));
+            // Parseval: sum_k |F_k / N|^2 = sum_x v_x^2 <= E, so no ring sum (weights 1 or 2) exceeds 2 E; scale = 2^(60-e), 4E < 2^e
+            const double sc2 = (double)stat[1] * (double)stat[1];
+            const double E = sc2 * (b2 - 2.0 * mu * b1 + (double)N * N * mu * mu);
+            int e2 = 0; (void)frexp(E > 1e-30 ? 4.0 * E : 1.0, &e2);
+            int ex = 60 - e2; ex = ex > 120 ? 120 : (ex < -120 ? -120 : ex);
+            stat[2] = ldexpf(1.f, ex);
         }
         __syncthreads();
     }
     const float mu = stat[0], sc = stat[1];
-    for (int i = tid; i < 2 * (B + 2); i += PT) ringpw[i] = 0.f;
+    const float qscale = stat[2];
+    for (int i = tid; i < B + 2; i += PT) { ringq[i] = 0ull; ringc[i] = 0u; }
 
     const float wf = P.wfall < 1e-3f ? 1e-3f : P.wfall;
     float2 *bandp = P.band + (size_t)p * H * W;
@@ -158,9 +171,9 @@ __global__ void __launch_bounds__(kPrepThreads) k_prep(PrepP P) {
                     float mb = rb >= P.Rm + 0.5f * wf ? 0.f : (rb > P.Rm - 0.5f * wf ? 0.5f * (1.f + cosf(kPiF * (rb - P.Rm + 0.5f * wf) / wf)) : 1.f);
                     va *= ma; vb *= mb;
                 }
-                Wk[l * N + P.plan.perm[x]] = make_float2(va, vb);
+                Wk[l * N + perm_s[x]] = make_float2(va, vb);
             }
-            lds_fft(Wk, P.plan, P.L, N, false, tid, PT);
+            lds_fft(Wk, P.plan, P.L, N, false, tid, PT, tw_s);
             for (int i = tid; i < P.L * ncol; i += PT) {
                 int l = i / ncol, c = i - l * ncol, kx = c0 + c;
                 float2 z = Wk[l * N + kx], zc = Wk[l * N + (kx ? N - kx : 0)];
@@ -168,12 +181,12 @@ __global__ void __launch_bounds__(kPrepThreads) k_prep(PrepP P) {
                 float2 d = make_float2(z.x - zc.x, z.y + zc.y);
                 float2 xb = make_float2(0.5f * d.y, -0.5f * d.x);
                 int ya = y0 + 2 * l;
-                T[c * TS + P.plan.perm[ya]] = xa;
-                T[c * TS + P.plan.perm[ya + 1]] = xb;
+                T[c * TS + perm_s[ya]] = xa;
+                T[c * TS + perm_s[ya + 1]] = xb;
             }
         }
         // ---- column pass
-        lds_fft(T, P.plan, ncol, TS, false, tid, PT);
+        lds_fft(T, P.plan, ncol, TS, false, tid, PT, tw_s);
         const float invN = 1.f / (float)N;
         for (int i = tid; i < ncol * H; i += PT) {
             int c = i % ncol, row = i / ncol, ky = row - B, kx = c0 + c;
@@ -185,8 +198,8 @@ __global__ void __launch_bounds__(kPrepThreads) k_prep(PrepP P) {
                 o = make_float2(v.x * sg, v.y * sg);
                 int b = (int)floorf(sqrtf(k2));
                 float al = kx == 0 ? 1.f : 2.f;
-                atomicAdd(&ringpw[b], al * (o.x * o.x + o.y * o.y));
-                atomicAdd(&ringpc[b], al);
+                atomicAdd(&ringq[b], (unsigned long long)__double2ll_rn((double)(al * (o.x * o.x + o.y * o.y)) * (double)qscale));
+                atomicAdd(&ringc[b], kx == 0 ? 1u : 2u);
             }
             bandp[row * W + kx] = o;
         }
@@ -195,7 +208,7 @@ __global__ void __launch_bounds__(kPrepThreads) k_prep(PrepP P) {
     __syncthreads();
     // ---- ring weights (re-using ringpw as the weight table)
     for (int b = tid; b < B + 2; b += PT) {
-        float pw = ringpc[b] > 0.f ? ringpw[b] / ringpc[b] : 0.f;
+        float pw = ringc[b] > 0u ? (float)((double)ringq[b] / (double)qscale / (double)ringc[b]) : 0.f;
         float wgt = P.whiten ? (pw > 0.f ? rsqrtf(pw) : 0.f) : 1.f;
         ringpw[b] = wgt;
         if (P.wring) P.wring[(size_t)p * (B + 2) + b] = wgt;
@@ -240,9 +253,9 @@ __global__ void __launch_bounds__(kPrepThreads) k_prep(PrepP P) {
         }
         ni = wave_sum(ni);
         __syncthreads();
-        if ((tid & 63) == 0) stat[2 + (tid >> 6)] = ni;
+        if ((tid & 63) == 0) stat[3 + (tid >> 6)] = ni;
         __syncthreads();
-        if (tid == 0) { float t = 0.f; for (int w = 0; w < PW; w++) t += stat[2 + w]; P.nI[p] = t; }
+        if (tid == 0) { float t = 0.f; for (int w = 0; w < PW; w++) t += stat[3 + w]; P.nI[p] = t; }
     }
 }
 

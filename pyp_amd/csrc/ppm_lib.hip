@@ -223,11 +223,13 @@ static int launch_prep(const float *d_images, const double *d_rows, int n_img, c
     P.nc = std::min(gm.W, (int)(139264 / ((gm.N + 1) * sizeof(float2))));
     P.nchunks = (gm.W + P.nc - 1) / P.nc;
     P.L = std::max(1, std::min(2048 / gm.N, gm.N / 2));
+    if (getenv("PPM_PREP_NCH")) { P.nchunks = atoi(getenv("PPM_PREP_NCH")); P.nc = (gm.W + P.nchunks - 1) / P.nchunks; P.nchunks = (gm.W + P.nc - 1) / P.nc; }
+    if (getenv("PPM_PREP_L")) P.L = atoi(getenv("PPM_PREP_L"));
     while ((gm.N / 2) % P.L) P.L--;          // the row pass walks the image 2 L rows at a time
     P.band = band; P.wring = wring; P.samples = samples; P.S_pad = S_pad; P.Il = Il; P.cw = cw;
     P.Wp = Wp; P.C2 = C2; P.nI = nI; P.Bs = gm.Bs; P.Hs = gm.Hs;
     P.r_s2 = (float)(gm.r_s * gm.r_s); P.r_lo2 = (float)(gm.r_lo * gm.r_lo);
-    size_t lds = (size_t)P.nc * (gm.N + 1) * sizeof(float2) + (size_t)P.L * gm.N * sizeof(float2) + 2 * (gm.B + 2) * sizeof(float) + 16 + 5 * (kPrepThreads / 64) * sizeof(double) + (4 + kPrepThreads / 64) * sizeof(float);
+    size_t lds = (size_t)P.nc * (gm.N + 1) * sizeof(float2) + (size_t)P.L * gm.N * sizeof(float2) + (size_t)(gm.B + 2) * 16 + 16 + 5 * (kPrepThreads / 64) * sizeof(double) + (4 + kPrepThreads / 64) * sizeof(float) + (size_t)gm.N * 10 + 16;
     if (lds > 160 * 1024) return fail(-12, "pre-processing kernel needs more than 160 KB of LDS");
     static bool attr_set = false;
     if (!attr_set) { HIPCHK(hipFuncSetAttribute((const void *)k_prep, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
