@@ -80,6 +80,8 @@ struct PrepP {
     int normalize, invert, do_mask, whiten;
     int nc, nchunks, L;
     float2 *band;  // [n][H*W] unscaled band spectrum (scratch; the final result for insertion)
+    int stop;      // timing experiments only (PPM_PREP_STOP): leave the kernel after phase `stop`
+    float2 *spill; // [n][N][W-nc] row-transformed columns beyond the first LDS chunk (only if nchunks > 1)
     float *wring;  // [n][B+2] ring weights 1/sqrt(mean power), may be null
     // ring-ordered list outputs (may be null)
     const uint32_t *samples; int S_pad; float2 *Il; float *cw;
@@ -106,17 +108,28 @@ __global__ void __launch_bounds__(kPrepThreads) k_prep(PrepP P) {
     float *stat = (float *)(red + PW * 5);            // mu, scale, fixed-point scale, nI partials
     float2 *tw_s = (float2 *)(stat + 4 + PW);         // [N] twiddles and [N] staging positions of the FFT plan, kept in LDS
     unsigned short *perm_s = (unsigned short *)(tw_s + N);
-    for (int i = tid; i < N; i += PT) { tw_s[i] = P.plan.tw[i]; perm_s[i] = P.plan.perm[i]; }
+    unsigned short *iperm_s = perm_s + N;             // inverse: the sample that is staged at LDS position d
+    for (int i = tid; i < N; i += PT) { tw_s[i] = P.plan.tw[i]; const unsigned short q = P.plan.perm[i]; perm_s[i] = q; iperm_s[q] = (unsigned short)i; }
+    __syncthreads();
     const float *img = P.images + (size_t)p * N * N;
 
     // ---- statistics of the background (outside the mask radius); whole image if that is empty
     double s1 = 0, s2 = 0, cnt = 0, t1 = 0, t2 = 0;
     const float Rm2 = P.Rm * P.Rm;
-    for (int i = tid; i < N * N; i += PT) {
-        int y = i / N, x = i - y * N;
-        float dx = (float)(x - N / 2), dy = (float)(y - N / 2), v = img[i];
-        t1 += v; t2 += (double)v * v;
-        if (dx * dx + dy * dy > Rm2) { s1 += v; s2 += (double)v * v; cnt += 1.0; }
+    {
+        const float invNf = 1.0f / (float)N;
+        const float4 *img4 = (const float4 *)img;          // N even: N^2 is a multiple of 4, every image starts 16-byte aligned
+        for (int i4 = tid; i4 < N * N / 4; i4 += PT) {
+            const float4 q = img4[i4];
+            const float vv[4] = { q.x, q.y, q.z, q.w };
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int i = 4 * i4 + j, y = fast_div(i, N, invNf), x = i - y * N;
+                const float dx = (float)(x - N / 2), dy = (float)(y - N / 2), v = vv[j];
+                t1 += v; t2 += (double)v * v;
+                if (dx * dx + dy * dy > Rm2) { s1 += v; s2 += (double)v * v; cnt += 1.0; }
+            }
+        }
     }
     s1 = wave_sum_d(s1); s2 = wave_sum_d(s2); cnt = wave_sum_d(cnt); t1 = wave_sum_d(t1); t2 = wave_sum_d(t2);
     if ((tid & 63) == 0) { int w = tid >> 6; red[w * 4] = s1; red[w * 4 + 1] = s2; red[w * 4 + 2] = cnt; red[w * 4 + 3] = t1; }
@@ -149,6 +162,7 @@ __global__ void __launch_bounds__(kPrepThreads) k_prep(PrepP P) {
         __syncthreads();
     }
     const float mu = stat[0], sc = stat[1];
+    if (P.stop == 1) return;
     const float qscale = stat[2];
     for (int i = tid; i < B + 2; i += PT) { ringq[i] = 0ull; ringc[i] = 0u; }
 
@@ -156,38 +170,79 @@ __global__ void __launch_bounds__(kPrepThreads) k_prep(PrepP P) {
     float2 *bandp = P.band + (size_t)p * H * W;
     for (int ch = 0; ch < P.nchunks; ch++) {
         const int c0 = ch * P.nc, ncol = (W - c0) < P.nc ? (W - c0) : P.nc;
-        // ---- row pass: two real rows per complex transform
-        for (int y0 = 0; y0 < N; y0 += 2 * P.L) {
-            __syncthreads();
-            for (int i = tid; i < P.L * N; i += PT) {
-                int l = i / N, x = i - l * N;
-                int ya = y0 + 2 * l, yb = ya + 1;
-                float va = (img[ya * N + x] - mu) * sc, vb = (img[yb * N + x] - mu) * sc;
-                if (P.do_mask) {
-                    float dx = (float)(x - N / 2);
-                    float ra = sqrtf(dx * dx + (float)((ya - N / 2) * (ya - N / 2)));
-                    float rb = sqrtf(dx * dx + (float)((yb - N / 2) * (yb - N / 2)));
-                    float ma = ra >= P.Rm + 0.5f * wf ? 0.f : (ra > P.Rm - 0.5f * wf ? 0.5f * (1.f + cosf(kPiF * (ra - P.Rm + 0.5f * wf) / wf)) : 1.f);
-                    float mb = rb >= P.Rm + 0.5f * wf ? 0.f : (rb > P.Rm - 0.5f * wf ? 0.5f * (1.f + cosf(kPiF * (rb - P.Rm + 0.5f * wf) / wf)) : 1.f);
-                    va *= ma; vb *= mb;
+        // ---- row pass: two real rows per complex transform.  Done ONCE: the columns that do not fit the LDS chunk are
+        // spilled to global memory (row-major, coalesced) and read back for the later chunks.
+        if (ch == 0) {
+            const int nsp = W - P.nc;
+            float2 *sp = nsp > 0 ? P.spill + (size_t)p * N * nsp : nullptr;
+            // the pixels of the NEXT pass are fetched into registers while this pass runs its FFT (host: L N <= 8 PT)
+            constexpr int MAXI = 8;
+            float2 pre[MAXI];
+            const float invNf = 1.0f / (float)N;
+            auto fetch = [&](int y0) {
+#pragma unroll
+                for (int k = 0; k < MAXI; k++) {
+                    const int i = tid + k * PT;
+                    if (i < P.L * N) {       // lane -> consecutive LDS positions d (no bank conflicts); the gather is on the global side
+                        const int l = fast_div(i, N, invNf), d = i - l * N, x = iperm_s[d], ya = y0 + 2 * l;
+                        pre[k] = make_float2(img[ya * N + x], img[(ya + 1) * N + x]);
+                    }
                 }
-                Wk[l * N + perm_s[x]] = make_float2(va, vb);
+            };
+            fetch(0);
+            for (int y0 = 0; y0 < N; y0 += 2 * P.L) {
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < MAXI; k++) {
+                    const int i = tid + k * PT;
+                    if (i < P.L * N) {
+                        const int l = fast_div(i, N, invNf), d = i - l * N, x = iperm_s[d];
+                        const int ya = y0 + 2 * l, yb = ya + 1;
+                        float va = (pre[k].x - mu) * sc, vb = (pre[k].y - mu) * sc;
+                        if (P.do_mask) {
+                            float dx = (float)(x - N / 2);
+                            float ra = sqrtf(dx * dx + (float)((ya - N / 2) * (ya - N / 2)));
+                            float rb = sqrtf(dx * dx + (float)((yb - N / 2) * (yb - N / 2)));
+                            float ma = ra >= P.Rm + 0.5f * wf ? 0.f : (ra > P.Rm - 0.5f * wf ? 0.5f * (1.f + cosf(kPiF * (ra - P.Rm + 0.5f * wf) / wf)) : 1.f);
+                            float mb = rb >= P.Rm + 0.5f * wf ? 0.f : (rb > P.Rm - 0.5f * wf ? 0.5f * (1.f + cosf(kPiF * (rb - P.Rm + 0.5f * wf) / wf)) : 1.f);
+                            va *= ma; vb *= mb;
+                        }
+                        Wk[l * N + d] = make_float2(va, vb);
+                    }
+                }
+                if (y0 + 2 * P.L < N) fetch(y0 + 2 * P.L);
+                lds_fft(Wk, P.plan, P.L, N, false, tid, PT, tw_s);
+                for (int i = tid; i < P.L * W; i += PT) {
+                    int l = i / W, kx = i - l * W;
+                    float2 z = Wk[l * N + kx], zc = Wk[l * N + (kx ? N - kx : 0)];
+                    float2 xa = make_float2(0.5f * (z.x + zc.x), 0.5f * (z.y - zc.y));
+                    float2 d = make_float2(z.x - zc.x, z.y + zc.y);
+                    float2 xb = make_float2(0.5f * d.y, -0.5f * d.x);
+                    int ya = y0 + 2 * l;
+                    if (kx < P.nc) {
+                        T[kx * TS + perm_s[ya]] = xa;
+                        T[kx * TS + perm_s[ya + 1]] = xb;
+                    } else {
+                        sp[(size_t)ya * nsp + (kx - P.nc)] = xa;
+                        sp[(size_t)(ya + 1) * nsp + (kx - P.nc)] = xb;
+                    }
+                }
             }
-            lds_fft(Wk, P.plan, P.L, N, false, tid, PT, tw_s);
-            for (int i = tid; i < P.L * ncol; i += PT) {
-                int l = i / ncol, c = i - l * ncol, kx = c0 + c;
-                float2 z = Wk[l * N + kx], zc = Wk[l * N + (kx ? N - kx : 0)];
-                float2 xa = make_float2(0.5f * (z.x + zc.x), 0.5f * (z.y - zc.y));
-                float2 d = make_float2(z.x - zc.x, z.y + zc.y);
-                float2 xb = make_float2(0.5f * d.y, -0.5f * d.x);
-                int ya = y0 + 2 * l;
-                T[c * TS + perm_s[ya]] = xa;
-                T[c * TS + perm_s[ya + 1]] = xb;
+        } else {
+            const int nsp = W - P.nc;
+            const float2 *sp = P.spill + (size_t)p * N * nsp;
+            __threadfence_block();
+            __syncthreads();
+            for (int i = tid; i < N * ncol; i += PT) {
+                int y = i / ncol, c = i - y * ncol;
+                T[c * TS + perm_s[y]] = sp[(size_t)y * nsp + (c0 - P.nc + c)];
             }
         }
+        if (P.stop == 2) return;
         // ---- column pass
         lds_fft(T, P.plan, ncol, TS, false, tid, PT, tw_s);
         const float invN = 1.f / (float)N;
+        if (P.stop == 3) return;
         for (int i = tid; i < ncol * H; i += PT) {
             int c = i % ncol, row = i / ncol, ky = row - B, kx = c0 + c;
             float k2 = (float)(kx * kx + ky * ky);
@@ -204,6 +259,7 @@ __global__ void __launch_bounds__(kPrepThreads) k_prep(PrepP P) {
             bandp[row * W + kx] = o;
         }
     }
+    if (P.stop == 4) return;
     __threadfence_block();
     __syncthreads();
     // ---- ring weights (re-using ringpw as the weight table)

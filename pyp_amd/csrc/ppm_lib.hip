@@ -127,6 +127,8 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+DevBuf<float2> g_prep_spill;     // k_prep: row-transformed columns that do not fit the first LDS chunk
+
 }  // namespace
 
 struct ppm_ref {
@@ -220,16 +222,29 @@ static int launch_prep(const float *d_images, const double *d_rows, int n_img, c
     P.N = gm.N; P.B = gm.B; P.W = gm.W; P.H = gm.H;
     P.r_hi2 = (float)(gm.r_hi * gm.r_hi); P.Rm = Rm_px; P.wfall = fall_px; P.a = (float)gm.a;
     P.normalize = normalize; P.invert = invert; P.do_mask = do_mask; P.whiten = whiten;
-    P.nc = std::min(gm.W, (int)(139264 / ((gm.N + 1) * sizeof(float2))));
-    P.nchunks = (gm.W + P.nc - 1) / P.nc;
-    P.L = std::max(1, std::min(2048 / gm.N, gm.N / 2));
-    if (getenv("PPM_PREP_NCH")) { P.nchunks = atoi(getenv("PPM_PREP_NCH")); P.nc = (gm.W + P.nchunks - 1) / P.nchunks; P.nchunks = (gm.W + P.nc - 1) / P.nc; }
-    if (getenv("PPM_PREP_L")) P.L = atoi(getenv("PPM_PREP_L"));
+    // LDS plan: L row pairs per row pass (L N <= 8 x 1024 threads: the next pass is prefetched into <= 8 registers pairs per
+    // thread; L divides N/2), the rest of the 160 KB holds nc columns of the half spectrum; further columns are spilled.
+    const size_t lds_fixed = (size_t)(gm.B + 2) * 16 + 16 + 5 * (kPrepThreads / 64) * sizeof(double) + (4 + kPrepThreads / 64) * sizeof(float) + (size_t)gm.N * 12 + 16;
+    P.L = std::max(1, std::min(8 * kPrepThreads / gm.N, gm.N / 2));
+    if (getenv("PPM_PREP_L")) P.L = std::max(1, std::min(atoi(getenv("PPM_PREP_L")), 8 * kPrepThreads / gm.N));
     while ((gm.N / 2) % P.L) P.L--;          // the row pass walks the image 2 L rows at a time
+    {
+        const size_t left = 160 * 1024 - lds_fixed - (size_t)P.L * gm.N * sizeof(float2);
+        P.nc = std::max(1, std::min(gm.W, (int)(left / ((gm.N + 1) * sizeof(float2)))));
+    }
+    P.nchunks = (gm.W + P.nc - 1) / P.nc;
+    P.nc = (gm.W + P.nchunks - 1) / P.nchunks;       // even chunks
+    if (getenv("PPM_PREP_NCH")) { P.nchunks = atoi(getenv("PPM_PREP_NCH")); P.nc = (gm.W + P.nchunks - 1) / P.nchunks; P.nchunks = (gm.W + P.nc - 1) / P.nc; }
+    P.stop = getenv("PPM_PREP_STOP") ? atoi(getenv("PPM_PREP_STOP")) : 0;
+    P.spill = nullptr;
+    if (P.nchunks > 1) {
+        if (int rc = g_prep_spill.ensure((size_t)n_img * gm.N * (gm.W - P.nc))) return rc;
+        P.spill = g_prep_spill.p;
+    }
     P.band = band; P.wring = wring; P.samples = samples; P.S_pad = S_pad; P.Il = Il; P.cw = cw;
     P.Wp = Wp; P.C2 = C2; P.nI = nI; P.Bs = gm.Bs; P.Hs = gm.Hs;
     P.r_s2 = (float)(gm.r_s * gm.r_s); P.r_lo2 = (float)(gm.r_lo * gm.r_lo);
-    size_t lds = (size_t)P.nc * (gm.N + 1) * sizeof(float2) + (size_t)P.L * gm.N * sizeof(float2) + (size_t)(gm.B + 2) * 16 + 16 + 5 * (kPrepThreads / 64) * sizeof(double) + (4 + kPrepThreads / 64) * sizeof(float) + (size_t)gm.N * 10 + 16;
+    size_t lds = (size_t)P.nc * (gm.N + 1) * sizeof(float2) + (size_t)P.L * gm.N * sizeof(float2) + lds_fixed;
     if (lds > 160 * 1024) return fail(-12, "pre-processing kernel needs more than 160 KB of LDS");
     static bool attr_set = false;
     if (!attr_set) { HIPCHK(hipFuncSetAttribute((const void *)k_prep, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
