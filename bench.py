@@ -247,12 +247,12 @@ def reconstruct_bench(a, rank, world, local, dev, vol, stack, rows, N, M, px):
                 "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": "3D reconstruction: Fourier-insert %dk %d^2 particles/GPU -> %d^3 half-maps, C1, one all-reduce"
                            % (M // 1000, N, N), "particles_per_gpu": M, "box": N, "parallelism": "particle-sharded x%d" % world},
-                "roofline": {"bound": "hbm", "kernel": "k_insert", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+                "roofline": {"bound": "hbm", "kernel": "k_insert_bricks", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                              "frac": round(achieved / 8000.0, 4), "traffic": None, "avg_launch_ms": round(ms, 3),
-                             "note": "algorithmic bytes = S(N/2) x 8 taps x 12 B x 2 (read-modify-write) per particle; float atomics execute at "
-                                     "the memory side per 64-byte request and the kernel issues about 149 k requests per particle "
-                                     "(TCC_EA0_ATOMIC, profiles/r01_final_pmc_reconstruct_20k.json) = 20 G requests/s, the chip's atomic "
-                                     "request rate (1.3 TB/s / 64 B), so this kernel sits on the atomic ceiling, not the HBM one",
+                             "note": "algorithmic bytes (SURVEY 8d) = S(N/2) x 8 taps x 12 B x 2 (read-modify-write) per particle, i.e. what a "
+                                     "scatter into HBM would move; k_insert_bricks keeps 16^3-voxel bricks of the accumulator in LDS "
+                                     "(64-bit fixed point, ds_add_u64) and touches HBM once per brick and launch, so its real HBM traffic "
+                                     "is far below that figure and the kernel is VALU / LDS-atomic bound (profiles/r01_bricks_pmc_reconstruct_8k.json)",
                              "path_bytes_per_particle": b_ins},
                 "kernels_ms": {k2: round(v["ms"], 2) for k2, v in prof.items() if v["launches"]},
                 "map_cc_vs_truth": round(cc, 4), "fsc_at_half_nyquist": round(float(stats[N // 4 - 1, 3]), 4)}
