@@ -12,6 +12,13 @@ __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 
 
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. it waits for every global load
+// in flight, which defeats register prefetching across the barrier-heavy FFT stages.  Use it where the data exchanged
+// between the threads lives in LDS; global writes read back by other threads of the block still need __syncthreads().
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // wave64 all-lanes sum (every lane gets the total)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -48,7 +55,7 @@ __device__ inline void lds_fft(float2 *buf, const FftPlan &pl, int nlines, int l
     for (int st = 0; st < pl.nfac; st++) {
         const int r = pl.fac[st], L = Lp * r, m = n / r, tws = n / L;
         const float inv_m = 1.0f / (float)m, inv_Lp = 1.0f / (float)Lp;
-        __syncthreads();
+        lds_barrier();
         for (int i = tid; i < nlines * m; i += nthr) {
             const int line = fast_div(i, m, inv_m), t = i - line * m, blk = fast_div(t, Lp, inv_Lp), j = t - blk * Lp;
             float2 *p = buf + line * lstride + blk * L + j;
@@ -89,10 +96,86 @@ __device__ inline void lds_fft(float2 *buf, const FftPlan &pl, int nlines, int l
         }
         Lp = L;
     }
-    __syncthreads();
+    lds_barrier();
 }
 __device__ inline void lds_fft(float2 *buf, const FftPlan &pl, int nlines, int lstride, bool inverse, int tid, int nthr) {
     lds_fft(buf, pl, nlines, lstride, inverse, tid, nthr, pl.tw);
+}
+
+// ---- N = 256 fast path: 16 x 16 four-step FFT with the 16-point transforms held in registers.
+// forward radix-4 butterfly on (a, b, c, d) -> outputs 0..3
+__device__ __forceinline__ void bfly4(float2 &a, float2 &b, float2 &c, float2 &d) {
+    const float2 t0 = cadd(a, c), t1 = csub(a, c), t2 = cadd(b, d), e = csub(b, d);
+    const float2 t3 = make_float2(e.y, -e.x);                    // -i (b - d)
+    a = cadd(t0, t2); c = csub(t0, t2); b = cadd(t1, t3); d = csub(t1, t3);
+}
+// in-place forward 16-point DFT: x[n] -> X[k] (natural order in and out)
+__device__ __forceinline__ void dft16(float2 (&x)[16]) {
+    // step 1: over n2 for each n1 (n = n1 + 4 n2): results Y[n1][k2] land in x[n1 + 4 k2]
+#pragma unroll
+    for (int n1 = 0; n1 < 4; n1++) bfly4(x[n1], x[n1 + 4], x[n1 + 8], x[n1 + 12]);
+    // step 2: twiddles W16^(n1 k2) = (cos, -sin)(2 pi n1 k2 / 16)
+    constexpr float C1 = 0.9238795325112867f, S1 = 0.3826834323650898f, C2 = 0.7071067811865476f;
+    x[1 + 4] = cmul(x[1 + 4], make_float2(C1, -S1));             // n1 = 1, k2 = 1 : m = 1
+    x[1 + 8] = cmul(x[1 + 8], make_float2(C2, -C2));             // m = 2
+    x[1 + 12] = cmul(x[1 + 12], make_float2(S1, -C1));           // m = 3
+    x[2 + 4] = cmul(x[2 + 4], make_float2(C2, -C2));             // n1 = 2: m = 2
+    x[2 + 8] = make_float2(x[2 + 8].y, -x[2 + 8].x);             // m = 4 : -i
+    x[2 + 12] = cmul(x[2 + 12], make_float2(-C2, -C2));          // m = 6
+    x[3 + 4] = cmul(x[3 + 4], make_float2(S1, -C1));             // n1 = 3: m = 3
+    x[3 + 8] = cmul(x[3 + 8], make_float2(-C2, -C2));            // m = 6
+    x[3 + 12] = cmul(x[3 + 12], make_float2(-C1, S1));           // m = 9
+    // step 3: over n1 for each k2: X[4 k1 + k2] from (Y[0][k2], Y[1][k2], Y[2][k2], Y[3][k2]) = x[4 k2 + 0..3]
+#pragma unroll
+    for (int k2 = 0; k2 < 4; k2++) bfly4(x[4 * k2], x[4 * k2 + 1], x[4 * k2 + 2], x[4 * k2 + 3]);
+    // now x[4 k2 + k1] = X[4 k1 + k2]: transpose the 4 x 4 index
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = i + 1; j < 4; j++) { const float2 t = x[4 * i + j]; x[4 * i + j] = x[4 * j + i]; x[4 * j + i] = t; }
+}
+
+// Forward FFT of `nlines` lines of 256 samples held in LDS in NATURAL order (line stride >= 272: the intermediate uses a
+// padded [16][17] layout against bank conflicts); output in natural order.  16 threads per line.  All threads must call.
+__device__ inline void lds_fft256(float2 *buf, int nlines, int lstride, int tid, int nthr, const float2 *tw) {
+    const int work = nlines * 16;
+    lds_barrier();
+    for (int base = 0; base < work; base += nthr) {              // pass 1: over n2 for each n1, times W256^(n1 k2)
+        const int w = base + tid, line = w >> 4, n1 = w & 15;
+        float2 x[16];
+        float2 *row = buf + line * lstride;
+        if (w < work) {
+#pragma unroll
+            for (int n2 = 0; n2 < 16; n2++) x[n2] = row[n1 + 16 * n2];
+        }
+        lds_barrier();
+        if (w < work) {
+            dft16(x);
+#pragma unroll
+            for (int k2 = 0; k2 < 16; k2++) {
+                float2 v = x[k2];
+                if (k2 > 0) { float2 t = tw[n1 * k2]; t.y = -t.y; v = cmul(v, t); }
+                row[k2 * 17 + n1] = v;
+            }
+        }
+    }
+    lds_barrier();
+    for (int base = 0; base < work; base += nthr) {              // pass 2: over n1 for each k2 -> X[16 k1 + k2]
+        const int w = base + tid, line = w >> 4, k2 = w & 15;
+        float2 y[16];
+        float2 *row = buf + line * lstride;
+        if (w < work) {
+#pragma unroll
+            for (int n1 = 0; n1 < 16; n1++) y[n1] = row[k2 * 17 + n1];
+        }
+        lds_barrier();
+        if (w < work) {
+            dft16(y);
+#pragma unroll
+            for (int k1 = 0; k1 < 16; k1++) row[16 * k1 + k2] = y[k1];
+        }
+    }
+    lds_barrier();
 }
 
 // Trilinear sample of the band-limited reference cube at Fourier coordinate (X,Y,Z).

@@ -80,8 +80,11 @@ struct PrepP {
     int normalize, invert, do_mask, whiten;
     int nc, nchunks, L;
     float2 *band;  // [n][H*W] unscaled band spectrum (scratch; the final result for insertion)
+    int TS, WS;    // line strides of the column buffer T and of the row work buffer Wk (>= 272 on the 256 fast path)
+    int fast256;   // N == 256: register-level 16 x 16 FFT (lds_fft256), natural-order staging
+    long long *dbg; // timing experiments only (PPM_PREP_DBG): s_memtime stamps of block 100's phases
     int stop;      // timing experiments only (PPM_PREP_STOP): leave the kernel after phase `stop`
-    float2 *spill; // [n][N][W-nc] row-transformed columns beyond the first LDS chunk (only if nchunks > 1)
+    float2 *spill; // [n][N][W] row-transformed half spectrum (global scratch between the row and the column phase)
     float *wring;  // [n][B+2] ring weights 1/sqrt(mean power), may be null
     // ring-ordered list outputs (may be null)
     const uint32_t *samples; int S_pad; float2 *Il; float *cw;
@@ -89,19 +92,24 @@ struct PrepP {
     float2 *Wp; float *C2; float *nI; int Bs, Hs; float r_s2, r_lo2;
 };
 
-constexpr int kPrepThreads = 1024;   // one block per CU (LDS-bound): 16 waves hide the LDS / barrier latency of the FFT stages
-
-__global__ void __launch_bounds__(kPrepThreads) k_prep(PrepP P) {
-    constexpr int PT = kPrepThreads, PW = PT / 64;
+// PT = 512 threads and <= 80 KB of LDS: two blocks per CU, so that one block's global-memory waits (image reads, the
+// spilled half spectrum) overlap the other's FFT work; PT = 1024 / 160 KB is kept for comparison (PPM_PREP_PT).
+template <int PT>
+__global__ void __launch_bounds__(PT) k_prep(PrepP P) {
+    constexpr int PW = PT / 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, N = P.N, B = P.B, W = P.W, H = P.H;
     const int p = blockIdx.x;
-    const int TS = N + 1;                             // padded line stride of T (bank spread)
-    float2 *T = (float2 *)smem;                       // [nc][N+1]
-    float2 *Wk = T + (size_t)P.nc * TS;               // [L][N]
+    int dbg_n = 0;
+    auto stamp = [&]() { if (P.dbg && p == 100 && tid == 0 && dbg_n < 60) P.dbg[dbg_n++] = (long long)__builtin_readcyclecounter(); };
+    stamp();
+    const int TS = P.TS, WS = P.WS;                   // padded line strides (bank spread)
+    float2 *T = (float2 *)smem;                       // [nc][TS] column chunk, followed by
+    float2 *Wk = T + (size_t)P.nc * TS;               // [L][WS]  the row work buffer
     // ring power sums in 64-bit fixed point and integer counts: a ds_add_f32 costs ~190 LDS cycles per wave-instruction on
     // gfx950, ds_add_u64 / ds_add_u32 ~8 / ~5 (scripts/micro/lds_atomic_bench.hip)
-    unsigned long long *ringq = (unsigned long long *)(Wk + (size_t)P.L * N);  // [B+2]
+    const size_t regionA = (size_t)P.nc * TS + (size_t)P.L * WS;
+    unsigned long long *ringq = (unsigned long long *)(T + regionA);  // [B+2]
     unsigned *ringc = (unsigned *)(ringq + (B + 2));  // [B+2]
     float *ringpw = (float *)(ringc + (B + 2));       // [B+2] ring weights
     double *red = (double *)(((uintptr_t)(ringpw + (B + 2)) + 15) & ~(uintptr_t)15);  // [PW*4 + PW]
@@ -109,7 +117,11 @@ __global__ void __launch_bounds__(kPrepThreads) k_prep(PrepP P) {
     float2 *tw_s = (float2 *)(stat + 4 + PW);         // [N] twiddles and [N] staging positions of the FFT plan, kept in LDS
     unsigned short *perm_s = (unsigned short *)(tw_s + N);
     unsigned short *iperm_s = perm_s + N;             // inverse: the sample that is staged at LDS position d
-    for (int i = tid; i < N; i += PT) { tw_s[i] = P.plan.tw[i]; const unsigned short q = P.plan.perm[i]; perm_s[i] = q; iperm_s[q] = (unsigned short)i; }
+    for (int i = tid; i < N; i += PT) {
+        tw_s[i] = P.plan.tw[i];
+        const unsigned short q = P.fast256 ? (unsigned short)i : P.plan.perm[i];
+        perm_s[i] = q; iperm_s[q] = (unsigned short)i;
+    }
     __syncthreads();
     const float *img = P.images + (size_t)p * N * N;
 
@@ -162,89 +174,144 @@ __global__ void __launch_bounds__(kPrepThreads) k_prep(PrepP P) {
         __syncthreads();
     }
     const float mu = stat[0], sc = stat[1];
+    stamp();
     if (P.stop == 1) return;
     const float qscale = stat[2];
     for (int i = tid; i < B + 2; i += PT) { ringq[i] = 0ull; ringc[i] = 0u; }
 
     const float wf = P.wfall < 1e-3f ? 1e-3f : P.wfall;
     float2 *bandp = P.band + (size_t)p * H * W;
-    for (int ch = 0; ch < P.nchunks; ch++) {
-        const int c0 = ch * P.nc, ncol = (W - c0) < P.nc ? (W - c0) : P.nc;
-        // ---- row pass: two real rows per complex transform.  Done ONCE: the columns that do not fit the LDS chunk are
-        // spilled to global memory (row-major, coalesced) and read back for the later chunks.
-        if (ch == 0) {
-            const int nsp = W - P.nc;
-            float2 *sp = nsp > 0 ? P.spill + (size_t)p * N * nsp : nullptr;
-            // the pixels of the NEXT pass are fetched into registers while this pass runs its FFT (host: L N <= 8 PT)
+    float2 *sp = P.spill + (size_t)p * N * W;         // [N][W] half spectrum after the row pass (global scratch, L2-resident)
+    // ---- row pass: two real rows per complex transform; every row of the half spectrum goes to the scratch
+    {
+        {
+            // the pixels of the NEXT pass are fetched into registers while this pass runs its FFT (host: L N <= 8 PT).
+            // N % 4 == 0: 16-byte loads of 4 consecutive pixels of both rows, staged at their plan positions; otherwise
+            // 4-byte loads gathered so that consecutive lanes write consecutive LDS positions.
             constexpr int MAXI = 8;
             float2 pre[MAXI];
-            const float invNf = 1.0f / (float)N;
+            float4 pa[MAXI / 4], pb[MAXI / 4];
+            const float invNf = 1.0f / (float)N, invN4 = 4.0f / (float)N;
+            const bool wide = (N & 3) == 0;
+            auto mask_at = [&](int x, int y) {
+                const float dx = (float)(x - N / 2), dy = (float)(y - N / 2);
+                const float r = sqrtf(dx * dx + dy * dy);
+                return r >= P.Rm + 0.5f * wf ? 0.f : (r > P.Rm - 0.5f * wf ? 0.5f * (1.f + cosf(kPiF * (r - P.Rm + 0.5f * wf) / wf)) : 1.f);
+            };
             auto fetch = [&](int y0) {
+                if (wide) {
 #pragma unroll
-                for (int k = 0; k < MAXI; k++) {
-                    const int i = tid + k * PT;
-                    if (i < P.L * N) {       // lane -> consecutive LDS positions d (no bank conflicts); the gather is on the global side
-                        const int l = fast_div(i, N, invNf), d = i - l * N, x = iperm_s[d], ya = y0 + 2 * l;
-                        pre[k] = make_float2(img[ya * N + x], img[(ya + 1) * N + x]);
+                    for (int k = 0; k < MAXI / 4; k++) {
+                        const int i4 = tid + k * PT;
+                        if (i4 < P.L * N / 4) {
+                            const int l = fast_div(i4, N / 4, invN4), x = 4 * (i4 - l * (N / 4)), ya = y0 + 2 * l;
+                            pa[k] = *(const float4 *)(img + ya * N + x); pb[k] = *(const float4 *)(img + (ya + 1) * N + x);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < MAXI; k++) {
+                        const int i = tid + k * PT;
+                        if (i < P.L * N) {
+                            const int l = fast_div(i, N, invNf), d = i - l * N, x = iperm_s[d], ya = y0 + 2 * l;
+                            pre[k] = make_float2(img[ya * N + x], img[(ya + 1) * N + x]);
+                        }
                     }
                 }
             };
             fetch(0);
             for (int y0 = 0; y0 < N; y0 += 2 * P.L) {
-                __syncthreads();
+                lds_barrier();
+                stamp();
+                if (wide) {
 #pragma unroll
-                for (int k = 0; k < MAXI; k++) {
-                    const int i = tid + k * PT;
-                    if (i < P.L * N) {
-                        const int l = fast_div(i, N, invNf), d = i - l * N, x = iperm_s[d];
-                        const int ya = y0 + 2 * l, yb = ya + 1;
-                        float va = (pre[k].x - mu) * sc, vb = (pre[k].y - mu) * sc;
-                        if (P.do_mask) {
-                            float dx = (float)(x - N / 2);
-                            float ra = sqrtf(dx * dx + (float)((ya - N / 2) * (ya - N / 2)));
-                            float rb = sqrtf(dx * dx + (float)((yb - N / 2) * (yb - N / 2)));
-                            float ma = ra >= P.Rm + 0.5f * wf ? 0.f : (ra > P.Rm - 0.5f * wf ? 0.5f * (1.f + cosf(kPiF * (ra - P.Rm + 0.5f * wf) / wf)) : 1.f);
-                            float mb = rb >= P.Rm + 0.5f * wf ? 0.f : (rb > P.Rm - 0.5f * wf ? 0.5f * (1.f + cosf(kPiF * (rb - P.Rm + 0.5f * wf) / wf)) : 1.f);
-                            va *= ma; vb *= mb;
+                    for (int k = 0; k < MAXI / 4; k++) {
+                        const int i4 = tid + k * PT;
+                        if (i4 < P.L * N / 4) {
+                            const int l = fast_div(i4, N / 4, invN4), x = 4 * (i4 - l * (N / 4));
+                            const int ya = y0 + 2 * l, yb = ya + 1;
+                            const float ra[4] = { pa[k].x, pa[k].y, pa[k].z, pa[k].w }, rb[4] = { pb[k].x, pb[k].y, pb[k].z, pb[k].w };
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                float va = (ra[j] - mu) * sc, vb = (rb[j] - mu) * sc;
+                                if (P.do_mask) { va *= mask_at(x + j, ya); vb *= mask_at(x + j, yb); }
+                                Wk[l * WS + perm_s[x + j]] = make_float2(va, vb);
+                            }
                         }
-                        Wk[l * N + d] = make_float2(va, vb);
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < MAXI; k++) {
+                        const int i = tid + k * PT;
+                        if (i < P.L * N) {
+                            const int l = fast_div(i, N, invNf), d = i - l * N, x = iperm_s[d];
+                            const int ya = y0 + 2 * l, yb = ya + 1;
+                            float va = (pre[k].x - mu) * sc, vb = (pre[k].y - mu) * sc;
+                            if (P.do_mask) { va *= mask_at(x, ya); vb *= mask_at(x, yb); }
+                            Wk[l * WS + d] = make_float2(va, vb);
+                        }
                     }
                 }
                 if (y0 + 2 * P.L < N) fetch(y0 + 2 * P.L);
-                lds_fft(Wk, P.plan, P.L, N, false, tid, PT, tw_s);
+                stamp();
+                if (P.fast256) lds_fft256(Wk, P.L, WS, tid, PT, tw_s);
+                else lds_fft(Wk, P.plan, P.L, WS, false, tid, PT, tw_s);
+                stamp();
+                const float invW = 1.0f / (float)W;
                 for (int i = tid; i < P.L * W; i += PT) {
-                    int l = i / W, kx = i - l * W;
-                    float2 z = Wk[l * N + kx], zc = Wk[l * N + (kx ? N - kx : 0)];
+                    const int l = fast_div(i, W, invW), kx = i - l * W;
+                    float2 z = Wk[l * WS + kx], zc = Wk[l * WS + (kx ? N - kx : 0)];
                     float2 xa = make_float2(0.5f * (z.x + zc.x), 0.5f * (z.y - zc.y));
                     float2 d = make_float2(z.x - zc.x, z.y + zc.y);
                     float2 xb = make_float2(0.5f * d.y, -0.5f * d.x);
-                    int ya = y0 + 2 * l;
-                    if (kx < P.nc) {
-                        T[kx * TS + perm_s[ya]] = xa;
-                        T[kx * TS + perm_s[ya + 1]] = xb;
-                    } else {
-                        sp[(size_t)ya * nsp + (kx - P.nc)] = xa;
-                        sp[(size_t)(ya + 1) * nsp + (kx - P.nc)] = xb;
-                    }
+                    const int ya = y0 + 2 * l;
+                    sp[(size_t)ya * W + kx] = xa;
+                    sp[(size_t)(ya + 1) * W + kx] = xb;
                 }
             }
-        } else {
-            const int nsp = W - P.nc;
-            const float2 *sp = P.spill + (size_t)p * N * nsp;
-            __threadfence_block();
-            __syncthreads();
-            for (int i = tid; i < N * ncol; i += PT) {
-                int y = i / ncol, c = i - y * ncol;
-                T[c * TS + perm_s[y]] = sp[(size_t)y * nsp + (c0 - P.nc + c)];
+        }
+    }
+    __threadfence_block();
+    __syncthreads();                                  // the scratch rows written above are read by other threads below
+    // the NEXT chunk's columns are fetched into registers while this chunk is transformed (host: N nc <= MAXC threads)
+    constexpr int MAXC = 12;
+    float2 nx[MAXC];
+    auto fetch_chunk = [&](int ch) {
+        const int c0 = ch * P.nc, ncol = (W - c0) < P.nc ? (W - c0) : P.nc;
+        const float inv_ncol = 1.0f / (float)ncol;
+#pragma unroll
+        for (int k = 0; k < MAXC; k++) {
+            const int i = tid + k * PT;
+            if (i < N * ncol) {
+                const int y = fast_div(i, ncol, inv_ncol), c = i - y * ncol;
+                nx[k] = sp[(size_t)y * W + c0 + c];
             }
         }
+    };
+    fetch_chunk(0);
+    for (int ch = 0; ch < P.nchunks; ch++) {
+        const int c0 = ch * P.nc, ncol = (W - c0) < P.nc ? (W - c0) : P.nc;
+        const float inv_ncol = 1.0f / (float)ncol;
+        lds_barrier();
+#pragma unroll
+        for (int k = 0; k < MAXC; k++) {                 // this chunk's columns, staged at their plan positions
+            const int i = tid + k * PT;
+            if (i < N * ncol) {
+                const int y = fast_div(i, ncol, inv_ncol), c = i - y * ncol;
+                T[c * TS + perm_s[y]] = nx[k];
+            }
+        }
+        if (ch + 1 < P.nchunks) fetch_chunk(ch + 1);
+        stamp();
         if (P.stop == 2) return;
         // ---- column pass
-        lds_fft(T, P.plan, ncol, TS, false, tid, PT, tw_s);
+        if (P.fast256) lds_fft256(T, ncol, TS, tid, PT, tw_s);
+        else lds_fft(T, P.plan, ncol, TS, false, tid, PT, tw_s);
         const float invN = 1.f / (float)N;
+        stamp();
         if (P.stop == 3) return;
         for (int i = tid; i < ncol * H; i += PT) {
-            int c = i % ncol, row = i / ncol, ky = row - B, kx = c0 + c;
+            const int row = fast_div(i, ncol, inv_ncol), c = i - row * ncol, ky = row - B, kx = c0 + c;
             float k2 = (float)(kx * kx + ky * ky);
             float2 o = make_float2(0.f, 0.f);
             if (k2 < P.r_hi2 && k2 > 0.f) {
@@ -259,6 +326,7 @@ __global__ void __launch_bounds__(kPrepThreads) k_prep(PrepP P) {
             bandp[row * W + kx] = o;
         }
     }
+    stamp();
     if (P.stop == 4) return;
     __threadfence_block();
     __syncthreads();
@@ -313,6 +381,8 @@ __global__ void __launch_bounds__(kPrepThreads) k_prep(PrepP P) {
         __syncthreads();
         if (tid == 0) { float t = 0.f; for (int w = 0; w < PW; w++) t += stat[3 + w]; P.nI[p] = t; }
     }
+    stamp();
+    if (P.dbg && p == 100 && tid == 0) P.dbg[63] = dbg_n;
 }
 
 // ---------------------------------------------------------------------------------- slice bank

@@ -127,7 +127,7 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
-DevBuf<float2> g_prep_spill;     // k_prep: row-transformed columns that do not fit the first LDS chunk
+DevBuf<float2> g_prep_spill;     // k_prep: the half spectrum between the row and the column phase, [n][N][W]
 
 }  // namespace
 
@@ -187,10 +187,10 @@ static int build_brick_items(ppm_accum *a, const Geom &gm, int BE, int nb) {
         }
         a->load_r = r; a->items_cap = -1;
     }
-    static const int smax_env = getenv("PPM_BRICK_SLICES") ? atoi(getenv("PPM_BRICK_SLICES")) : 16;
-    static const int minp_env = getenv("PPM_BRICK_MINP") ? atoi(getenv("PPM_BRICK_MINP")) : 512;
+    const int smax_env = getenv("PPM_BRICK_SLICES") ? atoi(getenv("PPM_BRICK_SLICES")) : 16;
+    const int minp_env = getenv("PPM_BRICK_MINP") ? atoi(getenv("PPM_BRICK_MINP")) : 512;
     const int cap = std::max(1, std::min(smax_env, nb / std::max(1, minp_env)));
-    if (cap == a->items_cap) return 0;
+    if (cap * 1000 + smax_env == a->items_cap) return 0;
     struct Tmp { BrickItem it; float load; };
     std::vector<Tmp> v;
     for (int bz = 0; bz < nby; bz++) for (int by = 0; by < nby; by++) for (int bx = 0; bx < nbx; bx++) {
@@ -208,7 +208,7 @@ static int build_brick_items(ppm_accum *a, const Geom &gm, int BE, int nb) {
     if (int rc = a->items.ensure(items.size())) return rc;
     HIPCHK(hipMemcpyAsync(a->items.p, items.data(), items.size() * sizeof(BrickItem), hipMemcpyHostToDevice, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
-    a->n_items = (int)items.size(); a->items_cap = cap;
+    a->n_items = (int)items.size(); a->items_cap = cap * 1000 + smax_env;
     return 0;
 }
 
@@ -222,34 +222,54 @@ static int launch_prep(const float *d_images, const double *d_rows, int n_img, c
     P.N = gm.N; P.B = gm.B; P.W = gm.W; P.H = gm.H;
     P.r_hi2 = (float)(gm.r_hi * gm.r_hi); P.Rm = Rm_px; P.wfall = fall_px; P.a = (float)gm.a;
     P.normalize = normalize; P.invert = invert; P.do_mask = do_mask; P.whiten = whiten;
-    // LDS plan: L row pairs per row pass (L N <= 8 x 1024 threads: the next pass is prefetched into <= 8 registers pairs per
-    // thread; L divides N/2), the rest of the 160 KB holds nc columns of the half spectrum; further columns are spilled.
-    const size_t lds_fixed = (size_t)(gm.B + 2) * 16 + 16 + 5 * (kPrepThreads / 64) * sizeof(double) + (4 + kPrepThreads / 64) * sizeof(float) + (size_t)gm.N * 12 + 16;
-    P.L = std::max(1, std::min(8 * kPrepThreads / gm.N, gm.N / 2));
-    if (getenv("PPM_PREP_L")) P.L = std::max(1, std::min(atoi(getenv("PPM_PREP_L")), 8 * kPrepThreads / gm.N));
-    while ((gm.N / 2) % P.L) P.L--;          // the row pass walks the image 2 L rows at a time
+    // LDS plan: L row pairs per row pass (L N <= 8 x threads: the next pass is prefetched into <= 8 register pairs per
+    // thread; L divides N/2) share their storage with the nc columns of one column chunk; the whole half spectrum goes
+    // through a global scratch between the two phases.  512 threads / 80 KB -> two blocks per CU.
+    const int PT = (getenv("PPM_PREP_PT") && atoi(getenv("PPM_PREP_PT")) == 1024) ? 1024 : 512;
+    const size_t budget = (PT == 1024 ? 160 : 80) * 1024;
+    const size_t lds_fixed = (size_t)(gm.B + 2) * 16 + 16 + 5 * (PT / 64) * sizeof(double) + (4 + PT / 64) * sizeof(float) + (size_t)gm.N * 12 + 16;
+    P.fast256 = (gm.N == 256 && !getenv("PPM_PREP_GENERIC")) ? 1 : 0;
+    P.TS = P.fast256 ? 273 : gm.N + 1; P.WS = P.fast256 ? 272 : gm.N;
+    P.L = std::max(1, std::min(8 * PT / gm.N, gm.N / 2));
+    if (getenv("PPM_PREP_L")) P.L = std::max(1, std::min(atoi(getenv("PPM_PREP_L")), 8 * PT / gm.N));
+    while ((gm.N / 2) % P.L || (size_t)P.L * P.WS * sizeof(float2) + lds_fixed + P.TS * sizeof(float2) > budget / 2 + 8192) P.L--;     // the row pass walks the image 2 L rows at a time; leave about half of the LDS to the column chunk
+    if (P.L < 1) return fail(-12, "pre-processing kernel: row buffer does not fit the LDS");
+    P.stop = getenv("PPM_PREP_STOP") ? atoi(getenv("PPM_PREP_STOP")) : 0;
     {
-        const size_t left = 160 * 1024 - lds_fixed - (size_t)P.L * gm.N * sizeof(float2);
-        P.nc = std::max(1, std::min(gm.W, (int)(left / ((gm.N + 1) * sizeof(float2)))));
+        const size_t wk = (size_t)P.L * P.WS * sizeof(float2);
+        const size_t left = budget - lds_fixed > wk ? budget - lds_fixed - wk : 0;
+        P.nc = std::max(1, std::min(gm.W, (int)(left / (P.TS * sizeof(float2)))));
+        P.nc = std::max(1, std::min(P.nc, 12 * PT / gm.N));        // k_prep prefetches one chunk into 12 registers pairs per thread
     }
     P.nchunks = (gm.W + P.nc - 1) / P.nc;
     P.nc = (gm.W + P.nchunks - 1) / P.nchunks;       // even chunks
-    if (getenv("PPM_PREP_NCH")) { P.nchunks = atoi(getenv("PPM_PREP_NCH")); P.nc = (gm.W + P.nchunks - 1) / P.nchunks; P.nchunks = (gm.W + P.nc - 1) / P.nc; }
+    if (getenv("PPM_PREP_NCH")) { P.nchunks = std::max(P.nchunks, atoi(getenv("PPM_PREP_NCH"))); P.nc = (gm.W + P.nchunks - 1) / P.nchunks; P.nchunks = (gm.W + P.nc - 1) / P.nc; }
     P.stop = getenv("PPM_PREP_STOP") ? atoi(getenv("PPM_PREP_STOP")) : 0;
-    P.spill = nullptr;
-    if (P.nchunks > 1) {
-        if (int rc = g_prep_spill.ensure((size_t)n_img * gm.N * (gm.W - P.nc))) return rc;
-        P.spill = g_prep_spill.p;
-    }
+    static long long *d_dbg = nullptr;
+    P.dbg = nullptr;
+    if (getenv("PPM_PREP_DBG") && n_img > 100) { if (!d_dbg) HIPCHK(hipMalloc(&d_dbg, 64 * sizeof(long long))); HIPCHK(hipMemsetAsync(d_dbg, 0, 64 * 8, g.stream)); P.dbg = d_dbg; }
+    if (int rc = g_prep_spill.ensure((size_t)n_img * gm.N * gm.W)) return rc;
+    P.spill = g_prep_spill.p;
     P.band = band; P.wring = wring; P.samples = samples; P.S_pad = S_pad; P.Il = Il; P.cw = cw;
     P.Wp = Wp; P.C2 = C2; P.nI = nI; P.Bs = gm.Bs; P.Hs = gm.Hs;
     P.r_s2 = (float)(gm.r_s * gm.r_s); P.r_lo2 = (float)(gm.r_lo * gm.r_lo);
-    size_t lds = (size_t)P.nc * (gm.N + 1) * sizeof(float2) + (size_t)P.L * gm.N * sizeof(float2) + lds_fixed;
-    if (lds > 160 * 1024) return fail(-12, "pre-processing kernel needs more than 160 KB of LDS");
+    size_t lds = ((size_t)P.nc * P.TS + (size_t)P.L * P.WS) * sizeof(float2) + lds_fixed;
+    if (lds > budget) return fail(-12, "pre-processing kernel: LDS plan exceeds its budget");
     static bool attr_set = false;
-    if (!attr_set) { HIPCHK(hipFuncSetAttribute((const void *)k_prep, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute((const void *)k_prep<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *)k_prep<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
     ProfScope ps(PPM_K_PREP);
-    hipLaunchKernelGGL(k_prep, dim3(n_img), dim3(kPrepThreads), lds, g.stream, P);
+    if (PT == 512) hipLaunchKernelGGL(k_prep<512>, dim3(n_img), dim3(512), lds, g.stream, P);
+    else hipLaunchKernelGGL(k_prep<1024>, dim3(n_img), dim3(1024), lds, g.stream, P);
+    if (P.dbg) {
+        long long h[64]; HIPCHK(hipStreamSynchronize(g.stream)); HIPCHK(hipMemcpy(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost));
+        fprintf(stderr, "k_prep phases (cycles, block 100, nc=%d nchunks=%d L=%d):", P.nc, P.nchunks, P.L);
+        for (int i = 1; i < (int)h[63] && i < 60; i++) fprintf(stderr, " %lld", h[i] - h[i - 1]);
+        fprintf(stderr, "\n");
+    }
     HIPCHK(hipGetLastError());
     return 0;
 }

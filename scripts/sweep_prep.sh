@@ -1,2 +1,3 @@
-for st in 1 2 3 4 0; do echo "== reconstruct stop=$st"; PPM_PREP_STOP=$st timeout -k 10 150 python bench.py --workload reconstruct --particles 50000 --steps 1 --warmup 1 2>&1 | grep -o "\"prep\": [0-9.]*\|ERROR.*" | cut -c1-60; done
-for st in 1 2 3 4 0; do echo "== refine stop=$st"; PPM_PREP_STOP=$st timeout -k 10 200 python bench.py --particles 20000 --steps 1 --warmup 1 --no-cpu 2>&1 | grep -o "\"prep\": [0-9.]*\|ERROR.*" | cut -c1-60; done
+timeout -k 10 600 python -m pytest tests -q -m gpu > gpurun_out/t_all.log 2>&1; tail -3 gpurun_out/t_all.log
+bash scripts/quick_bench.sh
+echo "== PT=1024"; PPM_PREP_PT=1024 bash scripts/quick_bench.sh

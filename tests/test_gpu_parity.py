@@ -229,6 +229,28 @@ def test_insertion_non_power_of_two_box(H, O):
         assert np.linalg.norm(a - b) / np.linalg.norm(a) < 1e-4
 
 
+@pytest.mark.parametrize("n,px,m,sym,minp", [(256, 1.0, 24, "C1", "4"), (160, 1.5, 12, "C2", None), (128, 2.0, 600, "C1", "64")])
+def test_insertion_large_boxes_bricks_and_slices(H, O, monkeypatch, n, px, m, sym, minp):
+    """Boxes >= 128 use 16^3-voxel bricks, 1024-thread blocks and (with more particles than PPM_BRICK_MINP per slice)
+    several particle slices per brick whose partial bricks are summed in global memory; 256 also takes the 16 x 16
+    register FFT of the pre-processing kernel."""
+    if minp:
+        monkeypatch.setenv("PPM_BRICK_MINP", minp)
+    vol, imgs, rows = dataset(n, min(m, 24), px, 0.2)
+    if m > imgs.shape[0]:                                               # many cheap particles: repeat with shifted halves
+        rep = (m + imgs.shape[0] - 1) // imgs.shape[0]
+        imgs = np.concatenate([imgs] * rep)[:m]; rows = np.concatenate([rows] * rep)[:m].copy()
+        rows[:, 0] = np.arange(1, m + 1); rows[:, 26] = np.arange(m)
+    rc = ReconCfg(box=n, pixel_size=px, res_limit=2 * px, normalize=1, split_by_pind=0, mask_radius=0.4 * n * px)
+    acc = np.zeros(O.accum_floats(n), dtype=np.float32)
+    counts = np.zeros(2, dtype=np.int64)
+    O.insert_batch(acc, counts, rc, sym, imgs, rows)
+    ga = H.Accumulator(n, px, sym)
+    ga.insert(rc, imgs, rows)
+    assert ga.counts() == list(counts)
+    assert np.linalg.norm(ga.download() - acc) / np.linalg.norm(acc) < 1e-4
+
+
 def test_external_accumulator_tensor_and_reduce(H, O):
     """The accumulator can live in a caller-allocated torch tensor (what RCCL reduces in place)."""
     import torch
