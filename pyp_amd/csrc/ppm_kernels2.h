@@ -481,9 +481,10 @@ __global__ void k_insert_params(const double *rows, PartIns *pp, CullEnt *cull, 
 // grid: (items, 2 halves), NW waves.  Per round of up to CULL_CAP (particle, operator) entries of the item's slice:
 //   CULL  every thread tests entries (slice-plane normal vs the brick's expanded box) and the cutting ones are collected in
 //         a block-wide LDS list;
-//   WORK  waves pull cuts from that list (dynamic balance); for one cut, 8x8 tiles of the candidate rectangle in the slice
-//         are TESTED (position only), the hits compacted into a per-wave LDS queue, and full groups of 64 hits EVALUATED
-//         (CTF, weights, phase, 8 taps).
+//   WORK  waves pull cuts from that list (dynamic balance); for one cut, lane = slice row: the kx interval that can reach
+//         the brick is solved per row (three slabs + the band), the candidates of all rows are dealt out densely over the
+//         lanes (prefix sum + search), TESTED exactly (position only), the hits compacted into a per-wave LDS queue, and
+//         full groups of 64 hits EVALUATED (CTF, weights, phase, 8 taps).
 // The brick is accumulated in 64-bit FIXED POINT: on gfx950 a ds_add_f32 wave-instruction occupies the LDS for ~190
 // cycles (lanes are serialised), a ds_add_u64 for ~8 (scripts/micro/lds_atomic_bench.hip).  Every tap is rounded to a
 // 31-bit integer relative to the largest possible value of the chunk (max |band| x max weight, found on the device
@@ -491,7 +492,9 @@ __global__ void k_insert_params(const double *rows, PartIns *pp, CullEnt *cull, 
 constexpr int CULL_CAP = 4096;
 template <int BE, int NW>
 __global__ void __launch_bounds__(NW * 64) k_insert_bricks(InsertBrickP P) {
-    extern __shared__ long long brick[];           // [BE][BE][BE][3]
+    extern __shared__ long long brick[];           // [BE][BE][BE][3] with padded row / plane strides SY, SZ (in 8-byte cells):
+    constexpr int SY = BE * 3 + 1, SZ = BE * SY + 3;   // odd strides spread the 8 taps of neighbouring samples over the banks
+                                                       // (unpadded, 3/4 of the LDS atomic cycles were bank conflicts)
     __shared__ unsigned queue_s[NW][128];
     __shared__ int cut_list[CULL_CAP];
     __shared__ int n_cut, cut_head;
@@ -511,7 +514,7 @@ __global__ void __launch_bounds__(NW * 64) k_insert_bricks(InsertBrickP P) {
     // voxel COORDINATES covered by this brick: x in [x_lo, x_lo+BE), y, z likewise (stored index = coordinate + N/2)
     const int x_lo = it.bx * BE, y_lo = it.by * BE - N / 2, z_lo = it.bz * BE - N / 2;
     const int p_lo = (int)((long)P.n_img * it.s / it.S), p_hi = (int)((long)P.n_img * (it.s + 1) / it.S);
-    for (int i = tid; i < BE * BE * BE * 3; i += NW * 64) brick[i] = 0ll;
+    for (int i = tid; i < BE * SZ; i += NW * 64) brick[i] = 0ll;
     __syncthreads();
     // sample positions Q whose floor() lies in [lo-1, lo+BE-1] touch the brick:  lo-1 <= Q < lo+BE
     const float cx = x_lo - 1 + 0.5f * (BE + 1), cy = y_lo - 1 + 0.5f * (BE + 1), cz = z_lo - 1 + 0.5f * (BE + 1), hh = 0.5f * (BE + 1);
@@ -581,7 +584,7 @@ __global__ void __launch_bounds__(NW * 64) k_insert_bricks(InsertBrickP P) {
                         const int xi = x0 + dx, yi = y0 + dy, zi = z0 + dz;
                         if ((unsigned)xi >= (unsigned)BE || (unsigned)yi >= (unsigned)BE || (unsigned)zi >= (unsigned)BE) continue;
                         const float wt = (dx ? fx : 1.f - fx) * (dy ? fy : 1.f - fy) * (dz ? fz : 1.f - fz);
-                        unsigned long long *v = (unsigned long long *)brick + ((zi * BE + yi) * BE + xi) * 3;
+                        unsigned long long *v = (unsigned long long *)brick + zi * SZ + yi * SY + xi * 3;
                         atomicAdd(v, (unsigned long long)(long long)__float2int_rn(wt * vr));
                         atomicAdd(v + 1, (unsigned long long)(long long)__float2int_rn(wt * vi));
                         atomicAdd(v + 2, (unsigned long long)(long long)__float2int_rn(wt * vw));
@@ -595,31 +598,62 @@ __global__ void __launch_bounds__(NW * 64) k_insert_bricks(InsertBrickP P) {
             int kx0 = (int)floorf(sgn * ka - ea) - 1, kx1 = (int)ceilf(sgn * ka + ea) + 1;
             int ky0 = (int)floorf(sgn * kb - eb) - 1, ky1 = (int)ceilf(sgn * kb + eb) + 1;
             kx0 = kx0 < 0 ? 0 : kx0; kx1 = kx1 > B ? B : kx1; ky0 = ky0 < -B ? -B : ky0; ky1 = ky1 > B ? B : ky1;
+            if (ky1 > ky0 + 63) ky1 = ky0 + 63;               // cannot happen for BE <= 16 (at most 2 sqrt(3) (BE+1)/2 + 4 rows)
             if (kx1 < kx0 || ky1 < ky0) continue;
-#pragma unroll 1
-            for (int ty = ky0; ty <= ky1; ty += 8)
-#pragma unroll 1
-                for (int tx = kx0; tx <= kx1; tx += 8) {
-                    const int kx = tx + (lane & 7), ky = ty + (lane >> 3);
-                    const float k2 = (float)(kx * kx + ky * ky);
-                    float X = a0 * kx + a1 * ky, Y = b0 * kx + b1 * ky, Z = c0 * kx + c1 * ky;
-                    const bool refl = X < 0.f;
-                    if (refl) { X = -X; Y = -Y; Z = -Z; }
-                    const int x0 = (int)floorf(X) - x_lo, y0 = (int)floorf(Y) - y_lo, z0 = (int)floorf(Z) - z_lo;
-                    const bool hit = kx <= kx1 && ky <= ky1 && k2 < P.r2 && k2 != 0.f && refl == (sgn < 0) &&
-                                     (unsigned)(x0 + 1) <= (unsigned)BE && (unsigned)(y0 + 1) <= (unsigned)BE && (unsigned)(z0 + 1) <= (unsigned)BE;
-                    const unsigned long long m = __ballot(hit);
-                    if (m == 0ull) continue;
-                    if (hit) queue[qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (unsigned)kx | ((unsigned)(ky + 512) << 16);
-                    qn += __popcll(m);
-                    __builtin_amdgcn_wave_barrier();
-                    if (qn >= 64) {
-                        qn -= 64;
-                        evaluate(queue[qn + lane], true);
-                        __builtin_amdgcn_wave_barrier();
-                    }
-                    touched = true;
+            // lane = slice row ky0 + lane: the kx interval on which s (kx A + ky B) can fall into the brick's expanded box and
+            // the band (conservative by one sample on both sides; the exact test follows)
+            const int kyr = ky0 + lane;
+            int lo = kx0, hi = kyr <= ky1 ? kx1 : kx0 - 1;
+            {
+                const float rem = P.r2 - (float)(kyr * kyr);
+                if (rem <= 0.f) hi = lo - 1; else { const int m = (int)sqrtf(rem) + 1; hi = hi < m ? hi : m; }
+                const float fs = (float)sgn, fky = fs * (float)kyr;
+                const float aa[3] = { fs * a0, fs * b0, fs * c0 }, tt[3] = { fky * a1, fky * b1, fky * c1 };
+                const float LL[3] = { (float)(x_lo - 1), (float)(y_lo - 1), (float)(z_lo - 1) };
+#pragma unroll
+                for (int ax = 0; ax < 3; ax++) {
+                    const float a = aa[ax], t = tt[ax], L = LL[ax], U = LL[ax] + (float)(BE + 1);
+                    if (fabsf(a) > 1e-3f) {
+                        const float ra = __frcp_rn(a), e0 = (L - t) * ra, e1 = (U - t) * ra;
+                        const float el = fminf(fmaxf(fminf(e0, e1), -1024.f), 1024.f), eh = fminf(fmaxf(fmaxf(e0, e1), -1024.f), 1024.f);
+                        const int l2 = (int)ceilf(el) - 1, h2 = (int)floorf(eh) + 1;
+                        lo = lo > l2 ? lo : l2; hi = hi < h2 ? hi : h2;
+                    } else if (t < L - 0.5f || t > U + 0.5f) hi = lo - 1;
                 }
+            }
+            const int cnt = hi >= lo ? hi - lo + 1 : 0;
+            int incl = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
+            const int total = __builtin_amdgcn_readlane(incl, 63);
+            const int base = lo - (incl - cnt);                   // kx of candidate j in this row = base + j
+#pragma unroll 1
+            for (int j0 = 0; j0 < total; j0 += 64) {
+                const int j = j0 + lane;
+                int r = 0;                                        // smallest row with incl[r] > j
+#pragma unroll
+                for (int st = 32; st >= 1; st >>= 1) { const int v = __shfl(incl, r + st - 1, 64); if (v <= j) r += st; }
+                r = r > 63 ? 63 : r;
+                const int kx = __shfl(base, r, 64) + j, ky = ky0 + r;
+                const float k2 = (float)(kx * kx + ky * ky);
+                float X = a0 * kx + a1 * ky, Y = b0 * kx + b1 * ky, Z = c0 * kx + c1 * ky;
+                const bool refl = X < 0.f;
+                if (refl) { X = -X; Y = -Y; Z = -Z; }
+                const int x0 = (int)floorf(X) - x_lo, y0 = (int)floorf(Y) - y_lo, z0 = (int)floorf(Z) - z_lo;
+                const bool hit = j < total && k2 < P.r2 && k2 != 0.f && refl == (sgn < 0) &&
+                                 (unsigned)(x0 + 1) <= (unsigned)BE && (unsigned)(y0 + 1) <= (unsigned)BE && (unsigned)(z0 + 1) <= (unsigned)BE;
+                const unsigned long long m = __ballot(hit);
+                if (m == 0ull) continue;
+                if (hit) queue[qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (unsigned)kx | ((unsigned)(ky + 512) << 16);
+                qn += __popcll(m);
+                __builtin_amdgcn_wave_barrier();
+                if (qn >= 64) {
+                    qn -= 64;
+                    evaluate(queue[qn + lane], true);
+                    __builtin_amdgcn_wave_barrier();
+                }
+                touched = true;
+            }
         }
         if (qn > 0) {              // the queue never crosses a (particle, operator): the rotation above is wave-uniform
             evaluate(queue[lane], lane < qn);
@@ -634,9 +668,9 @@ __global__ void __launch_bounds__(NW * 64) k_insert_bricks(InsertBrickP P) {
     const size_t NX = N / 2 + 1;
     float *A = P.acc + (size_t)h * N * N * NX * 3;
     for (int i = tid; i < BE * BE * BE * 3; i += NW * 64) {       // BE*3 consecutive floats per (y, z) row of the brick
-        const long long vq = brick[i];
-        if (vq == 0ll) continue;
         const int x3 = i % (BE * 3), yi = (i / (BE * 3)) % BE, zi = i / (BE * BE * 3);
+        const long long vq = brick[zi * SZ + yi * SY + x3];
+        if (vq == 0ll) continue;
         const int gy = y_lo + yi + N / 2, gz = z_lo + zi + N / 2;
         if (x_lo * 3 + x3 >= (int)NX * 3 || gy >= N || gz >= N) continue;
         float *o = A + (((size_t)gz * N + gy) * NX + x_lo) * 3 + x3;

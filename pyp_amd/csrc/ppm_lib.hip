@@ -631,7 +631,7 @@ ppm_accum_t *ppm_accum_create(int box, float pixel_size, const char *symmetry, v
     HIPCHKP(hipMemset(a->d_counts, 0, 2 * sizeof(unsigned long long)));
     HIPCHKP(hipMalloc(&a->d_max, 2 * sizeof(unsigned)));
     static bool attr_set = false;
-    if (!attr_set) { HIPCHKP(hipFuncSetAttribute((const void *)k_insert_bricks<16, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 16 * 16 * 3 * 8)); attr_set = true; }
+    if (!attr_set) { HIPCHKP(hipFuncSetAttribute((const void *)k_insert_bricks<16, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * (16 * 49 + 3) * 8)); attr_set = true; }
     return a;
 }
 
@@ -687,8 +687,8 @@ int ppm_insert_batch(ppm_accum_t *a, const ppm_recon_cfg *cfg, const void *image
         {
             ProfScope ps(PPM_K_INSERT);
             dim3 grid((unsigned)a->n_items, 2);
-            if (BE == 16) hipLaunchKernelGGL((k_insert_bricks<16, 16>), grid, dim3(1024), 16 * 16 * 16 * 3 * sizeof(long long), g.stream, IP);
-            else hipLaunchKernelGGL((k_insert_bricks<8, 4>), grid, dim3(256), 8 * 8 * 8 * 3 * sizeof(long long), g.stream, IP);
+            if (BE == 16) hipLaunchKernelGGL((k_insert_bricks<16, 16>), grid, dim3(1024), 16 * (16 * 49 + 3) * sizeof(long long), g.stream, IP);
+            else hipLaunchKernelGGL((k_insert_bricks<8, 4>), grid, dim3(256), 8 * (8 * 25 + 3) * sizeof(long long), g.stream, IP);
         }
         HIPCHK(hipGetLastError());
         if (!images_on_device && c0 + CH < n_img) {
