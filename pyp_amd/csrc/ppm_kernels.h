@@ -84,6 +84,7 @@ struct PrepP {
     int fast256;   // N == 256: register-level 16 x 16 FFT (lds_fft256), natural-order staging
     long long *dbg; // timing experiments only (PPM_PREP_DBG): s_memtime stamps of block 100's phases
     int stop;      // timing experiments only (PPM_PREP_STOP): leave the kernel after phase `stop`
+    unsigned *band_max; // may be null: bits of max |re|, |im| over the band images of the launch (atomicMax; floats >= 0)
     float2 *spill; // [n][N][W] row-transformed half spectrum (global scratch between the row and the column phase)
     float *wring;  // [n][B+2] ring weights 1/sqrt(mean power), may be null
     // ring-ordered list outputs (may be null)
@@ -289,6 +290,7 @@ __global__ void __launch_bounds__(PT) k_prep(PrepP P) {
         }
     };
     fetch_chunk(0);
+    float omax = 0.f;
     for (int ch = 0; ch < P.nchunks; ch++) {
         const int c0 = ch * P.nc, ncol = (W - c0) < P.nc ? (W - c0) : P.nc;
         const float inv_ncol = 1.0f / (float)ncol;
@@ -318,6 +320,7 @@ __global__ void __launch_bounds__(PT) k_prep(PrepP P) {
                 float2 v = T[c * TS + (ky < 0 ? ky + N : ky)];
                 float sg = ((kx + ky) & 1) ? -invN : invN;
                 o = make_float2(v.x * sg, v.y * sg);
+                omax = fmaxf(omax, fmaxf(fabsf(o.x), fabsf(o.y)));
                 int b = (int)floorf(sqrtf(k2));
                 float al = kx == 0 ? 1.f : 2.f;
                 atomicAdd(&ringq[b], (unsigned long long)__double2ll_rn((double)(al * (o.x * o.x + o.y * o.y)) * (double)qscale));
@@ -325,6 +328,11 @@ __global__ void __launch_bounds__(PT) k_prep(PrepP P) {
             }
             bandp[row * W + kx] = o;
         }
+    }
+    if (P.band_max) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o, 64));
+        if ((tid & 63) == 0 && omax > 0.f && omax < 3.0e38f) atomicMax(P.band_max, __float_as_uint(omax));
     }
     stamp();
     if (P.stop == 4) return;

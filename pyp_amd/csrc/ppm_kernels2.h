@@ -430,21 +430,9 @@ struct InsertBrickP {
     const float2 *band; const PartIns *pp; const CullEnt *cull; const float *symops; int nsym;
     float *acc; int N, B, W, H, n_img;
     const BrickItem *items;
-    const unsigned *maxima;   // [0] bits of max |band| component, [1] bits of max particle weight (floats >= 0, set by atomicMax)
+    const unsigned *maxima;   // [0] bits of max |band| component (k_prep), [1] bits of max particle weight (k_insert_params); floats >= 0, atomicMax
     float r2;
 };
-
-// max over the chunk of |re|, |im| of the band images (bits of a non-negative float compare like unsigned integers)
-__global__ void __launch_bounds__(256) k_band_absmax(const float2 *band, size_t n, unsigned *maxima) {
-    float m = 0.f;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const float2 v = band[i];
-        m = fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y)));
-    }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0 && m > 0.f && m < 3.0e38f) atomicMax(maxima, __float_as_uint(m));
-}
 
 __global__ void k_insert_params(const double *rows, PartIns *pp, CullEnt *cull, const float *symops, int nsym, int n, int N, double a, double bfac,
                                 double score_avg, double score_thr, int split_by_pind, double r2, unsigned long long *counts, unsigned *maxima) {

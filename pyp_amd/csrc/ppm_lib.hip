@@ -188,7 +188,7 @@ static int build_brick_items(ppm_accum *a, const Geom &gm, int BE, int nb) {
         a->load_r = r; a->items_cap = -1;
     }
     const int smax_env = getenv("PPM_BRICK_SLICES") ? atoi(getenv("PPM_BRICK_SLICES")) : 16;
-    const int minp_env = getenv("PPM_BRICK_MINP") ? atoi(getenv("PPM_BRICK_MINP")) : 512;
+    const int minp_env = getenv("PPM_BRICK_MINP") ? atoi(getenv("PPM_BRICK_MINP")) : 1024;
     const int cap = std::max(1, std::min(smax_env, nb / std::max(1, minp_env)));
     if (cap * 1000 + smax_env == a->items_cap) return 0;
     struct Tmp { BrickItem it; float load; };
@@ -213,6 +213,7 @@ static int build_brick_items(ppm_accum *a, const Geom &gm, int BE, int nb) {
 }
 
 // ------------------------------------------------------------------------------ pre-processing launch
+static unsigned *g_prep_band_max = nullptr;   // set by ppm_insert_batch around its launch_prep call
 static int launch_prep(const float *d_images, const double *d_rows, int n_img, const Geom &gm, float Rm_px, float fall_px,
                        int normalize, int invert, int do_mask, int whiten, float2 *band, float *wring,
                        const uint32_t *samples, int S_pad, float2 *Il, float *cw, float2 *Wp, float *C2, float *nI) {
@@ -250,6 +251,7 @@ static int launch_prep(const float *d_images, const double *d_rows, int n_img, c
     if (getenv("PPM_PREP_DBG") && n_img > 100) { if (!d_dbg) HIPCHK(hipMalloc(&d_dbg, 64 * sizeof(long long))); HIPCHK(hipMemsetAsync(d_dbg, 0, 64 * 8, g.stream)); P.dbg = d_dbg; }
     if (int rc = g_prep_spill.ensure((size_t)n_img * gm.N * gm.W)) return rc;
     P.spill = g_prep_spill.p;
+    P.band_max = g_prep_band_max;
     P.band = band; P.wring = wring; P.samples = samples; P.S_pad = S_pad; P.Il = Il; P.cw = cw;
     P.Wp = Wp; P.C2 = C2; P.nI = nI; P.Bs = gm.Bs; P.Hs = gm.Hs;
     P.r_s2 = (float)(gm.r_s * gm.r_s); P.r_lo2 = (float)(gm.r_lo * gm.r_lo);
@@ -655,7 +657,8 @@ int ppm_insert_batch(ppm_accum_t *a, const ppm_recon_cfg *cfg, const void *image
     Geom gm; std::string err;
     if (!geom_init(gm, rc, err)) return fail(-22, err);
     const size_t NN = (size_t)gm.N * gm.N, HW = (size_t)gm.H * gm.W;
-    int CH = (int)std::min<size_t>((size_t)n_img, std::max<size_t>(32, ((size_t)2 << 30) / (NN * 4 + HW * 8)));
+    const size_t chunk_gb = getenv("PPM_INSERT_GB") ? (size_t)std::max(1, atoi(getenv("PPM_INSERT_GB"))) : 8;
+    int CH = (int)std::min<size_t>((size_t)n_img, std::max<size_t>(32, (chunk_gb << 30) / (NN * 4 + HW * 8)));
     CH = std::min(CH, 32768);   // grid.y limit
     if (int r = a->rows.ensure((size_t)CH * PPM_NCOL)) return r;
     if (!images_on_device) if (int r = a->images.ensure((size_t)2 * CH * NN)) return r;       // double-buffered staging
@@ -668,16 +671,19 @@ int ppm_insert_batch(ppm_accum_t *a, const ppm_recon_cfg *cfg, const void *image
         const int nb = std::min(CH, n_img - c0);
         HIPCHK(hipMemcpyAsync(a->rows.p, rows + (size_t)c0 * PPM_NCOL, (size_t)nb * PPM_NCOL * sizeof(double), hipMemcpyHostToDevice, g.stream));
         const float *d_img = images_on_device ? (const float *)images + (size_t)c0 * NN : a->images.p + (size_t)(ci & 1) * CH * NN;
-        if (int r = launch_prep(d_img, a->rows.p, nb, gm, cfg->mask_radius / cfg->pixel_size, 1.f, cfg->normalize, cfg->invert, 0, 0,
-                                a->band.p, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr)) return r;
-        // per-particle constants and the chunk's value bounds, then one block per (brick, particle slice, half)
+        // the chunk's value bounds ([0] max |band| from k_prep, [1] max weight from k_insert_params) scale the fixed point
+        HIPCHK(hipMemsetAsync(a->d_max, 0, 2 * sizeof(unsigned), g.stream));
+        g_prep_band_max = a->d_max;
+        const int prc = launch_prep(d_img, a->rows.p, nb, gm, cfg->mask_radius / cfg->pixel_size, 1.f, cfg->normalize, cfg->invert, 0, 0,
+                                    a->band.p, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
+        g_prep_band_max = nullptr;
+        if (prc) return prc;
+        // per-particle constants, then one block per (brick, particle slice, half)
         if (int r = a->pp.ensure(nb)) return r;
         if (int r = a->cull.ensure((size_t)nb * a->nsym)) return r;
-        HIPCHK(hipMemsetAsync(a->d_max, 0, 2 * sizeof(unsigned), g.stream));
         hipLaunchKernelGGL(k_insert_params, dim3((nb + 255) / 256), dim3(256), 0, g.stream, a->rows.p, a->pp.p, a->cull.p, a->d_sym, a->nsym, nb, gm.N, (double)cfg->pixel_size,
                            (double)cfg->score_weight_bfactor, (double)cfg->score_average, (double)cfg->score_threshold, cfg->split_by_pind,
                            gm.r_hi * gm.r_hi, a->d_counts, a->d_max);
-        hipLaunchKernelGGL(k_band_absmax, dim3(1024), dim3(256), 0, g.stream, a->band.p, (size_t)nb * HW, a->d_max);
         const int BE = gm.N >= 128 ? 16 : 8;
         if (int r = build_brick_items(a, gm, BE, nb)) return r;
         InsertBrickP IP;
