@@ -134,3 +134,28 @@ def test_unsupported_options_fail_loudly(project):
     s[44] = "yes"                                     # refine defocus
     assert run("refine3d", "\n".join(s), d, "bad.log") != 0
     assert "ERROR" in open(d / "bad.log").read() and not (d / "bad_out.cistem").exists()
+
+
+@pytest.mark.gpu
+def test_two_class_round_assigns_particles_to_their_map():
+    """SURVEY 8f-4 (classification occupancies): particles projected from map A and from map B are refined against both
+    references on the GPU; the LOGP-based occupancy update (pinned on the CPU side by the reference's golden) must send
+    each particle to its own class."""
+    import numpy as np
+    from pyp_amd import classify, host, synth
+    from pyp_amd.abi import RefineCfg
+    n, px, m = 64, 2.0, 24
+    volA = synth.phantom(n)
+    volB = synth.phantom(n, seed=4242)
+    _, sA, rA = synth.make_dataset(n, m, pixel=px, snr=0.2, vol=volA)
+    _, sB, rB = synth.make_dataset(n, m, pixel=px, snr=0.2, vol=volB, seed_poses=99, seed_noise=98)
+    stack = np.concatenate([sA.numpy(), sB.numpy()])
+    rows = np.concatenate([rA, rB]); rows[:, 0] = np.arange(1, 2 * m + 1); rows[:, 11] = 50.0
+    start = synth.perturb_rows(rows, angle_sigma=2.0, shift_sigma_px=0.5, pixel=px)
+    cfg = RefineCfg.make(box=n, pixel_size=px, mask_radius=0.4 * n * px, res_high=px * n / 24.0, global_search=0, res_signed_cc=30.0)
+    refs = [host.Reference(volA, n / 2), host.Reference(volB, n / 2)]
+    out = classify.refine_classes(refs, cfg, stack, [start, start])
+    occ = np.stack([t[:, 11] for t in out])
+    assert np.allclose(occ.sum(axis=0), 100.0, atol=1e-6)
+    assert (occ[0, :m] > 90).mean() > 0.9 and (occ[1, m:] > 90).mean() > 0.9
+    assert np.array_equal(out[0][:, 13], out[1][:, 13])                    # one SIGMA per particle

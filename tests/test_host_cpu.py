@@ -76,3 +76,29 @@ def test_euler_convention_golden(golden_dir):
         assert np.allclose(synth.angles_from_pyp_matrix(np.array(e["matrix"])), e["out"], atol=1e-9)
         # the matrix PYP writes down is ours with all three angles negated
         assert np.allclose(m, synth.euler_matrix(-psi, -theta, -phi), atol=1e-12)
+
+
+def test_class_occupancies_match_reference_golden(golden_dir):
+    """tests/golden/occupancy_3class.npz was written by the reference's occupancy_extended (gen_golden_occ.py); the .cistem
+    codec stores float32, so inputs are taken at float32 precision and outputs compared at float32 resolution."""
+    import os
+    from pyp_amd import classify
+    g = np.load(os.path.join(golden_dir, "occupancy_3class.npz"))
+    f32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
+    logp, sigma, occ_in = f32(g["logp"]), f32(g["sigma"]), f32(g["occ_in"])
+    occ, sig = classify.occupancies_from_logp(logp, sigma, occ_in.mean(axis=1))
+    assert np.allclose(occ, g["occ_out"], rtol=2e-6, atol=2e-5)
+    assert np.allclose(sig[None, :].repeat(3, 0), g["sigma_out"], rtol=2e-6, atol=1e-6)
+    assert np.allclose(occ.sum(axis=0), 100.0)
+    assert occ[1, 3] == 0.0 and occ[2, 3] > 0.0                     # the delta < 10 window
+    # table-level wrapper: only OCCUPANCY and SIGMA change
+    K, M = logp.shape
+    tabs = []
+    for k in range(K):
+        t = np.zeros((M, 32)); t[:, 0] = np.arange(1, M + 1); t[:, 11] = occ_in[k]; t[:, 12] = logp[k]; t[:, 13] = sigma[k]; t[:, 14] = 7.0
+        tabs.append(t)
+    new = classify.update_class_rows(tabs)
+    for k in range(K):
+        assert np.allclose(new[k][:, 11], g["occ_out"][k], rtol=2e-6, atol=2e-5) and np.allclose(new[k][:, 13], g["sigma_out"][k], rtol=2e-6, atol=1e-6)
+        keep = [c for c in range(32) if c not in (11, 13)]
+        assert np.array_equal(new[k][:, keep], tabs[k][:, keep])
