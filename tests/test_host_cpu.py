@@ -102,3 +102,36 @@ def test_class_occupancies_match_reference_golden(golden_dir):
         assert np.allclose(new[k][:, 11], g["occ_out"][k], rtol=2e-6, atol=2e-5) and np.allclose(new[k][:, 13], g["sigma_out"][k], rtol=2e-6, atol=1e-6)
         keep = [c for c in range(32) if c not in (11, 13)]
         assert np.array_equal(new[k][:, keep], tabs[k][:, keep])
+
+
+def test_score_selection_rules():
+    """pyp_amd.select (unpinned restatement of scores.py shape_phase_residuals, SPA branch)."""
+    from pyp_amd import select
+    rng = np.random.default_rng(3)
+    M = 400
+    rows = np.zeros((M, 32)); rows[:, 0] = np.arange(1, M + 1)
+    rows[:, 2] = rng.uniform(0, 360, M); rows[:, 6] = rng.uniform(8000, 24000, M); rows[:, 11] = 100.0
+    rows[:, 14] = rng.uniform(0, 30, M); rows[:, 27] = np.arange(M) % 40
+    out = select.select_particles(rows, threshold=0.75)
+    kept = out[:, 11] > 0
+    cut = np.sort(rows[:, 14])[int((M - 1) * 0.25)]
+    assert np.array_equal(kept, rows[:, 14] >= cut) and abs(kept.mean() - 0.75) < 0.01
+    keep_cols = [c for c in range(32) if c != 11]
+    assert np.array_equal(out[:, keep_cols], rows[:, keep_cols])
+    assert (select.select_particles(rows, threshold=1.0)[:, 11] > 0).all()
+    assert (select.select_particles(rows, threshold=250)[:, 11] > 0).all()        # absolute counts: no-op, like the reference
+    d = select.select_particles(rows, threshold=1.0, mindefocus=10000, maxdefocus=20000)
+    assert np.array_equal(d[:, 11] > 0, (rows[:, 6] >= 10000) & (rows[:, 6] <= 20000))
+    a = select.select_particles(rows, threshold=1.0, minazh=30, maxazh=150)
+    assert np.array_equal(a[:, 11] > 0, (np.mod(rows[:, 2], 180) >= 30) & (np.mod(rows[:, 2], 180) <= 150))
+    fr = select.select_particles(rows, threshold=1.0, firstframe=5, lastframe=20)
+    assert np.array_equal(fr[:, 11] > 0, (rows[:, 27] >= 5) & (rows[:, 27] <= 20))
+    assert (select.select_particles(rows, threshold=1.0, odd=True)[::2, 11] == 0).all()
+    assert (select.select_particles(rows, threshold=1.0, even=True)[1::2, 11] == 0).all()
+    s = select.select_particles(rows, threshold=1.0, minscore=0.1, maxscore=0.9)
+    lo, hi = rows[:, 14].min(), rows[:, 14].max()
+    assert np.array_equal(s[:, 11] > 0, (rows[:, 14] >= lo + 0.1 * (hi - lo)) & (rows[:, 14] <= hi - 0.1 * (hi - lo)))
+    g = select.select_particles(rows, threshold=0.5, angles=3, defocuses=2)          # grouped thresholds keep roughly half
+    assert 0.3 < (g[:, 11] > 0).mean() < 0.8
+    with pytest.raises(ValueError):
+        select.select_particles(rows, threshold=0)
