@@ -75,7 +75,8 @@ def test_global_grid_search_matches_oracle_exactly(d64, H, O):
 
 
 @pytest.mark.parametrize("n,px,m,step", [(64, 2.0, 24, 15.0), (128, 1.5, 8, 15.0), (64, 2.0, 6, 20.0), (32, 3.0, 6, 30.0),
-                                          (96, 1.5, 6, 15.0), (80, 2.0, 6, 15.0), (48, 3.0, 6, 20.0)])   # 2^5 3, 2^4 5, 2^4 3: mixed-radix FFT
+                                          (96, 1.5, 6, 15.0), (80, 2.0, 6, 15.0), (48, 3.0, 6, 20.0),    # 2^5 3, 2^4 5, 2^4 3: mixed-radix FFT
+                                          (90, 2.0, 6, 20.0)])             # 2 3^2 5: not a multiple of 4 (4-byte row fetches)
 def test_full_refinement_matches_oracle(H, O, n, px, m, step):
     vol, imgs, rows = dataset(n, m, px, 0.1)
     g, o = H.Reference(vol, n / 2), O.Reference(vol, n / 2)
@@ -229,7 +230,8 @@ def test_insertion_non_power_of_two_box(H, O):
         assert np.linalg.norm(a - b) / np.linalg.norm(a) < 1e-4
 
 
-@pytest.mark.parametrize("n,px,m,sym,minp", [(256, 1.0, 24, "C1", "4"), (160, 1.5, 12, "C2", None), (128, 2.0, 600, "C1", "64")])
+@pytest.mark.parametrize("n,px,m,sym,minp", [(256, 1.0, 24, "C1", "4"), (160, 1.5, 12, "C2", None), (128, 2.0, 600, "C1", "64"),
+                                             (50, 2.5, 10, "C1", None), (150, 1.5, 8, "C3", "2")])
 def test_insertion_large_boxes_bricks_and_slices(H, O, monkeypatch, n, px, m, sym, minp):
     """Boxes >= 128 use 16^3-voxel bricks, 1024-thread blocks and (with more particles than PPM_BRICK_MINP per slice)
     several particle slices per brick whose partial bricks are summed in global memory; 256 also takes the 16 x 16
