@@ -8,7 +8,7 @@
 //   k_global         pruned correlation image of every (particle, orientation): lane = kx, rows
 //                    stream over ky, wavefront-shuffle reduction of the shift window, top-K hits
 //   k_local          ring-wise weighted correlation at arbitrary poses + compass refinement
-//   k_insert         CTF-weighted trilinear scatter-add into the half-map accumulators
+//   k_insert_bricks  CTF-weighted trilinear insertion into the half-map accumulators, brick by brick in LDS (ppm_kernels2.h)
 //   finalise         shell statistics, Wiener division, mask and gridding correction
 #pragma once
 #include "ppm_dev.h"
@@ -82,8 +82,6 @@ struct PrepP {
     float2 *band;  // [n][H*W] unscaled band spectrum (scratch; the final result for insertion)
     int TS, WS;    // line strides of the column buffer T and of the row work buffer Wk (>= 272 on the 256 fast path)
     int fast256;   // N == 256: register-level 16 x 16 FFT (lds_fft256), natural-order staging
-    long long *dbg; // timing experiments only (PPM_PREP_DBG): s_memtime stamps of block 100's phases
-    int stop;      // timing experiments only (PPM_PREP_STOP): leave the kernel after phase `stop`
     unsigned *band_max; // may be null: bits of max |re|, |im| over the band images of the launch (atomicMax; floats >= 0)
     float2 *spill; // [n][N][W] row-transformed half spectrum (global scratch between the row and the column phase)
     float *wring;  // [n][B+2] ring weights 1/sqrt(mean power), may be null
@@ -101,9 +99,6 @@ __global__ void __launch_bounds__(PT) k_prep(PrepP P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, N = P.N, B = P.B, W = P.W, H = P.H;
     const int p = blockIdx.x;
-    int dbg_n = 0;
-    auto stamp = [&]() { if (P.dbg && p == 100 && tid == 0 && dbg_n < 60) P.dbg[dbg_n++] = (long long)__builtin_readcyclecounter(); };
-    stamp();
     const int TS = P.TS, WS = P.WS;                   // padded line strides (bank spread)
     float2 *T = (float2 *)smem;                       // [nc][TS] column chunk, followed by
     float2 *Wk = T + (size_t)P.nc * TS;               // [L][WS]  the row work buffer
@@ -175,8 +170,6 @@ __global__ void __launch_bounds__(PT) k_prep(PrepP P) {
         __syncthreads();
     }
     const float mu = stat[0], sc = stat[1];
-    stamp();
-    if (P.stop == 1) return;
     const float qscale = stat[2];
     for (int i = tid; i < B + 2; i += PT) { ringq[i] = 0ull; ringc[i] = 0u; }
 
@@ -223,7 +216,6 @@ __global__ void __launch_bounds__(PT) k_prep(PrepP P) {
             fetch(0);
             for (int y0 = 0; y0 < N; y0 += 2 * P.L) {
                 lds_barrier();
-                stamp();
                 if (wide) {
 #pragma unroll
                     for (int k = 0; k < MAXI / 4; k++) {
@@ -254,10 +246,8 @@ __global__ void __launch_bounds__(PT) k_prep(PrepP P) {
                     }
                 }
                 if (y0 + 2 * P.L < N) fetch(y0 + 2 * P.L);
-                stamp();
                 if (P.fast256) lds_fft256(Wk, P.L, WS, tid, PT, tw_s);
                 else lds_fft(Wk, P.plan, P.L, WS, false, tid, PT, tw_s);
-                stamp();
                 const float invW = 1.0f / (float)W;
                 for (int i = tid; i < P.L * W; i += PT) {
                     const int l = fast_div(i, W, invW), kx = i - l * W;
@@ -304,14 +294,10 @@ __global__ void __launch_bounds__(PT) k_prep(PrepP P) {
             }
         }
         if (ch + 1 < P.nchunks) fetch_chunk(ch + 1);
-        stamp();
-        if (P.stop == 2) return;
         // ---- column pass
         if (P.fast256) lds_fft256(T, ncol, TS, tid, PT, tw_s);
         else lds_fft(T, P.plan, ncol, TS, false, tid, PT, tw_s);
         const float invN = 1.f / (float)N;
-        stamp();
-        if (P.stop == 3) return;
         for (int i = tid; i < ncol * H; i += PT) {
             const int row = fast_div(i, ncol, inv_ncol), c = i - row * ncol, ky = row - B, kx = c0 + c;
             float k2 = (float)(kx * kx + ky * ky);
@@ -334,8 +320,6 @@ __global__ void __launch_bounds__(PT) k_prep(PrepP P) {
         for (int o = 32; o >= 1; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o, 64));
         if ((tid & 63) == 0 && omax > 0.f && omax < 3.0e38f) atomicMax(P.band_max, __float_as_uint(omax));
     }
-    stamp();
-    if (P.stop == 4) return;
     __threadfence_block();
     __syncthreads();
     // ---- ring weights (re-using ringpw as the weight table)
@@ -389,8 +373,6 @@ __global__ void __launch_bounds__(PT) k_prep(PrepP P) {
         __syncthreads();
         if (tid == 0) { float t = 0.f; for (int w = 0; w < PW; w++) t += stat[3 + w]; P.nI[p] = t; }
     }
-    stamp();
-    if (P.dbg && p == 100 && tid == 0) P.dbg[63] = dbg_n;
 }
 
 // ---------------------------------------------------------------------------------- slice bank

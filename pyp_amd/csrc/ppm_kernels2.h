@@ -323,95 +323,11 @@ __global__ void k_rows_out(const LState *states, const double *rows_in, double *
     o[PPM_LOGP] = -0.5 * (3.14159265358979323846 * (r_hi * r_hi - r_lo * r_lo)) * (log(2.0 * 3.14159265358979323846 * res) + 1.0);
 }
 
-// ---------------------------------------------------------------------------------- Fourier insertion
-struct InsertP {
-    const float2 *band; const double *rows; const float *symops; int nsym;
-    float *acc;   // [2][N][N][N/2+1][3]
-    int N, B, W, H, n_img;
-    float r2, a, bfac, score_avg, score_thr;
-    int split_by_pind;
-    unsigned long long *counts;  // [2]
-};
-
-// grid: (ceil(H*W/256), n_img).  Thread = one Fourier sample of one particle and symmetry operator: 8 taps x
-// {re, im, weight}.  A tap pair (x0, x0+1) of one (y, z) row is 6 consecutive floats in the accumulator, so the
-// adds are issued TRANSPOSED: every wave stages its 64 x 4 row segments (base index + 6 values) in LDS and then
-// walks them 6 floats at a time, ~10.7 segments per wave-instruction.  One wave-instruction therefore produces
-// ~11 64-byte atomic requests instead of 64 (float atomics execute at the memory side, per 64-B request).
-__global__ void __launch_bounds__(256) k_insert(InsertP P) {
-    const int p = blockIdx.y, N = P.N, B = P.B, W = P.W;
-    const double *row = P.rows + (size_t)p * PPM_NCOL;
-    const double occ = row[PPM_OCC], scr = row[PPM_SCORE];
-    if (!(occ > 0) || scr < (double)P.score_thr) return;          // uniform over the block
-    long key = P.split_by_pind ? (long)row[PPM_PIND] : (long)row[PPM_POS];
-    const int h = (int)(((key % 2) + 2) % 2);
-    __shared__ CtfP ctf; __shared__ float m_s[6]; __shared__ float sh_s[2];
-    __shared__ int seg_base[4][256];          // [wave][row * 64 + lane]  -> float index of (x0, y, z).re, or -1
-    __shared__ float seg_val[4][256 * 6];     // [wave][(row * 64 + lane) * 6 + c]: neighbouring samples' segments of one
-                                              // (dy, dz) row are adjacent, so they tend to share 64-byte lines
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) {
-        ctf = ctf_from_row(row, N, (double)P.a);
-        double M[9]; d_euler(row[PPM_PSI], row[PPM_THETA], row[PPM_PHI], M);
-        m_s[0] = (float)M[0]; m_s[1] = (float)M[1]; m_s[2] = (float)M[3]; m_s[3] = (float)M[4]; m_s[4] = (float)M[6]; m_s[5] = (float)M[7];
-        sh_s[0] = (float)(row[PPM_XSHIFT] / (double)P.a); sh_s[1] = (float)(row[PPM_YSHIFT] / (double)P.a);
-        if (blockIdx.x == 0) atomicAdd(&P.counts[h], 1ull);
-    }
-    __syncthreads();
-    const int idx = blockIdx.x * 256 + tid;
-    const int kx = idx % W, ky = idx / W - B;
-    const float k2 = (float)(kx * kx + ky * ky);
-    const bool live = idx < P.H * W && k2 < P.r2 && k2 != 0.f;
-    float vr = 0.f, vi = 0.f, vw = 0.f, X0 = 0.f, Y0 = 0.f, Z0 = 0.f;
-    if (live) {
-        const float cv = ctf_eval(ctf, kx, ky);
-        float w = (float)(occ / 100.0);
-        if (P.bfac != 0.f) w *= expf(-0.25f * P.bfac * (P.score_avg - (float)scr) * k2 * ctf.inv_na2);
-        float rev = (kx * sh_s[0] + ky * sh_s[1]) / (float)N; rev -= floorf(rev);
-        float sn = __sinf(6.283185307179586f * rev), cs = __cosf(6.283185307179586f * rev);
-        const float2 iv = P.band[((size_t)p * P.H + (ky + B)) * W + kx];
-        vr = w * cv * (iv.x * cs - iv.y * sn); vi = w * cv * (iv.x * sn + iv.y * cs); vw = w * cv * cv;
-        X0 = m_s[0] * kx + m_s[1] * ky; Y0 = m_s[2] * kx + m_s[3] * ky; Z0 = m_s[4] * kx + m_s[5] * ky;
-    }
-    const size_t NX = N / 2 + 1;
-    float *A = P.acc + (size_t)h * N * N * NX * 3;
-    int *sb = seg_base[wave]; float *sv = seg_val[wave];
-    for (int s = 0; s < P.nsym; s++) {
-        const float *S = P.symops + s * 9;
-        float X = S[0] * X0 + S[1] * Y0 + S[2] * Z0, Y = S[3] * X0 + S[4] * Y0 + S[5] * Z0, Z = S[6] * X0 + S[7] * Y0 + S[8] * Z0;
-        float ui = vi;
-        if (X < 0.f) { X = -X; Y = -Y; Z = -Z; ui = -ui; }
-        const float xf = floorf(X), yf = floorf(Y), zf = floorf(Z);
-        const float fx = X - xf, fy = Y - yf, fz = Z - zf;
-        const int x0 = (int)xf, y0 = (int)yf + N / 2, z0 = (int)zf + N / 2;
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int dy = r & 1, dz = r >> 1, yi = y0 + dy, zi = z0 + dz;
-            const bool ok = live && yi >= 0 && yi < N && zi >= 0 && zi < N && x0 + 1 <= N / 2;
-            const float wyz = (dy ? fy : 1.f - fy) * (dz ? fz : 1.f - fz);
-            const float w0 = wyz * (1.f - fx), w1 = wyz * fx;
-            sb[r * 64 + lane] = ok ? (int)((((size_t)zi * N + yi) * NX + x0) * 3) : -1;
-            float *o = sv + (r * 64 + lane) * 6;
-            o[0] = w0 * vr; o[1] = w0 * ui; o[2] = w0 * vw; o[3] = w1 * vr; o[4] = w1 * ui; o[5] = w1 * vw;
-        }
-        // the wave is its own producer and consumer: LDS writes above are complete before the reads below
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0)
-#pragma unroll 4
-        for (int f = lane; f < 256 * 6; f += 64) {
-            const int seg = f / 6, c = f - seg * 6;
-            const int base = sb[seg];
-            if (base >= 0) atomicAdd(A + base + c, sv[f]);
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
 // ---------------------------------------------------------------------------------- brick-binned insertion
-// No global atomics: the accumulator is cut into bricks of BE^3 voxels; one block owns one brick of one half-map,
-// keeps it in LDS, walks over the particles of the batch, finds the slice samples whose 8-tap footprint touches the
-// brick (plane / box rejection, then a candidate rectangle in the slice plane) and adds them with LDS atomics; the
-// brick is written back once, by its only owner (plain read-modify-write, deterministic up to the LDS add order).
+// No per-sample global atomics: the accumulator is cut into bricks of BE^3 voxels; one block owns one brick of one half-map
+// (and one slice of the chunk's particles), keeps it in LDS in 64-bit fixed point, finds the slice samples whose 8-tap
+// footprint touches the brick and adds them with integer LDS atomics; the brick is written back once (plain
+// read-modify-write if the block is the brick's only owner in this launch, float atomics per brick cell otherwise).
 struct PartIns {       // per-particle constants, written by k_insert_params
     float m[6];        // X = m0 kx + m1 ky, Y = m2 kx + m3 ky, Z = m4 kx + m5 ky
     CtfP ctf;

@@ -235,7 +235,6 @@ static int launch_prep(const float *d_images, const double *d_rows, int n_img, c
     if (getenv("PPM_PREP_L")) P.L = std::max(1, std::min(atoi(getenv("PPM_PREP_L")), 8 * PT / gm.N));
     while ((gm.N / 2) % P.L || (size_t)P.L * P.WS * sizeof(float2) + lds_fixed + P.TS * sizeof(float2) > budget / 2 + 8192) P.L--;     // the row pass walks the image 2 L rows at a time; leave about half of the LDS to the column chunk
     if (P.L < 1) return fail(-12, "pre-processing kernel: row buffer does not fit the LDS");
-    P.stop = getenv("PPM_PREP_STOP") ? atoi(getenv("PPM_PREP_STOP")) : 0;
     {
         const size_t wk = (size_t)P.L * P.WS * sizeof(float2);
         const size_t left = budget - lds_fixed > wk ? budget - lds_fixed - wk : 0;
@@ -245,10 +244,6 @@ static int launch_prep(const float *d_images, const double *d_rows, int n_img, c
     P.nchunks = (gm.W + P.nc - 1) / P.nc;
     P.nc = (gm.W + P.nchunks - 1) / P.nchunks;       // even chunks
     if (getenv("PPM_PREP_NCH")) { P.nchunks = std::max(P.nchunks, atoi(getenv("PPM_PREP_NCH"))); P.nc = (gm.W + P.nchunks - 1) / P.nchunks; P.nchunks = (gm.W + P.nc - 1) / P.nc; }
-    P.stop = getenv("PPM_PREP_STOP") ? atoi(getenv("PPM_PREP_STOP")) : 0;
-    static long long *d_dbg = nullptr;
-    P.dbg = nullptr;
-    if (getenv("PPM_PREP_DBG") && n_img > 100) { if (!d_dbg) HIPCHK(hipMalloc(&d_dbg, 64 * sizeof(long long))); HIPCHK(hipMemsetAsync(d_dbg, 0, 64 * 8, g.stream)); P.dbg = d_dbg; }
     if (int rc = g_prep_spill.ensure((size_t)n_img * gm.N * gm.W)) return rc;
     P.spill = g_prep_spill.p;
     P.band_max = g_prep_band_max;
@@ -266,12 +261,6 @@ static int launch_prep(const float *d_images, const double *d_rows, int n_img, c
     ProfScope ps(PPM_K_PREP);
     if (PT == 512) hipLaunchKernelGGL(k_prep<512>, dim3(n_img), dim3(512), lds, g.stream, P);
     else hipLaunchKernelGGL(k_prep<1024>, dim3(n_img), dim3(1024), lds, g.stream, P);
-    if (P.dbg) {
-        long long h[64]; HIPCHK(hipStreamSynchronize(g.stream)); HIPCHK(hipMemcpy(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost));
-        fprintf(stderr, "k_prep phases (cycles, block 100, nc=%d nchunks=%d L=%d):", P.nc, P.nchunks, P.L);
-        for (int i = 1; i < (int)h[63] && i < 60; i++) fprintf(stderr, " %lld", h[i] - h[i - 1]);
-        fprintf(stderr, "\n");
-    }
     HIPCHK(hipGetLastError());
     return 0;
 }
