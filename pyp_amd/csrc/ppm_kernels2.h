@@ -674,7 +674,7 @@ __device__ __forceinline__ unsigned hash32(unsigned x) { x ^= x >> 16; x *= 0x7f
 
 // Block = one particle.  Window bounds exactly as the reference computes them (including its habit of dropping
 // the last row / column when the window touches the far edge); pass 1 = mean of the inside part, pass 2 =
-// emptiness probes + background statistics, pass 3 = write.  The micrograph window is re-read from L2.
+// emptiness probes + background statistics, pass 3 = write.  The micrograph window is re-read from L2 / Infinity Cache.
 __global__ void __launch_bounds__(256) k_extract(ExtractP P) {
     __shared__ double red[4][5];
     __shared__ double s_fill, s_mu, s_sd;
@@ -701,22 +701,43 @@ __global__ void __launch_bounds__(256) k_extract(ExtractP P) {
         if (lane == 0) red[wave][slot] = v;
     };
     // ---- pass 1: mean of the inside part
+    // All passes walk the window row by row (a wave covers 64 consecutive pixels of one row, no index division) and keep
+    // UR independent loads in flight per thread: with one load per loop trip every pass ran at memory latency.
+    constexpr int UR = 8;
+    auto sweep = [&](int nr, int ncl, auto load, auto use) {
+        for (int r0 = wave; r0 < nr; r0 += 4 * UR)
+            for (int c = lane; c < ncl; c += 64) {
+                float v[UR];
+#pragma unroll
+                for (int u = 0; u < UR; u++) { const int r = r0 + 4 * u; v[u] = r < nr ? load(r, c) : 0.f; }
+#pragma unroll
+                for (int u = 0; u < UR; u++) { const int r = r0 + 4 * u; if (r < nr) use(r, c, v[u]); }
+            }
+    };
     double s = 0;
-    if (has_inside) for (int i = tid; i < nX * nY; i += 256) s += P.image[(size_t)(iX0 + i / nY) * P.cols + (iY0 + i % nY)];
+    if (has_inside)
+        sweep(nX, nY, [&](int r, int c) { return P.image[(size_t)(iX0 + r) * P.cols + iY0 + c]; }, [&](int, int, float v) { s += v; });
     block_sum(s, 0);
     __syncthreads();
     if (tid == 0) s_fill = has_inside ? (red[0][0] + red[1][0] + red[2][0] + red[3][0]) / ((double)nX * nY) : 0.0;
     __syncthreads();
     const float fill = (float)s_fill;
-    // ---- pass 2: emptiness probes (three candidate "constant" values) + min/max
+    // ---- pass 2: emptiness probes (three candidate "constant" values, min/max) together with the background statistics
+    // (outside radius_px of the box centre) of the window as it is; an "empty" window (rare) is replaced by noise and its
+    // statistics are taken again.
     const int npx = box * box;
+    double b1 = 0, b2 = 0, bc = 0;
+    auto stat_use = [&](int r, int c, float vf) {
+        const int dr = r - box / 2, dc = c - box / 2;
+        if ((float)(dr * dr + dc * dc) > P.radius2) { const double v = vf; b1 += v; b2 += v * v; bc += 1; }
+    };
     if (P.fix_empty) {
         const float c0 = raw_at(0, 0, fill), c1 = raw_at(box / 2, box / 2, fill), c2 = fill;
         double n0 = 0, n1 = 0, n2 = 0; float mn = 3e38f, mx = -3e38f;
-        for (int i = tid; i < npx; i += 256) {
-            float v = raw_at(i / box, i % box, fill);
+        sweep(box, box, [&](int r, int c) { return raw_at(r, c, fill); }, [&](int r, int c, float v) {
             n0 += v == c0; n1 += v == c1; n2 += v == c2; mn = fminf(mn, v); mx = fmaxf(mx, v);
-        }
+            if (P.normalize) stat_use(r, c, v);
+        });
         for (int m = 32; m >= 1; m >>= 1) { mn = fminf(mn, __shfl_xor(mn, m, 64)); mx = fmaxf(mx, __shfl_xor(mx, m, 64)); }
         __syncthreads();
         block_sum(n0, 0); block_sum(n1, 1); block_sum(n2, 2); block_sum((double)mn, 3); block_sum((double)mx, 4);
@@ -728,21 +749,22 @@ __global__ void __launch_bounds__(256) k_extract(ExtractP P) {
             s_empty = (gmn == gmx) || ((double)npx - most < 0.01 * npx);
         }
         __syncthreads();
-    } else { if (tid == 0) s_empty = 0; __syncthreads(); }
+    } else {
+        if (tid == 0) s_empty = 0;
+        if (P.normalize) sweep(box, box, [&](int r, int c) { return raw_at(r, c, fill); }, stat_use);
+        __syncthreads();
+    }
     const bool empty = s_empty != 0;
-    auto value_at = [&](int i) -> float {       // the frame that gets normalised
-        if (!empty) return raw_at(i / box, i % box, fill);
+    auto value_at = [&](int r, int c) -> float {       // the frame that gets normalised
+        if (!empty) return raw_at(r, c, fill);
+        const int i = r * box + c;
         unsigned h1 = hash32((unsigned)p * 2654435761u + (unsigned)i * 2u + 1u), h2 = hash32(h1 ^ 0x9e3779b9u);
         float u1 = ((h1 >> 8) + 1) * (1.0f / 16777217.0f), u2 = (h2 >> 8) * (1.0f / 16777216.0f);
         return sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);       // unit white noise instead of numpy's
     };
-    // ---- background statistics (outside radius_px of the box centre)
-    double b1 = 0, b2 = 0, bc = 0;
-    if (P.normalize) {
-        for (int i = tid; i < npx; i += 256) {
-            int r = i / box - box / 2, c = i % box - box / 2;
-            if ((float)(r * r + c * c) > P.radius2) { double v = value_at(i); b1 += v; b2 += v * v; bc += 1; }
-        }
+    if (empty && P.normalize) {
+        b1 = b2 = bc = 0;
+        sweep(box, box, [&](int r, int c) { return value_at(r, c); }, stat_use);
     }
     __syncthreads();
     block_sum(b1, 0); block_sum(b2, 1); block_sum(bc, 2);
@@ -756,7 +778,7 @@ __global__ void __launch_bounds__(256) k_extract(ExtractP P) {
     __syncthreads();
     const double mu = s_mu, isd = 1.0 / s_sd;
     float *o = P.out + (size_t)p * npx;
-    for (int i = tid; i < npx; i += 256) o[i] = (float)(((double)value_at(i) - mu) * isd);
+    sweep(box, box, [&](int r, int c) { return value_at(r, c); }, [&](int r, int c, float v) { o[r * box + c] = (float)(((double)v - mu) * isd); });
 }
 
 __global__ void k_axpy(float *__restrict__ y, const float *__restrict__ x, size_t n) {
