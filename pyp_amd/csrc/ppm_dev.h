@@ -206,6 +206,37 @@ __device__ __forceinline__ float2 sample_cube(const CubeView &cv, float X, float
     return make_float2(rr, cj ? -ri : ri);
 }
 
+// The same sample split in two, so that the gathers of the NEXT evaluation can be in flight while the current one is
+// interpolated and scored (k_local): the 8 taps as four 16-byte x-pairs plus the interpolation fractions.
+struct CubeTaps { float4 a, b, c, d; float fx, fy, fz; bool cj; };
+
+__device__ __forceinline__ CubeTaps cube_fetch(const CubeView &cv, float X, float Y, float Z) {
+    CubeTaps t;
+    t.cj = X < 0.f;
+    if (t.cj) { X = -X; Y = -Y; Z = -Z; }
+    const float xf = floorf(X), yf = floorf(Y), zf = floorf(Z);
+    t.fx = X - xf; t.fy = Y - yf; t.fz = Z - zf;
+    const int x0 = (int)xf, y0 = (int)yf + cv.off, z0 = (int)zf + cv.off;
+    const float2 *p = cv.cube + ((size_t)z0 * cv.CY + y0) * cv.CX + x0;
+    const size_t sy = cv.CX, sz = (size_t)cv.CX * cv.CY;
+    const float2 a0 = p[0], a1 = p[1], b0 = p[sy], b1 = p[sy + 1], c0 = p[sz], c1 = p[sz + 1], d0 = p[sz + sy], d1 = p[sz + sy + 1];
+    t.a = make_float4(a0.x, a0.y, a1.x, a1.y); t.b = make_float4(b0.x, b0.y, b1.x, b1.y);
+    t.c = make_float4(c0.x, c0.y, c1.x, c1.y); t.d = make_float4(d0.x, d0.y, d1.x, d1.y);
+    return t;
+}
+
+__device__ __forceinline__ float2 cube_interp(const CubeTaps &t) {
+    const float fx = t.fx, fy = t.fy, fz = t.fz;
+    const float ar = t.a.x + fx * (t.a.z - t.a.x), ai = t.a.y + fx * (t.a.w - t.a.y);
+    const float br = t.b.x + fx * (t.b.z - t.b.x), bi = t.b.y + fx * (t.b.w - t.b.y);
+    const float cr = t.c.x + fx * (t.c.z - t.c.x), ci = t.c.y + fx * (t.c.w - t.c.y);
+    const float dr = t.d.x + fx * (t.d.z - t.d.x), di = t.d.y + fx * (t.d.w - t.d.y);
+    const float er = ar + fy * (br - ar), ei = ai + fy * (bi - ai);
+    const float gr = cr + fy * (dr - cr), gi = ci + fy * (di - ci);
+    const float rr = er + fz * (gr - er), ri = ei + fz * (gi - ei);
+    return make_float2(rr, t.cj ? -ri : ri);
+}
+
 // CTF of one particle: -sin(pi lambda s^2 (df(phi) - Cs lambda^2 s^2 / 2) + phase + amp)
 struct CtfP { float lambda, cs, dsum, ddif, c2a, s2a, extra, inv_na2; };
 

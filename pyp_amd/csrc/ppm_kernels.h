@@ -127,15 +127,23 @@ __global__ void __launch_bounds__(PT) k_prep(PrepP P) {
     {
         const float invNf = 1.0f / (float)N;
         const float4 *img4 = (const float4 *)img;          // N even: N^2 is a multiple of 4, every image starts 16-byte aligned
-        for (int i4 = tid; i4 < N * N / 4; i4 += PT) {
-            const float4 q = img4[i4];
-            const float vv[4] = { q.x, q.y, q.z, q.w };
+        constexpr int UR = 8;                              // independent 16-byte loads in flight per thread
+        for (int b4 = tid; b4 < N * N / 4; b4 += PT * UR) {
+            float4 qv[UR];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int i = 4 * i4 + j, y = fast_div(i, N, invNf), x = i - y * N;
-                const float dx = (float)(x - N / 2), dy = (float)(y - N / 2), v = vv[j];
-                t1 += v; t2 += (double)v * v;
-                if (dx * dx + dy * dy > Rm2) { s1 += v; s2 += (double)v * v; cnt += 1.0; }
+            for (int u = 0; u < UR; u++) { const int i4 = b4 + u * PT; if (i4 < N * N / 4) qv[u] = img4[i4]; }
+#pragma unroll
+            for (int u = 0; u < UR; u++) {
+                const int i4 = b4 + u * PT;
+                if (i4 >= N * N / 4) continue;
+                const float vv[4] = { qv[u].x, qv[u].y, qv[u].z, qv[u].w };
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int i = 4 * i4 + j, y = fast_div(i, N, invNf), x = i - y * N;
+                    const float dx = (float)(x - N / 2), dy = (float)(y - N / 2), v = vv[j];
+                    t1 += v; t2 += (double)v * v;
+                    if (dx * dx + dy * dy > Rm2) { s1 += v; s2 += (double)v * v; cnt += 1.0; }
+                }
             }
         }
     }

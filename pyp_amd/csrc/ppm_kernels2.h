@@ -134,9 +134,16 @@ __global__ void __launch_bounds__(256, 4) k_local(LocalP P) {
             const float fal = (float)al, fkx = (float)kx, fky = (float)ky;
             accC += fal * (iv.x * iv.x + iv.y * iv.y);
             const float ax = fal * iv.x, ay = fal * iv.y;
-            for (int g = 0; g < ng; g++) {
+            auto fetch = [&](int g) {
                 const float *m = plan.m[g];
-                float2 pv = sample_cube(P.cv, m[0] * fkx + m[1] * fky, m[2] * fkx + m[3] * fky, m[4] * fkx + m[5] * fky);
+                return cube_fetch(P.cv, m[0] * fkx + m[1] * fky, m[2] * fkx + m[3] * fky, m[4] * fkx + m[5] * fky);
+            };
+            CubeTaps cur = fetch(0);
+            for (int g = 0; g < ng; g++) {
+                CubeTaps nxt = cur;
+                if (g + 1 < ng) nxt = fetch(g + 1);          // the next group's gathers fly while this group is scored
+                float2 pv = cube_interp(cur);
+                cur = nxt;
                 pv.x *= c; pv.y *= c;
                 float bv = group16_sum_dpp(fal * (pv.x * pv.x + pv.y * pv.y));     // |m|^2 does not depend on the shift
                 const int nv = plan.nv[g], q0 = plan.slot0[g];
