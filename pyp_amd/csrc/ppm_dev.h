@@ -178,48 +178,40 @@ __device__ inline void lds_fft256(float2 *buf, int nlines, int lstride, int tid,
     lds_barrier();
 }
 
-// Trilinear sample of the band-limited reference cube at Fourier coordinate (X,Y,Z).
-// cube: float2 [CY][CY][CX], x fastest, index ((z+off)*CY + (y+off))*CX + x, x in 0..B+1.
-// Friedel symmetry supplies x < 0.  The two x-neighbours are fetched as one 16-byte load.
-struct CubeView { const float2 *cube; int CX, CY, off; };
+// Band-limited reference cube, x in 0..B+1, y and z in -B-1..B+1 (stored index = coordinate + off), in a BLOCKED layout:
+// one 128-byte line holds a 4 (x) x 2 (y) x 2 (z) brick of complex voxels, so that the 8 taps of a trilinear sample fall
+// into 1-4 lines (on average 2.25) whatever the slice orientation, and neighbouring samples of a slice share them; with
+// x fastest over the whole row every tap pair of a tilted slice sat in its own line.  The x-pair (x0, x0+1) is always
+// read as one 16-byte load: a second copy of the cube whose bricks start at x = 2 serves the pairs that would straddle two
+// bricks of the first copy (x0 % 4 == 3).
+//   element(copy, x, y, z) = copy * LB + (((z >> 1) * NBY + (y >> 1)) * NBX + ((x - 2 copy) >> 2)) * 16
+//                                      + ((z & 1) * 2 + (y & 1)) * 4 + ((x - 2 copy) & 3)
+struct CubeView { const float2 *cube; int NBX, NBY, off; unsigned LB; };
 
-__device__ __forceinline__ float2 sample_cube(const CubeView &cv, float X, float Y, float Z) {
-    bool cj = X < 0.f;
-    if (cj) { X = -X; Y = -Y; Z = -Z; }
-    float xf = floorf(X), yf = floorf(Y), zf = floorf(Z);
-    float fx = X - xf, fy = Y - yf, fz = Z - zf;
-    int x0 = (int)xf, y0 = (int)yf + cv.off, z0 = (int)zf + cv.off;
-    const float2 *p = cv.cube + ((size_t)z0 * cv.CY + y0) * cv.CX + x0;
-    const size_t sy = cv.CX, sz = (size_t)cv.CX * cv.CY;
-    // (re0, im0, re1, im1) of the two x taps; 8-byte aligned addresses
-    float2 a0 = p[0], a1 = p[1];
-    float2 b0 = p[sy], b1 = p[sy + 1];
-    float2 c0 = p[sz], c1 = p[sz + 1];
-    float2 d0 = p[sz + sy], d1 = p[sz + sy + 1];
-    float ar = a0.x + fx * (a1.x - a0.x), ai = a0.y + fx * (a1.y - a0.y);
-    float br = b0.x + fx * (b1.x - b0.x), bi = b0.y + fx * (b1.y - b0.y);
-    float cr = c0.x + fx * (c1.x - c0.x), ci = c0.y + fx * (c1.y - c0.y);
-    float dr = d0.x + fx * (d1.x - d0.x), di = d0.y + fx * (d1.y - d0.y);
-    float er = ar + fy * (br - ar), ei = ai + fy * (bi - ai);
-    float gr = cr + fy * (dr - cr), gi = ci + fy * (di - ci);
-    float rr = er + fz * (gr - er), ri = ei + fz * (gi - ei);
-    return make_float2(rr, cj ? -ri : ri);
+__host__ __device__ __forceinline__ size_t cube_element(int NBX, int NBY, unsigned LB, int copy, int x, int y, int z) {
+    const int xs = x - 2 * copy;
+    return (size_t)copy * LB + ((size_t)((z >> 1) * NBY + (y >> 1)) * NBX + (xs >> 2)) * 16 + ((z & 1) * 2 + (y & 1)) * 4 + (xs & 3);
 }
 
-// The same sample split in two, so that the gathers of the NEXT evaluation can be in flight while the current one is
-// interpolated and scored (k_local): the 8 taps as four 16-byte x-pairs plus the interpolation fractions.
+// The 8 taps as four 16-byte x-pairs plus the interpolation fractions: fetch and interpolation are split so that the
+// gathers of the NEXT evaluation can be in flight while the current one is interpolated and scored (k_local).
 struct CubeTaps { float4 a, b, c, d; float fx, fy, fz; bool cj; };
 
 __device__ __forceinline__ CubeTaps cube_fetch(const CubeView &cv, float X, float Y, float Z) {
     CubeTaps t;
-    t.cj = X < 0.f;
+    t.cj = X < 0.f;                                  // Friedel symmetry supplies x < 0
     if (t.cj) { X = -X; Y = -Y; Z = -Z; }
     const float xf = floorf(X), yf = floorf(Y), zf = floorf(Z);
     t.fx = X - xf; t.fy = Y - yf; t.fz = Z - zf;
     const int x0 = (int)xf, y0 = (int)yf + cv.off, z0 = (int)zf + cv.off;
-    const float2 *p = cv.cube + ((size_t)z0 * cv.CY + y0) * cv.CX + x0;
-    const size_t sy = cv.CX, sz = (size_t)cv.CX * cv.CY;
-    const float2 a0 = p[0], a1 = p[1], b0 = p[sy], b1 = p[sy + 1], c0 = p[sz], c1 = p[sz + 1], d0 = p[sz + sy], d1 = p[sz + sy + 1];
+    const bool second = (x0 & 3) == 3;
+    const int xs = second ? x0 - 2 : x0;
+    const unsigned rowb = (unsigned)cv.NBX * 16u, planeb = rowb * (unsigned)cv.NBY;
+    const unsigned xl = (unsigned)(xs >> 2) * 16u + (unsigned)(xs & 3) + (second ? cv.LB : 0u);
+    const unsigned yl0 = (unsigned)(y0 >> 1) * rowb + (unsigned)(y0 & 1) * 4u, yl1 = (y0 & 1) ? (unsigned)((y0 >> 1) + 1) * rowb : yl0 + 4u;
+    const unsigned zl0 = (unsigned)(z0 >> 1) * planeb + (unsigned)(z0 & 1) * 8u, zl1 = (z0 & 1) ? (unsigned)((z0 >> 1) + 1) * planeb : zl0 + 8u;
+    const float2 *pa = cv.cube + (xl + yl0 + zl0), *pb = cv.cube + (xl + yl1 + zl0), *pc = cv.cube + (xl + yl0 + zl1), *pd = cv.cube + (xl + yl1 + zl1);
+    const float2 a0 = pa[0], a1 = pa[1], b0 = pb[0], b1 = pb[1], c0 = pc[0], c1 = pc[1], d0 = pd[0], d1 = pd[1];
     t.a = make_float4(a0.x, a0.y, a1.x, a1.y); t.b = make_float4(b0.x, b0.y, b1.x, b1.y);
     t.c = make_float4(c0.x, c0.y, c1.x, c1.y); t.d = make_float4(d0.x, d0.y, d1.x, d1.y);
     return t;
@@ -236,6 +228,9 @@ __device__ __forceinline__ float2 cube_interp(const CubeTaps &t) {
     const float rr = er + fz * (gr - er), ri = ei + fz * (gi - ei);
     return make_float2(rr, t.cj ? -ri : ri);
 }
+
+// Trilinear sample of the reference cube at Fourier coordinate (X, Y, Z)
+__device__ __forceinline__ float2 sample_cube(const CubeView &cv, float X, float Y, float Z) { return cube_interp(cube_fetch(cv, X, Y, Z)); }
 
 // CTF of one particle: -sin(pi lambda s^2 (df(phi) - Cs lambda^2 s^2 / 2) + phase + amp)
 struct CtfP { float lambda, cs, dsum, ddif, c2a, s2a, extra, inv_na2; };

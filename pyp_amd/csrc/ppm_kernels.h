@@ -62,14 +62,17 @@ __global__ void k_ref_load(const float *__restrict__ vol, float2 *__restrict__ f
     f[i] = make_float2(vol[i] * g, 0.f);
 }
 
-__global__ void k_ref_crop(const float2 *__restrict__ f, float2 *__restrict__ cube, int n, int B, int CX, int CY) {
+__global__ void k_ref_crop(const float2 *__restrict__ f, float2 *__restrict__ cube, int n, int B, int CX, int CY, int NBX, int NBY, unsigned LB) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, tot = (size_t)CX * CY * CY;
     if (i >= tot) return;
-    int x = (int)(i % CX), y = (int)((i / CX) % CY) - (B + 1), z = (int)(i / ((size_t)CX * CY)) - (B + 1);
+    const int x = (int)(i % CX), ys = (int)((i / CX) % CY), zs = (int)(i / ((size_t)CX * CY));      // stored indices
+    const int y = ys - (B + 1), z = zs - (B + 1);
     int iz = ((z % n) + n) % n, iy = ((y % n) + n) % n, ix = x % n;
     float2 v = f[((size_t)iz * n + iy) * n + ix];
     float sg = (((x + y + z) & 1) ? -1.f : 1.f) / (float)n;
-    cube[i] = make_float2(v.x * sg, v.y * sg);
+    v = make_float2(v.x * sg, v.y * sg);
+    cube[cube_element(NBX, NBY, LB, 0, x, ys, zs)] = v;                     // both copies of the blocked layout (ppm_dev.h)
+    if (x >= 2) cube[cube_element(NBX, NBY, LB, 1, x, ys, zs)] = v;
 }
 
 // ---------------------------------------------------------------------------------- pre-processing

@@ -132,7 +132,7 @@ DevBuf<float2> g_prep_spill;     // k_prep: the half spectrum between the row an
 }  // namespace
 
 struct ppm_ref {
-    int N = 0, B = 0, CX = 0, CY = 0;
+    int N = 0, B = 0, CX = 0, CY = 0, NBX = 0, NBY = 0; unsigned LB = 0;
     float2 *cube = nullptr;
     // workspaces (grown on demand, reused across calls)
     DevBuf<double> rows_in, rows_out, dir_theta, dir_phi;
@@ -347,12 +347,17 @@ ppm_ref_t *ppm_reference_create(const float *vol, int n, float max_band_px) {
     ppm_ref *r = new ppm_ref();
     r->N = n; r->B = B; r->CX = B + 2; r->CY = 2 * B + 3;
     size_t cube_n = (size_t)r->CX * r->CY * r->CY;
-    if (hipMalloc(&r->cube, cube_n * sizeof(float2)) != hipSuccess) { fail(-12, "out of device memory for the reference cube"); delete r; return nullptr; }
+    r->NBX = (r->CX + 3) / 4; r->NBY = (r->CY + 1) / 2;
+    const size_t copy_n = (size_t)r->NBX * r->NBY * r->NBY * 16;         // blocked layout, two copies (ppm_dev.h)
+    if (2 * copy_n >= ((size_t)1 << 32)) { fail(-22, "reference cube too large"); delete r; return nullptr; }
+    r->LB = (unsigned)copy_n;
+    if (hipMalloc(&r->cube, 2 * copy_n * sizeof(float2)) != hipSuccess) { fail(-12, "out of device memory for the reference cube"); delete r; return nullptr; }
+    HIPCHKP(hipMemsetAsync(r->cube, 0, 2 * copy_n * sizeof(float2), g.stream));
     {
         ProfScope ps(PPM_K_BANK);
         hipLaunchKernelGGL(k_ref_load, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, g.stream, d_vol, d_f, n);
         if (fft3d(d_f, n, false)) { delete r; return nullptr; }
-        hipLaunchKernelGGL(k_ref_crop, dim3((unsigned)((cube_n + 255) / 256)), dim3(256), 0, g.stream, d_f, r->cube, n, B, r->CX, r->CY);
+        hipLaunchKernelGGL(k_ref_crop, dim3((unsigned)((cube_n + 255) / 256)), dim3(256), 0, g.stream, d_f, r->cube, n, B, r->CX, r->CY, r->NBX, r->NBY, r->LB);
     }
     HIPCHKP(hipStreamSynchronize(g.stream));
     HIPCHKP(hipGetLastError());
@@ -420,7 +425,7 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
     if (int rc = ref->Il.ensure((size_t)CH * S_pad)) return rc;
     if (int rc = ref->cw.ensure((size_t)CH * S_pad)) return rc;
     if (int rc = ref->states2.ensure(CH)) return rc;
-    CubeView cv; cv.cube = ref->cube; cv.CX = ref->CX; cv.CY = ref->CY; cv.off = ref->B + 1;
+    CubeView cv; cv.cube = ref->cube; cv.NBX = ref->NBX; cv.NBY = ref->NBY; cv.LB = ref->LB; cv.off = ref->B + 1;
 
     if (cfg->global_search) {
         if (int rc = ref->Wp.ensure((size_t)CH * HS)) return rc;
