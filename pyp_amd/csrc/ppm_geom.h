@@ -5,6 +5,7 @@
 // (src/pyp/refine/frealign/frealign.py:3918-3994) in Fourier-pixel units; the grid is the
 // build-defined global grid of SURVEY.md §8a K6 (theta = 0..180 step D, n_phi = round(360 sin(theta)/D)).
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -133,7 +134,7 @@ inline void euler_matrix(double psi, double theta, double phi, double M[9]) {
 // straddles two rings.  Packed: kx (9 bits) | ky+256 (10 bits) << 9 | alpha (2 bits) << 19 | ring << 21.
 struct SampleList {
     std::vector<uint32_t> packed;
-    std::vector<int> ring_off;   // ring_off[b] = first sample of ring b; size B+3
+    std::vector<int> ring_off;   // ring_off[b] = length of the list prefix holding all samples of rings < b; size B+3
 };
 
 inline uint32_t pack_sample(int kx, int ky, int alpha, int ring) {
@@ -150,11 +151,25 @@ inline void build_samples(const Geom &g, SampleList &sl) {
         int b = (int)std::floor(std::sqrt(k2));
         rings[b].push_back(pack_sample(kx, ky, kx == 0 ? 1 : 2, b));
     }
+    // List order: bands of kRingBand consecutive rings; inside a band the 16-sample groups (one ring each, ky-ordered = along
+    // the arc) of all its rings are sorted by their angular position, so that the four groups a wavefront takes (64
+    // consecutive entries) form a compact 4 x 16 patch of the slice rather than a 64-sample arc: fewer distinct cache lines
+    // of the reference cube per gather.  ring_off[b] = length of the list prefix that holds every sample of the rings < b
+    // (the end of the band of ring b - 1; samples beyond a band limit are masked individually by the kernels).
+    constexpr int kRingBand = 4;
     sl.packed.clear(); sl.ring_off.assign(B + 3, 0);
-    for (int b = 0; b <= B + 1; b++) {
-        sl.ring_off[b] = (int)sl.packed.size();
-        for (size_t i = 0; i < rings[b].size(); i++) sl.packed.push_back(rings[b][i]);
-        while (sl.packed.size() % 16) sl.packed.push_back(pack_sample(0, 0, 0, b));
+    for (int b0 = 0; b0 <= B + 1; b0 += kRingBand) {
+        struct Grp { double key; int ring; int first; };
+        std::vector<Grp> grps;
+        const int b1 = std::min(b0 + kRingBand - 1, B + 1);
+        for (int b = b0; b <= b1; b++) {
+            while (rings[b].size() % 16) rings[b].push_back(pack_sample(0, 0, 0, b));
+            const int G = (int)rings[b].size() / 16;
+            for (int gidx = 0; gidx < G; gidx++) grps.push_back({ (gidx + 0.5) / G, b, gidx * 16 });
+        }
+        std::stable_sort(grps.begin(), grps.end(), [](const Grp &x, const Grp &y) { return x.key < y.key; });
+        for (const Grp &gr : grps) for (int i = 0; i < 16; i++) sl.packed.push_back(rings[gr.ring][gr.first + i]);
+        for (int b = b0; b <= b1; b++) sl.ring_off[b + 1] = (int)sl.packed.size();
     }
     sl.ring_off[B + 2] = (int)sl.packed.size();
 }

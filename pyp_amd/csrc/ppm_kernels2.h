@@ -89,7 +89,7 @@ __device__ __forceinline__ float group16_sum_dpp(float v) {
 
 // A sweep evaluates `ng` gather groups; group g = one rotation (6 floats) with nv[g] shift variants, the
 // scores of which go to consecutive slots starting at slot0[g].
-struct SweepPlan { float m[kMaxGroup][6]; float sh[kMaxCand][2]; int nv[kMaxGroup]; int slot0[kMaxGroup]; int ng, nslots, S_used; float rmax2; };
+struct SweepPlan { float m[kMaxGroup][6]; float sh[kMaxCand][2]; int nv[kMaxGroup]; int slot0[kMaxGroup]; int ng, nslots, S_used, q_same; float rmax2; };   // slots 0 .. q_same use the shift sh[0]
 
 // Block = one trajectory, 256 threads.  A compass iteration scores the centre and the neighbouring poses in
 // one sweep over the ring-ordered samples (image value and CTF weight loaded once per sample; the centre and
@@ -139,6 +139,14 @@ __global__ void __launch_bounds__(256, 4) k_local(LocalP P) {
                 return cube_fetch(P.cv, m[0] * fkx + m[1] * fky, m[2] * fkx + m[3] * fky, m[4] * fkx + m[5] * fky);
             };
             CubeTaps cur = fetch(0);
+            // the angular neighbours and the centre share one shift (slots 0 .. q_same): one phase factor per sample for all
+            float cs0, sn0;
+            {
+                float rev = -(fkx * plan.sh[0][0] + fky * plan.sh[0][1]) * invN;
+                rev -= floorf(rev);
+                sn0 = __sinf(6.283185307179586f * rev); cs0 = __cosf(6.283185307179586f * rev);
+            }
+            const int q_same = plan.q_same;
             for (int g = 0; g < ng; g++) {
                 CubeTaps nxt = cur;
                 if (g + 1 < ng) nxt = fetch(g + 1);          // the next group's gathers fly while this group is scored
@@ -149,9 +157,12 @@ __global__ void __launch_bounds__(256, 4) k_local(LocalP P) {
                 const int nv = plan.nv[g], q0 = plan.slot0[g];
                 for (int v = 0; v < nv; v++) {
                     const int q = q0 + v;
-                    float rev = -(fkx * plan.sh[q][0] + fky * plan.sh[q][1]) * invN;     // phase in revolutions
-                    rev -= floorf(rev);
-                    float sn = __sinf(6.283185307179586f * rev), cs = __cosf(6.283185307179586f * rev);
+                    float sn = sn0, cs = cs0;
+                    if (q > q_same) {                                    // a shifted probe (wave-uniform branch)
+                        float rev = -(fkx * plan.sh[q][0] + fky * plan.sh[q][1]) * invN;     // phase in revolutions
+                        rev -= floorf(rev);
+                        sn = __sinf(6.283185307179586f * rev); cs = __cosf(6.283185307179586f * rev);
+                    }
                     float mr = pv.x * cs - pv.y * sn, mi = pv.x * sn + pv.y * cs;
                     float av = group16_sum_dpp(ax * mr + ay * mi);
                     if ((lane & 15) == 0) { atomicAdd(&ringA[q][ring], av); atomicAdd(&sumB[q], bv); }
@@ -175,7 +186,7 @@ __global__ void __launch_bounds__(256, 4) k_local(LocalP P) {
     };
     auto single = [&](const double *M, const double *sh) {      // plan for one pose (band fields are set by the caller)
         set_rot(0, M); plan.sh[0][0] = (float)sh[0]; plan.sh[0][1] = (float)sh[1];
-        plan.nv[0] = 1; plan.slot0[0] = 0; plan.ng = 1; plan.nslots = 1;
+        plan.nv[0] = 1; plan.slot0[0] = 0; plan.ng = 1; plan.nslots = 1; plan.q_same = 0;
     };
 
     int nfree = 0;
@@ -213,7 +224,7 @@ __global__ void __launch_bounds__(256, 4) k_local(LocalP P) {
                     }
                 }
                 plan.nv[g] = nv;
-                plan.ng = g + 1; plan.nslots = q; plan.S_used = P.S_it[it]; plan.rmax2 = P.rmax2_it[it];
+                plan.ng = g + 1; plan.nslots = q; plan.q_same = nang; plan.S_used = P.S_it[it]; plan.rmax2 = P.rmax2_it[it];
             }
         }
         __syncthreads();
