@@ -501,22 +501,25 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
         float2 pv[U], pn[U];
 #pragma unroll
         for (int u = 0; u < U; u++) pv[u] = Pp[u * 64 + lane];
-        for (int row0 = 0; row0 < HsP; row0 += U) {
+        // U rows per step; the rows of the next step are prefetched into the other register set (ping-pong: no copies).
+        // B' = Im(P) (Wy, Wx) is accumulated instead of Bq = Im(P) (Wy, -Wx): the sign of the y components of sb, ub, vb is
+        // restored once per slice below.
+        auto step = [&](int row0, const float2 (&cur)[U], float2 (&nxt)[U]) {
             if (row0 + U < HsP) {
-                const float2 *nxt = Pp + (row0 + U) * 64;       // scalar base; the row offsets below fit the 12-bit immediate
+                const float2 *np = Pp + (row0 + U) * 64;        // scalar base; the row offsets below fit the 12-bit immediate
 #pragma unroll
-                for (int u = 0; u < U; u++) pn[u] = nxt[u * 64 + lane];
+                for (int u = 0; u < U; u++) nxt[u] = np[u * 64 + lane];
             }
 #pragma unroll
             for (int u = 0; u < U; u += 2) {
                 const int ra = row0 + u, rb = ra + 1, tp = ra >> 1;
                 const float2 wa = Wl[ra * 64 + lane], wb = Wl[rb * 64 + lane];
                 const float ca = C2l[ra * 64 + lane], cb = C2l[rb * 64 + lane];
-                const float pax = pv[u].x, pay = pv[u].y, pbx = pv[u + 1].x, pby = pv[u + 1].y;
+                const float pax = cur[u].x, pay = cur[u].y, pbx = cur[u + 1].x, pby = cur[u + 1].y;
                 nP = fmaf(ca, fmaf(pax, pax, pay * pay), nP);
                 nP = fmaf(cb, fmaf(pbx, pbx, pby * pby), nP);
-                // A = Re(P) W, Bq = Im(P) (Wy, -Wx) for both rows; even (+) and odd (-) parts of the pair
-                const v2f wav = { wa.x, wa.y }, wbv = { wb.x, wb.y }, waq = { wa.y, -wa.x }, wbq = { wb.y, -wb.x };
+                // A = Re(P) W, B' = Im(P) (Wy, Wx) for both rows; even (+) and odd (-) parts of the pair
+                const v2f wav = { wa.x, wa.y }, wbv = { wb.x, wb.y }, waq = { wa.y, wa.x }, wbq = { wb.y, wb.x };
                 const v2f aa = wav * pax, ab = wbv * pbx, ba = waq * pay, bb = wbq * pby;
                 const v2f as2 = aa + ab, ad2 = aa - ab, bs2 = ba + bb, bd2 = ba - bb;
                 sa += as2; sb += bs2;
@@ -528,15 +531,14 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
                     va[j] += ad2 * ts; vb[j] += bd2 * ts;
                 }
             }
-#pragma unroll
-            for (int u = 0; u < U; u++) pv[u] = pn[u];
-        }
-        const float sax = sa.x, say = sa.y, sbx = sb.x, sby = sb.y;
+        };
+        for (int row0 = 0; row0 < HsP; row0 += 2 * U) { step(row0, pv, pn); step(row0 + U, pn, pv); }      // HsP is a multiple of 2 U
+        const float sax = sa.x, say = sa.y, sbx = sb.x, sby = -sb.y;
         float uax[R], uay[R], ubx[R], uby[R], vax[R], vay[R], vbx[R], vby[R];
 #pragma unroll
         for (int j = 0; j < R; j++) {
-            uax[j] = ua[j].x; uay[j] = ua[j].y; ubx[j] = ub[j].x; uby[j] = ub[j].y;
-            vax[j] = va[j].x; vay[j] = va[j].y; vbx[j] = vb[j].x; vby[j] = vb[j].y;
+            uax[j] = ua[j].x; uay[j] = ua[j].y; ubx[j] = ub[j].x; uby[j] = -ub[j].y;
+            vax[j] = va[j].x; vay[j] = va[j].y; vbx[j] = vb[j].x; vby[j] = -vb[j].y;
         }
         nP = wave_sum(nP);
         const float inv = (nP > 0.f && nI > 0.f) ? rsqrtf(nP * nI) : 0.f;

@@ -407,7 +407,7 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
     const size_t NN = (size_t)gm.N * gm.N, HW = (size_t)gm.H * gm.W, HS = (size_t)gm.Hs * 64;
     const int Rwin = std::max(gm.RSx, gm.RSy);
     // bank rows per slice in the paired order of k_global: row 0 = ky 0, row 1 = empty, rows 2t / 2t+1 = ky +t / -t
-    const int HsP = ((2 * (gm.Bs + 1) + global_unroll(Rwin) - 1) / global_unroll(Rwin)) * global_unroll(Rwin);
+    const int HsP = ((2 * (gm.Bs + 1) + 2 * global_unroll(Rwin) - 1) / (2 * global_unroll(Rwin))) * (2 * global_unroll(Rwin));   // k_global walks 2 U rows per trip
     const size_t HSP = (size_t)HsP * 64;
     const int nslices = gm.n_dir * gm.npsi_store;
     // chunk so that the scratch stays well inside HBM
