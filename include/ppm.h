@@ -120,6 +120,9 @@ const char *ppm_version(void);
 /* vol: n*n*n floats, x fastest. max_band_px: largest Fourier radius (pixels) any later call will
  * use with this reference (<= n/2). */
 ppm_ref_t *ppm_reference_create(const float *vol, int n, float max_band_px);
+/* The same with the "padding factor" answer (refine_iblow, frealign.py:3962): the reference is zero-padded to (pad n)^3 before
+ * its transform, which is then sampled pad times finer (smaller interpolation error).  pad = 1, 2 or 4, pad n <= 512. */
+ppm_ref_t *ppm_reference_create_padded(const float *vol, int n, float max_band_px, int pad);
 void ppm_reference_destroy(ppm_ref_t *ref);
 
 /* images: n_img * box * box floats. images_on_device != 0 means `images` is a device pointer.

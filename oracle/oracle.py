@@ -33,6 +33,8 @@ def lib():
         L = C.CDLL(_SO)
         L.orc_reference_create.restype = C.c_void_p
         L.orc_reference_create.argtypes = [C.c_void_p, C.c_int, C.c_float]
+        L.orc_reference_create_padded.restype = C.c_void_p
+        L.orc_reference_create_padded.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_int]
         L.orc_reference_destroy.argtypes = [C.c_void_p]
         L.orc_refine_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.orc_score_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
@@ -52,10 +54,10 @@ def _p(a):
 
 
 class Reference:
-    def __init__(self, vol, max_band_px):
+    def __init__(self, vol, max_band_px, pad=1):
         vol = np.ascontiguousarray(vol, dtype=np.float32)
         self.n = vol.shape[0]
-        self.h = lib().orc_reference_create(_p(vol), self.n, float(max_band_px))
+        self.h = lib().orc_reference_create_padded(_p(vol), self.n, float(max_band_px), int(pad))
         if not self.h:
             raise RuntimeError("oracle: reference_create failed")
 

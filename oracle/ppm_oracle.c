@@ -211,39 +211,45 @@ static void euler_cols(double psi, double theta, double phi, double m[6]) {
 /* ------------------------------------------------------------------ reference cube */
 /* K1: what refine3d does with answer 4 "input reconstruction" (frealign.py:3923) at padding 1 (answer 35, :3962);
  * the sinc^2 pre-compensation is the real-space counterpart of trilinear interpolation in Fourier space. */
-typedef struct { int N, B, CX, CY; cpx *cube; } oref_t;
+typedef struct { int N, B, CX, CY, pad; cpx *cube; } oref_t;   /* B, CX, CY count samples of the PADDED transform */
 
-void *orc_reference_create(const float *vol, int n, float max_band_px) {
+/* Reference preparation (answers "input reconstruction" and "padding factor" refine_iblow,
+ * frealign.py:3923, :3962): the volume, divided by the sinc^2 envelope of trilinear interpolation, is embedded in the centre
+ * of a (pad n)^3 box of zeros and transformed; the transform is then sampled pad times finer, a slice sample at image
+ * frequency k sits at pad k.  pad = 1, 2 or 4 with pad n <= 512. */
+void *orc_reference_create_padded(const float *vol, int n, float max_band_px, int pad) {
     fft_tables();
-    if (!box_ok(n) || max_band_px <= 0) return NULL;
+    if (!box_ok(n) || max_band_px <= 0 || (pad != 1 && pad != 2 && pad != 4) || n * pad > 512) return NULL;
     if (max_band_px > n / 2) max_band_px = n / 2;
-    int B = (int)ceil(max_band_px) - 1;
-    size_t n3 = (size_t)n * n * n;
-    cpx *f = (cpx *)malloc(n3 * sizeof(cpx));
+    const int np = n * pad, o0 = (np - n) / 2;
+    int B = (int)ceil((double)max_band_px * pad) - 1;
+    if (B > np / 2 - 1) B = np / 2 - 1;
+    size_t n3 = (size_t)np * np * np;
+    cpx *f = (cpx *)calloc(n3, sizeof(cpx));
     if (!f) return NULL;
     /* pre-compensate the trilinear interpolation kernel: divide by sinc^2 along each axis
-     * (the real-space envelope that linear interpolation of the transform imposes) */
+     * (the real-space envelope that linear interpolation of the padded transform imposes) */
     double *sc1 = (double *)malloc(n * sizeof(double));
     for (int i = 0; i < n; i++) {
-        double u = ORC_PI * (double)(i - n / 2) / n, sv = fabs(u) < 1e-12 ? 1.0 : sin(u) / u;
+        double u = ORC_PI * (double)(i - n / 2) / np, sv = fabs(u) < 1e-12 ? 1.0 : sin(u) / u;
         sc1[i] = 1.0 / (sv * sv);
     }
     for (int z = 0; z < n; z++) for (int y = 0; y < n; y++) for (int x = 0; x < n; x++) {
-        size_t i = ((size_t)z * n + y) * n + x;
-        f[i].re = (float)(vol[i] * sc1[x] * sc1[y] * sc1[z]); f[i].im = 0;
+        size_t i = ((size_t)z * n + y) * n + x, o = ((size_t)(z + o0) * np + (y + o0)) * np + (x + o0);
+        f[o].re = (float)(vol[i] * sc1[x] * sc1[y] * sc1[z]); f[o].im = 0;
     }
     free(sc1);
-    for (int z = 0; z < n; z++) for (int y = 0; y < n; y++) fft1d(f + ((size_t)z * n + y) * n, n, 1, 0);
-    for (int z = 0; z < n; z++) for (int x = 0; x < n; x++) fft1d(f + (size_t)z * n * n + x, n, n, 0);
-    for (int y = 0; y < n; y++) for (int x = 0; x < n; x++) fft1d(f + (size_t)y * n + x, n, n * n, 0);
+    for (int z = 0; z < np; z++) for (int y = 0; y < np; y++) fft1d(f + ((size_t)z * np + y) * np, np, 1, 0);
+    for (int z = 0; z < np; z++) for (int x = 0; x < np; x++) fft1d(f + (size_t)z * np * np + x, np, np, 0);
+    for (int y = 0; y < np; y++) for (int x = 0; x < np; x++) fft1d(f + (size_t)y * np + x, np, np * np, 0);
     oref_t *r = (oref_t *)calloc(1, sizeof(oref_t));
-    r->N = n; r->B = B; r->CX = B + 2; r->CY = 2 * B + 3;
+    r->N = n; r->pad = pad; r->B = B; r->CX = B + 2; r->CY = 2 * B + 3;
     r->cube = (cpx *)calloc((size_t)r->CX * r->CY * r->CY, sizeof(cpx));
     double sc = 1.0 / n;
     for (int z = -B - 1; z <= B + 1; z++) for (int y = -B - 1; y <= B + 1; y++) for (int x = 0; x <= B + 1; x++) {
-        int iz = ((z % n) + n) % n, iy = ((y % n) + n) % n, ix = x % n;
-        cpx v = f[((size_t)iz * n + iy) * n + ix];
-        double sg = ((x + y + z) & 1) ? -sc : sc;      /* origin at the box centre */
+        int iz = ((z % np) + np) % np, iy = ((y % np) + np) % np, ix = x % np;
+        cpx v = f[((size_t)iz * np + iy) * np + ix];
+        double sg = ((x + y + z) & 1) ? -sc : sc;      /* origin at the (padded) box centre */
         cpx *o = &r->cube[((size_t)(z + B + 1) * r->CY + (y + B + 1)) * r->CX + x];
         o->re = (float)(v.re * sg); o->im = (float)(v.im * sg);
     }
@@ -251,11 +257,14 @@ void *orc_reference_create(const float *vol, int n, float max_band_px) {
     return r;
 }
 
+void *orc_reference_create(const float *vol, int n, float max_band_px) { return orc_reference_create_padded(vol, n, max_band_px, 1); }
+
 void orc_reference_destroy(void *p) { oref_t *r = (oref_t *)p; if (r) { free(r->cube); free(r); } }
 
 /* trilinear sample of the cube at Fourier coordinate (X,Y,Z) */
 static void sample_cube(const oref_t *r, double X, double Y, double Z, double *ore, double *oim) {
     int conj = 0;
+    X *= r->pad; Y *= r->pad; Z *= r->pad;             /* the padded transform is sampled pad times finer */
     if (X < 0) { X = -X; Y = -Y; Z = -Z; conj = 1; }
     int x0 = (int)floor(X), y0 = (int)floor(Y), z0 = (int)floor(Z);
     double fx = X - x0, fy = Y - y0, fz = Z - z0;
@@ -598,7 +607,7 @@ int orc_refine_batch(void *refp, const ppm_refine_cfg *cfg, const float *images,
     oref_t *r = (oref_t *)refp;
     geom_t g;
     if (!r || geom_init(&g, cfg)) return -22;
-    if (g.B > r->B || r->N != g.N) return -22;
+    if (g.B > (r->B + 1) / r->pad - 1 || r->N != g.N) return -22;
     int K = cfg->top_hits > 0 ? cfg->top_hits : 20; if (K > PPM_MAX_TOP_HITS) K = PPM_MAX_TOP_HITS;
     int Tb = cfg->iters_hit > 0 ? cfg->iters_hit : 2, Tc = cfg->iters_final > 0 ? cfg->iters_final : 7;
     double fall = cfg->mask_falloff > 0 ? cfg->mask_falloff : 20.0;
@@ -717,7 +726,7 @@ int orc_score_batch(void *refp, const ppm_refine_cfg *cfg, const float *images, 
                     const double *rows, double *scores) {
     fft_tables();
     oref_t *r = (oref_t *)refp; geom_t g;
-    if (!r || geom_init(&g, cfg) || g.B > r->B) return -22;
+    if (!r || geom_init(&g, cfg) || g.B > (r->B + 1) / r->pad - 1) return -22;
     double fall = cfg->mask_falloff > 0 ? cfg->mask_falloff : 20.0;
     size_t nb = (size_t)g.H * g.W;
 #pragma omp parallel for schedule(dynamic, 1)
@@ -753,7 +762,7 @@ int orc_band_dims(const ppm_refine_cfg *cfg, int *B, int *n_orient, int *Ns, dou
 /* one reference slice at (psi,theta,phi), band layout, for kernel tests */
 int orc_extract_slice(void *refp, const ppm_refine_cfg *cfg, double psi, double theta, double phi, float *out_band) {
     oref_t *r = (oref_t *)refp; geom_t g;
-    if (!r || geom_init(&g, cfg) || g.B > r->B) return -22;
+    if (!r || geom_init(&g, cfg) || g.B > (r->B + 1) / r->pad - 1) return -22;
     double m[6]; euler_cols(psi, theta, phi, m);
     extract_slice(r, &g, m, g.r_hi, (cpx *)out_band);
     return 0;

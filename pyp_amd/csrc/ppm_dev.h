@@ -186,7 +186,7 @@ __device__ inline void lds_fft256(float2 *buf, int nlines, int lstride, int tid,
 // bricks of the first copy (x0 % 4 == 3).
 //   element(copy, x, y, z) = copy * LB + (((z >> 1) * NBY + (y >> 1)) * NBX + ((x - 2 copy) >> 2)) * 16
 //                                      + ((z & 1) * 2 + (y & 1)) * 4 + ((x - 2 copy) & 3)
-struct CubeView { const float2 *cube; int NBX, NBY, off; unsigned LB; };
+struct CubeView { const float2 *cube; int NBX, NBY, off; unsigned LB; float scale; };   // scale = padding factor: sample k sits at scale k
 
 __host__ __device__ __forceinline__ size_t cube_element(int NBX, int NBY, unsigned LB, int copy, int x, int y, int z) {
     const int xs = x - 2 * copy;
@@ -199,6 +199,7 @@ struct CubeTaps { float4 a, b, c, d; float fx, fy, fz; bool cj; };
 
 __device__ __forceinline__ CubeTaps cube_fetch(const CubeView &cv, float X, float Y, float Z) {
     CubeTaps t;
+    X *= cv.scale; Y *= cv.scale; Z *= cv.scale;
     t.cj = X < 0.f;                                  // Friedel symmetry supplies x < 0
     if (t.cj) { X = -X; Y = -Y; Z = -Z; }
     const float xf = floorf(X), yf = floorf(Y), zf = floorf(Z);

@@ -47,7 +47,8 @@ __global__ void __launch_bounds__(256) k_fft_lines(FftLinesP P) {
 }
 
 // ---------------------------------------------------------------------------------- reference
-__global__ void k_ref_load(const float *__restrict__ vol, float2 *__restrict__ f, int n) {
+// volume / sinc^2 (trilinear pre-compensation at the padded sampling), embedded in the centre of a zeroed (np)^3 box
+__global__ void k_ref_load(const float *__restrict__ vol, float2 *__restrict__ f, int n, int np) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, n3 = (size_t)n * n * n;
     if (i >= n3) return;
     int x = (int)(i % n), y = (int)((i / n) % n), z = (int)(i / ((size_t)n * n));
@@ -55,21 +56,22 @@ __global__ void k_ref_load(const float *__restrict__ vol, float2 *__restrict__ f
     int c[3] = { x, y, z };
 #pragma unroll
     for (int q = 0; q < 3; q++) {
-        float u = kPiF * (float)(c[q] - n / 2) / (float)n;
+        float u = kPiF * (float)(c[q] - n / 2) / (float)np;
         float sv = fabsf(u) < 1e-6f ? 1.f : sinf(u) / u;
         g *= 1.f / (sv * sv);
     }
-    f[i] = make_float2(vol[i] * g, 0.f);
+    const int o0 = (np - n) / 2;
+    f[((size_t)(z + o0) * np + (y + o0)) * np + (x + o0)] = make_float2(vol[i] * g, 0.f);
 }
 
-__global__ void k_ref_crop(const float2 *__restrict__ f, float2 *__restrict__ cube, int n, int B, int CX, int CY, int NBX, int NBY, unsigned LB) {
+__global__ void k_ref_crop(const float2 *__restrict__ f, float2 *__restrict__ cube, int n, int n_orig, int B, int CX, int CY, int NBX, int NBY, unsigned LB) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, tot = (size_t)CX * CY * CY;
     if (i >= tot) return;
     const int x = (int)(i % CX), ys = (int)((i / CX) % CY), zs = (int)(i / ((size_t)CX * CY));      // stored indices
     const int y = ys - (B + 1), z = zs - (B + 1);
     int iz = ((z % n) + n) % n, iy = ((y % n) + n) % n, ix = x % n;
     float2 v = f[((size_t)iz * n + iy) * n + ix];
-    float sg = (((x + y + z) & 1) ? -1.f : 1.f) / (float)n;
+    float sg = (((x + y + z) & 1) ? -1.f : 1.f) / (float)n_orig;
     v = make_float2(v.x * sg, v.y * sg);
     cube[cube_element(NBX, NBY, LB, 0, x, ys, zs)] = v;                     // both copies of the blocked layout (ppm_dev.h)
     if (x >= 2) cube[cube_element(NBX, NBY, LB, 1, x, ys, zs)] = v;

@@ -132,7 +132,7 @@ DevBuf<float2> g_prep_spill;     // k_prep: the half spectrum between the row an
 }  // namespace
 
 struct ppm_ref {
-    int N = 0, B = 0, CX = 0, CY = 0, NBX = 0, NBY = 0; unsigned LB = 0;
+    int N = 0, B = 0, CX = 0, CY = 0, NBX = 0, NBY = 0, pad = 1; unsigned LB = 0;   // B, CX, CY count samples of the padded transform
     float2 *cube = nullptr;
     // workspaces (grown on demand, reused across calls)
     DevBuf<double> rows_in, rows_out, dir_theta, dir_phi;
@@ -334,18 +334,22 @@ int ppm_device_upload(void *dst, const void *src, size_t bytes) { HIPCHK(hipMemc
 int ppm_device_sync(void) { if (g.stream) HIPCHK(hipStreamSynchronize(g.stream)); HIPCHK(hipDeviceSynchronize()); return 0; }
 
 // ------------------------------------------------------------------------------ reference
-ppm_ref_t *ppm_reference_create(const float *vol, int n, float max_band_px) {
+ppm_ref_t *ppm_reference_create_padded(const float *vol, int n, float max_band_px, int pad) {
     if (!g.inited) { fail(-1, "ppm_init has not been called"); return nullptr; }
     if (!vol || !box_ok(n) || !(max_band_px > 0)) { fail(-22, "reference box must be even, 32..512, with prime factors 2, 3, 5, and the band positive"); return nullptr; }
+    if ((pad != 1 && pad != 2 && pad != 4) || n * pad > 512) { fail(-22, "padding factor must be 1, 2 or 4 with padded box <= 512"); return nullptr; }
     if (max_band_px > n / 2) max_band_px = (float)(n / 2);
-    int B = (int)std::ceil(max_band_px) - 1;
-    size_t n3 = (size_t)n * n * n;
+    const int np = n * pad;
+    int B = (int)std::ceil((double)max_band_px * pad) - 1;
+    if (B > np / 2 - 1) B = np / 2 - 1;
+    size_t n3 = (size_t)n * n * n, np3 = (size_t)np * np * np;
     float *d_vol = nullptr; float2 *d_f = nullptr;
     HIPCHKP(hipMalloc(&d_vol, n3 * sizeof(float)));
-    HIPCHKP(hipMalloc(&d_f, n3 * sizeof(float2)));
+    HIPCHKP(hipMalloc(&d_f, np3 * sizeof(float2)));
     HIPCHKP(hipMemcpy(d_vol, vol, n3 * sizeof(float), hipMemcpyHostToDevice));
+    if (pad > 1) HIPCHKP(hipMemsetAsync(d_f, 0, np3 * sizeof(float2), g.stream));
     ppm_ref *r = new ppm_ref();
-    r->N = n; r->B = B; r->CX = B + 2; r->CY = 2 * B + 3;
+    r->N = n; r->pad = pad; r->B = B; r->CX = B + 2; r->CY = 2 * B + 3;
     size_t cube_n = (size_t)r->CX * r->CY * r->CY;
     r->NBX = (r->CX + 3) / 4; r->NBY = (r->CY + 1) / 2;
     const size_t copy_n = (size_t)r->NBX * r->NBY * r->NBY * 16;         // blocked layout, two copies (ppm_dev.h)
@@ -355,15 +359,17 @@ ppm_ref_t *ppm_reference_create(const float *vol, int n, float max_band_px) {
     HIPCHKP(hipMemsetAsync(r->cube, 0, 2 * copy_n * sizeof(float2), g.stream));
     {
         ProfScope ps(PPM_K_BANK);
-        hipLaunchKernelGGL(k_ref_load, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, g.stream, d_vol, d_f, n);
-        if (fft3d(d_f, n, false)) { delete r; return nullptr; }
-        hipLaunchKernelGGL(k_ref_crop, dim3((unsigned)((cube_n + 255) / 256)), dim3(256), 0, g.stream, d_f, r->cube, n, B, r->CX, r->CY, r->NBX, r->NBY, r->LB);
+        hipLaunchKernelGGL(k_ref_load, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, g.stream, d_vol, d_f, n, np);
+        if (fft3d(d_f, np, false)) { delete r; return nullptr; }
+        hipLaunchKernelGGL(k_ref_crop, dim3((unsigned)((cube_n + 255) / 256)), dim3(256), 0, g.stream, d_f, r->cube, np, n, B, r->CX, r->CY, r->NBX, r->NBY, r->LB);
     }
     HIPCHKP(hipStreamSynchronize(g.stream));
     HIPCHKP(hipGetLastError());
     (void)hipFree(d_vol); (void)hipFree(d_f);
     return r;
 }
+
+ppm_ref_t *ppm_reference_create(const float *vol, int n, float max_band_px) { return ppm_reference_create_padded(vol, n, max_band_px, 1); }
 
 void ppm_reference_destroy(ppm_ref_t *r) {
     if (!r) return;
@@ -384,7 +390,7 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
     Geom gm; std::string err;
     if (!geom_init(gm, *cfg, err)) return fail(-22, err);
     if (gm.N != ref->N) return fail(-22, "particle box differs from the reference box");
-    if (gm.B > ref->B) return fail(-22, "high-resolution limit exceeds the band the reference was prepared for");
+    if (gm.B > (ref->B + 1) / ref->pad - 1) return fail(-22, "high-resolution limit exceeds the band the reference was prepared for");
     if (cfg->global_search && gm.Bs + 1 > 64)
         return fail(-22, "global search band wider than 64 Fourier pixels is not supported; lower the 'resolution limit for search'");
     if (!cfg->global_search && !cfg->local_refine) { /* score only */ }
@@ -425,7 +431,7 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
     if (int rc = ref->Il.ensure((size_t)CH * S_pad)) return rc;
     if (int rc = ref->cw.ensure((size_t)CH * S_pad)) return rc;
     if (int rc = ref->states2.ensure(CH)) return rc;
-    CubeView cv; cv.cube = ref->cube; cv.NBX = ref->NBX; cv.NBY = ref->NBY; cv.LB = ref->LB; cv.off = ref->B + 1;
+    CubeView cv; cv.cube = ref->cube; cv.NBX = ref->NBX; cv.NBY = ref->NBY; cv.LB = ref->LB; cv.off = ref->B + 1; cv.scale = (float)ref->pad;
 
     if (cfg->global_search) {
         if (int rc = ref->Wp.ensure((size_t)CH * HS)) return rc;

@@ -106,8 +106,9 @@ def refine3d_main(argv=None, stdin=None):
         print(f"{k:28s}: {v}")
     _unsupported(d, [("use_priors", True), ("calc_match", True), ("mask_2d", True), ("refine_defocus", True),
                      ("exclude_edges", True), ("normalize_reference", True), ("threshold_reference", True)], "refine3d")
-    if abs(d["padding"] - 1.0) > 1e-6:
-        _die("ERROR: refine3d: only padding factor 1 is supported")
+    pad = int(round(d["padding"]))
+    if abs(d["padding"] - pad) > 1e-6 or pad not in (1, 2, 4):
+        _die("ERROR: refine3d: padding factor must be 1, 2 or 4")
     if any(abs(d[k]) > 0 for k in ("focus_x", "focus_y", "focus_z", "focus_r")):
         _die("ERROR: refine3d: focus masks are not supported")
     for p in (d["stack"], d["input_params"], d["reference"]):
@@ -144,7 +145,9 @@ def refine3d_main(argv=None, stdin=None):
     dev = int(os.environ.get("PPM_DEVICE", "0"))
     try:
         with gpu_lock(dev):
-            ref = host.Reference(vol, box / 2, device=dev)
+            if box * pad > 512:
+                _die(f"ERROR: refine3d: padding factor {pad} needs a padded box of {box * pad} > 512")
+            ref = host.Reference(vol, box / 2, device=dev, pad=pad)
             rout = ref.refine(cfg, imgs, rin)
             ref.close()
     except (lib.PpmError, ValueError) as e:

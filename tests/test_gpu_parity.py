@@ -89,6 +89,32 @@ def test_full_refinement_matches_oracle(H, O, n, px, m, step):
     assert ang.max() < ANG_TOL_DEG and shf.max() < SHIFT_TOL_PX
 
 
+@pytest.mark.parametrize("n,px,m,pad", [(64, 2.0, 12, 2), (48, 3.0, 6, 4), (128, 1.5, 6, 2)])
+def test_padded_reference_matches_oracle(H, O, n, px, m, pad):
+    """"padding factor" (refine_iblow): the reference transform sampled pad times finer, oracle and kernels alike."""
+    vol, imgs, rows = dataset(n, m, px, 0.1)
+    g, o = H.Reference(vol, n / 2, pad=pad), O.Reference(vol, n / 2, pad=pad)
+    c = cfg_for(n, px, angular_step=20.0)
+    want, counts = O.refine_batch(o, c, imgs, rows)
+    got = g.refine(c, imgs, rows)
+    ang, shf = synth.angular_error_deg(want, got), synth.shift_error_px(want, got, px)
+    assert ang.max() < ANG_TOL_DEG and shf.max() < SHIFT_TOL_PX
+    assert np.abs(want[:, 14] - got[:, 14]).max() < 0.02
+    # scores at the true poses: padding removes most of the interpolation loss on noise-free images
+    _, clean, truth = synth.make_dataset(n, m, pixel=px, snr=1e6)
+    s1 = H.Reference(vol, n / 2).refine(cfg_for(n, px, global_search=0, local_refine=0), clean.numpy(), truth)[:, 14]
+    s2 = g.refine(cfg_for(n, px, global_search=0, local_refine=0), clean.numpy(), truth)[:, 14]
+    assert s2.mean() > s1.mean()
+
+
+def test_padding_limits_are_loud(H):
+    vol = np.zeros((64, 64, 64), np.float32)
+    with pytest.raises(Exception):
+        H.Reference(vol, 32, pad=3)
+    with pytest.raises(Exception):
+        H.Reference(np.zeros((384, 384, 384), np.float32), 32, pad=2)
+
+
 def test_wide_band_grid_search_is_capped_at_64_pixels(H, O):
     """res_search beyond 64 Fourier pixels: the grid search runs at 64 px, the refinement at the full band (72 px)."""
     n, px = 160, 1.0
