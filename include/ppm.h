@@ -44,6 +44,7 @@ enum {
 
 #define PPM_MAX_SHIFT_STEPS 8 /* half-width of the global-search shift window, in search-grid steps */
 #define PPM_MAX_TOP_HITS 64
+#define PPM_MAX_DEFOCUS_STEPS 20 /* defocus offsets tried on either side when refine_defocus is set */
 
 /* Refinement settings = the numeric answers of the refine3d prompt script
  * (frealign.py:3918-3994; answer numbers as in SURVEY.md §9.1). */
@@ -80,6 +81,11 @@ typedef struct ppm_refine_cfg {
     float band_factor;        /* frequency marching: a compass iteration whose largest probe displacement is d pixels
                                  (mask radius x angular step in radians, or the shift step) scores only rings below
                                  band_factor * N / (2 pi d), capped by the stage's band.  0 = default 3, < 0 = off */
+    int refine_defocus;       /* 45: after the pose, score defocus offsets -range..+range in steps of `defocus_step` at the final
+                                 pose and full band (both DEFOCUS_1 and DEFOCUS_2 move together); the best offset is added to
+                                 the two columns; ties keep the smaller index (0 first) */
+    float defocus_range;      /* 33: Angstrom (the caller passes 500) */
+    float defocus_step;       /* 34: Angstrom (the caller passes 50); at most 20 steps either side */
 } ppm_refine_cfg;
 
 /* Reconstruction settings = numeric answers of the reconstruct3d script (frealign.py:1780-1824). */

@@ -704,6 +704,20 @@ int orc_refine_batch(void *refp, const ppm_refine_cfg *cfg, const float *images,
             if (cfg->local_refine) for (int t = 0; t < Tb + Tc; t++) compass_iter(r, &g, &c, I, wr, g.r_hi, rm_px, bf, en, &best, &nev, &sev);
             best.f = score_local(r, &g, &c, I, wr, g.r_hi, best.M, best.sh); nev++; sev += floor(ORC_PI * g.r_hi * g.r_hi / 2);
         }
+        /* defocus refinement (answers 33, 34, 45; frealign.py:3960-3961, :3978): offsets scored at the final pose */
+        if (cfg->refine_defocus && cfg->defocus_step > 0 && cfg->defocus_range >= cfg->defocus_step) {
+            int nt = (int)floor(cfg->defocus_range / cfg->defocus_step + 1e-6); if (nt > PPM_MAX_DEFOCUS_STEPS) nt = PPM_MAX_DEFOCUS_STEPS;
+            double bestf = best.f; int bt = 0;
+            for (int t = -nt; t <= nt; t++) {
+                if (t == 0) continue;
+                ctf_t c2 = c; c2.df1 += t * (double)cfg->defocus_step; c2.df2 += t * (double)cfg->defocus_step;
+                double f = score_local(r, &g, &c2, I, wr, g.r_hi, best.M, best.sh);
+                nev++; sev += floor(ORC_PI * g.r_hi * g.r_hi / 2);
+                if (f > bestf) { bestf = f; bt = t; }
+            }
+            best.f = bestf;
+            out[PPM_DF1] = row[PPM_DF1] + bt * (double)cfg->defocus_step; out[PPM_DF2] = row[PPM_DF2] + bt * (double)cfg->defocus_step;
+        }
         tot_l += nev; tot_s += sev;
         angles_from_matrix(best.M, &out[PPM_PSI], &out[PPM_THETA], &out[PPM_PHI]);
         out[PPM_XSHIFT] = best.sh[0] * g.a; out[PPM_YSHIFT] = best.sh[1] * g.a;

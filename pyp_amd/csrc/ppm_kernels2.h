@@ -324,8 +324,85 @@ __global__ void k_select_best(const LState *in, LState *out, int n, int K) {
     out[i] = in[(size_t)i * K + b];
 }
 
+// ---------------------------------------------------------------------------------- defocus refinement
+// One block per particle: the projection at the final pose is gathered once per sample; every defocus offset only changes
+// the CTF factor, so all 2 nt + 1 scores come out of one sweep (ring-wise sums per offset in LDS).  Best offset: highest
+// score, the unshifted one on ties, then the lower index (the oracle's scan order).
+struct DefocusP {
+    CubeView cv; const uint32_t *samples; const float2 *Il; const float *wring; int S_pad, nrings, N, B;
+    float rlo2, rmax2, ring_signed, a;
+    const double *rows; LState *states; float *ddef;   // ddef[n]: offset chosen (Angstrom)
+    int nt; float step;
+};
+
+__global__ void __launch_bounds__(256) k_defocus(DefocusP P) {
+    constexpr int MAXT = 2 * PPM_MAX_DEFOCUS_STEPS + 1;
+    extern __shared__ float dsm[];                    // ringA[T][nrings], sumB[T]
+    __shared__ float sumC;
+    __shared__ double score[MAXT];
+    __shared__ CtfP ctf0;
+    __shared__ float m_s[6], sh_s[2];
+    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, T = 2 * P.nt + 1;
+    float *ringA = dsm, *sumB = dsm + T * P.nrings;
+    for (int i = tid; i < T * P.nrings + T; i += 256) dsm[i] = 0.f;
+    if (tid == 0) {
+        const LState &st = P.states[p];
+        sumC = 0.f;
+        ctf0 = ctf_from_row(P.rows + (size_t)p * PPM_NCOL, P.N, (double)P.a);
+        m_s[0] = (float)st.M[0]; m_s[1] = (float)st.M[1]; m_s[2] = (float)st.M[3]; m_s[3] = (float)st.M[4]; m_s[4] = (float)st.M[6]; m_s[5] = (float)st.M[7];
+        sh_s[0] = (float)st.sh[0]; sh_s[1] = (float)st.sh[1];
+    }
+    __syncthreads();
+    const float2 *Il = P.Il + (size_t)p * P.S_pad;
+    const float *wr = P.wring + (size_t)p * (P.B + 2);
+    const float invN = 1.0f / (float)P.N;
+    float accC = 0.f;
+    for (int s0 = 0; s0 < P.S_pad; s0 += 256) {
+        const int s = s0 + tid;
+        int kx = 0, ky = 0, al = 0, ring = 0;
+        float2 iv = make_float2(0.f, 0.f);
+        if (s < P.S_pad) {
+            unpack_sample(P.samples[s], kx, ky, al, ring);
+            const float k2 = (float)(kx * kx + ky * ky);
+            if (!(k2 < P.rmax2 && k2 >= P.rlo2)) al = 0;
+            iv = Il[s];
+        }
+        const float fal = (float)al, fkx = (float)kx, fky = (float)ky;
+        accC += fal * (iv.x * iv.x + iv.y * iv.y);
+        float2 pv = sample_cube(P.cv, m_s[0] * fkx + m_s[1] * fky, m_s[2] * fkx + m_s[3] * fky, m_s[4] * fkx + m_s[5] * fky);
+        float rev = -(fkx * sh_s[0] + fky * sh_s[1]) * invN;
+        rev -= floorf(rev);
+        const float sn = __sinf(6.283185307179586f * rev), cs = __cosf(6.283185307179586f * rev);
+        const float mr = pv.x * cs - pv.y * sn, mi = pv.x * sn + pv.y * cs;
+        const float a0 = fal * (iv.x * mr + iv.y * mi), b0 = fal * (pv.x * pv.x + pv.y * pv.y), wgt = al ? wr[ring] : 0.f;
+        for (int t = 0; t < T; t++) {
+            CtfP c = ctf0;
+            c.dsum += 2.f * (float)(t - P.nt) * P.step;          // both defocus values move by the offset
+            const float ct = ctf_eval(c, kx, ky) * wgt;
+            const float av = group16_sum_dpp(a0 * ct), bv = group16_sum_dpp(b0 * ct * ct);
+            if ((lane & 15) == 0) { atomicAdd(&ringA[t * P.nrings + ring], av); atomicAdd(&sumB[t], bv); }
+        }
+    }
+    accC = wave_sum(accC);
+    if (lane == 0) atomicAdd(&sumC, accC);
+    __syncthreads();
+    if (tid < T) {
+        double sa = 0;
+        for (int b = 0; b < P.nrings; b++) { float a = ringA[tid * P.nrings + b]; sa += ((float)b <= P.ring_signed) ? (double)a : fabs((double)a); }
+        const double sb = sumB[tid], sc = sumC;
+        score[tid] = (sb > 0 && sc > 0) ? sa / sqrt(sb * sc) : 0.0;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int bt = P.nt; double bf = score[P.nt];                  // the unshifted CTF is the incumbent
+        for (int t = 0; t < T; t++) if (t != P.nt && score[t] > bf) { bf = score[t]; bt = t; }
+        P.states[p].f = bf;
+        P.ddef[p] = (float)(bt - P.nt) * P.step;
+    }
+}
+
 __global__ void k_rows_out(const LState *states, const double *rows_in, double *rows_out, int n, double a,
-                           double r_hi, double r_lo) {
+                           double r_hi, double r_lo, const float *ddef) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const LState &s = states[i];
@@ -335,6 +412,7 @@ __global__ void k_rows_out(const LState *states, const double *rows_in, double *
     double psi, th, ph; d_angles(s.M, psi, th, ph);
     o[PPM_PSI] = psi; o[PPM_THETA] = th; o[PPM_PHI] = ph;
     o[PPM_XSHIFT] = s.sh[0] * a; o[PPM_YSHIFT] = s.sh[1] * a;
+    if (ddef) { o[PPM_DF1] = r[PPM_DF1] + (double)ddef[i]; o[PPM_DF2] = r[PPM_DF2] + (double)ddef[i]; }
     double cc = s.f, res = 1.0 - cc * cc; if (res < 1e-6) res = 1e-6;
     o[PPM_SCORE] = 100.0 * cc;
     o[PPM_SIGMA] = sqrt(res);

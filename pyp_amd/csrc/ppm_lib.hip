@@ -136,7 +136,7 @@ struct ppm_ref {
     float2 *cube = nullptr;
     // workspaces (grown on demand, reused across calls)
     DevBuf<double> rows_in, rows_out, dir_theta, dir_phi;
-    DevBuf<float> images, wring, cw, C2, nI, cc, mats;
+    DevBuf<float> images, wring, cw, C2, nI, cc, mats, ddef;
     DevBuf<float2> band, Il, Wp, bank, twN;
     DevBuf<int> sh;
     DevBuf<uint32_t> samples;
@@ -375,7 +375,7 @@ void ppm_reference_destroy(ppm_ref_t *r) {
     if (!r) return;
     if (r->cube) (void)hipFree(r->cube);
     r->rows_in.release(); r->rows_out.release(); r->dir_theta.release(); r->dir_phi.release();
-    r->images.release(); r->wring.release(); r->cw.release(); r->C2.release(); r->nI.release(); r->cc.release(); r->mats.release();
+    r->images.release(); r->wring.release(); r->cw.release(); r->C2.release(); r->nI.release(); r->cc.release(); r->mats.release(); r->ddef.release();
     r->band.release(); r->Il.release(); r->Wp.release(); r->bank.release(); r->twN.release(); r->sh.release(); r->samples.release();
     r->hits.release(); r->states.release(); r->states2.release();
     delete r;
@@ -505,6 +505,9 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
     };
     auto prefix_of = [&](double rband) { int rg = (int)std::ceil(rband); if (rg > gm.B + 1) rg = gm.B + 1; return sl.ring_off[rg]; };
     double sample_evals = 0;   // in-band samples summed over all local score evaluations of one particle
+    int ndef = 0;              // defocus offsets tried on either side of the row's values
+    if (cfg->refine_defocus && cfg->defocus_step > 0 && cfg->defocus_range >= cfg->defocus_step)
+        ndef = std::min((int)std::floor(cfg->defocus_range / cfg->defocus_step + 1e-6), PPM_MAX_DEFOCUS_STEPS);
     LocalP LP;
     LP.cv = cv; LP.samples = ref->samples.p; LP.Il = ref->Il.p; LP.cw = ref->cw.p; LP.S_pad = S_pad; LP.nrings = nrings; LP.N = gm.N;
     LP.rlo2 = (float)(gm.r_lo * gm.r_lo); LP.ring_signed = (float)std::min(gm.ring_signed, 1e30);
@@ -579,7 +582,19 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
             ProfScope ps(PPM_K_LOCAL);
             hipLaunchKernelGGL(k_local, dim3(nb), dim3(256), 0, g.stream, LP);
         }
-        hipLaunchKernelGGL(k_rows_out, dim3((nb + 255) / 256), dim3(256), 0, g.stream, final_states, ref->rows_in.p, ref->rows_out.p, nb, gm.a, gm.r_hi, gm.r_lo);
+        const float *d_ddef = nullptr;
+        if (ndef > 0) {                                 // defocus offsets at the final pose
+            if (int rc = ref->ddef.ensure(CH)) return rc;
+            DefocusP DP;
+            DP.cv = cv; DP.samples = ref->samples.p; DP.Il = ref->Il.p; DP.wring = ref->wring.p; DP.S_pad = S_pad; DP.nrings = nrings; DP.N = gm.N; DP.B = gm.B;
+            DP.rlo2 = (float)(gm.r_lo * gm.r_lo); DP.rmax2 = (float)(gm.r_hi * gm.r_hi); DP.ring_signed = LP.ring_signed; DP.a = (float)gm.a;
+            DP.rows = ref->rows_in.p; DP.states = final_states; DP.ddef = ref->ddef.p; DP.nt = ndef; DP.step = cfg->defocus_step;
+            const int T = 2 * ndef + 1;
+            ProfScope ps(PPM_K_LOCAL);
+            hipLaunchKernelGGL(k_defocus, dim3(nb), dim3(256), (size_t)(T * nrings + T) * sizeof(float), g.stream, DP);
+            d_ddef = ref->ddef.p;
+        }
+        hipLaunchKernelGGL(k_rows_out, dim3((nb + 255) / 256), dim3(256), 0, g.stream, final_states, ref->rows_in.p, ref->rows_out.p, nb, gm.a, gm.r_hi, gm.r_lo, d_ddef);
         HIPCHK(hipGetLastError());
         if (!images_on_device && c0 + CH < n_img) {     // next chunk's images travel while this chunk computes
             const int nn = std::min(CH, n_img - (c0 + CH));
@@ -595,6 +610,8 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
     if (cfg->global_search) nl = cfg->local_refine ? (long)K * Tb * per_iter + (long)Tc * per_iter + 1 : 0;
     else nl = 1 + (cfg->local_refine ? (long)(Tb + Tc) * per_iter : 0);
     ref->last_counts[0] = cfg->global_search ? gm.n_orient : 0;
+    nl += 2L * ndef;
+    sample_evals += 2.0 * ndef * std::floor(kPi * gm.r_hi * gm.r_hi / 2);
     ref->last_counts[1] = nl;
     ref->last_counts[2] = (long)std::floor(kPi * gm.r_s * gm.r_s / 2);
     ref->last_counts[3] = (long)sample_evals;      // sum over the local evaluations of their in-band sample counts

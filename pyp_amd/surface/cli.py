@@ -104,7 +104,7 @@ def refine3d_main(argv=None, stdin=None):
     print("\n        **   Welcome to Refine3D (MI355X / libpypmatch)   **\n")
     for k, v in d.items():
         print(f"{k:28s}: {v}")
-    _unsupported(d, [("use_priors", True), ("calc_match", True), ("mask_2d", True), ("refine_defocus", True),
+    _unsupported(d, [("use_priors", True), ("calc_match", True), ("mask_2d", True),
                      ("exclude_edges", True), ("normalize_reference", True), ("threshold_reference", True)], "refine3d")
     pad = int(round(d["padding"]))
     if abs(d["padding"] - pad) > 1e-6 or pad not in (1, 2, 4):
@@ -140,7 +140,8 @@ def refine3d_main(argv=None, stdin=None):
         search_range_y=d["search_range_y"], global_search=int(d["global_search"]), local_refine=int(d["local_refine"]),
         refine_psi=int(d["refine_psi"]), refine_theta=int(d["refine_theta"]), refine_phi=int(d["refine_phi"]),
         refine_x=int(d["refine_x"]), refine_y=int(d["refine_y"]), normalize=int(d["normalize"]), invert=int(d["invert"]),
-        symmetry=d["symmetry"][:7])
+        symmetry=d["symmetry"][:7], refine_defocus=int(d["refine_defocus"]), defocus_range=d["defocus_range"],
+        defocus_step=d["defocus_step"])
     from .. import host, lib
     dev = int(os.environ.get("PPM_DEVICE", "0"))
     try:

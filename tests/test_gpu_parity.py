@@ -107,6 +107,28 @@ def test_padded_reference_matches_oracle(H, O, n, px, m, pad):
     assert s2.mean() > s1.mean()
 
 
+def test_defocus_refinement_matches_oracle_and_recovers_offsets(H, O):
+    """answers 33 / 34 / 45: defocus offsets scored at the final pose.  Rows start 200 A off their true defocus."""
+    n, px, m = 96, 1.5, 12
+    vol, stack, truth = synth.make_dataset(n, m, pixel=px, snr=0.5)
+    imgs = stack.numpy()
+    rows = truth.copy(); rows[:, 6] += 200.0; rows[:, 7] += 200.0
+    c = cfg_for(n, px, global_search=0, refine_defocus=1, defocus_range=400.0, defocus_step=50.0, res_high=2.2 * px)
+    o, g = O.Reference(vol, n / 2), H.Reference(vol, n / 2)
+    want, cw = O.refine_batch(o, c, imgs, rows)
+    got = g.refine(c, imgs, rows)
+    lc = g.last_counts()
+    assert (lc["n_local"], lc["samples_local"]) == (cw[1], cw[2])
+    same = np.abs(want[:, 6] - got[:, 6]) < 1e-6
+    assert same.mean() >= 0.9 and np.abs(want[:, 6] - got[:, 6]).max() <= 50.0 + 1e-6         # at most one step apart, rarely
+    assert np.allclose(got[:, 7] - rows[:, 7], got[:, 6] - rows[:, 6])
+    assert np.abs(want[:, 14] - got[:, 14]).max() < 0.05
+    err = np.abs(got[:, 6] - truth[:, 6])
+    assert np.median(err) <= 50.0 and (err <= 100.0).mean() >= 0.8                           # back to the truth within the grid
+    off = g.refine(cfg_for(n, px, global_search=0, res_high=2.2 * px), imgs, rows)
+    assert np.array_equal(off[:, 6], rows[:, 6]) and (got[:, 14] >= off[:, 14] - 1e-3).all()
+
+
 def test_padding_limits_are_loud(H):
     vol = np.zeros((64, 64, 64), np.float32)
     with pytest.raises(Exception):
