@@ -131,9 +131,15 @@ def test_reconstruct_merge_pipeline(project):
 def test_unsupported_options_fail_loudly(project):
     d, vol, imgs, truth, start = project
     s = refine_script(1, 10, True, out="bad_out.cistem").split("\n")
-    s[44] = "yes"                                     # refine defocus
+    s[6] = "yes"                                      # use priors
     assert run("refine3d", "\n".join(s), d, "bad.log") != 0
     assert "ERROR" in open(d / "bad.log").read() and not (d / "bad_out.cistem").exists()
+    s = refine_script(1, 10, True, out="def_out.cistem").split("\n")
+    s[44] = "yes"                                     # refine defocus: supported, columns 6 / 7 move on the 50 A grid
+    assert run("refine3d", "\n".join(s), d, "def.log") == 0 and (d / "def_out.cistem").exists()
+    got = cistem.read_parameters(str(d / "def_out.cistem"))
+    delta = got[:, 6] - start[:10, 6]
+    assert np.allclose(delta, np.round(delta / 50.0) * 50.0, atol=1e-2) and np.allclose(got[:, 7] - start[:10, 7], delta, atol=1e-2)
 
 
 @pytest.mark.gpu
