@@ -696,32 +696,50 @@ __global__ void k_fold_plane(const float *__restrict__ src, float *__restrict__ 
 }
 
 // pass 1: shell sums of the weights.  sums: [4][ns] = den1, den2, count, den1+den2
-__global__ void k_shell_den(const float *__restrict__ acc, double *sums, int N) {
+// (both shell passes first add up per block in LDS and then issue one global atomic per shell the block touched: a global
+// double atomic per voxel into <= 256 addresses serialised the whole pass)
+__global__ void __launch_bounds__(256) k_shell_den(const float *__restrict__ acc, double *sums, int N) {
+    __shared__ double part[4 * 256];
+    const int ns = N / 2, tid = threadIdx.x;
+    for (int k = tid; k < 4 * ns; k += 256) part[k] = 0.0;
+    __syncthreads();
     size_t NX = N / 2 + 1, tot = (size_t)N * N * NX, half_sz = tot * 3;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= tot) return;
-    int x = (int)(i % NX), y = (int)((i / NX) % N) - N / 2, z = (int)(i / (NX * N)) - N / 2;
-    int ns = N / 2, b = (int)floorf(sqrtf((float)(x * x + y * y + z * z)) + 0.5f);
-    if (b >= ns) return;
-    double al = x == 0 ? 1.0 : 2.0;
-    double d1 = acc[i * 3 + 2], d2 = acc[half_sz + i * 3 + 2];
-    atomicAdd(&sums[b], al * d1); atomicAdd(&sums[ns + b], al * d2); atomicAdd(&sums[2 * ns + b], al); atomicAdd(&sums[3 * ns + b], al * (d1 + d2));
+    if (i < tot) {
+        int x = (int)(i % NX), y = (int)((i / NX) % N) - N / 2, z = (int)(i / (NX * N)) - N / 2;
+        int b = (int)floorf(sqrtf((float)(x * x + y * y + z * z)) + 0.5f);
+        if (b < ns) {
+            double al = x == 0 ? 1.0 : 2.0;
+            double d1 = acc[i * 3 + 2], d2 = acc[half_sz + i * 3 + 2];
+            atomicAdd(&part[b], al * d1); atomicAdd(&part[ns + b], al * d2); atomicAdd(&part[2 * ns + b], al); atomicAdd(&part[3 * ns + b], al * (d1 + d2));
+        }
+    }
+    __syncthreads();
+    for (int k = tid; k < 4 * ns; k += 256) if (part[k] != 0.0) atomicAdd(&sums[k], part[k]);
 }
 
 // pass 2: FSC sums between the two halves.  fsc: [3][ns] = c12, c11, c22
-__global__ void k_shell_fsc(const float *__restrict__ acc, const double *sums, double *fsc, int N) {
+__global__ void __launch_bounds__(256) k_shell_fsc(const float *__restrict__ acc, const double *sums, double *fsc, int N) {
+    __shared__ double part[3 * 256];
+    const int ns = N / 2, tid = threadIdx.x;
+    for (int k = tid; k < 3 * ns; k += 256) part[k] = 0.0;
+    __syncthreads();
     size_t NX = N / 2 + 1, tot = (size_t)N * N * NX, half_sz = tot * 3;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= tot) return;
-    int x = (int)(i % NX), y = (int)((i / NX) % N) - N / 2, z = (int)(i / (NX * N)) - N / 2;
-    int ns = N / 2, b = (int)floorf(sqrtf((float)(x * x + y * y + z * z)) + 0.5f);
-    if (b >= ns) return;
-    double cnt = sums[2 * ns + b];
-    double e1 = 1e-3 * sums[b] / cnt + 1e-20, e2 = 1e-3 * sums[ns + b] / cnt + 1e-20;
-    double d1 = acc[i * 3 + 2] + e1, d2 = acc[half_sz + i * 3 + 2] + e2;
-    double ar = acc[i * 3] / d1, ai = acc[i * 3 + 1] / d1, br = acc[half_sz + i * 3] / d2, bi = acc[half_sz + i * 3 + 1] / d2;
-    double al = x == 0 ? 1.0 : 2.0;
-    atomicAdd(&fsc[b], al * (ar * br + ai * bi)); atomicAdd(&fsc[ns + b], al * (ar * ar + ai * ai)); atomicAdd(&fsc[2 * ns + b], al * (br * br + bi * bi));
+    if (i < tot) {
+        int x = (int)(i % NX), y = (int)((i / NX) % N) - N / 2, z = (int)(i / (NX * N)) - N / 2;
+        int b = (int)floorf(sqrtf((float)(x * x + y * y + z * z)) + 0.5f);
+        if (b < ns) {
+            double cnt = sums[2 * ns + b];
+            double e1 = 1e-3 * sums[b] / cnt + 1e-20, e2 = 1e-3 * sums[ns + b] / cnt + 1e-20;
+            double d1 = acc[i * 3 + 2] + e1, d2 = acc[half_sz + i * 3 + 2] + e2;
+            double ar = acc[i * 3] / d1, ai = acc[i * 3 + 1] / d1, br = acc[half_sz + i * 3] / d2, bi = acc[half_sz + i * 3 + 1] / d2;
+            double al = x == 0 ? 1.0 : 2.0;
+            atomicAdd(&part[b], al * (ar * br + ai * bi)); atomicAdd(&part[ns + b], al * (ar * ar + ai * ai)); atomicAdd(&part[2 * ns + b], al * (br * br + bi * bi));
+        }
+    }
+    __syncthreads();
+    for (int k = tid; k < 3 * ns; k += 256) if (part[k] != 0.0) atomicAdd(&fsc[k], part[k]);
 }
 
 // Wiener division into a full N^3 complex spectrum in FFT order (which: 0/1 = half maps, 2 = sum)
