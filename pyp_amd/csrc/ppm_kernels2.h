@@ -10,10 +10,16 @@ struct LState { double M[9]; double sh[2]; double f, ha, hs; int particle; int p
 
 __device__ inline void d_mat_mul3(const double *a, const double *b, double *c) {
     double t[9];
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
-        double v = 0; for (int k = 0; k < 3; k++) v += a[i * 3 + k] * b[k * 3 + j];
-        t[i * 3 + j] = v;
-    }
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            double v = 0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) v += a[i * 3 + k] * b[k * 3 + j];
+            t[i * 3 + j] = v;
+        }
+#pragma unroll
     for (int i = 0; i < 9; i++) c[i] = t[i];
 }
 
@@ -41,18 +47,25 @@ __device__ inline void d_angles(const double *M, double &psi, double &theta, dou
 
 // which: 0 = in-plane (psi), 1 / 2 = tilt about image x / y when tilt_frame, else theta / phi Euler steps.
 // The three image-frame steps are right-multiplications by Rz / Rx / Ry: plain column mixes.
+// (column indices are compile-time constants: with run-time indices the 3 x 3 temporaries lived in scratch memory, ~1.2 MB
+// of scratch traffic per particle from the serial set-up sections)
+template <int A, int B, int K>
+__device__ __forceinline__ void d_col_mix(const double *M, double s, double c, double *out) {
+    // M R with R rotating the (A, B) coordinate pair: out[:,A] = c M[:,A] + s M[:,B], out[:,B] = -s M[:,A] + c M[:,B]
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const double ma = M[r * 3 + A], mb = M[r * 3 + B];
+        out[r * 3 + A] = ma * c + mb * s;
+        out[r * 3 + B] = mb * c - ma * s;
+        out[r * 3 + K] = M[r * 3 + K];
+    }
+}
 __device__ inline void d_rot_step(const double *M, int which, int tilt_frame, double hdeg, double *out) {
     double s, c;
     sincos(hdeg * 3.14159265358979323846 / 180.0, &s, &c);
-    if (which == 0 || tilt_frame) {
-        const int a = which == 0 ? 0 : (which == 1 ? 1 : 2), b = which == 0 ? 1 : (which == 1 ? 2 : 0), keep = 3 - a - b;
-        // M R with R rotating the (a, b) coordinate pair: out[:,a] = c M[:,a] + s M[:,b], out[:,b] = -s M[:,a] + c M[:,b]
-        for (int r = 0; r < 3; r++) {
-            const double ma = M[r * 3 + a], mb = M[r * 3 + b];
-            out[r * 3 + a] = ma * c + mb * s;
-            out[r * 3 + b] = mb * c - ma * s;
-            out[r * 3 + keep] = M[r * 3 + keep];
-        }
+    if (which == 0) { d_col_mix<0, 1, 2>(M, s, c, out); return; }
+    if (tilt_frame) {
+        if (which == 1) d_col_mix<1, 2, 0>(M, s, c, out); else d_col_mix<2, 0, 1>(M, s, c, out);
         return;
     }
     if (which == 2) { double r[9] = { c, -s, 0, s, c, 0, 0, 0, 1 }; d_mat_mul3(r, M, out); return; }
