@@ -171,11 +171,11 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(kernel, particles_per_launch):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc summary (separate FETCH_SIZE and
-    WRITE_SIZE passes; units of 1 KB; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), scaled from
-    the profiled particle count to this launch.  None when no summary is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_final_pmc_summary_8k.json")
+def pmc_traffic(kernel, particles_per_launch, summary="r01_final5_pmc_traffic_refine_8k.json", profiled=8000):
+    """HBM-side bytes per launch of `kernel` from a committed rocprofv3 --pmc summary (scripts/pmc_traffic.sh: FETCH_SIZE and
+    WRITE_SIZE in separate passes; units of 1 KB; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), scaled
+    from the profiled particle count to this launch.  None when no summary is committed."""
+    path = os.path.join(ROOT, "profiles", summary)
     if not os.path.exists(path):
         return None, None
     d = json.load(open(path))
@@ -183,8 +183,8 @@ def pmc_traffic(kernel, particles_per_launch):
     if not key or "FETCH_SIZE" not in d[key[0]] or "WRITE_SIZE" not in d[key[0]]:
         return None, None
     e = d[key[0]]
-    per_particle = (2.0 * e["FETCH_SIZE"]["sum"] + e["WRITE_SIZE"]["sum"]) * 1024.0 / 8000.0
-    return per_particle * particles_per_launch, "profiles/r01_final_pmc_summary_8k.json (8000 particles, FETCH_SIZE x2 + WRITE_SIZE, KB)"
+    per_particle = (2.0 * e["FETCH_SIZE"]["sum"] + e["WRITE_SIZE"]["sum"]) * 1024.0 / profiled
+    return per_particle * particles_per_launch, "profiles/%s (%d particles, FETCH_SIZE x2 + WRITE_SIZE, KB)" % (summary, profiled)
 
 
 def reconstruct_bench(a, rank, world, local, dev, vol, stack, rows, N, M, px):
@@ -239,6 +239,7 @@ def reconstruct_bench(a, rank, world, local, dev, vol, stack, rows, N, M, px):
         nl = max(prof["insert"]["launches"], 1)
         ms = prof["insert"]["ms"] / nl
         achieved = (M * a.steps / nl) * (S * 192.0) / (ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic("k_insert_bricks", M * a.steps / nl, "r01_final5_pmc_traffic_reconstruct_16k.json", 16000)
         acc.set_counts(counts[0], counts[1])
         h1, h2, fl, stats = acc.finalize(FinalCfg(molecular_mass_kda=500.0, inner_radius=0.0, outer_radius=0.45 * N * px, mask_falloff=0.0))
         cc = float(np.corrcoef(fl.ravel(), vol.ravel())[0, 1])
@@ -248,11 +249,11 @@ def reconstruct_bench(a, rank, world, local, dev, vol, stack, rows, N, M, px):
                 "config": {"workload": "3D reconstruction: Fourier-insert %dk %d^2 particles/GPU -> %d^3 half-maps, C1, one all-reduce"
                            % (M // 1000, N, N), "particles_per_gpu": M, "box": N, "parallelism": "particle-sharded x%d" % world},
                 "roofline": {"bound": "hbm", "kernel": "k_insert_bricks", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                             "frac": round(achieved / 8000.0, 4), "traffic": None, "avg_launch_ms": round(ms, 3),
+                             "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(ms, 3),
                              "note": "algorithmic bytes (SURVEY 8d) = S(N/2) x 8 taps x 12 B x 2 (read-modify-write) per particle, i.e. what a "
                                      "scatter into HBM would move; k_insert_bricks keeps 16^3-voxel bricks of the accumulator in LDS "
                                      "(64-bit fixed point, ds_add_u64) and touches HBM once per brick and launch, so its real HBM traffic "
-                                     "is far below that figure and the kernel is VALU / LDS-atomic bound (profiles/r01_bricks_pmc_reconstruct_8k.json)",
+                                     "is far below that figure (see traffic) and the kernel is VALU / LDS-atomic bound (profiles/r01_bricks_pmc_reconstruct_8k.json)",
                              "path_bytes_per_particle": b_ins},
                 "kernels_ms": {k2: round(v["ms"], 2) for k2, v in prof.items() if v["launches"]},
                 "map_cc_vs_truth": round(cc, 4), "fsc_at_half_nyquist": round(float(stats[N // 4 - 1, 3]), 4)}
