@@ -504,8 +504,8 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
 #pragma unroll
         for (int u = 0; u < U; u++) pv[u] = Pp[u * 64 + lane];
         // U rows per step; the rows of the next step are prefetched into the other register set (ping-pong: no copies).
-        // B' = Im(P) (Wy, Wx) is accumulated instead of Bq = Im(P) (Wy, -Wx): the sign of the y components of sb, ub, vb is
-        // restored once per slice below.
+        // B = Im(P) (Wx, Wy) is accumulated instead of Bq = Im(P) (Wy, -Wx) (no swizzled copy of W per row): component swap
+        // and sign commute with the row sums and are applied once per slice below (Bq.x = B.y, Bq.y = -B.x).
         auto step = [&](int row0, const float2 (&cur)[U], float2 (&nxt)[U]) {
             if (row0 + U < HsP) {
                 const float2 *np = Pp + (row0 + U) * 64;        // scalar base; the row offsets below fit the 12-bit immediate
@@ -520,9 +520,9 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
                 const float pax = cur[u].x, pay = cur[u].y, pbx = cur[u + 1].x, pby = cur[u + 1].y;
                 nP = fmaf(ca, fmaf(pax, pax, pay * pay), nP);
                 nP = fmaf(cb, fmaf(pbx, pbx, pby * pby), nP);
-                // A = Re(P) W, B' = Im(P) (Wy, Wx) for both rows; even (+) and odd (-) parts of the pair
-                const v2f wav = { wa.x, wa.y }, wbv = { wb.x, wb.y }, waq = { wa.y, wa.x }, wbq = { wb.y, wb.x };
-                const v2f aa = wav * pax, ab = wbv * pbx, ba = waq * pay, bb = wbq * pby;
+                // A = Re(P) W, B = Im(P) W for both rows; even (+) and odd (-) parts of the pair
+                const v2f wav = { wa.x, wa.y }, wbv = { wb.x, wb.y };
+                const v2f aa = wav * pax, ab = wbv * pbx, ba = wav * pay, bb = wbv * pby;
                 const v2f as2 = aa + ab, ad2 = aa - ab, bs2 = ba + bb, bd2 = ba - bb;
                 sa += as2; sb += bs2;
 #pragma unroll
@@ -535,12 +535,12 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
             }
         };
         for (int row0 = 0; row0 < HsP; row0 += 2 * U) { step(row0, pv, pn); step(row0 + U, pn, pv); }      // HsP is a multiple of 2 U
-        const float sax = sa.x, say = sa.y, sbx = sb.x, sby = -sb.y;
+        const float sax = sa.x, say = sa.y, sbx = sb.y, sby = -sb.x;
         float uax[R], uay[R], ubx[R], uby[R], vax[R], vay[R], vbx[R], vby[R];
 #pragma unroll
         for (int j = 0; j < R; j++) {
-            uax[j] = ua[j].x; uay[j] = ua[j].y; ubx[j] = ub[j].x; uby[j] = -ub[j].y;
-            vax[j] = va[j].x; vay[j] = va[j].y; vbx[j] = vb[j].x; vby[j] = -vb[j].y;
+            uax[j] = ua[j].x; uay[j] = ua[j].y; ubx[j] = ub[j].y; uby[j] = -ub[j].x;
+            vax[j] = va[j].x; vay[j] = va[j].y; vbx[j] = vb[j].y; vby[j] = -vb[j].x;
         }
         nP = wave_sum(nP);
         const float inv = (nP > 0.f && nI > 0.f) ? rsqrtf(nP * nI) : 0.f;
