@@ -512,9 +512,17 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
 #pragma unroll
                 for (int u = 0; u < U; u++) nxt[u] = np[u * 64 + lane];
             }
+            // the (wave-uniform) twiddles of the NEXT row pair are requested before this pair is consumed
+            float4 tw[R], twn[R];
+#pragma unroll
+            for (int j = 0; j < R; j++) tw[j] = c_rowtw[(row0 >> 1) * PPM_MAX_SHIFT_STEPS + j];
 #pragma unroll
             for (int u = 0; u < U; u += 2) {
                 const int ra = row0 + u, rb = ra + 1, tp = ra >> 1;
+                if (u + 2 < U) {
+#pragma unroll
+                    for (int j = 0; j < R; j++) twn[j] = c_rowtw[(tp + 1) * PPM_MAX_SHIFT_STEPS + j];
+                }
                 const float2 wa = Wl[ra * 64 + lane], wb = Wl[rb * 64 + lane];
                 const float ca = C2l[ra * 64 + lane], cb = C2l[rb * 64 + lane];
                 const float pax = cur[u].x, pay = cur[u].y, pbx = cur[u + 1].x, pby = cur[u + 1].y;
@@ -527,11 +535,13 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
                 sa += as2; sb += bs2;
 #pragma unroll
                 for (int j = 0; j < R; j++) {
-                    const float4 t = c_rowtw[tp * PPM_MAX_SHIFT_STEPS + j];     // wave-uniform -> SGPRs {c, c, s, s}
+                    const float4 t = tw[j];                                       // wave-uniform -> SGPRs {c, c, s, s}
                     const v2f tc = { t.x, t.y }, ts = { t.z, t.w };
                     ua[j] += as2 * tc; ub[j] += bs2 * tc;
                     va[j] += ad2 * ts; vb[j] += bd2 * ts;
                 }
+#pragma unroll
+                for (int j = 0; j < R; j++) tw[j] = twn[j];
             }
         };
         for (int row0 = 0; row0 < HsP; row0 += 2 * U) { step(row0, pv, pn); step(row0 + U, pn, pv); }      // HsP is a multiple of 2 U
