@@ -419,8 +419,9 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
     // chunk so that the scratch stays well inside HBM
     size_t per = NN * 4 + HW * 8 + (size_t)S_pad * 12 + 2 * PPM_NCOL * 8 + (gm.B + 2) * 4;
     if (cfg->global_search) per += HS * 12 + (size_t)gm.n_orient * 8 + (size_t)K * (sizeof(Hit) + sizeof(LState)) + sizeof(LState);
-    int CH = (int)std::min<size_t>((size_t)n_img, std::max<size_t>(64, ((size_t)3 << 30) / per));
+    int CH = (int)std::min<size_t>((size_t)n_img, std::max<size_t>(64, ((size_t)4 << 30) / per));
     CH = std::min(CH, 8192);
+    if (CH >= 2048) CH &= ~1023;        // whole rounds of blocks: 256 CUs x 1 (k_global) and x 4 (k_local, one block per particle)
     if (const char *e = std::getenv("PPM_CHUNK")) { int v = std::atoi(e); if (v > 0) CH = std::min(CH, v); }   // tests: force several chunks
 
     if (int rc = ref->rows_in.ensure((size_t)CH * PPM_NCOL)) return rc;
