@@ -126,6 +126,13 @@ def test_reconstruct_merge_pipeline(project):
         return float((a * b).sum() / np.sqrt((a * a).sum() * (b * b).sum()))
     assert cc(m, vol) > 0.85
     assert cc(mrc.read(str(d / "p_half1.mrc")), mrc.read(str(d / "p_half2.mrc"))) > 0.8
+    # next iteration the way PYP runs it by default (refine_fssnr true): the merged map as the reference, "use statistics" yes
+    mrc.write(m, str(d / "p_r02.mrc"), pixel_size=PX)
+    s = refine_script(1, 30, True, out="p_r02_0000001_0000030.cistem").split("\n")
+    s[3], s[4], s[5] = "p_r02.mrc", "p_statistics.txt", "yes"
+    assert run("refine3d", "\n".join(s), d, "refine2.log") == 0 and "Normal termination" in open(d / "refine2.log").read()
+    r2 = cistem.read_parameters(str(d / "p_r02_0000001_0000030.cistem"))
+    assert np.median(synth.angular_error_deg(r2, truth[:30])) < 3.0
 
 
 def test_unsupported_options_fail_loudly(project):
