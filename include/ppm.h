@@ -129,6 +129,9 @@ ppm_ref_t *ppm_reference_create(const float *vol, int n, float max_band_px);
 /* The same with the "padding factor" answer (refine_iblow, frealign.py:3962): the reference is zero-padded to (pad n)^3 before
  * its transform, which is then sampled pad times finer (smaller interpolation error).  pad = 1, 2 or 4, pad n <= 512. */
 ppm_ref_t *ppm_reference_create_padded(const float *vol, int n, float max_band_px, int pad);
+/* ... and with the "use statistics" answer (6, frealign.py:3903-3910): ring_weight[k], k = 0 .. n_weight-1, multiplies the
+ * transform at |k| Fourier pixels of the unpadded box (linear interpolation; the last value beyond the table); NULL = none. */
+ppm_ref_t *ppm_reference_create_weighted(const float *vol, int n, float max_band_px, int pad, const float *ring_weight, int n_weight);
 void ppm_reference_destroy(ppm_ref_t *ref);
 
 /* images: n_img * box * box floats. images_on_device != 0 means `images` is a device pointer.

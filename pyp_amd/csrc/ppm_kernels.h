@@ -64,7 +64,9 @@ __global__ void k_ref_load(const float *__restrict__ vol, float2 *__restrict__ f
     f[((size_t)(z + o0) * np + (y + o0)) * np + (x + o0)] = make_float2(vol[i] * g, 0.f);
 }
 
-__global__ void k_ref_crop(const float2 *__restrict__ f, float2 *__restrict__ cube, int n, int n_orig, int B, int CX, int CY, int NBX, int NBY, unsigned LB) {
+// ringw (may be null): radial weight per Fourier pixel of the UNPADDED transform, [nw], linearly interpolated ("use statistics")
+__global__ void k_ref_crop(const float2 *__restrict__ f, float2 *__restrict__ cube, int n, int n_orig, int B, int CX, int CY, int NBX, int NBY, unsigned LB,
+                           const float *__restrict__ ringw, int nw) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, tot = (size_t)CX * CY * CY;
     if (i >= tot) return;
     const int x = (int)(i % CX), ys = (int)((i / CX) % CY), zs = (int)(i / ((size_t)CX * CY));      // stored indices
@@ -72,6 +74,12 @@ __global__ void k_ref_crop(const float2 *__restrict__ f, float2 *__restrict__ cu
     int iz = ((z % n) + n) % n, iy = ((y % n) + n) % n, ix = x % n;
     float2 v = f[((size_t)iz * n + iy) * n + ix];
     float sg = (((x + y + z) & 1) ? -1.f : 1.f) / (float)n_orig;
+    if (ringw) {
+        const float kk = sqrtf((float)(x * x + y * y + z * z)) * (float)n_orig / (float)n;      // radius in unpadded Fourier pixels
+        const int k0 = (int)kk;
+        const float fr = kk - (float)k0;
+        sg *= k0 + 1 < nw ? ringw[k0] + fr * (ringw[k0 + 1] - ringw[k0]) : ringw[nw - 1];
+    }
     v = make_float2(v.x * sg, v.y * sg);
     cube[cube_element(NBX, NBY, LB, 0, x, ys, zs)] = v;                     // both copies of the blocked layout (ppm_dev.h)
     if (x >= 2) cube[cube_element(NBX, NBY, LB, 1, x, ys, zs)] = v;

@@ -334,7 +334,7 @@ int ppm_device_upload(void *dst, const void *src, size_t bytes) { HIPCHK(hipMemc
 int ppm_device_sync(void) { if (g.stream) HIPCHK(hipStreamSynchronize(g.stream)); HIPCHK(hipDeviceSynchronize()); return 0; }
 
 // ------------------------------------------------------------------------------ reference
-ppm_ref_t *ppm_reference_create_padded(const float *vol, int n, float max_band_px, int pad) {
+ppm_ref_t *ppm_reference_create_weighted(const float *vol, int n, float max_band_px, int pad, const float *ring_weight, int n_weight) {
     if (!g.inited) { fail(-1, "ppm_init has not been called"); return nullptr; }
     if (!vol || !box_ok(n) || !(max_band_px > 0)) { fail(-22, "reference box must be even, 32..512, with prime factors 2, 3, 5, and the band positive"); return nullptr; }
     if ((pad != 1 && pad != 2 && pad != 4) || n * pad > 512) { fail(-22, "padding factor must be 1, 2 or 4 with padded box <= 512"); return nullptr; }
@@ -348,6 +348,11 @@ ppm_ref_t *ppm_reference_create_padded(const float *vol, int n, float max_band_p
     HIPCHKP(hipMalloc(&d_f, np3 * sizeof(float2)));
     HIPCHKP(hipMemcpy(d_vol, vol, n3 * sizeof(float), hipMemcpyHostToDevice));
     if (pad > 1) HIPCHKP(hipMemsetAsync(d_f, 0, np3 * sizeof(float2), g.stream));
+    float *d_w = nullptr;
+    if (ring_weight && n_weight > 0) {
+        HIPCHKP(hipMalloc(&d_w, (size_t)n_weight * sizeof(float)));
+        HIPCHKP(hipMemcpyAsync(d_w, ring_weight, (size_t)n_weight * sizeof(float), hipMemcpyHostToDevice, g.stream));
+    }
     ppm_ref *r = new ppm_ref();
     r->N = n; r->pad = pad; r->B = B; r->CX = B + 2; r->CY = 2 * B + 3;
     size_t cube_n = (size_t)r->CX * r->CY * r->CY;
@@ -361,15 +366,16 @@ ppm_ref_t *ppm_reference_create_padded(const float *vol, int n, float max_band_p
         ProfScope ps(PPM_K_BANK);
         hipLaunchKernelGGL(k_ref_load, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, g.stream, d_vol, d_f, n, np);
         if (fft3d(d_f, np, false)) { delete r; return nullptr; }
-        hipLaunchKernelGGL(k_ref_crop, dim3((unsigned)((cube_n + 255) / 256)), dim3(256), 0, g.stream, d_f, r->cube, np, n, B, r->CX, r->CY, r->NBX, r->NBY, r->LB);
+        hipLaunchKernelGGL(k_ref_crop, dim3((unsigned)((cube_n + 255) / 256)), dim3(256), 0, g.stream, d_f, r->cube, np, n, B, r->CX, r->CY, r->NBX, r->NBY, r->LB, d_w, n_weight);
     }
     HIPCHKP(hipStreamSynchronize(g.stream));
     HIPCHKP(hipGetLastError());
-    (void)hipFree(d_vol); (void)hipFree(d_f);
+    (void)hipFree(d_vol); (void)hipFree(d_f); if (d_w) (void)hipFree(d_w);
     return r;
 }
 
-ppm_ref_t *ppm_reference_create(const float *vol, int n, float max_band_px) { return ppm_reference_create_padded(vol, n, max_band_px, 1); }
+ppm_ref_t *ppm_reference_create_padded(const float *vol, int n, float max_band_px, int pad) { return ppm_reference_create_weighted(vol, n, max_band_px, pad, nullptr, 0); }
+ppm_ref_t *ppm_reference_create(const float *vol, int n, float max_band_px) { return ppm_reference_create_weighted(vol, n, max_band_px, 1, nullptr, 0); }
 
 void ppm_reference_destroy(ppm_ref_t *r) {
     if (!r) return;

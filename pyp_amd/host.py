@@ -29,14 +29,16 @@ def _images_arg(images, n_img, box):
 class Reference:
     """3-D reference prepared for projection matching up to `max_band_px` Fourier pixels."""
 
-    def __init__(self, vol, max_band_px=None, device=0, pad=1):
+    def __init__(self, vol, max_band_px=None, device=0, pad=1, ring_weight=None):
         lib.init(device)
         vol = np.ascontiguousarray(vol, dtype=np.float32)
         if vol.ndim != 3 or len(set(vol.shape)) != 1:
             raise ValueError("ERROR: reference must be a cubic volume")
         self.n = vol.shape[0]
         band = self.n / 2 if max_band_px is None else float(max_band_px)
-        self.h = lib.load().ppm_reference_create_padded(lib.ptr(vol), self.n, band, int(pad))
+        w = None if ring_weight is None else np.ascontiguousarray(ring_weight, dtype=np.float32)
+        self.h = lib.load().ppm_reference_create_weighted(lib.ptr(vol), self.n, band, int(pad), None if w is None else lib.ptr(w),
+                                                          0 if w is None else int(w.size))
         if not self.h:
             raise lib.PpmError(lib.last_error())
 

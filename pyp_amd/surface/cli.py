@@ -74,24 +74,18 @@ def _load_images(stack_path, positions, box_expected=None):
     return imgs
 
 
-def _ssnr_weighted_reference(vol, stats_path, pixel):
-    """'use statistics' = yes: figure-of-merit weighting of the reference rings,
-    w = sqrt(2 pFSC / (1 + pFSC)) from the part-FSC column of statistics_rNN.txt (7 columns,
-    src/pyp/postprocess/core.py:203-221)."""
+def _ssnr_ring_weights(n, stats_path, pixel):
+    """'use statistics' = yes: figure-of-merit weighting of the reference rings, w = sqrt(2 pFSC / (1 + pFSC)) from the
+    part-FSC column of statistics_rNN.txt (7 columns, src/pyp/postprocess/core.py:203-221), tabulated per Fourier pixel
+    0 .. n/2 for ppm_reference_create_weighted (applied on the device while the reference cube is cut out)."""
     st = np.loadtxt(stats_path, comments=["C"], ndmin=2)
     if st.shape[1] < 5 or len(st) < 2:
         _die(f"ERROR: {stats_path}: statistics file needs 7 columns")
-    n = vol.shape[0]
     res, pfsc = st[:, 1], np.clip(st[:, 4], 0.0, 1.0)
     w_tab = np.sqrt(2 * pfsc / (1 + pfsc))
-    f = np.fft.rfftn(vol)
-    kz, ky = np.fft.fftfreq(n) * n, np.fft.fftfreq(n) * n
-    kx = np.arange(n // 2 + 1)
-    k = np.sqrt(kz[:, None, None] ** 2 + ky[None, :, None] ** 2 + kx[None, None, :] ** 2)
-    s = k / (n * pixel)
+    s = np.arange(n // 2 + 1) / (n * pixel)
     order = np.argsort(1.0 / res)
-    w = np.interp(s, (1.0 / res)[order], w_tab[order], left=1.0, right=float(w_tab[order][-1]))
-    return np.fft.irfftn(f * w, s=vol.shape).astype(np.float32)
+    return np.interp(s, (1.0 / res)[order], w_tab[order], left=1.0, right=float(w_tab[order][-1])).astype(np.float32)
 
 
 # ------------------------------------------------------------------------------------------ refine3d
@@ -129,10 +123,11 @@ def refine3d_main(argv=None, stdin=None):
     vol = mrc.read(d["reference"]).astype(np.float32)
     if vol.shape != (box, box, box):
         _die(f"ERROR: refine3d: reference is {vol.shape}, particles are {box}^2")
+    ring_w = None
     if d["use_statistics"]:
         if not os.path.exists(d["statistics"]):
             _die(f"ERROR: refine3d: statistics file {d['statistics']} does not exist")
-        vol = _ssnr_weighted_reference(vol, d["statistics"], px)
+        ring_w = _ssnr_ring_weights(box, d["statistics"], px)
     cfg = RefineCfg.make(
         box=box, pixel_size=px, molecular_mass_kda=d["molecular_mass"], mask_radius=d["outer_radius"], res_low=d["res_low"],
         res_high=d["res_high"], res_signed_cc=d["res_signed_cc"], search_mask_radius=d["search_mask_radius"],
@@ -148,7 +143,7 @@ def refine3d_main(argv=None, stdin=None):
         with gpu_lock(dev):
             if box * pad > 512:
                 _die(f"ERROR: refine3d: padding factor {pad} needs a padded box of {box * pad} > 512")
-            ref = host.Reference(vol, box / 2, device=dev, pad=pad)
+            ref = host.Reference(vol, box / 2, device=dev, pad=pad, ring_weight=ring_w)
             rout = ref.refine(cfg, imgs, rin)
             ref.close()
     except (lib.PpmError, ValueError) as e:

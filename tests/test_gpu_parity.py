@@ -129,6 +129,25 @@ def test_defocus_refinement_matches_oracle_and_recovers_offsets(H, O):
     assert np.array_equal(off[:, 6], rows[:, 6]) and (got[:, 14] >= off[:, 14] - 1e-3).all()
 
 
+def test_ring_weighted_reference_equals_host_side_filter(H):
+    """"use statistics": the radial weight applied on the device while the cube is cut out = the same filter applied to the
+    volume with numpy beforehand."""
+    n, px, m = 64, 2.0, 10
+    vol, stack, rows = synth.make_dataset(n, m, pixel=px, snr=0.3)
+    imgs = stack.numpy()
+    w = np.clip(1.0 - np.arange(n // 2 + 1) / 40.0, 0.2, 1.0).astype(np.float32)
+    f = np.fft.rfftn(vol)
+    kz, ky, kx = np.fft.fftfreq(n) * n, np.fft.fftfreq(n) * n, np.arange(n // 2 + 1)
+    k = np.sqrt(kz[:, None, None] ** 2 + ky[None, :, None] ** 2 + kx[None, None, :] ** 2)
+    volw = np.fft.irfftn(f * np.interp(k, np.arange(n // 2 + 1), w), s=vol.shape).astype(np.float32)
+    c = cfg_for(n, px, global_search=0, local_refine=0)
+    a = H.Reference(vol, n / 2, ring_weight=w).refine(c, imgs, rows)[:, 14]
+    b = H.Reference(volw, n / 2).refine(c, imgs, rows)[:, 14]
+    plain = H.Reference(vol, n / 2).refine(c, imgs, rows)[:, 14]
+    # (not bit-identical: the host filter acts before the sinc^2 pre-compensation, the device weight after it)
+    assert np.abs(a - b).max() < 0.06 and np.abs(a - plain).max() > 10 * np.abs(a - b).max()
+
+
 def test_padding_limits_are_loud(H):
     vol = np.zeros((64, 64, 64), np.float32)
     with pytest.raises(Exception):
