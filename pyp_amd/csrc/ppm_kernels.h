@@ -552,7 +552,9 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
                 for (int j = 0; j < R; j++) tw[j] = twn[j];
             }
         };
+        __builtin_amdgcn_s_setprio(3);
         for (int row0 = 0; row0 < HsP; row0 += 2 * U) { step(row0, pv, pn); step(row0 + U, pn, pv); }      // HsP is a multiple of 2 U
+        __builtin_amdgcn_s_setprio(0);          // the reduction tail is a chain of dependent cross-lane steps: let it issue first
         const float sax = sa.x, say = sa.y, sbx = sb.y, sby = -sb.x;
         float uax[R], uay[R], ubx[R], uby[R], vax[R], vay[R], vbx[R], vby[R];
 #pragma unroll
