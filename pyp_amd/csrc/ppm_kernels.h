@@ -524,15 +524,19 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
             float4 tw[R], twn[R];
 #pragma unroll
             for (int j = 0; j < R; j++) tw[j] = c_rowtw[(row0 >> 1) * PPM_MAX_SHIFT_STEPS + j];
+            // ... and so are the particle's W / C2 rows (LDS) of the next pair
+            float2 wa = Wl[row0 * 64 + lane], wb = Wl[(row0 + 1) * 64 + lane];
+            float ca = C2l[row0 * 64 + lane], cb = C2l[(row0 + 1) * 64 + lane];
 #pragma unroll
             for (int u = 0; u < U; u += 2) {
-                const int ra = row0 + u, rb = ra + 1, tp = ra >> 1;
+                const int ra = row0 + u, tp = ra >> 1;
+                float2 wan = wa, wbn = wb; float can = ca, cbn = cb;
                 if (u + 2 < U) {
 #pragma unroll
                     for (int j = 0; j < R; j++) twn[j] = c_rowtw[(tp + 1) * PPM_MAX_SHIFT_STEPS + j];
+                    wan = Wl[(ra + 2) * 64 + lane]; wbn = Wl[(ra + 3) * 64 + lane];
+                    can = C2l[(ra + 2) * 64 + lane]; cbn = C2l[(ra + 3) * 64 + lane];
                 }
-                const float2 wa = Wl[ra * 64 + lane], wb = Wl[rb * 64 + lane];
-                const float ca = C2l[ra * 64 + lane], cb = C2l[rb * 64 + lane];
                 const float pax = cur[u].x, pay = cur[u].y, pbx = cur[u + 1].x, pby = cur[u + 1].y;
                 nP = fmaf(ca, fmaf(pax, pax, pay * pay), nP);
                 nP = fmaf(cb, fmaf(pbx, pbx, pby * pby), nP);
@@ -550,6 +554,7 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
                 }
 #pragma unroll
                 for (int j = 0; j < R; j++) tw[j] = twn[j];
+                wa = wan; wb = wbn; ca = can; cb = cbn;
             }
         };
         __builtin_amdgcn_s_setprio(3);
