@@ -139,7 +139,7 @@ def test_ring_weighted_reference_equals_host_side_filter(H):
     f = np.fft.rfftn(vol)
     kz, ky, kx = np.fft.fftfreq(n) * n, np.fft.fftfreq(n) * n, np.arange(n // 2 + 1)
     k = np.sqrt(kz[:, None, None] ** 2 + ky[None, :, None] ** 2 + kx[None, None, :] ** 2)
-    volw = np.fft.irfftn(f * np.interp(k, np.arange(n // 2 + 1), w), s=vol.shape).astype(np.float32)
+    volw = np.fft.irfftn(f * np.interp(k, np.arange(n // 2 + 1), w), s=vol.shape, axes=(0, 1, 2)).astype(np.float32)
     c = cfg_for(n, px, global_search=0, local_refine=0)
     a = H.Reference(vol, n / 2, ring_weight=w).refine(c, imgs, rows)[:, 14]
     b = H.Reference(volw, n / 2).refine(c, imgs, rows)[:, 14]
