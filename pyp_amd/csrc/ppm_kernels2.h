@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(256, 4) k_local(LocalP P) {
     __shared__ double score[kMaxCand];
     __shared__ LState st;
     __shared__ double sfp[5], sfm[5], sd[5], sMt[9], sshq[2], sf0;
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;      // 128 or 256 threads (few samples per sweep: smaller blocks)
     if (tid == 0) st = P.states[blockIdx.x];
     __syncthreads();
     const int part = st.particle;
@@ -129,12 +129,12 @@ __global__ void __launch_bounds__(256, 4) k_local(LocalP P) {
     auto sweep = [&]() {
         const int nslots = plan.nslots, ng = plan.ng, S_used = plan.S_used;
         const float rmax2 = plan.rmax2;
-        for (int i = tid; i < nslots * 260; i += 256) (&ringA[0][0])[i] = 0.f;
+        for (int i = tid; i < nslots * 260; i += nthr) (&ringA[0][0])[i] = 0.f;
         if (tid < kMaxCand) sumB[tid] = 0.f;
         if (tid == 0) sumC = 0.f;
         __syncthreads();
         float accC = 0.f;
-        for (int s0 = 0; s0 < S_used; s0 += 256) {
+        for (int s0 = 0; s0 < S_used; s0 += nthr) {
             const int s = s0 + tid;
             int kx = 0, ky = 0, al = 0, ring = 0;
             float2 iv = make_float2(0.f, 0.f); float c = 0.f;

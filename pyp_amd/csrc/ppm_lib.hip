@@ -566,7 +566,8 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
                 LP.states = ref->states.p; LP.T = Tb; LP.final_rescore = 0;
                 fill_schedule(0.5 * gm.dstep, gm.step, 0, Tb, gm.r_s, (double)K);
                 ProfScope ps(PPM_K_LOCAL);
-                hipLaunchKernelGGL(k_local, dim3(nb * K), dim3(256), 0, g.stream, LP);
+                // 128-thread blocks for the hit stage (<= ~800 samples per sweep: two waves waste less on the serial steps), 256 below
+                hipLaunchKernelGGL(k_local, dim3(nb * K), dim3(128), 0, g.stream, LP);
             }
             {
                 ProfScope ps(PPM_K_TOPK);
