@@ -109,7 +109,7 @@ struct SweepPlan { float m[kMaxGroup][6]; float sh[kMaxCand][2]; int nv[kMaxGrou
 // the four shift neighbours share one interpolated slice value), then one trial pose; all at the
 // iteration's band (frequency marching: a prefix of the ring-ordered list).  Ring sums: 16-lane DPP
 // reduction (a 16-lane group never straddles a ring), then one LDS atomic per group.
-__global__ void __launch_bounds__(256, 4) k_local(LocalP P) {
+__global__ void __launch_bounds__(256, 5) k_local(LocalP P) {
     __shared__ SweepPlan plan;
     __shared__ float ringA[kMaxCand][260];
     __shared__ float sumB[kMaxCand];
