@@ -636,18 +636,18 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
             }
         }
     }
-    // ---- top-K of this particle's scores (ties -> lower orientation index); winners so far are kept
-    // in an LDS exclusion list so that the score array is only ever read
+    // ---- top-K of this particle's scores (ties -> lower orientation index): the scores are copied into LDS once (the W
+    // table is no longer needed) and every winner is struck out there
     __threadfence_block();
     __syncthreads();
-    float *rv = (float *)smem; int *ri = (int *)(rv + 16); int *won = ri + 16;   // W table no longer needed
+    float *rv = (float *)smem; int *ri = (int *)(rv + 16); float *sc = rv + 32;
+    for (int o = tid; o < P.n_orient; o += NT) sc[o] = ccp[o];
+    __syncthreads();
     for (int k = 0; k < P.K; k++) {
         float bv = -3.0e38f; int bi = 0x7fffffff;
         for (int o = tid; o < P.n_orient; o += NT) {
-            float v = ccp[o];
-            bool taken = false;
-            for (int q = 0; q < k; q++) taken |= (won[q] == o);
-            if (!taken && (v > bv || (v == bv && o < bi))) { bv = v; bi = o; }
+            const float v = sc[o];                          // struck-out entries are -inf: never above the start value
+            if (v > bv || (v == bv && o < bi)) { bv = v; bi = o; }
         }
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) {
@@ -662,7 +662,7 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
             int sv = shp[bi];
             h.sx = (int)(short)(sv & 0xffff); h.sy = sv >> 16;
             P.hits[(size_t)p * P.K + k] = h;
-            won[k] = bi;
+            if (bi < P.n_orient) sc[bi] = -__builtin_inff();
         }
         __syncthreads();
     }
