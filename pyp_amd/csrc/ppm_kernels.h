@@ -658,6 +658,7 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
         __syncthreads();
         if (tid == 0) {
             for (int w = 1; w < NW; w++) if (rv[w] > bv || (rv[w] == bv && ri[w] < bi)) { bv = rv[w]; bi = ri[w]; }
+            if (bi >= P.n_orient) { bi = 0; bv = 0.f; }     // nothing comparable left (NaN scores): stay inside the tables
             Hit h; h.cc = bv; h.orient = bi;
             int sv = shp[bi];
             h.sx = (int)(short)(sv & 0xffff); h.sy = sv >> 16;
