@@ -148,6 +148,22 @@ def test_ring_weighted_reference_equals_host_side_filter(H):
     assert np.abs(a - b).max() < 0.06 and np.abs(a - plain).max() > 10 * np.abs(a - b).max()
 
 
+def test_non_finite_inputs_do_not_fault(H):
+    """NaN / Inf pixels, a NaN angle and an absurd shift: no device fault, the healthy particles are unaffected."""
+    n, px, m = 64, 2.0, 8
+    vol, stack, rows = synth.make_dataset(n, m, pixel=px, snr=0.2)
+    imgs = stack.numpy().copy()
+    good = H.Reference(vol, n / 2).refine(cfg_for(n, px, angular_step=30.0), imgs, rows)
+    imgs[1, 10, 10] = np.nan; imgs[2] = np.inf
+    bad = rows.copy(); bad[3, 1] = np.nan; bad[4, 4] = 1e30
+    out = H.Reference(vol, n / 2).refine(cfg_for(n, px, angular_step=30.0), imgs, bad)
+    ok = [0, 5, 6, 7]
+    assert synth.angular_error_deg(out[ok], good[ok]).max() < ANG_TOL_DEG
+    acc = H.Accumulator(n, px, "C1")
+    acc.insert(ReconCfg(box=n, pixel_size=px, res_limit=2 * px, normalize=1, split_by_pind=0, mask_radius=0.4 * n * px), imgs, bad)
+    assert acc.counts()[0] + acc.counts()[1] == m
+
+
 def test_padding_limits_are_loud(H):
     vol = np.zeros((64, 64, 64), np.float32)
     with pytest.raises(Exception):
