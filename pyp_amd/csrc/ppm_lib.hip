@@ -684,7 +684,8 @@ int ppm_insert_batch(ppm_accum_t *a, const ppm_recon_cfg *cfg, const void *image
     const size_t NN = (size_t)gm.N * gm.N, HW = (size_t)gm.H * gm.W;
     const size_t chunk_gb = getenv("PPM_INSERT_GB") ? (size_t)std::max(1, atoi(getenv("PPM_INSERT_GB"))) : 8;
     int CH = (int)std::min<size_t>((size_t)n_img, std::max<size_t>(32, (chunk_gb << 30) / (NN * 4 + HW * 8)));
-    CH = std::min(CH, 32768);   // grid.y limit
+    CH = std::min(CH, 32768);
+    if (const char *e = std::getenv("PPM_CHUNK")) { int v = std::atoi(e); if (v > 0) CH = std::min(CH, v); }   // tests: force several chunks
     if (int r = a->rows.ensure((size_t)CH * PPM_NCOL)) return r;
     if (!images_on_device) if (int r = a->images.ensure((size_t)2 * CH * NN)) return r;       // double-buffered staging
     if (int r = a->band.ensure((size_t)CH * HW)) return r;

@@ -336,6 +336,26 @@ def test_insertion_large_boxes_bricks_and_slices(H, O, monkeypatch, n, px, m, sy
     assert np.linalg.norm(ga.download() - acc) / np.linalg.norm(acc) < 1e-4
 
 
+def test_insertion_in_several_chunks_from_host_and_device(H, O, monkeypatch):
+    """PPM_CHUNK forces 5 chunks (double-buffered host uploads, a ragged last chunk, brick items rebuilt for it)."""
+    import torch
+    monkeypatch.setenv("PPM_CHUNK", "160")
+    monkeypatch.setenv("PPM_BRICK_MINP", "32")
+    n, px, m = 128, 2.0, 700
+    vol, imgs, rows = dataset(n, 20, px, 0.2)
+    imgs = np.concatenate([imgs] * 35)[:m]; rows = np.concatenate([rows] * 35)[:m].copy()
+    rows[:, 0] = np.arange(1, m + 1)
+    rc = ReconCfg(box=n, pixel_size=px, res_limit=2 * px, normalize=1, split_by_pind=0, mask_radius=0.4 * n * px)
+    acc = np.zeros(O.accum_floats(n), dtype=np.float32)
+    counts = np.zeros(2, dtype=np.int64)
+    O.insert_batch(acc, counts, rc, "C1", imgs, rows)
+    for stack in (imgs, torch.from_numpy(imgs).cuda()):
+        ga = H.Accumulator(n, px, "C1")
+        ga.insert(rc, stack, rows)
+        assert ga.counts() == list(counts)
+        assert np.linalg.norm(ga.download() - acc) / np.linalg.norm(acc) < 1e-4
+
+
 def test_external_accumulator_tensor_and_reduce(H, O):
     """The accumulator can live in a caller-allocated torch tensor (what RCCL reduces in place)."""
     import torch
