@@ -20,9 +20,19 @@
  * holds it in RAM (:716-727).  Angles in degrees, shifts in Angstrom (src/pyp/analysis/scores.py:693).
  *
  * Conventions: all functions return 0 on success, a negative errno-style code on failure and
- * leave a message for ppm_last_error().  The caller owns every host buffer; the library owns
- * device memory.  Handles are not thread-safe; different handles may be used from different
- * threads.  No torch types cross this boundary.
+ * leave a message for ppm_last_error() (thread-local).  The caller owns every host buffer; the library owns
+ * device memory.  No torch types cross this boundary.
+ *
+ * Process model: one process per GPU.  ppm_init binds the process to one device (a second call with another index
+ * fails); every call runs on the library's own HIP stream and its workspaces (FFT plans, scratch, event pools) are
+ * process-wide, so calls must be SERIALISED by the caller - the library is not thread-safe, also across different
+ * handles.  Several reference / accumulator handles may be alive and used alternately (each keeps its own search-grid
+ * tables).
+ *
+ * Stream ordering: device buffers handed in (resident particle stacks, an external accumulator buffer, extraction
+ * outputs) are read / written on the library's stream, which is NOT ordered against any stream of the caller: finish
+ * (or synchronise) the work that produces them before the call; every entry point returns only after its own device
+ * work has completed, so results may be used on any stream afterwards.
  */
 #ifndef PPM_H
 #define PPM_H
@@ -59,19 +69,24 @@ typedef struct ppm_refine_cfg {
                                  rest by absolute value; 0 = all signed */
     float search_mask_radius; /* 23: mask radius for the global search, Angstrom (0 = mask_radius) */
     float res_search;         /* 24: resolution limit of the global search, Angstrom; the grid search itself never uses more
-                                 than 64 Fourier pixels (the limit is lowered to that silently) */
+                                 than 64 Fourier pixels (a finer limit is lowered to that and ppm_refine_note() says so; the hits
+                                 are still refined up to res_high) */
     float angular_step;       /* 25: degrees */
     int top_hits;             /* 26: global-search hits that get refined (the caller passes 20) */
     float search_range_x;     /* 27: Angstrom, 0 = widest supported window */
     float search_range_y;     /* 28 */
-    int global_search;        /* 36 */
-    int local_refine;         /* 37 */
+    int global_search;        /* 36: grid search over the asymmetric unit; its `top_hits` best orientations are ALWAYS refined
+                                 (iters_hit compass iterations each, at the search band) and the best one is kept - PYP's default
+                                 call is global = yes, local = no with 20 hits to refine (frealign.py:3866-3871, :3953) */
+    int local_refine;         /* 37: with global_search: the best hit continues at the full band (iters_final iterations);
+                                 without: refinement starts at the row's pose (iters_hit + iters_final iterations).
+                                 SCORE / LOGP / SIGMA always come from one last evaluation at the full band */
     int refine_psi, refine_theta, refine_phi, refine_x, refine_y; /* 38-42 */
     int normalize;            /* 46: normalise particles */
     int invert;               /* 47: invert contrast */
     /* build-defined knobs (0 = default), DESIGN.md "search driver" */
     float mask_falloff;       /* cosine edge width of the mask, Angstrom (default 20) */
-    int iters_hit;            /* compass iterations run on every hit (default 2) */
+    int iters_hit;            /* compass iterations run on every hit (0 = default 2; < 0 = none: hits stay on the grid, test hook) */
     int iters_final;          /* further iterations on the best hit / on a local-only start (default 7) */
     float local_angle_step;   /* first step of a local-only refinement, degrees (default 2.5) */
     float local_shift_step;   /* same for shifts, pixels (default 2) */
@@ -143,6 +158,9 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
  * over all local evaluations (frequency marching makes early ones cheaper) */
 int ppm_refine_last_counts(ppm_ref_t *ref, long *n_global, long *n_local, long *samples_global,
                            long *samples_local);
+/* remarks of the last ppm_refine_batch on this reference that the caller should log (e.g. the search band was capped);
+ * "" if none */
+const char *ppm_refine_note(ppm_ref_t *ref);
 
 /* symmetry: "C1", "Cn", "Dn", "T", "O", "I".  ext_device_buffer: NULL, or a device buffer of
  * ppm_accum_floats(box) floats the caller allocated (e.g. a torch tensor, so that RCCL can

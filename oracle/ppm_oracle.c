@@ -14,7 +14,7 @@
  * (src/pyp/inout/metadata/cistem_star_file.py:596-628), angles in degrees / shifts in Angstrom
  * (src/pyp/analysis/scores.py:693) and the ZYZ Euler order phi -> theta -> psi
  * (src/pyp/analysis/geometry/core.py:1186-1197).  The oracle is pinned instead by synthetic
- * ground truth (tests/test_oracle_truth.py): poses recovered from projections of a known volume.
+ * ground truth (tests/test_oracle.py): poses recovered from projections of a known volume.
  *
  * Style: plain loops, double accumulators, no tricks.  The global-search correlation image is
  * computed BOTH ways: by a zero-filled inverse 2-D FFT (mode 0, the textbook statement) and by
@@ -609,7 +609,10 @@ int orc_refine_batch(void *refp, const ppm_refine_cfg *cfg, const float *images,
     if (!r || geom_init(&g, cfg)) return -22;
     if (g.B > (r->B + 1) / r->pad - 1 || r->N != g.N) return -22;
     int K = cfg->top_hits > 0 ? cfg->top_hits : 20; if (K > PPM_MAX_TOP_HITS) K = PPM_MAX_TOP_HITS;
-    int Tb = cfg->iters_hit > 0 ? cfg->iters_hit : 2, Tc = cfg->iters_final > 0 ? cfg->iters_final : 7;
+    /* answers 36 / 37 (frealign.py:3866-3871): PYP's default is global = yes, local = no together with "top hits to refine" = 20
+     * (:3953), so a global search always refines its top hits; answer 37 only decides whether the best one continues at the
+     * full band.  iters_hit < 0 leaves the hits at their grid points (test hook). */
+    int Tb = cfg->iters_hit > 0 ? cfg->iters_hit : (cfg->iters_hit < 0 ? 0 : 2), Tc = cfg->iters_final > 0 ? cfg->iters_final : 7;
     double fall = cfg->mask_falloff > 0 ? cfg->mask_falloff : 20.0;
     double dstep = cfg->angular_step > 0 ? cfg->angular_step : 15.0;
     int en[5] = { cfg->refine_psi, cfg->refine_theta, cfg->refine_phi, cfg->refine_x, cfg->refine_y };
@@ -686,15 +689,14 @@ int orc_refine_batch(void *refp, const ppm_refine_cfg *cfg, const float *images,
                 euler_full((hits[a].orient % g.n_psi) * g.dpsi, th, ph, s.M);
                 s.sh[0] = hits[a].sx * g.step; s.sh[1] = hits[a].sy * g.step;
                 s.ha = 0.5 * dstep; s.hs = g.step;
-                if (cfg->local_refine) {
+                if (Tb > 0) {
                     for (int t = 0; t < Tb; t++) compass_iter(r, &g, &c, I, wr, g.r_s, rm_px, bf, en, &s, &nev, &sev);
                 } else s.f = hits[a].cc;
                 if (!have || s.f > best.f) { best = s; have = 1; }
             }
-            if (cfg->local_refine) {       /* the best hit continues at the full band */
+            if (cfg->local_refine)         /* the best hit continues at the full band */
                 for (int t = 0; t < Tc; t++) compass_iter(r, &g, &c, I, wr, g.r_hi, rm_px, bf, en, &best, &nev, &sev);
-                best.f = score_local(r, &g, &c, I, wr, g.r_hi, best.M, best.sh); nev++; sev += floor(ORC_PI * g.r_hi * g.r_hi / 2);
-            }
+            best.f = score_local(r, &g, &c, I, wr, g.r_hi, best.M, best.sh); nev++; sev += floor(ORC_PI * g.r_hi * g.r_hi / 2);
             free(hits); free(work); free(Wp); free(C2); free(Isown); free(wrsown);
         } else {
             euler_full(row[PPM_PSI], row[PPM_THETA], row[PPM_PHI], best.M);

@@ -28,6 +28,7 @@ struct Geom {
     double step = 0;              // global-search shift grid: Ns points over the box, step = N/Ns pixels
     int n_theta = 0, n_psi = 0, n_dir = 0, n_orient = 0, npsi_store = 0, half = 0;
     double dpsi = 0, dstep = 0, phi_max = 360, theta_max = 180;
+    double r_s_asked = 0;         // search band the caller asked for (> r_s when the 64-pixel cap of the grid search applied)
 };
 
 // asymmetric unit of the global grid (include/ppm.h, field `symmetry`)
@@ -80,6 +81,7 @@ inline bool geom_init(Geom &g, const ppm_refine_cfg &c, std::string &err) {
     g.r_hi = na / c.res_high; if (g.r_hi > g.N / 2) g.r_hi = g.N / 2;
     g.r_lo = c.res_low > 0 ? na / c.res_low : 0.0;
     g.r_s = c.res_search > 0 ? na / c.res_search : g.r_hi; if (g.r_s > g.r_hi) g.r_s = g.r_hi;
+    g.r_s_asked = g.r_s;
     if (c.global_search && g.r_s > 64.0) g.r_s = 64.0;   // the grid-search kernel covers 64 Fourier pixels (lane = kx); finer
                                                          // detail only enters through the refinement of the hits
     g.ring_signed = c.res_signed_cc > 0 ? na / c.res_signed_cc : 1e30;

@@ -419,18 +419,24 @@ __global__ void __launch_bounds__(256) k_bank(BankP P) {
 // ---------------------------------------------------------------------------------- global search
 struct Hit { float cc; int orient; int sx, sy; };
 
+// Pair twiddles e^{+2 pi i t j / Ns}, [t][j-1] for the row pair ky = +-t: wave-uniform, fetched with scalar loads.
+// Stored as {cos, cos, sin, sin} so that a scalar load delivers the two operand pairs of the packed FMAs as they are.
+// The table belongs to the reference handle (two references with different search grids may be live at once); it is read
+// through the constant address space so that the wave-uniform loads stay scalar (s_load) although the kernel also stores
+// to global memory inside the slice loop.
+constexpr int kRowTwRows = 64;
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) v4f *RowTwPtr;
+
 struct GlobP {
     const float2 *bank; const float2 *Wp; const float *C2; const float *nI; const float2 *twN;  // twN: Ns-entry table e^{2 pi i t/Ns}
+    const float4 *rowtw;  // [kRowTwRows][PPM_MAX_SHIFT_STEPS] row-pair twiddles (device memory owned by the reference)
     float *cc; int *sh;   // [n][n_orient] scratch scores and packed shifts
     Hit *hits;            // [n][K]
     int Bs, Hs, HsP, Ns, RSx, RSy, n_dir, n_psi, npsi_store, n_orient, K;
+    int topk_lds;         // 1: the top-K pass works on an LDS copy of the particle's scores (they fit), 0: on the global scratch
 };
-
-// Pair twiddles e^{+2 pi i t j / Ns}, [t][j-1] for the row pair ky = +-t: wave-uniform, fetched with scalar loads.
-// Stored as {cos, cos, sin, sin} so that a scalar load delivers the two operand pairs of the packed FMAs as they are.
-constexpr int kRowTwRows = 64;
-__constant__ float4 c_rowtw[kRowTwRows * PPM_MAX_SHIFT_STEPS];
-typedef float v2f __attribute__((ext_vector_type(2)));
 
 constexpr int global_threads(int R) { return R <= 3 ? 1024 : 512; }   // wider windows need > 128 VGPRs
 constexpr int global_unroll(int R) { return R <= 3 ? 8 : 4; }         // rows in flight per wave (prefetch depth), even
@@ -497,6 +503,7 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
         float2 t = P.twN[(lane * j) & (Ns - 1)];
         txc[j] = t.x; txs[j] = t.y;
     }
+    const RowTwPtr c_rowtw = (RowTwPtr)P.rowtw;
     const int nslices = P.n_dir * P.npsi_store;
     float *ccp = P.cc + (size_t)p * P.n_orient; int *shp = P.sh + (size_t)p * P.n_orient;
     for (int sl = wave; sl < nslices; sl += NW) {
@@ -521,7 +528,7 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
                 for (int u = 0; u < U; u++) nxt[u] = np[u * 64 + lane];
             }
             // the (wave-uniform) twiddles of the NEXT row pair are requested before this pair is consumed
-            float4 tw[R], twn[R];
+            v4f tw[R], twn[R];
 #pragma unroll
             for (int j = 0; j < R; j++) tw[j] = c_rowtw[(row0 >> 1) * PPM_MAX_SHIFT_STEPS + j];
             // ... and so are the particle's W / C2 rows (LDS) of the next pair
@@ -547,7 +554,7 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
                 sa += as2; sb += bs2;
 #pragma unroll
                 for (int j = 0; j < R; j++) {
-                    const float4 t = tw[j];                                       // wave-uniform -> SGPRs {c, c, s, s}
+                    const v4f t = tw[j];                                          // wave-uniform -> SGPRs {c, c, s, s}
                     const v2f tc = { t.x, t.y }, ts = { t.z, t.w };
                     ua[j] += as2 * tc; ub[j] += bs2 * tc;
                     va[j] += ad2 * ts; vb[j] += bd2 * ts;
@@ -640,8 +647,9 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
     // table is no longer needed) and every winner is struck out there
     __threadfence_block();
     __syncthreads();
-    float *rv = (float *)smem; int *ri = (int *)(rv + 16); float *sc = rv + 32;
-    for (int o = tid; o < P.n_orient; o += NT) sc[o] = ccp[o];
+    float *rv = (float *)smem; int *ri = (int *)(rv + 16);
+    float *sc = P.topk_lds ? rv + 32 : ccp;           // host: the LDS allocation covers 32 + n_orient floats when topk_lds is set
+    if (P.topk_lds) for (int o = tid; o < P.n_orient; o += NT) sc[o] = ccp[o];
     __syncthreads();
     for (int k = 0; k < P.K; k++) {
         float bv = -3.0e38f; int bi = 0x7fffffff;
@@ -665,6 +673,7 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
             P.hits[(size_t)p * P.K + k] = h;
             if (bi < P.n_orient) sc[bi] = -__builtin_inff();
         }
+        __threadfence_block();
         __syncthreads();
     }
 }

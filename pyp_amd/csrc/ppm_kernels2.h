@@ -80,6 +80,7 @@ constexpr int kMaxIters = 24;
 struct LocalP {
     CubeView cv; const uint32_t *samples; const float2 *Il; const float *cw;
     int S_pad, nrings, N;
+    int nr;                // rings this launch can touch (<= nrings): sizes the per-wave ring sums in dynamic LDS
     float rlo2, ring_signed;
     LState *states; int T, final_rescore; int en[5];
     // frequency marching: band (squared) and sample-list prefix of every iteration, and of the final score
@@ -104,20 +105,32 @@ __device__ __forceinline__ float group16_sum_dpp(float v) {
 // scores of which go to consecutive slots starting at slot0[g].
 struct SweepPlan { float m[kMaxGroup][6]; float sh[kMaxCand][2]; int nv[kMaxGroup]; int slot0[kMaxGroup]; int ng, nslots, S_used, q_same; float rmax2; };   // slots 0 .. q_same use the shift sh[0]
 
-// Block = one trajectory, 256 threads.  A compass iteration scores the centre and the neighbouring poses in
+// sum over aligned groups of 8 lanes (double), every lane of the group gets the total; fixed combination order
+__device__ __forceinline__ double group8_sum_d(double v) {
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+    return v;
+}
+
+// dynamic LDS of k_local / k_defocus for `nw` waves, `nq` score slots and `nr` rings
+__host__ __device__ inline size_t ring_lds_bytes(int nw, int nq, int nr) { return ((size_t)nq * nw * nr + (size_t)nq * nw + nw) * sizeof(float); }
+
+// Block = one trajectory, 128 or 256 threads.  A compass iteration scores the centre and the neighbouring poses in
 // one sweep over the ring-ordered samples (image value and CTF weight loaded once per sample; the centre and
 // the four shift neighbours share one interpolated slice value), then one trial pose; all at the
 // iteration's band (frequency marching: a prefix of the ring-ordered list).  Ring sums: 16-lane DPP
-// reduction (a 16-lane group never straddles a ring), then one LDS atomic per group.
+// reduction (a 16-lane group never straddles a ring), then one LDS add per group into the WAVE'S OWN ring table:
+// a wave's adds happen in program order (and the lanes of one ds_add in lane order), the tables of the waves are
+// combined in a fixed order afterwards, so a score does not depend on how the waves of the block interleave
+// (bit-identical results from run to run; with one table shared by the waves a late compass decision could flip).
 __global__ void __launch_bounds__(256, 5) k_local(LocalP P) {
     __shared__ SweepPlan plan;
-    __shared__ float ringA[kMaxCand][260];
-    __shared__ float sumB[kMaxCand];
-    __shared__ float sumC;
+    extern __shared__ float lsm[];                    // ringA[slot][wave][nr], sumB[slot][wave], sumC[wave]
     __shared__ double score[kMaxCand];
     __shared__ LState st;
     __shared__ double sfp[5], sfm[5], sd[5], sMt[9], sshq[2], sf0;
     const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;      // 128 or 256 threads (few samples per sweep: smaller blocks)
+    const int nw = nthr >> 6, wave = tid >> 6, nr = P.nr;
+    float *const ringA = lsm, *const sumB = lsm + kMaxCand * nw * nr, *const sumC = sumB + kMaxCand * nw;
     if (tid == 0) st = P.states[blockIdx.x];
     __syncthreads();
     const int part = st.particle;
@@ -129,10 +142,10 @@ __global__ void __launch_bounds__(256, 5) k_local(LocalP P) {
     auto sweep = [&]() {
         const int nslots = plan.nslots, ng = plan.ng, S_used = plan.S_used;
         const float rmax2 = plan.rmax2;
-        for (int i = tid; i < nslots * 260; i += nthr) (&ringA[0][0])[i] = 0.f;
-        if (tid < kMaxCand) sumB[tid] = 0.f;
-        if (tid == 0) sumC = 0.f;
+        for (int i = tid; i < nslots * nw * nr; i += nthr) ringA[i] = 0.f;
+        if (tid < kMaxCand * nw) sumB[tid] = 0.f;
         __syncthreads();
+        float *const myA = ringA + wave * nr, *const myB = sumB + wave;
         float accC = 0.f;
         for (int s0 = 0; s0 < S_used; s0 += nthr) {
             const int s = s0 + tid;
@@ -178,18 +191,30 @@ __global__ void __launch_bounds__(256, 5) k_local(LocalP P) {
                     }
                     float mr = pv.x * cs - pv.y * sn, mi = pv.x * sn + pv.y * cs;
                     float av = group16_sum_dpp(ax * mr + ay * mi);
-                    if ((lane & 15) == 0) { atomicAdd(&ringA[q][ring], av); atomicAdd(&sumB[q], bv); }
+                    if ((lane & 15) == 0 && ring < nr) { atomicAdd(&myA[q * nw * nr + ring], av); atomicAdd(&myB[q * nw], bv); }
                 }
             }
         }
         accC = wave_sum(accC);
-        if (lane == 0) atomicAdd(&sumC, accC);
+        if (lane == 0) sumC[wave] = accC;
         __syncthreads();
-        if (tid < nslots) {
+        {   // 8 lanes per slot: lane j takes the rings j, j + 8, ...; waves and lanes are combined in a fixed order
+            const int slot = tid >> 3, j = tid & 7;
             double sa = 0;
-            for (int b = 0; b < P.nrings; b++) { float a = ringA[tid][b]; sa += ((float)b <= P.ring_signed) ? (double)a : fabs((double)a); }
-            double sb = sumB[tid], sc = sumC;
-            score[tid] = (sb > 0 && sc > 0) ? sa / sqrt(sb * sc) : 0.0;
+            if (slot < nslots)
+                for (int b = j; b < nr; b += 8) {
+                    const float *cell = ringA + (size_t)slot * nw * nr + b;
+                    float a = cell[0];
+                    for (int w = 1; w < nw; w++) a += cell[w * nr];
+                    sa += ((float)b <= P.ring_signed) ? (double)a : fabs((double)a);
+                }
+            sa = group8_sum_d(sa);
+            if (slot < nslots && j == 0) {
+                float fb = sumB[slot * nw], fc = sumC[0];
+                for (int w = 1; w < nw; w++) { fb += sumB[slot * nw + w]; fc += sumC[w]; }
+                const double sb = fb, sc = fc;
+                score[slot] = (sb > 0 && sc > 0) ? sa / sqrt(sb * sc) : 0.0;
+            }
         }
         __syncthreads();
     };
@@ -346,21 +371,19 @@ struct DefocusP {
     float rlo2, rmax2, ring_signed, a;
     const double *rows; LState *states; float *ddef;   // ddef[n]: offset chosen (Angstrom)
     int nt; float step;
+    int tchunk;            // offsets scored per pass over the samples (sizes the dynamic LDS)
 };
 
 __global__ void __launch_bounds__(256) k_defocus(DefocusP P) {
-    constexpr int MAXT = 2 * PPM_MAX_DEFOCUS_STEPS + 1;
-    extern __shared__ float dsm[];                    // ringA[T][nrings], sumB[T]
-    __shared__ float sumC;
+    constexpr int MAXT = 2 * PPM_MAX_DEFOCUS_STEPS + 1, NW = 4;
+    extern __shared__ float dsm[];                    // ringA[TC][NW][nrings], sumB[TC][NW], sumC[NW]: per-wave tables as in k_local
     __shared__ double score[MAXT];
     __shared__ CtfP ctf0;
     __shared__ float m_s[6], sh_s[2];
-    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, T = 2 * P.nt + 1;
-    float *ringA = dsm, *sumB = dsm + T * P.nrings;
-    for (int i = tid; i < T * P.nrings + T; i += 256) dsm[i] = 0.f;
+    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, T = 2 * P.nt + 1, TC = P.tchunk, nr = P.nrings;
+    float *const ringA = dsm, *const sumB = dsm + (size_t)TC * NW * nr, *const sumC = sumB + TC * NW;
     if (tid == 0) {
         const LState &st = P.states[p];
-        sumC = 0.f;
         ctf0 = ctf_from_row(P.rows + (size_t)p * PPM_NCOL, P.N, (double)P.a);
         m_s[0] = (float)st.M[0]; m_s[1] = (float)st.M[1]; m_s[2] = (float)st.M[3]; m_s[3] = (float)st.M[4]; m_s[4] = (float)st.M[6]; m_s[5] = (float)st.M[7];
         sh_s[0] = (float)st.sh[0]; sh_s[1] = (float)st.sh[1];
@@ -369,43 +392,61 @@ __global__ void __launch_bounds__(256) k_defocus(DefocusP P) {
     const float2 *Il = P.Il + (size_t)p * P.S_pad;
     const float *wr = P.wring + (size_t)p * (P.B + 2);
     const float invN = 1.0f / (float)P.N;
-    float accC = 0.f;
-    for (int s0 = 0; s0 < P.S_pad; s0 += 256) {
-        const int s = s0 + tid;
-        int kx = 0, ky = 0, al = 0, ring = 0;
-        float2 iv = make_float2(0.f, 0.f);
-        if (s < P.S_pad) {
-            unpack_sample(P.samples[s], kx, ky, al, ring);
-            const float k2 = (float)(kx * kx + ky * ky);
-            if (!(k2 < P.rmax2 && k2 >= P.rlo2)) al = 0;
-            iv = Il[s];
+    // offsets are scored TC at a time (the per-wave ring tables of all 2 nt + 1 offsets do not fit the LDS at wide bands);
+    // every chunk gathers the projection again
+    for (int t0 = 0; t0 < T; t0 += TC) {
+        const int tn = min(TC, T - t0);
+        for (int i = tid; i < tn * NW * nr + TC * NW; i += 256) { if (i < tn * NW * nr) ringA[i] = 0.f; else sumB[i - tn * NW * nr] = 0.f; }
+        __syncthreads();
+        float *const myA = ringA + wave * nr, *const myB = sumB + wave;
+        float accC = 0.f;
+        for (int s0 = 0; s0 < P.S_pad; s0 += 256) {
+            const int s = s0 + tid;
+            int kx = 0, ky = 0, al = 0, ring = 0;
+            float2 iv = make_float2(0.f, 0.f);
+            if (s < P.S_pad) {
+                unpack_sample(P.samples[s], kx, ky, al, ring);
+                const float k2 = (float)(kx * kx + ky * ky);
+                if (!(k2 < P.rmax2 && k2 >= P.rlo2)) al = 0;
+                iv = Il[s];
+            }
+            const float fal = (float)al, fkx = (float)kx, fky = (float)ky;
+            accC += fal * (iv.x * iv.x + iv.y * iv.y);
+            float2 pv = sample_cube(P.cv, m_s[0] * fkx + m_s[1] * fky, m_s[2] * fkx + m_s[3] * fky, m_s[4] * fkx + m_s[5] * fky);
+            float rev = -(fkx * sh_s[0] + fky * sh_s[1]) * invN;
+            rev -= floorf(rev);
+            const float sn = __sinf(6.283185307179586f * rev), cs = __cosf(6.283185307179586f * rev);
+            const float mr = pv.x * cs - pv.y * sn, mi = pv.x * sn + pv.y * cs;
+            const float a0 = fal * (iv.x * mr + iv.y * mi), b0 = fal * (pv.x * pv.x + pv.y * pv.y), wgt = al ? wr[ring] : 0.f;
+            for (int t = 0; t < tn; t++) {
+                CtfP c = ctf0;
+                c.dsum += 2.f * (float)(t0 + t - P.nt) * P.step;          // both defocus values move by the offset
+                const float ct = ctf_eval(c, kx, ky) * wgt;
+                const float av = group16_sum_dpp(a0 * ct), bv = group16_sum_dpp(b0 * ct * ct);
+                if ((lane & 15) == 0 && ring < nr) { atomicAdd(&myA[(size_t)t * NW * nr + ring], av); atomicAdd(&myB[t * NW], bv); }
+            }
         }
-        const float fal = (float)al, fkx = (float)kx, fky = (float)ky;
-        accC += fal * (iv.x * iv.x + iv.y * iv.y);
-        float2 pv = sample_cube(P.cv, m_s[0] * fkx + m_s[1] * fky, m_s[2] * fkx + m_s[3] * fky, m_s[4] * fkx + m_s[5] * fky);
-        float rev = -(fkx * sh_s[0] + fky * sh_s[1]) * invN;
-        rev -= floorf(rev);
-        const float sn = __sinf(6.283185307179586f * rev), cs = __cosf(6.283185307179586f * rev);
-        const float mr = pv.x * cs - pv.y * sn, mi = pv.x * sn + pv.y * cs;
-        const float a0 = fal * (iv.x * mr + iv.y * mi), b0 = fal * (pv.x * pv.x + pv.y * pv.y), wgt = al ? wr[ring] : 0.f;
-        for (int t = 0; t < T; t++) {
-            CtfP c = ctf0;
-            c.dsum += 2.f * (float)(t - P.nt) * P.step;          // both defocus values move by the offset
-            const float ct = ctf_eval(c, kx, ky) * wgt;
-            const float av = group16_sum_dpp(a0 * ct), bv = group16_sum_dpp(b0 * ct * ct);
-            if ((lane & 15) == 0) { atomicAdd(&ringA[t * P.nrings + ring], av); atomicAdd(&sumB[t], bv); }
+        accC = wave_sum(accC);
+        if (lane == 0) sumC[wave] = accC;
+        __syncthreads();
+        for (int tb = 0; tb < tn; tb += 32) {          // 8 lanes per offset, 32 offsets per pass
+            const int t = tb + (tid >> 3), j = tid & 7;
+            double sa = 0;
+            if (t < tn)
+                for (int b = j; b < nr; b += 8) {
+                    const float *cell = ringA + (size_t)t * NW * nr + b;
+                    const float a = ((cell[0] + cell[nr]) + cell[2 * nr]) + cell[3 * nr];
+                    sa += ((float)b <= P.ring_signed) ? (double)a : fabs((double)a);
+                }
+            sa = group8_sum_d(sa);
+            if (t < tn && j == 0) {
+                const double sb = ((sumB[t * NW] + sumB[t * NW + 1]) + sumB[t * NW + 2]) + sumB[t * NW + 3];
+                const double sc = ((sumC[0] + sumC[1]) + sumC[2]) + sumC[3];
+                score[t0 + t] = (sb > 0 && sc > 0) ? sa / sqrt(sb * sc) : 0.0;
+            }
         }
+        __syncthreads();
     }
-    accC = wave_sum(accC);
-    if (lane == 0) atomicAdd(&sumC, accC);
-    __syncthreads();
-    if (tid < T) {
-        double sa = 0;
-        for (int b = 0; b < P.nrings; b++) { float a = ringA[tid * P.nrings + b]; sa += ((float)b <= P.ring_signed) ? (double)a : fabs((double)a); }
-        const double sb = sumB[tid], sc = sumC;
-        score[tid] = (sb > 0 && sc > 0) ? sa / sqrt(sb * sc) : 0.0;
-    }
-    __syncthreads();
     if (tid == 0) {
         int bt = P.nt; double bf = score[P.nt];                  // the unshifted CTF is the incumbent
         for (int t = 0; t < T; t++) if (t != P.nt && score[t] > bf) { bf = score[t]; bt = t; }

@@ -138,12 +138,14 @@ struct ppm_ref {
     DevBuf<double> rows_in, rows_out, dir_theta, dir_phi;
     DevBuf<float> images, wring, cw, C2, nI, cc, mats, ddef;
     DevBuf<float2> band, Il, Wp, bank, twN;
+    DevBuf<float4> rowtw;            // k_global's row-pair twiddles for this reference's current search grid
     DevBuf<int> sh;
     DevBuf<uint32_t> samples;
     DevBuf<Hit> hits;
     DevBuf<LState> states, states2;
     std::string bank_key;
     long last_counts[4] = { 0, 0, 0, 0 };
+    std::string note;
 };
 
 struct ppm_accum {
@@ -280,9 +282,14 @@ static int launch_global_r(const GlobP &P, int n_img, bool half, size_t lds) {
     return 0;
 }
 
-static int launch_global(const GlobP &P, int n_img, bool half, int R) {
+static int launch_global(GlobP &P, int n_img, bool half, int R) {
     size_t lds = (size_t)P.HsP * 64 * (sizeof(float2) + sizeof(float));
     if (lds < 1024) lds = 1024;
+    // the top-K pass re-uses the block's LDS for a copy of the particle's n_orient scores when they fit (160 KB = 40 928
+    // orientations, e.g. 8 deg at C1); finer grids select on the global scratch instead
+    const size_t lds_topk = (size_t)(32 + P.n_orient) * sizeof(float);
+    P.topk_lds = lds_topk <= (size_t)160 * 1024 ? 1 : 0;
+    if (P.topk_lds && lds_topk > lds) lds = lds_topk;
     ProfScope ps(PPM_K_GLOBAL);
     switch (R) {
         case 1: return launch_global_r<1>(P, n_img, half, lds);
@@ -304,6 +311,7 @@ const char *ppm_version(void) { return "pypmatch 0.1 (gfx950)"; }
 
 int ppm_init(int device) {
     if (g.inited && g.device == device) return 0;
+    if (g.inited) return fail(-16, "libpypmatch is bound to device " + std::to_string(g.device) + " in this process (one process per GPU); start another process for device " + std::to_string(device));
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(-19, "no HIP device visible; libpypmatch has no CPU path");
     if (device < 0 || device >= count) return fail(-22, "device index out of range");
@@ -382,7 +390,7 @@ void ppm_reference_destroy(ppm_ref_t *r) {
     if (r->cube) (void)hipFree(r->cube);
     r->rows_in.release(); r->rows_out.release(); r->dir_theta.release(); r->dir_phi.release();
     r->images.release(); r->wring.release(); r->cw.release(); r->C2.release(); r->nI.release(); r->cc.release(); r->mats.release(); r->ddef.release();
-    r->band.release(); r->Il.release(); r->Wp.release(); r->bank.release(); r->twN.release(); r->sh.release(); r->samples.release();
+    r->band.release(); r->Il.release(); r->Wp.release(); r->bank.release(); r->twN.release(); r->rowtw.release(); r->sh.release(); r->samples.release();
     r->hits.release(); r->states.release(); r->states2.release();
     delete r;
 }
@@ -396,6 +404,14 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
     Geom gm; std::string err;
     if (!geom_init(gm, *cfg, err)) return fail(-22, err);
     if (gm.N != ref->N) return fail(-22, "particle box differs from the reference box");
+    ref->note.clear();
+    if (gm.r_s_asked > gm.r_s) {
+        char b[256];
+        std::snprintf(b, sizeof(b), "NOTE: global search band lowered from %.1f to %.1f Fourier pixels (%.2f A instead of %.2f A): the grid-search "
+                      "kernel covers 64 pixels; the top hits are refined up to the high-resolution limit as asked", gm.r_s_asked, gm.r_s,
+                      gm.N * gm.a / gm.r_s, gm.N * gm.a / gm.r_s_asked);
+        ref->note = b;
+    }
     if (gm.B > (ref->B + 1) / ref->pad - 1) return fail(-22, "high-resolution limit exceeds the band the reference was prepared for");
     if (cfg->global_search && gm.Bs + 1 > 64)
         return fail(-22, "global search band wider than 64 Fourier pixels is not supported; lower the 'resolution limit for search'");
@@ -403,7 +419,9 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
     int K = cfg->top_hits > 0 ? cfg->top_hits : 20;
     if (K > PPM_MAX_TOP_HITS) K = PPM_MAX_TOP_HITS;
     if (K > gm.n_orient) K = gm.n_orient;
-    const int Tb = cfg->iters_hit > 0 ? cfg->iters_hit : 2, Tc = cfg->iters_final > 0 ? cfg->iters_final : 7;
+    // answers 36 / 37 (ppm.h): a global search always refines its top hits (Tb iterations each); answer 37 decides whether the
+    // best hit continues at the full band (Tc iterations).  iters_hit < 0: hits stay at their grid points (test hook).
+    const int Tb = cfg->iters_hit > 0 ? cfg->iters_hit : (cfg->iters_hit < 0 ? 0 : 2), Tc = cfg->iters_final > 0 ? cfg->iters_final : 7;
     const double fall = cfg->mask_falloff > 0 ? cfg->mask_falloff : 20.0;
     const float fall_px = (float)(fall / gm.a), Rm_px = (float)(cfg->mask_radius / gm.a);
     const bool sep_search = cfg->global_search && cfg->search_mask_radius > 0 && cfg->search_mask_radius != cfg->mask_radius;
@@ -473,7 +491,7 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
             HIPCHK(hipMemcpyAsync(ref->dir_theta.p, dth.data(), dth.size() * sizeof(double), hipMemcpyHostToDevice, g.stream));
             HIPCHK(hipMemcpyAsync(ref->dir_phi.p, dph.data(), dph.size() * sizeof(double), hipMemcpyHostToDevice, g.stream));
             HIPCHK(hipMemcpyAsync(ref->twN.p, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice, g.stream));
-            // row twiddles of the shift window -> __constant__ (scalar loads in k_global)
+            // row twiddles of the shift window (scalar loads in k_global)
             {
                 std::vector<float4> rt((size_t)kRowTwRows * PPM_MAX_SHIFT_STEPS, make_float4(1.f, 1.f, 0.f, 0.f));
                 for (int tp = 0; tp <= gm.Bs && tp < kRowTwRows; tp++) for (int j = 1; j <= PPM_MAX_SHIFT_STEPS; j++) {
@@ -481,7 +499,9 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
                     const float c = (float)std::cos(2.0 * kPi * t / gm.Ns), sn = (float)std::sin(2.0 * kPi * t / gm.Ns);
                     rt[(size_t)tp * PPM_MAX_SHIFT_STEPS + j - 1] = make_float4(c, c, sn, sn);
                 }
-                HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_rowtw), rt.data(), rt.size() * sizeof(float4)));
+                if (int rc = ref->rowtw.ensure(rt.size())) return rc;
+                HIPCHK(hipMemcpyAsync(ref->rowtw.p, rt.data(), rt.size() * sizeof(float4), hipMemcpyHostToDevice, g.stream));
+                HIPCHK(hipStreamSynchronize(g.stream));
             }
             BankP BP; BP.cv = cv; BP.mats = ref->mats.p; BP.bank = ref->bank.p; BP.nslices = nslices; BP.Bs = gm.Bs; BP.Hs = HsP;
             BP.r_s2 = (float)(gm.r_s * gm.r_s);
@@ -551,7 +571,7 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
         LState *final_states = ref->states2.p;
         if (cfg->global_search) {
             GlobP GP;
-            GP.bank = ref->bank.p; GP.Wp = ref->Wp.p; GP.C2 = ref->C2.p; GP.nI = ref->nI.p; GP.twN = ref->twN.p;
+            GP.bank = ref->bank.p; GP.Wp = ref->Wp.p; GP.C2 = ref->C2.p; GP.nI = ref->nI.p; GP.twN = ref->twN.p; GP.rowtw = ref->rowtw.p;
             GP.cc = ref->cc.p; GP.sh = ref->sh.p; GP.hits = ref->hits.p;
             GP.Bs = gm.Bs; GP.Hs = gm.Hs; GP.HsP = HsP; GP.Ns = gm.Ns; GP.RSx = gm.RSx; GP.RSy = gm.RSy;
             GP.n_dir = gm.n_dir; GP.n_psi = gm.n_psi; GP.npsi_store = gm.npsi_store; GP.n_orient = gm.n_orient; GP.K = K;
@@ -561,34 +581,35 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
                 hipLaunchKernelGGL(k_states_from_hits, dim3((nb * K + 255) / 256), dim3(256), 0, g.stream, ref->hits.p, ref->states.p, nb, K,
                                    ref->dir_theta.p, ref->dir_phi.p, gm.n_psi, gm.dpsi, gm.step, 0.5 * gm.dstep, gm.step);
             }
-            if (cfg->local_refine) {
-                sample_evals = 0;
+            sample_evals = 0;
+            if (Tb > 0) {
                 LP.states = ref->states.p; LP.T = Tb; LP.final_rescore = 0;
+                LP.nr = std::min(nrings, (int)std::ceil(gm.r_s) + 1);
                 fill_schedule(0.5 * gm.dstep, gm.step, 0, Tb, gm.r_s, (double)K);
                 ProfScope ps(PPM_K_LOCAL);
                 // 128-thread blocks for the hit stage (<= ~800 samples per sweep: two waves waste less on the serial steps), 256 below
-                hipLaunchKernelGGL(k_local, dim3(nb * K), dim3(128), 0, g.stream, LP);
+                hipLaunchKernelGGL(k_local, dim3(nb * K), dim3(128), ring_lds_bytes(2, kMaxCand, LP.nr), g.stream, LP);
             }
             {
                 ProfScope ps(PPM_K_TOPK);
                 hipLaunchKernelGGL(k_select_best, dim3((nb + 255) / 256), dim3(256), 0, g.stream, ref->states.p, ref->states2.p, nb, K);
             }
-            if (cfg->local_refine) {
-                LP.states = ref->states2.p; LP.T = Tc; LP.final_rescore = 1;
-                fill_schedule(0.5 * gm.dstep / (double)(1 << Tb), gm.step / (double)(1 << Tb), Tb, Tc, gm.r_hi, 1.0);
+            {
+                LP.states = ref->states2.p; LP.T = cfg->local_refine ? Tc : 0; LP.final_rescore = 1; LP.nr = nrings;
+                fill_schedule(0.5 * gm.dstep / (double)(1 << Tb), gm.step / (double)(1 << Tb), Tb, LP.T, gm.r_hi, 1.0);
                 sample_evals += std::floor(kPi * gm.r_hi * gm.r_hi / 2);
                 ProfScope ps(PPM_K_LOCAL);
-                hipLaunchKernelGGL(k_local, dim3(nb), dim3(256), 0, g.stream, LP);
+                hipLaunchKernelGGL(k_local, dim3(nb), dim3(256), ring_lds_bytes(4, kMaxCand, LP.nr), g.stream, LP);
             }
         } else {
             double ha0 = cfg->local_angle_step > 0 ? cfg->local_angle_step : 2.5, hs0 = cfg->local_shift_step > 0 ? cfg->local_shift_step : 2.0;
             hipLaunchKernelGGL(k_states_from_rows, dim3((nb + 255) / 256), dim3(256), 0, g.stream, ref->rows_in.p, ref->states2.p, nb, gm.a, ha0, hs0);
             sample_evals = 0;
-            LP.states = ref->states2.p; LP.T = cfg->local_refine ? Tb + Tc : 0; LP.final_rescore = 1;
+            LP.states = ref->states2.p; LP.T = cfg->local_refine ? Tb + Tc : 0; LP.final_rescore = 1; LP.nr = nrings;
             fill_schedule(ha0, hs0, 0, LP.T, gm.r_hi, 1.0);
             sample_evals += std::floor(kPi * gm.r_hi * gm.r_hi / 2);
             ProfScope ps(PPM_K_LOCAL);
-            hipLaunchKernelGGL(k_local, dim3(nb), dim3(256), 0, g.stream, LP);
+            hipLaunchKernelGGL(k_local, dim3(nb), dim3(256), ring_lds_bytes(4, kMaxCand, LP.nr), g.stream, LP);
         }
         const float *d_ddef = nullptr;
         if (ndef > 0) {                                 // defocus offsets at the final pose
@@ -598,8 +619,9 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
             DP.rlo2 = (float)(gm.r_lo * gm.r_lo); DP.rmax2 = (float)(gm.r_hi * gm.r_hi); DP.ring_signed = LP.ring_signed; DP.a = (float)gm.a;
             DP.rows = ref->rows_in.p; DP.states = final_states; DP.ddef = ref->ddef.p; DP.nt = ndef; DP.step = cfg->defocus_step;
             const int T = 2 * ndef + 1;
+            DP.tchunk = std::max(1, std::min(T, (int)(60000 / (16 * (size_t)nrings))));      // per-wave ring tables of one pass stay below 64 KB
             ProfScope ps(PPM_K_LOCAL);
-            hipLaunchKernelGGL(k_defocus, dim3(nb), dim3(256), (size_t)(T * nrings + T) * sizeof(float), g.stream, DP);
+            hipLaunchKernelGGL(k_defocus, dim3(nb), dim3(256), ring_lds_bytes(4, DP.tchunk, nrings), g.stream, DP);
             d_ddef = ref->ddef.p;
         }
         hipLaunchKernelGGL(k_rows_out, dim3((nb + 255) / 256), dim3(256), 0, g.stream, final_states, ref->rows_in.p, ref->rows_out.p, nb, gm.a, gm.r_hi, gm.r_lo, d_ddef);
@@ -615,7 +637,7 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
     }
     // evaluation counts per particle, for the roofline's algorithmic bytes
     long nl;
-    if (cfg->global_search) nl = cfg->local_refine ? (long)K * Tb * per_iter + (long)Tc * per_iter + 1 : 0;
+    if (cfg->global_search) nl = (long)K * Tb * per_iter + (cfg->local_refine ? (long)Tc * per_iter : 0) + 1;
     else nl = 1 + (cfg->local_refine ? (long)(Tb + Tc) * per_iter : 0);
     ref->last_counts[0] = cfg->global_search ? gm.n_orient : 0;
     nl += 2L * ndef;
@@ -625,6 +647,8 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
     ref->last_counts[3] = (long)sample_evals;      // sum over the local evaluations of their in-band sample counts
     return 0;
 }
+
+const char *ppm_refine_note(ppm_ref_t *ref) { return ref ? ref->note.c_str() : ""; }
 
 int ppm_refine_last_counts(ppm_ref_t *ref, long *n_global, long *n_local, long *samples_global, long *samples_local) {
     if (!ref) return fail(-22, "null reference");

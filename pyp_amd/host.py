@@ -9,12 +9,20 @@ from . import lib
 from .abi import NCOL, STATS_COLS, K_NAMES, FinalCfg, ReconCfg, RefineCfg  # noqa: F401
 
 
+def _sync_producer(t):
+    """The library works on its own HIP stream (include/ppm.h, "Stream ordering"): whatever torch has queued on the
+    tensor's device (the copy or kernel that produced or zeroed it) must have finished before the raw pointer goes in."""
+    import torch
+    torch.cuda.current_stream(t.device).synchronize()
+
+
 def _images_arg(images, n_img, box):
     """numpy array (host) or an object with data_ptr() on the GPU (torch tensor) -> (pointer, on_device, keepalive)."""
     if hasattr(images, "data_ptr") and hasattr(images, "is_cuda"):
         if not images.is_cuda:
             images = images.numpy()
         else:
+            _sync_producer(images)
             if str(images.dtype) != "torch.float32" or not images.is_contiguous():
                 raise ValueError("ERROR: device image stack must be contiguous float32")
             if images.numel() != n_img * box * box:
@@ -51,6 +59,10 @@ class Reference:
         lib.check(lib.load().ppm_refine_batch(self.h, C.byref(cfg), p, on_dev, len(rows), lib.ptr(rows), lib.ptr(out)))
         del keep
         return out
+
+    def note(self):
+        """Remarks of the last refine() the caller should log ("" if none)."""
+        return (lib.load().ppm_refine_note(self.h) or b"").decode(errors="replace")
 
     def last_counts(self):
         v = [C.c_long() for _ in range(4)]
@@ -89,6 +101,8 @@ class Accumulator:
     def insert(self, cfg, images, rows):
         rows = np.ascontiguousarray(rows, dtype=np.float64)
         p, on_dev, keep = _images_arg(images, len(rows), self.box)
+        if self._ext is not None:
+            _sync_producer(self._ext)
         lib.check(lib.load().ppm_insert_batch(self.h, C.byref(cfg), p, on_dev, len(rows), lib.ptr(rows)))
         del keep
 
@@ -101,6 +115,8 @@ class Accumulator:
 
     def download(self):
         a = np.empty(self.nfloats, dtype=np.float32)
+        if self._ext is not None:
+            _sync_producer(self._ext)
         lib.check(lib.load().ppm_accum_download(self.h, lib.ptr(a)))
         return a
 
@@ -108,6 +124,8 @@ class Accumulator:
         a = np.ascontiguousarray(host, dtype=np.float32)
         if a.size != self.nfloats:
             raise ValueError("ERROR: dump has the wrong size for this box")
+        if self._ext is not None:
+            _sync_producer(self._ext)
         lib.check(lib.load().ppm_accum_add(self.h, lib.ptr(a)))
 
     def finalize(self, fcfg):
@@ -116,6 +134,8 @@ class Accumulator:
         h2 = np.empty_like(h1)
         fl = np.empty_like(h1)
         stats = np.zeros((n // 2 - 1, STATS_COLS), dtype=np.float64)
+        if self._ext is not None:
+            _sync_producer(self._ext)
         lib.check(lib.load().ppm_finalize(self.h, C.byref(fcfg), lib.ptr(h1), lib.ptr(h2), lib.ptr(fl), lib.ptr(stats)))
         return h1, h2, fl, stats
 
@@ -143,6 +163,7 @@ def extract_boxes(micrograph, coords, box, radius_A, pixel_size, coordinate_binn
     if hasattr(micrograph, "is_cuda") and micrograph.is_cuda:
         if str(micrograph.dtype) != "torch.float32" or not micrograph.is_contiguous() or micrograph.dim() != 2:
             raise ValueError("ERROR: device micrograph must be a contiguous 2-D float32 tensor")
+        _sync_producer(micrograph)
         ip, idev, rows, cols, keep = C.c_void_p(micrograph.data_ptr()), 1, micrograph.shape[0], micrograph.shape[1], micrograph
     else:
         a = np.ascontiguousarray(micrograph, dtype=np.float32)
@@ -152,6 +173,7 @@ def extract_boxes(micrograph, coords, box, radius_A, pixel_size, coordinate_binn
     if out is not None:
         if not out.is_cuda or out.numel() != m * box * box or not out.is_contiguous():
             raise ValueError("ERROR: output stack tensor has the wrong size or is not on the GPU")
+        _sync_producer(out)
         op, odev, res = C.c_void_p(out.data_ptr()), 1, out
     else:
         res = np.empty((m, box, box), dtype=np.float32)

@@ -28,18 +28,25 @@ class gpu_lock:
 
     def __init__(self, device):
         self.path = os.path.join(os.environ.get("PPM_LOCK_DIR", "/tmp"), "pyp_amd_gpu%d.lock" % int(device))
-        self.f = None
+        self.fd = None
 
     def __enter__(self):
         import fcntl
-        self.f = open(self.path, "w")
-        fcntl.flock(self.f, fcntl.LOCK_EX)
+        try:        # world-writable lock file: several users may share the node's GPUs
+            old = os.umask(0)
+            try:
+                self.fd = os.open(self.path, os.O_CREAT | os.O_RDWR, 0o666)
+            finally:
+                os.umask(old)
+        except OSError as e:
+            _die(f"ERROR: cannot open the GPU lock file {self.path}: {e} (set PPM_LOCK_DIR to a writable directory)")
+        fcntl.flock(self.fd, fcntl.LOCK_EX)
         return self
 
     def __exit__(self, *a):
         import fcntl
-        fcntl.flock(self.f, fcntl.LOCK_UN)
-        self.f.close()
+        fcntl.flock(self.fd, fcntl.LOCK_UN)
+        os.close(self.fd)
         return False
 
 
@@ -145,13 +152,21 @@ def refine3d_main(argv=None, stdin=None):
                 _die(f"ERROR: refine3d: padding factor {pad} needs a padded box of {box * pad} > 512")
             ref = host.Reference(vol, box / 2, device=dev, pad=pad, ring_weight=ring_w)
             rout = ref.refine(cfg, imgs, rin)
+            note = ref.note()
             ref.close()
     except (lib.PpmError, ValueError) as e:
         _die(str(e))
+    if note:
+        print("\n" + note)
     changes = rout - rin
     changes[:, C["POSITION_IN_STACK"]] = rin[:, C["POSITION_IN_STACK"]]
     if d["surface"] == "par":
-        parfile.write(d["output_params"], parfile.cistem_to_par(rout, version, change=changes[:, C["SCORE"]]), version=version)
+        # MAG and, for an extended file, the 29 trailing columns are not touched by the refinement: carried over from the input
+        nstd = 17 if version == parfile.FREALIGNX else 16
+        pout = parfile.cistem_to_par(rout, version, mag=par[sel, 6], change=changes[:, C["SCORE"]])
+        if ext:
+            pout = np.hstack([pout, par[sel, nstd:]])
+        parfile.write(d["output_params"], pout, version=version, extended=ext)
     else:
         cistem.write_parameters(d["output_params"], rout)
         if d["output_changes"] not in ("/dev/null", "null"):
