@@ -96,6 +96,19 @@ def _ssnr_ring_weights(n, stats_path, pixel):
 
 
 # ------------------------------------------------------------------------------------------ refine3d
+def refine_cfg_from_answers(d, box):
+    """ppm_refine_cfg from the parsed refine3d answers (frealign.py:3918-3994; answer numbers in include/ppm.h)."""
+    return RefineCfg.make(
+        box=box, pixel_size=d["pixel_size"], molecular_mass_kda=d["molecular_mass"], mask_radius=d["outer_radius"], res_low=d["res_low"],
+        res_high=d["res_high"], res_signed_cc=d["res_signed_cc"], search_mask_radius=d["search_mask_radius"],
+        res_search=d["res_search"], angular_step=d["angular_step"], top_hits=d["top_hits"], search_range_x=d["search_range_x"],
+        search_range_y=d["search_range_y"], global_search=int(d["global_search"]), local_refine=int(d["local_refine"]),
+        refine_psi=int(d["refine_psi"]), refine_theta=int(d["refine_theta"]), refine_phi=int(d["refine_phi"]),
+        refine_x=int(d["refine_x"]), refine_y=int(d["refine_y"]), normalize=int(d["normalize"]), invert=int(d["invert"]),
+        symmetry=d["symmetry"][:7], refine_defocus=int(d["refine_defocus"]), defocus_range=d["defocus_range"],
+        defocus_step=d["defocus_step"])
+
+
 def refine3d_main(argv=None, stdin=None):
     t0 = time.time()
     try:
@@ -135,15 +148,7 @@ def refine3d_main(argv=None, stdin=None):
         if not os.path.exists(d["statistics"]):
             _die(f"ERROR: refine3d: statistics file {d['statistics']} does not exist")
         ring_w = _ssnr_ring_weights(box, d["statistics"], px)
-    cfg = RefineCfg.make(
-        box=box, pixel_size=px, molecular_mass_kda=d["molecular_mass"], mask_radius=d["outer_radius"], res_low=d["res_low"],
-        res_high=d["res_high"], res_signed_cc=d["res_signed_cc"], search_mask_radius=d["search_mask_radius"],
-        res_search=d["res_search"], angular_step=d["angular_step"], top_hits=d["top_hits"], search_range_x=d["search_range_x"],
-        search_range_y=d["search_range_y"], global_search=int(d["global_search"]), local_refine=int(d["local_refine"]),
-        refine_psi=int(d["refine_psi"]), refine_theta=int(d["refine_theta"]), refine_phi=int(d["refine_phi"]),
-        refine_x=int(d["refine_x"]), refine_y=int(d["refine_y"]), normalize=int(d["normalize"]), invert=int(d["invert"]),
-        symmetry=d["symmetry"][:7], refine_defocus=int(d["refine_defocus"]), defocus_range=d["defocus_range"],
-        defocus_step=d["defocus_step"])
+    cfg = refine_cfg_from_answers(d, box)
     from .. import host, lib
     dev = int(os.environ.get("PPM_DEVICE", "0"))
     try:

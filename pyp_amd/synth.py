@@ -56,6 +56,26 @@ def phantom(n, seed=SEED_VOLUME, n_blobs=40, n_atoms=None):
     return np.real(np.fft.ifftn(f)).astype(np.float32)
 
 
+def phantom_sym(n, ops, seed=SEED_VOLUME, n_blobs=12):
+    """Phantom with the point-group symmetry given by `ops` (k x 3 x 3 rotation matrices acting on (x, y, z)): Gaussian blobs
+    (sigma 1.2-3 px at n = 64, scaled with n) replicated under every operator, inside radius 0.3 n."""
+    rng = np.random.default_rng(seed)
+    ax = np.arange(n, dtype=np.float32) - n // 2
+    z, y, x = np.meshgrid(ax, ax, ax, indexing="ij")
+    v = np.zeros((n, n, n), dtype=np.float32)
+    for _ in range(n_blobs):
+        while True:
+            c = rng.uniform(-0.3 * n, 0.3 * n, 3)
+            if 0.08 * n <= np.linalg.norm(c) <= 0.3 * n:
+                break
+        s = max(1.2, rng.uniform(1.2, 3.0) * n / 64.0)
+        amp = rng.uniform(0.5, 1.5)
+        for R in np.asarray(ops, dtype=np.float64).reshape(-1, 3, 3):
+            q = R @ c
+            v += amp * np.exp(-((x - q[0]) ** 2 + (y - q[1]) ** 2 + (z - q[2]) ** 2) / (2 * s * s)).astype(np.float32)
+    return v
+
+
 def euler_matrix(psi, theta, phi):
     """M = Rz(phi) Ry(theta) Rz(psi) (degrees): image-plane coordinates -> reference coordinates
     ("rotates the reference by PHI -> THETA -> PSI", src/pyp/analysis/geometry/core.py:1186-1187)."""

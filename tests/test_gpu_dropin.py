@@ -197,3 +197,106 @@ def test_in_memory_iterations_improve_the_map():
     assert cc(it2["filtered"]) >= cc(it1["filtered"]) - 1e-3 and cc(it1["filtered"]) > cc(ref0) - 0.05
     assert abs((it1["rows"][:, 11] > 0).mean() - 0.9) < 0.02                      # selection kept 90 %
     assert it2["stats"][10, 3] >= it1["stats"][10, 3] - 0.02                      # FSC at shell 11
+
+
+def test_refine3d_verbatim_default_script_matches_oracle(tmp_path):
+    """The script exactly as PYP's default iteration writes it (tests/test_surface_cpu.py:REFINE_CISTEM: global = yes,
+    local = no, 20 hits to refine, D7, 143 particles; frealign.py:3866-3871, :3918-3994) fed through the shell; the
+    refined poses are sub-grid and agree with the oracle run on the parsed answers."""
+    import io
+    from oracle import oracle
+    from pyp_amd.surface import cli, prompts
+    from test_surface_cpu import REFINE_CISTEM
+    n, px, m = 64, 4.32, 143
+    work = tmp_path / "swarm"
+    work.mkdir()
+    vol = synth.phantom_sym(n, oracle.symmetry_ops("D7"))
+    _, stack, truth = synth.make_dataset(n, m, pixel=px, snr=0.3, vol=vol, particle_rad_frac=85.0 / (n * px))
+    mrc.write(stack.numpy(), str(tmp_path / "ds_stack.mrc"), pixel_size=px)
+    mrc.write(vol, str(work / "name_r01.mrc"), pixel_size=px)
+    start = cistem.default_rows(m, px, 300.0, 2.7, 0.07)
+    for c in ("DEFOCUS_1", "DEFOCUS_2", "DEFOCUS_ANGLE"):
+        start[:, cistem.COL[c]] = truth[:, cistem.COL[c]]
+    cistem.write_parameters(str(work / "name_r01.cistem"), start)
+    assert run("refine3d", REFINE_CISTEM.replace("eot\n", ""), work, "msearch.log") == 0
+    log = open(work / "msearch.log").read()
+    assert "Refine3D: Normal termination" in log and "ERROR" not in log
+    got = cistem.read_parameters(str(work / "name_r01_0000001_0000143.cistem"))
+    assert got.shape == (m, 32)
+    d = prompts.parse_refine3d(prompts.read_answers(io.StringIO(REFINE_CISTEM)))
+    cfg = cli.refine_cfg_from_answers(d, n)
+    assert cfg.global_search == 1 and cfg.local_refine == 0 and cfg.top_hits == 20
+    rin = cistem.read_parameters(str(work / "name_r01.cistem"))
+    want, counts = oracle.refine_batch(oracle.Reference(vol, n / 2), cfg, stack.numpy(), rin)
+    assert counts[1] == 20 * 2 * 12 + 1                       # 20 hits x 2 compass iterations x 12 scores, one final score
+    assert synth.angular_error_deg(want, got).max() < 0.1 and synth.shift_error_px(want, got, px).max() < 0.5
+    assert np.abs(want[:, 14] - got[:, 14]).max() < 0.05
+    # sub-grid: most poses sit off the 20 degree grid the search walks
+    on_grid = np.isclose(got[:, 2] % 18.0, 0.0, atol=1e-3) | np.isclose(got[:, 2] % 18.0, 18.0, atol=1e-3)
+    assert on_grid.mean() < 0.1
+    # answer 26 is honoured: refining only the first hit finds worse poses on average
+    s1 = REFINE_CISTEM.replace("eot\n", "").split("\n")
+    s1[25] = "1"
+    s1[8] = "one_hit.cistem"
+    assert run("refine3d", "\n".join(s1), work, "msearch1.log") == 0
+    one = cistem.read_parameters(str(work / "one_hit.cistem"))
+    assert (got[:, 14] > one[:, 14] + 1e-3).sum() > 2 * (got[:, 14] < one[:, 14] - 1e-3).sum() and got[:, 14].mean() > one[:, 14].mean()
+
+
+def test_config1_local_refinement_1k_128_par_surface_matches_oracle(tmp_path):
+    """BASELINE.json configs[0] as SURVEY.md 8(d) states it: 1 000 particles of 128^2, one 128^3 reference, local refinement
+    (refine_mode = 1 -> global no / local yes) from poses perturbed by N(0, 2 deg) / N(0, 1 px), rhref 8 A (r = 16 px),
+    through the .par surface (answer order of src/pyp/system/wrapper_functions.py:512-561); HIP path vs oracle."""
+    import io
+    import torch
+    from oracle import oracle
+    from pyp_amd.surface import cli, prompts
+    n, px, m = 128, 1.0, 1000
+    vol, stack, truth = synth.make_dataset(n, m, pixel=px, snr=0.05, device="cuda" if torch.cuda.is_available() else "cpu")
+    imgs = stack.cpu().numpy()
+    mrc.write(imgs, str(tmp_path / "c1_stack.mrc"), pixel_size=px)
+    mrc.write(vol, str(tmp_path / "c1_r01_01.mrc"), pixel_size=px)
+    pert = synth.perturb_rows(truth, 2.0, 1.0, px)
+    parfile.write(str(tmp_path / "c1_r01_02.par"), parfile.cistem_to_par(pert, parfile.NEW), version=parfile.NEW)
+    lines = ["c1_stack.mrc", "c1_r01_02.par", "c1_r01_01.mrc", "statistics_r01.txt", "no", "c1_r01_02_match.mrc_0000001_0001000",
+             "c1_r01_02.par_0000001_0001000", "/dev/null", "C1", 1, m, px, 300.0, 2.7, 0.07, 400.0, 0.32 * n * px, 100.0, 8.0, 30.0, 8,
+             0.48 * n * px, 8.0, 200, 20, 0, 0, 0, 0, 0, 0, 500.0, 50.0, 1, "no", "yes", "yes", "yes", "yes", "yes", "yes",
+             "no", "no", "no", "no"]
+    script = "\n".join(str(x) for x in lines) + "\n"
+    assert run("refine3d", script, tmp_path, "c1.log") == 0
+    assert "Refine3D: Normal termination" in open(tmp_path / "c1.log").read()
+    out, version, ext, _, _ = parfile.read(str(tmp_path / "c1_r01_02.par_0000001_0001000"))
+    assert out.shape == (m, 16) and version == parfile.NEW
+    got = parfile.par_to_cistem(out, version, px, 300.0, 2.7, 0.07)
+    # the oracle starts from the same (two-decimal) text the executable read
+    inp, _, _, _, _ = parfile.read(str(tmp_path / "c1_r01_02.par"))
+    rin = parfile.par_to_cistem(inp, parfile.NEW, px, 300.0, 2.7, 0.07)
+    d = prompts.parse_refine3d(prompts.read_answers(io.StringIO(script)))
+    cfg = cli.refine_cfg_from_answers(d, n)
+    assert cfg.global_search == 0 and cfg.local_refine == 1 and abs(n * px / cfg.res_high - 16.0) < 1e-6
+    want, counts = oracle.refine_batch(oracle.Reference(vol, n / 2), cfg, imgs, rin)
+    assert counts[0] == 0 and counts[1] == 9 * 12 + 1
+    ang, shf = synth.angular_error_deg(want, got), synth.shift_error_px(want, got, px)
+    assert ang.max() < 0.1 and shf.max() < 0.5, (ang.max(), shf.max())          # north_star tolerance (text rounding 0.005 included)
+    assert np.abs(want[:, 14] - got[:, 14]).max() < 0.02
+    assert np.median(synth.angular_error_deg(got, truth)) < np.median(synth.angular_error_deg(rin, truth))
+    assert np.array_equal(out[:, 6], inp[:, 6]) and np.array_equal(out[:, 7], inp[:, 7])      # MAG and FILM carried over
+
+
+def test_refine3d_par_surface_keeps_extended_columns(project):
+    """A 45-column (extended NEW) input comes back with its MAG and its 29 trailing columns untouched."""
+    d, vol, imgs, truth, start = project
+    pert = synth.perturb_rows(truth[:10], 2.0, 1.0, PX)
+    base = parfile.cistem_to_par(pert, parfile.NEW, mag=12345.0)
+    ext = np.arange(10 * 29, dtype=np.float64).reshape(10, 29) / 8.0
+    ext[:, 0] = np.arange(10); ext[:, 3] = np.arange(10) % 3
+    parfile.write(str(d / "x_r01_02.par"), np.hstack([base, ext]), version=parfile.NEW, extended=True)
+    lines = ["p_stack.mrc", "x_r01_02.par", "p_r01.mrc", "statistics_r01.txt", "no", "x_match.mrc_0000001_0000010",
+             "x_r01_02.par_0000001_0000010", "/dev/null", "C1", 1, 10, PX, 300.0, 2.7, 0.07, 300.0, 0.4 * N * PX, 0, PX * N / 24, 30.0, 8,
+             0.4 * N * PX, PX * N / 24, 200, 20, 0, 0, 0, 0, 0, 0, 500.0, 50.0, 1, "no", "yes", "yes", "yes", "yes", "yes", "yes",
+             "no", "no", "no", "no"]
+    assert run("refine3d", "\n".join(str(x) for x in lines) + "\n", d, "refine_parx.log") == 0
+    data, version, extended, _, _ = parfile.read(str(d / "x_r01_02.par_0000001_0000010"))
+    inp, _, _, _, _ = parfile.read(str(d / "x_r01_02.par"))
+    assert data.shape == (10, 45) and extended and version == parfile.NEW
+    assert np.array_equal(data[:, 16:], inp[:, 16:]) and np.all(data[:, 6] == 12345.0)
