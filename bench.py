@@ -8,13 +8,21 @@ particle stack, which is resident in HBM before the timed region starts.
 Workload at N=1 = BASELINE.json configs[1]: "SPA global search: 100k 256^2 particles,
 15 deg angular step, 1 MI355X" (search band r = 64 Fourier px).  Particles
 shard across ranks with no data-path collective (weak scaling: --particles is per GPU).
+The same line carries a second block, "reconstruct" = configs[2]: Fourier insertion of
+500k 256^2 particles per GPU into the half-map accumulators + one all-reduce (RCCL).
 
-Contract: python bench.py --gpus N --steps K --warmup W   (torchrun launches N ranks for N > 1)
-prints ONE JSON line on rank 0.
+Contract: python bench.py --gpus N --steps K --warmup W
+  * N > 1 without a torchrun environment: this process starts
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`
+    as a CHILD (it never touches the GPU itself) and exits with the child's code;
+  * under torchrun (RANK / LOCAL_RANK / WORLD_SIZE set) it is one rank of N.
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,37 +31,161 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PEAK_VALU_TFLOPS = 157.3      # MI355X_MICROARCH.md: peak fp32 vector
+PEAK_HBM_GBPS = 8000.0        # HBM3E spec
 
-def parse():
+
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--particles", type=int, default=100000, help="particles per GPU per step (resident stack)")
+    ap.add_argument("--particles", type=int, default=100000, help="particles per GPU per step of the refinement workload (resident stack)")
+    ap.add_argument("--recon-particles", type=int, default=500000, help="particles per GPU per step of the reconstruction block")
     ap.add_argument("--box", type=int, default=256)
     ap.add_argument("--band", type=float, default=64.0, help="search / refinement band limit, Fourier pixels")
     ap.add_argument("--angular-step", type=float, default=15.0)
-    ap.add_argument("--unique", type=int, default=512, help="distinct clean projections (each particle gets fresh noise)")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target wall time of the CPU oracle sample (0 = skip)")
+    ap.add_argument("--unique", type=int, default=0, help="distinct clean projections (0 = one per particle: every particle has its own pose)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of each CPU oracle leg (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--workload", choices=["refine", "reconstruct"], default="refine",
-                    help="refine = BASELINE.json configs[1] (the headline metric); reconstruct = configs[2]: Fourier insertion into "
-                         "half-map accumulators + one all-reduce over the ranks")
-    return ap.parse_args()
+    ap.add_argument("--workload", choices=["both", "refine", "reconstruct"], default="both",
+                    help="both = the refinement line (BASELINE.json configs[1], the headline metric) carrying a 'reconstruct' block "
+                         "(configs[2]); refine / reconstruct = that workload alone (the line's metric is then that workload's)")
+    return ap.parse_args(argv)
 
 
-def main():
-    a = parse()
+# --------------------------------------------------------------------------------------------- launcher
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(a, argv):
+    """--gpus N outside torchrun: start the N ranks as a child torchrun.  Nothing here initialises the GPU
+    (torch.cuda.device_count() does not), and the child is a new process, not an exec of this one."""
+    probe = os.environ.get("PPM_BENCH_PROBE") == "1"
+    if not probe and "PPM_FORCE_DEVICE" not in os.environ:
+        import torch
+        have = torch.cuda.device_count()
+        if have < a.gpus:
+            print(f"ERROR: bench.py --gpus {a.gpus}: only {have} GPU(s) visible", file=sys.stderr)
+            return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def probe_main(a, rank, world):
+    """PPM_BENCH_PROBE=1: the launcher / rendezvous / timing-reduction path without any GPU work (CPU test of --gpus N)."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group(os.environ.get("PPM_DIST_BACKEND", "gloo"))
+        dist.barrier()
+    t = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "particles/sec projection-matching, 256^2 box", "value": None, "unit": "particles/s", "n_gpus": world,
+                          "steps": a.steps, "warmup": a.warmup, "probe": True, "max_over_ranks_s": float(t.item())}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+# --------------------------------------------------------------------------------------------- helpers
+def so_sha16():
+    import hashlib
+    p = os.path.join(ROOT, "pyp_amd", "libpypmatch.so")
+    return hashlib.sha256(open(p, "rb").read()).hexdigest()[:16] if os.path.exists(p) else None
+
+
+def pmc_entry(summary, kernel):
+    """One kernel's counters from a committed rocprofv3 --pmc summary (scripts/pmc_r02.sh -> scripts/pmc_summary.py).
+    Returns (entry, meta) or (None, None)."""
+    path = os.path.join(ROOT, "profiles", summary)
+    if not os.path.exists(path):
+        return None, None
+    d = json.load(open(path))
+    meta = d.get("_meta", {})
+    key = [k for k in d if kernel in k]
+    return (d[key[0]], meta) if key else (None, meta)
+
+
+def pmc_traffic(summary, kernel, particles_per_launch):
+    """HBM-side bytes per launch of `kernel`: FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes (units of 1 KB);
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 (128-byte requests tallied at 64 B); scaled from the
+    profiled particle count to this launch.  None when no summary with these counters is committed; the source string says
+    whether the summary was taken from the library build that is being timed."""
+    e, meta = pmc_entry(summary, kernel)
+    if not e or "FETCH_SIZE" not in e or "WRITE_SIZE" not in e or not meta.get("particles"):
+        return None, "no FETCH_SIZE / WRITE_SIZE summary for %s under profiles/%s" % (kernel, summary)
+    per_particle = (2.0 * e["FETCH_SIZE"]["sum"] + e["WRITE_SIZE"]["sum"]) * 1024.0 / meta["particles"]
+    same = meta.get("so_sha16") == so_sha16()
+    src = "profiles/%s (%d particles, 2 x FETCH_SIZE + WRITE_SIZE, KB; library %s%s)" % (
+        summary, meta["particles"], meta.get("so_sha16", "?"), " = timed build" if same else ", timed build is " + str(so_sha16()))
+    return per_particle * particles_per_launch, src
+
+
+def pmc_valu(summary, kernel, slices_per_particle):
+    """Vector-instruction counters of the same summary: wave-instructions per particle and per stored slice."""
+    e, meta = pmc_entry(summary, kernel)
+    if not e or "SQ_INSTS_VALU" not in e or not meta.get("particles"):
+        return None
+    per_particle = e["SQ_INSTS_VALU"]["sum"] / meta["particles"]
+    out = {"source": "profiles/" + summary, "SQ_INSTS_VALU_per_particle": round(per_particle, 1),
+           "SQ_INSTS_VALU_per_slice": round(per_particle / slices_per_particle, 1)}
+    for c in ("SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY"):
+        if c in e:
+            out[c + "_per_particle"] = round(e[c]["sum"] / meta["particles"], 1)
+    return out
+
+
+def global_flops_per_slice(band, search_range_px, box):
+    """Executed fp32 operations of k_global per STORED slice (it serves psi and psi + 180): per lane and row PAIR
+    16 R FMA-flops for the shift rows (4 R packed FMAs on 2-vectors), 12 for the model norm and 20 for the even / odd
+    (A, Bq) parts; about 800 per lane for the window reduction and the recombination.  Row pairs = HsP / 2 with
+    HsP = 2 (Bs + 1) rounded up to the loop's trip (16 rows for R <= 3, 8 above); 64 lanes, masked lanes included
+    (they execute).  DESIGN.md §4."""
+    Bs = int(np.ceil(band)) - 1
+    Ns = 2
+    while Ns < 2 * (Bs + 1):
+        Ns *= 2
+    R = max(1, min(8, int(np.ceil(search_range_px / (box / Ns))))) if search_range_px > 0 else 8
+    trip = 16 if R <= 3 else 8
+    HsP = ((2 * (Bs + 1) + trip - 1) // trip) * trip
+    return 64 * (HsP // 2) * (16 * R + 12 + 20) + 64 * 800, R, HsP
+
+
+# --------------------------------------------------------------------------------------------- main
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    a = parse(argv)
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        return launch_ranks(a, argv)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(a.gpus, 1) and rank == 0:
+        print(f"WARNING: --gpus {a.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
+    if os.environ.get("PPM_BENCH_PROBE") == "1":
+        return probe_main(a, rank, world)
     if "PPM_FORCE_DEVICE" in os.environ:          # rehearsal of the N > 1 path on a one-GPU box (with PPM_DIST_BACKEND=gloo)
         local = int(os.environ["PPM_FORCE_DEVICE"])
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
         print("ERROR: bench.py needs a GPU (the product path has no CPU fallback)", file=sys.stderr)
-        sys.exit(2)
+        return 2
+    if local >= torch.cuda.device_count():
+        print(f"ERROR: rank {rank} wants device {local}, only {torch.cuda.device_count()} visible", file=sys.stderr)
+        return 2
     torch.cuda.set_device(local)
     if world > 1:
         backend = os.environ.get("PPM_DIST_BACKEND", "nccl")          # "nccl" is RCCL on ROCm
@@ -61,35 +193,73 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
-    from pyp_amd import host, synth
-    from pyp_amd.abi import RefineCfg
+    ctx = dict(a=a, rank=rank, world=world, local=local, dev=torch.device("cuda", local), px=1.0)
+    from pyp_amd import synth
+    ctx["vol"] = synth.phantom(a.box)
+    line = None
+    if a.workload in ("both", "refine"):
+        line = refine_bench(ctx)
+    if a.workload in ("both", "reconstruct"):
+        rec = reconstruct_bench(ctx)
+        if rank == 0:
+            if line is None:
+                line = rec
+            else:
+                line["reconstruct"] = rec
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
 
-    N, M, px = a.box, a.particles, 1.0
-    dev = torch.device("cuda", local)
-    # ---- synthetic inputs: phantom, poses, CTF, SNR 0.05; rank r gets its own poses/noise
-    vol = synth.phantom(N)
-    _, stack, rows = synth.make_dataset(N, M, pixel=px, snr=0.05, vol=vol, device=dev, unique=min(a.unique, M),
-                                        seed_poses=synth.SEED_POSES + rank, seed_noise=synth.SEED_NOISE + rank, batch=32)
-    torch.cuda.synchronize()
-    res = px * N / a.band
-    cfg = RefineCfg.make(box=N, pixel_size=px, mask_radius=0.32 * N * px, res_high=res, res_search=res, res_low=0.0,
-                         angular_step=a.angular_step, top_hits=20, search_range_x=6.0 * px, search_range_y=6.0 * px,
-                         res_signed_cc=30.0, molecular_mass_kda=500.0)
-    if a.workload == "reconstruct":
-        return reconstruct_bench(a, rank, world, local, dev, vol, stack, rows, N, M, px)
-    t0 = time.time()
-    ref = host.Reference(vol, N / 2, device=local)
-    t_refprep = time.time() - t0
-    start_rows = synth.cistem.default_rows(M, px, 300.0, 2.7, 0.07)      # from-scratch rows: the search ignores the poses
-    for c in ("DEFOCUS_1", "DEFOCUS_2", "DEFOCUS_ANGLE"):
-        start_rows[:, synth.cistem.COL[c]] = rows[:, synth.cistem.COL[c]]
+
+def make_barrier(world):
+    import torch
+    import torch.distributed as dist
+    from pyp_amd import host
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         host.lib.load().ppm_device_sync()
+    return barrier
 
+
+def max_over_ranks(dt, world, dev):
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def refine_bench(ctx):
+    import torch
+    from pyp_amd import host, synth
+    from pyp_amd.abi import RefineCfg
+    a, rank, world, local, dev, px, vol = (ctx[k] for k in ("a", "rank", "world", "local", "dev", "px", "vol"))
+    N, M = a.box, a.particles
+    # ---- synthetic inputs: phantom, one pose per particle, CTF, SNR 0.05; rank r gets its own poses / noise
+    uniq = M if a.unique <= 0 else min(a.unique, M)
+    _, stack, rows = synth.make_dataset(N, M, pixel=px, snr=0.05, vol=vol, device=dev, unique=uniq,
+                                        seed_poses=synth.SEED_POSES + rank, seed_noise=synth.SEED_NOISE + rank, batch=32)
+    torch.cuda.synchronize()
+    res = px * N / a.band
+    srange = 6.0 * px
+    cfg = RefineCfg.make(box=N, pixel_size=px, mask_radius=0.32 * N * px, res_high=res, res_search=res, res_low=0.0,
+                         angular_step=a.angular_step, top_hits=20, search_range_x=srange, search_range_y=srange,
+                         res_signed_cc=30.0, molecular_mass_kda=500.0)
+    t0 = time.time()
+    ref = host.Reference(vol, N / 2, device=local)
+    t_refprep = time.time() - t0
+    start_rows = synth.cistem.default_rows(M, px, 300.0, 2.7, 0.07)      # from-scratch rows: the search ignores the poses
+    for c in ("DEFOCUS_1", "DEFOCUS_2", "DEFOCUS_ANGLE"):
+        start_rows[:, synth.cistem.COL[c]] = rows[:, synth.cistem.COL[c]]
+    barrier = make_barrier(world)
     out = None
     for _ in range(a.warmup):
         out = ref.refine(cfg, stack, start_rows)
@@ -99,120 +269,98 @@ def main():
     for _ in range(a.steps):
         out = ref.refine(cfg, stack, start_rows)
     barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(time.perf_counter() - t0, world, dev)
     prof = host.profile_report()
     host.profile(False, False)
     counts = ref.last_counts()
-
-    if rank == 0:
-        total = world * M * a.steps
-        value = total / dt
-        # ---- roofline of the dominant kernel: algorithmic bytes per launch / measured launch time (HIP events
-        # recorded by the library on its own stream around every launch).  SURVEY.md §8(d) streaming model:
-        # 8 S(r) bytes per orientation evaluated (+ 4 N^2 + 128 per particle for the whole path).
-        S_g = counts["samples_global"]
-        launches_g = max(prof["global"]["launches"], 1)
-        per_launch_particles = M * a.steps / launches_g
-        bytes_g = per_launch_particles * counts["n_global"] * 8.0 * S_g
-        ms_g = prof["global"]["ms"] / launches_g
-        bytes_l_total = M * a.steps * 8.0 * counts["samples_local"]          # samples_local = sum over local evaluations
-        ms_l_total = max(prof["local"]["ms"], 1e-9)
-        dom = "global" if prof["global"]["ms"] >= prof["local"]["ms"] else "local"
-        if dom == "global":
-            achieved = bytes_g / (ms_g * 1e-3) / 1e9
-            kname, kms, kbytes = "k_global", ms_g, bytes_g
-        else:
-            nl = max(prof["local"]["launches"], 1)
-            achieved = bytes_l_total / (ms_l_total * 1e-3) / 1e9
-            kname, kms, kbytes = "k_local", ms_l_total / nl, bytes_l_total / nl
-        b_pm = 4.0 * N * N + counts["n_global"] * 8.0 * S_g + 8.0 * counts["samples_local"] + 128
-        traffic, traffic_src = pmc_traffic(kname, per_launch_particles if dom == "global" else M * a.steps / max(prof["local"]["launches"], 1))
-        roof = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(kms, 3),
-                "algorithmic_bytes_per_launch": kbytes,
-                "note": "streaming-model bytes (8 S(r) per orientation); the slice bank is served from L2 / Infinity Cache and each "
-                        "stored slice serves psi and psi+180, so frac can exceed the HBM-only ceiling; the kernel is fp32-VALU bound",
-                "path_bytes_per_particle": b_pm, "path_achieved_GBps": round(b_pm * M * a.steps / dt / 1e9, 1),
-                "path_frac": round(b_pm * M * a.steps / dt / 8e12, 4)}
-        if dom == "global":
-            # secondary: fp32 vector rate of k_global.  Per slice row pair and lane: 24 FMA (shift rows), 2 x 3 for the norm,
-            # 8 mul + 12 add for the (A, Bq) even/odd parts; plus ~800 ops per lane and slice for the window reduction.
-            R = 3
-            flops_slice = 64 * 64 * (2 * 8 * R + 12 + 20) + 64 * 800
-            flops = per_launch_particles * (counts["n_global"] / 2) * flops_slice
-            roof["k_global_fp32_TFLOPs"] = round(flops / (ms_g * 1e-3) / 1e12, 1)
-            roof["k_global_fp32_frac_of_157"] = round(flops / (ms_g * 1e-3) / 157.3e12, 3)
-        # ---- accuracy of what was timed (vs the synthetic ground truth), first 2000 particles
-        k = min(M, 2000)
-        ang = synth.angular_error_deg(out[:k], rows[:k])
-        shf = synth.shift_error_px(out[:k], rows[:k], px)
-        line = {
-            "metric": "particles/sec projection-matching, 256^2 box", "value": round(value, 1), "unit": "particles/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "SPA global search: %dk %d^2 particles/GPU, %g deg angular step, band r=%g px, top-20 hits refined"
-                       % (M // 1000, N, a.angular_step, a.band), "particles_per_gpu": M, "box": N, "orientations": counts["n_global"],
-                       "local_evaluations": counts["n_local"], "parallelism": "particle-sharded x%d" % world},
-            "roofline": roof,
-            "kernels_ms": {k2: round(v["ms"], 2) for k2, v in prof.items() if v["launches"]},
-            "reference_prep_s": round(t_refprep, 3),
-            "accuracy_vs_truth": {"median_deg": round(float(np.median(ang)), 3), "frac_within_2deg": round(float((ang < 2).mean()), 3),
-                                  "median_shift_px": round(float(np.median(shf)), 3)},
-        }
-        if not a.no_cpu and a.cpu_seconds > 0:
-            line["cpu_baseline"] = cpu_baseline(vol, stack, start_rows, cfg, N, a.cpu_seconds)
-        print(json.dumps(line))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
-
-
-def pmc_traffic(kernel, particles_per_launch, summary="r01_final5_pmc_traffic_refine_8k.json", profiled=8000):
-    """HBM-side bytes per launch of `kernel` from a committed rocprofv3 --pmc summary (scripts/pmc_traffic.sh: FETCH_SIZE and
-    WRITE_SIZE in separate passes; units of 1 KB; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), scaled
-    from the profiled particle count to this launch.  None when no summary is committed."""
-    path = os.path.join(ROOT, "profiles", summary)
-    if not os.path.exists(path):
-        return None, None
-    d = json.load(open(path))
-    key = [k for k in d if kernel in k]
-    if not key or "FETCH_SIZE" not in d[key[0]] or "WRITE_SIZE" not in d[key[0]]:
-        return None, None
-    e = d[key[0]]
-    per_particle = (2.0 * e["FETCH_SIZE"]["sum"] + e["WRITE_SIZE"]["sum"]) * 1024.0 / profiled
-    return per_particle * particles_per_launch, "profiles/%s (%d particles, FETCH_SIZE x2 + WRITE_SIZE, KB)" % (summary, profiled)
+    ref.close()
+    if rank != 0:
+        del stack
+        torch.cuda.empty_cache()
+        return None
+    total = world * M * a.steps
+    value = total / dt
+    # ---- roofline of the dominant kernel, from the launch durations the library measured with HIP events on ITS stream
+    # around every launch of the timed region
+    S_g = counts["samples_global"]
+    launches_g = max(prof["global"]["launches"], 1)
+    ppl = M * a.steps / launches_g                                            # particles per k_global launch
+    ms_g = prof["global"]["ms"] / launches_g
+    fl_slice, R, HsP = global_flops_per_slice(a.band, srange / px, N)
+    n_slices = counts["n_global"] / 2.0                                        # stored slices (psi and psi + 180 share one)
+    flops_g = ppl * n_slices * fl_slice
+    tf = flops_g / (ms_g * 1e-3) / 1e12
+    bytes_model = ppl * counts["n_global"] * 8.0 * S_g                        # SURVEY §8(d) streaming model
+    gbps_model = bytes_model / (ms_g * 1e-3) / 1e9
+    traffic, traffic_src = pmc_traffic("r02_pmc_refine.json", "k_global", ppl)
+    roof = {"bound": "valu_fp32", "kernel": "k_global", "achieved": round(tf, 2), "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tf / PEAK_VALU_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(ms_g, 3),
+            "particles_per_launch": round(ppl, 1), "flops_per_launch": flops_g,
+            "flop_model": "stored slices (%d) x [64 lanes x %d row pairs x (16 R + 32) + 64 x 800], R = %d shift rows; executed fp32 "
+                          "operations incl. masked lanes (DESIGN.md §4)" % (int(n_slices), HsP // 2, R),
+            "in_band_fraction_of_lane_rows": round(S_g / (64.0 * HsP), 3),
+            "hbm_streaming_model": {"bytes_per_launch": bytes_model, "GBps": round(gbps_model, 1),
+                                    "frac_clamped": round(min(1.0, gbps_model / PEAK_HBM_GBPS), 4), "exceeds_peak": bool(gbps_model > PEAK_HBM_GBPS),
+                                    "note": "SURVEY §8(d) contract figure 8 S(r) bytes per orientation; the 144 MB slice bank is shared by all "
+                                            "particles and served from L2 / Infinity Cache, so this is not HBM traffic (see traffic)"},
+            "hbm_traffic_frac": None if traffic is None else round(traffic / (ms_g * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4)}
+    pv = pmc_valu("r02_pmc_refine.json", "k_global", n_slices)
+    if pv:
+        pv["model_flops_per_lane_instruction"] = round(fl_slice / (pv["SQ_INSTS_VALU_per_slice"] * 64.0), 3)
+        roof["pmc"] = pv
+    b_pm = 4.0 * N * N + counts["n_global"] * 8.0 * S_g + 8.0 * counts["samples_local"] + 128
+    per_particle_us = {k2: round(v["ms"] * 1e3 / (M * a.steps), 3) for k2, v in prof.items() if v["launches"]}
+    k = min(M, 2000)
+    ang = synth.angular_error_deg(out[:k], rows[:k])
+    shf = synth.shift_error_px(out[:k], rows[:k], px)
+    line = {
+        "metric": "particles/sec projection-matching, 256^2 box", "value": round(value, 1), "unit": "particles/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "SPA global search: %dk %d^2 particles/GPU, %g deg angular step, band r=%g px, top-20 hits refined + best hit "
+                               "continued at the full band" % (M // 1000, N, a.angular_step, a.band),
+                   "particles_per_gpu": M, "distinct_poses_per_gpu": uniq, "box": N, "orientations": counts["n_global"],
+                   "local_evaluations": counts["n_local"], "parallelism": "particle-sharded x%d" % world},
+        "roofline": roof,
+        "compulsory_bytes_per_particle": 4 * N * N + 128, "contract_bytes_per_particle": b_pm,
+        "kernels_ms": {k2: round(v["ms"], 2) for k2, v in prof.items() if v["launches"]},
+        "kernels_us_per_particle": per_particle_us,
+        "reference_prep_s": round(t_refprep, 3), "library": so_sha16(),
+        "accuracy_vs_truth": {"median_deg": round(float(np.median(ang)), 3), "frac_within_2deg": round(float((ang < 2).mean()), 3),
+                              "median_shift_px": round(float(np.median(shf)), 3)},
+    }
+    if world == 1 and not a.no_cpu and a.cpu_seconds > 0:
+        line["cpu_baseline"] = cpu_baseline(vol, stack, start_rows, cfg, N, a.cpu_seconds)
+    del stack
+    torch.cuda.empty_cache()
+    return line
 
 
-def reconstruct_bench(a, rank, world, local, dev, vol, stack, rows, N, M, px):
+def reconstruct_bench(ctx):
     """configs[2]: every rank inserts its particles into private accumulators (a torch tensor handed to the
     library), then ONE all-reduce (sum, f32) over RCCL; finalisation on rank 0 is outside the timed region."""
     import torch
-    import torch.distributed as dist
     from pyp_amd import dist as pdist
-    from pyp_amd import host
+    from pyp_amd import host, synth
     from pyp_amd.abi import FinalCfg, ReconCfg
+    a, rank, world, local, dev, px, vol = (ctx[k] for k in ("a", "rank", "world", "local", "dev", "px", "vol"))
+    N, M = a.box, a.recon_particles
+    uniq = min(M, 4096 if a.unique <= 0 else a.unique)     # distinct poses; every particle still has its own noise (insertion cost is pose-independent)
+    _, stack, rows = synth.make_dataset(N, M, pixel=px, snr=0.05, vol=vol, device=dev, unique=uniq,
+                                        seed_poses=synth.SEED_POSES + 100 + rank, seed_noise=synth.SEED_NOISE + 100 + rank, batch=32)
+    torch.cuda.synchronize()
     nfl = int(host.lib.load().ppm_accum_floats(N))
     host.lib.init(local)
     acc_t = torch.zeros(nfl, dtype=torch.float32, device=dev)
     acc = host.Accumulator(N, px, "C1", device=local, ext_tensor=acc_t)
     rows = rows.copy()
-    rows[:, 0] += rank * M                 # global positions: half assignment must not depend on the rank count
+    rows[:, 0] = np.arange(1, M + 1) + rank * M     # global positions: half assignment must not depend on the rank count
     rc = ReconCfg(box=N, pixel_size=px, res_limit=2 * px, score_weight_bfactor=0.0, score_average=0.0, score_threshold=0.0,
                   normalize=1, invert=0, split_by_pind=0, mask_radius=0.32 * N * px)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        host.lib.load().ppm_device_sync()
+    barrier = make_barrier(world)
 
     def step():
         acc_t.zero_()
-        torch.cuda.synchronize()
         acc.set_counts(0, 0)
         acc.insert(rc, stack, rows)
         return pdist.reduce_accumulators(acc_t, acc.counts())[1]
@@ -226,69 +374,119 @@ def reconstruct_bench(a, rank, world, local, dev, vol, stack, rows, N, M, px):
     for _ in range(a.steps):
         counts = step()
     barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(time.perf_counter() - t0, world, dev)
     prof = host.profile_report()
     host.profile(False, False)
-    if rank == 0:
-        S = int(np.floor(np.pi * (N / 2) ** 2 / 2))
-        b_ins = 4.0 * N * N + S * 192.0
-        nl = max(prof["insert"]["launches"], 1)
-        ms = prof["insert"]["ms"] / nl
-        achieved = (M * a.steps / nl) * (S * 192.0) / (ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic("k_insert_bricks", M * a.steps / nl, "r01_final5_pmc_traffic_reconstruct_16k.json", 16000)
-        acc.set_counts(counts[0], counts[1])
-        h1, h2, fl, stats = acc.finalize(FinalCfg(molecular_mass_kda=500.0, inner_radius=0.0, outer_radius=0.45 * N * px, mask_falloff=0.0))
-        cc = float(np.corrcoef(fl.ravel(), vol.ravel())[0, 1])
-        line = {"metric": "particles/sec Fourier insertion, 256^2 box", "value": round(world * M * a.steps / dt, 1), "unit": "particles/s",
-                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True,
-                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": "3D reconstruction: Fourier-insert %dk %d^2 particles/GPU -> %d^3 half-maps, C1, one all-reduce"
-                           % (M // 1000, N, N), "particles_per_gpu": M, "box": N, "parallelism": "particle-sharded x%d" % world},
-                "roofline": {"bound": "hbm", "kernel": "k_insert_bricks", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                             "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(ms, 3),
-                             "note": "algorithmic bytes (SURVEY 8d) = S(N/2) x 8 taps x 12 B x 2 (read-modify-write) per particle, i.e. what a "
-                                     "scatter into HBM would move; k_insert_bricks keeps 16^3-voxel bricks of the accumulator in LDS "
-                                     "(64-bit fixed point, ds_add_u64) and touches HBM once per brick and launch, so its real HBM traffic "
-                                     "is far below that figure (see traffic) and the kernel is VALU / LDS-atomic bound (profiles/r01_bricks_pmc_reconstruct_8k.json)",
-                             "path_bytes_per_particle": b_ins},
-                "kernels_ms": {k2: round(v["ms"], 2) for k2, v in prof.items() if v["launches"]},
-                "map_cc_vs_truth": round(cc, 4), "fsc_at_half_nyquist": round(float(stats[N // 4 - 1, 3]), 4)}
-        print(json.dumps(line))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    if rank != 0:
+        acc.close()
+        return None
+    S = int(np.floor(np.pi * (N / 2) ** 2 / 2))
+    b_ins = 4.0 * N * N + S * 192.0
+    per_us = {k2: round(v["ms"] * 1e3 / (M * a.steps), 3) for k2, v in prof.items() if v["launches"]}
+    # dominant kernel of this workload: pre-processing (image -> band spectrum) or brick insertion
+    dom = "prep" if prof["prep"]["ms"] >= prof["insert"]["ms"] else "insert"
+    nl = max(prof[dom]["launches"], 1)
+    ms = prof[dom]["ms"] / nl
+    ppl = M * a.steps / nl
+    kname = "k_prep" if dom == "prep" else "k_insert_bricks"
+    traffic, traffic_src = pmc_traffic("r02_pmc_reconstruct.json", kname, ppl)
+    if dom == "prep":
+        B = N // 2 - 1
+        alg = ppl * (4.0 * N * N + 8.0 * (2 * B + 1) * (B + 1))       # image read once + band spectrum written once
+        what = "4 N^2 image bytes read + 8 (2B+1)(B+1) band-spectrum bytes written per particle"
+    else:
+        B = N // 2 - 1
+        alg = ppl * 8.0 * (2 * B + 1) * (B + 1)                        # band spectrum read once; the bricks live in LDS
+        what = "band spectrum read once (8 (2B+1)(B+1) bytes per particle); accumulator bricks are written once per launch"
+    gbps = alg / (ms * 1e-3) / 1e9
+    model_gbps = ppl * S * 192.0 / (ms * 1e-3) / 1e9
+    roof = {"bound": "hbm", "kernel": kname, "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 4),
+            "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(ms, 3), "particles_per_launch": round(ppl, 1),
+            "algorithmic_bytes": what,
+            "scatter_model": {"bytes_per_particle": b_ins, "GBps": round(model_gbps, 1), "frac_clamped": round(min(1.0, model_gbps / PEAK_HBM_GBPS), 4),
+                              "exceeds_peak": bool(model_gbps > PEAK_HBM_GBPS),
+                              "note": "SURVEY §8(d) contract figure (what a scatter into HBM would move: S x 8 taps x 12 B x 2); the bricks are "
+                                      "accumulated in LDS, so this is not HBM traffic"}}
+    acc.set_counts(counts[0], counts[1])
+    h1, h2, fl, stats = acc.finalize(FinalCfg(molecular_mass_kda=500.0, inner_radius=0.0, outer_radius=0.45 * N * px, mask_falloff=0.0))
+    acc.close()
+    cc = float(np.corrcoef(fl.ravel(), vol.ravel())[0, 1])
+    return {"metric": "particles/sec Fourier insertion, 256^2 box", "value": round(world * M * a.steps / dt, 1), "unit": "particles/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "3D reconstruction: Fourier-insert %dk %d^2 particles/GPU (resident stack, %.0f GB) -> %d^3 half-maps, C1, "
+                                   "one all-reduce" % (M // 1000, N, M * N * N * 4 / 1e9, N),
+                       "particles_per_gpu": M, "box": N, "parallelism": "particle-sharded x%d" % world},
+            "roofline": roof, "kernels_ms": {k2: round(v["ms"], 2) for k2, v in prof.items() if v["launches"]},
+            "kernels_us_per_particle": per_us, "compulsory_bytes_per_particle": 4 * N * N,
+            "path_hbm_frac_compulsory": round(world * M * a.steps * 4.0 * N * N / dt / 1e9 / PEAK_HBM_GBPS / world, 4),
+            "map_cc_vs_truth": round(cc, 4), "fsc_at_half_nyquist": round(float(stats[N // 4 - 1, 3]), 4)}
 
 
+# --------------------------------------------------------------------------------------------- CPU legs
 def cpu_baseline(vol, stack, start_rows, cfg, N, seconds):
-    """The CPU oracle (kind "port": the reference binaries are absent) on a bounded sample of
-    the SAME stack, all host cores via OpenMP, reference preparation excluded like on the GPU side."""
+    """The CPU oracle (kind "port": the reference binaries are absent) on bounded samples of the SAME stack,
+    three ways: all host cores through OpenMP (the headline `value`), one thread, and P independent
+    single-thread processes that each prepare the reference themselves - the reference's process model
+    (one refine3d per particle range with OMP_NUM_THREADS=1, src/pyp/refine/frealign/frealign.py:3183)."""
+    import ctypes
+    import tempfile
     from oracle import oracle
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    os.environ["OMP_NUM_THREADS"] = str(cores)
+    gomp = ctypes.CDLL("libgomp.so.1")
+    imgs = stack[:max(2 * cores, 8)].cpu().numpy()
     t0 = time.time()
     oref = oracle.Reference(vol, N / 2)
     t_prep = time.time() - t0
+    legs = {}
+    # ---- one thread, one particle (+ its own reference preparation)
+    gomp.omp_set_num_threads(1)
+    t0 = time.time()
+    oracle.refine_batch(oref, cfg, imgs[:1], start_rows[:1], ccf_mode=1)
+    t1 = time.time() - t0
+    legs["single_thread"] = {"value": round(1.0 / t1, 4), "unit": "particles/s", "cores": 1,
+                             "value_incl_reference_prep": round(1.0 / (t1 + t_prep), 4),
+                             "sample": "1 particle, %.1f s; reference preparation %.1f s" % (t1, t_prep)}
+    # ---- all cores, OpenMP over particles
+    gomp.omp_set_num_threads(cores)
     n = cores
-    imgs = stack[:max(4 * cores, 8)].cpu().numpy()
     t0 = time.time()
     oracle.refine_batch(oref, cfg, imgs[:n], start_rows[:n], ccf_mode=1)
-    t1 = time.time() - t0
-    rate = n / t1
-    if t1 < 0.5 * seconds and len(imgs) > n:     # extend the sample towards the time budget
-        n2 = int(min(len(imgs), max(n, rate * seconds)))
-        n2 = max(cores, (n2 // cores) * cores)
+    t2 = time.time() - t0
+    if t2 < 0.5 * seconds and len(imgs) > n:
+        n2 = max(cores, (int(min(len(imgs), n / t2 * seconds)) // cores) * cores)
         t0 = time.time()
         oracle.refine_batch(oref, cfg, imgs[:n2], start_rows[:n2], ccf_mode=1)
-        t1 = time.time() - t0
-        n = n2
-        rate = n / t1
-    return {"value": round(rate, 3), "unit": "particles/s", "cores": cores, "kind": "port",
-            "sample": "%d particles of the same stack, %.1f s wall, OpenMP over particles; reference prep %.1f s excluded" % (n, t1, t_prep)}
+        t2, n = time.time() - t0, n2
+    legs["openmp_all_cores"] = {"value": round(n / t2, 3), "unit": "particles/s", "cores": cores,
+                                "sample": "%d particles, %.1f s wall, OpenMP over particles; reference preparation %.1f s excluded" % (n, t2, t_prep)}
+    oref.close()
+    # ---- P single-thread processes, one particle range each, reference prepared per process
+    P = max(1, min(cores, 64))
+    per = 1
+    tmp = tempfile.mkdtemp(prefix="ppm_cpu_leg_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        np.save(os.path.join(tmp, "vol.npy"), vol)
+        np.save(os.path.join(tmp, "imgs.npy"), imgs[:P * per])
+        np.save(os.path.join(tmp, "rows.npy"), start_rows[:P * per])
+        with open(os.path.join(tmp, "cfg.bin"), "wb") as f:
+            f.write(bytes(cfg))
+        env = dict(os.environ, OMP_NUM_THREADS="1", NCPUS="1")
+        t0 = time.time()
+        procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "oracle", "cpu_leg.py"), tmp, str(i * per), str((i + 1) * per)], env=env)
+                 for i in range(P)]
+        rcs = [p.wait() for p in procs]
+        t3 = time.time() - t0
+    finally:
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+    if all(r == 0 for r in rcs):
+        legs["processes_single_thread"] = {"value": round(P * per / t3, 3), "unit": "particles/s", "cores": P,
+                                           "sample": "%d processes x %d particle(s), OMP_NUM_THREADS=1, each prepares the reference itself "
+                                                     "(frealign.py:3183 process model), %.1f s wall" % (P, per, t3)}
+    best = legs["openmp_all_cores"]
+    return {"value": best["value"], "unit": "particles/s", "cores": cores, "kind": "port", "sample": best["sample"], "legs": legs}
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -82,3 +82,28 @@ def test_two_ranks_equal_one_rank(tmp_path):
     assert np.array_equal(outs[1][0], outs[2][0])                               # refined rows identical
     assert list(outs[1][2]) == list(outs[2][2]) == [5, 5]
     assert np.linalg.norm(outs[1][1] - outs[2][1]) / np.linalg.norm(outs[1][1]) < 1e-6    # float sum order only
+
+
+def test_bench_gpus_flag_launches_that_many_ranks():
+    """`python bench.py --gpus 2` outside torchrun starts two ranks itself (child torchrun over 127.0.0.1) and rank 0 reports
+    n_gpus = 2; PPM_BENCH_PROBE=1 exercises launcher + rendezvous + max-over-ranks reduction without GPU work."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PPM_BENCH_PROBE="1", PPM_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["probe"] is True and abs(d["max_over_ranks_s"] - 0.002) < 1e-9
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "PPM_FORCE_DEVICE", "PPM_BENCH_PROBE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64"], env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode != 0 and "ERROR" in r.stderr and "GPU(s) visible" in r.stderr

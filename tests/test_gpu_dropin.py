@@ -300,3 +300,21 @@ def test_refine3d_par_surface_keeps_extended_columns(project):
     inp, _, _, _, _ = parfile.read(str(d / "x_r01_02.par"))
     assert data.shape == (10, 45) and extended and version == parfile.NEW
     assert np.array_equal(data[:, 16:], inp[:, 16:]) and np.all(data[:, 6] == 12345.0)
+
+
+def test_bench_two_ranks_share_one_gpu_over_gloo():
+    """bench.py --gpus 2 launches two ranks itself; here both use device 0 (PPM_FORCE_DEVICE) and rendezvous over gloo, so the
+    sharded refinement and the reduced reconstruction run on the one-GPU box.  Small sizes; the line must say n_gpus = 2."""
+    import json
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PPM_FORCE_DEVICE="0", PPM_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--box", "64",
+                        "--band", "24", "--particles", "512", "--recon-particles", "1024", "--no-cpu"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["particles_per_gpu"] == 512
+    assert d["roofline"]["bound"] == "valu_fp32" and 0 < d["roofline"]["frac"] <= 1
+    rec = d["reconstruct"]
+    assert rec["n_gpus"] == 2 and rec["value"] > 0 and 0 < rec["roofline"]["frac"] <= 1 and rec["map_cc_vs_truth"] > 0.5
