@@ -242,14 +242,16 @@ def perturb_rows(rows, angle_sigma=2.0, shift_sigma_px=1.0, pixel=1.0, seed=7):
     return r
 
 
-def angular_error_deg(rows_a, rows_b):
-    """Geodesic angle (degrees) between the rotations of two row sets."""
+def angular_error_deg(rows_a, rows_b, ops=None):
+    """Geodesic angle (degrees) between the rotations of two row sets; with `ops` (k x 3 x 3 point-group operators acting on
+    the reference frame) the smallest angle over the symmetry-equivalent poses S M."""
     C = cistem.COL
     out = np.empty(len(rows_a))
+    sym = [np.eye(3)] if ops is None else list(np.asarray(ops, dtype=np.float64).reshape(-1, 3, 3))
     for i in range(len(rows_a)):
         ma = euler_matrix(rows_a[i, C["PSI"]], rows_a[i, C["THETA"]], rows_a[i, C["PHI"]])
         mb = euler_matrix(rows_b[i, C["PSI"]], rows_b[i, C["THETA"]], rows_b[i, C["PHI"]])
-        t = (np.trace(ma.T @ mb) - 1.0) / 2.0
+        t = max((np.trace((S @ ma).T @ mb) - 1.0) / 2.0 for S in sym)
         out[i] = np.degrees(np.arccos(np.clip(t, -1.0, 1.0)))
     return out
 

@@ -229,8 +229,12 @@ def test_refine3d_verbatim_default_script_matches_oracle(tmp_path):
     rin = cistem.read_parameters(str(work / "name_r01.cistem"))
     want, counts = oracle.refine_batch(oracle.Reference(vol, n / 2), cfg, stack.numpy(), rin)
     assert counts[1] == 20 * 2 * 12 + 1                       # 20 hits x 2 compass iterations x 12 scores, one final score
-    assert synth.angular_error_deg(want, got).max() < 0.1 and synth.shift_error_px(want, got, px).max() < 0.5
+    # D7 reference: a grid point on the edge of the asymmetric unit and its symmetry mate score the same up to round-off,
+    # so poses are compared modulo the point group
+    d7 = oracle.symmetry_ops("D7")
+    assert synth.angular_error_deg(want, got, d7).max() < 0.1 and synth.shift_error_px(want, got, px).max() < 0.5
     assert np.abs(want[:, 14] - got[:, 14]).max() < 0.05
+    assert np.median(synth.angular_error_deg(got, truth, d7)) < 2.5
     # sub-grid: most poses sit off the 20 degree grid the search walks
     on_grid = np.isclose(got[:, 2] % 18.0, 0.0, atol=1e-3) | np.isclose(got[:, 2] % 18.0, 18.0, atol=1e-3)
     assert on_grid.mean() < 0.1
