@@ -424,6 +424,30 @@ def reconstruct_bench(ctx):
 
 
 # --------------------------------------------------------------------------------------------- CPU legs
+def host_cores():
+    """CPU cores this process may really use: the affinity mask, capped by a cgroup CPU quota when one is set
+    (a GPU box hands a share of the host's cores to each GPU)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(p)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / p
+        except (OSError, ValueError):
+            pass
+    if quota:
+        n = max(1, min(n, int(round(quota))))
+    if os.environ.get("PPM_CPU_CORES"):
+        n = max(1, int(os.environ["PPM_CPU_CORES"]))
+    return n
+
+
 def cpu_baseline(vol, stack, start_rows, cfg, N, seconds):
     """The CPU oracle (kind "port": the reference binaries are absent) on bounded samples of the SAME stack,
     three ways: all host cores through OpenMP (the headline `value`), one thread, and P independent
@@ -432,7 +456,7 @@ def cpu_baseline(vol, stack, start_rows, cfg, N, seconds):
     import ctypes
     import tempfile
     from oracle import oracle
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     gomp = ctypes.CDLL("libgomp.so.1")
     imgs = stack[:max(2 * cores, 8)].cpu().numpy()
     t0 = time.time()
@@ -459,6 +483,7 @@ def cpu_baseline(vol, stack, start_rows, cfg, N, seconds):
         oracle.refine_batch(oref, cfg, imgs[:n2], start_rows[:n2], ccf_mode=1)
         t2, n = time.time() - t0, n2
     legs["openmp_all_cores"] = {"value": round(n / t2, 3), "unit": "particles/s", "cores": cores,
+                                "speedup_over_one_thread": round(n / t2 * t1, 1),
                                 "sample": "%d particles, %.1f s wall, OpenMP over particles; reference preparation %.1f s excluded" % (n, t2, t_prep)}
     oref.close()
     # ---- P single-thread processes, one particle range each, reference prepared per process
@@ -477,6 +502,8 @@ def cpu_baseline(vol, stack, start_rows, cfg, N, seconds):
                  for i in range(P)]
         rcs = [p.wait() for p in procs]
         t3 = time.time() - t0
+        if any(rcs):
+            print("WARNING: %d of %d CPU-leg processes failed" % (sum(1 for r in rcs if r), P), file=sys.stderr)
     finally:
         import shutil
         shutil.rmtree(tmp, ignore_errors=True)

@@ -8,7 +8,8 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+_HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path[:] = [os.path.dirname(_HERE)] + [p for p in sys.path if os.path.abspath(p or ".") != _HERE]      # `oracle` must be the package
 
 
 def main():
