@@ -124,6 +124,30 @@ typedef struct ppm_final_cfg {
     float mask_falloff;     /* Angstrom (default 10) */
 } ppm_final_cfg;
 
+/* Constrained refinement of tilt-series particles (the `csp` program, src/pyp/system/local_run.py:306-467 argv,
+ * mode list src/pyp/align/core.py:1015-1023): every projection row belongs to one particle (PIND) and one tilt (TIND, RIND);
+ * its pose is not free but follows from the particle's 3-D pose and the tilt geometry (the relation the reference states in
+ * csp_euler_angles, src/pyp/analysis/geometry/core.py:1081-1213):
+ *     M_row = E(-ppsi, -ptheta, -pphi) Ry(-tilt_angle) Rz(tilt_axis),   E = Rz(phi) Ry(theta) Rz(psi)
+ *     (shx, shy) = [Rz(-tilt_axis) Ry(tilt_angle) (-pshift)]_xy + (tshift_x, tshift_y)            (pixels)
+ * A unit (particle or tilt) is scored by the mean score of its rows. */
+enum { PPM_CSP_PARTICLES = 1, PPM_CSP_MICROGRAPHS = 2 };
+#define PPM_NPCOL 12 /* particle block columns of _extended.cistem (cistem_star_file.py:247): PIND, shift x y z, psi theta phi,
+                        x y z position 3-D, score, occ */
+#define PPM_NTCOL 6  /* tilt block columns (:248): TIND, RIND, shift x y, angle, axis */
+typedef struct ppm_csp_cfg {
+    int unit;               /* PPM_CSP_PARTICLES (csp modes 1 / 2 / 5) or PPM_CSP_MICROGRAPHS (modes 0 / 3 / 6) */
+    int refine_rotation;    /* particles: the three rotations (about the specimen x, y, z axes); tilts: tilt angle and tilt-axis angle */
+    int refine_translation; /* particles: the 3-D shift; tilts: the two image shifts */
+    float tol_angle[3];     /* search bound either side of the start, degrees (csp_ToleranceParticlesPsi / Theta / Phi ->
+                               specimen x / y / z; tilts: [0] csp_ToleranceMicrographTiltAngles, [1] ...TiltAxisAngles) */
+    float tol_shift;        /* the same for shifts, pixels (csp_ToleranceParticlesShifts / csp_ToleranceMicrographShifts) */
+    float step_tolerance;   /* smallest compass step, degrees / pixels (csp_OptimizerStepTolerance; default 0.01) */
+    int max_iterations;     /* compass iterations; 0 = until the step falls below step_tolerance, at most 12 */
+    int tind_min, tind_max; /* rows with TIND outside do not enter a unit's score (csp_UseImagesForRefinementMin / Max; max < 0 = no limit) */
+    int first, last;        /* units to refine: PIND (particles) or TIND (tilts) in first..last; last < 0 = up to the end */
+} ppm_csp_cfg;
+
 #define PPM_STATS_COLS 7 /* shell, resolution A, ring radius, FSC, part-FSC, part-SSNR, rec-SSNR
                             (src/pyp/postprocess/core.py:203-221; frealign.py:2559) */
 
@@ -161,6 +185,14 @@ int ppm_refine_last_counts(ppm_ref_t *ref, long *n_global, long *n_local, long *
 /* remarks of the last ppm_refine_batch on this reference that the caller should log (e.g. the search band was capped);
  * "" if none */
 const char *ppm_refine_note(ppm_ref_t *ref);
+
+/* Constrained refinement: rows (n_proj x PPM_NCOL, image i belongs to row i), particles (n_part x PPM_NPCOL) and tilts
+ * (n_tilt x PPM_NTCOL) are read and updated in place: refined units get their parameters, their rows get the poses that
+ * follow from them (angles from M_row, shifts moved by the change of the geometric shift) and SCORE / LOGP / SIGMA at the
+ * full band; rows of units outside first..last are left untouched.  cfg gives box, pixel, mask radius, resolution limits
+ * and band_factor as in ppm_refine_batch (its search fields are ignored). */
+int ppm_csp_refine(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const ppm_csp_cfg *csp, const void *images, int images_on_device,
+                   int n_proj, double *rows, double *particles, int n_part, double *tilts, int n_tilt);
 
 /* symmetry: "C1", "Cn", "Dn", "T", "O", "I".  ext_device_buffer: NULL, or a device buffer of
  * ppm_accum_floats(box) floats the caller allocated (e.g. a torch tensor, so that RCCL can

@@ -45,6 +45,9 @@ def lib():
         L.orc_fft1d.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.orc_insert_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_void_p]
         L.orc_finalize.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_csp_pose.argtypes = [C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+        L.orc_csp_pose.restype = None
+        L.orc_csp_refine.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         _lib = L
     return _lib
 
@@ -156,3 +159,26 @@ def fft1d(x, inverse=False):
     if lib().orc_fft1d(_p(a), len(a), 1 if inverse else 0):
         raise ValueError("oracle: unsupported FFT length")
     return a
+
+
+def csp_pose(tilt_angle, tilt_axis, particle):
+    """(PSI, THETA, PHI, SHX, SHY) of a projection row from the tilt geometry and the stored particle parameters
+    {psi, theta, phi, shift x, y, z} (restates csp_euler_angles, src/pyp/analysis/geometry/core.py:1081-1213)."""
+    p = np.ascontiguousarray(particle, dtype=np.float64)
+    out = np.zeros(5, dtype=np.float64)
+    lib().orc_csp_pose(float(tilt_angle), float(tilt_axis), _p(p), _p(out))
+    return out
+
+
+def csp_refine(ref, cfg, csp_cfg, images, rows, particles, tilts):
+    """Returns (rows, particles, tilts, evaluations) after constrained refinement (copies; inputs untouched)."""
+    images = np.ascontiguousarray(images, dtype=np.float32)
+    rows = np.array(rows, dtype=np.float64, order="C")
+    particles = np.array(particles, dtype=np.float64, order="C")
+    tilts = np.array(tilts, dtype=np.float64, order="C")
+    nev = C.c_long(0)
+    rc = lib().orc_csp_refine(ref.h, C.byref(cfg), C.byref(csp_cfg), _p(images), len(rows), _p(rows), _p(particles), len(particles),
+                              _p(tilts), len(tilts), C.byref(nev))
+    if rc:
+        raise RuntimeError(f"oracle: csp_refine failed ({rc})")
+    return rows, particles, tilts, nev.value

@@ -994,3 +994,229 @@ int orc_finalize(const float *acc_in, int N, double a, const ppm_final_cfg *cfg,
     free(f); free(kap); free(c12); free(c11); free(c22); free(sden); free(scnt); free(sdt); free(acc);
     return 0;
 }
+
+/* ------------------------------------------------------------------ constrained refinement (csp) */
+/* f-1 / H13: the absent `csp` program (argv at src/pyp/system/local_run.py:364-376, :451-463; modes at
+ * src/pyp/align/core.py:1015-1023).  The row <-> (particle, tilt) geometry IS stated in the reference's Python
+ * (csp_euler_angles, src/pyp/analysis/geometry/core.py:1081-1213) and is pinned by golden vectors produced with it
+ * (tests/golden/golden_r02.json "csp_geometry"); the optimiser (compass search with frequency marching over the
+ * constrained parameters, unit score = mean row score) is build-defined: PARITY UNPINNED like the refine3d restatement. */
+static void rot_xyz(int k, double deg, double R[9]) {      /* right-handed rotation about x (0), y (1), z (2) */
+    double t = deg * ORC_PI / 180, c = cos(t), s = sin(t);
+    double rx[9] = { 1, 0, 0, 0, c, -s, 0, s, c }, ry[9] = { c, 0, s, 0, 1, 0, -s, 0, c }, rz[9] = { c, -s, 0, s, c, 0, 0, 0, 1 };
+    memcpy(R, k == 0 ? rx : (k == 1 ? ry : rz), 9 * sizeof(double));
+}
+
+/* M_row = N Ry(-tilt) Rz(axis); geometric shift (pixels) = [Rz(-axis) Ry(tilt) (-p)]_xy + tilt shift */
+static void csp_row_pose(const double N[9], const double p[3], double tilt, double axis, double tsx, double tsy, double M[9], double g[2]) {
+    double a[9], b[9], t[9];
+    rot_xyz(1, -tilt, a); rot_xyz(2, axis, b);
+    mat_mul3(N, a, t); mat_mul3(t, b, M);
+    rot_xyz(2, -axis, a); rot_xyz(1, tilt, b);
+    double q[3] = { -p[0], -p[1], -p[2] }, u[3], v[3];
+    for (int i = 0; i < 3; i++) u[i] = b[i * 3] * q[0] + b[i * 3 + 1] * q[1] + b[i * 3 + 2] * q[2];
+    for (int i = 0; i < 3; i++) v[i] = a[i * 3] * u[0] + a[i * 3 + 1] * u[1] + a[i * 3 + 2] * u[2];
+    g[0] = v[0] + tsx; g[1] = v[1] + tsy;
+}
+
+/* exported for the golden test: particle = {psi, theta, phi (as stored in the particle block), shift x, y, z};
+ * out = {PSI, THETA, PHI, SHX, SHY} of the projection row */
+void orc_csp_pose(double tilt, double axis, const double *particle, double *out) {
+    double N[9], M[9], g[2];
+    euler_full(-particle[0], -particle[1], -particle[2], N);
+    csp_row_pose(N, particle + 3, tilt, axis, 0.0, 0.0, M, g);
+    angles_from_matrix(M, &out[0], &out[1], &out[2]);
+    out[3] = g[0]; out[4] = g[1];
+}
+
+typedef struct { double N[9], p[3], tl[4] /* angle, axis, sx, sy (tilts) */, acc[6]; } cunit_t;
+
+/* state + displacement d (particles: rotations about specimen x, y, z in degrees, then shifts; tilts: angle, axis, -, sx, sy, -) */
+static void csp_apply(int unit_kind, const cunit_t *s, const double d[6], cunit_t *o) {
+    *o = *s;
+    if (unit_kind == PPM_CSP_PARTICLES) {
+        double R[9], T[9];
+        for (int k = 0; k < 3; k++) if (d[k] != 0) { rot_xyz(k, d[k], R); mat_mul3(o->N, R, T); memcpy(o->N, T, sizeof(T)); }
+        for (int k = 0; k < 3; k++) o->p[k] += d[3 + k];
+    } else {
+        o->tl[0] += d[0]; o->tl[1] += d[1]; o->tl[2] += d[3]; o->tl[3] += d[4];
+    }
+    for (int k = 0; k < 6; k++) o->acc[k] += d[k];
+}
+
+typedef struct {
+    const oref_t *r; const geom_t *g; int n_proj; const double *rows; cpx **I; double **wr; ctf_t *ctf;
+    const int *row_part, *row_tilt; const double *s0, *g0; const cunit_t *parts, *tls; const unsigned char *usable;
+} cspctx_t;
+
+static double csp_row_score(const cspctx_t *c, int j, const cunit_t *pu, const cunit_t *tu, double rmax, double M[9], double sh[2]) {
+    double g[2];
+    csp_row_pose(pu->N, pu->p, tu->tl[0], tu->tl[1], tu->tl[2], tu->tl[3], M, g);
+    sh[0] = c->s0[2 * j] + g[0] - c->g0[2 * j]; sh[1] = c->s0[2 * j + 1] + g[1] - c->g0[2 * j + 1];
+    return score_local(c->r, c->g, &c->ctf[j], c->I[j], c->wr[j], rmax, M, sh);
+}
+
+/* mean score of the usable rows of a unit for candidate state `cand` */
+static double csp_unit_score(const cspctx_t *c, int kind, const int *urows, int nrows, const cunit_t *cand, double rmax, long *nev) {
+    double s = 0; int n = 0, M9 = 0; (void)M9;
+    for (int q = 0; q < nrows; q++) {
+        int j = urows[q];
+        if (!c->usable[j]) continue;
+        double M[9], sh[2];
+        const cunit_t *pu = kind == PPM_CSP_PARTICLES ? cand : &c->parts[c->row_part[j]];
+        const cunit_t *tu = kind == PPM_CSP_PARTICLES ? &c->tls[c->row_tilt[j]] : cand;
+        s += csp_row_score(c, j, pu, tu, rmax, M, sh); n++; (*nev)++;
+    }
+    return n ? s / n : -1e300;
+}
+
+int orc_csp_refine(void *refp, const ppm_refine_cfg *cfg, const ppm_csp_cfg *cc, const float *images, int n_proj,
+                   double *rows, double *particles, int n_part, double *tilts, int n_tilt, long *eval_count) {
+    fft_tables();
+    oref_t *r = (oref_t *)refp; geom_t g;
+    ppm_refine_cfg c2 = *cfg; c2.global_search = 0;
+    if (!r || geom_init(&g, &c2) || g.B > (r->B + 1) / r->pad - 1 || r->N != g.N) return -22;
+    if (cc->unit != PPM_CSP_PARTICLES && cc->unit != PPM_CSP_MICROGRAPHS) return -22;
+    const double fall = cfg->mask_falloff > 0 ? cfg->mask_falloff : 20.0, bf = cfg->band_factor == 0 ? 3.0 : cfg->band_factor;
+    const double rm_px = cfg->mask_radius / g.a;
+    size_t nb = (size_t)g.H * g.W;
+    cspctx_t c; memset(&c, 0, sizeof(c));
+    c.r = r; c.g = &g; c.n_proj = n_proj; c.rows = rows;
+    c.I = (cpx **)calloc(n_proj, sizeof(cpx *)); c.wr = (double **)calloc(n_proj, sizeof(double *)); c.ctf = (ctf_t *)calloc(n_proj, sizeof(ctf_t));
+    int *row_part = (int *)malloc(n_proj * sizeof(int)), *row_tilt = (int *)malloc(n_proj * sizeof(int));
+    double *s0 = (double *)malloc(2 * n_proj * sizeof(double)), *g0 = (double *)malloc(2 * n_proj * sizeof(double));
+    unsigned char *usable = (unsigned char *)calloc(n_proj, 1);
+    cunit_t *parts = (cunit_t *)calloc(n_part, sizeof(cunit_t)), *tls = (cunit_t *)calloc(n_tilt, sizeof(cunit_t));
+    for (int i = 0; i < n_part; i++) {
+        const double *P = particles + (size_t)i * PPM_NPCOL;
+        euler_full(-P[4], -P[5], -P[6], parts[i].N);
+        parts[i].p[0] = P[1]; parts[i].p[1] = P[2]; parts[i].p[2] = P[3];
+    }
+    for (int i = 0; i < n_tilt; i++) {
+        const double *T = tilts + (size_t)i * PPM_NTCOL;
+        tls[i].tl[0] = T[4]; tls[i].tl[1] = T[5]; tls[i].tl[2] = T[2]; tls[i].tl[3] = T[3];
+    }
+    int err = 0;
+    for (int j = 0; j < n_proj && !err; j++) {
+        const double *row = rows + (size_t)j * PPM_NCOL;
+        row_part[j] = row_tilt[j] = -1;
+        for (int i = 0; i < n_part; i++) if ((long)particles[(size_t)i * PPM_NPCOL] == (long)row[PPM_PIND]) { row_part[j] = i; break; }
+        for (int i = 0; i < n_tilt; i++) if ((long)tilts[(size_t)i * PPM_NTCOL] == (long)row[PPM_TIND] && (long)tilts[(size_t)i * PPM_NTCOL + 1] == (long)row[28]) { row_tilt[j] = i; break; }
+        if (row_part[j] < 0 || row_tilt[j] < 0) { err = -22; break; }
+        long tind = (long)row[PPM_TIND];
+        usable[j] = row[PPM_OCC] > 0 && tind >= cc->tind_min && (cc->tind_max < 0 || tind <= cc->tind_max);
+        s0[2 * j] = row[PPM_XSHIFT] / g.a; s0[2 * j + 1] = row[PPM_YSHIFT] / g.a;
+        double M[9];
+        csp_row_pose(parts[row_part[j]].N, parts[row_part[j]].p, tls[row_tilt[j]].tl[0], tls[row_tilt[j]].tl[1], tls[row_tilt[j]].tl[2], tls[row_tilt[j]].tl[3], M, g0 + 2 * j);
+    }
+    c.row_part = row_part; c.row_tilt = row_tilt; c.s0 = s0; c.g0 = g0; c.parts = parts; c.tls = tls; c.usable = usable;
+    if (!err) {
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int j = 0; j < n_proj; j++) {
+            c.I[j] = (cpx *)malloc(nb * sizeof(cpx)); c.wr[j] = (double *)malloc((g.B + 2) * sizeof(double));
+            preprocess(images + (size_t)j * g.N * g.N, &g, cfg->mask_radius, fall, cfg->normalize, cfg->invert, 1, 1, g.r_hi, c.I[j], c.wr[j]);
+            ctf_init(&c.ctf[j], rows + (size_t)j * PPM_NCOL, g.N, g.a);
+        }
+    }
+    const int kind = cc->unit, nu_all = kind == PPM_CSP_PARTICLES ? n_part : n_tilt;
+    int en[6] = { 0, 0, 0, 0, 0, 0 }; double tol[6] = { 0, 0, 0, 0, 0, 0 };
+    if (kind == PPM_CSP_PARTICLES) {
+        for (int k = 0; k < 3; k++) { en[k] = cc->refine_rotation != 0; tol[k] = cc->tol_angle[k]; en[3 + k] = cc->refine_translation != 0; tol[3 + k] = cc->tol_shift; }
+    } else {
+        en[0] = en[1] = cc->refine_rotation != 0; tol[0] = cc->tol_angle[0]; tol[1] = cc->tol_angle[1];
+        en[3] = en[4] = cc->refine_translation != 0; tol[3] = tol[4] = cc->tol_shift;
+    }
+    for (int k = 0; k < 6; k++) if (!(tol[k] > 0)) en[k] = 0;
+    double ha0 = 0, hs0 = 0;
+    for (int k = 0; k < 3; k++) if (en[k] && 0.5 * tol[k] > ha0) ha0 = 0.5 * tol[k];
+    for (int k = 3; k < 6; k++) if (en[k] && 0.5 * tol[k] > hs0) hs0 = 0.5 * tol[k];
+    const double steptol = cc->step_tolerance > 0 ? cc->step_tolerance : 0.01;
+    int T = cc->max_iterations;
+    if (T <= 0) { double m = ha0 > hs0 ? ha0 : hs0; T = m > steptol ? (int)ceil(log(m / steptol) / log(2.0)) : 1; if (T > 12) T = 12; if (T < 1) T = 1; }
+    int en5[5] = { en[0] || en[1] || en[2], 0, 0, en[3] || en[4] || en[5], 0 };       /* for iter_band: any angle / any shift */
+    long nev = 0;
+    /* rows of every unit */
+    int *ucount = (int *)calloc(nu_all, sizeof(int)), **urows = (int **)calloc(nu_all, sizeof(int *));
+    for (int j = 0; j < n_proj && !err; j++) ucount[kind == PPM_CSP_PARTICLES ? row_part[j] : row_tilt[j]]++;
+    for (int u = 0; u < nu_all; u++) { urows[u] = (int *)malloc((ucount[u] + 1) * sizeof(int)); ucount[u] = 0; }
+    for (int j = 0; j < n_proj && !err; j++) { int u = kind == PPM_CSP_PARTICLES ? row_part[j] : row_tilt[j]; urows[u][ucount[u]++] = j; }
+    cunit_t *units = kind == PPM_CSP_PARTICLES ? parts : tls;
+    unsigned char *refined = (unsigned char *)calloc(nu_all, 1);
+    for (int u = 0; u < nu_all && !err; u++) {
+        long id = (long)(kind == PPM_CSP_PARTICLES ? particles[(size_t)u * PPM_NPCOL] : tilts[(size_t)u * PPM_NTCOL]);
+        if (id < cc->first || (cc->last >= 0 && id > cc->last)) continue;
+        int nus = 0; for (int q = 0; q < ucount[u]; q++) nus += usable[urows[u][q]];
+        refined[u] = 1;
+        if (!nus) continue;
+        cunit_t s = units[u];
+        double ha = ha0, hs = hs0;
+        for (int it = 0; it < T; it++) {
+            const double rmax = iter_band(&g, rm_px, bf, en5, ha, hs, g.r_hi);
+            const double f0 = csp_unit_score(&c, kind, urows[u], ucount[u], &s, rmax, &nev);
+            double fp[6], fm[6], d[6];
+            int okp[6], okm[6];
+            for (int i = 0; i < 6; i++) {
+                d[i] = 0; fp[i] = fm[i] = -1e300; okp[i] = okm[i] = 0;
+                if (!en[i]) continue;
+                const double h = i < 3 ? ha : hs;
+                for (int sg = 0; sg < 2; sg++) {
+                    double dd[6] = { 0, 0, 0, 0, 0, 0 }; dd[i] = sg ? -h : h;
+                    cunit_t q; csp_apply(kind, &s, dd, &q);
+                    const int ok = fabs(q.acc[i]) <= tol[i] + 1e-9;
+                    const double v = csp_unit_score(&c, kind, urows[u], ucount[u], &q, rmax, &nev);   /* evaluated like the device does; ignored when out of bounds */
+                    if (sg) { fm[i] = ok ? v : -1e300; okm[i] = ok; } else { fp[i] = ok ? v : -1e300; okp[i] = ok; }
+                }
+                if (okp[i] && okm[i]) {
+                    const double den = 2.0 * f0 - fp[i] - fm[i];
+                    if (den > 1e-12) { double t = 0.5 * h * (fp[i] - fm[i]) / den; d[i] = t > h ? h : (t < -h ? -h : t); }
+                    else { const double best = fp[i] > fm[i] ? fp[i] : fm[i]; d[i] = best > f0 ? (fp[i] > fm[i] ? h : -h) : 0.0; }
+                } else if (okp[i]) d[i] = fp[i] > f0 ? h : 0.0;
+                else if (okm[i]) d[i] = fm[i] > f0 ? -h : 0.0;
+                if (s.acc[i] + d[i] > tol[i]) d[i] = tol[i] - s.acc[i];
+                if (s.acc[i] + d[i] < -tol[i]) d[i] = -tol[i] - s.acc[i];
+            }
+            cunit_t tr; csp_apply(kind, &s, d, &tr);
+            const double ft = csp_unit_score(&c, kind, urows[u], ucount[u], &tr, rmax, &nev);
+            int bi = -1, bs = 0; double fb = f0;
+            for (int i = 0; i < 6; i++) {
+                if (!en[i]) continue;
+                if (fp[i] > fb) { fb = fp[i]; bi = i; bs = 1; }
+                if (fm[i] > fb) { fb = fm[i]; bi = i; bs = -1; }
+            }
+            if (ft > f0 && ft >= fb) s = tr;
+            else if (bi >= 0) { double dd[6] = { 0, 0, 0, 0, 0, 0 }; dd[bi] = bs * (bi < 3 ? ha : hs); cunit_t q; csp_apply(kind, &s, dd, &q); s = q; }
+            ha *= 0.5; hs *= 0.5;
+        }
+        units[u] = s;
+    }
+    /* write back: unit parameters, rows of refined units */
+    for (int u = 0; u < nu_all && !err; u++) {
+        if (!refined[u]) continue;
+        if (kind == PPM_CSP_PARTICLES) {
+            double *P = particles + (size_t)u * PPM_NPCOL, a1, a2, a3;
+            angles_from_matrix(units[u].N, &a1, &a2, &a3);
+            P[4] = -a1; P[5] = -a2; P[6] = -a3; P[1] = units[u].p[0]; P[2] = units[u].p[1]; P[3] = units[u].p[2];
+        } else {
+            double *Tt = tilts + (size_t)u * PPM_NTCOL;
+            Tt[4] = units[u].tl[0]; Tt[5] = units[u].tl[1]; Tt[2] = units[u].tl[2]; Tt[3] = units[u].tl[3];
+        }
+        double ssum = 0; int sn = 0;
+        for (int q = 0; q < ucount[u]; q++) {
+            int j = urows[u][q];
+            double *row = rows + (size_t)j * PPM_NCOL, M[9], sh[2];
+            double cc2 = csp_row_score(&c, j, &parts[row_part[j]], &tls[row_tilt[j]], g.r_hi, M, sh); nev++;
+            angles_from_matrix(M, &row[PPM_PSI], &row[PPM_THETA], &row[PPM_PHI]);
+            row[PPM_XSHIFT] = sh[0] * g.a; row[PPM_YSHIFT] = sh[1] * g.a;
+            double res = 1.0 - cc2 * cc2; if (res < 1e-6) res = 1e-6;
+            row[PPM_SCORE] = 100.0 * cc2; row[PPM_SIGMA] = sqrt(res);
+            row[PPM_LOGP] = -0.5 * (ORC_PI * (g.r_hi * g.r_hi - g.r_lo * g.r_lo)) * (log(2.0 * ORC_PI * res) + 1.0);
+            if (usable[j]) { ssum += row[PPM_SCORE]; sn++; }
+        }
+        if (kind == PPM_CSP_PARTICLES) particles[(size_t)u * PPM_NPCOL + 10] = sn ? ssum / sn : -1.0;
+    }
+    if (eval_count) *eval_count = nev;
+    for (int j = 0; j < n_proj; j++) { free(c.I[j]); free(c.wr[j]); }
+    for (int u = 0; u < nu_all; u++) free(urows[u]);
+    free(urows); free(ucount); free(refined); free(c.I); free(c.wr); free(c.ctf); free(row_part); free(row_tilt); free(s0); free(g0); free(usable); free(parts); free(tls);
+    return err;
+}

@@ -1,0 +1,114 @@
+// ppm_csp_kernels.h — constrained (tilt-series) scoring kernel of libpypmatch (gfx950).
+//
+// A projection row's pose follows from its particle's 3-D pose and its tilt's geometry (include/ppm.h, ppm_csp_cfg; the
+// relation restates csp_euler_angles, src/pyp/analysis/geometry/core.py:1081-1213).  The optimiser lives on the host
+// (ppm_csp_refine in ppm_lib.hip): every sweep it hands the device one displacement table per unit and gets one score per
+// (row, candidate) back; the rows of a unit are averaged on the host in a fixed order.
+#pragma once
+#include "ppm_kernels2.h"
+
+namespace ppm {
+
+struct CspEvalP {
+    CubeView cv; const uint32_t *samples; const float2 *Il; const float *cw;
+    int S_pad, N, nr; float rlo2, ring_signed;
+    int S_used; float rmax2;              // band of this sweep (frequency marching)
+    int kind, ncand;                      // PPM_CSP_PARTICLES / PPM_CSP_MICROGRAPHS; candidates per unit (<= kMaxCand)
+    const int *eval_rows;                 // [grid] row evaluated by each block
+    const int *row_part, *row_tilt;       // [n_proj] unit indices of a row
+    const int *unit_slot;                 // [n_part] or [n_tilt]: position of the unit in `delta` (-1: not refined)
+    const double *Nmat;                   // [n_part][9] particle orientation E(-ppsi, -ptheta, -pphi)
+    const double *pshift;                 // [n_part][3] particle shift, pixels
+    const double *tl;                     // [n_tilt][4] tilt angle, tilt-axis angle, shift x, shift y
+    const double *delta;                  // [n_units][ncand][6] displacement of every candidate
+    const double *s0, *g0;                // [n_proj][2] row shift (pixels) and geometric shift at the start
+    double *out;                          // [grid][ncand] scores
+};
+
+__device__ __forceinline__ void d_rot_xyz(int k, double deg, double *R) {      // right-handed rotation about x, y, z
+    double s, c;
+    sincos(deg * 3.14159265358979323846 / 180.0, &s, &c);
+    if (k == 0) { R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = c; R[5] = -s; R[6] = 0; R[7] = s; R[8] = c; }
+    else if (k == 1) { R[0] = c; R[1] = 0; R[2] = s; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = -s; R[7] = 0; R[8] = c; }
+    else { R[0] = c; R[1] = -s; R[2] = 0; R[3] = s; R[4] = c; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1; }
+}
+
+// M_row = N Ry(-tilt) Rz(axis); g = [Rz(-axis) Ry(tilt) (-p)]_xy + tilt shift
+__device__ inline void d_csp_row_pose(const double *N, const double *p, double tilt, double axis, double tsx, double tsy, double *M, double *g) {
+    double a[9], b[9], t[9];
+    d_rot_xyz(1, -tilt, a); d_rot_xyz(2, axis, b);
+    d_mat_mul3(N, a, t); d_mat_mul3(t, b, M);
+    d_rot_xyz(2, -axis, a); d_rot_xyz(1, tilt, b);
+    const double q0 = -p[0], q1 = -p[1], q2 = -p[2];
+    double u[3], v[2];
+#pragma unroll
+    for (int i = 0; i < 3; i++) u[i] = b[i * 3] * q0 + b[i * 3 + 1] * q1 + b[i * 3 + 2] * q2;
+#pragma unroll
+    for (int i = 0; i < 2; i++) v[i] = a[i * 3] * u[0] + a[i * 3 + 1] * u[1] + a[i * 3 + 2] * u[2];
+    g[0] = v[0] + tsx; g[1] = v[1] + tsy;
+}
+
+// Block = one projection row, 256 threads: thread q < ncand derives candidate q's row pose in double precision; the
+// candidates that keep the unit's rotation share one gather group (shift variants), every rotated candidate is a group
+// of its own; one sweep (sweep_plan) scores them all.
+__global__ void __launch_bounds__(256, 4) k_csp_eval(CspEvalP P) {
+    __shared__ SweepPlan plan;
+    extern __shared__ float lsm[];
+    __shared__ double score[kMaxCand];
+    __shared__ float cm[kMaxCand][6], csh[kMaxCand][2];
+    __shared__ int csame[kMaxCand], cslot[kMaxCand];
+    const int tid = threadIdx.x, nthr = blockDim.x, nw = nthr >> 6, nr = P.nr;
+    const int j = P.eval_rows[blockIdx.x], ip = P.row_part[j], it = P.row_tilt[j];
+    const int ncand = P.ncand;
+    if (tid < ncand) {
+        const int unit = P.kind == PPM_CSP_PARTICLES ? ip : it;
+        const double *d = P.delta + ((size_t)P.unit_slot[unit] * ncand + tid) * 6;
+        double N[9], p[3], tl[4], M[9], g[2];
+#pragma unroll
+        for (int k = 0; k < 9; k++) N[k] = P.Nmat[(size_t)ip * 9 + k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) p[k] = P.pshift[(size_t)ip * 3 + k];
+#pragma unroll
+        for (int k = 0; k < 4; k++) tl[k] = P.tl[(size_t)it * 4 + k];
+        int same;
+        if (P.kind == PPM_CSP_PARTICLES) {
+            same = d[0] == 0.0 && d[1] == 0.0 && d[2] == 0.0;
+            for (int k = 0; k < 3; k++)
+                if (d[k] != 0.0) { double R[9], T[9]; d_rot_xyz(k, d[k], R); d_mat_mul3(N, R, T); for (int q = 0; q < 9; q++) N[q] = T[q]; }
+            p[0] += d[3]; p[1] += d[4]; p[2] += d[5];
+        } else {
+            same = d[0] == 0.0 && d[1] == 0.0;
+            tl[0] += d[0]; tl[1] += d[1]; tl[2] += d[3]; tl[3] += d[4];
+        }
+        d_csp_row_pose(N, p, tl[0], tl[1], tl[2], tl[3], M, g);
+        cm[tid][0] = (float)M[0]; cm[tid][1] = (float)M[1]; cm[tid][2] = (float)M[3]; cm[tid][3] = (float)M[4]; cm[tid][4] = (float)M[6]; cm[tid][5] = (float)M[7];
+        csh[tid][0] = (float)(P.s0[2 * j] + g[0] - P.g0[2 * j]); csh[tid][1] = (float)(P.s0[2 * j + 1] + g[1] - P.g0[2 * j + 1]);
+        csame[tid] = same;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int ng = 0, q = 0, first_same = -1;
+        for (int c = 0; c < ncand; c++) if (csame[c]) { first_same = c; break; }
+        if (first_same >= 0) {                     // group 0: the unit's own rotation with all its shift variants
+            for (int k = 0; k < 6; k++) plan.m[0][k] = cm[first_same][k];
+            plan.slot0[0] = 0;
+            for (int c = 0; c < ncand; c++) if (csame[c]) { plan.sh[q][0] = csh[c][0]; plan.sh[q][1] = csh[c][1]; cslot[c] = q++; }
+            plan.nv[0] = q; ng = 1;
+        }
+        for (int c = 0; c < ncand; c++) {
+            if (csame[c]) continue;
+            for (int k = 0; k < 6; k++) plan.m[ng][k] = cm[c][k];
+            plan.slot0[ng] = q; plan.nv[ng] = 1; plan.sh[q][0] = csh[c][0]; plan.sh[q][1] = csh[c][1]; cslot[c] = q++; ng++;
+        }
+        plan.ng = ng; plan.nslots = q; plan.q_same = 0; plan.S_used = P.S_used; plan.rmax2 = P.rmax2;
+    }
+    __syncthreads();
+    SweepCtx SC;
+    SC.cv = P.cv; SC.samples = P.samples; SC.Il = P.Il + (size_t)j * P.S_pad; SC.cw = P.cw + (size_t)j * P.S_pad;
+    SC.invN = 1.0f / (float)P.N; SC.rlo2 = P.rlo2; SC.ring_signed = P.ring_signed; SC.nr = nr; SC.nw = nw;
+    SC.ringA = lsm; SC.sumB = lsm + kMaxCand * nw * nr; SC.sumC = SC.sumB + kMaxCand * nw; SC.score = score;
+    sweep_plan(plan, SC, tid, nthr);
+    if (tid < ncand) P.out[(size_t)blockIdx.x * ncand + tid] = score[cslot[tid]];
+}
+
+}  // namespace ppm

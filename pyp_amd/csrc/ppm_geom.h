@@ -131,6 +131,40 @@ inline void euler_matrix(double psi, double theta, double phi, double M[9]) {
     M[6] = -sth * cps;                  M[7] = sth * sps;                    M[8] = cth;
 }
 
+// (psi, theta, phi) in degrees of M = Rz(phi) Ry(theta) Rz(psi); at theta = 0 / 180 everything goes into psi
+inline void angles_from_matrix(const double M[9], double &psi, double &theta, double &phi) {
+    const double r2d = 180.0 / kPi;
+    double ct = M[8] > 1 ? 1 : (M[8] < -1 ? -1 : M[8]);
+    double st = std::sqrt(M[2] * M[2] + M[5] * M[5]);
+    if (st > 1e-7) { theta = std::atan2(st, ct) * r2d; phi = std::atan2(M[5], M[2]) * r2d; psi = std::atan2(M[7], -M[6]) * r2d; }
+    else { theta = ct > 0 ? 0.0 : 180.0; phi = 0.0; psi = (ct > 0 ? std::atan2(M[3], M[0]) : std::atan2(-M[3], -M[0])) * r2d; }
+    if (psi < 0) psi += 360;
+    if (phi < 0) phi += 360;
+}
+
+inline void mat_mul3h(const double *a, const double *b, double *c) {
+    double t[9];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double v = 0; for (int k = 0; k < 3; k++) v += a[i * 3 + k] * b[k * 3 + j]; t[i * 3 + j] = v; }
+    std::memcpy(c, t, sizeof(t));
+}
+inline void rot_xyz(int k, double deg, double R[9]) {      // right-handed rotation about x (0), y (1), z (2)
+    double t = deg * kPi / 180, c = std::cos(t), s = std::sin(t);
+    double rx[9] = { 1, 0, 0, 0, c, -s, 0, s, c }, ry[9] = { c, 0, s, 0, 1, 0, -s, 0, c }, rz[9] = { c, -s, 0, s, c, 0, 0, 0, 1 };
+    std::memcpy(R, k == 0 ? rx : (k == 1 ? ry : rz), sizeof(rx));
+}
+// Row pose of the constrained geometry (include/ppm.h, ppm_csp_cfg): M_row = N Ry(-tilt) Rz(axis),
+// g = [Rz(-axis) Ry(tilt) (-p)]_xy + tilt shift (pixels)
+inline void csp_row_pose(const double N[9], const double p[3], double tilt, double axis, double tsx, double tsy, double M[9], double g[2]) {
+    double a[9], b[9], t[9];
+    rot_xyz(1, -tilt, a); rot_xyz(2, axis, b);
+    mat_mul3h(N, a, t); mat_mul3h(t, b, M);
+    rot_xyz(2, -axis, a); rot_xyz(1, tilt, b);
+    double q[3] = { -p[0], -p[1], -p[2] }, u[3], v[3];
+    for (int i = 0; i < 3; i++) u[i] = b[i * 3] * q[0] + b[i * 3 + 1] * q[1] + b[i * 3 + 2] * q[2];
+    for (int i = 0; i < 3; i++) v[i] = a[i * 3] * u[0] + a[i * 3 + 1] * u[1] + a[i * 3 + 2] * u[2];
+    g[0] = v[0] + tsx; g[1] = v[1] + tsy;
+}
+
 // Ring-ordered sample list of the half plane kx >= 0, 0 < k^2 < r_hi^2, ring = floor(|k|); every
 // ring padded to a multiple of 16 samples with weightless dummies so that a 16-lane group never
 // straddles two rings.  Packed: kx (9 bits) | ky+256 (10 bits) << 9 | alpha (2 bits) << 19 | ring << 21.

@@ -88,7 +88,7 @@ struct LocalP {
     float rmax2_final; int S_final;
 };
 
-constexpr int kMaxCand = 11;   // scores per sweep: 2 per free parameter + the centre, or 1 (trial / final score)
+constexpr int kMaxCand = 13;   // scores per sweep: 2 per free parameter + the centre (k_local: 11; constrained particle search: 13), or 1
 constexpr int kMaxGroup = 7;   // gathers per sweep: 6 angular neighbours + the centre (shared with the 4 shift neighbours)
 
 // sum over aligned groups of 16 lanes with DPP only (quad swaps, then half-row and row mirrors);
@@ -113,6 +113,98 @@ __device__ __forceinline__ double group8_sum_d(double v) {
 
 // dynamic LDS of k_local / k_defocus for `nw` waves, `nq` score slots and `nr` rings
 __host__ __device__ inline size_t ring_lds_bytes(int nw, int nq, int nr) { return ((size_t)nq * nw * nr + (size_t)nq * nw + nw) * sizeof(float); }
+
+// Context of a sweep that does not change between sweeps of one block
+struct SweepCtx {
+    CubeView cv; const uint32_t *samples; const float2 *Il; const float *cw;
+    float invN, rlo2, ring_signed; int nr, nw;
+    float *ringA, *sumB, *sumC; double *score;     // LDS: per-wave ring tables (ring_lds_bytes) and the slot scores
+};
+
+// One sweep over the ring-ordered sample list for the poses of `plan` (in LDS): scores of all slots -> C.score[].
+// All threads of the block call.  Shared by k_local (single-image compass search) and k_csp_eval (constrained search).
+__device__ __forceinline__ void sweep_plan(const SweepPlan &plan, const SweepCtx &C, const int tid, const int nthr) {
+    const int lane = tid & 63, wave = tid >> 6, nw = C.nw, nr = C.nr;
+    float *const ringA = C.ringA, *const sumB = C.sumB, *const sumC = C.sumC; double *const score = C.score;
+    const float2 *const Il = C.Il; const float *const cw = C.cw; const float invN = C.invN;
+    const int nslots = plan.nslots, ng = plan.ng, S_used = plan.S_used;
+    const float rmax2 = plan.rmax2;
+    for (int i = tid; i < nslots * nw * nr; i += nthr) ringA[i] = 0.f;
+    if (tid < kMaxCand * nw) sumB[tid] = 0.f;
+    __syncthreads();
+    float *const myA = ringA + wave * nr, *const myB = sumB + wave;
+    float accC = 0.f;
+    for (int s0 = 0; s0 < S_used; s0 += nthr) {
+        const int s = s0 + tid;
+        int kx = 0, ky = 0, al = 0, ring = 0;
+        float2 iv = make_float2(0.f, 0.f); float c = 0.f;
+        if (s < S_used) {
+            unpack_sample(C.samples[s], kx, ky, al, ring);
+            float k2 = (float)(kx * kx + ky * ky);
+            if (!(k2 < rmax2 && k2 >= C.rlo2)) al = 0;
+            iv = Il[s]; c = cw[s];
+        }
+        const float fal = (float)al, fkx = (float)kx, fky = (float)ky;
+        accC += fal * (iv.x * iv.x + iv.y * iv.y);
+        const float ax = fal * iv.x, ay = fal * iv.y;
+        auto fetch = [&](int g) {
+            const float *m = plan.m[g];
+            return cube_fetch(C.cv, m[0] * fkx + m[1] * fky, m[2] * fkx + m[3] * fky, m[4] * fkx + m[5] * fky);
+        };
+        CubeTaps cur = fetch(0);
+        // the angular neighbours and the centre share one shift (slots 0 .. q_same): one phase factor per sample for all
+        float cs0, sn0;
+        {
+            float rev = -(fkx * plan.sh[0][0] + fky * plan.sh[0][1]) * invN;
+            rev -= floorf(rev);
+            sn0 = __sinf(6.283185307179586f * rev); cs0 = __cosf(6.283185307179586f * rev);
+        }
+        const int q_same = plan.q_same;
+        for (int g = 0; g < ng; g++) {
+            CubeTaps nxt = cur;
+            if (g + 1 < ng) nxt = fetch(g + 1);          // the next group's gathers fly while this group is scored
+            float2 pv = cube_interp(cur);
+            cur = nxt;
+            pv.x *= c; pv.y *= c;
+            float bv = group16_sum_dpp(fal * (pv.x * pv.x + pv.y * pv.y));     // |m|^2 does not depend on the shift
+            const int nv = plan.nv[g], q0 = plan.slot0[g];
+            for (int v = 0; v < nv; v++) {
+                const int q = q0 + v;
+                float sn = sn0, cs = cs0;
+                if (q > q_same) {                                    // a shifted probe (wave-uniform branch)
+                    float rev = -(fkx * plan.sh[q][0] + fky * plan.sh[q][1]) * invN;     // phase in revolutions
+                    rev -= floorf(rev);
+                    sn = __sinf(6.283185307179586f * rev); cs = __cosf(6.283185307179586f * rev);
+                }
+                float mr = pv.x * cs - pv.y * sn, mi = pv.x * sn + pv.y * cs;
+                float av = group16_sum_dpp(ax * mr + ay * mi);
+                if ((lane & 15) == 0 && ring < nr) { atomicAdd(&myA[q * nw * nr + ring], av); atomicAdd(&myB[q * nw], bv); }
+            }
+        }
+    }
+    accC = wave_sum(accC);
+    if (lane == 0) sumC[wave] = accC;
+    __syncthreads();
+    {   // 8 lanes per slot: lane j takes the rings j, j + 8, ...; waves and lanes are combined in a fixed order
+        const int slot = tid >> 3, j = tid & 7;
+        double sa = 0;
+        if (slot < nslots)
+            for (int b = j; b < nr; b += 8) {
+                const float *cell = ringA + (size_t)slot * nw * nr + b;
+                float a = cell[0];
+                for (int w = 1; w < nw; w++) a += cell[w * nr];
+                sa += ((float)b <= C.ring_signed) ? (double)a : fabs((double)a);
+            }
+        sa = group8_sum_d(sa);
+        if (slot < nslots && j == 0) {
+            float fb = sumB[slot * nw], fc = sumC[0];
+            for (int w = 1; w < nw; w++) { fb += sumB[slot * nw + w]; fc += sumC[w]; }
+            const double sb = fb, sc = fc;
+            score[slot] = (sb > 0 && sc > 0) ? sa / sqrt(sb * sc) : 0.0;
+        }
+    }
+    __syncthreads();
+}
 
 // Block = one trajectory, 128 or 256 threads.  A compass iteration scores the centre and the neighbouring poses in
 // one sweep over the ring-ordered samples (image value and CTF weight loaded once per sample; the centre and
@@ -139,85 +231,10 @@ __global__ void __launch_bounds__(256, 5) k_local(LocalP P) {
     const float invN = 1.0f / (float)P.N;
     const int tilt = P.en[1] && P.en[2];
 
-    auto sweep = [&]() {
-        const int nslots = plan.nslots, ng = plan.ng, S_used = plan.S_used;
-        const float rmax2 = plan.rmax2;
-        for (int i = tid; i < nslots * nw * nr; i += nthr) ringA[i] = 0.f;
-        if (tid < kMaxCand * nw) sumB[tid] = 0.f;
-        __syncthreads();
-        float *const myA = ringA + wave * nr, *const myB = sumB + wave;
-        float accC = 0.f;
-        for (int s0 = 0; s0 < S_used; s0 += nthr) {
-            const int s = s0 + tid;
-            int kx = 0, ky = 0, al = 0, ring = 0;
-            float2 iv = make_float2(0.f, 0.f); float c = 0.f;
-            if (s < S_used) {
-                unpack_sample(P.samples[s], kx, ky, al, ring);
-                float k2 = (float)(kx * kx + ky * ky);
-                if (!(k2 < rmax2 && k2 >= P.rlo2)) al = 0;
-                iv = Il[s]; c = cw[s];
-            }
-            const float fal = (float)al, fkx = (float)kx, fky = (float)ky;
-            accC += fal * (iv.x * iv.x + iv.y * iv.y);
-            const float ax = fal * iv.x, ay = fal * iv.y;
-            auto fetch = [&](int g) {
-                const float *m = plan.m[g];
-                return cube_fetch(P.cv, m[0] * fkx + m[1] * fky, m[2] * fkx + m[3] * fky, m[4] * fkx + m[5] * fky);
-            };
-            CubeTaps cur = fetch(0);
-            // the angular neighbours and the centre share one shift (slots 0 .. q_same): one phase factor per sample for all
-            float cs0, sn0;
-            {
-                float rev = -(fkx * plan.sh[0][0] + fky * plan.sh[0][1]) * invN;
-                rev -= floorf(rev);
-                sn0 = __sinf(6.283185307179586f * rev); cs0 = __cosf(6.283185307179586f * rev);
-            }
-            const int q_same = plan.q_same;
-            for (int g = 0; g < ng; g++) {
-                CubeTaps nxt = cur;
-                if (g + 1 < ng) nxt = fetch(g + 1);          // the next group's gathers fly while this group is scored
-                float2 pv = cube_interp(cur);
-                cur = nxt;
-                pv.x *= c; pv.y *= c;
-                float bv = group16_sum_dpp(fal * (pv.x * pv.x + pv.y * pv.y));     // |m|^2 does not depend on the shift
-                const int nv = plan.nv[g], q0 = plan.slot0[g];
-                for (int v = 0; v < nv; v++) {
-                    const int q = q0 + v;
-                    float sn = sn0, cs = cs0;
-                    if (q > q_same) {                                    // a shifted probe (wave-uniform branch)
-                        float rev = -(fkx * plan.sh[q][0] + fky * plan.sh[q][1]) * invN;     // phase in revolutions
-                        rev -= floorf(rev);
-                        sn = __sinf(6.283185307179586f * rev); cs = __cosf(6.283185307179586f * rev);
-                    }
-                    float mr = pv.x * cs - pv.y * sn, mi = pv.x * sn + pv.y * cs;
-                    float av = group16_sum_dpp(ax * mr + ay * mi);
-                    if ((lane & 15) == 0 && ring < nr) { atomicAdd(&myA[q * nw * nr + ring], av); atomicAdd(&myB[q * nw], bv); }
-                }
-            }
-        }
-        accC = wave_sum(accC);
-        if (lane == 0) sumC[wave] = accC;
-        __syncthreads();
-        {   // 8 lanes per slot: lane j takes the rings j, j + 8, ...; waves and lanes are combined in a fixed order
-            const int slot = tid >> 3, j = tid & 7;
-            double sa = 0;
-            if (slot < nslots)
-                for (int b = j; b < nr; b += 8) {
-                    const float *cell = ringA + (size_t)slot * nw * nr + b;
-                    float a = cell[0];
-                    for (int w = 1; w < nw; w++) a += cell[w * nr];
-                    sa += ((float)b <= P.ring_signed) ? (double)a : fabs((double)a);
-                }
-            sa = group8_sum_d(sa);
-            if (slot < nslots && j == 0) {
-                float fb = sumB[slot * nw], fc = sumC[0];
-                for (int w = 1; w < nw; w++) { fb += sumB[slot * nw + w]; fc += sumC[w]; }
-                const double sb = fb, sc = fc;
-                score[slot] = (sb > 0 && sc > 0) ? sa / sqrt(sb * sc) : 0.0;
-            }
-        }
-        __syncthreads();
-    };
+    SweepCtx SC;
+    SC.cv = P.cv; SC.samples = P.samples; SC.Il = Il; SC.cw = cw; SC.invN = invN; SC.rlo2 = P.rlo2; SC.ring_signed = P.ring_signed;
+    SC.nr = nr; SC.nw = nw; SC.ringA = ringA; SC.sumB = sumB; SC.sumC = sumC; SC.score = score;
+    auto sweep = [&]() { sweep_plan(plan, SC, tid, nthr); };
     auto set_rot = [&](int g, const double *M) {
         plan.m[g][0] = (float)M[0]; plan.m[g][1] = (float)M[1]; plan.m[g][2] = (float)M[3];
         plan.m[g][3] = (float)M[4]; plan.m[g][4] = (float)M[6]; plan.m[g][5] = (float)M[7];

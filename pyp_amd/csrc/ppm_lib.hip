@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -14,6 +15,7 @@
 #include "../../include/ppm.h"
 #include "ppm_geom.h"
 #include "ppm_kernels2.h"
+#include "ppm_csp_kernels.h"
 
 using namespace ppm;
 
@@ -877,3 +879,297 @@ int ppm_finalize(ppm_accum_t *a, const ppm_final_cfg *cfg, float *half1, float *
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------ constrained refinement (csp)
+namespace {
+struct CUnit { double N[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 }, p[3] = { 0, 0, 0 }, tl[4] = { 0, 0, 0, 0 }, acc[6] = { 0, 0, 0, 0, 0, 0 }; };
+
+void csp_apply(int kind, const CUnit &s, const double d[6], CUnit &o) {
+    o = s;
+    if (kind == PPM_CSP_PARTICLES) {
+        double R[9], T[9];
+        for (int k = 0; k < 3; k++) if (d[k] != 0) { rot_xyz(k, d[k], R); mat_mul3h(o.N, R, T); std::memcpy(o.N, T, sizeof(T)); }
+        for (int k = 0; k < 3; k++) o.p[k] += d[3 + k];
+    } else { o.tl[0] += d[0]; o.tl[1] += d[1]; o.tl[2] += d[3]; o.tl[3] += d[4]; }
+    for (int k = 0; k < 6; k++) o.acc[k] += d[k];
+}
+}  // namespace
+
+extern "C" int ppm_csp_refine(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const ppm_csp_cfg *cc, const void *images, int images_on_device,
+                              int n_proj, double *rows, double *particles, int n_part, double *tilts, int n_tilt) {
+    if (!g.inited) return fail(-1, "ppm_init has not been called");
+    if (!ref || !cfg || !cc || !images || !rows || !particles || !tilts) return fail(-22, "null argument");
+    if (cc->unit != PPM_CSP_PARTICLES && cc->unit != PPM_CSP_MICROGRAPHS) return fail(-22, "csp: unit must be particles (1) or micrographs (2)");
+    if (n_proj <= 0) return 0;
+    if (n_part <= 0 || n_tilt <= 0) return fail(-22, "csp: the extended parameters hold no particles or no tilts");
+    ppm_refine_cfg c2 = *cfg; c2.global_search = 0;
+    Geom gm; std::string err;
+    if (!geom_init(gm, c2, err)) return fail(-22, err);
+    if (gm.N != ref->N) return fail(-22, "particle box differs from the reference box");
+    if (gm.B > (ref->B + 1) / ref->pad - 1) return fail(-22, "high-resolution limit exceeds the band the reference was prepared for");
+    const int kind = cc->unit;
+    // ---- rows -> units
+    std::map<long, int> pmap; std::map<std::pair<long, long>, int> tmap;
+    for (int i = 0; i < n_part; i++) pmap[(long)particles[(size_t)i * PPM_NPCOL]] = i;
+    for (int i = 0; i < n_tilt; i++) tmap[{ (long)tilts[(size_t)i * PPM_NTCOL], (long)tilts[(size_t)i * PPM_NTCOL + 1] }] = i;
+    std::vector<int> row_part(n_proj), row_tilt(n_proj);
+    std::vector<unsigned char> usable(n_proj);
+    std::vector<CUnit> parts(n_part), tls(n_tilt);
+    for (int i = 0; i < n_part; i++) {
+        const double *P = particles + (size_t)i * PPM_NPCOL;
+        euler_matrix(-P[4], -P[5], -P[6], parts[i].N);
+        parts[i].p[0] = P[1]; parts[i].p[1] = P[2]; parts[i].p[2] = P[3];
+    }
+    for (int i = 0; i < n_tilt; i++) {
+        const double *T = tilts + (size_t)i * PPM_NTCOL;
+        tls[i].tl[0] = T[4]; tls[i].tl[1] = T[5]; tls[i].tl[2] = T[2]; tls[i].tl[3] = T[3];
+    }
+    std::vector<double> s0((size_t)2 * n_proj), g0((size_t)2 * n_proj);
+    for (int j = 0; j < n_proj; j++) {
+        const double *row = rows + (size_t)j * PPM_NCOL;
+        auto ip = pmap.find((long)row[PPM_PIND]); auto it = tmap.find({ (long)row[PPM_TIND], (long)row[28] });
+        if (ip == pmap.end() || it == tmap.end()) return fail(-22, "csp: row " + std::to_string(j + 1) + " refers to a particle or tilt missing from the extended parameters");
+        row_part[j] = ip->second; row_tilt[j] = it->second;
+        const long tind = (long)row[PPM_TIND];
+        usable[j] = row[PPM_OCC] > 0 && tind >= cc->tind_min && (cc->tind_max < 0 || tind <= cc->tind_max);
+        s0[2 * j] = row[PPM_XSHIFT] / gm.a; s0[2 * j + 1] = row[PPM_YSHIFT] / gm.a;
+        double M[9];
+        const CUnit &pu = parts[row_part[j]], &tu = tls[row_tilt[j]];
+        csp_row_pose(pu.N, pu.p, tu.tl[0], tu.tl[1], tu.tl[2], tu.tl[3], M, &g0[2 * j]);
+    }
+    const int nu_all = kind == PPM_CSP_PARTICLES ? n_part : n_tilt;
+    std::vector<CUnit> &units = kind == PPM_CSP_PARTICLES ? parts : tls;
+    std::vector<std::vector<int>> urows(nu_all);
+    for (int j = 0; j < n_proj; j++) urows[kind == PPM_CSP_PARTICLES ? row_part[j] : row_tilt[j]].push_back(j);
+    std::vector<int> unit_slot(nu_all, -1), active;        // active: refined units with at least one usable row
+    std::vector<unsigned char> refined(nu_all, 0);
+    for (int u = 0; u < nu_all; u++) {
+        const long id = (long)(kind == PPM_CSP_PARTICLES ? particles[(size_t)u * PPM_NPCOL] : tilts[(size_t)u * PPM_NTCOL]);
+        if (id < cc->first || (cc->last >= 0 && id > cc->last)) continue;
+        refined[u] = 1;
+        int nus = 0; for (int j : urows[u]) nus += usable[j];
+        if (nus) { unit_slot[u] = (int)active.size(); active.push_back(u); }
+    }
+    std::vector<int> eval_rows, final_rows;
+    for (int u : active) for (int j : urows[u]) if (usable[j]) eval_rows.push_back(j);
+    for (int u = 0; u < nu_all; u++) if (refined[u]) for (int j : urows[u]) final_rows.push_back(j);
+    if (final_rows.empty()) return 0;
+    // units without usable rows still need a slot for the final scoring of their rows (zero displacement)
+    int n_slots = (int)active.size();
+    for (int u = 0; u < nu_all; u++) if (refined[u] && unit_slot[u] < 0) unit_slot[u] = n_slots++;
+    // in the other kind's lookups (a particle sweep reads the tilt of a row and vice versa) no slot is needed
+
+    int en[6] = { 0, 0, 0, 0, 0, 0 }; double tol[6] = { 0, 0, 0, 0, 0, 0 };
+    if (kind == PPM_CSP_PARTICLES) {
+        for (int k = 0; k < 3; k++) { en[k] = cc->refine_rotation != 0; tol[k] = cc->tol_angle[k]; en[3 + k] = cc->refine_translation != 0; tol[3 + k] = cc->tol_shift; }
+    } else {
+        en[0] = en[1] = cc->refine_rotation != 0; tol[0] = cc->tol_angle[0]; tol[1] = cc->tol_angle[1];
+        en[3] = en[4] = cc->refine_translation != 0; tol[3] = tol[4] = cc->tol_shift;
+    }
+    int nfree = 0;
+    for (int k = 0; k < 6; k++) { if (!(tol[k] > 0)) en[k] = 0; nfree += en[k]; }
+    double ha0 = 0, hs0 = 0;
+    for (int k = 0; k < 3; k++) if (en[k] && 0.5 * tol[k] > ha0) ha0 = 0.5 * tol[k];
+    for (int k = 3; k < 6; k++) if (en[k] && 0.5 * tol[k] > hs0) hs0 = 0.5 * tol[k];
+    const double steptol = cc->step_tolerance > 0 ? cc->step_tolerance : 0.01;
+    int T = cc->max_iterations;
+    if (T <= 0) { const double m = std::max(ha0, hs0); T = m > steptol ? (int)std::ceil(std::log(m / steptol) / std::log(2.0)) : 1; T = std::min(12, std::max(1, T)); }
+    if (!nfree || active.empty()) T = 0;
+    const double bf = cfg->band_factor == 0 ? 3.0 : cfg->band_factor, rm_px = cfg->mask_radius / gm.a;
+    const bool any_ang = en[0] || en[1] || en[2], any_sh = en[3] || en[4] || en[5];
+    auto iter_band = [&](double ha, double hs) {
+        if (bf < 0) return gm.r_hi;
+        double d = 0;
+        if (any_ang) d = rm_px * ha * kPi / 180.0;
+        if (any_sh && hs > d) d = hs;
+        if (!(d > 0)) return gm.r_hi;
+        double rit = bf * gm.N / (2.0 * kPi * d);
+        if (rit < 4.0) rit = 4.0;
+        return rit < gm.r_hi ? rit : gm.r_hi;
+    };
+
+    // ---- device: sample list, prepared spectra of all rows
+    SampleList sl; build_samples(gm, sl);
+    const int S_pad = (int)sl.packed.size(), nrings = gm.B + 2;
+    auto prefix_of = [&](double rband) { int rg = (int)std::ceil(rband); if (rg > gm.B + 1) rg = gm.B + 1; return sl.ring_off[rg]; };
+    const size_t NN = (size_t)gm.N * gm.N, HW = (size_t)gm.H * gm.W;
+    if (int rc = ref->samples.ensure(S_pad)) return rc;
+    HIPCHK(hipMemcpyAsync(ref->samples.p, sl.packed.data(), S_pad * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
+    DevBuf<float2> Il, band; DevBuf<float> cw, img; DevBuf<double> d_rows, d_N, d_p, d_tl, d_delta, d_s0, d_g0, d_out;
+    DevBuf<int> d_eval, d_rp, d_rt, d_slot;
+    struct Cleanup { std::vector<std::function<void()>> f; ~Cleanup() { for (auto &x : f) x(); } } cleanup;
+    cleanup.f = { [&] { Il.release(); band.release(); cw.release(); img.release(); d_rows.release(); d_N.release(); d_p.release(); d_tl.release();
+                        d_delta.release(); d_s0.release(); d_g0.release(); d_out.release(); d_eval.release(); d_rp.release(); d_rt.release(); d_slot.release(); } };
+    const int CH = (int)std::min<size_t>((size_t)n_proj, std::max<size_t>(64, ((size_t)2 << 30) / (NN * 4 + HW * 8)));
+    if (int rc = Il.ensure((size_t)n_proj * S_pad)) return rc;
+    if (int rc = cw.ensure((size_t)n_proj * S_pad)) return rc;
+    if (int rc = band.ensure((size_t)CH * HW)) return rc;
+    if (int rc = d_rows.ensure((size_t)n_proj * PPM_NCOL)) return rc;
+    if (!images_on_device) if (int rc = img.ensure((size_t)CH * NN)) return rc;
+    HIPCHK(hipMemcpyAsync(d_rows.p, rows, (size_t)n_proj * PPM_NCOL * sizeof(double), hipMemcpyHostToDevice, g.stream));
+    const double fall = cfg->mask_falloff > 0 ? cfg->mask_falloff : 20.0;
+    for (int c0 = 0; c0 < n_proj; c0 += CH) {
+        const int nb = std::min(CH, n_proj - c0);
+        const float *d_img = (const float *)images + (size_t)c0 * NN;
+        if (!images_on_device) {
+            HIPCHK(hipMemcpyAsync(img.p, (const float *)images + (size_t)c0 * NN, (size_t)nb * NN * sizeof(float), hipMemcpyHostToDevice, g.stream));
+            d_img = img.p;
+        }
+        if (int rc = launch_prep(d_img, d_rows.p + (size_t)c0 * PPM_NCOL, nb, gm, (float)rm_px, (float)(fall / gm.a), cfg->normalize, cfg->invert, 1, 1,
+                                 band.p, nullptr, ref->samples.p, S_pad, Il.p + (size_t)c0 * S_pad, cw.p + (size_t)c0 * S_pad, nullptr, nullptr, nullptr)) return rc;
+        HIPCHK(hipStreamSynchronize(g.stream));
+    }
+    // ---- static tables
+    if (int rc = d_rp.ensure(n_proj)) return rc;
+    if (int rc = d_rt.ensure(n_proj)) return rc;
+    if (int rc = d_slot.ensure(nu_all)) return rc;
+    if (int rc = d_s0.ensure((size_t)2 * n_proj)) return rc;
+    if (int rc = d_g0.ensure((size_t)2 * n_proj)) return rc;
+    if (int rc = d_N.ensure((size_t)9 * n_part)) return rc;
+    if (int rc = d_p.ensure((size_t)3 * n_part)) return rc;
+    if (int rc = d_tl.ensure((size_t)4 * n_tilt)) return rc;
+    const int ncand_max = 1 + 2 * nfree;
+    if (ncand_max > kMaxCand) return fail(-22, "csp: too many free parameters");
+    if (int rc = d_delta.ensure((size_t)std::max(n_slots, 1) * ncand_max * 6)) return rc;
+    if (int rc = d_eval.ensure(std::max(eval_rows.size(), final_rows.size()))) return rc;
+    if (int rc = d_out.ensure(std::max(eval_rows.size() * ncand_max, final_rows.size()))) return rc;
+    HIPCHK(hipMemcpyAsync(d_rp.p, row_part.data(), n_proj * sizeof(int), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemcpyAsync(d_rt.p, row_tilt.data(), n_proj * sizeof(int), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemcpyAsync(d_slot.p, unit_slot.data(), nu_all * sizeof(int), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemcpyAsync(d_s0.p, s0.data(), s0.size() * sizeof(double), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemcpyAsync(d_g0.p, g0.data(), g0.size() * sizeof(double), hipMemcpyHostToDevice, g.stream));
+    std::vector<double> hN((size_t)9 * n_part), hp((size_t)3 * n_part), htl((size_t)4 * n_tilt);
+    auto upload_units = [&]() -> int {
+        for (int i = 0; i < n_part; i++) { std::memcpy(&hN[(size_t)9 * i], parts[i].N, 9 * sizeof(double)); std::memcpy(&hp[(size_t)3 * i], parts[i].p, 3 * sizeof(double)); }
+        for (int i = 0; i < n_tilt; i++) std::memcpy(&htl[(size_t)4 * i], tls[i].tl, 4 * sizeof(double));
+        HIPCHK(hipMemcpyAsync(d_N.p, hN.data(), hN.size() * sizeof(double), hipMemcpyHostToDevice, g.stream));
+        HIPCHK(hipMemcpyAsync(d_p.p, hp.data(), hp.size() * sizeof(double), hipMemcpyHostToDevice, g.stream));
+        HIPCHK(hipMemcpyAsync(d_tl.p, htl.data(), htl.size() * sizeof(double), hipMemcpyHostToDevice, g.stream));
+        HIPCHK(hipStreamSynchronize(g.stream));
+        return 0;
+    };
+    CspEvalP EP;
+    EP.cv.cube = ref->cube; EP.cv.NBX = ref->NBX; EP.cv.NBY = ref->NBY; EP.cv.LB = ref->LB; EP.cv.off = ref->B + 1; EP.cv.scale = (float)ref->pad;
+    EP.samples = ref->samples.p; EP.Il = Il.p; EP.cw = cw.p; EP.S_pad = S_pad; EP.N = gm.N; EP.nr = nrings;
+    EP.rlo2 = (float)(gm.r_lo * gm.r_lo); EP.ring_signed = (float)std::min(gm.ring_signed, 1e30);
+    EP.kind = kind; EP.eval_rows = d_eval.p; EP.row_part = d_rp.p; EP.row_tilt = d_rt.p; EP.unit_slot = d_slot.p;
+    EP.Nmat = d_N.p; EP.pshift = d_p.p; EP.tl = d_tl.p; EP.delta = d_delta.p; EP.s0 = d_s0.p; EP.g0 = d_g0.p; EP.out = d_out.p;
+    std::vector<double> hdelta, hout;
+    // one sweep: `ncand` candidates per unit (hdelta laid out [slot][ncand][6]) over `rows_list`; scores -> hout [row][ncand]
+    auto sweep = [&](const std::vector<int> &rows_list, int ncand, double rband) -> int {
+        HIPCHK(hipMemcpyAsync(d_delta.p, hdelta.data(), (size_t)n_slots * ncand * 6 * sizeof(double), hipMemcpyHostToDevice, g.stream));
+        HIPCHK(hipMemcpyAsync(d_eval.p, rows_list.data(), rows_list.size() * sizeof(int), hipMemcpyHostToDevice, g.stream));
+        EP.ncand = ncand; EP.S_used = prefix_of(rband); EP.rmax2 = (float)(rband * rband);
+        {
+            ProfScope ps(PPM_K_LOCAL);
+            hipLaunchKernelGGL(k_csp_eval, dim3((unsigned)rows_list.size()), dim3(256), ring_lds_bytes(4, kMaxCand, nrings), g.stream, EP);
+        }
+        HIPCHK(hipGetLastError());
+        hout.resize(rows_list.size() * (size_t)ncand);
+        HIPCHK(hipMemcpyAsync(hout.data(), d_out.p, hout.size() * sizeof(double), hipMemcpyDeviceToHost, g.stream));
+        HIPCHK(hipStreamSynchronize(g.stream));
+        return 0;
+    };
+    // mean over the usable rows of every active unit, rows in eval_rows order (grouped by unit, ascending row index)
+    auto unit_means = [&](int ncand, std::vector<double> &mean) {
+        mean.assign((size_t)active.size() * ncand, 0.0);
+        size_t pos = 0;
+        for (size_t a = 0; a < active.size(); a++) {
+            int n = 0;
+            for (int j : urows[active[a]]) {
+                if (!usable[j]) continue;
+                for (int c = 0; c < ncand; c++) mean[a * ncand + c] += hout[pos * ncand + c];
+                pos++; n++;
+            }
+            for (int c = 0; c < ncand; c++) mean[a * ncand + c] /= n;
+        }
+    };
+    if (int rc = upload_units()) return rc;
+    double ha = ha0, hs = hs0;
+    std::vector<double> mean, tmean, dtrial((size_t)active.size() * 6);
+    std::vector<int> cand_param, cand_sign;      // candidate c >= 1 moves parameter cand_param[c] by cand_sign[c] h
+    cand_param.push_back(-1); cand_sign.push_back(0);
+    for (int i = 0; i < 6; i++) if (en[i]) { cand_param.push_back(i); cand_sign.push_back(1); cand_param.push_back(i); cand_sign.push_back(-1); }
+    const int ncand = (int)cand_param.size();
+    for (int it = 0; it < T; it++) {
+        const double rband = iter_band(ha, hs);
+        hdelta.assign((size_t)n_slots * ncand * 6, 0.0);
+        for (size_t a = 0; a < active.size(); a++)
+            for (int c = 1; c < ncand; c++) hdelta[((size_t)unit_slot[active[a]] * ncand + c) * 6 + cand_param[c]] = cand_sign[c] * (cand_param[c] < 3 ? ha : hs);
+        if (int rc = sweep(eval_rows, ncand, rband)) return rc;
+        unit_means(ncand, mean);
+        // parabolic step per unit (same rule as the oracle's loop and k_local's compass iteration)
+        std::vector<double> fpv((size_t)active.size() * 6, -1e300), fmv((size_t)active.size() * 6, -1e300);
+        for (size_t a = 0; a < active.size(); a++) {
+            const CUnit &s = units[active[a]];
+            const double f0 = mean[a * ncand];
+            double *d = &dtrial[a * 6];
+            for (int i = 0, c = 1; i < 6; i++) {
+                d[i] = 0;
+                if (!en[i]) continue;
+                const double h = i < 3 ? ha : hs;
+                const bool okp = std::fabs(s.acc[i] + h) <= tol[i] + 1e-9, okm = std::fabs(s.acc[i] - h) <= tol[i] + 1e-9;
+                const double fp = okp ? mean[a * ncand + c] : -1e300, fm = okm ? mean[a * ncand + c + 1] : -1e300;
+                c += 2;
+                fpv[a * 6 + i] = fp; fmv[a * 6 + i] = fm;
+                if (okp && okm) {
+                    const double den = 2.0 * f0 - fp - fm;
+                    if (den > 1e-12) { double t = 0.5 * h * (fp - fm) / den; d[i] = t > h ? h : (t < -h ? -h : t); }
+                    else { const double best = fp > fm ? fp : fm; d[i] = best > f0 ? (fp > fm ? h : -h) : 0.0; }
+                } else if (okp) d[i] = fp > f0 ? h : 0.0;
+                else if (okm) d[i] = fm > f0 ? -h : 0.0;
+                if (s.acc[i] + d[i] > tol[i]) d[i] = tol[i] - s.acc[i];
+                if (s.acc[i] + d[i] < -tol[i]) d[i] = -tol[i] - s.acc[i];
+            }
+        }
+        hdelta.assign((size_t)n_slots * 6, 0.0);
+        for (size_t a = 0; a < active.size(); a++) std::memcpy(&hdelta[(size_t)unit_slot[active[a]] * 6], &dtrial[a * 6], 6 * sizeof(double));
+        if (int rc = sweep(eval_rows, 1, rband)) return rc;
+        unit_means(1, tmean);
+        for (size_t a = 0; a < active.size(); a++) {
+            CUnit &s = units[active[a]];
+            const double f0 = mean[a * ncand], ft = tmean[a];
+            int bi = -1, bs = 0; double fb = f0;
+            for (int i = 0; i < 6; i++) {
+                if (!en[i]) continue;
+                if (fpv[a * 6 + i] > fb) { fb = fpv[a * 6 + i]; bi = i; bs = 1; }
+                if (fmv[a * 6 + i] > fb) { fb = fmv[a * 6 + i]; bi = i; bs = -1; }
+            }
+            CUnit q;
+            if (ft > f0 && ft >= fb) { csp_apply(kind, s, &dtrial[a * 6], q); s = q; }
+            else if (bi >= 0) { double dd[6] = { 0, 0, 0, 0, 0, 0 }; dd[bi] = bs * (bi < 3 ? ha : hs); csp_apply(kind, s, dd, q); s = q; }
+        }
+        if (int rc = upload_units()) return rc;
+        ha *= 0.5; hs *= 0.5;
+    }
+    // ---- final scores of every row of the refined units at the full band; write-back
+    hdelta.assign((size_t)std::max(n_slots, 1) * 6, 0.0);
+    if (int rc = sweep(final_rows, 1, gm.r_hi)) return rc;
+    std::vector<double> row_score(n_proj, 0.0);
+    for (size_t q = 0; q < final_rows.size(); q++) row_score[final_rows[q]] = hout[q];
+    for (int u = 0; u < nu_all; u++) {
+        if (!refined[u]) continue;
+        if (kind == PPM_CSP_PARTICLES) {
+            double *P = particles + (size_t)u * PPM_NPCOL, a1, a2, a3;
+            angles_from_matrix(units[u].N, a1, a2, a3);
+            P[4] = -a1; P[5] = -a2; P[6] = -a3; P[1] = units[u].p[0]; P[2] = units[u].p[1]; P[3] = units[u].p[2];
+        } else {
+            double *Tt = tilts + (size_t)u * PPM_NTCOL;
+            Tt[4] = units[u].tl[0]; Tt[5] = units[u].tl[1]; Tt[2] = units[u].tl[2]; Tt[3] = units[u].tl[3];
+        }
+        double ssum = 0; int sn = 0;
+        for (int j : urows[u]) {
+            double *row = rows + (size_t)j * PPM_NCOL, M[9], gq[2];
+            const CUnit &pu = parts[row_part[j]], &tu = tls[row_tilt[j]];
+            csp_row_pose(pu.N, pu.p, tu.tl[0], tu.tl[1], tu.tl[2], tu.tl[3], M, gq);
+            angles_from_matrix(M, row[PPM_PSI], row[PPM_THETA], row[PPM_PHI]);
+            row[PPM_XSHIFT] = (s0[2 * j] + gq[0] - g0[2 * j]) * gm.a; row[PPM_YSHIFT] = (s0[2 * j + 1] + gq[1] - g0[2 * j + 1]) * gm.a;
+            const double ccv = row_score[j]; double res = 1.0 - ccv * ccv; if (res < 1e-6) res = 1e-6;
+            row[PPM_SCORE] = 100.0 * ccv; row[PPM_SIGMA] = std::sqrt(res);
+            row[PPM_LOGP] = -0.5 * (kPi * (gm.r_hi * gm.r_hi - gm.r_lo * gm.r_lo)) * (std::log(2.0 * kPi * res) + 1.0);
+            if (usable[j]) { ssum += row[PPM_SCORE]; sn++; }
+        }
+        if (kind == PPM_CSP_PARTICLES) particles[(size_t)u * PPM_NPCOL + 10] = sn ? ssum / sn : -1.0;
+    }
+    return 0;
+}

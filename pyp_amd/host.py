@@ -60,6 +60,19 @@ class Reference:
         del keep
         return out
 
+    def csp_refine(self, cfg, csp_cfg, images, rows, particles, tilts):
+        """Constrained refinement (ppm_csp_refine): returns updated copies (rows, particles, tilts)."""
+        rows = np.array(rows, dtype=np.float64, order="C")
+        particles = np.array(particles, dtype=np.float64, order="C")
+        tilts = np.array(tilts, dtype=np.float64, order="C")
+        if rows.ndim != 2 or rows.shape[1] != NCOL or particles.ndim != 2 or particles.shape[1] != 12 or tilts.ndim != 2 or tilts.shape[1] != 6:
+            raise ValueError("ERROR: rows must be (M, 32), particles (P, 12), tilts (T, 6)")
+        p, on_dev, keep = _images_arg(images, len(rows), cfg.box)
+        lib.check(lib.load().ppm_csp_refine(self.h, C.byref(cfg), C.byref(csp_cfg), p, on_dev, len(rows), lib.ptr(rows), lib.ptr(particles),
+                                            len(particles), lib.ptr(tilts), len(tilts)))
+        del keep
+        return rows, particles, tilts
+
     def note(self):
         """Remarks of the last refine() the caller should log ("" if none)."""
         return (lib.load().ppm_refine_note(self.h) or b"").decode(errors="replace")

@@ -193,6 +193,22 @@ def make_dataset(n, m, pixel=1.0, snr=0.05, seed_poses=SEED_POSES, seed_noise=SE
     rows[:, C["X_SHIFT"]], rows[:, C["Y_SHIFT"]] = sh[rep, 0] * pixel, sh[rep, 1] * pixel
     rows[:, C["DEFOCUS_1"]], rows[:, C["DEFOCUS_2"]], rows[:, C["DEFOCUS_ANGLE"]] = df1[rep], df2[rep], ast[rep]
 
+    stack = render_rows(vol, rows[:u], pixel, snr, seed_noise, device, batch, particle_rad_frac, kv, cs_mm, amp, m=m, rep=rep)
+    return vol, stack, rows
+
+
+def render_rows(vol, rows, pixel=1.0, snr=0.05, seed_noise=SEED_NOISE, device="cpu", batch=64, particle_rad_frac=0.32,
+                kv=300.0, cs_mm=2.7, amp=0.07, m=None, rep=None):
+    """Images of the poses / CTF parameters in `rows` (u x 32): projection x CTF, shifted, white noise at `snr`, background
+    normalised.  With m / rep, image i of the m returned is clean projection rep[i] with fresh noise."""
+    C = cistem.COL
+    u = len(rows)
+    n = vol.shape[0]
+    if m is None:
+        m, rep = u, np.arange(u)
+    psi, theta, phi = rows[:, C["PSI"]], rows[:, C["THETA"]], rows[:, C["PHI"]]
+    sh = np.stack([rows[:, C["X_SHIFT"]], rows[:, C["Y_SHIFT"]]], axis=1) / pixel
+    df1, df2, ast = rows[:, C["DEFOCUS_1"]], rows[:, C["DEFOCUS_2"]], rows[:, C["DEFOCUS_ANGLE"]]
     dev = torch.device(device)
     proj = Projector(vol, dev)
     k = torch.arange(-n // 2, n // 2, device=dev, dtype=torch.float32)
@@ -227,7 +243,128 @@ def make_dataset(n, m, pixel=1.0, snr=0.05, seed_poses=SEED_POSES, seed_noise=SE
         mu = x[:, bg].mean(dim=1).view(-1, 1, 1)
         sd = x[:, bg].std(dim=1, unbiased=False).view(-1, 1, 1)
         stack[b0:b1] = (x - mu) / sd
-    return vol, stack, rows
+    return stack
+
+
+
+
+def rot_xyz(k, deg):
+    """Right-handed rotation about x (0), y (1), z (2)."""
+    t = np.radians(deg)
+    c, s = np.cos(t), np.sin(t)
+    return np.array([[[1, 0, 0], [0, c, -s], [0, s, c]], [[c, 0, s], [0, 1, 0], [-s, 0, c]], [[c, -s, 0], [s, c, 0], [0, 0, 1]]][k], dtype=np.float64)
+
+
+def angles_from_matrix(M):
+    """(psi, theta, phi) in [0, 360) of M = euler_matrix(psi, theta, phi)."""
+    ct = min(1.0, max(-1.0, M[2, 2]))
+    st = math.hypot(M[0, 2], M[1, 2])
+    if st > 1e-7:
+        theta, phi, psi = math.atan2(st, ct), math.atan2(M[1, 2], M[0, 2]), math.atan2(M[2, 1], -M[2, 0])
+    else:
+        theta, phi = (0.0 if ct > 0 else math.pi), 0.0
+        psi = math.atan2(M[1, 0], M[0, 0]) if ct > 0 else math.atan2(-M[1, 0], -M[0, 0])
+    out = np.degrees([psi, theta, phi])
+    out[out < 0] += 360.0
+    return out
+
+
+def csp_row_pose(particle, tilt):
+    """Pose of a projection row from its particle (12 columns of the particle block) and tilt (6 columns of the tilt block):
+    returns (psi, theta, phi, gx, gy) with the geometric shift g in pixels.  Numpy statement of the relation in
+    include/ppm.h (ppm_csp_cfg), which restates csp_euler_angles (src/pyp/analysis/geometry/core.py:1081-1213)."""
+    N = euler_matrix(-particle[4], -particle[5], -particle[6])
+    M = N @ rot_xyz(1, -tilt[4]) @ rot_xyz(2, tilt[5])
+    g = rot_xyz(2, -tilt[5]) @ rot_xyz(1, tilt[4]) @ (-np.asarray(particle[1:4], dtype=np.float64))
+    a = angles_from_matrix(M)
+    return np.array([a[0], a[1], a[2], g[0] + tilt[2], g[1] + tilt[3]])
+
+
+def make_tilt_series(n, n_part, tilt_angles, pixel=1.0, snr=0.1, vol=None, seed=20240601, device="cpu", axis=85.0,
+                     particle_rad_frac=0.32, defocus=(15000.0, 25000.0), dose_defocus_slope=0.0):
+    """Synthetic constrained data set (one tilt series): `n_part` particles with random 3-D orientations and small 3-D shifts,
+    one projection per (particle, tilt).  Returns (vol, stack (n_part * n_tilt, n, n), rows (M, 32), particles (n_part, 12),
+    tilts (n_tilt, 6)): the TRUE parameters; rows carry the poses that follow from them (csp_row_pose) and a random
+    sub-pixel residual in X_SHIFT / Y_SHIFT like the reference's extraction leaves (metadata/core.py:2745-2752)."""
+    if vol is None:
+        vol = phantom(n)
+    rng = np.random.default_rng(seed)
+    n_tilt = len(tilt_angles)
+    particles = np.zeros((n_part, 12))
+    particles[:, 0] = np.arange(n_part)
+    particles[:, 1:4] = rng.normal(0, 1.0, (n_part, 3))
+    for i in range(n_part):
+        a = angles_from_matrix(euler_matrix(rng.uniform(0, 360), np.degrees(np.arccos(rng.uniform(-1, 1))), rng.uniform(0, 360)))
+        particles[i, 4:7] = -a
+    particles[:, 7:10] = rng.uniform(100, 900, (n_part, 3))
+    particles[:, 10], particles[:, 11] = 0.0, 100.0
+    tilts = np.zeros((n_tilt, 6))
+    tilts[:, 0] = np.arange(n_tilt)
+    tilts[:, 2:4] = rng.normal(0, 0.5, (n_tilt, 2))
+    tilts[:, 4] = np.asarray(tilt_angles, dtype=np.float64)
+    tilts[:, 5] = axis + rng.normal(0, 0.3, n_tilt)
+    m = n_part * n_tilt
+    rows = cistem.default_rows(m, pixel, 300.0, 2.7, 0.07)
+    C = cistem.COL
+    resid = rng.uniform(-0.5, 0.5, (m, 2))
+    df = rng.uniform(defocus[0], defocus[1], n_tilt)
+    j = 0
+    for ip in range(n_part):
+        for it in range(n_tilt):
+            pose = csp_row_pose(particles[ip], tilts[it])
+            rows[j, C["PSI"]], rows[j, C["THETA"]], rows[j, C["PHI"]] = pose[0], pose[1], pose[2]
+            rows[j, C["X_SHIFT"]], rows[j, C["Y_SHIFT"]] = (pose[3] + resid[j, 0]) * pixel, (pose[4] + resid[j, 1]) * pixel
+            rows[j, C["DEFOCUS_1"]] = df[it] + 40.0 * (ip % 7)
+            rows[j, C["DEFOCUS_2"]] = rows[j, C["DEFOCUS_1"]] - 200.0
+            rows[j, C["DEFOCUS_ANGLE"]] = 30.0
+            rows[j, C["PIND"]], rows[j, C["TIND"]], rows[j, C["IMIND"]] = ip, it, it
+            j += 1
+    stack = render_rows(vol, rows, pixel, snr, seed + 1, device, 64, particle_rad_frac)
+    return vol, stack, rows, particles, tilts
+
+
+def paste_tilt_series(stack, rows, n_tilt, shape=(512, 512), seed=5):
+    """Tilt-series images (n_tilt, H, W) with every projection of `stack` pasted at a well-separated integer position of its
+    tilt image (IMIND) on a unit-noise background; sets ORIGINAL_X_POSITION (column) / ORIGINAL_Y_POSITION (row) in `rows`
+    (returned copy) so that extracting a box of the same size around them gives the projection back."""
+    C = cistem.COL
+    st = stack.numpy() if hasattr(stack, "numpy") else np.asarray(stack)
+    m, n = st.shape[0], st.shape[1]
+    rng = np.random.default_rng(seed)
+    series = rng.normal(0, 1, (n_tilt,) + tuple(shape)).astype(np.float32)
+    rows = rows.copy()
+    pind = np.unique(rows[:, C["PIND"]].astype(int))
+    per_row = max(1, (shape[1] - n) // (n + 16))
+    centre = {}
+    for k, pid in enumerate(pind):
+        gy, gx = divmod(k, per_row)
+        centre[pid] = (n // 2 + 8 + gx * (n + 16), n // 2 + 8 + gy * (n + 16))
+        if centre[pid][1] + n // 2 >= shape[0]:
+            raise ValueError("ERROR: tilt image too small for the particles")
+    for j in range(m):
+        x, y = centre[int(rows[j, C["PIND"]])]
+        x, y = x + int(rng.integers(-3, 4)), y + int(rng.integers(-3, 4))
+        t = int(rows[j, C["IMIND"]])
+        series[t, y - n // 2:y - n // 2 + n, x - n // 2:x - n // 2 + n] = st[j]
+        rows[j, C["ORIGINAL_X_POSITION"]], rows[j, C["ORIGINAL_Y_POSITION"]] = x, y
+    return series, rows
+
+
+def csp_rows_from_params(rows_ref, particles_ref, tilts_ref, particles, tilts):
+    """Rows that follow from (particles, tilts) when `rows_ref` followed from (particles_ref, tilts_ref): angles from the
+    geometry, shifts moved by the change of the geometric shift (what ppm_csp_refine writes back)."""
+    C = cistem.COL
+    out = rows_ref.copy()
+    pidx = {int(p[0]): i for i, p in enumerate(particles)}
+    tidx = {(int(t[0]), int(t[1])): i for i, t in enumerate(tilts)}
+    for j, r in enumerate(rows_ref):
+        ip, it = pidx[int(r[C["PIND"]])], tidx[(int(r[C["TIND"]]), int(r[C["RIND"]]))]
+        a, b = csp_row_pose(particles_ref[ip], tilts_ref[it]), csp_row_pose(particles[ip], tilts[it])
+        px = r[C["PIXEL_SIZE"]]
+        out[j, C["PSI"]], out[j, C["THETA"]], out[j, C["PHI"]] = b[0], b[1], b[2]
+        out[j, C["X_SHIFT"]] = r[C["X_SHIFT"]] + (b[3] - a[3]) * px
+        out[j, C["Y_SHIFT"]] = r[C["Y_SHIFT"]] + (b[4] - a[4]) * px
+    return out
 
 
 def perturb_rows(rows, angle_sigma=2.0, shift_sigma_px=1.0, pixel=1.0, seed=7):

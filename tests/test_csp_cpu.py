@@ -1,0 +1,134 @@
+"""CPU tests of the constrained-refinement row: the row <-> (particle, tilt) geometry against golden
+vectors produced by the reference's csp_euler_angles (tests/golden/gen_golden_r02.py), the CPU oracle's recovery of perturbed
+particle / tilt parameters on a synthetic tilt series, and the `csp` argv surface (src/pyp/system/local_run.py:364-376)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from pyp_amd import synth
+from pyp_amd.abi import CSP_MICROGRAPHS, CSP_PARTICLES, CspCfg, RefineCfg
+from pyp_amd.surface import csp_cli
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_r02.json")))
+
+
+def _angdiff(a, b):
+    return np.abs(((np.asarray(a) - np.asarray(b) + 180.0) % 360.0) - 180.0)
+
+
+def test_row_geometry_matches_reference_csp_euler_angles():
+    """PSI / THETA / PHI / SHX / SHY of a projection from (tilt angle, tilt axis, stored particle pose): the C oracle and the
+    numpy statement both reproduce what the reference's csp_euler_angles returned (geometry/core.py:1081-1213)."""
+    for c in GOLD["csp_geometry"]:
+        want = np.array(c["projection"])
+        got = oracle.csp_pose(c["tilt_angle"], c["tilt_axis"], c["particle"])
+        P = np.zeros(12); P[4:7] = c["particle"][:3]; P[1:4] = c["particle"][3:]
+        T = np.zeros(6); T[4], T[5] = c["tilt_angle"], c["tilt_axis"]
+        got2 = synth.csp_row_pose(P, T)
+        for g in (got, got2):
+            Mw, Mg = synth.euler_matrix(*want[:3]), synth.euler_matrix(*g[:3])
+            assert np.abs(Mw - Mg).max() < 1e-9                       # same rotation (angles may split differently at theta = 0)
+            assert np.abs(g[3:] - want[3:]).max() < 1e-9
+        if want[1] > 1e-3:
+            assert _angdiff(got[:3], want[:3]).max() < 1e-7
+
+
+@pytest.fixture(scope="module")
+def series():
+    n, px = 64, 2.0
+    vol, stack, rows, parts, tilts = synth.make_tilt_series(n, 5, np.arange(-48, 49, 16.0), pixel=px, snr=0.3)
+    cfg = RefineCfg.make(box=n, pixel_size=px, mask_radius=0.4 * n * px, res_high=px * n / 24, res_signed_cc=30.0, global_search=0)
+    return n, px, vol, stack.numpy(), rows, parts, tilts, cfg, oracle.Reference(vol, n / 2)
+
+
+def _perturb_particles(parts, seed=3, ang=2.0, sh=1.0):
+    rng = np.random.default_rng(seed)
+    p2 = parts.copy()
+    for i in range(len(p2)):
+        N = synth.euler_matrix(-p2[i, 4], -p2[i, 5], -p2[i, 6])
+        for k in range(3):
+            N = N @ synth.rot_xyz(k, rng.normal(0, ang))
+        p2[i, 4:7] = -synth.angles_from_matrix(N)
+        p2[i, 1:4] += rng.normal(0, sh, 3)
+    return p2
+
+
+def _particle_angle_err(a, b):
+    out = []
+    for x, y in zip(a, b):
+        Na, Nb = synth.euler_matrix(-x[4], -x[5], -x[6]), synth.euler_matrix(-y[4], -y[5], -y[6])
+        out.append(np.degrees(np.arccos(np.clip((np.trace(Na.T @ Nb) - 1) / 2, -1, 1))))
+    return np.array(out)
+
+
+def test_oracle_recovers_perturbed_particles(series):
+    n, px, vol, imgs, rows, parts, tilts, cfg, ref = series
+    p2 = _perturb_particles(parts)
+    rows2 = synth.csp_rows_from_params(rows, parts, tilts, p2, tilts)
+    cc = CspCfg.make(CSP_PARTICLES, tol_angle=(8, 8, 8), tol_shift=4.0)
+    r3, p3, t3, nev = oracle.csp_refine(ref, cfg, cc, imgs, rows2, p2, tilts)
+    assert np.array_equal(t3, tilts)
+    assert _particle_angle_err(p3, parts).max() < 1.2 and _particle_angle_err(p3, parts).mean() < 0.5 * _particle_angle_err(p2, parts).mean()
+    assert np.linalg.norm(p3[:, 1:4] - parts[:, 1:4], axis=1).max() < 0.35
+    # the rows follow from the parameters, and the score is back at the truth's level
+    want_rows = synth.csp_rows_from_params(rows2, p2, tilts, p3, tilts)
+    assert synth.angular_error_deg(r3, want_rows).max() < 1e-4 and synth.shift_error_px(r3, want_rows, px).max() < 1e-6       # arccos near 1
+    truth_score = oracle.score_batch(ref, cfg, imgs, rows).mean()
+    assert r3[:, 14].mean() / 100 > truth_score - 0.01 > oracle.score_batch(ref, cfg, imgs, rows2).mean()
+    assert np.allclose(p3[:, 10], [r3[r3[:, 26] == i, 14].mean() for i in range(len(p3))])
+    # a range refines only its own particles and leaves the other rows alone
+    cc2 = CspCfg.make(CSP_PARTICLES, tol_angle=(8, 8, 8), tol_shift=4.0, first=1, last=2)
+    r4, p4, _, _ = oracle.csp_refine(ref, cfg, cc2, imgs, rows2, p2, tilts)
+    inside = (rows2[:, 26] >= 1) & (rows2[:, 26] <= 2)
+    assert np.array_equal(r4[~inside], rows2[~inside]) and np.array_equal(p4[[0, 3, 4]], p2[[0, 3, 4]])
+    assert np.allclose(p4[1:3], p3[1:3]) and np.allclose(r4[inside], r3[inside])
+
+
+def test_oracle_recovers_tilt_shifts_and_respects_bounds(series):
+    n, px, vol, imgs, rows, parts, tilts, cfg, ref = series
+    rng = np.random.default_rng(5)
+    t2 = tilts.copy()
+    t2[:, 2:4] += rng.normal(0, 1.0, (len(t2), 2))
+    rows2 = synth.csp_rows_from_params(rows, parts, tilts, parts, t2)
+    cm = CspCfg.make(CSP_MICROGRAPHS, refine_rotation=0, tol_shift=4.0)
+    r3, p3, t3, _ = oracle.csp_refine(ref, cfg, cm, imgs, rows2, parts, t2)
+    assert np.array_equal(p3[:, :10], parts[:, :10]) and np.array_equal(t3[:, 4:], t2[:, 4:])
+    assert np.linalg.norm(t3[:, 2:4] - tilts[:, 2:4], axis=1).max() < 0.3
+    tight = CspCfg.make(CSP_MICROGRAPHS, refine_rotation=0, tol_shift=0.25)
+    _, _, t4, _ = oracle.csp_refine(ref, cfg, tight, imgs, rows2, parts, t2)
+    assert np.abs(t4[:, 2:4] - t2[:, 2:4]).max() <= 0.25 + 1e-9
+    # exposures outside UseImagesForRefinementMin / Max do not steer a particle
+    cc = CspCfg.make(CSP_PARTICLES, tol_angle=(8, 8, 8), tol_shift=4.0, tind_min=2, tind_max=4)
+    p2 = _perturb_particles(parts)
+    rows5 = synth.csp_rows_from_params(rows, parts, tilts, p2, tilts)
+    junk = imgs.copy()
+    junk[(rows[:, 27] < 2) | (rows[:, 27] > 4)] = 0.0
+    a = oracle.csp_refine(ref, cfg, cc, imgs, rows5, p2, tilts)[1]
+    b = oracle.csp_refine(ref, cfg, cc, junk, rows5, p2, tilts)[1]
+    assert np.allclose(a[:, 1:7], b[:, 1:7])
+
+
+def test_flat_toml_and_schedules(tmp_path):
+    f = tmp_path / ".pyp_config.toml"
+    f.write_text('data_set = "tomo"\nscope_pixel = 1.35\nextract_box = 64\nrefine_rhref = "8:7:6"\ncsp_refine_particles = true\n'
+                 'csp_Grid = "1,1,1"\ncsp_ToleranceParticlesShifts = 20.0\nrefine_iter = 3\nparticle_rad = 75\nslurm_tasks = 7\n')
+    p = csp_cli.read_flat_toml(str(f))
+    assert p["data_set"] == "tomo" and p["scope_pixel"] == 1.35 and p["csp_refine_particles"] is True and p["slurm_tasks"] == 7
+    assert [csp_cli.schedule("8:7:6", it) for it in range(2, 7)] == [8.0, 7.0, 6.0, 6.0, 6.0] and csp_cli.schedule(4, 9) == 4.0
+    s = csp_cli._settings(p)
+    assert s["res_high"] == 7.0 and s["box"] == 64 and s["tol_p_shift"] == 20.0 and s["tol_m_rot"][:2] == (1.5, 1.0) and s["iteration"] == 3
+
+
+def test_csp_executable_fails_loudly(tmp_path):
+    exe = os.path.join(ROOT, "bin", "csp")
+    r = subprocess.run([sys.executable, exe, "a.cistem", "a_extended.cistem", "5", "0", "3", "1", "frealign/x.mrc", "frealign/x_stack.mrc"],
+                       capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode != 0 and "ERROR" in r.stdout and not list(tmp_path.glob("*.cistem"))
+    r = subprocess.run([sys.executable, exe, "a.cistem"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode != 0 and "ERROR" in r.stdout and "usage" in r.stdout

@@ -1,0 +1,155 @@
+"""Constrained tilt-series refinement on the GPU (ppm_csp_refine, bin/csp) against the CPU oracle on the same synthetic tilt
+series.  Tolerances: BASELINE.json's 0.1 deg / 0.5 px on the unit parameters and on the rows that follow from them."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from pyp_amd import synth
+from pyp_amd.abi import CSP_MICROGRAPHS, CSP_PARTICLES, CspCfg, RefineCfg
+from pyp_amd.formats import cistem, mrc
+from test_csp_cpu import _particle_angle_err, _perturb_particles
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "bin")
+
+
+@pytest.fixture(scope="module")
+def series():
+    from oracle import oracle
+    from pyp_amd import host
+    n, px = 64, 2.0
+    vol, stack, rows, parts, tilts = synth.make_tilt_series(n, 8, np.arange(-54, 55, 12.0), pixel=px, snr=0.3)
+    cfg = RefineCfg.make(box=n, pixel_size=px, mask_radius=0.4 * n * px, res_high=px * n / 24, res_signed_cc=30.0, global_search=0)
+    return n, px, vol, stack.numpy(), rows, parts, tilts, cfg, host.Reference(vol, n / 2), oracle.Reference(vol, n / 2), oracle
+
+
+def test_particle_mode_matches_oracle(series):
+    n, px, vol, imgs, rows, parts, tilts, cfg, g, o, O = series
+    p2 = _perturb_particles(parts)
+    rows2 = synth.csp_rows_from_params(rows, parts, tilts, p2, tilts)
+    for kw in (dict(), dict(refine_translation=0), dict(refine_rotation=0), dict(first=2, last=5), dict(tind_min=1, tind_max=7)):
+        cc = CspCfg.make(CSP_PARTICLES, tol_angle=(8, 8, 8), tol_shift=4.0, **kw)
+        wr, wp, wt, _ = O.csp_refine(o, cfg, cc, imgs, rows2, p2, tilts)
+        gr, gp, gt = g.csp_refine(cfg, cc, imgs, rows2, p2, tilts)
+        assert _particle_angle_err(wp, gp).max() < 0.1 and np.abs(wp[:, 1:4] - gp[:, 1:4]).max() < 0.5, kw
+        assert synth.angular_error_deg(wr, gr).max() < 0.1 and synth.shift_error_px(wr, gr, px).max() < 0.5, kw
+        assert np.abs(wr[:, 14] - gr[:, 14]).max() < 0.05 and np.abs(wp[:, 10] - gp[:, 10]).max() < 0.05, kw
+        assert np.array_equal(gt, tilts)
+    # and it did refine: closer to the truth than the start
+    cc = CspCfg.make(CSP_PARTICLES, tol_angle=(8, 8, 8), tol_shift=4.0)
+    gr, gp, _ = g.csp_refine(cfg, cc, imgs, rows2, p2, tilts)
+    assert _particle_angle_err(gp, parts).mean() < 0.4 * _particle_angle_err(p2, parts).mean()
+    assert np.linalg.norm(gp[:, 1:4] - parts[:, 1:4], axis=1).max() < 0.35
+    assert np.array_equal(gr, g.csp_refine(cfg, cc, imgs, rows2, p2, tilts)[0])            # deterministic
+
+
+def test_micrograph_mode_matches_oracle(series):
+    n, px, vol, imgs, rows, parts, tilts, cfg, g, o, O = series
+    rng = np.random.default_rng(5)
+    t2 = tilts.copy()
+    t2[:, 4] += rng.normal(0, 0.8, len(t2)); t2[:, 5] += rng.normal(0, 0.6, len(t2)); t2[:, 2:4] += rng.normal(0, 1.0, (len(t2), 2))
+    rows2 = synth.csp_rows_from_params(rows, parts, tilts, parts, t2)
+    for kw in (dict(), dict(refine_rotation=0), dict(first=3, last=6)):
+        cm = CspCfg.make(CSP_MICROGRAPHS, tol_angle=(3, 3, 0), tol_shift=4.0, **kw)
+        wr, wp, wt, _ = O.csp_refine(o, cfg, cm, imgs, rows2, parts, t2)
+        gr, gp, gt = g.csp_refine(cfg, cm, imgs, rows2, parts, t2)
+        assert np.abs(wt[:, 4:6] - gt[:, 4:6]).max() < 0.1 and np.abs(wt[:, 2:4] - gt[:, 2:4]).max() < 0.5, kw
+        assert synth.angular_error_deg(wr, gr).max() < 0.1 and synth.shift_error_px(wr, gr, px).max() < 0.5, kw
+        assert np.abs(wr[:, 14] - gr[:, 14]).max() < 0.05
+        assert np.array_equal(gp[:, :10], parts[:, :10])
+    cm = CspCfg.make(CSP_MICROGRAPHS, refine_rotation=0, tol_shift=4.0)
+    _, _, gt = g.csp_refine(cfg, cm, imgs, rows2, parts, t2)
+    t_ref = tilts.copy(); t_ref[:, 4:6] = t2[:, 4:6]
+    assert np.linalg.norm(gt[:, 2:4] - tilts[:, 2:4], axis=1).mean() < 0.5 * np.linalg.norm(t2[:, 2:4] - tilts[:, 2:4], axis=1).mean()
+
+
+def test_csp_errors_are_loud(series):
+    from pyp_amd import lib
+    n, px, vol, imgs, rows, parts, tilts, cfg, g, o, O = series
+    bad = rows.copy(); bad[3, 26] = 999
+    with pytest.raises(lib.PpmError, match="ERROR"):
+        g.csp_refine(cfg, CspCfg.make(CSP_PARTICLES), imgs, bad, parts, tilts)
+    with pytest.raises(lib.PpmError, match="ERROR"):
+        g.csp_refine(cfg, CspCfg.make(7), imgs, rows, parts, tilts)
+
+
+def test_csp_executable_extracts_then_refines_like_the_caller_drives_it(tmp_path):
+    """The argv of create_csp_split_commands (local_run.py:364-376, :451-463): mode -2 per particle range into per-range
+    stacks (merged like mrc.merge_fast), then mode 5 over particle ranges and mode 6 over tilts; the range outputs are
+    merged like merge_alignment_parameters does (particle_cspt.py:96-138) and match the library called directly."""
+    from pyp_amd import host
+    n, px = 64, 2.0
+    vol, stack, rows, parts, tilts = synth.make_tilt_series(n, 6, np.arange(-48, 49, 16.0), pixel=px, snr=0.3)
+    series_img, rows = synth.paste_tilt_series(stack, rows, len(tilts), (256, 512))
+    p2 = _perturb_particles(parts)
+    rows2 = synth.csp_rows_from_params(rows, parts, tilts, p2, tilts)
+    (tmp_path / "frealign" / "maps").mkdir(parents=True)
+    scratch = tmp_path / "scratch"; scratch.mkdir()
+    mrc.write(series_img, str(tmp_path / "frealign" / "ts.mrc"), pixel_size=px)
+    mrc.write(vol, str(scratch / "tomo_frames_CSP_01.mrc"), pixel_size=px)
+    par, ext = "frealign/maps/ts_r01_02.cistem", "frealign/maps/ts_r01_02_extended.cistem"
+    cistem.write_parameters(str(tmp_path / par), rows2)
+    cistem.write_extended(str(tmp_path / ext), p2, tilts)
+    (tmp_path / ".pyp_config.toml").write_text(
+        'data_set = "tomo"\nscope_pixel = 2.0\ndata_bin = 1\nextract_bin = 1\nextract_box = 64\nparticle_rad = 51.2\nparticle_mw = 300\n'
+        'refine_iter = 2\nrefine_rlref = 0.0\nrefine_rhref = "5.3333333:4"\nrefine_fboost = false\ncsp_UseImagesForRefinementMin = 0\n'
+        'csp_UseImagesForRefinementMax = -1\ncsp_ToleranceParticlesPsi = 8.0\ncsp_ToleranceParticlesTheta = 8.0\ncsp_ToleranceParticlesPhi = 8.0\n'
+        'csp_ToleranceParticlesShifts = 8.0\ncsp_ToleranceMicrographTiltAngles = 1.5\ncsp_ToleranceMicrographTiltAxisAngles = 1.0\n'
+        'csp_ToleranceMicrographShifts = 8.0\ncsp_OptimizerStepTolerance = 0.01\nreconstruct_norm = true\nrefine_invert = false\n')
+    env = dict(os.environ, PYP_SCRATCH=str(scratch))
+
+    def csp(*args, log="csp.log"):
+        cmd = f"{BIN}/csp {' '.join(str(a) for a in args)} >> {log} 2>&1"
+        return subprocess.run(cmd, shell=True, cwd=tmp_path, env=env).returncode
+
+    # ---- mode -2 over two particle ranges, stacks concatenated in range order
+    assert csp(par, ext, -2, 0, 2, 1, "frealign/ts.mrc", "frealign/ts_stack_0000_0002.mrc") == 0
+    assert csp(par, ext, -2, 3, 5, 1, "frealign/ts.mrc", "frealign/ts_stack_0003_0005.mrc") == 0
+    a, b = mrc.read(str(tmp_path / "frealign/ts_stack_0000_0002.mrc")), mrc.read(str(tmp_path / "frealign/ts_stack_0003_0005.mrc"))
+    merged = np.concatenate([a, b])
+    assert merged.shape == stack.shape
+    cc = np.array([np.corrcoef(merged[j].ravel(), stack[j].numpy().ravel())[0, 1] for j in range(len(merged))])
+    assert cc.min() > 0.999                                             # the pasted projections come back (re-normalised)
+    mrc.write(merged, str(tmp_path / "frealign/ts_stack.mrc"), pixel_size=px)
+    # ---- mode 5 (particles) over two ranges, merged like the caller
+    assert csp(par, ext, 5, 0, 2, 1, "frealign/ts.mrc", "frealign/ts_stack.mrc") == 0
+    assert csp(par, ext, 5, 3, 5, 1, "frealign/ts.mrc", "frealign/ts_stack.mrc") == 0
+    log = (tmp_path / "csp.log").read_text()
+    assert log.count("CSP: Normal termination") == 4 and "ERROR" not in log
+    outs = sorted(str(p) for p in (tmp_path / "frealign/maps").glob("ts_r01_02_??????_??????.cistem"))
+    assert [os.path.basename(o) for o in outs] == ["ts_r01_02_000000_000002.cistem", "ts_r01_02_000003_000005.cistem"]
+    rows_m = cistem.merge_parameters(outs)
+    assert rows_m.shape == rows2.shape and np.array_equal(rows_m[:, 0], rows2[:, 0])
+    pm = p2.copy()
+    for o in outs:
+        e = cistem.read_extended(o.replace(".cistem", "_extended.cistem"))
+        assert np.allclose(e["tilts"], tilts, atol=1e-4)
+        for r in e["particles"]:
+            pm[int(r[0])] = r
+    cfg = RefineCfg.make(box=n, pixel_size=px, molecular_mass_kda=300, mask_radius=51.2, res_high=5.3333333, res_signed_cc=30.0, global_search=0)
+    gr, gp, _ = host.Reference(vol, n / 2).csp_refine(cfg, CspCfg.make(CSP_PARTICLES, tol_angle=(8, 8, 8), tol_shift=4.0), merged, rows2, p2, tilts)
+    assert _particle_angle_err(pm, gp).max() < 0.05 and np.abs(pm[:, 1:4] - gp[:, 1:4]).max() < 0.05      # float32 files, re-normalised boxes
+    assert synth.angular_error_deg(rows_m, gr).max() < 0.05
+    assert _particle_angle_err(pm, parts).mean() < 0.5 * _particle_angle_err(p2, parts).mean()
+    # ---- mode 6 (tilts), one job per tilt like the caller (first = last = scanning-order index); merged over the original
+    cistem.write_parameters(str(tmp_path / par), rows_m)
+    cistem.write_extended(str(tmp_path / ext), pm, tilts)
+    for f in outs:
+        os.remove(f); os.remove(f.replace(".cistem", "_extended.cistem"))
+    for t in range(len(tilts)):
+        assert csp(par, ext, 6, t, t, 1, "frealign/ts.mrc", "frealign/ts_stack.mrc", log="csp6.log") == 0
+    outs = sorted(str(p) for p in (tmp_path / "frealign/maps").glob("ts_r01_02_??????_??????.cistem"))
+    assert len(outs) == len(tilts)
+    rows_t = cistem.merge_parameters(outs)
+    assert rows_t.shape == rows2.shape and np.array_equal(rows_t[:, 0], rows2[:, 0])
+    for o in outs:
+        e = cistem.read_extended(o.replace(".cistem", "_extended.cistem"))
+        assert len(e["tilts"]) == 1 and len(e["particles"]) == len(parts)
+    assert rows_t[:, 14].mean() >= rows_m[:, 14].mean() - 1e-3
+    # unsupported mode
+    assert csp(par, ext, 4, 0, 0, 1, "frealign/ts.mrc", "frealign/ts_stack.mrc", log="csp4.log") != 0
+    assert "ERROR" in (tmp_path / "csp4.log").read_text()
