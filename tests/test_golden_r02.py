@@ -58,13 +58,12 @@ def test_automatic_cutoff_and_tomo_rules():
     tilt = np.tile(tl, npart)
     good = np.repeat(np.arange(npart) >= 10, len(tl))
     rows[:, 14] = np.where(good, 20.0, 8.0) + rng.normal(0, 0.5, len(rows)) - 0.1 * np.abs(tilt)
-    out = select.select_particles(rows, threshold=0.75, tilt_angles=tilt)
+    out = select.select_particles(rows, threshold=0.7, tilt_angles=tilt)
     occ = out[:, 11].reshape(npart, len(tl))
-    # the cut sits at sorted(particle means)[int(39 * 0.25)] = the best of the ten junk particles, which therefore stays:
-    # whole particles go (nine of them), no row of a good particle is touched, high tilts included
+    # the cut sits at sorted(particle means over |tilt| <= 12)[int(39 * 0.3)] = among the good particles: every junk particle
+    # goes as a whole, high tilts included; a good particle is kept or dropped as a whole too
     gone = (occ == 0).all(axis=1)
-    assert gone[:10].sum() == 9 and not gone[10:].any() and ((occ == 0) | (occ == 100)).all() and (occ[10:] == 100).all()
-    assert ((occ == 0).any(axis=1) == gone).all()
+    assert gone[:10].all() and gone[10:].sum() <= 3 and ((occ == 0) | (occ == 100)).all() and ((occ == 0).any(axis=1) == gone).all()
     out = select.select_particles(rows, threshold=1.0, tilt_angles=tilt, mintilt=-30, maxtilt=30)
     assert ((out[:, 11] > 0) == (np.abs(tilt) <= 30)).all()
 
