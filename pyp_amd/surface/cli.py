@@ -311,6 +311,12 @@ def format_stats_table(stats):
     return lines
 
 
+def format_statistics_rows(stats):
+    """Rows of <name>_statistics.txt: 7 x %14.5f, what numpy.savetxt writes when the reference rewrites the file
+    (src/pyp/postprocess/core.py:219-221; pinned by tests/golden/golden_r02.json)."""
+    return "".join("%14.5f%14.5f%14.5f%14.5f%14.5f%14.5f%14.5f\n" % tuple(s) for s in stats)
+
+
 def merge3d_main(argv=None, stdin=None):
     t0 = time.time()
     try:
@@ -338,8 +344,7 @@ def merge3d_main(argv=None, stdin=None):
     mrc.write(filt, d["filtered"], pixel_size=pixel)
     with open(d["statistics"], "w") as f:
         f.write("C  NO.   RESOL  RING RAD       FSC  Part_FSC Part_SSNR  Rec_SSNR\n")
-        for s in stats:
-            f.write("%14.5f%14.5f%14.5f%14.5f%14.5f%14.5f%14.5f\n" % tuple(s))
+        f.write(format_statistics_rows(stats))
     print(f"\nParticles: {counts[0]} (map 1) + {counts[1]} (map 2); finalised in {time.time() - t0:.1f} s\n")
     print("   NO.   RESOL  RING RAD       FSC  Part_FSC Part_SSNR  Rec_SSNR")
     for line in format_stats_table(stats):

@@ -81,9 +81,5 @@ def test_statistics_file_format_matches_reference_writer(tmp_path):
     """merge3d's <name>_statistics.txt rows = numpy.savetxt(fmt 7 x %14.5f) as the reference rewrites the file
     (src/pyp/postprocess/core.py:219-221)."""
     st = np.array(GOLD["statistics_txt"]["input"])
-    text = "".join("%14.5f%14.5f%14.5f%14.5f%14.5f%14.5f%14.5f\n" % tuple(r) for r in st)
-    assert text == GOLD["statistics_txt"]["text"]
-    src = open(cli.__file__).read()
-    assert '"%14.5f%14.5f%14.5f%14.5f%14.5f%14.5f%14.5f\\n" % tuple(s)' in src          # the line merge3d_main writes
-    back = np.loadtxt(os.path.join(tmp_path, "x.txt") if False else __import__("io").StringIO(GOLD["statistics_txt"]["text"]), comments=["C"])
-    assert back.shape == st.shape
+    assert cli.format_statistics_rows(st) == GOLD["statistics_txt"]["text"]
+    assert np.loadtxt(__import__("io").StringIO(GOLD["statistics_txt"]["text"]), comments=["C"]).shape == st.shape
