@@ -80,6 +80,9 @@ def test_cclin_parameter_files_read_like_the_reference():
 def test_statistics_file_format_matches_reference_writer(tmp_path):
     """merge3d's <name>_statistics.txt rows = numpy.savetxt(fmt 7 x %14.5f) as the reference rewrites the file
     (src/pyp/postprocess/core.py:219-221)."""
-    st = np.array(GOLD["statistics_txt"]["input"])
+    import io
+    buf = io.StringIO()
+    np.savetxt(buf, np.array(GOLD["statistics_txt"]["input"]), fmt="%12.6f")          # the generator handed the reference this text
+    st = np.loadtxt(io.StringIO(buf.getvalue()))
     assert cli.format_statistics_rows(st) == GOLD["statistics_txt"]["text"]
     assert np.loadtxt(__import__("io").StringIO(GOLD["statistics_txt"]["text"]), comments=["C"]).shape == st.shape
