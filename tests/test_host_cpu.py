@@ -133,5 +133,5 @@ def test_score_selection_rules():
     assert np.array_equal(s[:, 11] > 0, (rows[:, 14] >= lo + 0.1 * (hi - lo)) & (rows[:, 14] <= hi - 0.1 * (hi - lo)))
     g = select.select_particles(rows, threshold=0.5, angles=3, defocuses=2)          # grouped thresholds keep roughly half
     assert 0.3 < (g[:, 11] > 0).mean() < 0.8
-    with pytest.raises(ValueError):
-        select.select_particles(rows, threshold=0)
+    auto = select.select_particles(rows, threshold=0)          # reconstruct_cutoff = 0: the bimodal automatic threshold
+    assert auto.shape == rows.shape and 0 < (auto[:, 11] > 0).sum() <= len(rows)
