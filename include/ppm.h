@@ -115,6 +115,13 @@ typedef struct ppm_recon_cfg {
     int invert;
     int split_by_pind;      /* 1: half = PIND parity, 0: half = POSITION_IN_STACK parity */
     float mask_radius;      /* outer radius for the normalisation statistics, Angstrom */
+    /* data-driven dose weighting (the five-line answer of frealign.py:1731-1753): a row of exposure t = TIND is attenuated by
+     * q_t ^ (dose_exponent min(1, (s / (dose_transition s_Nyquist))^2)), q_t = dose_weights[t] in (0, 1] (the exposure's mean
+     * score over the best exposure's, src/pyp/inout/metadata/core.py:3039-3075); exposures beyond the table or with
+     * q <= 0 are not attenuated.  NULL / 0 = off. */
+    const float *dose_weights; int n_dose_weights;
+    float dose_exponent;    /* "fraction" answer (x frames per exposure when "multiply" is yes); larger = fewer exposures at high resolution */
+    float dose_transition;  /* fraction of Nyquist at which the full attenuation is reached (0 = 1) */
 } ppm_recon_cfg;
 
 typedef struct ppm_final_cfg {

@@ -866,6 +866,13 @@ int orc_insert_batch(float *acc, long *counts, const ppm_recon_cfg *cfg, const c
             double w = row[PPM_OCC] / 100.0;
             if (cfg->score_weight_bfactor != 0)
                 w *= exp(-0.25 * cfg->score_weight_bfactor * (cfg->score_average - row[PPM_SCORE]) * k2 / na2);
+            if (cfg->dose_weights && cfg->n_dose_weights > 0 && cfg->dose_exponent > 0) {
+                /* data-driven dose weighting (frealign.py:1731-1753): exposure t = TIND attenuated by q_t^(F min(1, (s / (tr s_Nyq))^2)) */
+                long t = (long)row[PPM_TIND];
+                double dq = (t >= 0 && t < cfg->n_dose_weights) ? cfg->dose_weights[t] : 0.0;
+                double tr = cfg->dose_transition > 0 && cfg->dose_transition <= 1 ? cfg->dose_transition : 1.0, cap2 = (tr * N / 2) * (tr * N / 2);
+                if (dq > 0 && dq < 1) w *= exp(cfg->dose_exponent * log(dq) * (k2 < cap2 ? k2 : cap2) / cap2);
+            }
             double ph = 2.0 * ORC_PI * (kx * sx + ky * sy) / N, cr = cos(ph), ci = sin(ph);
             const cpx *iv = &I[(size_t)(ky + g.B) * g.W + kx];
             double vr = w * cv * (iv->re * cr - iv->im * ci), vi = w * cv * (iv->re * ci + iv->im * cr), vw = w * cv * cv;

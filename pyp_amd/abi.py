@@ -43,7 +43,18 @@ class ReconCfg(C.Structure):
         ("box", C.c_int), ("pixel_size", C.c_float), ("res_limit", C.c_float),
         ("score_weight_bfactor", C.c_float), ("score_average", C.c_float), ("score_threshold", C.c_float),
         ("normalize", C.c_int), ("invert", C.c_int), ("split_by_pind", C.c_int), ("mask_radius", C.c_float),
+        ("dose_weights", C.c_void_p), ("n_dose_weights", C.c_int), ("dose_exponent", C.c_float), ("dose_transition", C.c_float),
     ]
+
+    def set_dose_weights(self, q, exponent, transition=1.0):
+        """q[t] in (0, 1] per exposure (TIND); the array is kept alive on the struct."""
+        import numpy as np
+        self._dose = np.ascontiguousarray(q, dtype=np.float32)
+        self.dose_weights = self._dose.ctypes.data_as(C.c_void_p)
+        self.n_dose_weights = int(self._dose.size)
+        self.dose_exponent = float(exponent)
+        self.dose_transition = float(transition)
+        return self
 
 
 NPCOL, NTCOL = 12, 6

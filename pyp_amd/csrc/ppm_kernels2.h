@@ -499,6 +499,7 @@ struct PartIns {       // per-particle constants, written by k_insert_params
     float m[6];        // X = m0 kx + m1 ky, Y = m2 kx + m3 ky, Z = m4 kx + m5 ky
     CtfP ctf;
     float sx, sy, w0, wexp;   // shifts (px), occupancy weight, exponent coefficient of the score weighting (per k^2)
+    float dexp, dcap2;        // dose weighting: weight x exp(dexp min(k^2, dcap2)) (dexp <= 0; 0 = off)
     int half, valid;
 };
 
@@ -518,7 +519,8 @@ struct InsertBrickP {
 };
 
 __global__ void k_insert_params(const double *rows, PartIns *pp, CullEnt *cull, const float *symops, int nsym, int n, int N, double a, double bfac,
-                                double score_avg, double score_thr, int split_by_pind, double r2, unsigned long long *counts, unsigned *maxima) {
+                                double score_avg, double score_thr, int split_by_pind, double r2, unsigned long long *counts, unsigned *maxima,
+                                const float *dose_q, int n_dose, float dose_exponent, float dose_cap2) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const double *row = rows + (size_t)i * PPM_NCOL;
@@ -533,6 +535,12 @@ __global__ void k_insert_params(const double *rows, PartIns *pp, CullEnt *cull, 
     q.sx = (float)(row[PPM_XSHIFT] / a); q.sy = (float)(row[PPM_YSHIFT] / a);
     q.w0 = (float)(occ / 100.0);
     q.wexp = (float)(-0.25 * bfac * (score_avg - scr)) * q.ctf.inv_na2;
+    q.dexp = 0.f; q.dcap2 = dose_cap2;
+    if (dose_q) {
+        const long t = (long)row[PPM_TIND];
+        const float dq = (t >= 0 && t < n_dose) ? dose_q[t] : 0.f;
+        if (dq > 0.f && dq < 1.f) q.dexp = dose_exponent * logf(dq) / dose_cap2;
+    }
     pp[i] = q;
     for (int so = 0; so < nsym; so++) {
         const float *S = symops + so * 9;
@@ -639,7 +647,8 @@ __global__ void __launch_bounds__(NW * 64) k_insert_bricks(InsertBrickP P) {
             const int x0 = (int)xf - x_lo, y0 = (int)yf - y_lo, z0 = (int)zf - z_lo;      // brick-local base tap
             const float fx = X - xf, fy = Y - yf, fz = Z - zf;
             const float cv = ctf_eval_fast(q.ctf, kx, ky);
-            const float w = q.w0 * (q.wexp != 0.f ? expf(q.wexp * k2) : 1.f);
+            float w = q.w0 * (q.wexp != 0.f ? expf(q.wexp * k2) : 1.f);
+            if (q.dexp != 0.f) w *= expf(q.dexp * fminf(k2, q.dcap2));
             float rev = (kx * q.sx + ky * q.sy) / (float)N; rev -= floorf(rev);
             const float sn = __sinf(6.283185307179586f * rev), cs = __cosf(6.283185307179586f * rev);
             const float2 iv = P.band[((size_t)p * P.H + (ky + B)) * W + kx];

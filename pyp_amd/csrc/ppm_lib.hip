@@ -158,7 +158,7 @@ struct ppm_accum {
     unsigned long long *d_counts = nullptr;
     unsigned *d_max = nullptr;       // chunk maxima for the fixed-point scales of k_insert_bricks
     long counts[2] = { 0, 0 };
-    DevBuf<double> rows; DevBuf<float> images; DevBuf<float2> band; DevBuf<PartIns> pp; DevBuf<CullEnt> cull; DevBuf<BrickItem> items;
+    DevBuf<double> rows; DevBuf<float> images, dose; DevBuf<float2> band; DevBuf<PartIns> pp; DevBuf<CullEnt> cull; DevBuf<BrickItem> items;
     std::vector<float> brick_load; float load_r = -1.f; int n_items = 0, items_cap = -1;
 };
 
@@ -694,7 +694,7 @@ void ppm_accum_destroy(ppm_accum_t *a) {
     if (a->d_sym) (void)hipFree(a->d_sym);
     if (a->d_counts) (void)hipFree(a->d_counts);
     if (a->d_max) (void)hipFree(a->d_max);
-    a->rows.release(); a->images.release(); a->band.release(); a->pp.release(); a->cull.release(); a->items.release();
+    a->rows.release(); a->images.release(); a->dose.release(); a->band.release(); a->pp.release(); a->cull.release(); a->items.release();
     delete a;
 }
 
@@ -715,6 +715,15 @@ int ppm_insert_batch(ppm_accum_t *a, const ppm_recon_cfg *cfg, const void *image
     if (int r = a->rows.ensure((size_t)CH * PPM_NCOL)) return r;
     if (!images_on_device) if (int r = a->images.ensure((size_t)2 * CH * NN)) return r;       // double-buffered staging
     if (int r = a->band.ensure((size_t)CH * HW)) return r;
+    const float *d_dose = nullptr;
+    float dose_cap2 = 1.f;
+    if (cfg->dose_weights && cfg->n_dose_weights > 0 && cfg->dose_exponent > 0) {
+        if (int r = a->dose.ensure(cfg->n_dose_weights)) return r;
+        HIPCHK(hipMemcpyAsync(a->dose.p, cfg->dose_weights, (size_t)cfg->n_dose_weights * sizeof(float), hipMemcpyHostToDevice, g.stream));
+        d_dose = a->dose.p;
+        const float tr = cfg->dose_transition > 0 && cfg->dose_transition <= 1 ? cfg->dose_transition : 1.f;
+        dose_cap2 = (tr * gm.N / 2) * (tr * gm.N / 2);
+    }
     if (!images_on_device) {
         HIPCHK(hipMemcpyAsync(a->images.p, images, (size_t)std::min(CH, n_img) * NN * sizeof(float), hipMemcpyHostToDevice, g.copy));
         HIPCHK(hipStreamSynchronize(g.copy));
@@ -735,7 +744,7 @@ int ppm_insert_batch(ppm_accum_t *a, const ppm_recon_cfg *cfg, const void *image
         if (int r = a->cull.ensure((size_t)nb * a->nsym)) return r;
         hipLaunchKernelGGL(k_insert_params, dim3((nb + 255) / 256), dim3(256), 0, g.stream, a->rows.p, a->pp.p, a->cull.p, a->d_sym, a->nsym, nb, gm.N, (double)cfg->pixel_size,
                            (double)cfg->score_weight_bfactor, (double)cfg->score_average, (double)cfg->score_threshold, cfg->split_by_pind,
-                           gm.r_hi * gm.r_hi, a->d_counts, a->d_max);
+                           gm.r_hi * gm.r_hi, a->d_counts, a->d_max, d_dose, cfg->n_dose_weights, cfg->dose_exponent, dose_cap2);
         const int BE = gm.N >= 128 ? 16 : 8;
         if (int r = build_brick_items(a, gm, BE, nb)) return r;
         InsertBrickP IP;

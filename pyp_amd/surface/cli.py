@@ -216,7 +216,7 @@ def reconstruct3d_main(argv=None, stdin=None):
     print("\n        **   Welcome to Reconstruct3D (MI355X / libpypmatch)   **\n")
     for k, v in d.items():
         print(f"{k:28s}: {v}")
-    _unsupported(d, [("dose_weighting", True), ("crop", True), ("center_mass", True), ("likelihood_blurring", True),
+    _unsupported(d, [("crop", True), ("center_mass", True), ("likelihood_blurring", True),
                      ("threshold_reference", True), ("exclude_edges", True), ("split_even_odd", False), ("dump", False)], "reconstruct3d")
     if abs(d["padding"] - 1.0) > 1e-6:
         _die("ERROR: reconstruct3d: only padding factor 1 is supported")
@@ -246,6 +246,18 @@ def reconstruct3d_main(argv=None, stdin=None):
     rc = ReconCfg(box=box, pixel_size=px, res_limit=d["res_limit"], score_weight_bfactor=d["score_bfactor"] if d["score_weighting"] else 0.0,
                   score_average=score_avg, score_threshold=d["score_threshold"], normalize=int(d["normalize"]), invert=int(d["invert"]),
                   split_by_pind=int(d["per_particle_splitting"]), mask_radius=d["outer_radius"])
+    if d["dose_weighting"]:
+        # the five-line answer (frealign.py:1731-1753): external per-exposure weights or the ones this parameter file gives
+        # (src/pyp/inout/metadata/core.py:3039-3075); side files weights.txt / scores.txt for the caller's plots
+        from .. import dose
+        wf = d["dose_weights_file"]
+        gw = dose.read_global_weights(wf) if (wf != "/scratch/not_provided" and os.path.exists(wf)) else dose.compute_global_weights(rows)
+        frames = max(1, len(np.unique(rows[:, C["FIND"]]))) if d["dose_multiply"] else 1
+        q = dose.normalised(gw)
+        rc.set_dose_weights(q, d["dose_fraction"] * frames, d["dose_transition"])
+        dose.write_weights_txt("weights.txt", q, box, d["dose_fraction"] * frames, d["dose_transition"])
+        dose.write_scores_txt("scores.txt", gw)
+        print(f"dose weighting: {int((q > 0).sum())} exposures, exponent {d['dose_fraction'] * frames:g}, transition {d['dose_transition']:g}")
     from .. import host, lib
     dev = int(os.environ.get("PPM_DEVICE", "0"))
     try:

@@ -199,6 +199,37 @@ def test_in_memory_iterations_improve_the_map():
     assert it2["stats"][10, 3] >= it1["stats"][10, 3] - 0.02                      # FSC at shell 11
 
 
+def test_reconstruct3d_with_dose_weighting_writes_the_side_files(project):
+    """The five-line dose-weighting answer (frealign.py:1731-1753) is honoured: weights.txt / scores.txt appear next to the
+    dumps (particle_cspt.py:808-810 plots them) and the dump differs from the unweighted one."""
+    d, vol, imgs, truth, start = project
+    used = truth.copy()
+    used[:, cistem.COL["TIND"]] = np.arange(M) % 5
+    used[:, cistem.COL["SCORE"]] = 25.0 - 4.0 * used[:, cistem.COL["TIND"]]
+    cistem.write_parameters(str(d / "dw_r01_used.cistem"), used)
+    from pyp_amd.surface import cli as pcli
+
+    def script(dose, tag):
+        lines = ["p_stack.mrc", "dw_r01_used.cistem", "null", "p_r01.mrc", "dw_map1.mrc", "dw_map2.mrc", "output.mrc", f"dw_r01_n1.res", "C1", 1, M, PX, 300, 0,
+                 PX * N / 2, 2 * PX, 0, 2.0, "no", 0, -1] + dose + [0, 1, 1, "yes", "no", "no", "no", "no", "yes", "no", "no", "no", "no", "yes",
+                 f"{d}/dw{tag}_map1_n1.mrc", f"{d}/dw{tag}_map2_n1.mrc", 1]
+        return "\n".join(str(x) for x in lines) + "\n"
+    for f in ("weights.txt", "scores.txt"):
+        if (d / f).exists():
+            os.remove(d / f)
+    assert run("reconstruct3d", script(["no"], "a"), d, "rec_dw.log") == 0 and not (d / "weights.txt").exists()
+    assert run("reconstruct3d", script(["yes", "/scratch/not_provided", "yes", 4, 0.75], "b"), d, "rec_dw.log") == 0
+    log = open(d / "rec_dw.log").read()
+    assert log.count("Reconstruct3D: Normal termination") == 2 and "ERROR" not in log and "dose weighting: 5 exposures" in log
+    A = np.loadtxt(str(d / "weights.txt"))
+    assert A.shape[0] == 5 * (N + 1) * (N // 2) and A.max() <= 1.0 + 1e-6 and A.min() > 0
+    sc = np.loadtxt(str(d / "scores.txt"))
+    assert np.allclose(sc, np.array([25.0, 21.0, 17.0, 13.0, 9.0]) / 25.0, atol=1e-5)
+    a = pcli.read_dump(str(d / "dwa_map1_n1.mrc"))[3]; b = pcli.read_dump(str(d / "dwb_map1_n1.mrc"))[3]
+    wa, wb = a.reshape(-1, 3)[:, 2].sum(), b.reshape(-1, 3)[:, 2].sum()
+    assert 0.3 * wa < wb < 0.95 * wa                                        # weaker exposures weigh less at high resolution
+
+
 def test_refine3d_verbatim_default_script_matches_oracle(tmp_path):
     """The script exactly as PYP's default iteration writes it (tests/test_surface_cpu.py:REFINE_CISTEM: global = yes,
     local = no, 20 hits to refine, D7, 143 particles; frealign.py:3866-3871, :3918-3994) fed through the shell; the

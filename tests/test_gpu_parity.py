@@ -354,6 +354,28 @@ def test_insertion_and_finalise_match_oracle(H, O, sym):
     assert np.abs(ws[:, 3:5] - gs[:, 3:5]).max() < 1e-4                  # FSC, part-FSC
 
 
+def test_dose_weighted_insertion_matches_oracle(H, O):
+    """Data-driven dose weighting (the five-line reconstruct3d answer, frealign.py:1731-1753): per-exposure attenuation by TIND."""
+    n, px, m = 64, 2.0, 36
+    vol, imgs, rows = dataset(n, m, px, 0.2)
+    rows[:, 27] = np.arange(m) % 6
+    rows[:, 14] = 30.0 - 4.0 * rows[:, 27]
+    from pyp_amd import dose
+    q = dose.normalised(dose.compute_global_weights(rows))
+    rc = ReconCfg(box=n, pixel_size=px, res_limit=2 * px, normalize=1, invert=0, split_by_pind=0, mask_radius=0.4 * n * px)
+    rc.set_dose_weights(q, 4.0, 0.75)
+    acc = np.zeros(O.accum_floats(n), dtype=np.float32)
+    counts = np.zeros(2, dtype=np.int64)
+    O.insert_batch(acc, counts, rc, "C1", imgs, rows)
+    ga = H.Accumulator(n, px, "C1")
+    ga.insert(rc, imgs, rows)
+    got = ga.download()
+    assert ga.counts() == list(counts) and np.linalg.norm(got - acc) / np.linalg.norm(acc) < 1e-4
+    plain = H.Accumulator(n, px, "C1")
+    plain.insert(ReconCfg(box=n, pixel_size=px, res_limit=2 * px, normalize=1, invert=0, split_by_pind=0, mask_radius=0.4 * n * px), imgs, rows)
+    assert np.linalg.norm(plain.download() - acc) / np.linalg.norm(acc) > 0.05        # the weighting is not a no-op
+
+
 def test_insertion_non_power_of_two_box(H, O):
     n, px, m = 96, 1.5, 16
     vol, imgs, rows = dataset(n, m, px, 0.2)
