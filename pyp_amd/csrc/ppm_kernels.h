@@ -106,8 +106,10 @@ struct PrepP {
 
 // PT = 512 threads and <= 80 KB of LDS: two blocks per CU, so that one block's global-memory waits (image reads, the
 // spilled half spectrum) overlap the other's FFT work; PT = 1024 / 160 KB is kept for comparison (PPM_PREP_PT).
-template <int PT>
-__global__ void __launch_bounds__(PT) k_prep(PrepP P) {
+// MINW = waves per SIMD the register allocation has to leave room for: 4 with PT = 512 makes two blocks per CU resident
+// (128 VGPRs, some spills), 1 lets the compiler keep everything in registers (one block per CU)
+template <int PT, int MINW>
+__global__ void __launch_bounds__(PT, MINW) k_prep(PrepP P) {
     constexpr int PW = PT / 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, N = P.N, B = P.B, W = P.W, H = P.H;

@@ -230,8 +230,14 @@ static int launch_prep(const float *d_images, const double *d_rows, int n_img, c
     // LDS plan: L row pairs per row pass (L N <= 8 x threads: the next pass is prefetched into <= 8 register pairs per
     // thread; L divides N/2) share their storage with the nc columns of one column chunk; the whole half spectrum goes
     // through a global scratch between the two phases.  512 threads / 80 KB -> two blocks per CU.
-    const int PT = (getenv("PPM_PREP_PT") && atoi(getenv("PPM_PREP_PT")) == 1024) ? 1024 : 512;
-    const size_t budget = (PT == 1024 ? 160 : 80) * 1024;
+    // Block shape (A/B on one box, 100 k x 256^2 insertion workload, us per particle): 512 threads / 80 KB (233 VGPRs: ONE block per
+    // CU resident) 0.456; 512 threads held to 128 VGPRs for two blocks 0.646 (spills); 1024 threads / 160 KB 0.69; 256 threads /
+    // 52 KB at 233 VGPRs (two blocks) 0.399; 256 threads / 40 KB held to 168 VGPRs (three blocks, 252 B of scratch) 0.376 <- default.
+    // The FFT stages are barrier-bound: several small independent blocks overlap each other's barrier waits.
+    int PT = 256;
+    if (const char *e = getenv("PPM_PREP_PT")) { const int v = atoi(e); if (v == 512 || v == 1024 || v == 256) PT = v; }
+    const int occ3 = !(getenv("PPM_PREP_OCC") && atoi(getenv("PPM_PREP_OCC")) == 2);
+    const size_t budget = (PT == 1024 ? 160 : (PT == 256 ? (getenv("PPM_PREP_LDS") ? atoi(getenv("PPM_PREP_LDS")) : (occ3 ? 40 : 52)) : 80)) * 1024;
     const size_t lds_fixed = (size_t)(gm.B + 2) * 16 + 16 + 5 * (PT / 64) * sizeof(double) + (4 + PT / 64) * sizeof(float) + (size_t)gm.N * 12 + 16;
     P.fast256 = (gm.N == 256 && !getenv("PPM_PREP_GENERIC")) ? 1 : 0;
     P.TS = P.fast256 ? 273 : gm.N + 1; P.WS = P.fast256 ? 272 : gm.N;
@@ -258,13 +264,20 @@ static int launch_prep(const float *d_images, const double *d_rows, int n_img, c
     if (lds > budget) return fail(-12, "pre-processing kernel: LDS plan exceeds its budget");
     static bool attr_set = false;
     if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute((const void *)k_prep<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        HIPCHK(hipFuncSetAttribute((const void *)k_prep<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *)k_prep<512, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *)k_prep<512, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *)k_prep<1024, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *)k_prep<256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *)k_prep<256, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         attr_set = true;
     }
+    const bool two_blocks = getenv("PPM_PREP_OCC") && atoi(getenv("PPM_PREP_OCC")) == 4;
     ProfScope ps(PPM_K_PREP);
-    if (PT == 512) hipLaunchKernelGGL(k_prep<512>, dim3(n_img), dim3(512), lds, g.stream, P);
-    else hipLaunchKernelGGL(k_prep<1024>, dim3(n_img), dim3(1024), lds, g.stream, P);
+    if (PT == 512 && two_blocks) hipLaunchKernelGGL((k_prep<512, 4>), dim3(n_img), dim3(512), lds, g.stream, P);
+    else if (PT == 512) hipLaunchKernelGGL((k_prep<512, 2>), dim3(n_img), dim3(512), lds, g.stream, P);
+    else if (PT == 256 && occ3) hipLaunchKernelGGL((k_prep<256, 3>), dim3(n_img), dim3(256), lds, g.stream, P);
+    else if (PT == 256) hipLaunchKernelGGL((k_prep<256, 2>), dim3(n_img), dim3(256), lds, g.stream, P);
+    else hipLaunchKernelGGL((k_prep<1024, 1>), dim3(n_img), dim3(1024), lds, g.stream, P);
     HIPCHK(hipGetLastError());
     return 0;
 }
