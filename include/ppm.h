@@ -243,6 +243,10 @@ void *ppm_device_alloc(size_t bytes);
 void ppm_device_free(void *p);
 int ppm_device_upload(void *dst, const void *src, size_t bytes);
 int ppm_device_sync(void);
+/* page-locked host staging memory: uploads from it overlap the kernels of the previous chunk (pageable memory makes them
+ * synchronous); the drop-in executables read their particle ranges from the stack file through two such buffers */
+void *ppm_host_alloc(size_t bytes);
+void ppm_host_free(void *p);
 
 #ifdef __cplusplus
 }

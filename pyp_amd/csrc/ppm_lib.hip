@@ -9,6 +9,7 @@
 #include <cstring>
 #include <functional>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -127,6 +128,17 @@ struct DevBuf {
         return 0;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+// device temporary freed on every exit path (error returns included)
+template <typename T>
+struct DevTmp {
+    T *p = nullptr;
+    DevTmp() = default;
+    DevTmp(const DevTmp &) = delete;
+    DevTmp &operator=(const DevTmp &) = delete;
+    ~DevTmp() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n * sizeof(T)); }
 };
 
 DevBuf<float2> g_prep_spill;     // k_prep: the half spectrum between the row and the column phase, [n][N][W]
@@ -354,6 +366,8 @@ int ppm_profile_get(int id, double *ms, long *n) {
 void *ppm_device_alloc(size_t bytes) { void *p = nullptr; if (hipMalloc(&p, bytes) != hipSuccess) { g_err = "ERROR: device allocation failed"; return nullptr; } return p; }
 void ppm_device_free(void *p) { if (p) (void)hipFree(p); }
 int ppm_device_upload(void *dst, const void *src, size_t bytes) { HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return 0; }
+void *ppm_host_alloc(size_t bytes) { void *p = nullptr; if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { g_err = "ERROR: pinned host allocation failed"; return nullptr; } return p; }
+void ppm_host_free(void *p) { if (p) (void)hipHostFree(p); }
 int ppm_device_sync(void) { if (g.stream) HIPCHK(hipStreamSynchronize(g.stream)); HIPCHK(hipDeviceSynchronize()); return 0; }
 
 // ------------------------------------------------------------------------------ reference
@@ -366,35 +380,36 @@ ppm_ref_t *ppm_reference_create_weighted(const float *vol, int n, float max_band
     int B = (int)std::ceil((double)max_band_px * pad) - 1;
     if (B > np / 2 - 1) B = np / 2 - 1;
     size_t n3 = (size_t)n * n * n, np3 = (size_t)np * np * np;
-    float *d_vol = nullptr; float2 *d_f = nullptr;
-    HIPCHKP(hipMalloc(&d_vol, n3 * sizeof(float)));
-    HIPCHKP(hipMalloc(&d_f, np3 * sizeof(float2)));
+    DevTmp<float> t_vol, t_w; DevTmp<float2> t_f;
+    HIPCHKP(t_vol.alloc(n3));
+    HIPCHKP(t_f.alloc(np3));
+    float *d_vol = t_vol.p; float2 *d_f = t_f.p;
     HIPCHKP(hipMemcpy(d_vol, vol, n3 * sizeof(float), hipMemcpyHostToDevice));
     if (pad > 1) HIPCHKP(hipMemsetAsync(d_f, 0, np3 * sizeof(float2), g.stream));
     float *d_w = nullptr;
     if (ring_weight && n_weight > 0) {
-        HIPCHKP(hipMalloc(&d_w, (size_t)n_weight * sizeof(float)));
+        HIPCHKP(t_w.alloc((size_t)n_weight));
+        d_w = t_w.p;
         HIPCHKP(hipMemcpyAsync(d_w, ring_weight, (size_t)n_weight * sizeof(float), hipMemcpyHostToDevice, g.stream));
     }
-    ppm_ref *r = new ppm_ref();
+    std::unique_ptr<ppm_ref, void (*)(ppm_ref_t *)> guard(new ppm_ref(), ppm_reference_destroy);     // freed on every error return
+    ppm_ref *r = guard.get();
     r->N = n; r->pad = pad; r->B = B; r->CX = B + 2; r->CY = 2 * B + 3;
     size_t cube_n = (size_t)r->CX * r->CY * r->CY;
     r->NBX = (r->CX + 3) / 4; r->NBY = (r->CY + 1) / 2;
     const size_t copy_n = (size_t)r->NBX * r->NBY * r->NBY * 16;         // blocked layout, two copies (ppm_dev.h)
-    if (2 * copy_n >= ((size_t)1 << 32)) { fail(-22, "reference cube too large"); delete r; return nullptr; }
+    if (2 * copy_n >= ((size_t)1 << 32)) { fail(-22, "reference cube too large"); return nullptr; }
     r->LB = (unsigned)copy_n;
-    if (hipMalloc(&r->cube, 2 * copy_n * sizeof(float2)) != hipSuccess) { fail(-12, "out of device memory for the reference cube"); delete r; return nullptr; }
+    if (hipMalloc(&r->cube, 2 * copy_n * sizeof(float2)) != hipSuccess) { r->cube = nullptr; fail(-12, "out of device memory for the reference cube"); return nullptr; }
     HIPCHKP(hipMemsetAsync(r->cube, 0, 2 * copy_n * sizeof(float2), g.stream));
     {
         ProfScope ps(PPM_K_BANK);
         hipLaunchKernelGGL(k_ref_load, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, g.stream, d_vol, d_f, n, np);
-        if (fft3d(d_f, np, false)) { delete r; return nullptr; }
+        if (fft3d(d_f, np, false)) return nullptr;
         hipLaunchKernelGGL(k_ref_crop, dim3((unsigned)((cube_n + 255) / 256)), dim3(256), 0, g.stream, d_f, r->cube, np, n, B, r->CX, r->CY, r->NBX, r->NBY, r->LB, d_w, n_weight);
     }
-    HIPCHKP(hipStreamSynchronize(g.stream));
-    HIPCHKP(hipGetLastError());
-    (void)hipFree(d_vol); (void)hipFree(d_f); if (d_w) (void)hipFree(d_w);
-    return r;
+    if (hipStreamSynchronize(g.stream) != hipSuccess || hipGetLastError() != hipSuccess) { fail(-5, "reference preparation failed on the device"); return nullptr; }
+    return guard.release();
 }
 
 ppm_ref_t *ppm_reference_create_padded(const float *vol, int n, float max_band_px, int pad) { return ppm_reference_create_weighted(vol, n, max_band_px, pad, nullptr, 0); }
@@ -680,14 +695,15 @@ size_t ppm_accum_floats(int box) { return (size_t)2 * box * box * (box / 2 + 1) 
 ppm_accum_t *ppm_accum_create(int box, float pixel_size, const char *symmetry, void *ext) {
     if (!g.inited) { fail(-1, "ppm_init has not been called"); return nullptr; }
     if (!box_ok(box) || !(pixel_size > 0)) { fail(-22, "box must be even, 32..512, with prime factors 2, 3, 5, and the pixel size positive"); return nullptr; }
-    ppm_accum *a = new ppm_accum();
+    std::unique_ptr<ppm_accum, void (*)(ppm_accum_t *)> guard(new ppm_accum(), ppm_accum_destroy);      // freed on every error return
+    ppm_accum *a = guard.get();
     a->N = box; a->pixel = pixel_size;
     a->nsym = symmetry_ops(symmetry, a->symops);
-    if (a->nsym < 1) { fail(-22, std::string("unknown symmetry symbol '") + (symmetry ? symmetry : "") + "'"); delete a; return nullptr; }
+    if (a->nsym < 1) { fail(-22, std::string("unknown symmetry symbol '") + (symmetry ? symmetry : "") + "'"); return nullptr; }
     size_t nf = ppm_accum_floats(box);
     if (ext) { a->acc = (float *)ext; a->external = true; }
     else {
-        if (hipMalloc(&a->acc, nf * sizeof(float)) != hipSuccess) { fail(-12, "out of device memory for the accumulators"); delete a; return nullptr; }
+        if (hipMalloc(&a->acc, nf * sizeof(float)) != hipSuccess) { a->acc = nullptr; fail(-12, "out of device memory for the accumulators"); return nullptr; }
         (void)hipMemset(a->acc, 0, nf * sizeof(float));
     }
     std::vector<float> s(a->symops.begin(), a->symops.end());
@@ -698,7 +714,7 @@ ppm_accum_t *ppm_accum_create(int box, float pixel_size, const char *symmetry, v
     HIPCHKP(hipMalloc(&a->d_max, 2 * sizeof(unsigned)));
     static bool attr_set = false;
     if (!attr_set) { HIPCHKP(hipFuncSetAttribute((const void *)k_insert_bricks<16, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * (16 * 49 + 3) * 8)); attr_set = true; }
-    return a;
+    return guard.release();
 }
 
 void ppm_accum_destroy(ppm_accum_t *a) {
@@ -803,13 +819,12 @@ int ppm_accum_download(ppm_accum_t *a, float *host) {
 int ppm_accum_add(ppm_accum_t *a, const float *host) {
     if (!a || !host) return fail(-22, "null argument");
     size_t nf = ppm_accum_floats(a->N);
-    float *tmp = nullptr;
-    HIPCHK(hipMalloc(&tmp, nf * sizeof(float)));
-    HIPCHK(hipMemcpy(tmp, host, nf * sizeof(float), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_axpy, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, g.stream, a->acc, tmp, nf);
+    DevTmp<float> tmp;
+    HIPCHK(tmp.alloc(nf));
+    HIPCHK(hipMemcpy(tmp.p, host, nf * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_axpy, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, g.stream, a->acc, tmp.p, nf);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(g.stream));
-    (void)hipFree(tmp);
     return 0;
 }
 
@@ -821,12 +836,14 @@ int ppm_extract_boxes(const void *image, int image_on_device, int rows, int cols
     if (rows <= 0 || cols <= 0 || box < 2 || box > 4096 || !(coordinate_binning > 0)) return fail(-22, "bad extraction geometry");
     if (m <= 0) return 0;
     if (radius_px > box / 2.0) radius_px = box / 2.0;        // "Particle radius falls outside box" (image.py:323-331)
-    float *d_img = nullptr, *d_out = nullptr; double *d_xy = nullptr;
+    float *d_img = nullptr, *d_out = nullptr;
+    DevTmp<float> t_img, t_out; DevTmp<double> t_xy;
     const size_t npix = (size_t)rows * cols, nout = (size_t)m * box * box;
     if (image_on_device) d_img = (float *)image;
-    else { HIPCHK(hipMalloc(&d_img, npix * sizeof(float))); HIPCHK(hipMemcpy(d_img, image, npix * sizeof(float), hipMemcpyHostToDevice)); }
-    if (out_on_device) d_out = (float *)out; else HIPCHK(hipMalloc(&d_out, nout * sizeof(float)));
-    HIPCHK(hipMalloc(&d_xy, (size_t)m * 2 * sizeof(double)));
+    else { HIPCHK(t_img.alloc(npix)); d_img = t_img.p; HIPCHK(hipMemcpy(d_img, image, npix * sizeof(float), hipMemcpyHostToDevice)); }
+    if (out_on_device) d_out = (float *)out; else { HIPCHK(t_out.alloc(nout)); d_out = t_out.p; }
+    HIPCHK(t_xy.alloc((size_t)m * 2));
+    double *d_xy = t_xy.p;
     HIPCHK(hipMemcpyAsync(d_xy, coords, (size_t)m * 2 * sizeof(double), hipMemcpyHostToDevice, g.stream));
     ExtractP P; P.image = d_img; P.rows = rows; P.cols = cols; P.coords = d_xy; P.box = box; P.cbin = coordinate_binning;
     P.radius2 = (float)(radius_px * radius_px); P.normalize = normalize; P.fix_empty = fix_empty; P.out = d_out;
@@ -837,9 +854,6 @@ int ppm_extract_boxes(const void *image, int image_on_device, int rows, int cols
     HIPCHK(hipGetLastError());
     if (!out_on_device) HIPCHK(hipMemcpyAsync(out, d_out, nout * sizeof(float), hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
-    (void)hipFree(d_xy);
-    if (!image_on_device) (void)hipFree(d_img);
-    if (!out_on_device) (void)hipFree(d_out);
     return 0;
 }
 
@@ -849,16 +863,18 @@ int ppm_finalize(ppm_accum_t *a, const ppm_final_cfg *cfg, float *half1, float *
     const int N = a->N, ns = N / 2;
     const double px = a->pixel;
     const size_t nf = ppm_accum_floats(N), n3 = (size_t)N * N * N, tot = (size_t)N * N * (N / 2 + 1);
-    float *tmp = nullptr; double *d_s = nullptr; float2 *d_f = nullptr; float *d_out = nullptr;
-    HIPCHK(hipMalloc(&tmp, nf * sizeof(float)));
-    HIPCHK(hipMalloc(&d_s, 8 * ns * sizeof(double)));
+    DevTmp<float> t_tmp, t_out; DevTmp<double> t_s; DevTmp<float2> t_f;
+    HIPCHK(t_tmp.alloc(nf));
+    HIPCHK(t_s.alloc((size_t)8 * ns));
+    float *tmp = t_tmp.p; double *d_s = t_s.p;
     HIPCHK(hipMemset(d_s, 0, 8 * ns * sizeof(double)));
     HIPCHK(hipMemcpyAsync(tmp, a->acc, nf * sizeof(float), hipMemcpyDeviceToDevice, g.stream));
-    ProfScope *ps = new ProfScope(PPM_K_FINAL);
+    {
+    ProfScope ps(PPM_K_FINAL);
     hipLaunchKernelGGL(k_fold_plane, dim3((unsigned)(((size_t)2 * N * N + 255) / 256)), dim3(256), 0, g.stream, a->acc, tmp, N);
     hipLaunchKernelGGL(k_shell_den, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, g.stream, tmp, d_s, N);
     hipLaunchKernelGGL(k_shell_fsc, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, g.stream, tmp, d_s, d_s + 4 * ns, N);
-    delete ps;
+    }
     std::vector<double> hs(8 * ns);
     HIPCHK(hipMemcpyAsync(hs.data(), d_s, 8 * ns * sizeof(double), hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
@@ -878,8 +894,9 @@ int ppm_finalize(ppm_accum_t *a, const ppm_final_cfg *cfg, float *half1, float *
         }
     }
     HIPCHK(hipMemcpy(d_s, kap.data(), ns * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(hipMalloc(&d_f, n3 * sizeof(float2)));
-    HIPCHK(hipMalloc(&d_out, n3 * sizeof(float)));
+    HIPCHK(t_f.alloc(n3));
+    HIPCHK(t_out.alloc(n3));
+    float2 *d_f = t_f.p; float *d_out = t_out.p;
     float *outs[3] = { half1, half2, filtered };
     const float rout = (float)(cfg->outer_radius / px), rin = (float)(cfg->inner_radius / px);
     const float fo = (float)((cfg->mask_falloff > 0 ? cfg->mask_falloff : 10.0) / px);
@@ -896,7 +913,6 @@ int ppm_finalize(ppm_accum_t *a, const ppm_final_cfg *cfg, float *half1, float *
         HIPCHK(hipMemcpyAsync(outs[which], d_out, n3 * sizeof(float), hipMemcpyDeviceToHost, g.stream));
         HIPCHK(hipStreamSynchronize(g.stream));
     }
-    (void)hipFree(tmp); (void)hipFree(d_s); (void)hipFree(d_f); (void)hipFree(d_out);
     return 0;
 }
 

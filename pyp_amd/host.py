@@ -197,6 +197,30 @@ def extract_boxes(micrograph, coords, box, radius_A, pixel_size, coordinate_binn
     return res
 
 
+class PinnedBuffer:
+    """Page-locked host memory as a float32 numpy array (ppm_host_alloc): staging for uploads that overlap compute."""
+
+    def __init__(self, n_floats, device=0):
+        lib.init(device)
+        self.n = int(n_floats)
+        self.ptr = lib.load().ppm_host_alloc(self.n * 4)
+        if not self.ptr:
+            raise lib.PpmError(lib.last_error())
+        self.array = np.ctypeslib.as_array((C.c_float * self.n).from_address(self.ptr))
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            self.array = None
+            lib.load().ppm_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def profile(enable=True, reset=True):
     lib.load().ppm_profile_enable(1 if enable else 0)
     if reset:

@@ -15,7 +15,7 @@ EXPORTS = [
     "ppm_refine_batch", "ppm_refine_last_counts", "ppm_refine_note", "ppm_csp_refine", "ppm_accum_floats", "ppm_accum_create", "ppm_accum_destroy",
     "ppm_insert_batch", "ppm_accum_download", "ppm_accum_add", "ppm_accum_count", "ppm_accum_set_count",
     "ppm_finalize", "ppm_profile_enable", "ppm_profile_reset", "ppm_profile_get", "ppm_device_alloc",
-    "ppm_device_free", "ppm_device_upload", "ppm_device_sync", "ppm_extract_boxes",
+    "ppm_device_free", "ppm_device_upload", "ppm_device_sync", "ppm_extract_boxes", "ppm_host_alloc", "ppm_host_free",
 ]
 
 
@@ -63,6 +63,8 @@ def load():
     L.ppm_device_free.argtypes = [vp]; L.ppm_device_free.restype = None
     L.ppm_device_upload.argtypes = [vp, vp, C.c_size_t]; L.ppm_device_upload.restype = ci
     L.ppm_device_sync.argtypes = []; L.ppm_device_sync.restype = ci
+    L.ppm_host_alloc.argtypes = [C.c_size_t]; L.ppm_host_alloc.restype = vp
+    L.ppm_host_free.argtypes = [vp]; L.ppm_host_free.restype = None
     L.ppm_extract_boxes.argtypes = [vp, ci, ci, ci, vp, ci, ci, C.c_double, C.c_double, ci, ci, vp, ci]; L.ppm_extract_boxes.restype = ci
     _lib = L
     return L

@@ -71,14 +71,51 @@ def _select(rows, first, last):
     return sel
 
 
-def _load_images(stack_path, positions, box_expected=None):
+def _open_stack(stack_path, positions):
     mm = mrc.mmap(stack_path)
     if positions.max() > mm.shape[0] or positions.min() < 1:
         _die(f"ERROR: {stack_path}: stack has {mm.shape[0]} images, rows ask for {int(positions.max())}")
     if mm.shape[1] != mm.shape[2]:
         _die(f"ERROR: {stack_path}: particle images must be square")
-    imgs = np.ascontiguousarray(mm[positions.astype(np.int64) - 1], dtype=np.float32)
-    return imgs
+    return mm
+
+
+def _iter_image_chunks(mm, positions, device, chunk=None):
+    """Yield (lo, hi, images[hi - lo, N, N]) over the range: the particle images are read from the memory-mapped stack chunk by
+    chunk into two page-locked buffers, the next chunk by a reader thread while the caller computes on the current one, so
+    the host never holds more than two chunks (a 500 k x 256^2 range is 131 GB) and uploads overlap the kernels."""
+    import threading
+    from .. import host
+    n, box = len(positions), mm.shape[1]
+    if chunk is None:
+        chunk = int(os.environ.get("PPM_IO_CHUNK", "8192"))
+    chunk = max(1, min(chunk, n))
+    idx = positions.astype(np.int64) - 1
+    contiguous = bool(np.all(np.diff(idx) == 1))
+    bufs = [host.PinnedBuffer(chunk * box * box, device) for _ in range(2 if n > chunk else 1)]
+
+    def fill(b, lo, hi):
+        dst = bufs[b].array[:(hi - lo) * box * box].reshape(hi - lo, box, box)
+        dst[...] = mm[idx[lo]:idx[lo] + (hi - lo)] if contiguous else mm[idx[lo:hi]]
+        return dst
+
+    try:
+        cur = fill(0, 0, min(chunk, n))
+        lo, b = 0, 0
+        while lo < n:
+            hi = min(lo + chunk, n)
+            nxt, t = [None], None
+            if hi < n:
+                t = threading.Thread(target=lambda: nxt.__setitem__(0, fill(1 - b, hi, min(hi + chunk, n))))
+                t.start()
+            yield lo, hi, cur
+            if t is not None:
+                t.join()
+                cur, b = nxt[0], 1 - b
+            lo = hi
+    finally:
+        for pb in bufs:
+            pb.close()
 
 
 def _ssnr_ring_weights(n, stats_path, pixel):
@@ -138,8 +175,8 @@ def refine3d_main(argv=None, stdin=None):
         rows = cistem.read_parameters(d["input_params"])
     sel = _select(rows, d["first"], d["last"])
     rin = rows[sel]
-    imgs = _load_images(d["stack"], rin[:, C["POSITION_IN_STACK"]])
-    box = imgs.shape[1]
+    mm = _open_stack(d["stack"], rin[:, C["POSITION_IN_STACK"]])
+    box = mm.shape[1]
     vol = mrc.read(d["reference"]).astype(np.float32)
     if vol.shape != (box, box, box):
         _die(f"ERROR: refine3d: reference is {vol.shape}, particles are {box}^2")
@@ -156,7 +193,9 @@ def refine3d_main(argv=None, stdin=None):
             if box * pad > 512:
                 _die(f"ERROR: refine3d: padding factor {pad} needs a padded box of {box * pad} > 512")
             ref = host.Reference(vol, box / 2, device=dev, pad=pad, ring_weight=ring_w)
-            rout = ref.refine(cfg, imgs, rin)
+            rout = np.empty_like(rin)
+            for lo, hi, imgs in _iter_image_chunks(mm, rin[:, C["POSITION_IN_STACK"]], dev):
+                rout[lo:hi] = ref.refine(cfg, imgs, rin[lo:hi])
             note = ref.note()
             ref.close()
     except (lib.PpmError, ValueError) as e:
@@ -241,8 +280,8 @@ def reconstruct3d_main(argv=None, stdin=None):
         score_avg = float(cistem.read_parameters(d["global_stats"])[0, C["SCORE"]])
     else:
         score_avg = float(rin[used, C["SCORE"]].mean()) if used.any() else 0.0
-    imgs = _load_images(d["stack"], rin[:, C["POSITION_IN_STACK"]])
-    box = imgs.shape[1]
+    mm = _open_stack(d["stack"], rin[:, C["POSITION_IN_STACK"]])
+    box = mm.shape[1]
     rc = ReconCfg(box=box, pixel_size=px, res_limit=d["res_limit"], score_weight_bfactor=d["score_bfactor"] if d["score_weighting"] else 0.0,
                   score_average=score_avg, score_threshold=d["score_threshold"], normalize=int(d["normalize"]), invert=int(d["invert"]),
                   split_by_pind=int(d["per_particle_splitting"]), mask_radius=d["outer_radius"])
@@ -263,7 +302,8 @@ def reconstruct3d_main(argv=None, stdin=None):
     try:
         with gpu_lock(dev):
             acc = host.Accumulator(box, px, d["symmetry"], device=dev)
-            acc.insert(rc, imgs, rin)
+            for lo, hi, imgs in _iter_image_chunks(mm, rin[:, C["POSITION_IN_STACK"]], dev):
+                acc.insert(rc, imgs, rin[lo:hi])
             data = acc.download()
             counts = acc.counts()
             acc.close()

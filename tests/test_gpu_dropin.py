@@ -69,6 +69,11 @@ def test_refine3d_ranges_then_merge(project):
     assert np.median(ang) < 3.0
     ch = cistem.read_parameters(str(d / "p_r01_0000001_0000031_changes.cistem"))
     assert ch.shape == (31, 32) and np.allclose(ch[:, 14], merged[:31, 14] - 0.5, atol=1e-3)
+    # the range is streamed from the stack file through two pinned buffers: a 7-image chunk gives the same bytes
+    env = dict(os.environ, PPM_IO_CHUNK="7")
+    cmd = f"{BIN}/refine3d << eot >> refine_chunk.log 2>&1\n{refine_script(1, 31, True, out='chunked.cistem')}eot\n"
+    assert subprocess.run(cmd, shell=True, cwd=d, env=env).returncode == 0
+    assert np.array_equal(cistem.read_parameters(str(d / "chunked.cistem")), cistem.read_parameters(files[0]))
 
 
 def test_refine3d_par_surface_local(project):
