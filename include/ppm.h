@@ -201,6 +201,29 @@ const char *ppm_refine_note(ppm_ref_t *ref);
 int ppm_csp_refine(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const ppm_csp_cfg *csp, const void *images, int images_on_device,
                    int n_proj, double *rows, double *particles, int n_part, double *tilts, int n_tilt);
 
+/* Sub-tomogram alignment (3DAVG, `external/TOMO/MPI_Classification`, driven by src/pyp/refine/tomo_avg/sub_tomo_avg.py:318-555
+ * with the XML protocols of src/pyp/refine/3DAVG/): every sub-volume is aligned to the reference by a rotation + 3-D shift that
+ * maximise the band-passed, missing-wedge-weighted normalised cross-correlation of its 3-D transform with the rotated
+ * reference transform.  Pose convention = the particle block of constrained refinement: the sub-volume's transform at k
+ * matches the reference's at N k, times e^{+2 pi i k.p / box} (N = E(-ppsi, -ptheta, -pphi), p = particle shift), so a refined
+ * pose can be written straight into a particle's (ppsi, ptheta, pphi, shift) and vice versa. */
+typedef struct ppm_sva_cfg {
+    int box; float pixel_size;
+    float window[3];        /* <mode>_image_window_x/y/z: half-axes of the real-space window, pixels (0 = none) */
+    float window_sigma;     /* <mode>_image_window_sigma: Gaussian fall-off outside the window, pixels */
+    float highpass_cutoff, highpass_decay, lowpass_cutoff, lowpass_decay;   /* <mode>_high/low_pass_cutoff/decay, cycles per pixel (Nyquist = 0.5) */
+    int use_missing_wedge;  /* metric/use_missing_wedge: samples outside the tilt range lwedge..uwedge do not count */
+    float tol_angle;        /* <mode>_out_of_plane_search_range: search bound either side of the start, degrees (all three rotations) */
+    float tol_shift;        /* <mode>_shifts_tolerance, pixels */
+    float step_tolerance;   /* smallest compass step (default 0.05 degrees / pixels) */
+    int max_iterations;     /* 0 = until the step falls below step_tolerance, at most 12 */
+    float band_factor;      /* frequency marching as in ppm_refine_cfg (0 = default 3, < 0 = off) */
+} ppm_sva_cfg;
+/* volumes: n_vol * box^3 floats (x fastest); wedges: n_vol x {lwedge, uwedge} tilt limits in degrees (tilt axis = y);
+ * poses: n_vol x 12 doubles {N row-major (9), shift x y z (pixels)}, start values in, refined values out; scores: n_vol. */
+int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void *volumes, int volumes_on_device, int n_vol, const float *wedges,
+                  double *poses, double *scores);
+
 /* symmetry: "C1", "Cn", "Dn", "T", "O", "I".  ext_device_buffer: NULL, or a device buffer of
  * ppm_accum_floats(box) floats the caller allocated (e.g. a torch tensor, so that RCCL can
  * reduce it in place); it must be zeroed by the caller. */

@@ -45,6 +45,7 @@ def lib():
         L.orc_fft1d.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.orc_insert_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_void_p]
         L.orc_finalize.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_sva_align.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_csp_pose.argtypes = [C.c_double, C.c_double, C.c_void_p, C.c_void_p]
         L.orc_csp_pose.restype = None
         L.orc_csp_refine.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
@@ -182,3 +183,16 @@ def csp_refine(ref, cfg, csp_cfg, images, rows, particles, tilts):
     if rc:
         raise RuntimeError(f"oracle: csp_refine failed ({rc})")
     return rows, particles, tilts, nev.value
+
+
+def sva_align(ref, cfg, volumes, wedges, poses):
+    """Sub-tomogram alignment (orc_sva_align): returns (poses, scores, evaluations); inputs untouched."""
+    volumes = np.ascontiguousarray(volumes, dtype=np.float32)
+    wedges = np.ascontiguousarray(wedges, dtype=np.float32)
+    poses = np.array(poses, dtype=np.float64, order="C")
+    scores = np.zeros(len(poses), dtype=np.float64)
+    nev = C.c_long(0)
+    rc = lib().orc_sva_align(ref.h, C.byref(cfg), _p(volumes), len(poses), _p(wedges), _p(poses), _p(scores), C.byref(nev))
+    if rc:
+        raise RuntimeError(f"oracle: sva_align failed ({rc})")
+    return poses, scores, nev.value

@@ -76,6 +76,22 @@ class CspCfg(C.Structure):
                    tind_max=int(tind_max), first=int(first), last=int(last))
 
 
+class SvaCfg(C.Structure):
+    """ppm_sva_cfg (include/ppm.h)."""
+    _fields_ = [("box", C.c_int), ("pixel_size", C.c_float), ("window", C.c_float * 3), ("window_sigma", C.c_float),
+                ("highpass_cutoff", C.c_float), ("highpass_decay", C.c_float), ("lowpass_cutoff", C.c_float), ("lowpass_decay", C.c_float),
+                ("use_missing_wedge", C.c_int), ("tol_angle", C.c_float), ("tol_shift", C.c_float), ("step_tolerance", C.c_float),
+                ("max_iterations", C.c_int), ("band_factor", C.c_float)]
+
+    @classmethod
+    def make(cls, box, pixel_size=1.0, window=(0, 0, 0), window_sigma=0.0, highpass=(0.0, 0.0), lowpass=(0.25, 0.05), use_missing_wedge=1,
+             tol_angle=10.0, tol_shift=5.0, step_tolerance=0.05, max_iterations=0, band_factor=0.0):
+        return cls(box=int(box), pixel_size=float(pixel_size), window=(C.c_float * 3)(*[float(x) for x in window]), window_sigma=float(window_sigma),
+                   highpass_cutoff=float(highpass[0]), highpass_decay=float(highpass[1]), lowpass_cutoff=float(lowpass[0]),
+                   lowpass_decay=float(lowpass[1]), use_missing_wedge=int(use_missing_wedge), tol_angle=float(tol_angle),
+                   tol_shift=float(tol_shift), step_tolerance=float(step_tolerance), max_iterations=int(max_iterations), band_factor=float(band_factor))
+
+
 class FinalCfg(C.Structure):
     _fields_ = [("molecular_mass_kda", C.c_float), ("inner_radius", C.c_float), ("outer_radius", C.c_float),
                 ("mask_falloff", C.c_float)]

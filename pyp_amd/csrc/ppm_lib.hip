@@ -17,6 +17,7 @@
 #include "ppm_geom.h"
 #include "ppm_kernels2.h"
 #include "ppm_csp_kernels.h"
+#include "ppm_sva_kernels.h"
 
 using namespace ppm;
 
@@ -1208,6 +1209,186 @@ extern "C" int ppm_csp_refine(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const p
             if (usable[j]) { ssum += row[PPM_SCORE]; sn++; }
         }
         if (kind == PPM_CSP_PARTICLES) particles[(size_t)u * PPM_NPCOL + 10] = sn ? ssum / sn : -1.0;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ sub-tomogram alignment (3DAVG)
+namespace {
+double sva_band_weight(const ppm_sva_cfg &c, double s) {
+    double w = 1.0;
+    if (c.highpass_cutoff > 0 && s < c.highpass_cutoff) { const double d = c.highpass_cutoff - s; w *= c.highpass_decay > 0 ? std::exp(-d * d / (2.0 * c.highpass_decay * c.highpass_decay)) : 0.0; }
+    if (c.lowpass_cutoff > 0 && s > c.lowpass_cutoff) { const double d = s - c.lowpass_cutoff; w *= c.lowpass_decay > 0 ? std::exp(-d * d / (2.0 * c.lowpass_decay * c.lowpass_decay)) : 0.0; }
+    return w;
+}
+double sva_band_radius(const ppm_sva_cfg &c) {
+    const int N = c.box;
+    double s = c.lowpass_cutoff > 0 ? c.lowpass_cutoff + (c.lowpass_decay > 0 ? 3.7169 * c.lowpass_decay : 0.0) : 0.5;
+    if (s > 0.5) s = 0.5;
+    double r = s * N; if (r > N / 2 - 1) r = N / 2 - 1;
+    return r;
+}
+}  // namespace
+
+extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void *volumes, int volumes_on_device, int n_vol, const float *wedges,
+                             double *poses, double *scores) {
+    if (!g.inited) return fail(-1, "ppm_init has not been called");
+    if (!ref || !cfg || !volumes || !poses) return fail(-22, "null argument");
+    if (n_vol <= 0) return 0;
+    const int N = cfg->box;
+    if (!box_ok(N) || N != ref->N) return fail(-22, "sub-volume box differs from the reference box (even, 32..512, prime factors 2, 3, 5)");
+    if (ref->pad != 1) return fail(-22, "sub-tomogram alignment needs a reference prepared with padding 1");
+    const double rband = sva_band_radius(*cfg);
+    if (rband > ref->B) return fail(-22, "low-pass limit exceeds the band the reference was prepared for");
+    const size_t n3 = (size_t)N * N * N;
+    // ---- sample list of the band (half space, shell by shell), common to all sub-volumes; the wedge is applied per volume
+    const int R = (int)std::ceil(rband);
+    std::vector<uint32_t> samples; std::vector<float> bandw; std::vector<int> shell_off(R + 2, 0);
+    for (int sh = 0; sh <= R; sh++) {
+        for (int kz = -R; kz <= R; kz++) for (int ky = -R; ky <= R; ky++) for (int kx = 0; kx <= R; kx++) {
+            const double k2 = (double)kx * kx + (double)ky * ky + (double)kz * kz;
+            if (k2 == 0 || k2 >= rband * rband || (int)std::floor(std::sqrt(k2)) != sh) continue;
+            if (kx == 0 && (ky < 0 || (ky == 0 && kz < 0))) continue;
+            const double w = sva_band_weight(*cfg, std::sqrt(k2) / N);
+            if (w < 1e-3) continue;
+            samples.push_back(sva_pack(kx, ky, kz)); bandw.push_back((float)w);
+        }
+        shell_off[sh + 1] = (int)samples.size();
+    }
+    const int S = (int)samples.size();
+    if (S == 0) return fail(-22, "the band-pass filter leaves no Fourier samples");
+    auto prefix_of = [&](double rb) { int rg = (int)std::ceil(rb); if (rg > R + 1) rg = R + 1; return shell_off[rg]; };
+    // ---- search plan (the particle unit of the constrained search: rotations about the specimen axes + 3-D shift)
+    int en[6]; double tol[6];
+    for (int k = 0; k < 3; k++) { en[k] = cfg->tol_angle > 0; tol[k] = cfg->tol_angle; en[3 + k] = cfg->tol_shift > 0; tol[3 + k] = cfg->tol_shift; }
+    const int nrot = en[0] ? 6 : 0, nsh = en[3] ? 6 : 0, ncand = 1 + nrot + nsh;
+    const double steptol = cfg->step_tolerance > 0 ? cfg->step_tolerance : 0.05;
+    const double ha0 = 0.5 * cfg->tol_angle, hs0 = 0.5 * cfg->tol_shift;
+    int T = cfg->max_iterations;
+    if (T <= 0) { const double m = std::max(ha0, hs0); T = m > steptol ? (int)std::ceil(std::log(m / steptol) / std::log(2.0)) : 1; T = std::min(12, std::max(1, T)); }
+    if (ncand == 1) T = 0;
+    const double bf = cfg->band_factor == 0 ? 3.0 : cfg->band_factor;
+    double rm_px = std::max(cfg->window[0], std::max(cfg->window[1], cfg->window[2]));
+    if (!(rm_px > 0)) rm_px = 0.4 * N;
+    auto iter_band = [&](double ha, double hs) {
+        if (bf < 0) return rband;
+        double d = 0;
+        if (en[0]) d = rm_px * ha * kPi / 180.0;
+        if (en[3] && hs > d) d = hs;
+        if (!(d > 0)) return rband;
+        double rit = bf * N / (2.0 * kPi * d);
+        if (rit < 4.0) rit = 4.0;
+        return rit < rband ? rit : rband;
+    };
+    // ---- device buffers (RAII), chunks of sub-volumes
+    const int CH = (int)std::min<size_t>((size_t)n_vol, std::max<size_t>(1, ((size_t)4 << 30) / (n3 * 4 + (size_t)S * 8)));
+    DevTmp<uint32_t> d_samples; DevTmp<float> d_bandw, d_vols, d_wedges; DevTmp<float2> d_f, d_F; DevTmp<double> d_stats, d_poses, d_delta, d_out;
+    HIPCHK(d_samples.alloc(S)); HIPCHK(d_bandw.alloc(S)); HIPCHK(d_f.alloc(n3)); HIPCHK(d_F.alloc((size_t)CH * S));
+    HIPCHK(d_stats.alloc((size_t)2 * CH)); HIPCHK(d_poses.alloc((size_t)12 * CH)); HIPCHK(d_delta.alloc((size_t)CH * ncand * 6)); HIPCHK(d_out.alloc((size_t)CH * ncand));
+    HIPCHK(d_wedges.alloc((size_t)2 * CH));
+    if (!volumes_on_device) HIPCHK(d_vols.alloc((size_t)CH * n3));
+    HIPCHK(hipMemcpyAsync(d_samples.p, samples.data(), (size_t)S * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemcpyAsync(d_bandw.p, bandw.data(), (size_t)S * sizeof(float), hipMemcpyHostToDevice, g.stream));
+    SvaWin W; for (int k = 0; k < 3; k++) W.w[k] = cfg->window[k]; W.sigma = cfg->window_sigma;
+    SvaEvalP EP;
+    EP.cv.cube = ref->cube; EP.cv.NBX = ref->NBX; EP.cv.NBY = ref->NBY; EP.cv.LB = ref->LB; EP.cv.off = ref->B + 1; EP.cv.scale = 1.f;
+    EP.samples = d_samples.p; EP.bandw = d_bandw.p; EP.F = d_F.p; EP.S = S; EP.N = N; EP.use_wedge = cfg->use_missing_wedge != 0;
+    EP.wedges = d_wedges.p; EP.poses = d_poses.p; EP.delta = d_delta.p; EP.out = d_out.p;
+    std::vector<float> hw((size_t)2 * CH);
+    std::vector<double> hdelta, hout;
+    for (int c0 = 0; c0 < n_vol; c0 += CH) {
+        const int nb = std::min(CH, n_vol - c0);
+        const float *dv = (const float *)volumes + (size_t)c0 * n3;
+        if (!volumes_on_device) { HIPCHK(hipMemcpyAsync(d_vols.p, dv, (size_t)nb * n3 * sizeof(float), hipMemcpyHostToDevice, g.stream)); dv = d_vols.p; }
+        for (int v = 0; v < nb; v++) { hw[2 * v] = wedges ? wedges[2 * (size_t)(c0 + v)] : -90.f; hw[2 * v + 1] = wedges ? wedges[2 * (size_t)(c0 + v) + 1] : 90.f; }
+        HIPCHK(hipMemcpyAsync(d_wedges.p, hw.data(), (size_t)2 * nb * sizeof(float), hipMemcpyHostToDevice, g.stream));
+        HIPCHK(hipMemsetAsync(d_stats.p, 0, (size_t)2 * nb * sizeof(double), g.stream));
+        {
+            ProfScope ps(PPM_K_PREP);
+            hipLaunchKernelGGL(k_sva_stats, dim3(64, nb), dim3(256), 0, g.stream, dv, n3, d_stats.p);
+            for (int v = 0; v < nb; v++) {
+                hipLaunchKernelGGL(k_sva_load, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, g.stream, dv + (size_t)v * n3, d_stats.p + 2 * v, d_f.p, N, W);
+                if (int rc = fft3d(d_f.p, N, false)) return rc;
+                hipLaunchKernelGGL(k_sva_gather, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, g.stream, d_f.p, d_samples.p, S, N, d_F.p + (size_t)v * S);
+            }
+        }
+        HIPCHK(hipGetLastError());
+        std::vector<CUnit> st(nb);
+        for (int v = 0; v < nb; v++) { std::memcpy(st[v].N, poses + (size_t)(c0 + v) * 12, 9 * sizeof(double)); std::memcpy(st[v].p, poses + (size_t)(c0 + v) * 12 + 9, 3 * sizeof(double)); }
+        std::vector<double> hp((size_t)12 * nb);
+        auto upload_poses = [&]() -> int {
+            for (int v = 0; v < nb; v++) { std::memcpy(&hp[(size_t)12 * v], st[v].N, 9 * sizeof(double)); std::memcpy(&hp[(size_t)12 * v + 9], st[v].p, 3 * sizeof(double)); }
+            HIPCHK(hipMemcpyAsync(d_poses.p, hp.data(), hp.size() * sizeof(double), hipMemcpyHostToDevice, g.stream));
+            return 0;
+        };
+        auto sweep = [&](int nc, int nr_, double rb) -> int {
+            HIPCHK(hipMemcpyAsync(d_delta.p, hdelta.data(), (size_t)nb * nc * 6 * sizeof(double), hipMemcpyHostToDevice, g.stream));
+            EP.ncand = nc; EP.nrot = nr_; EP.S_used = prefix_of(rb); EP.rmax2 = (float)(rb * rb);
+            { ProfScope ps(PPM_K_LOCAL); hipLaunchKernelGGL(k_sva_eval, dim3(nb), dim3(256), 0, g.stream, EP); }
+            HIPCHK(hipGetLastError());
+            hout.resize((size_t)nb * nc);
+            HIPCHK(hipMemcpyAsync(hout.data(), d_out.p, hout.size() * sizeof(double), hipMemcpyDeviceToHost, g.stream));
+            HIPCHK(hipStreamSynchronize(g.stream));
+            return 0;
+        };
+        if (int rc = upload_poses()) return rc;
+        double ha = ha0, hs = hs0;
+        std::vector<double> mean, dtrial((size_t)nb * 6), fpv((size_t)nb * 6), fmv((size_t)nb * 6);
+        auto cand_of = [&](int i, int sign) { return i < 3 ? 1 + 2 * i + (sign < 0) : 1 + nrot + 2 * (i - 3) + (sign < 0); };
+        for (int it = 0; it < T; it++) {
+            const double rb = iter_band(ha, hs);
+            hdelta.assign((size_t)nb * ncand * 6, 0.0);
+            for (int v = 0; v < nb; v++) for (int i = 0; i < 6; i++) if (en[i]) {
+                const double h = i < 3 ? ha : hs;
+                hdelta[((size_t)v * ncand + cand_of(i, 1)) * 6 + i] = h; hdelta[((size_t)v * ncand + cand_of(i, -1)) * 6 + i] = -h;
+            }
+            if (int rc = sweep(ncand, nrot, rb)) return rc;
+            mean = hout;
+            for (int v = 0; v < nb; v++) {
+                const CUnit &s = st[v];
+                const double f0 = mean[(size_t)v * ncand];
+                double *d = &dtrial[(size_t)v * 6];
+                for (int i = 0; i < 6; i++) {
+                    d[i] = 0; fpv[(size_t)v * 6 + i] = fmv[(size_t)v * 6 + i] = -1e300;
+                    if (!en[i]) continue;
+                    const double h = i < 3 ? ha : hs;
+                    const bool okp = std::fabs(s.acc[i] + h) <= tol[i] + 1e-9, okm = std::fabs(s.acc[i] - h) <= tol[i] + 1e-9;
+                    const double fp = okp ? mean[(size_t)v * ncand + cand_of(i, 1)] : -1e300, fm = okm ? mean[(size_t)v * ncand + cand_of(i, -1)] : -1e300;
+                    fpv[(size_t)v * 6 + i] = fp; fmv[(size_t)v * 6 + i] = fm;
+                    if (okp && okm) {
+                        const double den = 2.0 * f0 - fp - fm;
+                        if (den > 1e-12) { double t = 0.5 * h * (fp - fm) / den; d[i] = t > h ? h : (t < -h ? -h : t); }
+                        else { const double best = fp > fm ? fp : fm; d[i] = best > f0 ? (fp > fm ? h : -h) : 0.0; }
+                    } else if (okp) d[i] = fp > f0 ? h : 0.0;
+                    else if (okm) d[i] = fm > f0 ? -h : 0.0;
+                    if (s.acc[i] + d[i] > tol[i]) d[i] = tol[i] - s.acc[i];
+                    if (s.acc[i] + d[i] < -tol[i]) d[i] = -tol[i] - s.acc[i];
+                }
+            }
+            hdelta = dtrial;
+            if (int rc = sweep(1, 0, rb)) return rc;
+            for (int v = 0; v < nb; v++) {
+                CUnit &s = st[v];
+                const double f0 = mean[(size_t)v * ncand], ft = hout[v];
+                int bi = -1, bs = 0; double fb = f0;
+                for (int i = 0; i < 6; i++) {
+                    if (!en[i]) continue;
+                    if (fpv[(size_t)v * 6 + i] > fb) { fb = fpv[(size_t)v * 6 + i]; bi = i; bs = 1; }
+                    if (fmv[(size_t)v * 6 + i] > fb) { fb = fmv[(size_t)v * 6 + i]; bi = i; bs = -1; }
+                }
+                CUnit q;
+                if (ft > f0 && ft >= fb) { csp_apply(PPM_CSP_PARTICLES, s, &dtrial[(size_t)v * 6], q); s = q; }
+                else if (bi >= 0) { double dd[6] = { 0, 0, 0, 0, 0, 0 }; dd[bi] = bs * (bi < 3 ? ha : hs); csp_apply(PPM_CSP_PARTICLES, s, dd, q); s = q; }
+            }
+            if (int rc = upload_poses()) return rc;
+            ha *= 0.5; hs *= 0.5;
+        }
+        hdelta.assign((size_t)nb * 6, 0.0);
+        if (int rc = sweep(1, 0, rband)) return rc;
+        for (int v = 0; v < nb; v++) {
+            std::memcpy(poses + (size_t)(c0 + v) * 12, st[v].N, 9 * sizeof(double)); std::memcpy(poses + (size_t)(c0 + v) * 12 + 9, st[v].p, 3 * sizeof(double));
+            if (scores) scores[c0 + v] = hout[v];
+        }
     }
     return 0;
 }

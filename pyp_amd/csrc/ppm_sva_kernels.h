@@ -1,0 +1,143 @@
+// ppm_sva_kernels.h — sub-tomogram alignment kernels of libpypmatch (gfx950): pre-processing of a sub-volume into its
+// band-limited half-space transform, and the wedge-weighted correlation of that transform with the rotated reference for a
+// set of candidate poses (include/ppm.h, ppm_sva_cfg; CPU restatement: oracle/ppm_oracle.c, orc_sva_align).
+#pragma once
+#include "ppm_csp_kernels.h"
+
+namespace ppm {
+
+// sum and sum of squares of one sub-volume: grid (blocks, n_vol), stats[v] = {sum, sumsq} (double atomics, one per block)
+__global__ void __launch_bounds__(256) k_sva_stats(const float *__restrict__ vols, size_t n3, double *stats) {
+    __shared__ double r1[4], r2[4];
+    const float *v = vols + (size_t)blockIdx.y * n3;
+    double s1 = 0, s2 = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n3; i += (size_t)gridDim.x * 256) { const double x = v[i]; s1 += x; s2 += x * x; }
+    s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+    if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = s1; r2[threadIdx.x >> 6] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&stats[2 * blockIdx.y], ((r1[0] + r1[1]) + r1[2]) + r1[3]);
+        atomicAdd(&stats[2 * blockIdx.y + 1], ((r2[0] + r2[1]) + r2[2]) + r2[3]);
+    }
+}
+
+struct SvaWin { float w[3], sigma; };
+
+// (v - mean) / sigma x real-space window -> complex work volume
+__global__ void k_sva_load(const float *__restrict__ vol, const double *stats, float2 *__restrict__ f, int N, SvaWin W) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, n3 = (size_t)N * N * N;
+    if (i >= n3) return;
+    const double mu = stats[0] / (double)n3, var = stats[1] / (double)n3 - mu * mu, sd = var > 0 ? sqrt(var) : 1.0;
+    const int c[3] = { (int)(i % N) - N / 2, (int)((i / N) % N) - N / 2, (int)(i / ((size_t)N * N)) - N / 2 };
+    float wv = 1.f;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        if (!(W.w[k] > 0.f)) continue;
+        const float d = fabsf((float)c[k]) - W.w[k];
+        if (d > 0.f) wv *= W.sigma > 0.f ? expf(-d * d / (2.f * W.sigma * W.sigma)) : 0.f;
+    }
+    f[i] = make_float2((float)(((double)vol[i] - mu) / sd) * wv, 0.f);
+}
+
+// packed sample: kx (10 bits) | ky + 512 (11 bits) << 10 | kz + 512 (11 bits) << 21
+__host__ __device__ __forceinline__ uint32_t sva_pack(int kx, int ky, int kz) { return (uint32_t)kx | ((uint32_t)(ky + 512) << 10) | ((uint32_t)(kz + 512) << 21); }
+__device__ __forceinline__ void sva_unpack(uint32_t u, int &kx, int &ky, int &kz) { kx = (int)(u & 1023u); ky = (int)((u >> 10) & 2047u) - 512; kz = (int)(u >> 21) - 512; }
+
+// band-limited half-space transform of one sub-volume, origin moved to the box centre
+__global__ void k_sva_gather(const float2 *__restrict__ f, const uint32_t *__restrict__ samples, int S, int N, float2 *__restrict__ F) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S) return;
+    int kx, ky, kz; sva_unpack(samples[i], kx, ky, kz);
+    const float2 v = f[((size_t)((kz + N) % N) * N + ((ky + N) % N)) * N + kx];
+    const float sg = ((kx + ky + kz) & 1) ? -1.f : 1.f;
+    F[i] = make_float2(v.x * sg, v.y * sg);
+}
+
+struct SvaEvalP {
+    CubeView cv; const uint32_t *samples; const float *bandw; const float2 *F; int S, N;
+    int S_used; float rmax2;
+    int ncand, nrot, use_wedge;   // candidates per volume; 1 .. nrot are the rotated ones
+    const float *wedges;          // [n_vol][2]
+    const double *poses;          // [n_vol][12] N row-major + shift
+    const double *delta;          // [n_vol][ncand][6]
+    double *out;                  // [n_vol][ncand]
+};
+
+// Block = one sub-volume: thread q < ncand derives candidate q's pose in double precision (rotations about the specimen
+// axes, then the shift, exactly like a particle unit of k_csp_eval).  Candidate layout (host): 0 = the unit's own pose (or the
+// trial pose), 1 .. nrot = rotated candidates (one gather each), the rest keep candidate 0's rotation (shift variants: they
+// share its gather).  Every thread accumulates its samples' sums in registers (static indices); the block combines them
+// through LDS in a fixed order.
+__global__ void __launch_bounds__(256) k_sva_eval(SvaEvalP P) {
+    __shared__ float cm[kMaxCand][9], csh[kMaxCand][3];
+    __shared__ float red[4][2 * kMaxCand + 1];
+    const int v = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ncand = P.ncand, nrot = P.nrot;
+    if (tid < ncand) {
+        const double *d = P.delta + ((size_t)v * ncand + tid) * 6, *pose = P.poses + (size_t)v * 12;
+        double Nm[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) Nm[k] = pose[k];
+        for (int k = 0; k < 3; k++)
+            if (d[k] != 0.0) { double R[9], T[9]; d_rot_xyz(k, d[k], R); d_mat_mul3(Nm, R, T); for (int q = 0; q < 9; q++) Nm[q] = T[q]; }
+#pragma unroll
+        for (int k = 0; k < 9; k++) cm[tid][k] = (float)Nm[k];
+        for (int k = 0; k < 3; k++) csh[tid][k] = (float)(pose[9 + k] + d[3 + k]);
+    }
+    __syncthreads();
+    const float lw = P.wedges[2 * v], uw = P.wedges[2 * v + 1], invN = 1.0f / (float)P.N;
+    const float2 *F = P.F + (size_t)v * P.S;
+    float A[kMaxCand], B[kMaxGroup], Csum = 0.f;
+#pragma unroll
+    for (int c = 0; c < kMaxCand; c++) A[c] = 0.f;
+#pragma unroll
+    for (int g = 0; g < kMaxGroup; g++) B[g] = 0.f;
+    for (int s = tid; s < P.S_used; s += 256) {
+        int kx, ky, kz; sva_unpack(P.samples[s], kx, ky, kz);
+        float w = P.bandw[s];
+        if (!((float)(kx * kx + ky * ky + kz * kz) < P.rmax2)) w = 0.f;
+        if (P.use_wedge && !(kx == 0 && kz == 0)) {
+            float a = atan2f((float)kz, (float)kx) * 57.29577951308232f;
+            if (a > 90.f) a -= 180.f;
+            if (a <= -90.f) a += 180.f;
+            if (!(a >= lw && a <= uw)) w = 0.f;
+        }
+        const float2 iv = F[s];
+        const float fkx = (float)kx, fky = (float)ky, fkz = (float)kz;
+        const float wx = w * iv.x, wy = w * iv.y;
+        Csum += wx * iv.x + wy * iv.y;
+        auto gather = [&](int c) {
+            const float *m = cm[c];
+            return sample_cube(P.cv, m[0] * fkx + m[1] * fky + m[2] * fkz, m[3] * fkx + m[4] * fky + m[5] * fkz, m[6] * fkx + m[7] * fky + m[8] * fkz);
+        };
+        auto corr = [&](const float2 p, int c) {
+            float rev = (fkx * csh[c][0] + fky * csh[c][1] + fkz * csh[c][2]) * invN;
+            rev -= floorf(rev);
+            const float sn = __sinf(6.283185307179586f * rev), cs = __cosf(6.283185307179586f * rev);
+            return wx * (p.x * cs - p.y * sn) + wy * (p.x * sn + p.y * cs);
+        };
+        const float2 p0 = gather(0);
+        B[0] += w * (p0.x * p0.x + p0.y * p0.y);
+        A[0] += corr(p0, 0);
+#pragma unroll
+        for (int c = 1; c < kMaxGroup; c++)
+            if (c <= nrot) { const float2 p = gather(c); B[c] += w * (p.x * p.x + p.y * p.y); A[c] += corr(p, c); }
+#pragma unroll
+        for (int c = 1; c < kMaxCand; c++)
+            if (c > nrot && c < ncand) A[c] += corr(p0, c);
+    }
+#pragma unroll
+    for (int c = 0; c < kMaxCand; c++) { const float t = wave_sum(A[c]); if (lane == 0) red[wave][c] = t; }
+#pragma unroll
+    for (int g = 0; g < kMaxGroup; g++) { const float t = wave_sum(B[g]); if (lane == 0) red[wave][kMaxCand + g] = t; }
+    { const float t = wave_sum(Csum); if (lane == 0) red[wave][2 * kMaxCand] = t; }
+    __syncthreads();
+    if (tid < ncand) {
+        const int g = (tid >= 1 && tid <= nrot) ? tid : 0;
+        const double a = (((double)red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+        const double b = (((double)red[0][kMaxCand + g] + red[1][kMaxCand + g]) + red[2][kMaxCand + g]) + red[3][kMaxCand + g];
+        const double c = (((double)red[0][2 * kMaxCand] + red[1][2 * kMaxCand]) + red[2][2 * kMaxCand]) + red[3][2 * kMaxCand];
+        P.out[(size_t)v * ncand + tid] = (b > 0 && c > 0) ? a / sqrt(b * c) : 0.0;
+    }
+}
+
+}  // namespace ppm

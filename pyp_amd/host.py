@@ -73,6 +73,28 @@ class Reference:
         del keep
         return rows, particles, tilts
 
+    def sva_align(self, cfg, volumes, wedges, poses):
+        """Sub-tomogram alignment (ppm_sva_align): volumes (V, N, N, N) float32 (numpy or CUDA tensor), wedges (V, 2) tilt limits in
+        degrees, poses (V, 12) = N row-major + shift.  Returns (refined poses, scores)."""
+        poses = np.array(poses, dtype=np.float64, order="C")
+        if poses.ndim != 2 or poses.shape[1] != 12:
+            raise ValueError("ERROR: poses must be (V, 12)")
+        w = np.ascontiguousarray(wedges, dtype=np.float32).reshape(len(poses), 2)
+        scores = np.zeros(len(poses), dtype=np.float64)
+        if hasattr(volumes, "is_cuda") and volumes.is_cuda:
+            if str(volumes.dtype) != "torch.float32" or not volumes.is_contiguous() or volumes.numel() != len(poses) * cfg.box ** 3:
+                raise ValueError("ERROR: device volumes must be contiguous float32 of V * box^3 elements")
+            _sync_producer(volumes)
+            p, on_dev, keep = C.c_void_p(volumes.data_ptr()), 1, volumes
+        else:
+            a = np.ascontiguousarray(volumes.numpy() if hasattr(volumes, "numpy") else volumes, dtype=np.float32)
+            if a.size != len(poses) * cfg.box ** 3:
+                raise ValueError("ERROR: volumes do not match the poses")
+            p, on_dev, keep = lib.ptr(a), 0, a
+        lib.check(lib.load().ppm_sva_align(self.h, C.byref(cfg), p, on_dev, len(poses), lib.ptr(w), lib.ptr(poses), lib.ptr(scores)))
+        del keep
+        return poses, scores
+
     def note(self):
         """Remarks of the last refine() the caller should log ("" if none)."""
         return (lib.load().ppm_refine_note(self.h) or b"").decode(errors="replace")

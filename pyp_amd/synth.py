@@ -323,6 +323,79 @@ def make_tilt_series(n, n_part, tilt_angles, pixel=1.0, snr=0.1, vol=None, seed=
     return vol, stack, rows, particles, tilts
 
 
+def make_subtomograms(n, n_vol, pixel=1.0, snr=0.5, vol=None, seed=20240701, wedge=(-60.0, 60.0), shift_sigma=1.5, device="cpu"):
+    """Synthetic sub-tomograms of `vol`: sub-volume v has the transform ref(N_v k) e^{+2 pi i k.p_v / n} inside the measured
+    wedge (tilt axis y, tilt range `wedge` degrees), zero in the missing wedge, plus white noise.  Returns (vol, volumes
+    (n_vol, n, n, n) float32, poses (n_vol, 12) = N row-major + shift, wedges (n_vol, 2))."""
+    if vol is None:
+        vol = phantom(n)
+    rng = np.random.default_rng(seed)
+    dev = torch.device(device)
+    proj = Projector(vol, dev)                  # 2 x padded centred transform
+    p2 = proj.p
+    k = torch.arange(-n // 2, n // 2, device=dev, dtype=torch.float32)
+    kz, ky, kx = torch.meshgrid(k, k, k, indexing="ij")
+    poses = np.zeros((n_vol, 12))
+    out = torch.empty((n_vol, n, n, n), dtype=torch.float32, device=dev)
+    ang = torch.rad2deg(torch.atan2(kz, kx))
+    ang = torch.where(ang > 90, ang - 180, ang)
+    ang = torch.where(ang <= -90, ang + 180, ang)
+    inw = ((ang >= wedge[0]) & (ang <= wedge[1])) | ((kx == 0) & (kz == 0))
+    band = (kx * kx + ky * ky + kz * kz) < (n / 2 - 1) ** 2
+    flat = proj.f.reshape(-1)
+    for v in range(n_vol):
+        Nm = euler_matrix(rng.uniform(0, 360), np.degrees(np.arccos(rng.uniform(-1, 1))), rng.uniform(0, 360))
+        p = rng.normal(0, shift_sigma, 3)
+        poses[v, :9], poses[v, 9:] = Nm.ravel(), p
+        m = torch.as_tensor(Nm, device=dev, dtype=torch.float32)
+        X = 2 * (m[0, 0] * kx + m[0, 1] * ky + m[0, 2] * kz) + p2 // 2
+        Y = 2 * (m[1, 0] * kx + m[1, 1] * ky + m[1, 2] * kz) + p2 // 2
+        Z = 2 * (m[2, 0] * kx + m[2, 1] * ky + m[2, 2] * kz) + p2 // 2
+        x0, y0, z0 = X.floor(), Y.floor(), Z.floor()
+        fx, fy, fz = X - x0, Y - y0, Z - z0
+        spec = torch.zeros(X.shape, dtype=torch.complex64, device=dev)
+        for dz in (0, 1):
+            for dy in (0, 1):
+                for dx in (0, 1):
+                    xi, yi, zi = (x0 + dx).long(), (y0 + dy).long(), (z0 + dz).long()
+                    ok = (xi >= 0) & (xi < p2) & (yi >= 0) & (yi < p2) & (zi >= 0) & (zi < p2)
+                    idx = (zi.clamp(0, p2 - 1) * p2 + yi.clamp(0, p2 - 1)) * p2 + xi.clamp(0, p2 - 1)
+                    w = (fx if dx else 1 - fx) * (fy if dy else 1 - fy) * (fz if dz else 1 - fz)
+                    spec += torch.where(ok, w, torch.zeros_like(w)) * flat[idx]
+        ramp = torch.exp(2j * math.pi * (kx * float(p[0]) + ky * float(p[1]) + kz * float(p[2])) / n)
+        spec = spec * ramp * (inw & band)
+        real = torch.fft.fftshift(torch.fft.ifftn(torch.fft.ifftshift(spec))).real
+        out[v] = real
+    sig = out.var(dim=(1, 2, 3)).mean()
+    if snr > 0:
+        gen = torch.Generator(device=dev); gen.manual_seed(seed + 1)
+        out = out + float(torch.sqrt(sig / snr)) * torch.randn(out.shape, generator=gen, device=dev)
+    wedges = np.tile(np.asarray(wedge, dtype=np.float32), (n_vol, 1))
+    return vol, out, poses, wedges
+
+
+def perturb_poses(poses, angle_sigma=3.0, shift_sigma=1.0, seed=11):
+    """Copies of (N, shift) poses with small random rotations about the specimen axes and shifts added."""
+    rng = np.random.default_rng(seed)
+    out = poses.copy()
+    for v in range(len(out)):
+        Nm = out[v, :9].reshape(3, 3)
+        for k in range(3):
+            Nm = Nm @ rot_xyz(k, rng.normal(0, angle_sigma))
+        out[v, :9] = Nm.ravel()
+        out[v, 9:] += rng.normal(0, shift_sigma, 3)
+    return out
+
+
+def pose_angle_error(a, b):
+    """Rotation angle (degrees) between the N matrices of two pose tables."""
+    out = []
+    for x, y in zip(a, b):
+        t = (np.trace(x[:9].reshape(3, 3).T @ y[:9].reshape(3, 3)) - 1.0) / 2.0
+        out.append(np.degrees(np.arccos(np.clip(t, -1.0, 1.0))))
+    return np.array(out)
+
+
 def paste_tilt_series(stack, rows, n_tilt, shape=(512, 512), seed=5):
     """Tilt-series images (n_tilt, H, W) with every projection of `stack` pasted at a well-separated integer position of its
     tilt image (IMIND) on a unit-noise background; sets ORIGINAL_X_POSITION (column) / ORIGINAL_Y_POSITION (row) in `rows`
