@@ -1,0 +1,148 @@
+"""Sub-tomogram averaging host side (BASELINE config 5): the `*_volumes.txt` tables 3DAVG exchanges with PYP,
+the conversion between a table line (normal, 4 x 4 alignment matrix) and the particle pose the rest of the path uses, the
+protocol XML fields that set the metric, and the alignment of all sub-volumes of a table against a reference on the GPU.
+
+Table format: tab-separated, header `number lwedge uwedge posX posY posZ geomX geomY geomZ normalX normalY normalZ matrix[0..15]
+magnification[0..2] cutOffset filename` (src/pyp/detect/tomo/core.py:352, src/pyp_main.py:1003); PYP reads normals from
+columns 9-11, the matrix from 12-27 and re-uses cutOffset (31) for the correlation score (src/pyp/inout/metadata/core.py:2578-2610).
+The line -> pose relation is the one the reference applies in spa_euler_angles (src/pyp/analysis/geometry/core.py:238-470) at
+tilt 0 / axis 0 and is pinned by golden vectors it produced (tests/golden/golden_r02.json "sva_matrix_to_particle"):
+
+    N = Sy R^-1 norm^-1 Sy,   norm = Rz(-normalZ) Rx(-normalX) Rz(-normalY),   Sy = diag(1, -1, 1)
+    p = norm_rev^-1 R_rev^-1 tr,   tr = (-a0, a1, -a2),  a = R^-1 t,   R_rev[i][j] = (-1)^(i+j) R[j][i],  norm_rev = Rz(-nY) Rx(-nX) Rz(-nZ)
+
+(R, t = rotation and translation of the matrix).  This is NOT a drop-in of MPI_Classification: its binary side files
+(`*_averages.bin`) are not described anywhere in the reference; what is provided is the alignment step (mode 3 "align all
+volumes to the reference") on the same tables.
+"""
+import os
+import xml.etree.ElementTree as ET
+
+import numpy as np
+
+from .abi import SvaCfg
+from .formats import mrc
+from .synth import rot_xyz
+
+HEADER = ["number", "lwedge", "uwedge", "posX", "posY", "posZ", "geomX", "geomY", "geomZ", "normalX", "normalY", "normalZ"] + \
+         ["matrix[%d]" % i for i in range(16)] + ["magnification[0]", "magnification[1]", "magnification[2]", "cutOffset", "filename"]
+_SY = np.diag([1.0, -1.0, 1.0])
+
+
+def read_volumes(path):
+    """-> (table (V, 32) float64 in HEADER order without the file name, filenames list)."""
+    rows, names = [], []
+    with open(path) as f:
+        for line in f:
+            if not line.strip() or line.startswith("number"):
+                continue
+            parts = line.rstrip("\n").split("\t")
+            if len(parts) < 33:
+                parts = line.split()
+            if len(parts) != 33:
+                raise IOError(f"ERROR: {path}: expected 33 tab-separated columns, got {len(parts)}")
+            rows.append([float(x) for x in parts[:32]])
+            names.append(parts[32].strip())
+    if not rows:
+        raise IOError(f"ERROR: {path}: no sub-volumes listed")
+    return np.array(rows, dtype=np.float64), names
+
+
+def write_volumes(path, table, names):
+    with open(path, "w") as f:
+        f.write("\t".join(HEADER) + "\n")
+        for r, n in zip(np.asarray(table, dtype=np.float64), names):
+            f.write("%d\t" % int(r[0]) + "\t".join("%.6f" % x for x in r[1:32]) + "\t" + n + "\n")
+
+
+def _norm_matrices(normal):
+    nx, ny, nz = (float(x) for x in normal)
+    norm = rot_xyz(2, -nz) @ rot_xyz(0, -nx) @ rot_xyz(2, -ny)
+    norm_rev = rot_xyz(2, -ny) @ rot_xyz(0, -nx) @ rot_xyz(2, -nz)
+    return norm, norm_rev
+
+
+def _reverse(R):
+    s = np.array([[1, -1, 1], [-1, 1, -1], [1, -1, 1]], dtype=np.float64)
+    return (R.T) * s
+
+
+def line_to_pose(normal, matrix):
+    """(N (3, 3), p (3,)) of a table line: the pose convention of ppm_sva_align / the particle block."""
+    m = np.asarray(matrix, dtype=np.float64).reshape(4, 4)
+    R, t = m[:3, :3], m[:3, 3]
+    norm, norm_rev = _norm_matrices(normal)
+    N = _SY @ np.linalg.inv(R) @ np.linalg.inv(norm) @ _SY
+    a = np.linalg.inv(R) @ t
+    tr = np.array([-a[0], a[1], -a[2]])
+    p = np.linalg.inv(norm_rev) @ np.linalg.inv(_reverse(R)) @ tr
+    return N, p
+
+
+def pose_to_matrix(N, p, normal):
+    """The 16 matrix values of a table line that line_to_pose maps back to (N, p), for the line's normal."""
+    norm, norm_rev = _norm_matrices(normal)
+    R = np.linalg.inv(_SY @ np.asarray(N, dtype=np.float64).reshape(3, 3) @ _SY @ norm)
+    tr = _reverse(R) @ norm_rev @ np.asarray(p, dtype=np.float64)
+    a = np.array([-tr[0], tr[1], -tr[2]])
+    m = np.eye(4)
+    m[:3, :3], m[:3, 3] = R, R @ a
+    return m.ravel()
+
+
+def particle_from_pose(N, p):
+    """Stored particle parameters (psi, theta, phi, shift x, y, z) of a pose (what spa_euler_angles hands to the particle block)."""
+    from .synth import angles_from_matrix
+    a = angles_from_matrix(np.asarray(N, dtype=np.float64).reshape(3, 3))
+    return np.array([-a[0], -a[1], -a[2], p[0], p[1], p[2]])
+
+
+def cfg_from_xml(xml_path, box, pixel_size=1.0, mode=None):
+    """ppm_sva_cfg from a 3DAVG protocol file (src/pyp/refine/3DAVG/iteration_*_mode_*.xml as patched by parse_xml,
+    src/pyp/refine/tomo_avg/sub_tomo_avg.py:318-465): image window, band-pass, missing wedge, search ranges of the mode's section."""
+    root = ET.parse(xml_path).getroot()
+    gen = root.find("general")
+    m = int(gen.find("mode").text) if mode is None else int(mode)
+    sec_name = ["mra", "class", "refine", "mra"][m]          # mode 0 (re-centring) uses the mra fields (:349-351)
+    sec = root.find(sec_name)
+
+    def val(tag, default=0.0):
+        e = sec.find(f"{sec_name}_{tag}")
+        return float(e.text) if e is not None and e.text not in (None, "") else default
+    metric = gen.find("metric")
+    wedge = int(metric.find("use_missing_wedge").text) if metric is not None and metric.find("use_missing_wedge") is not None else 1
+    return SvaCfg.make(box, pixel_size, window=(val("image_window_x"), val("image_window_y"), val("image_window_z")),
+                       window_sigma=val("image_window_sigma"), highpass=(val("high_pass_cutoff"), val("high_pass_decay")),
+                       lowpass=(val("low_pass_cutoff"), val("low_pass_decay")), use_missing_wedge=wedge,
+                       tol_angle=val("out_of_plane_search_range"), tol_shift=val("shifts_tolerance"))
+
+
+def align_table(reference, table, names, cfg, base_dir=".", device=0, chunk=64, max_band_px=None):
+    """Align every sub-volume of a table to `reference` (N^3 array): returns the refined table (matrix columns replaced, the
+    correlation score in cutOffset) and the scores.  Sub-volumes are read chunk by chunk (10 k x 192^3 is 283 GB)."""
+    from . import host
+    n = int(cfg.box)
+    ref = host.Reference(reference, n / 2 if max_band_px is None else max_band_px, device=device)
+    out = np.array(table, dtype=np.float64, copy=True)
+    scores = np.zeros(len(out))
+    try:
+        for lo in range(0, len(out), chunk):
+            hi = min(lo + chunk, len(out))
+            vols = np.empty((hi - lo, n, n, n), dtype=np.float32)
+            poses = np.zeros((hi - lo, 12))
+            for k in range(lo, hi):
+                fn = names[k] if os.path.isabs(names[k]) else os.path.join(base_dir, names[k])
+                v = mrc.read(fn)
+                if v.shape != (n, n, n):
+                    raise ValueError(f"ERROR: {fn} is {v.shape}, expected {n}^3")
+                vols[k - lo] = v
+                N, p = line_to_pose(out[k, 9:12], out[k, 12:28])
+                poses[k - lo, :9], poses[k - lo, 9:] = N.ravel(), p
+            got, sc = ref.sva_align(cfg, vols, out[lo:hi, 1:3].astype(np.float32), poses)
+            for k in range(lo, hi):
+                out[k, 12:28] = pose_to_matrix(got[k - lo, :9], got[k - lo, 9:], out[k, 9:12])
+                out[k, 31] = sc[k - lo]
+            scores[lo:hi] = sc
+    finally:
+        ref.close()
+    return out, scores

@@ -68,3 +68,79 @@ def test_gpu_alignment_errors_are_loud():
         g.sva_align(cfg_for(32), vols.numpy(), wedges, poses)
     with pytest.raises(lib.PpmError, match="ERROR"):
         host.Reference(vol, 16).sva_align(cfg_for(48), np.zeros((2, 48, 48, 48), np.float32), wedges, poses)
+
+
+def test_table_line_to_pose_matches_reference_spa_euler_angles():
+    """A 3DAVG line (normal, 4 x 4 matrix) -> the particle pose PYP derives from it (spa_euler_angles at tilt 0, geometry/core.py:238-470;
+    golden produced by that function), and the inverse used when the refined pose is written back."""
+    import json
+    import os
+    from pyp_amd import sva
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_r02.json")))["sva_matrix_to_particle"]
+    for c in gold:
+        N, p = sva.line_to_pose(c["normal"], c["matrix"])
+        want = np.array(c["particle"])
+        assert np.abs(N - synth.euler_matrix(-want[0], -want[1], -want[2])).max() < 1e-9
+        assert np.abs(p - want[3:]).max() < 1e-9
+        got = sva.particle_from_pose(N, p)
+        assert np.abs(synth.euler_matrix(-got[0], -got[1], -got[2]) - N).max() < 1e-9 and np.allclose(got[3:], want[3:])
+        back = sva.pose_to_matrix(N, p, c["normal"])
+        assert np.abs(back - np.array(c["matrix"])).max() < 1e-9
+
+
+def test_volumes_table_roundtrip_and_protocol_fields(tmp_path):
+    from pyp_amd import sva
+    tab = np.zeros((3, 32))
+    tab[:, 0] = [1, 2, 3]; tab[:, 1] = -60; tab[:, 2] = 60; tab[:, 3:6] = [[10, 20, 30]] * 3
+    for k in range(3):
+        tab[k, 12:28] = np.eye(4).ravel()
+    names = ["TS_01_spk0000.rec", "TS_01_spk0001.rec", "sub/TS_02_vir0001_spk0003.mrc"]
+    sva.write_volumes(str(tmp_path / "d_volumes.txt"), tab, names)
+    t2, n2 = sva.read_volumes(str(tmp_path / "d_volumes.txt"))
+    assert np.allclose(t2, tab) and n2 == names
+    assert open(tmp_path / "d_volumes.txt").readline().startswith("number\tlwedge\tuwedge\tposX")
+    xml = tmp_path / "iteration_002_mode_3.xml"
+    xml.write_text("""<?xml version="1.0"?><config><general><mode>3</mode><metric><use_missing_wedge>1</use_missing_wedge></metric></general>
+      <refine><refine_image_window_x>20</refine_image_window_x></refine>
+      <mra><mra_image_window_x>32</mra_image_window_x><mra_image_window_y>32</mra_image_window_y><mra_image_window_z>28</mra_image_window_z>
+      <mra_image_window_sigma>4</mra_image_window_sigma><mra_high_pass_cutoff>.05</mra_high_pass_cutoff><mra_high_pass_decay>.01</mra_high_pass_decay>
+      <mra_low_pass_cutoff>0.125</mra_low_pass_cutoff><mra_low_pass_decay>.05</mra_low_pass_decay>
+      <mra_out_of_plane_search_range>15</mra_out_of_plane_search_range><mra_shifts_tolerance>10.0</mra_shifts_tolerance></mra></config>""")
+    c = sva.cfg_from_xml(str(xml), 96)
+    assert (c.box, list(c.window), c.window_sigma) == (96, [32.0, 32.0, 28.0], 4.0)
+    assert abs(c.lowpass_cutoff - 0.125) < 1e-7 and abs(c.highpass_decay - 0.01) < 1e-7 and c.tol_angle == 15.0 and c.tol_shift == 10.0 and c.use_missing_wedge == 1
+
+
+@pytest.mark.gpu
+def test_sva_align_executable_refines_a_table(tmp_path):
+    import os
+    import subprocess
+    import sys
+    from pyp_amd import sva
+    from pyp_amd.formats import mrc
+    n = 32
+    vol, vols, poses, wedges = synth.make_subtomograms(n, 5, snr=0.5)
+    start = synth.perturb_poses(poses, 3.0, 1.0)
+    tab = np.zeros((5, 32)); names = []
+    for k in range(5):
+        tab[k, 0], tab[k, 1], tab[k, 2] = k + 1, wedges[k, 0], wedges[k, 1]
+        tab[k, 9:12] = [10.0 * k, 0.0, -20.0 * k]
+        tab[k, 12:28] = sva.pose_to_matrix(start[k, :9], start[k, 9:], tab[k, 9:12])
+        names.append(f"TS_01_spk{k:04d}.rec")
+        mrc.write(vols[k].numpy(), str(tmp_path / names[-1]))
+    sva.write_volumes(str(tmp_path / "d_volumes.txt"), tab, names)
+    mrc.write(vol, str(tmp_path / "ref.mrc"))
+    (tmp_path / "p.xml").write_text("""<config><general><mode>2</mode><metric><use_missing_wedge>1</use_missing_wedge></metric></general>
+      <refine><refine_image_window_x>12</refine_image_window_x><refine_image_window_y>12</refine_image_window_y><refine_image_window_z>12</refine_image_window_z>
+      <refine_image_window_sigma>2</refine_image_window_sigma><refine_high_pass_cutoff>.03</refine_high_pass_cutoff><refine_high_pass_decay>.01</refine_high_pass_decay>
+      <refine_low_pass_cutoff>0.30</refine_low_pass_cutoff><refine_low_pass_decay>.04</refine_low_pass_decay>
+      <refine_out_of_plane_search_range>10</refine_out_of_plane_search_range><refine_shifts_tolerance>4.0</refine_shifts_tolerance></refine></config>""")
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bin", "sva_align")
+    r = subprocess.run([sys.executable, exe, "p.xml", "d_volumes.txt", "ref.mrc", "out_volumes.txt"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0 and "SVA: Normal termination" in r.stdout, r.stdout + r.stderr
+    out, n2 = sva.read_volumes(str(tmp_path / "out_volumes.txt"))
+    got = np.array([np.concatenate([sva.line_to_pose(out[k, 9:12], out[k, 12:28])[0].ravel(), sva.line_to_pose(out[k, 9:12], out[k, 12:28])[1]]) for k in range(5)])
+    assert synth.pose_angle_error(got, poses).mean() < 0.4 * synth.pose_angle_error(start, poses).mean()
+    assert np.linalg.norm(got[:, 9:] - poses[:, 9:], axis=1).max() < 0.2 and (out[:, 31] > 0.8).all() and np.array_equal(out[:, 9:12], tab[:, 9:12])
+    r = subprocess.run([sys.executable, exe, "p.xml", "missing.txt", "ref.mrc", "o.txt"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode != 0 and "ERROR" in r.stdout and not (tmp_path / "o.txt").exists()
