@@ -217,7 +217,7 @@ typedef struct ppm_sva_cfg {
     float tol_shift;        /* <mode>_shifts_tolerance, pixels */
     float step_tolerance;   /* smallest compass step (default 0.05 degrees / pixels) */
     int max_iterations;     /* 0 = until the step falls below step_tolerance, at most 12 */
-    float band_factor;      /* frequency marching as in ppm_refine_cfg (0 = default 3, < 0 = off) */
+    float band_factor;      /* frequency marching like the band_factor field of the refinement settings (0 = default 3, < 0 = off) */
 } ppm_sva_cfg;
 /* volumes: n_vol * box^3 floats (x fastest); wedges: n_vol x {lwedge, uwedge} tilt limits in degrees (tilt axis = y);
  * poses: n_vol x 12 doubles {N row-major (9), shift x y z (pixels)}, start values in, refined values out; scores: n_vol. */
