@@ -1,6 +1,6 @@
 // ppm_sva_kernels.h — sub-tomogram alignment kernels of libpypmatch (gfx950): pre-processing of a sub-volume into its
 // band-limited half-space transform, and the wedge-weighted correlation of that transform with the rotated reference for a
-// set of candidate poses (include/ppm.h, ppm_sva_cfg; CPU restatement: oracle/ppm_oracle.c, orc_sva_align).
+// set of candidate poses (include/ppm.h, ppm_sva_cfg).
 #pragma once
 #include "ppm_csp_kernels.h"
 
