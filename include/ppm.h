@@ -153,6 +153,12 @@ typedef struct ppm_csp_cfg {
     int max_iterations;     /* compass iterations; 0 = until the step falls below step_tolerance, at most 12 */
     int tind_min, tind_max; /* rows with TIND outside do not enter a unit's score (csp_UseImagesForRefinementMin / Max; max < 0 = no limit) */
     int first, last;        /* units to refine: PIND (particles) or TIND (tilts) in first..last; last < 0 = up to the end */
+    /* csp mode 4 (tilts only; excludes the geometric parameters): one defocus offset per tilt, -range .. +range in steps, added
+     * to DEFOCUS_1 and DEFOCUS_2 of all its rows; the offset with the best mean score of the usable rows wins (the unshifted
+     * values on ties, then the lower offset) */
+    int refine_defocus;
+    float defocus_range;    /* csp_ToleranceMicrographDefocus1, Angstrom */
+    float defocus_step;     /* Angstrom (default 50); at most PPM_MAX_DEFOCUS_STEPS either side */
 } ppm_csp_cfg;
 
 #define PPM_STATS_COLS 7 /* shell, resolution A, ring radius, FSC, part-FSC, part-SSNR, rec-SSNR

@@ -1125,6 +1125,50 @@ int orc_csp_refine(void *refp, const ppm_refine_cfg *cfg, const ppm_csp_cfg *cc,
             ctf_init(&c.ctf[j], rows + (size_t)j * PPM_NCOL, g.N, g.a);
         }
     }
+    if (cc->refine_defocus && cc->unit == PPM_CSP_MICROGRAPHS && !err) {
+        /* csp mode 4: one defocus offset per tilt, scored at the rows' current poses and the full band */
+        int nt = 0;
+        const double step = cc->defocus_step > 0 ? cc->defocus_step : 50.0;
+        if (cc->defocus_range >= step) { nt = (int)floor(cc->defocus_range / step + 1e-6); if (nt > PPM_MAX_DEFOCUS_STEPS) nt = PPM_MAX_DEFOCUS_STEPS; }
+        long nev4 = 0;
+        for (int u = 0; u < n_tilt; u++) {
+            long id = (long)tilts[(size_t)u * PPM_NTCOL];
+            if (id < cc->first || (cc->last >= 0 && id > cc->last)) continue;
+            double best = -1e300; int bt = 0;
+            for (int pass = 0; pass < 2; pass++) {           /* the unshifted values first (they win ties), then -nt .. nt */
+                for (int t = (pass ? -nt : 0); t <= (pass ? nt : 0); t++) {
+                    if (pass && t == 0) continue;
+                    double ssum = 0; int sn = 0;
+                    for (int j = 0; j < n_proj; j++) {
+                        if (row_tilt[j] != u || !usable[j]) continue;
+                        ctf_t c2 = c.ctf[j]; c2.df1 += t * step; c2.df2 += t * step;
+                        double M[9], g2[2], sh[2];
+                        csp_row_pose(parts[row_part[j]].N, parts[row_part[j]].p, tls[u].tl[0], tls[u].tl[1], tls[u].tl[2], tls[u].tl[3], M, g2);
+                        sh[0] = s0[2 * j] + g2[0] - g0[2 * j]; sh[1] = s0[2 * j + 1] + g2[1] - g0[2 * j + 1];
+                        ssum += score_local(r, &g, &c2, c.I[j], c.wr[j], g.r_hi, M, sh); sn++; nev4++;
+                    }
+                    if (sn && ssum / sn > best) { best = ssum / sn; bt = t; }
+                }
+            }
+            for (int j = 0; j < n_proj; j++) {
+                if (row_tilt[j] != u) continue;
+                double *row = rows + (size_t)j * PPM_NCOL;
+                row[PPM_DF1] += bt * step; row[PPM_DF2] += bt * step;
+                ctf_t c2; ctf_init(&c2, row, g.N, g.a);
+                double M[9], g2[2], sh[2];
+                csp_row_pose(parts[row_part[j]].N, parts[row_part[j]].p, tls[u].tl[0], tls[u].tl[1], tls[u].tl[2], tls[u].tl[3], M, g2);
+                sh[0] = s0[2 * j] + g2[0] - g0[2 * j]; sh[1] = s0[2 * j + 1] + g2[1] - g0[2 * j + 1];
+                double cc2 = score_local(r, &g, &c2, c.I[j], c.wr[j], g.r_hi, M, sh), res = 1.0 - cc2 * cc2; nev4++;
+                if (res < 1e-6) res = 1e-6;
+                row[PPM_SCORE] = 100.0 * cc2; row[PPM_SIGMA] = sqrt(res);
+                row[PPM_LOGP] = -0.5 * (ORC_PI * (g.r_hi * g.r_hi - g.r_lo * g.r_lo)) * (log(2.0 * ORC_PI * res) + 1.0);
+            }
+        }
+        if (eval_count) *eval_count = nev4;
+        for (int j = 0; j < n_proj; j++) { free(c.I[j]); free(c.wr[j]); }
+        free(c.I); free(c.wr); free(c.ctf); free(row_part); free(row_tilt); free(s0); free(g0); free(usable); free(parts); free(tls);
+        return 0;
+    }
     const int kind = cc->unit, nu_all = kind == PPM_CSP_PARTICLES ? n_part : n_tilt;
     int en[6] = { 0, 0, 0, 0, 0, 0 }; double tol[6] = { 0, 0, 0, 0, 0, 0 };
     if (kind == PPM_CSP_PARTICLES) {

@@ -65,15 +65,17 @@ class CspCfg(C.Structure):
     """ppm_csp_cfg (include/ppm.h)."""
     _fields_ = [("unit", C.c_int), ("refine_rotation", C.c_int), ("refine_translation", C.c_int), ("tol_angle", C.c_float * 3),
                 ("tol_shift", C.c_float), ("step_tolerance", C.c_float), ("max_iterations", C.c_int), ("tind_min", C.c_int),
-                ("tind_max", C.c_int), ("first", C.c_int), ("last", C.c_int)]
+                ("tind_max", C.c_int), ("first", C.c_int), ("last", C.c_int), ("refine_defocus", C.c_int),
+                ("defocus_range", C.c_float), ("defocus_step", C.c_float)]
 
     @classmethod
     def make(cls, unit, refine_rotation=1, refine_translation=1, tol_angle=(30.0, 30.0, 30.0), tol_shift=20.0, step_tolerance=0.01,
-             max_iterations=0, tind_min=0, tind_max=-1, first=0, last=-1):
+             max_iterations=0, tind_min=0, tind_max=-1, first=0, last=-1, refine_defocus=0, defocus_range=750.0, defocus_step=50.0):
         return cls(unit=int(unit), refine_rotation=int(refine_rotation), refine_translation=int(refine_translation),
                    tol_angle=(C.c_float * 3)(*[float(x) for x in tol_angle]), tol_shift=float(tol_shift),
                    step_tolerance=float(step_tolerance), max_iterations=int(max_iterations), tind_min=int(tind_min),
-                   tind_max=int(tind_max), first=int(first), last=int(last))
+                   tind_max=int(tind_max), first=int(first), last=int(last), refine_defocus=int(refine_defocus),
+                   defocus_range=float(defocus_range), defocus_step=float(defocus_step))
 
 
 class SvaCfg(C.Structure):

@@ -389,6 +389,7 @@ struct DefocusP {
     const double *rows; LState *states; float *ddef;   // ddef[n]: offset chosen (Angstrom)
     int nt; float step;
     int tchunk;            // offsets scored per pass over the samples (sizes the dynamic LDS)
+    double *all_scores;    // null, or [n][2 nt + 1]: every offset's score is written out and nothing is chosen (constrained search)
 };
 
 __global__ void __launch_bounds__(256) k_defocus(DefocusP P) {
@@ -463,6 +464,10 @@ __global__ void __launch_bounds__(256) k_defocus(DefocusP P) {
             }
         }
         __syncthreads();
+    }
+    if (P.all_scores) {
+        if (tid < T) P.all_scores[(size_t)p * T + tid] = score[tid];
+        return;
     }
     if (tid == 0) {
         int bt = P.nt; double bf = score[P.nt];                  // the unshifted CTF is the incumbent

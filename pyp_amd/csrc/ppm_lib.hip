@@ -648,7 +648,7 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
             DefocusP DP;
             DP.cv = cv; DP.samples = ref->samples.p; DP.Il = ref->Il.p; DP.wring = ref->wring.p; DP.S_pad = S_pad; DP.nrings = nrings; DP.N = gm.N; DP.B = gm.B;
             DP.rlo2 = (float)(gm.r_lo * gm.r_lo); DP.rmax2 = (float)(gm.r_hi * gm.r_hi); DP.ring_signed = LP.ring_signed; DP.a = (float)gm.a;
-            DP.rows = ref->rows_in.p; DP.states = final_states; DP.ddef = ref->ddef.p; DP.nt = ndef; DP.step = cfg->defocus_step;
+            DP.rows = ref->rows_in.p; DP.states = final_states; DP.ddef = ref->ddef.p; DP.nt = ndef; DP.step = cfg->defocus_step; DP.all_scores = nullptr;
             const int T = 2 * ndef + 1;
             DP.tchunk = std::max(1, std::min(T, (int)(60000 / (16 * (size_t)nrings))));      // per-wave ring tables of one pass stay below 64 KB
             ProfScope ps(PPM_K_LOCAL);
@@ -1036,14 +1036,19 @@ extern "C" int ppm_csp_refine(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const p
     HIPCHK(hipMemcpyAsync(ref->samples.p, sl.packed.data(), S_pad * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
     DevBuf<float2> Il, band; DevBuf<float> cw, img; DevBuf<double> d_rows, d_N, d_p, d_tl, d_delta, d_s0, d_g0, d_out;
     DevBuf<int> d_eval, d_rp, d_rt, d_slot;
+    DevBuf<float> wring; DevBuf<LState> d_states;
+    const bool mode4 = cc->refine_defocus != 0;
+    if (mode4 && kind != PPM_CSP_MICROGRAPHS) return fail(-22, "csp: defocus refinement works on tilts (unit = micrographs)");
     struct Cleanup { std::vector<std::function<void()>> f; ~Cleanup() { for (auto &x : f) x(); } } cleanup;
     cleanup.f = { [&] { Il.release(); band.release(); cw.release(); img.release(); d_rows.release(); d_N.release(); d_p.release(); d_tl.release();
-                        d_delta.release(); d_s0.release(); d_g0.release(); d_out.release(); d_eval.release(); d_rp.release(); d_rt.release(); d_slot.release(); } };
+                        d_delta.release(); d_s0.release(); d_g0.release(); d_out.release(); d_eval.release(); d_rp.release(); d_rt.release(); d_slot.release();
+                        wring.release(); d_states.release(); } };
     const int CH = (int)std::min<size_t>((size_t)n_proj, std::max<size_t>(64, ((size_t)2 << 30) / (NN * 4 + HW * 8)));
     if (int rc = Il.ensure((size_t)n_proj * S_pad)) return rc;
     if (int rc = cw.ensure((size_t)n_proj * S_pad)) return rc;
     if (int rc = band.ensure((size_t)CH * HW)) return rc;
     if (int rc = d_rows.ensure((size_t)n_proj * PPM_NCOL)) return rc;
+    if (mode4) if (int rc = wring.ensure((size_t)n_proj * (gm.B + 2))) return rc;
     if (!images_on_device) if (int rc = img.ensure((size_t)CH * NN)) return rc;
     HIPCHK(hipMemcpyAsync(d_rows.p, rows, (size_t)n_proj * PPM_NCOL * sizeof(double), hipMemcpyHostToDevice, g.stream));
     const double fall = cfg->mask_falloff > 0 ? cfg->mask_falloff : 20.0;
@@ -1055,8 +1060,51 @@ extern "C" int ppm_csp_refine(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const p
             d_img = img.p;
         }
         if (int rc = launch_prep(d_img, d_rows.p + (size_t)c0 * PPM_NCOL, nb, gm, (float)rm_px, (float)(fall / gm.a), cfg->normalize, cfg->invert, 1, 1,
-                                 band.p, nullptr, ref->samples.p, S_pad, Il.p + (size_t)c0 * S_pad, cw.p + (size_t)c0 * S_pad, nullptr, nullptr, nullptr)) return rc;
+                                 band.p, mode4 ? wring.p + (size_t)c0 * (gm.B + 2) : nullptr, ref->samples.p, S_pad, Il.p + (size_t)c0 * S_pad, cw.p + (size_t)c0 * S_pad, nullptr, nullptr, nullptr)) return rc;
         HIPCHK(hipStreamSynchronize(g.stream));
+    }
+    if (mode4) {
+        // ---- csp mode 4: every row's score for every defocus offset in one sweep (k_defocus), averaged per tilt on the host
+        const double step = cc->defocus_step > 0 ? cc->defocus_step : 50.0;
+        int nt = 0;
+        if (cc->defocus_range >= step) nt = std::min((int)std::floor(cc->defocus_range / step + 1e-6), PPM_MAX_DEFOCUS_STEPS);
+        const int Tn = 2 * nt + 1;
+        if (int rc = d_states.ensure(n_proj)) return rc;
+        if (int rc = d_out.ensure((size_t)n_proj * Tn)) return rc;
+        hipLaunchKernelGGL(k_states_from_rows, dim3((n_proj + 255) / 256), dim3(256), 0, g.stream, d_rows.p, d_states.p, n_proj, gm.a, 1.0, 1.0);
+        DefocusP DP;
+        DP.cv.cube = ref->cube; DP.cv.NBX = ref->NBX; DP.cv.NBY = ref->NBY; DP.cv.LB = ref->LB; DP.cv.off = ref->B + 1; DP.cv.scale = (float)ref->pad;
+        DP.samples = ref->samples.p; DP.Il = Il.p; DP.wring = wring.p; DP.S_pad = S_pad; DP.nrings = nrings; DP.N = gm.N; DP.B = gm.B;
+        DP.rlo2 = (float)(gm.r_lo * gm.r_lo); DP.rmax2 = (float)(gm.r_hi * gm.r_hi); DP.ring_signed = (float)std::min(gm.ring_signed, 1e30); DP.a = (float)gm.a;
+        DP.rows = d_rows.p; DP.states = d_states.p; DP.ddef = nullptr; DP.nt = nt; DP.step = (float)step; DP.all_scores = d_out.p;
+        DP.tchunk = std::max(1, std::min(Tn, (int)(60000 / (16 * (size_t)nrings))));
+        {
+            ProfScope ps(PPM_K_LOCAL);
+            hipLaunchKernelGGL(k_defocus, dim3(n_proj), dim3(256), ring_lds_bytes(4, DP.tchunk, nrings), g.stream, DP);
+        }
+        HIPCHK(hipGetLastError());
+        std::vector<double> sc((size_t)n_proj * Tn);
+        HIPCHK(hipMemcpyAsync(sc.data(), d_out.p, sc.size() * sizeof(double), hipMemcpyDeviceToHost, g.stream));
+        HIPCHK(hipStreamSynchronize(g.stream));
+        for (int u = 0; u < n_tilt; u++) {
+            if (!refined[u]) continue;
+            double best = -1e300; int bt = nt;
+            for (int pass = 0; pass < 2; pass++)
+                for (int t = (pass ? 0 : nt); t < (pass ? Tn : nt + 1); t++) {
+                    if (pass && t == nt) continue;
+                    double ssum = 0; int sn = 0;
+                    for (int j : urows[u]) if (usable[j]) { ssum += sc[(size_t)j * Tn + t]; sn++; }
+                    if (sn && ssum / sn > best) { best = ssum / sn; bt = t; }
+                }
+            for (int j : urows[u]) {
+                double *row = rows + (size_t)j * PPM_NCOL;
+                row[PPM_DF1] += (bt - nt) * step; row[PPM_DF2] += (bt - nt) * step;
+                const double ccv = sc[(size_t)j * Tn + bt]; double res = 1.0 - ccv * ccv; if (res < 1e-6) res = 1e-6;
+                row[PPM_SCORE] = 100.0 * ccv; row[PPM_SIGMA] = std::sqrt(res);
+                row[PPM_LOGP] = -0.5 * (kPi * (gm.r_hi * gm.r_hi - gm.r_lo * gm.r_lo)) * (std::log(2.0 * kPi * res) + 1.0);
+            }
+        }
+        return 0;
     }
     // ---- static tables
     if (int rc = d_rp.ensure(n_proj)) return rc;

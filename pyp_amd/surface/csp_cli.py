@@ -11,7 +11,7 @@ Modes (src/pyp/align/core.py:1015-1023 and the 2 -> 5, 3 -> 6 remaps of local_ru
    -2  extract the projections of particles first..last from the tilt series into <stack>
     1 / 2 / 5  particle rotations / 3-D shifts / both, particles first..last (PIND)
     0 / 3 / 6  tilt angle + axis / image shifts / both, tilts first..last (TIND; last = -1: up to the end)
-    4  per-tilt defocus: not built (fails loudly)
+    4  one defocus offset per tilt (csp_ToleranceMicrographDefocus1 either side, 50 A steps), tilts first..last
 Outputs of a refinement mode: <param>_<first:06d>_<last:06d>.cistem with the rows of the refined units only and its
 _extended twin holding only the refined units' block entries (the caller merges them over the original,
 src/pyp/refine/csp/particle_cspt.py:96-138 -> cistem_star_file.py:655-692).
@@ -75,7 +75,7 @@ def _settings(p):
         tol_p_rot=(float(p.get("csp_ToleranceParticlesPsi", 30.0)), float(p.get("csp_ToleranceParticlesTheta", 30.0)), float(p.get("csp_ToleranceParticlesPhi", 30.0))),
         tol_p_shift=float(p.get("csp_ToleranceParticlesShifts", 20.0)),
         tol_m_rot=(float(p.get("csp_ToleranceMicrographTiltAngles", 1.5)), float(p.get("csp_ToleranceMicrographTiltAxisAngles", 1.0)), 0.0),
-        tol_m_shift=float(p.get("csp_ToleranceMicrographShifts", 100.0)),
+        tol_m_shift=float(p.get("csp_ToleranceMicrographShifts", 100.0)), tol_defocus=float(p.get("csp_ToleranceMicrographDefocus1", 750.0)),
         normalize=int(bool(p.get("reconstruct_norm", True))), invert=int(bool(p.get("refine_invert", False))),
         data_set=str(p.get("data_set", "")))
 
@@ -108,9 +108,7 @@ def csp_main(argv=None):
     particles, tilts = ext["particles"], ext["tilts"]
     if mode == -2:
         return _extract(s, rows, first, last, images, stack, t0)
-    if mode == 4:
-        _die("ERROR: csp: mode 4 (per-tilt defocus refinement) is not supported by this build")
-    if mode not in (0, 1, 2, 3, 5, 6):
+    if mode not in (0, 1, 2, 3, 4, 5, 6):
         _die(f"ERROR: csp: unknown mode {mode}")
     unit = CSP_PARTICLES if mode in (1, 2, 5) else CSP_MICROGRAPHS
     rot, trans = mode in (0, 1, 5, 6), mode in (2, 3, 5, 6)
@@ -138,7 +136,7 @@ def csp_main(argv=None):
     px = float(rin[0, C["PIXEL_SIZE"]]) if rin[0, C["PIXEL_SIZE"]] > 0 else s["pixel"]
     cfg = RefineCfg.make(box=box, pixel_size=px, molecular_mass_kda=s["mw"], mask_radius=s["radius"], res_low=s["res_low"], res_high=s["res_high"],
                          res_signed_cc=s["res_signed"], global_search=0, local_refine=1, normalize=s["normalize"], invert=s["invert"])
-    cc = CspCfg.make(unit, refine_rotation=rot, refine_translation=trans,
+    cc = CspCfg.make(unit, refine_rotation=rot, refine_translation=trans, refine_defocus=int(mode == 4), defocus_range=s["tol_defocus"],
                      tol_angle=s["tol_p_rot"] if unit == CSP_PARTICLES else s["tol_m_rot"],
                      tol_shift=(s["tol_p_shift"] if unit == CSP_PARTICLES else s["tol_m_shift"]) / px,        # the tolerances are in Angstrom
                      step_tolerance=s["step_tol"], tind_min=s["tind_min"], tind_max=s["tind_max"], first=first, last=last)

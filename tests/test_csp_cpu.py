@@ -114,6 +114,34 @@ def test_oracle_recovers_tilt_shifts_and_respects_bounds(series):
     assert np.allclose(a[:, 1:7], b[:, 1:7])
 
 
+def defocus_series():
+    """1 A / pixel, band 28 of 32 Fourier pixels: a 100 A defocus error moves the CTF phase by ~1.2 rad at the band edge."""
+    n, px = 64, 1.0
+    vol, stack, rows, parts, tilts = synth.make_tilt_series(n, 8, np.arange(-48, 49, 16.0), pixel=px, snr=2.0)
+    cfg = RefineCfg.make(box=n, pixel_size=px, mask_radius=0.4 * n * px, res_high=px * n / 28, res_signed_cc=30.0, global_search=0)
+    return n, px, vol, stack.numpy(), rows, parts, tilts, cfg
+
+
+def test_oracle_recovers_per_tilt_defocus_offsets():
+    """csp mode 4: one defocus offset per tilt from the mean score of its rows."""
+    n, px, vol, imgs, rows, parts, tilts, cfg = defocus_series()
+    ref = oracle.Reference(vol, n / 2)
+    off = np.array([300.0, -200.0, 0.0, 150.0, -350.0, 100.0, 0.0][:len(tilts)])
+    rows2 = rows.copy()
+    for t in range(len(tilts)):
+        rows2[rows2[:, 27] == t, 6:8] -= off[t]              # the rows start that far from the truth
+    cc = CspCfg.make(CSP_MICROGRAPHS, refine_defocus=1, defocus_range=400.0, defocus_step=50.0)
+    r3, p3, t3, _ = oracle.csp_refine(ref, cfg, cc, imgs, rows2, parts, tilts)
+    assert np.array_equal(p3, parts) and np.array_equal(t3, tilts)
+    found = np.array([(r3[r3[:, 27] == t, 6] - rows2[rows2[:, 27] == t, 6]).mean() for t in range(len(tilts))])
+    assert np.abs(found - off).max() <= 1e-6
+    assert all(np.ptp(r3[r3[:, 27] == t, 6] - rows2[rows2[:, 27] == t, 6]) == 0 for t in range(len(tilts)))     # one offset per tilt
+    assert np.array_equal(r3[:, 1:6], rows2[:, 1:6]) and r3[:, 14].mean() > oracle.score_batch(ref, cfg, imgs, rows2).mean() * 100
+    only = CspCfg.make(CSP_MICROGRAPHS, refine_defocus=1, defocus_range=400.0, defocus_step=50.0, first=1, last=1)
+    r4 = oracle.csp_refine(ref, cfg, only, imgs, rows2, parts, tilts)[0]
+    assert np.array_equal(r4[rows2[:, 27] != 1], rows2[rows2[:, 27] != 1]) and np.allclose(r4[rows2[:, 27] == 1], r3[rows2[:, 27] == 1])
+
+
 def test_flat_toml_and_schedules(tmp_path):
     f = tmp_path / ".pyp_config.toml"
     f.write_text('data_set = "tomo"\nscope_pixel = 1.35\nextract_box = 64\nrefine_rhref = "8:7:6"\ncsp_refine_particles = true\n'

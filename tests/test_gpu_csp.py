@@ -10,7 +10,7 @@ import pytest
 from pyp_amd import synth
 from pyp_amd.abi import CSP_MICROGRAPHS, CSP_PARTICLES, CspCfg, RefineCfg
 from pyp_amd.formats import cistem, mrc
-from test_csp_cpu import _particle_angle_err, _perturb_particles
+from test_csp_cpu import _particle_angle_err, _perturb_particles, defocus_series
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -65,6 +65,27 @@ def test_micrograph_mode_matches_oracle(series):
     _, _, gt = g.csp_refine(cfg, cm, imgs, rows2, parts, t2)
     t_ref = tilts.copy(); t_ref[:, 4:6] = t2[:, 4:6]
     assert np.linalg.norm(gt[:, 2:4] - tilts[:, 2:4], axis=1).mean() < 0.5 * np.linalg.norm(t2[:, 2:4] - tilts[:, 2:4], axis=1).mean()
+
+
+def test_defocus_mode_matches_oracle(series):
+    """csp mode 4 (per-tilt defocus offset): same offsets as the oracle, scores to float round-off."""
+    from pyp_amd import host
+    O = series[-1]
+    n, px, vol, imgs, rows, parts, tilts, cfg = defocus_series()
+    g, o = host.Reference(vol, n / 2), O.Reference(vol, n / 2)
+    off = np.linspace(-350.0, 350.0, len(tilts)).round(-1)
+    rows2 = rows.copy()
+    for t in range(len(tilts)):
+        rows2[rows2[:, 27] == t, 6:8] -= off[t]
+    for kw in (dict(), dict(first=2, last=6), dict(tind_min=1, tind_max=5)):
+        cc = CspCfg.make(CSP_MICROGRAPHS, refine_defocus=1, defocus_range=400.0, defocus_step=50.0, **kw)
+        wr, wp, wt, _ = O.csp_refine(o, cfg, cc, imgs, rows2, parts, tilts)
+        gr, gp, gt = g.csp_refine(cfg, cc, imgs, rows2, parts, tilts)
+        assert np.array_equal(gr[:, 6:8], wr[:, 6:8]), kw                       # the same offset for every tilt
+        assert np.abs(gr[:, 14] - wr[:, 14]).max() < 0.02 and np.array_equal(gr[:, 1:6], wr[:, 1:6])
+        assert np.array_equal(gp, parts) and np.array_equal(gt, tilts)
+    found = np.array([(gr[gr[:, 27] == t, 6] - rows2[rows2[:, 27] == t, 6]).mean() for t in range(1, 6)])
+    assert np.abs(found - off[1:6]).max() <= 1e-6
 
 
 def test_csp_errors_are_loud(series):
@@ -150,6 +171,7 @@ def test_csp_executable_extracts_then_refines_like_the_caller_drives_it(tmp_path
         e = cistem.read_extended(o.replace(".cistem", "_extended.cistem"))
         assert len(e["tilts"]) == 1 and len(e["particles"]) == len(parts)
     assert rows_t[:, 14].mean() >= rows_m[:, 14].mean() - 1e-3
-    # unsupported mode
-    assert csp(par, ext, 4, 0, 0, 1, "frealign/ts.mrc", "frealign/ts_stack.mrc", log="csp4.log") != 0
-    assert "ERROR" in (tmp_path / "csp4.log").read_text()
+    # mode 4 (defocus per tilt) runs; an unknown mode fails loudly
+    assert csp(par, ext, 4, 0, 0, 1, "frealign/ts.mrc", "frealign/ts_stack.mrc", log="csp4.log") == 0
+    assert csp(par, ext, 9, 0, 0, 1, "frealign/ts.mrc", "frealign/ts_stack.mrc", log="csp9.log") != 0
+    assert "ERROR" in (tmp_path / "csp9.log").read_text()
