@@ -257,12 +257,18 @@ def reconstruct3d_main(argv=None, stdin=None):
     print("\n        **   Welcome to Reconstruct3D (MI355X / libpypmatch)   **\n")
     for k, v in d.items():
         print(f"{k:28s}: {v}")
-    _unsupported(d, [("crop", True), ("center_mass", True), ("likelihood_blurring", True),
+    _unsupported(d, [("center_mass", True),
                      ("threshold_reference", True), ("exclude_edges", True), ("split_even_odd", False), ("dump", False)], "reconstruct3d")
     if abs(d["padding"] - 1.0) > 1e-6:
         _die("ERROR: reconstruct3d: only padding factor 1 is supported")
     if not d["input_params"].endswith(".cistem"):
         _die("ERROR: reconstruct3d: input parameters must be a .cistem file")
+    if d["crop"]:
+        # `refine_crop` (frealign.py:1717-1720) lets the CPU program transform cropped images to save time; the GPU path always
+        # transforms the full box, so the answer changes nothing here - said in the log rather than refused
+        print("NOTE: crop = yes has no effect: the full box is transformed")
+    if d["likelihood_blurring"] and not os.path.exists(d["reference"]):
+        _die(f"ERROR: reconstruct3d: likelihood blurring needs the reference {d['reference']}")
     for p in (d["stack"], d["input_params"]):
         if not os.path.exists(p):
             _die(f"ERROR: reconstruct3d: input file {p} does not exist")
@@ -304,8 +310,23 @@ def reconstruct3d_main(argv=None, stdin=None):
     try:
         with gpu_lock(dev):
             acc = host.Accumulator(box, px, d["symmetry"], device=dev)
+            blur_ref = None
+            if d["likelihood_blurring"]:
+                vol = mrc.read(d["reference"]).astype(np.float32)
+                if vol.shape != (box, box, box):
+                    _die(f"ERROR: reconstruct3d: reference is {vol.shape}, particles are {box}^2")
+                blur_ref = host.Reference(vol, box / 2, device=dev)
             for lo, hi, imgs in _iter_image_chunks(mm, rin[:, C["POSITION_IN_STACK"]], dev):
-                acc.insert(rc, imgs, rin[lo:hi])
+                if blur_ref is None:
+                    acc.insert(rc, imgs, rin[lo:hi])
+                else:
+                    n_blur = blurred_insert(acc, rc, blur_ref, imgs, rin[lo:hi], d)
+                    print(f"likelihood blurring: rows {lo + 1}..{hi}: {n_blur:.2f} orientations inserted per particle on average")
+            if blur_ref is not None:
+                blur_ref.close()
+                ok = (rin[:, C["OCCUPANCY"]] > 0) & ~(rin[:, C["SCORE"]] < d["score_threshold"])
+                key = rin[:, C["PIND"] if d["per_particle_splitting"] else C["POSITION_IN_STACK"]].astype(np.int64) % 2
+                acc.set_counts(int((ok & (key == 0)).sum()), int((ok & (key == 1)).sum()))      # particles, not inserted copies
             data = acc.download()
             counts = acc.counts()
             acc.close()
@@ -320,6 +341,35 @@ def reconstruct3d_main(argv=None, stdin=None):
     print("\nNormal termination, intermediate files dumped")
     print("\nReconstruct3D: Normal termination\n", flush=True)
     return 0
+
+
+BLUR_NROT, BLUR_START, BLUR_STEP, BLUR_RANGE = 21, -10.0, 1.0, 20.0      # reconstruct_lblur_* defaults (config/pyp_config.toml:5995-6025)
+
+
+def blurred_insert(acc, rc, ref, imgs, rows, d, nrot=BLUR_NROT, start=BLUR_START, step=BLUR_STEP, logp_range=BLUR_RANGE):
+    """Likelihood blurring (answer "likelihood blurring" = yes, frealign.py:1772, :1817): every particle is inserted at `nrot`
+    in-plane rotations psi + start + k step, each weighted by its likelihood against the reference, exp(LOGP_k - LOGP_max)
+    normalised to sum 1 over the rotations whose LOGP lies within `logp_range` of the best (the others are dropped).  The
+    script carries only yes / no: the grid is PYP's reconstruct_lblur_* defaults.  Build-defined (the absent program's rule
+    is not visible).  Returns the mean number of rotations inserted per particle."""
+    cfg = RefineCfg.make(box=int(rc.box), pixel_size=float(rc.pixel_size), mask_radius=float(rc.mask_radius), res_high=float(rc.res_limit),
+                         global_search=0, local_refine=0, normalize=int(rc.normalize), invert=int(rc.invert))
+    logp = np.empty((len(rows), nrot))
+    for k in range(nrot):
+        rk = rows.copy()
+        rk[:, C["PSI"]] = np.mod(rk[:, C["PSI"]] + start + k * step, 360.0)
+        logp[:, k] = ref.refine(cfg, imgs, rk)[:, C["LOGP"]]
+    rel = logp - logp.max(axis=1, keepdims=True)
+    w = np.where(rel >= -logp_range, np.exp(rel), 0.0)
+    w /= w.sum(axis=1, keepdims=True)
+    for k in range(nrot):
+        if not np.any(w[:, k] > 1e-3):
+            continue
+        rk = rows.copy()
+        rk[:, C["PSI"]] = np.mod(rk[:, C["PSI"]] + start + k * step, 360.0)
+        rk[:, C["OCCUPANCY"]] = np.where(w[:, k] > 1e-3, rows[:, C["OCCUPANCY"]] * w[:, k], 0.0)
+        acc.insert(rc, imgs, rk)
+    return float((w > 1e-3).sum(axis=1).mean())
 
 
 def _sum_dumps(seed1, seed2, n):

@@ -235,6 +235,34 @@ def test_reconstruct3d_with_dose_weighting_writes_the_side_files(project):
     assert 0.3 * wa < wb < 0.95 * wa                                        # weaker exposures weigh less at high resolution
 
 
+def test_reconstruct3d_likelihood_blurring_and_crop_answers(project):
+    """"likelihood blurring" = yes (reconstruct_lblur, frealign.py:1772, :1817) inserts every particle at the in-plane rotations
+    around its pose weighted by their likelihood against the reference; "crop" = yes is accepted with a note.  With sharp
+    likelihoods (high SNR, true poses) the blurred map stays close to the plain one."""
+    d, vol, imgs, truth, start = project
+    used = truth.copy()
+    used[:, cistem.COL["SCORE"]] = 20.0
+    cistem.write_parameters(str(d / "lb_r01_used.cistem"), used)
+    from pyp_amd.surface import cli as pcli
+
+    def script(crop, blur, tag):
+        lines = ["p_stack.mrc", "lb_r01_used.cistem", "null", "p_r01.mrc", "lb_map1.mrc", "lb_map2.mrc", "output.mrc", "lb_r01_n1.res", "C1", 1, M, PX, 300, 0,
+                 PX * N / 2, 2 * PX, 0, 2.0, "no", 0, -1, "no", 0, 1, 1, "yes", "no", "no", "no", crop, "yes", "no", "no", blur, "no", "yes",
+                 f"{d}/lb{tag}_map1_n1.mrc", f"{d}/lb{tag}_map2_n1.mrc", 1]
+        return "\n".join(str(x) for x in lines) + "\n"
+    assert run("reconstruct3d", script("no", "no", "a"), d, "rec_lb.log") == 0
+    assert run("reconstruct3d", script("yes", "yes", "b"), d, "rec_lb.log") == 0
+    log = open(d / "rec_lb.log").read()
+    assert log.count("Reconstruct3D: Normal termination") == 2 and "ERROR" not in log
+    assert "crop = yes has no effect" in log and "likelihood blurring: rows 1..60" in log
+    ba, pa, ca, a = pcli.read_dump(str(d / "lba_map1_n1.mrc")); bb, pb, cb, b = pcli.read_dump(str(d / "lbb_map1_n1.mrc"))
+    assert ca == cb                                                        # particles are counted once, not once per rotation
+    wa, wb = a.reshape(-1, 3)[:, 2], b.reshape(-1, 3)[:, 2]
+    assert abs(wb.sum() / wa.sum() - 1.0) < 0.05                           # the weights of a particle's rotations sum to one
+    cc = np.corrcoef(a.reshape(-1, 3)[:, 0], b.reshape(-1, 3)[:, 0])[0, 1]
+    assert 0.7 < cc < 0.9999                                                # close to the plain insertion, but not the same
+
+
 def test_refine3d_verbatim_default_script_matches_oracle(tmp_path):
     """The script exactly as PYP's default iteration writes it (tests/test_surface_cpu.py:REFINE_CISTEM: global = yes,
     local = no, 20 hits to refine, D7, 143 particles; frealign.py:3866-3871, :3918-3994) fed through the shell; the
