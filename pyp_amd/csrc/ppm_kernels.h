@@ -508,8 +508,18 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
     const RowTwPtr c_rowtw = (RowTwPtr)P.rowtw;
     const int nslices = P.n_dir * P.npsi_store;
     float *ccp = P.cc + (size_t)p * P.n_orient; int *shp = P.sh + (size_t)p * P.n_orient;
+    // The first rows of a wave's NEXT slice are requested by the last step of the current one (and those of its first slice
+    // here): no load stall at a slice start, and the prefetch of every step is unconditional (a conditional one made the
+    // compiler copy the 8 row registers of the untouched set on every step).
+    float2 pv[U], pn[U];
+    if (wave < nslices) {
+        const float2 *P0 = P.bank + (size_t)wave * nsampP;
+#pragma unroll
+        for (int u = 0; u < U; u++) pv[u] = P0[u * 64 + lane];
+    }
     for (int sl = wave; sl < nslices; sl += NW) {
         const float2 *Pp = P.bank + (size_t)sl * nsampP;          // wave-uniform base, lane added as a 32-bit offset
+        const float2 *Pnext = P.bank + (size_t)(sl + NW < nslices ? sl + NW : sl) * nsampP;
         // accumulators (packed re/im pairs): s* = sum over rows (shift row 0); per j: even part x cos (ua, ub),
         // odd part x sin (va, vb)
         v2f sa = { 0.f, 0.f }, sb = { 0.f, 0.f };
@@ -517,15 +527,12 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
         v2f ua[R], ub[R], va[R], vb[R];
 #pragma unroll
         for (int j = 0; j < R; j++) { ua[j] = ub[j] = va[j] = vb[j] = (v2f){ 0.f, 0.f }; }
-        float2 pv[U], pn[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) pv[u] = Pp[u * 64 + lane];
         // U rows per step; the rows of the next step are prefetched into the other register set (ping-pong: no copies).
         // B = Im(P) (Wx, Wy) is accumulated instead of Bq = Im(P) (Wy, -Wx) (no swizzled copy of W per row): component swap
         // and sign commute with the row sums and are applied once per slice below (Bq.x = B.y, Bq.y = -B.x).
         auto step = [&](int row0, const float2 (&cur)[U], float2 (&nxt)[U]) {
-            if (row0 + U < HsP) {
-                const float2 *np = Pp + (row0 + U) * 64;        // scalar base; the row offsets below fit the 12-bit immediate
+            {
+                const float2 *np = (row0 + U < HsP) ? Pp + (row0 + U) * 64 : Pnext;     // scalar base; the row offsets below fit the 12-bit immediate
 #pragma unroll
                 for (int u = 0; u < U; u++) nxt[u] = np[u * 64 + lane];
             }
