@@ -230,10 +230,10 @@ static int build_brick_items(ppm_accum *a, const Geom &gm, int BE, int nb) {
 }
 
 // ------------------------------------------------------------------------------ pre-processing launch
-static unsigned *g_prep_band_max = nullptr;   // set by ppm_insert_batch around its launch_prep call
 static int launch_prep(const float *d_images, const double *d_rows, int n_img, const Geom &gm, float Rm_px, float fall_px,
                        int normalize, int invert, int do_mask, int whiten, float2 *band, float *wring,
-                       const uint32_t *samples, int S_pad, float2 *Il, float *cw, float2 *Wp, float *C2, float *nI) {
+                       const uint32_t *samples, int S_pad, float2 *Il, float *cw, float2 *Wp, float *C2, float *nI,
+                       unsigned *band_max = nullptr /* insertion: receives the chunk's largest |band| component */) {
     if (int rc = ensure_plan(gm.N)) return rc;
     PrepP P;
     P.images = d_images; P.rows = d_rows; P.plan = g.plans[gm.N].plan;
@@ -269,7 +269,7 @@ static int launch_prep(const float *d_images, const double *d_rows, int n_img, c
     if (getenv("PPM_PREP_NCH")) { P.nchunks = std::max(P.nchunks, atoi(getenv("PPM_PREP_NCH"))); P.nc = (gm.W + P.nchunks - 1) / P.nchunks; P.nchunks = (gm.W + P.nc - 1) / P.nc; }
     if (int rc = g_prep_spill.ensure((size_t)n_img * gm.N * gm.W)) return rc;
     P.spill = g_prep_spill.p;
-    P.band_max = g_prep_band_max;
+    P.band_max = band_max;
     P.band = band; P.wring = wring; P.samples = samples; P.S_pad = S_pad; P.Il = Il; P.cw = cw;
     P.Wp = Wp; P.C2 = C2; P.nI = nI; P.Bs = gm.Bs; P.Hs = gm.Hs;
     P.r_s2 = (float)(gm.r_s * gm.r_s); P.r_lo2 = (float)(gm.r_lo * gm.r_lo);
@@ -764,11 +764,8 @@ int ppm_insert_batch(ppm_accum_t *a, const ppm_recon_cfg *cfg, const void *image
         const float *d_img = images_on_device ? (const float *)images + (size_t)c0 * NN : a->images.p + (size_t)(ci & 1) * CH * NN;
         // the chunk's value bounds ([0] max |band| from k_prep, [1] max weight from k_insert_params) scale the fixed point
         HIPCHK(hipMemsetAsync(a->d_max, 0, 2 * sizeof(unsigned), g.stream));
-        g_prep_band_max = a->d_max;
-        const int prc = launch_prep(d_img, a->rows.p, nb, gm, cfg->mask_radius / cfg->pixel_size, 1.f, cfg->normalize, cfg->invert, 0, 0,
-                                    a->band.p, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
-        g_prep_band_max = nullptr;
-        if (prc) return prc;
+        if (int prc = launch_prep(d_img, a->rows.p, nb, gm, cfg->mask_radius / cfg->pixel_size, 1.f, cfg->normalize, cfg->invert, 0, 0,
+                                  a->band.p, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, a->d_max)) return prc;
         // per-particle constants, then one block per (brick, particle slice, half)
         if (int r = a->pp.ensure(nb)) return r;
         if (int r = a->cull.ensure((size_t)nb * a->nsym)) return r;
