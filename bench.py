@@ -100,10 +100,22 @@ def probe_main(a, rank, world):
 
 
 # --------------------------------------------------------------------------------------------- helpers
+KERNEL_SOURCES = ("ppm_dev.h", "ppm_kernels.h", "ppm_kernels2.h", "ppm_csp_kernels.h", "ppm_sva_kernels.h")
+
+
 def so_sha16():
     import hashlib
     p = os.path.join(ROOT, "pyp_amd", "libpypmatch.so")
     return hashlib.sha256(open(p, "rb").read()).hexdigest()[:16] if os.path.exists(p) else None
+
+
+def kernels_sha16():
+    """Identity of the DEVICE code (the kernel headers): a PMC summary stays valid across host-only changes of the library."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, "pyp_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def pmc_entry(summary, kernel):
@@ -127,9 +139,9 @@ def pmc_traffic(summary, kernel, particles_per_launch):
     if not e or "FETCH_SIZE" not in e or "WRITE_SIZE" not in e or not meta.get("particles"):
         return None, "no FETCH_SIZE / WRITE_SIZE summary for %s under profiles/%s" % (kernel, summary)
     per_particle = (2.0 * e["FETCH_SIZE"]["sum"] + e["WRITE_SIZE"]["sum"]) * 1024.0 / meta["particles"]
-    same = meta.get("so_sha16") == so_sha16()
-    src = "profiles/%s (%d particles, 2 x FETCH_SIZE + WRITE_SIZE, KB; library %s%s)" % (
-        summary, meta["particles"], meta.get("so_sha16", "?"), " = timed build" if same else ", timed build is " + str(so_sha16()))
+    same = meta.get("kernels_sha16") == kernels_sha16()
+    src = "profiles/%s (%d particles, 2 x FETCH_SIZE + WRITE_SIZE, KB; kernel sources %s%s)" % (
+        summary, meta["particles"], meta.get("kernels_sha16", "?"), " = the timed ones" if same else ", the timed ones are " + kernels_sha16())
     return per_particle * particles_per_launch, src
 
 
@@ -325,7 +337,7 @@ def refine_bench(ctx):
         "compulsory_bytes_per_particle": 4 * N * N + 128, "contract_bytes_per_particle": b_pm,
         "kernels_ms": {k2: round(v["ms"], 2) for k2, v in prof.items() if v["launches"]},
         "kernels_us_per_particle": per_particle_us,
-        "reference_prep_s": round(t_refprep, 3), "library": so_sha16(),
+        "reference_prep_s": round(t_refprep, 3), "library": so_sha16(), "kernel_sources": kernels_sha16(),
         "accuracy_vs_truth": {"median_deg": round(float(np.median(ang)), 3), "frac_within_2deg": round(float((ang < 2).mean()), 3),
                               "median_shift_px": round(float(np.median(shf)), 3)},
     }

@@ -29,5 +29,6 @@ for grp in "${GROUPS_[@]}"; do
   echo "pass $i done: $grp"
 done
 SHA=$(python3 -c "import bench; print(bench.so_sha16())")
-python3 scripts/pmc_summary.py $R --meta particles=$N workload=$W so_sha16=$SHA "command=bench.py $ARGS" > $OUT
+KSHA=$(python3 -c "import bench; print(bench.kernels_sha16())")
+python3 scripts/pmc_summary.py $R --meta particles=$N workload=$W so_sha16=$SHA kernels_sha16=$KSHA "command=bench.py $ARGS" > $OUT
 echo done $OUT
