@@ -55,3 +55,29 @@ def reduce_accumulators(acc_tensor, counts, group=None):
     c = torch.as_tensor(list(counts), dtype=torch.int64, device=acc_tensor.device)
     dist.all_reduce(c, op=dist.ReduceOp.SUM, group=group)
     return acc_tensor, [int(x) for x in c.cpu()]
+
+
+def shard_units(unit_ids, world, rank):
+    """Constrained refinement / sub-tomogram alignment: the units of a rank (particles, tilts, table rows) as an inclusive
+    (first, last) range over the SORTED unit ids, balanced by count; units never interact, so there is no collective - every
+    rank writes its own `<param>_<first>_<last>` output exactly like one job of create_csp_split_commands
+    (src/pyp/system/local_run.py:416-463).  Returns None when the rank has nothing to do."""
+    ids = np.sort(np.unique(np.asarray(unit_ids).astype(np.int64)))
+    lo, hi = shard_bounds(len(ids), world, rank)
+    if hi <= lo:
+        return None
+    return int(ids[lo]), int(ids[hi - 1])
+
+
+def merge_unit_results(rows_list, particles_list, tilts_list, rows_ref, particles_ref, tilts_ref, kind_particles=True):
+    """Union of per-rank constrained-refinement results (each a full copy in which only the rank's units changed), the way
+    Parameters.merge overlays range outputs on the original (src/pyp/inout/metadata/cistem_star_file.py:655-692)."""
+    rows, parts, tl = rows_ref.copy(), particles_ref.copy(), tilts_ref.copy()
+    for r, p, t in zip(rows_list, particles_list, tilts_list):
+        ch = np.any(r != rows_ref, axis=1)
+        rows[ch] = r[ch]
+        if kind_particles:
+            chp = np.any(p != particles_ref, axis=1); parts[chp] = p[chp]
+        else:
+            cht = np.any(t != tilts_ref, axis=1); tl[cht] = t[cht]
+    return rows, parts, tl

@@ -84,6 +84,53 @@ def test_two_ranks_equal_one_rank(tmp_path):
     assert np.linalg.norm(outs[1][1] - outs[2][1]) / np.linalg.norm(outs[1][1]) < 1e-6    # float sum order only
 
 
+CSP_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch.distributed as dist
+from pyp_amd import synth, dist as pdist
+from pyp_amd.abi import RefineCfg, CspCfg, CSP_PARTICLES
+from oracle import oracle
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+n, px = 32, 3.0
+vol, stack, rows, parts, tilts = synth.make_tilt_series(n, 5, np.arange(-40, 41, 20.0), pixel=px, snr=0.5)
+rng = np.random.default_rng(1)
+p2 = parts.copy(); p2[:, 1:4] += rng.normal(0, 1.0, (len(p2), 3))
+rows2 = synth.csp_rows_from_params(rows, parts, tilts, p2, tilts)
+cfg = RefineCfg.make(box=n, pixel_size=px, mask_radius=0.4*n*px, res_high=px*n/12, global_search=0)
+rng_units = pdist.shard_units(p2[:, 0], world, rank)
+cc = CspCfg.make(CSP_PARTICLES, refine_rotation=0, tol_shift=3.0, first=rng_units[0], last=rng_units[1])
+r, p, t, _ = oracle.csp_refine(oracle.Reference(vol, n/2), cfg, cc, stack.numpy(), rows2, p2, tilts)
+np.savez(os.environ["OUT"] + "_%%d.npz" %% rank, rows=r, parts=p, tilts=t, rows0=rows2, parts0=p2, tilts0=tilts, units=np.array(rng_units))
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_constrained_refinement_shards_by_unit_without_a_collective(tmp_path):
+    """Two ranks refine disjoint particle ranges (pdist.shard_units); the overlay of their results equals the single-rank run."""
+    script = tmp_path / "c.py"
+    script.write_text(CSP_WORKER % {"root": ROOT})
+    merged = {}
+    for world in (1, 2):
+        port = _free_port()
+        procs = []
+        for r in range(world):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       OUT=str(tmp_path / f"c{world}"), OMP_NUM_THREADS="2")
+            procs.append(subprocess.Popen([sys.executable, str(script)], env=env))
+        for p in procs:
+            assert p.wait(timeout=600) == 0
+        outs = [np.load(str(tmp_path / f"c{world}_{r}.npz")) for r in range(world)]
+        merged[world] = pdist.merge_unit_results([o["rows"] for o in outs], [o["parts"] for o in outs], [o["tilts"] for o in outs],
+                                                 outs[0]["rows0"], outs[0]["parts0"], outs[0]["tilts0"])
+        if world == 2:
+            assert [tuple(o["units"]) for o in outs] == [(0, 2), (3, 4)]
+    for a, b in zip(merged[1], merged[2]):
+        assert np.array_equal(a, b)
+    assert pdist.shard_units([7, 3, 5], 4, 3) is None and pdist.shard_units([7, 3, 5], 2, 0) == (3, 5)
+
+
 def test_bench_gpus_flag_launches_that_many_ranks():
     """`python bench.py --gpus 2` outside torchrun starts two ranks itself (child torchrun over 127.0.0.1) and rank 0 reports
     n_gpus = 2; PPM_BENCH_PROBE=1 exercises launcher + rendezvous + max-over-ranks reduction without GPU work."""
