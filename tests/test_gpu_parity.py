@@ -109,6 +109,27 @@ def test_fine_angular_steps_select_top_hits_correctly(H, O, step):
     assert synth.angular_error_deg(want, got).max() < ANG_TOL_DEG and synth.shift_error_px(want, got, 3.0).max() < SHIFT_TOL_PX
 
 
+@pytest.mark.parametrize("kw", [dict(angular_step=24.0), dict(angular_step=40.0),                       # odd psi counts: no psi / psi + 180 pairing
+                                dict(search_range_x=10.0, search_range_y=10.0), dict(search_range_x=0.0, search_range_y=0.0),   # shift windows of 5 and 8 steps
+                                dict(search_range_x=4.0, search_range_y=14.0), dict(search_range_x=2.0, search_range_y=2.0)])
+def test_search_grid_variants_match_oracle(H, O, kw):
+    """Code paths of the grid search the default configuration never takes: an odd number of in-plane angles (every slice
+    stored, no conjugate pairing), shift windows wider than 3 steps (512-thread kernel, per-shift wave sums), anisotropic and
+    one-step windows."""
+    vol, imgs, rows = dataset(64, 8, 2.0, 0.1)
+    g, o = H.Reference(vol, 32), O.Reference(vol, 32)
+    raw = cfg_for(64, 2.0, local_refine=0, iters_hit=-1, **kw)
+    want, counts = O.refine_batch(o, raw, imgs, rows)
+    got = g.refine(raw, imgs, rows)
+    assert g.last_counts()["n_global"] == counts[0]
+    assert synth.angular_error_deg(want, got).max() < 1e-4, kw                          # same grid point ...
+    assert np.array_equal(np.round(want[:, 4:6] / 2.0), np.round(got[:, 4:6] / 2.0)), kw   # ... and the same integer shift
+    full = cfg_for(64, 2.0, **kw)
+    want, _ = O.refine_batch(o, full, imgs, rows)
+    got = g.refine(full, imgs, rows)
+    assert synth.angular_error_deg(want, got).max() < ANG_TOL_DEG and synth.shift_error_px(want, got, 2.0).max() < SHIFT_TOL_PX, kw
+
+
 def test_two_live_references_with_different_search_grids(H, O):
     """Row twiddles of the grid search belong to the reference handle: alternating calls on two references with different
     boxes / bands must not see each other's tables."""
