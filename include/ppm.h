@@ -169,7 +169,7 @@ typedef struct ppm_accum ppm_accum_t;
 
 /* kernels whose device time the library accumulates when profiling is on */
 enum { PPM_K_PREP = 0, PPM_K_BANK = 1, PPM_K_GLOBAL = 2, PPM_K_TOPK = 3, PPM_K_LOCAL = 4,
-       PPM_K_INSERT = 5, PPM_K_FINAL = 6, PPM_K_EXTRACT = 7, PPM_K_COUNT = 8 };
+       PPM_K_INSERT = 5, PPM_K_FINAL = 6, PPM_K_EXTRACT = 7, PPM_K_NORMS = 8, PPM_K_COUNT = 9 };
 
 int ppm_init(int device);
 const char *ppm_last_error(void);

@@ -3,7 +3,7 @@ import ctypes as C
 
 NCOL = 32
 STATS_COLS = 7
-K_NAMES = ("prep", "bank", "global", "topk", "local", "insert", "final", "extract")
+K_NAMES = ("prep", "bank", "global", "topk", "local", "insert", "final", "extract", "norms")
 
 
 class RefineCfg(C.Structure):

@@ -19,11 +19,42 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// wave64 all-lanes sum (every lane gets the total)
+// ---- wave64 cross-lane steps without the LDS crossbar (ds_bpermute): DPP inside a row of 16 lanes, the gfx950
+// v_permlane16_swap / v_permlane32_swap between rows.  Pairings: xor 1 and xor 2 (quad_perm), i <-> 7 - i (row_half_mirror;
+// flips bit 2), xor 8 (row_ror:8), rows 0 <-> 1 and 2 <-> 3 (16-swap), halves (32-swap).
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140, kDppRor8 = 0x128;
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float x) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL> __device__ __forceinline__ int dpp_mov(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, false); }
+// rows 1 and 3 of `a` trade places with rows 0 and 2 of `b` (M = 16), or the upper half of `a` with the lower half of `b`
+// (M = 32); afterwards lanes with (lane & M) == 0 hold both halves of their `a` pair, the others those of their `b` pair
+template <int M> __device__ __forceinline__ void lane_swap(float &a, float &b) {
+    static_assert(M == 16 || M == 32, "row swaps only");
+    if constexpr (M == 32) { auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false); a = __uint_as_float(r[0]); b = __uint_as_float(r[1]); }
+    else { auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false); a = __uint_as_float(r[0]); b = __uint_as_float(r[1]); }
+}
+template <int M> __device__ __forceinline__ void lane_swap(int &a, int &b) {
+    if constexpr (M == 32) { auto r = __builtin_amdgcn_permlane32_swap((unsigned)a, (unsigned)b, false, false); a = (int)r[0]; b = (int)r[1]; }
+    else { auto r = __builtin_amdgcn_permlane16_swap((unsigned)a, (unsigned)b, false, false); a = (int)r[0]; b = (int)r[1]; }
+}
+
+// wave64 all-lanes sum / max / min (every lane gets the result)
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
+    v += dpp_mov<kDppXor1>(v); v += dpp_mov<kDppXor2>(v); v += dpp_mov<kDppHalfMirror>(v); v += dpp_mov<kDppMirror>(v);
+    float w = v; lane_swap<16>(v, w); v += w;
+    w = v; lane_swap<32>(v, w); return v + w;
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = fmaxf(v, dpp_mov<kDppXor1>(v)); v = fmaxf(v, dpp_mov<kDppXor2>(v)); v = fmaxf(v, dpp_mov<kDppHalfMirror>(v)); v = fmaxf(v, dpp_mov<kDppMirror>(v));
+    float w = v; lane_swap<16>(v, w); v = fmaxf(v, w);
+    w = v; lane_swap<32>(v, w); return fmaxf(v, w);
+}
+__device__ __forceinline__ float wave_min(float v) { return -wave_max(-v); }
+__device__ __forceinline__ int wave_min(int v) {
+    v = min(v, dpp_mov<kDppXor1>(v)); v = min(v, dpp_mov<kDppXor2>(v)); v = min(v, dpp_mov<kDppHalfMirror>(v)); v = min(v, dpp_mov<kDppMirror>(v));
+    int w = v; lane_swap<16>(v, w); v = min(v, w);
+    w = v; lane_swap<32>(v, w); return min(v, w);
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll

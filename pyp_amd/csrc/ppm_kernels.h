@@ -418,6 +418,90 @@ __global__ void __launch_bounds__(256) k_bank(BankP P) {
     P.bank[i] = v;
 }
 
+// ---------------------------------------------------------------------------------- slice norms (MFMA)
+// nP[p][s] = sum_k C2_p(k) |P_s(k)|^2, the reference-side norm of every (particle, slice) pair: a dense product of the
+// particles' CTF^2 tables (n x samples) with the squared slice bank (samples x slices) — the one GEMM-shaped piece of the
+// search, so it runs on the matrix cores (v_mfma_f32_32x32x2_f32, fp32 in and out) instead of costing k_global six vector
+// instructions per row pair and lane.  Block = 4 waves, tile 128 particles x 128 slices, K tile = half a paired bank row
+// (32 kx); each wave owns 64 x 64 = 2 x 2 MFMA tiles (64 accumulator registers).  LDS rows are padded to 33 floats: the
+// operand reads (lane = row, two k per instruction) then touch 32 distinct banks.
+struct NormP { const float *C2; const float2 *bank; float *nP; int n, nslices, Bs, Hs, HsP; };
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+__global__ void __launch_bounds__(256, 2) k_slice_norms(NormP P) {
+    constexpr int TM = 128, TK = 32, LD = TK + 1;
+    __shared__ float As[TM * LD], Bq[TM * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int p0 = blockIdx.x * TM, s0 = blockIdx.y * TM;
+    const size_t HS = (size_t)P.Hs * 64, HSP = (size_t)P.HsP * 64;
+    const int nhalf = P.Bs >= 32 ? 2 : 1;                         // kx > Bs holds zeros only
+    v16f acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int v = 0; v < 16; v++) acc[a][b][v] = 0.f;
+    // this thread's share of a tile load: A 4 x float4 (row = idx / 8), B 8 x float4 = 16 complex (row = idx / 16);
+    // rows beyond the tables are clamped (their products are never stored)
+    for (int rr = 0; rr < 2 * P.Bs + 2; rr++) {
+        if (rr == 1) continue;                                     // paired order: row 1 is empty
+        const int t = rr >> 1, ky = (rr & 1) ? -t : t;
+        const size_t aoff = (size_t)(ky + P.Bs) * 64, boff = (size_t)rr * 64;
+        for (int h = 0; h < nhalf; h++) {
+            float4 av[4], bv[8];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int idx = tid + 256 * q, row = idx >> 3, c4 = idx & 7;
+                const int pr = min(p0 + row, P.n - 1);
+                av[q] = *(const float4 *)(P.C2 + (size_t)pr * HS + aoff + h * TK + c4 * 4);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int idx = tid + 256 * q, row = idx >> 4, c = idx & 15;
+                const int sr = min(s0 + row, P.nslices - 1);
+                bv[q] = *(const float4 *)(P.bank + (size_t)sr * HSP + boff + h * TK + c * 2);
+            }
+            __syncthreads();                                       // the previous tile has been consumed
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int idx = tid + 256 * q, row = idx >> 3, c4 = idx & 7;
+                float *d = As + row * LD + c4 * 4;
+                d[0] = av[q].x; d[1] = av[q].y; d[2] = av[q].z; d[3] = av[q].w;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int idx = tid + 256 * q, row = idx >> 4, c = idx & 15;
+                float *d = Bq + row * LD + c * 2;
+                d[0] = fmaf(bv[q].x, bv[q].x, bv[q].y * bv[q].y); d[1] = fmaf(bv[q].z, bv[q].z, bv[q].w * bv[q].w);
+            }
+            __syncthreads();
+            const float *ap = As + (64 * wm + (lane & 31)) * LD + (lane >> 5);
+            const float *bp = Bq + (64 * wn + (lane & 31)) * LD + (lane >> 5);
+#pragma unroll
+            for (int kk = 0; kk < TK; kk += 2) {
+                const float a0 = ap[kk], a1 = ap[32 * LD + kk], b0 = bp[kk], b1 = bp[32 * LD + kk];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+        }
+    }
+    // accumulator register v of lane l: row 8 (v / 4) + 4 (l / 32) + v % 4, column l % 32 of the 32 x 32 tile
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            const int sc = s0 + 64 * wn + 32 * b + (lane & 31);
+#pragma unroll
+            for (int v = 0; v < 16; v++) {
+                const int pr = p0 + 64 * wm + 32 * a + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3);
+                if (pr < P.n && sc < P.nslices) P.nP[(size_t)pr * P.nslices + sc] = acc[a][b][v];
+            }
+        }
+}
+
 // ---------------------------------------------------------------------------------- global search
 struct Hit { float cc; int orient; int sx, sy; };
 
@@ -432,7 +516,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(4))) v4f *RowTwPtr;
 
 struct GlobP {
-    const float2 *bank; const float2 *Wp; const float *C2; const float *nI; const float2 *twN;  // twN: Ns-entry table e^{2 pi i t/Ns}
+    const float2 *bank; const float2 *Wp; const float *nP; const float *nI; const float2 *twN;  // nP: [n][n_dir * npsi_store] slice norms (k_slice_norms); twN: Ns-entry table e^{2 pi i t/Ns}
     const float4 *rowtw;  // [kRowTwRows][PPM_MAX_SHIFT_STEPS] row-pair twiddles (device memory owned by the reference)
     float *cc; int *sh;   // [n][n_orient] scratch scores and packed shifts
     Hit *hits;            // [n][K]
@@ -443,15 +527,19 @@ struct GlobP {
 constexpr int global_threads(int R) { return R <= 3 ? 1024 : 512; }   // wider windows need > 128 VGPRs
 constexpr int global_unroll(int R) { return R <= 3 ? 8 : 4; }         // rows in flight per wave (prefetch depth), even
 
-// pairwise halving step of a cross-lane reduction: afterwards lanes with (lane & m) == 0 carry the
-// partial sum of `a`, the others that of `b`
-__device__ __forceinline__ float halve_pair(float a, float b, int lane, int m) {
-    const bool hi = (lane & m) != 0;
-    float send = hi ? a : b, keep = hi ? b : a;
-    return keep + __shfl_xor(send, m, 64);
+// pairwise halving step of a cross-lane reduction: afterwards lanes with (lane & M) == 0 carry the partial sum of `a`, the
+// others that of `b`.  Between rows the two registers trade halves (one swap, one add); inside a row both are folded
+// with a DPP operand and the lane keeps the one it owns.
+template <int M> __device__ __forceinline__ float halve_pair(float a, float b, int lane) {
+    if constexpr (M >= 16) { lane_swap<M>(a, b); return a + b; }
+    else {
+        constexpr int ctrl = M == 8 ? kDppRor8 : M == 4 ? kDppHalfMirror : M == 2 ? kDppXor2 : kDppXor1;
+        const float t = a + dpp_mov<ctrl>(a), u = b + dpp_mov<ctrl>(b);
+        return (lane & M) ? u : t;
+    }
 }
 
-// Sums NV per-lane values over the 64 lanes in 6 halving stages (NV + NV/2 + ... shuffles instead of
+// Sums NV per-lane values over the 64 lanes in 6 halving stages (NV + NV/2 + ... cross-lane steps instead of
 // 6 NV).  Returns one register: lane l holds the total of value index bitrev6(l) (if that is < NV <= 64).
 template <int NV>
 __device__ __forceinline__ float reduce_halving(float (&v)[NV], int lane) {
@@ -459,20 +547,20 @@ __device__ __forceinline__ float reduce_halving(float (&v)[NV], int lane) {
     constexpr int n1 = (NV + 1) / 2, n2 = (n1 + 1) / 2, n3 = (n2 + 1) / 2, n4 = (n3 + 1) / 2, n5 = (n4 + 1) / 2;
     float a1[n1], a2[n2], a3[n3], a4[n4], a5[n5];
 #pragma unroll
-    for (int i = 0; i < n1; i++) a1[i] = halve_pair(v[2 * i], (2 * i + 1 < NV) ? v[2 * i + 1] : 0.f, lane, 32);
+    for (int i = 0; i < n1; i++) a1[i] = halve_pair<32>(v[2 * i], (2 * i + 1 < NV) ? v[2 * i + 1] : 0.f, lane);
 #pragma unroll
-    for (int i = 0; i < n2; i++) a2[i] = halve_pair(a1[2 * i], (2 * i + 1 < n1) ? a1[2 * i + 1] : 0.f, lane, 16);
+    for (int i = 0; i < n2; i++) a2[i] = halve_pair<16>(a1[2 * i], (2 * i + 1 < n1) ? a1[2 * i + 1] : 0.f, lane);
 #pragma unroll
-    for (int i = 0; i < n3; i++) a3[i] = halve_pair(a2[2 * i], (2 * i + 1 < n2) ? a2[2 * i + 1] : 0.f, lane, 8);
+    for (int i = 0; i < n3; i++) a3[i] = halve_pair<8>(a2[2 * i], (2 * i + 1 < n2) ? a2[2 * i + 1] : 0.f, lane);
 #pragma unroll
-    for (int i = 0; i < n4; i++) a4[i] = halve_pair(a3[2 * i], (2 * i + 1 < n3) ? a3[2 * i + 1] : 0.f, lane, 4);
+    for (int i = 0; i < n4; i++) a4[i] = halve_pair<4>(a3[2 * i], (2 * i + 1 < n3) ? a3[2 * i + 1] : 0.f, lane);
 #pragma unroll
-    for (int i = 0; i < n5; i++) a5[i] = halve_pair(a4[2 * i], (2 * i + 1 < n4) ? a4[2 * i + 1] : 0.f, lane, 2);
-    return halve_pair(a5[0], (n5 > 1) ? a5[1] : 0.f, lane, 1);
+    for (int i = 0; i < n5; i++) a5[i] = halve_pair<2>(a4[2 * i], (2 * i + 1 < n4) ? a4[2 * i + 1] : 0.f, lane);
+    return halve_pair<1>(a5[0], (n5 > 1) ? a5[1] : 0.f, lane);
 }
 
-// Block = one particle.  The particle's CTF-weighted spectrum W and CTF^2 table sit in LDS for the whole
-// orientation loop; each wave streams whole slices of the bank: lane = kx, rows = ky in +-t pairs, U rows
+// Block = one particle.  The particle's CTF-weighted spectrum W sits in LDS for the whole orientation loop (the slice
+// norms sum C2 |P|^2 come from k_slice_norms); each wave streams whole slices of the bank: lane = kx, rows = ky in +-t pairs, U rows
 // prefetched ahead.  With P the slice sample, A = Re(P) W and Bq = Im(P) (Wy, -Wx): W conj(P) = A + Bq
 // (orientation psi) and W P = A - Bq (psi + 180 deg).  The transforms over ky use the even / odd parts of a
 // row pair: sum_ky Q e^{i 2 pi ky j/Ns} = sum_t (Q(+t) + Q(-t)) cos + i (Q(+t) - Q(-t)) sin, accumulated in the
@@ -486,15 +574,13 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: slice addresses stay in SGPRs
     const int Hs = P.Hs, HsP = P.HsP, Bs = P.Bs, Ns = P.Ns, nsampP = HsP * 64;
     float2 *Wl = (float2 *)smem;
-    float *C2l = (float *)(Wl + nsampP);
     {
-        const float2 *src = P.Wp + (size_t)p * Hs * 64; const float *src2 = P.C2 + (size_t)p * Hs * 64;
+        const float2 *src = P.Wp + (size_t)p * Hs * 64;
         for (int i = tid; i < nsampP; i += NT) {
             const int rr = i >> 6, t = rr >> 1, ky = (rr & 1) ? -t : t;
             const bool ok = rr != 1 && t <= Bs;
             const int srow = ky + Bs;
             Wl[i] = ok ? src[srow * 64 + (i & 63)] : make_float2(0.f, 0.f);
-            C2l[i] = ok ? src2[srow * 64 + (i & 63)] : 0.f;
         }
     }
     __syncthreads();
@@ -507,6 +593,7 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
     }
     const RowTwPtr c_rowtw = (RowTwPtr)P.rowtw;
     const int nslices = P.n_dir * P.npsi_store;
+    const __attribute__((address_space(4))) float *c_nP = (const __attribute__((address_space(4))) float *)P.nP + (size_t)p * nslices;   // wave-uniform reads: scalar loads
     float *ccp = P.cc + (size_t)p * P.n_orient; int *shp = P.sh + (size_t)p * P.n_orient;
     // The first rows of a wave's NEXT slice are requested by the last step of the current one (and those of its first slice
     // here): no load stall at a slice start, and the prefetch of every step is unconditional (a conditional one made the
@@ -523,7 +610,7 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
         // accumulators (packed re/im pairs): s* = sum over rows (shift row 0); per j: even part x cos (ua, ub),
         // odd part x sin (va, vb)
         v2f sa = { 0.f, 0.f }, sb = { 0.f, 0.f };
-        float nP = 0.f;
+        const float nP = c_nP[sl];
         v2f ua[R], ub[R], va[R], vb[R];
 #pragma unroll
         for (int j = 0; j < R; j++) { ua[j] = ub[j] = va[j] = vb[j] = (v2f){ 0.f, 0.f }; }
@@ -540,22 +627,18 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
             v4f tw[R], twn[R];
 #pragma unroll
             for (int j = 0; j < R; j++) tw[j] = c_rowtw[(row0 >> 1) * PPM_MAX_SHIFT_STEPS + j];
-            // ... and so are the particle's W / C2 rows (LDS) of the next pair
+            // ... and so are the particle's W rows (LDS) of the next pair
             float2 wa = Wl[row0 * 64 + lane], wb = Wl[(row0 + 1) * 64 + lane];
-            float ca = C2l[row0 * 64 + lane], cb = C2l[(row0 + 1) * 64 + lane];
 #pragma unroll
             for (int u = 0; u < U; u += 2) {
                 const int ra = row0 + u, tp = ra >> 1;
-                float2 wan = wa, wbn = wb; float can = ca, cbn = cb;
+                float2 wan = wa, wbn = wb;
                 if (u + 2 < U) {
 #pragma unroll
                     for (int j = 0; j < R; j++) twn[j] = c_rowtw[(tp + 1) * PPM_MAX_SHIFT_STEPS + j];
                     wan = Wl[(ra + 2) * 64 + lane]; wbn = Wl[(ra + 3) * 64 + lane];
-                    can = C2l[(ra + 2) * 64 + lane]; cbn = C2l[(ra + 3) * 64 + lane];
                 }
                 const float pax = cur[u].x, pay = cur[u].y, pbx = cur[u + 1].x, pby = cur[u + 1].y;
-                nP = fmaf(ca, fmaf(pax, pax, pay * pay), nP);
-                nP = fmaf(cb, fmaf(pbx, pbx, pby * pby), nP);
                 // A = Re(P) W, B = Im(P) W for both rows; even (+) and odd (-) parts of the pair
                 const v2f wav = { wa.x, wa.y }, wbv = { wb.x, wb.y };
                 const v2f aa = wav * pax, ab = wbv * pbx, ba = wav * pay, bb = wbv * pby;
@@ -570,7 +653,7 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
                 }
 #pragma unroll
                 for (int j = 0; j < R; j++) tw[j] = twn[j];
-                wa = wan; wb = wbn; ca = can; cb = cbn;
+                wa = wan; wb = wbn;
             }
         };
         __builtin_amdgcn_s_setprio(3);
@@ -583,7 +666,6 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
             uax[j] = ua[j].x; uay[j] = ua[j].y; ubx[j] = ub[j].y; uby[j] = -ub[j].x;
             vax[j] = va[j].x; vay[j] = va[j].y; vbx[j] = vb[j].y; vby[j] = -vb[j].x;
         }
-        nP = wave_sum(nP);
         const float inv = (nP > 0.f && nI > 0.f) ? rsqrtf(nP * nI) : 0.f;
         const int dir = sl / P.npsi_store, ks = sl - dir * P.npsi_store;
 #pragma unroll
@@ -616,14 +698,12 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
                 const int vi = (int)(__brev((unsigned)lane) >> 26);            // the value index this lane ended up with
                 const int iy = vi / NS, ix = vi - iy * NS;
                 const int ay = iy - R < 0 ? R - iy : iy - R, ax = ix - R < 0 ? R - ix : ix - R;
-                float cand = (vi < NS * NS && ax <= P.RSx && ay <= P.RSy) ? tot : -3.0e38f;
-                int ci = vi;
-#pragma unroll
-                for (int m = 32; m >= 1; m >>= 1) {     // arg-max over lanes; ties -> lower (sy, sx) index like the oracle's scan order
-                    float ov = __shfl_xor(cand, m, 64); int oi = __shfl_xor(ci, m, 64);
-                    if (ov > cand || (ov == cand && oi < ci)) { cand = ov; ci = oi; }
-                }
-                best = cand; bsy_ = ci / NS - R; bsx_ = ci - (ci / NS) * NS - R;
+                const float cand = (vi < NS * NS && ax <= P.RSx && ay <= P.RSy) ? tot : -3.0e38f;
+                // arg-max over lanes; ties -> lower (sy, sx) index like the oracle's scan order
+                best = wave_max(cand);
+                int ci = wave_min(cand == best ? vi : 64);
+                if (ci > 63) ci = 0;                                         // no comparable value (NaN scores)
+                bsy_ = ci / NS - R; bsx_ = ci - (ci / NS) * NS - R;
             } else {
 #pragma unroll
                 for (int iy = 0; iy < NS; iy++) {

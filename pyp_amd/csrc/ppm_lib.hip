@@ -151,7 +151,7 @@ struct ppm_ref {
     float2 *cube = nullptr;
     // workspaces (grown on demand, reused across calls)
     DevBuf<double> rows_in, rows_out, dir_theta, dir_phi;
-    DevBuf<float> images, wring, cw, C2, nI, cc, mats, ddef;
+    DevBuf<float> images, wring, cw, C2, nP, nI, cc, mats, ddef;
     DevBuf<float2> band, Il, Wp, bank, twN;
     DevBuf<float4> rowtw;            // k_global's row-pair twiddles for this reference's current search grid
     DevBuf<int> sh;
@@ -311,7 +311,7 @@ static int launch_global_r(const GlobP &P, int n_img, bool half, size_t lds) {
 }
 
 static int launch_global(GlobP &P, int n_img, bool half, int R) {
-    size_t lds = (size_t)P.HsP * 64 * (sizeof(float2) + sizeof(float));
+    size_t lds = (size_t)P.HsP * 64 * sizeof(float2);
     if (lds < 1024) lds = 1024;
     // the top-K pass re-uses the block's LDS for a copy of the particle's n_orient scores when they fit (160 KB = 40 928
     // orientations, e.g. 8 deg at C1); finer grids select on the global scratch instead
@@ -420,7 +420,7 @@ void ppm_reference_destroy(ppm_ref_t *r) {
     if (!r) return;
     if (r->cube) (void)hipFree(r->cube);
     r->rows_in.release(); r->rows_out.release(); r->dir_theta.release(); r->dir_phi.release();
-    r->images.release(); r->wring.release(); r->cw.release(); r->C2.release(); r->nI.release(); r->cc.release(); r->mats.release(); r->ddef.release();
+    r->images.release(); r->wring.release(); r->cw.release(); r->C2.release(); r->nP.release(); r->nI.release(); r->cc.release(); r->mats.release(); r->ddef.release();
     r->band.release(); r->Il.release(); r->Wp.release(); r->bank.release(); r->twN.release(); r->rowtw.release(); r->sh.release(); r->samples.release();
     r->hits.release(); r->states.release(); r->states2.release();
     delete r;
@@ -473,7 +473,7 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
     const int nslices = gm.n_dir * gm.npsi_store;
     // chunk so that the scratch stays well inside HBM
     size_t per = NN * 4 + HW * 8 + (size_t)S_pad * 12 + 2 * PPM_NCOL * 8 + (gm.B + 2) * 4;
-    if (cfg->global_search) per += HS * 12 + (size_t)gm.n_orient * 8 + (size_t)K * (sizeof(Hit) + sizeof(LState)) + sizeof(LState);
+    if (cfg->global_search) per += HS * 12 + (size_t)nslices * 4 + (size_t)gm.n_orient * 8 + (size_t)K * (sizeof(Hit) + sizeof(LState)) + sizeof(LState);
     int CH = (int)std::min<size_t>((size_t)n_img, std::max<size_t>(64, ((size_t)4 << 30) / per));
     CH = std::min(CH, 8192);
     if (CH >= 2048) CH &= ~1023;        // whole rounds of blocks: 256 CUs x 1 (k_global) and x 4 (k_local, one block per particle)
@@ -492,6 +492,7 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
     if (cfg->global_search) {
         if (int rc = ref->Wp.ensure((size_t)CH * HS)) return rc;
         if (int rc = ref->C2.ensure((size_t)CH * HS)) return rc;
+        if (int rc = ref->nP.ensure((size_t)CH * nslices)) return rc;
         if (int rc = ref->nI.ensure(CH)) return rc;
         if (int rc = ref->cc.ensure((size_t)CH * gm.n_orient)) return rc;
         if (int rc = ref->sh.ensure((size_t)CH * gm.n_orient)) return rc;
@@ -602,10 +603,15 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
         LState *final_states = ref->states2.p;
         if (cfg->global_search) {
             GlobP GP;
-            GP.bank = ref->bank.p; GP.Wp = ref->Wp.p; GP.C2 = ref->C2.p; GP.nI = ref->nI.p; GP.twN = ref->twN.p; GP.rowtw = ref->rowtw.p;
+            GP.bank = ref->bank.p; GP.Wp = ref->Wp.p; GP.nP = ref->nP.p; GP.nI = ref->nI.p; GP.twN = ref->twN.p; GP.rowtw = ref->rowtw.p;
             GP.cc = ref->cc.p; GP.sh = ref->sh.p; GP.hits = ref->hits.p;
             GP.Bs = gm.Bs; GP.Hs = gm.Hs; GP.HsP = HsP; GP.Ns = gm.Ns; GP.RSx = gm.RSx; GP.RSy = gm.RSy;
             GP.n_dir = gm.n_dir; GP.n_psi = gm.n_psi; GP.npsi_store = gm.npsi_store; GP.n_orient = gm.n_orient; GP.K = K;
+            {
+                ProfScope ps(PPM_K_NORMS);
+                NormP NP; NP.C2 = ref->C2.p; NP.bank = ref->bank.p; NP.nP = ref->nP.p; NP.n = nb; NP.nslices = nslices; NP.Bs = gm.Bs; NP.Hs = gm.Hs; NP.HsP = HsP;
+                hipLaunchKernelGGL(k_slice_norms, dim3((nb + 127) / 128, (nslices + 127) / 128), dim3(256), 0, g.stream, NP);
+            }
             if (int rc = launch_global(GP, nb, gm.half != 0, Rwin)) return rc;
             {
                 ProfScope ps(PPM_K_TOPK);
