@@ -511,6 +511,16 @@ struct Hit { float cc; int orient; int sx, sy; };
 // through the constant address space so that the wave-uniform loads stay scalar (s_load) although the kernel also stores
 // to global memory inside the slice loop.
 constexpr int kRowTwRows = 64;
+// build-time knobs of k_global's default (R <= 3) shape, for A/B runs (scripts/ab_global.sh)
+#ifndef PPM_GLOBAL_PARTICLES
+#define PPM_GLOBAL_PARTICLES 2
+#endif
+#ifndef PPM_GLOBAL_THREADS
+#define PPM_GLOBAL_THREADS 512
+#endif
+#ifndef PPM_GLOBAL_UNROLL
+#define PPM_GLOBAL_UNROLL 4
+#endif
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(4))) v4f *RowTwPtr;
@@ -520,12 +530,17 @@ struct GlobP {
     const float4 *rowtw;  // [kRowTwRows][PPM_MAX_SHIFT_STEPS] row-pair twiddles (device memory owned by the reference)
     float *cc; int *sh;   // [n][n_orient] scratch scores and packed shifts
     Hit *hits;            // [n][K]
-    int Bs, Hs, HsP, Ns, RSx, RSy, n_dir, n_psi, npsi_store, n_orient, K;
+    int n, Bs, Hs, HsP, Ns, RSx, RSy, n_dir, n_psi, npsi_store, n_orient, K;   // n: particles of this launch
     int topk_lds;         // 1: the top-K pass works on an LDS copy of the particle's scores (they fit), 0: on the global scratch
 };
 
-constexpr int global_threads(int R) { return R <= 3 ? 1024 : 512; }   // wider windows need > 128 VGPRs
-constexpr int global_unroll(int R) { return R <= 3 ? 8 : 4; }         // rows in flight per wave (prefetch depth), even
+// Particles per block: every slice row a wave streams from the bank is used for NQ particles from registers (the bank is
+// re-read by every block, 141 MB per block at the default grid: with one particle per block the L2 -> L1 path, not the vector
+// unit, set the pace).  Two particles keep W tables of 2 x 64 KB in LDS; 512 threads (two waves per SIMD, 139 registers)
+// measured faster than 768 or 1024.
+constexpr int global_particles(int R) { return R <= 3 ? PPM_GLOBAL_PARTICLES : 1; }
+constexpr int global_threads(int R) { return R <= 3 ? PPM_GLOBAL_THREADS : 512; }   // wider windows need > 128 VGPRs
+constexpr int global_unroll(int R) { return R <= 3 ? PPM_GLOBAL_UNROLL : 4; }         // rows in flight per wave (prefetch depth), even
 
 // pairwise halving step of a cross-lane reduction: afterwards lanes with (lane & M) == 0 carry the partial sum of `a`, the
 // others that of `b`.  Between rows the two registers trade halves (one swap, one add); inside a row both are folded
@@ -568,23 +583,34 @@ __device__ __forceinline__ float reduce_halving(float (&v)[NV], int lane) {
 // the sum over kx of the shift window is a wavefront halving reduction.
 template <int R, bool HALF>
 __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
-    constexpr int NT = global_threads(R), NW = NT / 64, U = global_unroll(R), NS = 2 * R + 1;
+    constexpr int NT = global_threads(R), NW = NT / 64, U = global_unroll(R), NS = 2 * R + 1, NQ = global_particles(R);
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, p = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, p0 = blockIdx.x * NQ;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: slice addresses stay in SGPRs
     const int Hs = P.Hs, HsP = P.HsP, Bs = P.Bs, Ns = P.Ns, nsampP = HsP * 64;
-    float2 *Wl = (float2 *)smem;
-    {
-        const float2 *src = P.Wp + (size_t)p * Hs * 64;
+    const int nslices = P.n_dir * P.npsi_store;
+    float2 *Wl = (float2 *)smem;                                    // [NQ][nsampP]
+    int pq[NQ];                                                     // a short last block computes its last particle twice
+#pragma unroll
+    for (int q = 0; q < NQ; q++) pq[q] = min(p0 + q, P.n - 1);
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        const float2 *src = P.Wp + (size_t)pq[q] * Hs * 64;
         for (int i = tid; i < nsampP; i += NT) {
             const int rr = i >> 6, t = rr >> 1, ky = (rr & 1) ? -t : t;
             const bool ok = rr != 1 && t <= Bs;
             const int srow = ky + Bs;
-            Wl[i] = ok ? src[srow * 64 + (i & 63)] : make_float2(0.f, 0.f);
+            Wl[q * nsampP + i] = ok ? src[srow * 64 + (i & 63)] : make_float2(0.f, 0.f);
         }
     }
     __syncthreads();
-    const float nI = P.nI[p];
+    float nI[NQ];
+    const __attribute__((address_space(4))) float *c_nP[NQ];        // wave-uniform reads: scalar loads
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        nI[q] = P.nI[pq[q]];
+        c_nP[q] = (const __attribute__((address_space(4))) float *)P.nP + (size_t)pq[q] * nslices;
+    }
     float txc[R + 1], txs[R + 1];      // per-lane x twiddles e^{+2 pi i kx j / Ns}
 #pragma unroll
     for (int j = 0; j <= R; j++) {
@@ -592,9 +618,6 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
         txc[j] = t.x; txs[j] = t.y;
     }
     const RowTwPtr c_rowtw = (RowTwPtr)P.rowtw;
-    const int nslices = P.n_dir * P.npsi_store;
-    const __attribute__((address_space(4))) float *c_nP = (const __attribute__((address_space(4))) float *)P.nP + (size_t)p * nslices;   // wave-uniform reads: scalar loads
-    float *ccp = P.cc + (size_t)p * P.n_orient; int *shp = P.sh + (size_t)p * P.n_orient;
     // The first rows of a wave's NEXT slice are requested by the last step of the current one (and those of its first slice
     // here): no load stall at a slice start, and the prefetch of every step is unconditional (a conditional one made the
     // compiler copy the 8 row registers of the untouched set on every step).
@@ -607,13 +630,15 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
     for (int sl = wave; sl < nslices; sl += NW) {
         const float2 *Pp = P.bank + (size_t)sl * nsampP;          // wave-uniform base, lane added as a 32-bit offset
         const float2 *Pnext = P.bank + (size_t)(sl + NW < nslices ? sl + NW : sl) * nsampP;
-        // accumulators (packed re/im pairs): s* = sum over rows (shift row 0); per j: even part x cos (ua, ub),
+        // accumulators (packed re/im pairs) per particle: s* = sum over rows (shift row 0); per j: even part x cos (ua, ub),
         // odd part x sin (va, vb)
-        v2f sa = { 0.f, 0.f }, sb = { 0.f, 0.f };
-        const float nP = c_nP[sl];
-        v2f ua[R], ub[R], va[R], vb[R];
+        v2f sa[NQ], sb[NQ], ua[NQ][R], ub[NQ][R], va[NQ][R], vb[NQ][R];
 #pragma unroll
-        for (int j = 0; j < R; j++) { ua[j] = ub[j] = va[j] = vb[j] = (v2f){ 0.f, 0.f }; }
+        for (int q = 0; q < NQ; q++) {
+            sa[q] = sb[q] = (v2f){ 0.f, 0.f };
+#pragma unroll
+            for (int j = 0; j < R; j++) { ua[q][j] = ub[q][j] = va[q][j] = vb[q][j] = (v2f){ 0.f, 0.f }; }
+        }
         // U rows per step; the rows of the next step are prefetched into the other register set (ping-pong: no copies).
         // B = Im(P) (Wx, Wy) is accumulated instead of Bq = Im(P) (Wy, -Wx) (no swizzled copy of W per row): component swap
         // and sign commute with the row sums and are applied once per slice below (Bq.x = B.y, Bq.y = -B.x).
@@ -627,143 +652,161 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
             v4f tw[R], twn[R];
 #pragma unroll
             for (int j = 0; j < R; j++) tw[j] = c_rowtw[(row0 >> 1) * PPM_MAX_SHIFT_STEPS + j];
-            // ... and so are the particle's W rows (LDS) of the next pair
-            float2 wa = Wl[row0 * 64 + lane], wb = Wl[(row0 + 1) * 64 + lane];
+            // ... and so are the particles' W rows (LDS) of the next pair
+            float2 wa[NQ], wb[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; q++) { wa[q] = Wl[q * nsampP + row0 * 64 + lane]; wb[q] = Wl[q * nsampP + (row0 + 1) * 64 + lane]; }
 #pragma unroll
             for (int u = 0; u < U; u += 2) {
                 const int ra = row0 + u, tp = ra >> 1;
-                float2 wan = wa, wbn = wb;
+                float2 wan[NQ], wbn[NQ];
+#pragma unroll
+                for (int q = 0; q < NQ; q++) { wan[q] = wa[q]; wbn[q] = wb[q]; }
                 if (u + 2 < U) {
 #pragma unroll
                     for (int j = 0; j < R; j++) twn[j] = c_rowtw[(tp + 1) * PPM_MAX_SHIFT_STEPS + j];
-                    wan = Wl[(ra + 2) * 64 + lane]; wbn = Wl[(ra + 3) * 64 + lane];
+#pragma unroll
+                    for (int q = 0; q < NQ; q++) { wan[q] = Wl[q * nsampP + (ra + 2) * 64 + lane]; wbn[q] = Wl[q * nsampP + (ra + 3) * 64 + lane]; }
                 }
                 const float pax = cur[u].x, pay = cur[u].y, pbx = cur[u + 1].x, pby = cur[u + 1].y;
-                // A = Re(P) W, B = Im(P) W for both rows; even (+) and odd (-) parts of the pair
-                const v2f wav = { wa.x, wa.y }, wbv = { wb.x, wb.y };
-                const v2f aa = wav * pax, ab = wbv * pbx, ba = wav * pay, bb = wbv * pby;
-                const v2f as2 = aa + ab, ad2 = aa - ab, bs2 = ba + bb, bd2 = ba - bb;
-                sa += as2; sb += bs2;
 #pragma unroll
-                for (int j = 0; j < R; j++) {
-                    const v4f t = tw[j];                                          // wave-uniform -> SGPRs {c, c, s, s}
-                    const v2f tc = { t.x, t.y }, ts = { t.z, t.w };
-                    ua[j] += as2 * tc; ub[j] += bs2 * tc;
-                    va[j] += ad2 * ts; vb[j] += bd2 * ts;
+                for (int q = 0; q < NQ; q++) {
+                    // A = Re(P) W, B = Im(P) W for both rows; even (+) and odd (-) parts of the pair
+                    const v2f wav = { wa[q].x, wa[q].y }, wbv = { wb[q].x, wb[q].y };
+                    const v2f aa = wav * pax, ab = wbv * pbx, ba = wav * pay, bb = wbv * pby;
+                    const v2f as2 = aa + ab, ad2 = aa - ab, bs2 = ba + bb, bd2 = ba - bb;
+                    sa[q] += as2; sb[q] += bs2;
+#pragma unroll
+                    for (int j = 0; j < R; j++) {
+                        const v4f t = tw[j];                                          // wave-uniform -> SGPRs {c, c, s, s}
+                        const v2f tc = { t.x, t.y }, ts = { t.z, t.w };
+                        ua[q][j] += as2 * tc; ub[q][j] += bs2 * tc;
+                        va[q][j] += ad2 * ts; vb[q][j] += bd2 * ts;
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < R; j++) tw[j] = twn[j];
-                wa = wan; wb = wbn;
+#pragma unroll
+                for (int q = 0; q < NQ; q++) { wa[q] = wan[q]; wb[q] = wbn[q]; }
             }
         };
         __builtin_amdgcn_s_setprio(3);
         for (int row0 = 0; row0 < HsP; row0 += 2 * U) { step(row0, pv, pn); step(row0 + U, pn, pv); }      // HsP is a multiple of 2 U
         __builtin_amdgcn_s_setprio(0);          // the reduction tail is a chain of dependent cross-lane steps: let it issue first
-        const float sax = sa.x, say = sa.y, sbx = sb.y, sby = -sb.x;
-        float uax[R], uay[R], ubx[R], uby[R], vax[R], vay[R], vbx[R], vby[R];
-#pragma unroll
-        for (int j = 0; j < R; j++) {
-            uax[j] = ua[j].x; uay[j] = ua[j].y; ubx[j] = ub[j].y; uby[j] = -ub[j].x;
-            vax[j] = va[j].x; vay[j] = va[j].y; vbx[j] = vb[j].y; vby[j] = -vb[j].x;
-        }
-        const float inv = (nP > 0.f && nI > 0.f) ? rsqrtf(nP * nI) : 0.f;
         const int dir = sl / P.npsi_store, ks = sl - dir * P.npsi_store;
 #pragma unroll
-        for (int e = 0; e < (HALF ? 2 : 1); e++) {
-            // this orientation's Q = A + sg Bq: U = ua + sg ub, V = va + sg vb; G(+j) = U + iV, G(-j) = U - iV;
-            // value(iy, ix) = Re(G[iy] e^{+2 pi i kx (ix-R)/Ns})
-            const float sg = e ? -1.f : 1.f;
-            float best = -3.0e38f; int bsx_ = 0, bsy_ = 0;
-            if constexpr (NS * NS <= 64) {
-                float val[NS * NS];
+        for (int q = 0; q < NQ; q++) {
+            const float nP = c_nP[q][sl];
+            const float sax = sa[q].x, say = sa[q].y, sbx = sb[q].y, sby = -sb[q].x;
+            float uax[R], uay[R], ubx[R], uby[R], vax[R], vay[R], vbx[R], vby[R];
 #pragma unroll
-                for (int iy = 0; iy < NS; iy++) {
-                    const int jy = iy - R, ja = jy < 0 ? -jy : jy;
-                    float gx, gy;
-                    if (jy == 0) { gx = sax + sg * sbx; gy = say + sg * sby; }
-                    else {
-                        const float ux = uax[ja - 1] + sg * ubx[ja - 1], uy = uay[ja - 1] + sg * uby[ja - 1];
-                        const float vx = vax[ja - 1] + sg * vbx[ja - 1], vy = vay[ja - 1] + sg * vby[ja - 1];
-                        gx = jy > 0 ? ux - vy : ux + vy; gy = jy > 0 ? uy + vx : uy - vx;
-                    }
-                    val[iy * NS + R] = gx;
-#pragma unroll
-                    for (int j = 1; j <= R; j++) {
-                        const float pc = gx * txc[j], qs = gy * txs[j];
-                        val[iy * NS + R + j] = pc - qs;
-                        val[iy * NS + R - j] = pc + qs;
-                    }
-                }
-                const float tot = reduce_halving<NS * NS>(val, lane);
-                const int vi = (int)(__brev((unsigned)lane) >> 26);            // the value index this lane ended up with
-                const int iy = vi / NS, ix = vi - iy * NS;
-                const int ay = iy - R < 0 ? R - iy : iy - R, ax = ix - R < 0 ? R - ix : ix - R;
-                const float cand = (vi < NS * NS && ax <= P.RSx && ay <= P.RSy) ? tot : -3.0e38f;
-                // arg-max over lanes; ties -> lower (sy, sx) index like the oracle's scan order
-                best = wave_max(cand);
-                int ci = wave_min(cand == best ? vi : 64);
-                if (ci > 63) ci = 0;                                         // no comparable value (NaN scores)
-                bsy_ = ci / NS - R; bsx_ = ci - (ci / NS) * NS - R;
-            } else {
-#pragma unroll
-                for (int iy = 0; iy < NS; iy++) {
-                    const int jy = iy - R, ja = jy < 0 ? -jy : jy;
-                    float gx, gy;
-                    if (jy == 0) { gx = sax + sg * sbx; gy = say + sg * sby; }
-                    else {
-                        const float ux = uax[ja - 1] + sg * ubx[ja - 1], uy = uay[ja - 1] + sg * uby[ja - 1];
-                        const float vx = vax[ja - 1] + sg * vbx[ja - 1], vy = vay[ja - 1] + sg * vby[ja - 1];
-                        gx = jy > 0 ? ux - vy : ux + vy; gy = jy > 0 ? uy + vx : uy - vx;
-                    }
-#pragma unroll
-                    for (int ix = 0; ix < NS; ix++) {
-                        const int j = ix - R, jx = j < 0 ? -j : j;
-                        float v = j >= 0 ? (gx * txc[jx] - gy * txs[jx]) : (gx * txc[jx] + gy * txs[jx]);
-                        v = wave_sum(v);
-                        bool ok = (jx <= P.RSx) && (ja <= P.RSy);
-                        if (ok && v > best) { best = v; bsx_ = j; bsy_ = jy; }
-                    }
-                }
+            for (int j = 0; j < R; j++) {
+                uax[j] = ua[q][j].x; uay[j] = ua[q][j].y; ubx[j] = ub[q][j].y; uby[j] = -ub[q][j].x;
+                vax[j] = va[q][j].x; vay[j] = va[q][j].y; vbx[j] = vb[q][j].y; vby[j] = -vb[q][j].x;
             }
-            if (lane == 0) {
-                int o = dir * P.n_psi + ks + e * P.npsi_store;
-                ccp[o] = best * inv;
-                shp[o] = (bsx_ & 0xffff) | (bsy_ << 16);
+            const float inv = (nP > 0.f && nI[q] > 0.f) ? rsqrtf(nP * nI[q]) : 0.f;
+            float *ccp = P.cc + (size_t)pq[q] * P.n_orient; int *shp = P.sh + (size_t)pq[q] * P.n_orient;
+#pragma unroll
+            for (int e = 0; e < (HALF ? 2 : 1); e++) {
+                // this orientation's Q = A + sg Bq: U = ua + sg ub, V = va + sg vb; G(+j) = U + iV, G(-j) = U - iV;
+                // value(iy, ix) = Re(G[iy] e^{+2 pi i kx (ix-R)/Ns})
+                const float sg = e ? -1.f : 1.f;
+                float best = -3.0e38f; int bsx_ = 0, bsy_ = 0;
+                if constexpr (NS * NS <= 64) {
+                    float val[NS * NS];
+#pragma unroll
+                    for (int iy = 0; iy < NS; iy++) {
+                        const int jy = iy - R, ja = jy < 0 ? -jy : jy;
+                        float gx, gy;
+                        if (jy == 0) { gx = sax + sg * sbx; gy = say + sg * sby; }
+                        else {
+                            const float ux = uax[ja - 1] + sg * ubx[ja - 1], uy = uay[ja - 1] + sg * uby[ja - 1];
+                            const float vx = vax[ja - 1] + sg * vbx[ja - 1], vy = vay[ja - 1] + sg * vby[ja - 1];
+                            gx = jy > 0 ? ux - vy : ux + vy; gy = jy > 0 ? uy + vx : uy - vx;
+                        }
+                        val[iy * NS + R] = gx;
+#pragma unroll
+                        for (int j = 1; j <= R; j++) {
+                            const float pc = gx * txc[j], qs = gy * txs[j];
+                            val[iy * NS + R + j] = pc - qs;
+                            val[iy * NS + R - j] = pc + qs;
+                        }
+                    }
+                    const float tot = reduce_halving<NS * NS>(val, lane);
+                    const int vi = (int)(__brev((unsigned)lane) >> 26);            // the value index this lane ended up with
+                    const int iy = vi / NS, ix = vi - iy * NS;
+                    const int ay = iy - R < 0 ? R - iy : iy - R, ax = ix - R < 0 ? R - ix : ix - R;
+                    const float cand = (vi < NS * NS && ax <= P.RSx && ay <= P.RSy) ? tot : -3.0e38f;
+                    // arg-max over lanes; ties -> lower (sy, sx) index like the oracle's scan order
+                    best = wave_max(cand);
+                    int ci = wave_min(cand == best ? vi : 64);
+                    if (ci > 63) ci = 0;                                         // no comparable value (NaN scores)
+                    bsy_ = ci / NS - R; bsx_ = ci - (ci / NS) * NS - R;
+                } else {
+#pragma unroll
+                    for (int iy = 0; iy < NS; iy++) {
+                        const int jy = iy - R, ja = jy < 0 ? -jy : jy;
+                        float gx, gy;
+                        if (jy == 0) { gx = sax + sg * sbx; gy = say + sg * sby; }
+                        else {
+                            const float ux = uax[ja - 1] + sg * ubx[ja - 1], uy = uay[ja - 1] + sg * uby[ja - 1];
+                            const float vx = vax[ja - 1] + sg * vbx[ja - 1], vy = vay[ja - 1] + sg * vby[ja - 1];
+                            gx = jy > 0 ? ux - vy : ux + vy; gy = jy > 0 ? uy + vx : uy - vx;
+                        }
+#pragma unroll
+                        for (int ix = 0; ix < NS; ix++) {
+                            const int j = ix - R, jx = j < 0 ? -j : j;
+                            float v = j >= 0 ? (gx * txc[jx] - gy * txs[jx]) : (gx * txc[jx] + gy * txs[jx]);
+                            v = wave_sum(v);
+                            bool ok = (jx <= P.RSx) && (ja <= P.RSy);
+                            if (ok && v > best) { best = v; bsx_ = j; bsy_ = jy; }
+                        }
+                    }
+                }
+                if (lane == 0 && (q == 0 || p0 + q < P.n)) {
+                    int o = dir * P.n_psi + ks + e * P.npsi_store;
+                    ccp[o] = best * inv;
+                    shp[o] = (bsx_ & 0xffff) | (bsy_ << 16);
+                }
             }
         }
     }
-    // ---- top-K of this particle's scores (ties -> lower orientation index): the scores are copied into LDS once (the W
-    // table is no longer needed) and every winner is struck out there
+    // ---- top-K of each particle's scores (ties -> lower orientation index): the scores are copied into LDS once (the W
+    // tables are no longer needed) and every winner is struck out there
     __threadfence_block();
     __syncthreads();
     float *rv = (float *)smem; int *ri = (int *)(rv + 16);
-    float *sc = P.topk_lds ? rv + 32 : ccp;           // host: the LDS allocation covers 32 + n_orient floats when topk_lds is set
-    if (P.topk_lds) for (int o = tid; o < P.n_orient; o += NT) sc[o] = ccp[o];
-    __syncthreads();
-    for (int k = 0; k < P.K; k++) {
-        float bv = -3.0e38f; int bi = 0x7fffffff;
-        for (int o = tid; o < P.n_orient; o += NT) {
-            const float v = sc[o];                          // struck-out entries are -inf: never above the start value
-            if (v > bv || (v == bv && o < bi)) { bv = v; bi = o; }
-        }
+    for (int q = 0; q < NQ && p0 + q < P.n; q++) {
+        const int p = p0 + q;
+        float *ccp = P.cc + (size_t)p * P.n_orient; int *shp = P.sh + (size_t)p * P.n_orient;
+        float *sc = P.topk_lds ? rv + 32 : ccp;           // host: the LDS allocation covers 32 + n_orient floats when topk_lds is set
+        if (P.topk_lds) for (int o = tid; o < P.n_orient; o += NT) sc[o] = ccp[o];
+        __syncthreads();
+        for (int k = 0; k < P.K; k++) {
+            float bv = -3.0e38f; int bi = 0x7fffffff;
+            for (int o = tid; o < P.n_orient; o += NT) {
+                const float v = sc[o];                          // struck-out entries are -inf: never above the start value
+                if (v > bv || (v == bv && o < bi)) { bv = v; bi = o; }
+            }
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-            float ov = __shfl_xor(bv, m, 64); int oi = __shfl_xor(bi, m, 64);
-            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            for (int m = 32; m >= 1; m >>= 1) {
+                float ov = __shfl_xor(bv, m, 64); int oi = __shfl_xor(bi, m, 64);
+                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
+            if (lane == 0) { rv[wave] = bv; ri[wave] = bi; }
+            __syncthreads();
+            if (tid == 0) {
+                for (int w = 1; w < NW; w++) if (rv[w] > bv || (rv[w] == bv && ri[w] < bi)) { bv = rv[w]; bi = ri[w]; }
+                if (bi >= P.n_orient) { bi = 0; bv = 0.f; }     // nothing comparable left (NaN scores): stay inside the tables
+                Hit h; h.cc = bv; h.orient = bi;
+                int sv = shp[bi];
+                h.sx = (int)(short)(sv & 0xffff); h.sy = sv >> 16;
+                P.hits[(size_t)p * P.K + k] = h;
+                if (bi < P.n_orient) sc[bi] = -__builtin_inff();
+            }
+            __threadfence_block();
+            __syncthreads();
         }
-        if (lane == 0) { rv[wave] = bv; ri[wave] = bi; }
-        __syncthreads();
-        if (tid == 0) {
-            for (int w = 1; w < NW; w++) if (rv[w] > bv || (rv[w] == bv && ri[w] < bi)) { bv = rv[w]; bi = ri[w]; }
-            if (bi >= P.n_orient) { bi = 0; bv = 0.f; }     // nothing comparable left (NaN scores): stay inside the tables
-            Hit h; h.cc = bv; h.orient = bi;
-            int sv = shp[bi];
-            h.sx = (int)(short)(sv & 0xffff); h.sy = sv >> 16;
-            P.hits[(size_t)p * P.K + k] = h;
-            if (bi < P.n_orient) sc[bi] = -__builtin_inff();
-        }
-        __threadfence_block();
-        __syncthreads();
     }
 }
 

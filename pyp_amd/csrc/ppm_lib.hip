@@ -300,18 +300,19 @@ static int launch_global_r(const GlobP &P, int n_img, bool half, size_t lds) {
     if (half) {
         static bool set = false;
         if (!set) { HIPCHK(hipFuncSetAttribute((const void *)k_global<R, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; }
-        hipLaunchKernelGGL((k_global<R, true>), dim3(n_img), dim3(global_threads(R)), lds, g.stream, P);
+        hipLaunchKernelGGL((k_global<R, true>), dim3((n_img + global_particles(R) - 1) / global_particles(R)), dim3(global_threads(R)), lds, g.stream, P);
     } else {
         static bool set = false;
         if (!set) { HIPCHK(hipFuncSetAttribute((const void *)k_global<R, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; }
-        hipLaunchKernelGGL((k_global<R, false>), dim3(n_img), dim3(global_threads(R)), lds, g.stream, P);
+        hipLaunchKernelGGL((k_global<R, false>), dim3((n_img + global_particles(R) - 1) / global_particles(R)), dim3(global_threads(R)), lds, g.stream, P);
     }
     HIPCHK(hipGetLastError());
     return 0;
 }
 
 static int launch_global(GlobP &P, int n_img, bool half, int R) {
-    size_t lds = (size_t)P.HsP * 64 * sizeof(float2);
+    size_t lds = (size_t)P.HsP * 64 * sizeof(float2) * global_particles(R);
+    P.n = n_img;
     if (lds < 1024) lds = 1024;
     // the top-K pass re-uses the block's LDS for a copy of the particle's n_orient scores when they fit (160 KB = 40 928
     // orientations, e.g. 8 deg at C1); finer grids select on the global scratch instead
