@@ -161,8 +161,9 @@ def pmc_valu(summary, kernel, slices_per_particle):
 
 def global_flops_per_slice(band, search_range_px, box):
     """Executed fp32 operations of k_global per STORED slice (it serves psi and psi + 180): per lane and row PAIR
-    16 R FMA-flops for the shift rows (4 R packed FMAs on 2-vectors), 12 for the model norm and 20 for the even / odd
-    (A, Bq) parts; about 800 per lane for the window reduction and the recombination.  Row pairs = HsP / 2 with
+    16 R FMA-flops for the shift rows (4 R packed FMAs on 2-vectors), 20 for the even / odd (A, Bq) parts and 4 for the
+    two row sums; about 800 per lane for the window reduction and the recombination.  (The model norm sum C2 |P|^2 is a
+    separate fp32 MFMA product, k_slice_norms, reported as `norms_mfma`.)  Row pairs = HsP / 2 with
     HsP = 2 (Bs + 1) rounded up to the loop's trip (16 rows for R <= 3, 8 above); 64 lanes, masked lanes included
     (they execute).  DESIGN.md §4."""
     Bs = int(np.ceil(band)) - 1
@@ -172,7 +173,7 @@ def global_flops_per_slice(band, search_range_px, box):
     R = max(1, min(8, int(np.ceil(search_range_px / (box / Ns))))) if search_range_px > 0 else 8
     trip = 16 if R <= 3 else 8
     HsP = ((2 * (Bs + 1) + trip - 1) // trip) * trip
-    return 64 * (HsP // 2) * (16 * R + 12 + 20) + 64 * 800, R, HsP
+    return 64 * (HsP // 2) * (16 * R + 20 + 4) + 64 * 800, R, HsP
 
 
 # --------------------------------------------------------------------------------------------- main
@@ -308,7 +309,7 @@ def refine_bench(ctx):
     roof = {"bound": "valu_fp32", "kernel": "k_global", "achieved": round(tf, 2), "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tf / PEAK_VALU_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(ms_g, 3),
             "particles_per_launch": round(ppl, 1), "flops_per_launch": flops_g,
-            "flop_model": "stored slices (%d) x [64 lanes x %d row pairs x (16 R + 32) + 64 x 800], R = %d shift rows; executed fp32 "
+            "flop_model": "stored slices (%d) x [64 lanes x %d row pairs x (16 R + 24) + 64 x 800], R = %d shift rows; executed fp32 "
                           "operations incl. masked lanes (DESIGN.md §4)" % (int(n_slices), HsP // 2, R),
             "in_band_fraction_of_lane_rows": round(S_g / (64.0 * HsP), 3),
             "hbm_streaming_model": {"bytes_per_launch": bytes_model, "GBps": round(gbps_model, 1),
@@ -316,6 +317,15 @@ def refine_bench(ctx):
                                     "note": "SURVEY §8(d) contract figure 8 S(r) bytes per orientation; the 144 MB slice bank is shared by all "
                                             "particles and served from L2 / Infinity Cache, so this is not HBM traffic (see traffic)"},
             "hbm_traffic_frac": None if traffic is None else round(traffic / (ms_g * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4)}
+    if prof.get("norms", {}).get("launches"):
+        # the slice norms: n x n_slices x K fp32 MFMA product per launch, K = (2 Bs + 1) bank rows x 64 columns
+        Bs_ = int(np.ceil(a.band)) - 1
+        ms_n = prof["norms"]["ms"] / prof["norms"]["launches"]
+        fl_n = 2.0 * ppl * n_slices * (2 * Bs_ + 1) * 64
+        roof["norms_mfma"] = {"kernel": "k_slice_norms", "avg_launch_ms": round(ms_n, 3), "flops_per_launch": fl_n,
+                              "achieved": round(fl_n / (ms_n * 1e-3) / 1e12, 2), "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s",
+                              "frac": round(fl_n / (ms_n * 1e-3) / 1e12 / PEAK_VALU_TFLOPS, 4),
+                              "note": "v_mfma_f32_32x32x2_f32: the fp32 matrix peak equals the fp32 vector peak (256 flop / cycle / CU)"}
     pv = pmc_valu("r02_pmc_refine.json", "k_global", n_slices)
     if pv:
         pv["model_flops_per_lane_instruction"] = round(fl_slice / (pv["SQ_INSTS_VALU_per_slice"] * 64.0), 3)
