@@ -45,10 +45,12 @@ __device__ __forceinline__ float wave_sum(float v) {
     float w = v; lane_swap<16>(v, w); v += w;
     w = v; lane_swap<32>(v, w); return v + w;
 }
+// v_max_f32 as it is (returns the other operand for a NaN): fmaxf() adds a canonicalising v_max per operand
+__device__ __forceinline__ float max_raw(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float wave_max(float v) {
-    v = fmaxf(v, dpp_mov<kDppXor1>(v)); v = fmaxf(v, dpp_mov<kDppXor2>(v)); v = fmaxf(v, dpp_mov<kDppHalfMirror>(v)); v = fmaxf(v, dpp_mov<kDppMirror>(v));
-    float w = v; lane_swap<16>(v, w); v = fmaxf(v, w);
-    w = v; lane_swap<32>(v, w); return fmaxf(v, w);
+    v = max_raw(v, dpp_mov<kDppXor1>(v)); v = max_raw(v, dpp_mov<kDppXor2>(v)); v = max_raw(v, dpp_mov<kDppHalfMirror>(v)); v = max_raw(v, dpp_mov<kDppMirror>(v));
+    float w = v; lane_swap<16>(v, w); v = max_raw(v, w);
+    w = v; lane_swap<32>(v, w); return max_raw(v, w);
 }
 __device__ __forceinline__ float wave_min(float v) { return -wave_max(-v); }
 __device__ __forceinline__ int wave_min(int v) {

@@ -534,6 +534,39 @@ struct GlobP {
     int topk_lds;         // 1: the top-K pass works on an LDS copy of the particle's scores (they fit), 0: on the global scratch
 };
 
+// The same for pairs of values held in packed registers (both orientations of a stored slice): the swaps and DPP steps work
+// on 32-bit registers, the adds between rows on the pair.
+template <int M> __device__ __forceinline__ v2f halve_pair2(v2f a, v2f b, int lane) {
+    float a0 = a.x, a1 = a.y, b0 = b.x, b1 = b.y;
+    if constexpr (M >= 16) {
+        lane_swap<M>(a0, b0); lane_swap<M>(a1, b1);
+        return (v2f){ a0, a1 } + (v2f){ b0, b1 };
+    } else {
+        constexpr int ctrl = M == 8 ? kDppRor8 : M == 4 ? kDppHalfMirror : M == 2 ? kDppXor2 : kDppXor1;
+        const bool hi = (lane & M) != 0;
+        const float t0 = a0 + dpp_mov<ctrl>(a0), t1 = a1 + dpp_mov<ctrl>(a1), u0 = b0 + dpp_mov<ctrl>(b0), u1 = b1 + dpp_mov<ctrl>(b1);
+        return (v2f){ hi ? u0 : t0, hi ? u1 : t1 };
+    }
+}
+template <int NV>
+__device__ __forceinline__ v2f reduce_halving2(v2f (&v)[NV], int lane) {
+    static_assert(NV <= 64, "one output register pair");
+    constexpr int n1 = (NV + 1) / 2, n2 = (n1 + 1) / 2, n3 = (n2 + 1) / 2, n4 = (n3 + 1) / 2, n5 = (n4 + 1) / 2;
+    const v2f z = { 0.f, 0.f };
+    v2f a1[n1], a2[n2], a3[n3], a4[n4], a5[n5];
+#pragma unroll
+    for (int i = 0; i < n1; i++) a1[i] = halve_pair2<32>(v[2 * i], (2 * i + 1 < NV) ? v[2 * i + 1] : z, lane);
+#pragma unroll
+    for (int i = 0; i < n2; i++) a2[i] = halve_pair2<16>(a1[2 * i], (2 * i + 1 < n1) ? a1[2 * i + 1] : z, lane);
+#pragma unroll
+    for (int i = 0; i < n3; i++) a3[i] = halve_pair2<8>(a2[2 * i], (2 * i + 1 < n2) ? a2[2 * i + 1] : z, lane);
+#pragma unroll
+    for (int i = 0; i < n4; i++) a4[i] = halve_pair2<4>(a3[2 * i], (2 * i + 1 < n3) ? a3[2 * i + 1] : z, lane);
+#pragma unroll
+    for (int i = 0; i < n5; i++) a5[i] = halve_pair2<2>(a4[2 * i], (2 * i + 1 < n4) ? a4[2 * i + 1] : z, lane);
+    return halve_pair2<1>(a5[0], (n5 > 1) ? a5[1] : z, lane);
+}
+
 // Particles per block: every slice row a wave streams from the bank is used for NQ particles from registers (the bank is
 // re-read by every block, 141 MB per block at the default grid: with one particle per block the L2 -> L1 path, not the vector
 // unit, set the pace).  Two particles keep W tables of 2 x 64 KB in LDS; 512 threads (two waves per SIMD, 139 registers)
@@ -706,6 +739,50 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
             }
             const float inv = (nP > 0.f && nI[q] > 0.f) ? rsqrtf(nP * nI[q]) : 0.f;
             float *ccp = P.cc + (size_t)pq[q] * P.n_orient; int *shp = P.sh + (size_t)pq[q] * P.n_orient;
+            if constexpr (HALF && NS * NS <= 64) {
+                // both orientations of the stored slice at once, in the halves of packed registers (.x: psi, sg = +1; .y: psi + 180 deg,
+                // sg = -1): Q = A + sg Bq, U = ua + sg ub, V = va + sg vb; G(+j) = U + iV, G(-j) = U - iV;
+                // value(iy, ix) = Re(G[iy] e^{+2 pi i kx (ix-R)/Ns})
+                const v2f sg2 = { 1.f, -1.f };
+                v2f val[NS * NS];
+#pragma unroll
+                for (int iy = 0; iy < NS; iy++) {
+                    const int jy = iy - R, ja = jy < 0 ? -jy : jy;
+                    v2f gx, gy;
+                    if (jy == 0) { gx = sax + sg2 * sbx; gy = say + sg2 * sby; }
+                    else {
+                        const v2f ux = uax[ja - 1] + sg2 * ubx[ja - 1], uy = uay[ja - 1] + sg2 * uby[ja - 1];
+                        const v2f vx = vax[ja - 1] + sg2 * vbx[ja - 1], vy = vay[ja - 1] + sg2 * vby[ja - 1];
+                        gx = jy > 0 ? ux - vy : ux + vy; gy = jy > 0 ? uy + vx : uy - vx;
+                    }
+                    val[iy * NS + R] = gx;
+#pragma unroll
+                    for (int j = 1; j <= R; j++) {
+                        const v2f pc = gx * txc[j], qs = gy * txs[j];
+                        val[iy * NS + R + j] = pc - qs;
+                        val[iy * NS + R - j] = pc + qs;
+                    }
+                }
+                const v2f tot = reduce_halving2<NS * NS>(val, lane);
+                const int vi = (int)(__brev((unsigned)lane) >> 26);            // the value index this lane ended up with
+                const int iy = vi / NS, ix = vi - iy * NS;
+                const int ay = iy - R < 0 ? R - iy : iy - R, ax = ix - R < 0 ? R - ix : ix - R;
+                const bool inwin = vi < NS * NS && ax <= P.RSx && ay <= P.RSy;
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const float cand = inwin ? (e ? tot.y : tot.x) : -3.0e38f;
+                    // arg-max over lanes; ties -> lower (sy, sx) index like the oracle's scan order
+                    const float best = wave_max(cand);
+                    int ci = wave_min(cand == best ? vi : 64);
+                    if (ci > 63) ci = 0;                                         // no comparable value (NaN scores)
+                    const int bsy_ = ci / NS - R, bsx_ = ci - (ci / NS) * NS - R;
+                    if (lane == 0 && (q == 0 || p0 + q < P.n)) {
+                        int o = dir * P.n_psi + ks + e * P.npsi_store;
+                        ccp[o] = best * inv;
+                        shp[o] = (bsx_ & 0xffff) | (bsy_ << 16);
+                    }
+                }
+            } else
 #pragma unroll
             for (int e = 0; e < (HALF ? 2 : 1); e++) {
                 // this orientation's Q = A + sg Bq: U = ua + sg ub, V = va + sg vb; G(+j) = U + iV, G(-j) = U - iV;
