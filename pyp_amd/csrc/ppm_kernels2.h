@@ -562,8 +562,11 @@ __global__ void k_insert_params(const double *rows, PartIns *pp, CullEnt *cull, 
     }
 }
 
-// grid: (items, 2 halves), NW waves.  Per round of up to CULL_CAP (particle, operator) entries of the item's slice:
-//   CULL  every thread tests entries (slice-plane normal vs the brick's expanded box) and the cutting ones are collected in
+// grid: (items, 2 halves), NW waves.  A brick OWNS the samples whose base voxel floor(Q) lies in its BE^3 box and keeps a
+// one-voxel halo on the + faces for their upper taps ((BE+1)^3 cells in LDS): every sample is evaluated exactly once, none
+// of its 8 taps needs a bounds test, and the halo cells are added to the neighbours' voxels when the brick is written back.
+// Per round of up to CULL_CAP (particle, operator) entries of the item's slice:
+//   CULL  every thread tests entries (slice-plane normal vs the brick's box) and the cutting ones are collected in
 //         a block-wide LDS list;
 //   WORK  waves pull cuts from that list (dynamic balance); for one cut, lane = slice row: the kx interval that can reach
 //         the brick is solved per row (three slabs + the band), the candidates of all rows are dealt out densely over the
@@ -576,8 +579,8 @@ __global__ void k_insert_params(const double *rows, PartIns *pp, CullEnt *cull, 
 constexpr int CULL_CAP = 4096;
 template <int BE, int NW>
 __global__ void __launch_bounds__(NW * 64) k_insert_bricks(InsertBrickP P) {
-    extern __shared__ long long brick[];           // [BE][BE][BE][3] with padded row / plane strides SY, SZ (in 8-byte cells):
-    constexpr int SY = BE * 3 + 1, SZ = BE * SY + 3;   // odd strides spread the 8 taps of neighbouring samples over the banks
+    extern __shared__ long long brick[];           // [BE+1][BE+1][BE+1][3] with padded row / plane strides SY, SZ (in 8-byte cells):
+    constexpr int BH = BE + 1, SY = BH * 3 + 1, SZ = BH * SY + 3;   // odd strides spread the 8 taps of neighbouring samples over the banks
                                                        // (unpadded, 3/4 of the LDS atomic cycles were bank conflicts)
     __shared__ unsigned queue_s[NW][128];
     __shared__ int cut_list[CULL_CAP];
@@ -598,10 +601,10 @@ __global__ void __launch_bounds__(NW * 64) k_insert_bricks(InsertBrickP P) {
     // voxel COORDINATES covered by this brick: x in [x_lo, x_lo+BE), y, z likewise (stored index = coordinate + N/2)
     const int x_lo = it.bx * BE, y_lo = it.by * BE - N / 2, z_lo = it.bz * BE - N / 2;
     const int p_lo = (int)((long)P.n_img * it.s / it.S), p_hi = (int)((long)P.n_img * (it.s + 1) / it.S);
-    for (int i = tid; i < BE * SZ; i += NW * 64) brick[i] = 0ll;
+    for (int i = tid; i < BH * SZ; i += NW * 64) brick[i] = 0ll;
     __syncthreads();
-    // sample positions Q whose floor() lies in [lo-1, lo+BE-1] touch the brick:  lo-1 <= Q < lo+BE
-    const float cx = x_lo - 1 + 0.5f * (BE + 1), cy = y_lo - 1 + 0.5f * (BE + 1), cz = z_lo - 1 + 0.5f * (BE + 1), hh = 0.5f * (BE + 1);
+    // sample positions Q whose floor() lies in [lo, lo+BE-1] belong to the brick:  lo <= Q < lo+BE
+    const float cx = x_lo + 0.5f * BE, cy = y_lo + 0.5f * BE, cz = z_lo + 0.5f * BE, hh = 0.5f * BE;
     unsigned *queue = queue_s[wave];
     int qn = 0;
     bool touched = false;
@@ -660,16 +663,15 @@ __global__ void __launch_bounds__(NW * 64) k_insert_bricks(InsertBrickP P) {
             const float vr = sv * w * cv * (iv.x * cs - iv.y * sn), vw = sw * w * cv * cv;
             float vi = sv * w * cv * (iv.x * sn + iv.y * cs);
             if (refl) vi = -vi;
+            unsigned long long *const v0 = (unsigned long long *)brick + z0 * SZ + y0 * SY + x0 * 3;      // base voxel inside the box: all taps inside the haloed brick
 #pragma unroll
             for (int dz = 0; dz < 2; dz++)
 #pragma unroll
                 for (int dy = 0; dy < 2; dy++)
 #pragma unroll
                     for (int dx = 0; dx < 2; dx++) {
-                        const int xi = x0 + dx, yi = y0 + dy, zi = z0 + dz;
-                        if ((unsigned)xi >= (unsigned)BE || (unsigned)yi >= (unsigned)BE || (unsigned)zi >= (unsigned)BE) continue;
                         const float wt = (dx ? fx : 1.f - fx) * (dy ? fy : 1.f - fy) * (dz ? fz : 1.f - fz);
-                        unsigned long long *v = (unsigned long long *)brick + zi * SZ + yi * SY + xi * 3;
+                        unsigned long long *v = v0 + dz * SZ + dy * SY + dx * 3;
                         atomicAdd(v, (unsigned long long)(long long)__float2int_rn(wt * vr));
                         atomicAdd(v + 1, (unsigned long long)(long long)__float2int_rn(wt * vi));
                         atomicAdd(v + 2, (unsigned long long)(long long)__float2int_rn(wt * vw));
@@ -694,10 +696,10 @@ __global__ void __launch_bounds__(NW * 64) k_insert_bricks(InsertBrickP P) {
                 if (rem <= 0.f) hi = lo - 1; else { const int m = (int)sqrtf(rem) + 1; hi = hi < m ? hi : m; }
                 const float fs = (float)sgn, fky = fs * (float)kyr;
                 const float aa[3] = { fs * a0, fs * b0, fs * c0 }, tt[3] = { fky * a1, fky * b1, fky * c1 };
-                const float LL[3] = { (float)(x_lo - 1), (float)(y_lo - 1), (float)(z_lo - 1) };
+                const float LL[3] = { (float)x_lo, (float)y_lo, (float)z_lo };
 #pragma unroll
                 for (int ax = 0; ax < 3; ax++) {
-                    const float a = aa[ax], t = tt[ax], L = LL[ax], U = LL[ax] + (float)(BE + 1);
+                    const float a = aa[ax], t = tt[ax], L = LL[ax], U = LL[ax] + (float)BE;
                     if (fabsf(a) > 1e-3f) {
                         const float ra = __frcp_rn(a), e0 = (L - t) * ra, e1 = (U - t) * ra;
                         const float el = fminf(fmaxf(fminf(e0, e1), -1024.f), 1024.f), eh = fminf(fmaxf(fmaxf(e0, e1), -1024.f), 1024.f);
@@ -726,7 +728,7 @@ __global__ void __launch_bounds__(NW * 64) k_insert_bricks(InsertBrickP P) {
                 if (refl) { X = -X; Y = -Y; Z = -Z; }
                 const int x0 = (int)floorf(X) - x_lo, y0 = (int)floorf(Y) - y_lo, z0 = (int)floorf(Z) - z_lo;
                 const bool hit = j < total && k2 < P.r2 && k2 != 0.f && refl == (sgn < 0) &&
-                                 (unsigned)(x0 + 1) <= (unsigned)BE && (unsigned)(y0 + 1) <= (unsigned)BE && (unsigned)(z0 + 1) <= (unsigned)BE;
+                                 (unsigned)x0 < (unsigned)BE && (unsigned)y0 < (unsigned)BE && (unsigned)z0 < (unsigned)BE;
                 const unsigned long long m = __ballot(hit);
                 if (m == 0ull) continue;
                 if (hit) queue[qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (unsigned)kx | ((unsigned)(ky + 512) << 16);
@@ -752,16 +754,15 @@ __global__ void __launch_bounds__(NW * 64) k_insert_bricks(InsertBrickP P) {
     if (!any) return;
     const size_t NX = N / 2 + 1;
     float *A = P.acc + (size_t)h * N * N * NX * 3;
-    for (int i = tid; i < BE * BE * BE * 3; i += NW * 64) {       // BE*3 consecutive floats per (y, z) row of the brick
-        const int x3 = i % (BE * 3), yi = (i / (BE * 3)) % BE, zi = i / (BE * BE * 3);
+    for (int i = tid; i < BH * BH * BH * 3; i += NW * 64) {       // BH*3 consecutive floats per (y, z) row of the brick
+        const int x3 = i % (BH * 3), yi = (i / (BH * 3)) % BH, zi = i / (BH * BH * 3);
         const long long vq = brick[zi * SZ + yi * SY + x3];
         if (vq == 0ll) continue;
         const int gy = y_lo + yi + N / 2, gz = z_lo + zi + N / 2;
         if (x_lo * 3 + x3 >= (int)NX * 3 || gy >= N || gz >= N) continue;
         float *o = A + (((size_t)gz * N + gy) * NX + x_lo) * 3 + x3;
         const float v = (float)((double)vq / (double)(i % 3 == 2 ? sw : sv));
-        if (it.S == 1) *o += v;          // sole owner of this brick in this launch
-        else atomicAdd(o, v);
+        atomicAdd(o, v);                 // halo cells belong to the neighbours' boxes: no voxel has a sole owner
     }
 }
 

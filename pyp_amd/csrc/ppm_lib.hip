@@ -176,11 +176,11 @@ struct ppm_accum {
 };
 
 // Work items of the brick insertion (k_insert_bricks): expected load of a brick = share of random slice planes that cut
-// its (expanded) box, estimated with a fixed set of normals; heavy bricks are cut into up to `cap` particle slices and the
+// its box, estimated with a fixed set of normals; heavy bricks are cut into up to `cap` particle slices and the
 // items are sorted heavy-first.  Bricks wholly outside the band carry no item.
 static int build_brick_items(ppm_accum *a, const Geom &gm, int BE, int nb) {
     const int N = gm.N, nbx = (N / 2 + 1 + BE - 1) / BE, nby = (N + BE - 1) / BE;
-    const float r = (float)gm.r_hi, hh = 0.5f * (BE + 1);
+    const float r = (float)gm.r_hi, hh = 0.5f * BE;
     if (a->load_r != r || a->brick_load.empty()) {
         const int NS = 192;
         std::vector<float> nrm(NS * 3);
@@ -191,10 +191,10 @@ static int build_brick_items(ppm_accum *a, const Geom &gm, int BE, int nb) {
         a->brick_load.assign((size_t)nbx * nby * nby, -1.f);
         for (int bz = 0; bz < nby; bz++) for (int by = 0; by < nby; by++) for (int bx = 0; bx < nbx; bx++) {
             const int x_lo = bx * BE, y_lo = by * BE - N / 2, z_lo = bz * BE - N / 2;
-            const float dx = std::max(std::max((float)(x_lo - 1), -(float)(x_lo + BE)), 0.f), dy = std::max(std::max((float)(y_lo - 1), -(float)(y_lo + BE)), 0.f),
-                        dz = std::max(std::max((float)(z_lo - 1), -(float)(z_lo + BE)), 0.f);
+            const float dx = std::max(std::max((float)x_lo, -(float)(x_lo + BE)), 0.f), dy = std::max(std::max((float)y_lo, -(float)(y_lo + BE)), 0.f),
+                        dz = std::max(std::max((float)z_lo, -(float)(z_lo + BE)), 0.f);
             if (dx * dx + dy * dy + dz * dz >= r * r) continue;
-            const float cx = x_lo - 1 + hh, cy = y_lo - 1 + hh, cz = z_lo - 1 + hh;
+            const float cx = x_lo + hh, cy = y_lo + hh, cz = z_lo + hh;
             int cut = 0;
             for (int i = 0; i < NS; i++) {
                 const float *n = &nrm[i * 3];
@@ -721,7 +721,7 @@ ppm_accum_t *ppm_accum_create(int box, float pixel_size, const char *symmetry, v
     HIPCHKP(hipMemset(a->d_counts, 0, 2 * sizeof(unsigned long long)));
     HIPCHKP(hipMalloc(&a->d_max, 2 * sizeof(unsigned)));
     static bool attr_set = false;
-    if (!attr_set) { HIPCHKP(hipFuncSetAttribute((const void *)k_insert_bricks<16, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * (16 * 49 + 3) * 8)); attr_set = true; }
+    if (!attr_set) { HIPCHKP(hipFuncSetAttribute((const void *)k_insert_bricks<16, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 17 * (17 * 52 + 3) * 8)); attr_set = true; }
     return guard.release();
 }
 
@@ -788,8 +788,8 @@ int ppm_insert_batch(ppm_accum_t *a, const ppm_recon_cfg *cfg, const void *image
         {
             ProfScope ps(PPM_K_INSERT);
             dim3 grid((unsigned)a->n_items, 2);
-            if (BE == 16) hipLaunchKernelGGL((k_insert_bricks<16, 16>), grid, dim3(1024), 16 * (16 * 49 + 3) * sizeof(long long), g.stream, IP);
-            else hipLaunchKernelGGL((k_insert_bricks<8, 4>), grid, dim3(256), 8 * (8 * 25 + 3) * sizeof(long long), g.stream, IP);
+            if (BE == 16) hipLaunchKernelGGL((k_insert_bricks<16, 16>), grid, dim3(1024), 17 * (17 * 52 + 3) * sizeof(long long), g.stream, IP);
+            else hipLaunchKernelGGL((k_insert_bricks<8, 4>), grid, dim3(256), 9 * (9 * 28 + 3) * sizeof(long long), g.stream, IP);
         }
         HIPCHK(hipGetLastError());
         if (!images_on_device && c0 + CH < n_img) {
