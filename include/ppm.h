@@ -101,6 +101,11 @@ typedef struct ppm_refine_cfg {
                                  the two columns; ties keep the smaller index (0 first) */
     float defocus_range;      /* 33: Angstrom (the caller passes 500) */
     float defocus_step;       /* 34: Angstrom (the caller passes 50); at most 20 steps either side */
+    float focus[4];           /* 29-32 + 44 "apply 2D masking" (class_focusmask, frealign.py:3846-3849, :3958): centre (x, y, z) of a sphere
+                                 in the reference, Angstrom FROM THE BOX CENTRE, and its radius; radius > 0 replaces the centred circular
+                                 mask of every particle image by a cosine-edged disc of that radius around the sphere's projection at the
+                                 row's INPUT pose: centre = (M^T c)_xy + shift (M = Rz(phi) Ry(theta) Rz(psi)).  The background
+                                 statistics keep using mask_radius.  Radius <= 0: off */
 } ppm_refine_cfg;
 
 /* Reconstruction settings = numeric answers of the reconstruct3d script (frealign.py:1780-1824). */

@@ -320,11 +320,15 @@ static double ctf_eval(const ctf_t *c, int kx, int ky) {
 /* K2: answers 46 "normalize particles", 47 "invert contrast", 18 outer mask radius (frealign.py:3937, :3984-3988);
  * the background statistics are those of the stack's own normalisation (analysis/image.py:406-417). */
 /* out: band layout [ky+B][kx] (zero outside k^2 < r_hi^2), whitened when `whiten`. */
-static void preprocess(const float *img, const geom_t *g, double mask_radius_A, double falloff_A,
+/* `disc` (may be NULL): centre (pixels from the box centre) and radius (pixels) of the mask disc when it is not the centred one
+ * of radius mask_radius_A — the focus mask of answers 29-32 / 44 (frealign.py:3846-3849, :3958); the background statistics
+ * keep using mask_radius_A. */
+static void preprocess_disc(const float *img, const geom_t *g, double mask_radius_A, double falloff_A,
                        int normalize, int invert, int do_mask, int whiten, double rband, cpx *out,
-                       double *wring /* B+2 ring weights 1/sqrt(P_b), or NULL */) {
+                       double *wring /* B+2 ring weights 1/sqrt(P_b), or NULL */, const double *disc) {
     int N = g->N;
     double Rm = mask_radius_A / g->a, w = falloff_A / g->a;
+    const double mcx = disc ? disc[0] : 0.0, mcy = disc ? disc[1] : 0.0, mrad = disc ? disc[2] : Rm;
     if (w < 1e-3) w = 1e-3;
     double s1 = 0, s2 = 0; long cnt = 0;
     for (int y = 0; y < N; y++) for (int x = 0; x < N; x++) {
@@ -339,10 +343,10 @@ static void preprocess(const float *img, const geom_t *g, double mask_radius_A, 
     double sgn = invert ? -1.0 : 1.0, sc = normalize ? 1.0 / sd : 1.0;
     cpx *f = (cpx *)malloc((size_t)N * N * sizeof(cpx));
     for (int y = 0; y < N; y++) for (int x = 0; x < N; x++) {
-        double dx = x - N / 2, dy = y - N / 2, rho = sqrt(dx * dx + dy * dy), m = 1.0;
+        double dx = x - N / 2 - mcx, dy = y - N / 2 - mcy, rho = sqrt(dx * dx + dy * dy), m = 1.0;
         if (do_mask) {
-            if (rho >= Rm + 0.5 * w) m = 0.0;
-            else if (rho > Rm - 0.5 * w) m = 0.5 * (1.0 + cos(ORC_PI * (rho - Rm + 0.5 * w) / w));
+            if (rho >= mrad + 0.5 * w) m = 0.0;
+            else if (rho > mrad - 0.5 * w) m = 0.5 * (1.0 + cos(ORC_PI * (rho - mrad + 0.5 * w) / w));
         }
         f[y * N + x].re = (float)((img[y * N + x] - mu) * sc * sgn * m);
         f[y * N + x].im = 0;
@@ -379,6 +383,11 @@ static void preprocess(const float *img, const geom_t *g, double mask_radius_A, 
         }
     }
     free(pw); free(pc); free(f);
+}
+
+static void preprocess(const float *img, const geom_t *g, double mask_radius_A, double falloff_A,
+                       int normalize, int invert, int do_mask, int whiten, double rband, cpx *out, double *wring) {
+    preprocess_disc(img, g, mask_radius_A, falloff_A, normalize, invert, do_mask, whiten, rband, out, wring, NULL);
 }
 
 /* ------------------------------------------------------------------ local score */
@@ -428,6 +437,18 @@ static void euler_full(double psi, double theta, double phi, double M[9]) {
     M[0] = m[0]; M[1] = m[1]; M[2] = cos(ph) * sin(th);
     M[3] = m[2]; M[4] = m[3]; M[5] = sin(ph) * sin(th);
     M[6] = m[4]; M[7] = m[5]; M[8] = cos(th);
+}
+
+/* Focus mask (answers 29-32 / 44): disc = centre (pixels from the box centre) and radius (pixels) around the projection of the
+ * focus sphere at the row's input pose: centre = (M^T c)_xy + shift, M = Rz(phi) Ry(theta) Rz(psi).  Returns 0 when off. */
+static int focus_disc(const ppm_refine_cfg *cfg, const geom_t *g, const double *row, double disc[3]) {
+    if (!(cfg->focus[3] > 0.f)) return 0;
+    double M[9]; euler_full(row[PPM_PSI], row[PPM_THETA], row[PPM_PHI], M);
+    const double c0 = cfg->focus[0] / g->a, c1 = cfg->focus[1] / g->a, c2 = cfg->focus[2] / g->a;
+    disc[0] = M[0] * c0 + M[3] * c1 + M[6] * c2 + row[PPM_XSHIFT] / g->a;
+    disc[1] = M[1] * c0 + M[4] * c1 + M[7] * c2 + row[PPM_YSHIFT] / g->a;
+    disc[2] = cfg->focus[3] / g->a;
+    return 1;
 }
 
 static void angles_from_matrix(const double M[9], double *psi, double *theta, double *phi) {
@@ -644,12 +665,13 @@ int orc_refine_batch(void *refp, const ppm_refine_cfg *cfg, const float *images,
         ctf_t c; ctf_init(&c, row, g.N, g.a);
         cpx *I = (cpx *)malloc(nb * sizeof(cpx));
         double *wr = (double *)malloc((g.B + 2) * sizeof(double)), *wrs = wr, *wrsown = NULL;
-        preprocess(img, &g, cfg->mask_radius, fall, cfg->normalize, cfg->invert, 1, 1, g.r_hi, I, wr);
+        double disc[3]; const int focus_on = focus_disc(cfg, &g, row, disc);
+        preprocess_disc(img, &g, cfg->mask_radius, fall, cfg->normalize, cfg->invert, 1, 1, g.r_hi, I, wr, focus_on ? disc : NULL);
         long nev = 0; double sev = 0;
         cstate_t best; memset(&best, 0, sizeof(best));
         if (cfg->global_search) {
             cpx *Is = I, *Isown = NULL;
-            if (cfg->search_mask_radius > 0 && cfg->search_mask_radius != cfg->mask_radius) {
+            if (!focus_on && cfg->search_mask_radius > 0 && cfg->search_mask_radius != cfg->mask_radius) {
                 Isown = (cpx *)malloc(nb * sizeof(cpx)); wrsown = (double *)malloc((g.B + 2) * sizeof(double));
                 preprocess(img, &g, cfg->search_mask_radius, fall, cfg->normalize, cfg->invert, 1, 1, g.r_hi, Isown, wrsown);
                 Is = Isown; wrs = wrsown;
@@ -751,7 +773,8 @@ int orc_score_batch(void *refp, const ppm_refine_cfg *cfg, const float *images, 
         ctf_t c; ctf_init(&c, row, g.N, g.a);
         cpx *I = (cpx *)malloc(nb * sizeof(cpx));
         double *wr = (double *)malloc((g.B + 2) * sizeof(double));
-        preprocess(images + (size_t)ip * g.N * g.N, &g, cfg->mask_radius, fall, cfg->normalize, cfg->invert, 1, 1, g.r_hi, I, wr);
+        double disc[3]; const int focus_on = focus_disc(cfg, &g, row, disc);
+        preprocess_disc(images + (size_t)ip * g.N * g.N, &g, cfg->mask_radius, fall, cfg->normalize, cfg->invert, 1, 1, g.r_hi, I, wr, focus_on ? disc : NULL);
         double M[9], sh[2] = { row[PPM_XSHIFT] / g.a, row[PPM_YSHIFT] / g.a };
         euler_full(row[PPM_PSI], row[PPM_THETA], row[PPM_PHI], M);
         scores[ip] = score_local(r, &g, &c, I, wr, g.r_hi, M, sh);

@@ -18,10 +18,12 @@ class RefineCfg(C.Structure):
         ("mask_falloff", C.c_float), ("iters_hit", C.c_int), ("iters_final", C.c_int),
         ("local_angle_step", C.c_float), ("local_shift_step", C.c_float), ("symmetry", C.c_char * 8), ("band_factor", C.c_float),
         ("refine_defocus", C.c_int), ("defocus_range", C.c_float), ("defocus_step", C.c_float),
+        ("focus", C.c_float * 4),
     ]
 
     @classmethod
     def make(cls, **kw):
+        focus = kw.pop("focus", None)
         d = dict(molecular_mass_kda=0.0, res_low=0.0, res_signed_cc=0.0, search_mask_radius=0.0, res_search=0.0,
                  angular_step=15.0, top_hits=20, search_range_x=0.0, search_range_y=0.0, global_search=1,
                  local_refine=1, refine_psi=1, refine_theta=1, refine_phi=1, refine_x=1, refine_y=1, normalize=1,
@@ -35,7 +37,10 @@ class RefineCfg(C.Structure):
             d["res_search"] = d["res_high"]
         if isinstance(d["symmetry"], str):
             d["symmetry"] = d["symmetry"].encode()
-        return cls(**d)
+        c = cls(**d)
+        if focus is not None:
+            c.focus[:] = [float(v) for v in focus]
+        return c
 
 
 class ReconCfg(C.Structure):

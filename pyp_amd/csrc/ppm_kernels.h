@@ -90,6 +90,7 @@ struct PrepP {
     const float *images; const double *rows; FftPlan plan;
     int N, B, W, H;
     float r_hi2, Rm, wfall, a;
+    float focus[4];   // focus mask: sphere centre (pixels from the box centre) and radius in the reference; radius <= 0: centred mask of radius Rm
     int normalize, invert, do_mask, whiten;
     int nc, nchunks, L;
     float2 *band;  // [n][H*W] unscaled band spectrum (scratch; the final result for insertion)
@@ -125,7 +126,8 @@ __global__ void __launch_bounds__(PT, MINW) k_prep(PrepP P) {
     float *ringpw = (float *)(ringc + (B + 2));       // [B+2] ring weights
     double *red = (double *)(((uintptr_t)(ringpw + (B + 2)) + 15) & ~(uintptr_t)15);  // [PW*4 + PW]
     float *stat = (float *)(red + PW * 5);            // mu, scale, fixed-point scale, nI partials
-    float2 *tw_s = (float2 *)(stat + 4 + PW);         // [N] twiddles and [N] staging positions of the FFT plan, kept in LDS
+    float *fmask = stat + 4 + PW;                     // mask disc of this particle: centre (pixels from the box centre) and radius
+    float2 *tw_s = (float2 *)(stat + 8 + PW);         // [N] twiddles and [N] staging positions of the FFT plan, kept in LDS
     unsigned short *perm_s = (unsigned short *)(tw_s + N);
     unsigned short *iperm_s = perm_s + N;             // inverse: the sample that is staged at LDS position d
     for (int i = tid; i < N; i += PT) {
@@ -189,11 +191,25 @@ __global__ void __launch_bounds__(PT, MINW) k_prep(PrepP P) {
             int e2 = 0; (void)frexp(E > 1e-30 ? 4.0 * E : 1.0, &e2);
             int ex = 60 - e2; ex = ex > 120 ? 120 : (ex < -120 ? -120 : ex);
             stat[2] = ldexpf(1.f, ex);
+            // mask disc: centred with radius Rm, or around the projection of the focus sphere at the row's pose
+            fmask[0] = 0.f; fmask[1] = 0.f; fmask[2] = P.Rm;
+            if (P.focus[3] > 0.f) {
+                const double *row = P.rows + (size_t)p * PPM_NCOL;
+                const double d2r = 3.14159265358979323846 / 180.0;
+                double sps, cps, sth, cth, sph, cph;
+                sincos(row[PPM_PSI] * d2r, &sps, &cps); sincos(row[PPM_THETA] * d2r, &sth, &cth); sincos(row[PPM_PHI] * d2r, &sph, &cph);
+                const double c0 = P.focus[0], c1 = P.focus[1], c2 = P.focus[2];
+                // first two rows of M^T, M = Rz(phi) Ry(theta) Rz(psi)
+                fmask[0] = (float)((cph * cth * cps - sph * sps) * c0 + (sph * cth * cps + cph * sps) * c1 - sth * cps * c2 + row[PPM_XSHIFT] / (double)P.a);
+                fmask[1] = (float)((-cph * cth * sps - sph * cps) * c0 + (-sph * cth * sps + cph * cps) * c1 + sth * sps * c2 + row[PPM_YSHIFT] / (double)P.a);
+                fmask[2] = P.focus[3];
+            }
         }
         __syncthreads();
     }
     const float mu = stat[0], sc = stat[1];
     const float qscale = stat[2];
+    const float mcx = fmask[0], mcy = fmask[1], mrad = fmask[2];
     for (int i = tid; i < B + 2; i += PT) { ringq[i] = 0ull; ringc[i] = 0u; }
 
     const float wf = P.wfall < 1e-3f ? 1e-3f : P.wfall;
@@ -211,9 +227,9 @@ __global__ void __launch_bounds__(PT, MINW) k_prep(PrepP P) {
             const float invNf = 1.0f / (float)N, invN4 = 4.0f / (float)N;
             const bool wide = (N & 3) == 0;
             auto mask_at = [&](int x, int y) {
-                const float dx = (float)(x - N / 2), dy = (float)(y - N / 2);
+                const float dx = (float)(x - N / 2) - mcx, dy = (float)(y - N / 2) - mcy;
                 const float r = sqrtf(dx * dx + dy * dy);
-                return r >= P.Rm + 0.5f * wf ? 0.f : (r > P.Rm - 0.5f * wf ? 0.5f * (1.f + cosf(kPiF * (r - P.Rm + 0.5f * wf) / wf)) : 1.f);
+                return r >= mrad + 0.5f * wf ? 0.f : (r > mrad - 0.5f * wf ? 0.5f * (1.f + cosf(kPiF * (r - mrad + 0.5f * wf) / wf)) : 1.f);
             };
             auto fetch = [&](int y0) {
                 if (wide) {

@@ -233,13 +233,15 @@ static int build_brick_items(ppm_accum *a, const Geom &gm, int BE, int nb) {
 static int launch_prep(const float *d_images, const double *d_rows, int n_img, const Geom &gm, float Rm_px, float fall_px,
                        int normalize, int invert, int do_mask, int whiten, float2 *band, float *wring,
                        const uint32_t *samples, int S_pad, float2 *Il, float *cw, float2 *Wp, float *C2, float *nI,
-                       unsigned *band_max = nullptr /* insertion: receives the chunk's largest |band| component */) {
+                       unsigned *band_max = nullptr /* insertion: receives the chunk's largest |band| component */,
+                       const float *focus_px = nullptr /* focus mask: sphere centre and radius in pixels, or null */) {
     if (int rc = ensure_plan(gm.N)) return rc;
     PrepP P;
     P.images = d_images; P.rows = d_rows; P.plan = g.plans[gm.N].plan;
     P.N = gm.N; P.B = gm.B; P.W = gm.W; P.H = gm.H;
     P.r_hi2 = (float)(gm.r_hi * gm.r_hi); P.Rm = Rm_px; P.wfall = fall_px; P.a = (float)gm.a;
     P.normalize = normalize; P.invert = invert; P.do_mask = do_mask; P.whiten = whiten;
+    for (int k = 0; k < 4; k++) P.focus[k] = focus_px ? focus_px[k] : 0.f;
     // LDS plan: L row pairs per row pass (L N <= 8 x threads: the next pass is prefetched into <= 8 register pairs per
     // thread; L divides N/2) share their storage with the nc columns of one column chunk; the whole half spectrum goes
     // through a global scratch between the two phases.  512 threads / 80 KB -> two blocks per CU.
@@ -251,7 +253,7 @@ static int launch_prep(const float *d_images, const double *d_rows, int n_img, c
     if (const char *e = getenv("PPM_PREP_PT")) { const int v = atoi(e); if (v == 512 || v == 1024 || v == 256) PT = v; }
     const int occ3 = !(getenv("PPM_PREP_OCC") && atoi(getenv("PPM_PREP_OCC")) == 2);
     const size_t budget = (PT == 1024 ? 160 : (PT == 256 ? (getenv("PPM_PREP_LDS") ? atoi(getenv("PPM_PREP_LDS")) : (occ3 ? 40 : 52)) : 80)) * 1024;
-    const size_t lds_fixed = (size_t)(gm.B + 2) * 16 + 16 + 5 * (PT / 64) * sizeof(double) + (4 + PT / 64) * sizeof(float) + (size_t)gm.N * 12 + 16;
+    const size_t lds_fixed = (size_t)(gm.B + 2) * 16 + 16 + 5 * (PT / 64) * sizeof(double) + (8 + PT / 64) * sizeof(float) + (size_t)gm.N * 12 + 16;
     P.fast256 = (gm.N == 256 && !getenv("PPM_PREP_GENERIC")) ? 1 : 0;
     P.TS = P.fast256 ? 273 : gm.N + 1; P.WS = P.fast256 ? 272 : gm.N;
     P.L = std::max(1, std::min(8 * PT / gm.N, gm.N / 2));
@@ -456,7 +458,9 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
     const int Tb = cfg->iters_hit > 0 ? cfg->iters_hit : (cfg->iters_hit < 0 ? 0 : 2), Tc = cfg->iters_final > 0 ? cfg->iters_final : 7;
     const double fall = cfg->mask_falloff > 0 ? cfg->mask_falloff : 20.0;
     const float fall_px = (float)(fall / gm.a), Rm_px = (float)(cfg->mask_radius / gm.a);
-    const bool sep_search = cfg->global_search && cfg->search_mask_radius > 0 && cfg->search_mask_radius != cfg->mask_radius;
+    const bool focus_on = cfg->focus[3] > 0.f;     // a focus mask replaces the centred masks of both stages
+    const float focus_px[4] = { (float)(cfg->focus[0] / gm.a), (float)(cfg->focus[1] / gm.a), (float)(cfg->focus[2] / gm.a), (float)(cfg->focus[3] / gm.a) };
+    const bool sep_search = !focus_on && cfg->global_search && cfg->search_mask_radius > 0 && cfg->search_mask_radius != cfg->mask_radius;
 
     SampleList sl; build_samples(gm, sl);
     const int S_pad = (int)sl.packed.size();
@@ -597,7 +601,7 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
         // refinement spectra (+ search tables when the same mask serves both)
         if (int rc = launch_prep(d_img, ref->rows_in.p, nb, gm, Rm_px, fall_px, cfg->normalize, cfg->invert, 1, 1, ref->band.p, ref->wring.p,
                                  ref->samples.p, S_pad, ref->Il.p, ref->cw.p,
-                                 (cfg->global_search && !sep_search) ? ref->Wp.p : nullptr, ref->C2.p, ref->nI.p)) return rc;
+                                 (cfg->global_search && !sep_search) ? ref->Wp.p : nullptr, ref->C2.p, ref->nI.p, nullptr, focus_on ? focus_px : nullptr)) return rc;
         if (sep_search)
             if (int rc = launch_prep(d_img, ref->rows_in.p, nb, gm, (float)(cfg->search_mask_radius / gm.a), fall_px, cfg->normalize, cfg->invert, 1, 1,
                                      ref->band.p, nullptr, nullptr, 0, nullptr, nullptr, ref->Wp.p, ref->C2.p, ref->nI.p)) return rc;

@@ -136,8 +136,14 @@ def _ssnr_ring_weights(n, stats_path, pixel):
 
 # ------------------------------------------------------------------------------------------ refine3d
 def refine_cfg_from_answers(d, box):
-    """ppm_refine_cfg from the parsed refine3d answers (frealign.py:3918-3994; answer numbers in include/ppm.h)."""
-    return RefineCfg.make(
+    """ppm_refine_cfg from the parsed refine3d answers (frealign.py:3918-3994; answer numbers in include/ppm.h).
+    Focus mask (answers 29-32, used when answer 44 "apply 2D masking" is yes, frealign.py:3846-3849): the caller's X, Y, Z are
+    Angstrom from the corner of the reference box (what a map viewer displays); the library takes them from the box centre."""
+    focus = None
+    if d.get("mask_2d"):
+        half = 0.5 * box * d["pixel_size"]
+        focus = (d["focus_x"] - half, d["focus_y"] - half, d["focus_z"] - half, d["focus_r"])
+    return RefineCfg.make(focus=focus,
         box=box, pixel_size=d["pixel_size"], molecular_mass_kda=d["molecular_mass"], mask_radius=d["outer_radius"], res_low=d["res_low"],
         res_high=d["res_high"], res_signed_cc=d["res_signed_cc"], search_mask_radius=d["search_mask_radius"],
         res_search=d["res_search"], angular_step=d["angular_step"], top_hits=d["top_hits"], search_range_x=d["search_range_x"],
@@ -157,13 +163,13 @@ def refine3d_main(argv=None, stdin=None):
     print("\n        **   Welcome to Refine3D (MI355X / libpypmatch)   **\n")
     for k, v in d.items():
         print(f"{k:28s}: {v}")
-    _unsupported(d, [("use_priors", True), ("calc_match", True), ("mask_2d", True),
+    _unsupported(d, [("use_priors", True), ("calc_match", True),
                      ("exclude_edges", True), ("normalize_reference", True), ("threshold_reference", True)], "refine3d")
     pad = int(round(d["padding"]))
     if abs(d["padding"] - pad) > 1e-6 or pad not in (1, 2, 4):
         _die("ERROR: refine3d: padding factor must be 1, 2 or 4")
-    if any(abs(d[k]) > 0 for k in ("focus_x", "focus_y", "focus_z", "focus_r")):
-        _die("ERROR: refine3d: focus masks are not supported")
+    if d["mask_2d"] and not d["focus_r"] > 0:
+        _die("ERROR: refine3d: 2D masking asked for with a focus mask of radius 0")
     for p in (d["stack"], d["input_params"], d["reference"]):
         if not os.path.exists(p):
             _die(f"ERROR: refine3d: input file {p} does not exist")

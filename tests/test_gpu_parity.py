@@ -51,6 +51,32 @@ def test_score_at_given_poses_matches_oracle(d64, H, O):
         assert np.abs(want - got).max() < 2e-5, kw                       # float32 round-off of a normalised sum
 
 
+def test_focus_mask_matches_oracle(d64, H, O):
+    """Answers 29-32 + 44 (class_focusmask): the disc around the projected focus sphere replaces the centred mask.  A sphere at
+    the box centre with the mask radius IS the centred mask for a row without shift (bit-identical rows); an off-centre sphere gives other scores,
+    the same on both sides, and its disc follows the row's pose and shift."""
+    vol, imgs, rows, g, o = d64
+    base = cfg_for(64, 2.0, global_search=0, local_refine=0)
+    rows0 = rows.copy(); rows0[:, 4:6] = 0.0                       # the disc follows the row's shift: no shift, no offset
+    assert np.array_equal(g.refine(base, imgs, rows0),
+                          g.refine(cfg_for(64, 2.0, global_search=0, local_refine=0, focus=(0.0, 0.0, 0.0, 0.4 * 64 * 2.0)), imgs, rows0))
+    plain = g.refine(base, imgs, rows)
+    off = cfg_for(64, 2.0, global_search=0, local_refine=0, focus=(14.0, -9.0, 11.0, 26.0))          # Angstrom from the box centre
+    want = O.score_batch(o, off, imgs, rows)
+    got = g.refine(off, imgs, rows)[:, 14] / 100.0
+    assert np.abs(want - got).max() < 2e-5
+    assert np.abs(got - plain[:, 14] / 100.0).max() > 1e-3                                            # a different region is scored
+    start = synth.perturb_rows(rows, 2.0, 1.0, 2.0)
+    c = cfg_for(64, 2.0, global_search=0, focus=(14.0, -9.0, 11.0, 40.0))
+    want, _ = O.refine_batch(o, c, imgs, start)
+    got = g.refine(c, imgs, start)
+    assert synth.angular_error_deg(want, got).max() < ANG_TOL_DEG and synth.shift_error_px(want, got, 2.0).max() < SHIFT_TOL_PX
+    cg = cfg_for(64, 2.0, focus=(14.0, -9.0, 11.0, 40.0))                                               # global search under the focus disc
+    want, _ = O.refine_batch(o, cg, imgs[:6], rows[:6])
+    got = g.refine(cg, imgs[:6], rows[:6])
+    assert synth.angular_error_deg(want, got).max() < ANG_TOL_DEG and synth.shift_error_px(want, got, 2.0).max() < SHIFT_TOL_PX
+
+
 def test_local_refinement_matches_oracle(d64, H, O):
     vol, imgs, rows, g, o = d64
     start = synth.perturb_rows(rows, 2.0, 1.0, 2.0)

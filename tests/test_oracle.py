@@ -212,3 +212,20 @@ def test_dose_weighting_attenuates_weak_exposures_at_high_resolution(tmp_path):
     oracle.insert_batch(b0, np.zeros(2, dtype=np.int64), rc, "C1", stack.numpy()[sel0], rows[sel0])
     oracle.insert_batch(b1, np.zeros(2, dtype=np.int64), rd, "C1", stack.numpy()[sel0], rows[sel0])
     assert np.array_equal(b0, b1)
+
+
+def test_focus_mask_disc_follows_the_projected_sphere():
+    """Focus mask (answers 29-32 / 44): a sphere at the box centre with the mask radius reproduces the centred mask exactly
+    for a row without shift (the disc follows the row's pose AND shift); an off-centre sphere scores another region."""
+    from oracle import oracle
+    n, px = 32, 3.0
+    vol, stack, rows = synth.make_dataset(n, 6, pixel=px, snr=1.0)
+    imgs = stack.numpy()
+    ref = oracle.Reference(vol, n / 2)
+    base = dict(box=n, pixel_size=px, mask_radius=0.4 * n * px, res_high=px * n / 12, global_search=0, local_refine=0)
+    rows0 = rows.copy(); rows0[:, 4:6] = 0.0                       # the disc follows the row's shift: no shift, no offset
+    assert np.array_equal(oracle.score_batch(ref, RefineCfg.make(**base), imgs, rows0),
+                          oracle.score_batch(ref, RefineCfg.make(focus=(0, 0, 0, 0.4 * n * px), **base), imgs, rows0))
+    plain = oracle.score_batch(ref, RefineCfg.make(**base), imgs, rows)
+    other = oracle.score_batch(ref, RefineCfg.make(focus=(12.0, 6.0, -9.0, 20.0), **base), imgs, rows)
+    assert np.abs(other - plain).max() > 1e-3

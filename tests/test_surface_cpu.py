@@ -165,6 +165,22 @@ def test_refine3d_cistem_script():
     assert d["output_params"] == "name_r01_0000001_0000143.cistem"
 
 
+def test_focus_mask_answers_reach_the_library_configuration():
+    """class_focusmask "X,Y,Z,R" (frealign.py:3958) with answer 44 "apply 2D masking" = yes (:3846-3849): corner-based Angstrom
+    become centre-based ones in ppm_refine_cfg.focus; masking = no leaves the mask off whatever the four numbers say."""
+    from pyp_amd.surface import cli
+    lines = REFINE_CISTEM.splitlines()
+    lines[28:32] = ["300.0", "250.5", "276.48", "60"]            # answers 29-32
+    d = prompts.parse_refine3d(prompts.read_answers(io.StringIO("\n".join(lines) + "\n")))
+    assert (d["focus_x"], d["focus_y"], d["focus_z"], d["focus_r"]) == (300.0, 250.5, 276.48, 60.0) and not d["mask_2d"]
+    assert list(cli.refine_cfg_from_answers(d, 128).focus) == [0.0, 0.0, 0.0, 0.0]
+    lines[43] = "yes"                                              # answer 44
+    d = prompts.parse_refine3d(prompts.read_answers(io.StringIO("\n".join(lines) + "\n")))
+    assert d["mask_2d"]
+    f = list(cli.refine_cfg_from_answers(d, 128).focus)           # box 128 x 4.32 A: centre at 276.48 A
+    assert np.allclose(f, [300.0 - 276.48, 250.5 - 276.48, 0.0, 60.0], atol=1e-4)
+
+
 def test_refine3d_par_script_verbatim_from_reference():
     d = prompts.parse_refine3d(prompts.read_answers(io.StringIO(REFINE_PAR)))
     assert d["surface"] == "par" and d["symmetry"] == "O" and (d["first"], d["last"]) == (1, 27)
