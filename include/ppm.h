@@ -204,6 +204,11 @@ int ppm_refine_last_counts(ppm_ref_t *ref, long *n_global, long *n_local, long *
  * "" if none */
 const char *ppm_refine_note(ppm_ref_t *ref);
 
+/* refine3d answers 8 / 43 "matching projections" (frealign.py:3929-3931, refine_fmatch): out[i] (box * box floats, host) = the
+ * reference projected at row i's pose, times the row's CTF, moved to the row's X / Y shift and band-limited at cfg->res_high — the
+ * noise-free model of the stored particle image (negated when cfg->invert is set, so that it overlays the stack as stored). */
+int ppm_match_projections(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const double *rows, int n_rows, float *out);
+
 /* Constrained refinement: rows (n_proj x PPM_NCOL, image i belongs to row i), particles (n_part x PPM_NPCOL) and tilts
  * (n_tilt x PPM_NTCOL) are read and updated in place: refined units get their parameters, their rows get the poses that
  * follow from them (angles from M_row, shifts moved by the change of the geometric shift) and SCORE / LOGP / SIGMA at the

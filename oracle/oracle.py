@@ -38,6 +38,7 @@ def lib():
         L.orc_reference_destroy.argtypes = [C.c_void_p]
         L.orc_refine_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.orc_score_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_match_projections.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.orc_preprocess.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
         L.orc_band_dims.argtypes = [C.c_void_p] + [C.c_void_p] * 6
         L.orc_extract_slice.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p]
@@ -103,6 +104,15 @@ def score_batch(ref, cfg, images, rows):
     if rc:
         raise RuntimeError(f"oracle: score_batch failed ({rc})")
     return sc
+
+
+def match_projections(ref, cfg, rows):
+    rows = np.ascontiguousarray(rows, dtype=np.float64)
+    out = np.empty((len(rows), cfg.box, cfg.box), dtype=np.float32)
+    rc = lib().orc_match_projections(ref.h, C.byref(cfg), _p(rows), len(rows), _p(out))
+    if rc:
+        raise RuntimeError(f"oracle: match_projections failed ({rc})")
+    return out
 
 
 def preprocess(cfg, img, mask_radius):

@@ -783,6 +783,46 @@ int orc_score_batch(void *refp, const ppm_refine_cfg *cfg, const float *images, 
     return 0;
 }
 
+/* refine3d answers 8 / 43 "matching projections" (frealign.py:3929-3931): the reference projected at a row's pose, times the
+ * row's CTF, at the row's shift, band-limited at res_high; out: n * N * N floats.  cube = FFT / N, so the unnormalised inverse
+ * transform is divided by N once more. */
+int orc_match_projections(void *refp, const ppm_refine_cfg *cfg, const double *rows, int n, float *out) {
+    fft_tables();
+    oref_t *r = (oref_t *)refp; geom_t g;
+    ppm_refine_cfg c2 = *cfg; c2.global_search = 0;
+    if (!r || geom_init(&g, &c2) || g.B > (r->B + 1) / r->pad - 1) return -22;
+    const int N = g.N;
+    const double rh2 = g.r_hi * g.r_hi;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int ip = 0; ip < n; ip++) {
+        const double *row = rows + (size_t)ip * PPM_NCOL;
+        ctf_t c; ctf_init(&c, row, N, g.a);
+        double M[9]; euler_full(row[PPM_PSI], row[PPM_THETA], row[PPM_PHI], M);
+        const double m[6] = { M[0], M[1], M[3], M[4], M[6], M[7] }, sx = row[PPM_XSHIFT] / g.a, sy = row[PPM_YSHIFT] / g.a;
+        cpx *f = (cpx *)calloc((size_t)N * N, sizeof(cpx));
+        for (int ky = -g.B; ky <= g.B; ky++) for (int kx = 0; kx <= g.B; kx++) {
+            const double k2 = (double)kx * kx + (double)ky * ky;
+            if (k2 >= rh2) continue;
+            double pr, pi;
+            sample_cube(r, m[0] * kx + m[1] * ky, m[2] * kx + m[3] * ky, m[4] * kx + m[5] * ky, &pr, &pi);
+            double cv = ctf_eval(&c, kx, ky);
+            if ((kx + ky) & 1) cv = -cv;                              /* projection centred on pixel (N/2, N/2) */
+            const double ph = -2.0 * ORC_PI * (kx * sx + ky * sy) / N, cr = cos(ph), ci = sin(ph);
+            const double vr = cv * (pr * cr - pi * ci), vi = cv * (pr * ci + pi * cr);
+            cpx *o = &f[(size_t)((ky + N) % N) * N + kx];
+            o->re = (float)vr; o->im = (float)vi;
+            if (kx > 0) { cpx *q = &f[(size_t)((N - ky) % N) * N + (N - kx)]; q->re = (float)vr; q->im = (float)-vi; }
+        }
+        for (int y = 0; y < N; y++) fft1d(f + (size_t)y * N, N, 1, 1);
+        for (int x = 0; x < N; x++) fft1d(f + x, N, N, 1);
+        const double sc = (cfg->invert ? -1.0 : 1.0) / N;
+        float *o = out + (size_t)ip * N * N;
+        for (size_t i = 0; i < (size_t)N * N; i++) o[i] = (float)(f[i].re * sc);
+        free(f);
+    }
+    return 0;
+}
+
 /* preprocessed (whitened, masked) band spectrum of one image: [2B+1][B+1] complex, for kernel tests */
 int orc_preprocess(const ppm_refine_cfg *cfg, const float *img, float mask_radius, float *out_band, double *out_wring) {
     fft_tables();

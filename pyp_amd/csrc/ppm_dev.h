@@ -269,7 +269,7 @@ __device__ __forceinline__ float2 sample_cube(const CubeView &cv, float X, float
 // CTF of one particle: -sin(pi lambda s^2 (df(phi) - Cs lambda^2 s^2 / 2) + phase + amp)
 struct CtfP { float lambda, cs, dsum, ddif, c2a, s2a, extra, inv_na2; };
 
-__device__ __forceinline__ CtfP ctf_from_row(const double *row, int N, double a) {
+__host__ __device__ __forceinline__ CtfP ctf_from_row(const double *row, int N, double a) {
     CtfP c;
     double v = row[PPM_VOLTAGE] * 1000.0;
     double lam = 12.2639 / sqrt(v + 0.97845e-6 * v * v);

@@ -766,6 +766,41 @@ __global__ void __launch_bounds__(NW * 64) k_insert_bricks(InsertBrickP P) {
     }
 }
 
+// ---------------------------------------------------------------------------------- matching projections
+// refine3d answers 8 / 43 (frealign.py:3929-3931, refine_fmatch): the reference projected at a row's pose, times the row's CTF,
+// moved to the particle's position — the noise-free model of the stored particle image.  One thread per entry of the full
+// N x N spectrum (FFT order; kx < 0 from the Hermitian mate); the inverse transforms are two k_fft_lines passes.
+struct MatchRow { float m[6]; float sx, sy; CtfP ctf; };
+struct MatchP { CubeView cv; const MatchRow *rows; float2 *f; int N, B; float r_hi2; int n; };
+
+__global__ void __launch_bounds__(256) k_match_fill(MatchP P) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, NN = (size_t)P.N * P.N;
+    if (i >= NN * P.n) return;
+    const int im = (int)(i / NN), r = (int)(i - (size_t)im * NN), y = r / P.N, x = r - y * P.N;
+    int kx = x < P.N / 2 ? x : x - P.N, ky = y < P.N / 2 ? y : y - P.N;
+    const bool mate = kx < 0;
+    if (mate) { kx = -kx; ky = -ky; }
+    float2 v = make_float2(0.f, 0.f);
+    const float k2 = (float)(kx * kx + ky * ky);
+    if (kx <= P.B && ky >= -P.B && ky <= P.B && k2 < P.r_hi2) {
+        const MatchRow &q = P.rows[im];
+        const float fx = (float)kx, fy = (float)ky;
+        const float2 s = sample_cube(P.cv, q.m[0] * fx + q.m[1] * fy, q.m[2] * fx + q.m[3] * fy, q.m[4] * fx + q.m[5] * fy);
+        float c = ctf_eval(q.ctf, kx, ky);
+        if ((kx + ky) & 1) c = -c;                                   // projection centred on pixel (N/2, N/2)
+        float rev = -(fx * q.sx + fy * q.sy) / (float)P.N; rev -= floorf(rev);
+        float sn, cs; __sincosf(6.283185307179586f * rev, &sn, &cs);
+        v = make_float2(c * (s.x * cs - s.y * sn), c * (s.x * sn + s.y * cs));
+        if (mate) v.y = -v.y;
+    }
+    P.f[i] = v;
+}
+
+__global__ void k_match_real(const float2 *__restrict__ f, float *__restrict__ out, size_t n, float scale) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = f[i].x * scale;
+}
+
 // ---------------------------------------------------------------------------------- finalisation
 // kx = 0 plane: fold Friedel mates together (reads `src`, writes `dst`)
 __global__ void k_fold_plane(const float *__restrict__ src, float *__restrict__ dst, int N) {

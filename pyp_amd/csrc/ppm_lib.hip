@@ -429,6 +429,64 @@ void ppm_reference_destroy(ppm_ref_t *r) {
     delete r;
 }
 
+// 2-D FFTs of `nimg` complex n x n images in place (rows, then columns)
+static int fft2d_batch(float2 *d, int n, long nimg, bool inverse) {
+    if (int rc = ensure_plan(n)) return rc;
+    int L = std::max(1, std::min(16, 8192 / n));
+    const long nlines = nimg * n;
+    while (nlines % L) L--;
+    for (int pass = 0; pass < 2; pass++) {
+        FftLinesP P;
+        P.data = d; P.plan = g.plans[n].plan; P.n = n; P.inverse = inverse ? 1 : 0; P.L = L; P.nlines = nlines;
+        if (pass == 0) { P.inner = nlines; P.inner_stride = n; P.outer_stride = 0; P.elem_stride = 1; P.line_major = 0; }
+        else { P.inner = n; P.inner_stride = 1; P.outer_stride = (long)n * n; P.elem_stride = n; P.line_major = 1; }
+        hipLaunchKernelGGL(k_fft_lines, dim3((unsigned)((nlines + L - 1) / L)), dim3(256), (size_t)L * n * sizeof(float2), g.stream, P);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ matching projections
+int ppm_match_projections(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const double *rows, int n_rows, float *out) {
+    if (!g.inited) return fail(-1, "ppm_init has not been called");
+    if (!ref || !cfg || !rows || !out) return fail(-22, "null argument");
+    if (n_rows <= 0) return 0;
+    ppm_refine_cfg c2 = *cfg; c2.global_search = 0;          // only box, pixel size and the high-resolution limit matter here
+    Geom gm; std::string err;
+    if (!geom_init(gm, c2, err)) return fail(-22, err);
+    if (gm.N != ref->N) return fail(-22, "particle box differs from the reference box");
+    if (gm.B > (ref->B + 1) / ref->pad - 1) return fail(-22, "high-resolution limit exceeds the band the reference was prepared for");
+    const size_t NN = (size_t)gm.N * gm.N;
+    const int CH = (int)std::min<size_t>((size_t)n_rows, std::max<size_t>(1, ((size_t)1 << 30) / (NN * 12)));
+    DevTmp<float2> d_f; DevTmp<float> d_o; DevTmp<MatchRow> d_rows;
+    HIPCHK(d_f.alloc(NN * CH)); HIPCHK(d_o.alloc(NN * CH)); HIPCHK(d_rows.alloc(CH));
+    MatchP MP;
+    MP.cv.cube = ref->cube; MP.cv.NBX = ref->NBX; MP.cv.NBY = ref->NBY; MP.cv.LB = ref->LB; MP.cv.off = ref->B + 1; MP.cv.scale = (float)ref->pad;
+    MP.rows = d_rows.p; MP.f = d_f.p; MP.N = gm.N; MP.B = gm.B; MP.r_hi2 = (float)(gm.r_hi * gm.r_hi);
+    std::vector<MatchRow> hr(CH);
+    const float scale = (cfg->invert ? -1.f : 1.f) / (float)gm.N;     // cube = FFT / N: the unnormalised inverse transform needs 1 / N more
+    for (int c0 = 0; c0 < n_rows; c0 += CH) {
+        const int nb = std::min(CH, n_rows - c0);
+        for (int i = 0; i < nb; i++) {
+            const double *row = rows + (size_t)(c0 + i) * PPM_NCOL;
+            double M[9]; euler_matrix(row[PPM_PSI], row[PPM_THETA], row[PPM_PHI], M);
+            MatchRow &q = hr[i];
+            q.m[0] = (float)M[0]; q.m[1] = (float)M[1]; q.m[2] = (float)M[3]; q.m[3] = (float)M[4]; q.m[4] = (float)M[6]; q.m[5] = (float)M[7];
+            q.sx = (float)(row[PPM_XSHIFT] / gm.a); q.sy = (float)(row[PPM_YSHIFT] / gm.a);
+            q.ctf = ctf_from_row(row, gm.N, gm.a);
+        }
+        HIPCHK(hipMemcpyAsync(d_rows.p, hr.data(), (size_t)nb * sizeof(MatchRow), hipMemcpyHostToDevice, g.stream));
+        MP.n = nb;
+        hipLaunchKernelGGL(k_match_fill, dim3((unsigned)((NN * nb + 255) / 256)), dim3(256), 0, g.stream, MP);
+        if (int rc = fft2d_batch(d_f.p, gm.N, nb, true)) return rc;
+        hipLaunchKernelGGL(k_match_real, dim3((unsigned)((NN * nb + 255) / 256)), dim3(256), 0, g.stream, d_f.p, d_o.p, NN * nb, scale);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(out + (size_t)c0 * NN, d_o.p, NN * nb * sizeof(float), hipMemcpyDeviceToHost, g.stream));
+        HIPCHK(hipStreamSynchronize(g.stream));            // `hr` is reused by the next chunk
+    }
+    return 0;
+}
+
 // ------------------------------------------------------------------------------ refine
 int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *images, int images_on_device,
                      int n_img, const double *rows_in, double *rows_out) {

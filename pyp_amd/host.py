@@ -60,6 +60,15 @@ class Reference:
         del keep
         return out
 
+    def match_projections(self, cfg, rows):
+        """Matching projections of refine3d (ppm_match_projections): float32 [M, box, box], the noise-free model of each row's particle."""
+        rows = np.ascontiguousarray(rows, dtype=np.float64)
+        if rows.ndim != 2 or rows.shape[1] != NCOL:
+            raise ValueError("ERROR: rows must be (M, 32)")
+        out = np.empty((len(rows), cfg.box, cfg.box), dtype=np.float32)
+        lib.check(lib.load().ppm_match_projections(self.h, C.byref(cfg), lib.ptr(rows), len(rows), lib.ptr(out)))
+        return out
+
     def csp_refine(self, cfg, csp_cfg, images, rows, particles, tilts):
         """Constrained refinement (ppm_csp_refine): returns updated copies (rows, particles, tilts)."""
         rows = np.array(rows, dtype=np.float64, order="C")

@@ -12,7 +12,7 @@ SO_PATH = os.path.join(_HERE, "libpypmatch.so")
 
 EXPORTS = [
     "ppm_init", "ppm_last_error", "ppm_version", "ppm_reference_create", "ppm_reference_create_padded", "ppm_reference_create_weighted", "ppm_reference_destroy",
-    "ppm_refine_batch", "ppm_refine_last_counts", "ppm_refine_note", "ppm_csp_refine", "ppm_sva_align", "ppm_accum_floats", "ppm_accum_create", "ppm_accum_destroy",
+    "ppm_refine_batch", "ppm_refine_last_counts", "ppm_refine_note", "ppm_match_projections", "ppm_csp_refine", "ppm_sva_align", "ppm_accum_floats", "ppm_accum_create", "ppm_accum_destroy",
     "ppm_insert_batch", "ppm_accum_download", "ppm_accum_add", "ppm_accum_count", "ppm_accum_set_count",
     "ppm_finalize", "ppm_profile_enable", "ppm_profile_reset", "ppm_profile_get", "ppm_device_alloc",
     "ppm_device_free", "ppm_device_upload", "ppm_device_sync", "ppm_extract_boxes", "ppm_host_alloc", "ppm_host_free",
@@ -46,6 +46,7 @@ def load():
     L.ppm_refine_batch.argtypes = [vp, vp, vp, ci, ci, vp, vp]; L.ppm_refine_batch.restype = ci
     L.ppm_refine_last_counts.argtypes = [vp, vp, vp, vp, vp]; L.ppm_refine_last_counts.restype = ci
     L.ppm_refine_note.argtypes = [vp]; L.ppm_refine_note.restype = C.c_char_p
+    L.ppm_match_projections.argtypes = [vp, vp, vp, ci, vp]; L.ppm_match_projections.restype = ci
     L.ppm_csp_refine.argtypes = [vp, vp, vp, vp, ci, ci, vp, vp, ci, vp, ci]; L.ppm_csp_refine.restype = ci
     L.ppm_sva_align.argtypes = [vp, vp, vp, ci, ci, vp, vp, vp]; L.ppm_sva_align.restype = ci
     L.ppm_accum_floats.argtypes = [ci]; L.ppm_accum_floats.restype = C.c_size_t

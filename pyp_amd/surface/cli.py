@@ -163,7 +163,7 @@ def refine3d_main(argv=None, stdin=None):
     print("\n        **   Welcome to Refine3D (MI355X / libpypmatch)   **\n")
     for k, v in d.items():
         print(f"{k:28s}: {v}")
-    _unsupported(d, [("use_priors", True), ("calc_match", True),
+    _unsupported(d, [("use_priors", True),
                      ("exclude_edges", True), ("normalize_reference", True), ("threshold_reference", True)], "refine3d")
     pad = int(round(d["padding"]))
     if abs(d["padding"] - pad) > 1e-6 or pad not in (1, 2, 4):
@@ -205,6 +205,12 @@ def refine3d_main(argv=None, stdin=None):
             for lo, hi, imgs in _iter_image_chunks(mm, rin[:, C["POSITION_IN_STACK"]], dev):
                 rout[lo:hi] = ref.refine(cfg, imgs, rin[lo:hi])
             note = ref.note()
+            if d["calc_match"]:         # answers 8 / 43: the model of every particle of the range at its refined pose, one section each
+                step = max(1, (256 << 20) // (box * box * 4))
+                match = np.empty((len(rout), box, box), dtype=np.float32)
+                for lo in range(0, len(rout), step):
+                    match[lo:lo + step] = ref.match_projections(cfg, rout[lo:lo + step])
+                mrc.write(match, d["match_out"], pixel_size=px)
             ref.close()
     except (lib.PpmError, ValueError) as e:
         _die(str(e))

@@ -171,7 +171,7 @@ class Projector:
 
 def make_dataset(n, m, pixel=1.0, snr=0.05, seed_poses=SEED_POSES, seed_noise=SEED_NOISE, vol=None,
                  device="cpu", batch=64, particle_rad_frac=0.32, shift_sigma=2.0, shift_clip=6.0,
-                 kv=300.0, cs_mm=2.7, amp=0.07, unique=None):
+                 kv=300.0, cs_mm=2.7, amp=0.07, unique=None, normalize=True):
     """Return (vol, stack (m,n,n) float32 torch tensor on `device`, rows (m,32) float64 with the TRUE poses).
 
     unique: if set (< m), only that many distinct clean projections are computed and reused cyclically with
@@ -193,14 +193,14 @@ def make_dataset(n, m, pixel=1.0, snr=0.05, seed_poses=SEED_POSES, seed_noise=SE
     rows[:, C["X_SHIFT"]], rows[:, C["Y_SHIFT"]] = sh[rep, 0] * pixel, sh[rep, 1] * pixel
     rows[:, C["DEFOCUS_1"]], rows[:, C["DEFOCUS_2"]], rows[:, C["DEFOCUS_ANGLE"]] = df1[rep], df2[rep], ast[rep]
 
-    stack = render_rows(vol, rows[:u], pixel, snr, seed_noise, device, batch, particle_rad_frac, kv, cs_mm, amp, m=m, rep=rep)
+    stack = render_rows(vol, rows[:u], pixel, snr, seed_noise, device, batch, particle_rad_frac, kv, cs_mm, amp, m=m, rep=rep, normalize=normalize)
     return vol, stack, rows
 
 
 def render_rows(vol, rows, pixel=1.0, snr=0.05, seed_noise=SEED_NOISE, device="cpu", batch=64, particle_rad_frac=0.32,
-                kv=300.0, cs_mm=2.7, amp=0.07, m=None, rep=None):
+                kv=300.0, cs_mm=2.7, amp=0.07, m=None, rep=None, normalize=True):
     """Images of the poses / CTF parameters in `rows` (u x 32): projection x CTF, shifted, white noise at `snr`, background
-    normalised.  With m / rep, image i of the m returned is clean projection rep[i] with fresh noise."""
+    normalised (unless normalize is False: the images keep the reference's density scale).  With m / rep, image i of the m returned is clean projection rep[i] with fresh noise."""
     C = cistem.COL
     u = len(rows)
     n = vol.shape[0]
@@ -242,7 +242,7 @@ def render_rows(vol, rows, pixel=1.0, snr=0.05, seed_noise=SEED_NOISE, device="c
         # the callers pass invert = no.
         mu = x[:, bg].mean(dim=1).view(-1, 1, 1)
         sd = x[:, bg].std(dim=1, unbiased=False).view(-1, 1, 1)
-        stack[b0:b1] = (x - mu) / sd
+        stack[b0:b1] = (x - mu) / sd if normalize else x
     return stack
 
 

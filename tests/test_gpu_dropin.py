@@ -45,6 +45,22 @@ def project(tmp_path_factory):
     return d, vol, stack.numpy(), rows, start
 
 
+def test_refine3d_writes_matching_projections(project):
+    """Answer 43 "calculate matching projections" = yes (refine_fmatch, frealign.py:3929-3931): answer 8's file holds one section
+    per particle of the range, the model at the refined pose; it overlays the particle it belongs to."""
+    d, vol, imgs, truth, start = project
+    lines = refine_script(5, 16, True, out="m.cistem").splitlines()
+    lines[42] = "yes"                                               # answer 43
+    assert run("refine3d", "\n".join(lines) + "\n", d, "match.log") == 0, open(d / "match.log").read()[-2000:]
+    m = mrc.read(str(d / "p_r01_match.mrc_0000005_0000016"))
+    assert m.shape == (12, N, N)
+    for a, b in zip(m, imgs[4:16]):
+        a0, b0 = a - a.mean(), b - b.mean()
+        assert (a0 * b0).sum() / np.sqrt((a0 * a0).sum() * (b0 * b0).sum()) > 0.25      # SNR 0.2: cc with the noisy particle ~ 0.4
+    other = (m[0] - m[0].mean()) * (imgs[20] - imgs[20].mean())
+    assert abs(other.sum()) / np.sqrt(((m[0] - m[0].mean()) ** 2).sum() * ((imgs[20] - imgs[20].mean()) ** 2).sum()) < 0.2
+
+
 def test_refine3d_ranges_then_merge(project):
     d, vol, imgs, truth, start = project
     for first, last in ((1, 31), (32, 60)):                 # ranges like local_run.create_split_commands

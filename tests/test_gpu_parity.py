@@ -77,6 +77,25 @@ def test_focus_mask_matches_oracle(d64, H, O):
     assert synth.angular_error_deg(want, got).max() < ANG_TOL_DEG and synth.shift_error_px(want, got, 2.0).max() < SHIFT_TOL_PX
 
 
+def test_matching_projections_match_oracle_and_an_independent_projector(d64, H, O):
+    """Answers 8 / 43 (refine_fmatch): reference projected at the row's pose x CTF at the row's shift.  HIP = oracle to float
+    round-off; and both overlay the noise-free image an independent real-space projector (pyp_amd.synth, torch) renders for
+    the same rows — sign, shift direction, CTF and scale conventions at once."""
+    vol, imgs, rows, g, o = d64
+    c = cfg_for(64, 2.0, res_high=2.0 * 2.0 * 64 / 62.0)                 # band limit just inside Nyquist
+    want = O.match_projections(o, c, rows[:8])
+    got = g.match_projections(c, rows[:8])
+    assert got.shape == (8, 64, 64) and np.linalg.norm(got - want) / np.linalg.norm(want) < 1e-4
+    clean = synth.render_rows(vol, rows[:8], 2.0, snr=0, normalize=False).numpy()      # the same rows, no noise, density scale kept
+    for a, b in zip(got, clean):
+        a0, b0 = a - a.mean(), b - b.mean()
+        cc = float((a0 * b0).sum() / np.sqrt((a0 * a0).sum() * (b0 * b0).sum()))
+        assert cc > 0.98, cc
+        assert 0.9 < float((a0 * b0).sum() / (b0 * b0).sum()) < 1.1      # same scale
+    neg = g.match_projections(cfg_for(64, 2.0, res_high=2.0 * 2.0 * 64 / 62.0, invert=1), rows[:2])
+    assert np.allclose(neg, -got[:2], atol=1e-6)
+
+
 def test_local_refinement_matches_oracle(d64, H, O):
     vol, imgs, rows, g, o = d64
     start = synth.perturb_rows(rows, 2.0, 1.0, 2.0)

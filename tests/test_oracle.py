@@ -229,3 +229,18 @@ def test_focus_mask_disc_follows_the_projected_sphere():
     plain = oracle.score_batch(ref, RefineCfg.make(**base), imgs, rows)
     other = oracle.score_batch(ref, RefineCfg.make(focus=(12.0, 6.0, -9.0, 20.0), **base), imgs, rows)
     assert np.abs(other - plain).max() > 1e-3
+
+
+def test_matching_projections_overlay_an_independent_projector():
+    """refine3d answers 8 / 43: the oracle's model image (reference slice x CTF at the row's shift, inverse transform) against the
+    real-space projector of pyp_amd.synth for the same rows, no noise: same sign, position, CTF and scale."""
+    n, px = 48, 2.5
+    vol, clean, rows = synth.make_dataset(n, 4, pixel=px, snr=0, normalize=False)
+    ref = oracle.Reference(vol, n / 2)
+    c = RefineCfg.make(box=n, pixel_size=px, mask_radius=0.4 * n * px, res_high=2 * px * n / (n - 2.0))
+    m = oracle.match_projections(ref, c, rows)
+    for a, b in zip(m, clean.numpy()):
+        a0, b0 = a - a.mean(), b - b.mean()
+        assert (a0 * b0).sum() / np.sqrt((a0 * a0).sum() * (b0 * b0).sum()) > 0.98
+        assert 0.9 < (a0 * b0).sum() / (b0 * b0).sum() < 1.12
+    assert np.allclose(oracle.match_projections(ref, RefineCfg.make(box=n, pixel_size=px, mask_radius=0.4 * n * px, res_high=2 * px * n / (n - 2.0), invert=1), rows[:1]), -m[:1])
