@@ -145,23 +145,30 @@ __global__ void __launch_bounds__(PT, MINW) k_prep(PrepP P) {
         const float invNf = 1.0f / (float)N;
         const float4 *img4 = (const float4 *)img;          // N even: N^2 is a multiple of 4, every image starts 16-byte aligned
         constexpr int UR = 8;                              // independent 16-byte loads in flight per thread
+        const bool rows4 = (N & 3) == 0;                   // then the 4 pixels of a 16-byte load share their image row
         for (int b4 = tid; b4 < N * N / 4; b4 += PT * UR) {
             float4 qv[UR];
 #pragma unroll
             for (int u = 0; u < UR; u++) { const int i4 = b4 + u * PT; if (i4 < N * N / 4) qv[u] = img4[i4]; }
+            // the <= 32 pixels of one trip are summed in single precision, the trips in double (fp64 adds issue at a fraction
+            // of the fp32 rate: five of them per pixel made this pass a fifth of the kernel's vector instructions)
+            float f1 = 0.f, f2 = 0.f, fc = 0.f, g1 = 0.f, g2 = 0.f;
 #pragma unroll
             for (int u = 0; u < UR; u++) {
                 const int i4 = b4 + u * PT;
                 if (i4 >= N * N / 4) continue;
                 const float vv[4] = { qv[u].x, qv[u].y, qv[u].z, qv[u].w };
+                const int i0 = 4 * i4, y0 = fast_div(i0, N, invNf), x0 = i0 - y0 * N;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const int i = 4 * i4 + j, y = fast_div(i, N, invNf), x = i - y * N;
+                    int y = y0, x = x0 + j;
+                    if (!rows4 && x >= N) { x -= N; y += 1; }
                     const float dx = (float)(x - N / 2), dy = (float)(y - N / 2), v = vv[j];
-                    t1 += v; t2 += (double)v * v;
-                    if (dx * dx + dy * dy > Rm2) { s1 += v; s2 += (double)v * v; cnt += 1.0; }
+                    g1 += v; g2 = fmaf(v, v, g2);
+                    if (dx * dx + dy * dy > Rm2) { f1 += v; f2 = fmaf(v, v, f2); fc += 1.f; }
                 }
             }
+            s1 += (double)f1; s2 += (double)f2; cnt += (double)fc; t1 += (double)g1; t2 += (double)g2;
         }
     }
     s1 = wave_sum_d(s1); s2 = wave_sum_d(s2); cnt = wave_sum_d(cnt); t1 = wave_sum_d(t1); t2 = wave_sum_d(t2);
