@@ -175,6 +175,17 @@ def test_search_grid_variants_match_oracle(H, O, kw):
     assert synth.angular_error_deg(want, got).max() < ANG_TOL_DEG and synth.shift_error_px(want, got, 2.0).max() < SHIFT_TOL_PX, kw
 
 
+def test_particle_pairs_of_the_grid_search_do_not_couple(H):
+    """k_global works on two particles per block (they share the streamed slice rows): a particle's result must not depend on
+    its neighbour, on being the odd one of a short last block, or on where the chunk boundaries fall."""
+    vol, imgs, rows = dataset(64, 9, 2.0, 0.1)
+    g = H.Reference(vol, 32)
+    c = cfg_for(64, 2.0)
+    full = g.refine(c, imgs, rows)
+    for sel in ([0], [8], [0, 1, 2], [1, 0], [3, 7, 5, 2, 8]):
+        assert np.array_equal(g.refine(c, imgs[sel], rows[sel]), full[sel]), sel
+
+
 def test_two_live_references_with_different_search_grids(H, O):
     """Row twiddles of the grid search belong to the reference handle: alternating calls on two references with different
     boxes / bands must not see each other's tables."""
