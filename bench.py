@@ -48,9 +48,13 @@ def parse(argv=None):
     ap.add_argument("--unique", type=int, default=0, help="distinct clean projections (0 = one per particle: every particle has its own pose)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of each CPU oracle leg (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--workload", choices=["both", "refine", "reconstruct"], default="both",
+    ap.add_argument("--workload", choices=["both", "refine", "reconstruct", "csp", "sva"], default="both",
                     help="both = the refinement line (BASELINE.json configs[1], the headline metric) carrying a 'reconstruct' block "
-                         "(configs[2]); refine / reconstruct = that workload alone (the line's metric is then that workload's)")
+                         "(configs[2]) and the two next-row blocks 'csp' (configs[3]: constrained tilt-series refinement) and 'sva' "
+                         "(configs[4]: sub-tomogram alignment); refine / reconstruct / csp / sva = that workload alone")
+    ap.add_argument("--csp-particles", type=int, default=500, help="particles of the tilt series of the csp block (41 tilts, 128^2 boxes)")
+    ap.add_argument("--sva-volumes", type=int, default=256, help="resident 192^3 sub-volumes of the sva block")
+    ap.add_argument("--no-next-rows", action="store_true", help="leave the csp / sva blocks out of the default line")
     return ap.parse_args(argv)
 
 
@@ -219,6 +223,14 @@ def main(argv=None):
                 line = rec
             else:
                 line["reconstruct"] = rec
+    for name, fn in (("csp", csp_bench), ("sva", sva_bench)):
+        if a.workload == name or (a.workload == "both" and not a.no_next_rows):
+            blk = fn(ctx)
+            if rank == 0:
+                if line is None:
+                    line = blk
+                else:
+                    line[name] = blk
     if rank == 0:
         print(json.dumps(line))
     if world > 1:
@@ -443,6 +455,152 @@ def reconstruct_bench(ctx):
             "kernels_us_per_particle": per_us, "compulsory_bytes_per_particle": 4 * N * N,
             "path_hbm_frac_compulsory": round(world * M * a.steps * 4.0 * N * N / dt / 1e9 / PEAK_HBM_GBPS / world, 4),
             "map_cc_vs_truth": round(cc, 4), "fsc_at_half_nyquist": round(float(stats[N // 4 - 1, 3]), 4)}
+
+
+# --------------------------------------------------------------------------------------------- next rows
+def _omp_threads(n):
+    import ctypes
+    ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(n))
+
+
+def csp_bench(ctx):
+    """configs[3] at one tilt series per rank: P particles x 41 tilts of 128^2 boxes (resident), constrained refinement of the
+    particle units (csp modes 2 / 5: three rotations + 3-D shift per particle, scored over its 41 projections).  Units shard
+    over ranks with no collective (pyp_amd.dist.shard_units); every rank refines its own series here.  A step = one call of
+    ppm_csp_refine over the series."""
+    import torch
+    from pyp_amd import host, synth
+    from pyp_amd.abi import CSP_PARTICLES, CspCfg, RefineCfg
+    a, rank, world, local, dev = (ctx[k] for k in ("a", "rank", "world", "local", "dev"))
+    n, px, npart = 128, 2.0, a.csp_particles
+    tl = np.linspace(-60, 60, 41)
+    vol, stack, rows, parts, tilts = synth.make_tilt_series(n, npart, tl, pixel=px, snr=0.1, device=dev, seed=20240601 + rank)
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(3 + rank)
+    p2 = parts.copy()
+    for i in range(len(p2)):
+        Nm = synth.euler_matrix(-p2[i, 4], -p2[i, 5], -p2[i, 6])
+        for k in range(3):
+            Nm = Nm @ synth.rot_xyz(k, rng.normal(0, 2.0))
+        p2[i, 4:7] = -synth.angles_from_matrix(Nm)
+        p2[i, 1:4] += rng.normal(0, 1.0, 3)
+    rows2 = synth.csp_rows_from_params(rows, parts, tilts, p2, tilts)
+    cfg = RefineCfg.make(box=n, pixel_size=px, mask_radius=0.32 * n * px, res_high=px * n / (0.25 * n), res_signed_cc=30.0, global_search=0)
+    host.lib.init(local)
+    ref = host.Reference(vol, n / 2, device=local)
+    cc = CspCfg.make(CSP_PARTICLES, tol_angle=(8, 8, 8), tol_shift=4.0)
+    barrier = make_barrier(world)
+    out = None
+    for _ in range(max(a.warmup, 1)):
+        out = ref.csp_refine(cfg, cc, stack, rows2, p2, tilts)
+    host.profile(True, True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = ref.csp_refine(cfg, cc, stack, rows2, p2, tilts)
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0, world, dev)
+    prof = host.profile_report()
+    host.profile(False, False)
+    ref.close()
+    if rank != 0:
+        return None
+
+    def perr(x, y):
+        return np.array([np.degrees(np.arccos(np.clip((np.trace(synth.euler_matrix(-u[4], -u[5], -u[6]).T @ synth.euler_matrix(-v[4], -v[5], -v[6])) - 1) / 2, -1, 1)))
+                         for u, v in zip(x, y)])
+    nproj = len(rows)
+    blk = {"metric": "projections/sec constrained tilt-series refinement, 128^2 box", "value": round(world * nproj * a.steps / dt, 1), "unit": "projections/s",
+           "particles_per_s": round(world * npart * a.steps / dt, 1), "n_gpus": world, "steps": a.steps, "ms_per_step": round(dt / a.steps * 1e3, 2),
+           "higher_is_better": True, "scaling": "weak", "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "one tilt series per GPU: %d particles x 41 tilts (+-60 deg), 128^2 boxes resident, particle units refined "
+                                  "(3 rotations + 3-D shift, +-8 deg / +-4 px), band r = 32 px" % npart,
+                      "projections_per_gpu": nproj, "parallelism": "unit-sharded x%d, no collective" % world},
+           "device_ms_per_step": {k2: round(v["ms"] / a.steps, 2) for k2, v in prof.items() if v["launches"]},
+           "device_busy_frac": round(sum(v["ms"] for v in prof.values()) * 1e-3 / dt, 3),
+           "note": "host-driven compass search: the device scores <= 13 candidate poses per projection and sweep (k_csp_eval, the sweep of k_local: "
+                   "vector-issue-bound like it); the rest of a step is the host's fixed-order reductions and candidate tables",
+           "accuracy_vs_truth": {"median_deg_before": round(float(np.median(perr(p2, parts))), 3), "median_deg_after": round(float(np.median(perr(out[1], parts))), 3),
+                                 "median_shift_px_after": round(float(np.median(np.linalg.norm(out[1][:, 1:4] - parts[:, 1:4], axis=1))), 3)}}
+    if world == 1 and not a.no_cpu and a.cpu_seconds > 0:
+        from oracle import oracle
+        cores = host_cores()
+        _omp_threads(cores)
+        k = max(1, min(npart, cores // 2))                      # a bounded sample of particle units with all their projections
+        from pyp_amd.formats import cistem
+        sel = np.where(np.isin(rows2[:, cistem.COL["PIND"]], p2[:k, 0]))[0]
+        t0 = time.time()
+        oref = oracle.Reference(vol, n / 2)
+        cc1 = CspCfg.make(CSP_PARTICLES, tol_angle=(8, 8, 8), tol_shift=4.0, first=int(p2[0, 0]), last=int(p2[k - 1, 0]))
+        t1 = time.time()
+        oracle.csp_refine(oref, cfg, cc1, stack.cpu().numpy(), rows2, p2, tilts)
+        tc = time.time() - t1
+        oref.close()
+        blk["cpu_baseline"] = {"value": round(len(sel) / tc, 2), "unit": "projections/s", "cores": cores, "kind": "port",
+                               "sample": "%d particle units (%d projections), %.1f s wall, OpenMP; reference preparation %.1f s excluded" % (k, len(sel), tc, t1 - t0)}
+    return blk
+
+
+def sva_bench(ctx):
+    """configs[4] at a resident batch per rank: V sub-volumes of 192^3 aligned to the reference (3DAVG refine mode: +-10 deg, +-10
+    px, 7 compass iterations, missing wedge +-60 deg).  Sub-volumes shard over ranks by table rows with no collective.  A step =
+    one call of ppm_sva_align over the batch (3-D FFT of every sub-volume + search)."""
+    import torch
+    from pyp_amd import host, synth
+    from pyp_amd.abi import SvaCfg
+    a, rank, world, local, dev = (ctx[k] for k in ("a", "rank", "world", "local", "dev"))
+    n, nv = 192, a.sva_volumes
+    vol, vols, poses, wedges = synth.make_subtomograms(n, nv, snr=0.1, device=dev, seed=20240701 + rank)
+    torch.cuda.synchronize()
+    cfg = SvaCfg.make(n, window=(0.33 * n, 0.33 * n, 0.33 * n), window_sigma=4.0, highpass=(0.05, 0.01), lowpass=(0.125, 0.05), tol_angle=10.0, tol_shift=10.0)
+    start = synth.perturb_poses(poses, 3.0, 2.0)
+    host.lib.init(local)
+    ref = host.Reference(vol, n / 2, device=local)
+    barrier = make_barrier(world)
+    ref.sva_align(cfg, vols[:4], wedges[:4], start[:4])
+    host.profile(True, True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out, sc = ref.sva_align(cfg, vols, wedges, start)
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0, world, dev)
+    prof = host.profile_report()
+    host.profile(False, False)
+    ref.close()
+    if rank != 0:
+        return None
+    n3 = float(n) ** 3
+    ms_prep = prof["prep"]["ms"] / (nv * a.steps)
+    blk = {"metric": "sub-volumes/sec sub-tomogram alignment, 192^3 box", "value": round(world * nv * a.steps / dt, 1), "unit": "sub-volumes/s",
+           "n_gpus": world, "steps": a.steps, "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "%d resident 192^3 sub-volumes per GPU (%.1f GB), +-10 deg / +-10 px, missing wedge +-60 deg, band 0.125 cycles/pixel" % (nv, nv * n3 * 4 / 1e9),
+                      "sub_volumes_per_gpu": nv, "parallelism": "row-sharded x%d, no collective" % world},
+           "device_ms_per_sub_volume": {"pre_processing": round(ms_prep, 3), "search": round(prof["local"]["ms"] / (nv * a.steps), 3)},
+           "roofline": {"bound": "hbm", "kernel": "sub-volume pre-processing (k_sva_load + three k_fft_lines passes + k_sva_gather)",
+                        "achieved": round((4.0 + 8.0 * 7) * n3 / (ms_prep * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                        "frac": round((4.0 + 8.0 * 7) * n3 / (ms_prep * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4), "traffic": None,
+                        "algorithmic_bytes": "4 n^3 read + 8 n^3 written by the load, 8 n^3 read and written by each of the three strided FFT passes"},
+           "pcie_bound_note": "config 5's 10 k sub-volumes (283 GB) stream from the host: 28 MB each, i.e. ~1.9 k sub-volumes/s at PCIe Gen5 rates",
+           "accuracy_vs_truth": {"median_deg_before": round(float(np.median(synth.pose_angle_error(start, poses))), 3),
+                                 "median_deg_after": round(float(np.median(synth.pose_angle_error(out, poses))), 3),
+                                 "median_shift_px_after": round(float(np.median(np.linalg.norm(out[:, 9:] - poses[:, 9:], axis=1))), 3),
+                                 "mean_score": round(float(sc.mean()), 4)}}
+    if world == 1 and not a.no_cpu and a.cpu_seconds > 0:
+        from oracle import oracle
+        cores = host_cores()
+        _omp_threads(cores)
+        k = 4
+        t0 = time.time()
+        oref = oracle.Reference(vol, n / 2)
+        t1 = time.time()
+        oracle.sva_align(oref, cfg, vols[:k].cpu().numpy(), wedges[:k], start[:k])
+        tc = time.time() - t1
+        oref.close()
+        blk["cpu_baseline"] = {"value": round(k / tc, 3), "unit": "sub-volumes/s", "cores": cores, "kind": "port",
+                               "sample": "%d sub-volumes, %.1f s wall, OpenMP; reference preparation %.1f s excluded" % (k, tc, t1 - t0)}
+    return blk
 
 
 # --------------------------------------------------------------------------------------------- CPU legs

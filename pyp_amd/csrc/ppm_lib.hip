@@ -1358,16 +1358,24 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
     // ---- sample list of the band (half space, shell by shell), common to all sub-volumes; the wedge is applied per volume
     const int R = (int)std::ceil(rband);
     std::vector<uint32_t> samples; std::vector<float> bandw; std::vector<int> shell_off(R + 2, 0);
-    for (int sh = 0; sh <= R; sh++) {
+    {
+        // one pass over the half space, bucketed by shell (the order inside a shell is the scan order kz, ky, kx)
+        std::vector<std::vector<uint32_t>> sh_s(R + 1); std::vector<std::vector<float>> sh_w(R + 1);
         for (int kz = -R; kz <= R; kz++) for (int ky = -R; ky <= R; ky++) for (int kx = 0; kx <= R; kx++) {
             const double k2 = (double)kx * kx + (double)ky * ky + (double)kz * kz;
-            if (k2 == 0 || k2 >= rband * rband || (int)std::floor(std::sqrt(k2)) != sh) continue;
+            if (k2 == 0 || k2 >= rband * rband) continue;
             if (kx == 0 && (ky < 0 || (ky == 0 && kz < 0))) continue;
-            const double w = sva_band_weight(*cfg, std::sqrt(k2) / N);
+            const double kr = std::sqrt(k2);
+            const int sh = (int)std::floor(kr);
+            if (sh > R) continue;
+            const double w = sva_band_weight(*cfg, kr / N);
             if (w < 1e-3) continue;
-            samples.push_back(sva_pack(kx, ky, kz)); bandw.push_back((float)w);
+            sh_s[sh].push_back(sva_pack(kx, ky, kz)); sh_w[sh].push_back((float)w);
         }
-        shell_off[sh + 1] = (int)samples.size();
+        for (int sh = 0; sh <= R; sh++) {
+            samples.insert(samples.end(), sh_s[sh].begin(), sh_s[sh].end()); bandw.insert(bandw.end(), sh_w[sh].begin(), sh_w[sh].end());
+            shell_off[sh + 1] = (int)samples.size();
+        }
     }
     const int S = (int)samples.size();
     if (S == 0) return fail(-22, "the band-pass filter leaves no Fourier samples");
