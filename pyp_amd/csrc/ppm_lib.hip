@@ -117,6 +117,20 @@ int fft3d(float2 *d, int n, bool inverse) {
     return 0;
 }
 
+// one pass of length-n transforms over strided lines of `d` (see FftLinesP)
+static int fft_lines_pass(float2 *d, int n, long nlines, long inner, long inner_stride, long outer_stride, long elem_stride, int line_major, bool inverse) {
+    if (nlines <= 0) return 0;
+    if (int rc = ensure_plan(n)) return rc;
+    int L = std::max(1, std::min(16, 8192 / n));
+    while (nlines % L) L--;
+    FftLinesP P;
+    P.data = d; P.plan = g.plans[n].plan; P.n = n; P.inverse = inverse ? 1 : 0; P.L = L; P.nlines = nlines;
+    P.inner = inner; P.inner_stride = inner_stride; P.outer_stride = outer_stride; P.elem_stride = elem_stride; P.line_major = line_major;
+    hipLaunchKernelGGL(k_fft_lines, dim3((unsigned)((nlines + L - 1) / L)), dim3(256), (size_t)L * n * sizeof(float2), g.stream, P);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 template <typename T>
 struct DevBuf {
     T *p = nullptr; size_t cap = 0;
@@ -1405,7 +1419,8 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
     // ---- device buffers (RAII), chunks of sub-volumes
     const int CH = (int)std::min<size_t>((size_t)n_vol, std::max<size_t>(1, ((size_t)4 << 30) / (n3 * 4 + (size_t)S * 8)));
     DevTmp<uint32_t> d_samples; DevTmp<float> d_bandw, d_vols, d_wedges; DevTmp<float2> d_f, d_F; DevTmp<double> d_stats, d_poses, d_delta, d_out;
-    HIPCHK(d_samples.alloc(S)); HIPCHK(d_bandw.alloc(S)); HIPCHK(d_f.alloc(n3)); HIPCHK(d_F.alloc((size_t)CH * S));
+    const int KX = std::min(N / 2 + 1, R + 1);          // x coefficients kept; |ky|, |kz| <= R are the lines the later passes touch
+    HIPCHK(d_samples.alloc(S)); HIPCHK(d_bandw.alloc(S)); HIPCHK(d_f.alloc((size_t)N * N * KX)); HIPCHK(d_F.alloc((size_t)CH * S));
     HIPCHK(d_stats.alloc((size_t)2 * CH)); HIPCHK(d_poses.alloc((size_t)12 * CH)); HIPCHK(d_delta.alloc((size_t)CH * ncand * 6)); HIPCHK(d_out.alloc((size_t)CH * ncand));
     HIPCHK(d_wedges.alloc((size_t)2 * CH));
     if (!volumes_on_device) HIPCHK(d_vols.alloc((size_t)CH * n3));
@@ -1428,10 +1443,22 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
         {
             ProfScope ps(PPM_K_PREP);
             hipLaunchKernelGGL(k_sva_stats, dim3(64, nb), dim3(256), 0, g.stream, dv, n3, d_stats.p);
+            if (int rc = ensure_plan(N)) return rc;
+            SvaXP XP; XP.stats = nullptr; XP.out = d_f.p; XP.plan = g.plans[N].plan; XP.n = N; XP.KX = KX; XP.nlines = (long)N * N; XP.W = W;
+            XP.L = std::max(1, std::min(16, 8192 / N));
+            while (XP.nlines % XP.L) XP.L--;
             for (int v = 0; v < nb; v++) {
-                hipLaunchKernelGGL(k_sva_load, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, g.stream, dv + (size_t)v * n3, d_stats.p + 2 * v, d_f.p, N, W);
-                if (int rc = fft3d(d_f.p, N, false)) return rc;
-                hipLaunchKernelGGL(k_sva_gather, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, g.stream, d_f.p, d_samples.p, S, N, d_F.p + (size_t)v * S);
+                // pruned transform (k_sva_xpass): x pass from the real volume into [z][y][KX], y pass on that, z pass on |ky| <= R only
+                XP.vol = dv + (size_t)v * n3; XP.stats = d_stats.p + 2 * v;
+                hipLaunchKernelGGL(k_sva_xpass, dim3((unsigned)((XP.nlines + XP.L - 1) / XP.L)), dim3(256), (size_t)XP.L * N * sizeof(float2), g.stream, XP);
+                if (int rc = fft_lines_pass(d_f.p, N, (long)N * KX, KX, 1, (long)N * KX, KX, 1, false)) return rc;
+                if (2 * R + 1 >= N) {
+                    if (int rc = fft_lines_pass(d_f.p, N, (long)N * KX, (long)N * KX, 1, 0, (long)N * KX, 1, false)) return rc;
+                } else {
+                    if (int rc = fft_lines_pass(d_f.p, N, (long)(R + 1) * KX, (long)(R + 1) * KX, 1, 0, (long)N * KX, 1, false)) return rc;
+                    if (int rc = fft_lines_pass(d_f.p + (size_t)(N - R) * KX, N, (long)R * KX, (long)R * KX, 1, 0, (long)N * KX, 1, false)) return rc;
+                }
+                hipLaunchKernelGGL(k_sva_gather, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, g.stream, d_f.p, d_samples.p, S, N, KX, d_F.p + (size_t)v * S);
             }
         }
         HIPCHK(hipGetLastError());
