@@ -240,10 +240,11 @@ __device__ __forceinline__ CubeTaps cube_fetch(const CubeView &cv, float X, floa
     const int x0 = (int)xf, y0 = (int)yf + cv.off, z0 = (int)zf + cv.off;
     const bool second = (x0 & 3) == 3;
     const int xs = second ? x0 - 2 : x0;
-    const unsigned rowb = (unsigned)cv.NBX * 16u, planeb = rowb * (unsigned)cv.NBY;
+    // brick counts and element offsets stay below 2^24: 24-bit multiplies (full rate; v_mul_lo_u32 issues at a quarter of it)
+    const unsigned rowb = (unsigned)cv.NBX * 16u, planeb = __umul24(rowb, (unsigned)cv.NBY);
     const unsigned xl = (unsigned)(xs >> 2) * 16u + (unsigned)(xs & 3) + (second ? cv.LB : 0u);
-    const unsigned yl0 = (unsigned)(y0 >> 1) * rowb + (unsigned)(y0 & 1) * 4u, yl1 = (y0 & 1) ? (unsigned)((y0 >> 1) + 1) * rowb : yl0 + 4u;
-    const unsigned zl0 = (unsigned)(z0 >> 1) * planeb + (unsigned)(z0 & 1) * 8u, zl1 = (z0 & 1) ? (unsigned)((z0 >> 1) + 1) * planeb : zl0 + 8u;
+    const unsigned yl0 = __umul24((unsigned)(y0 >> 1), rowb) + (unsigned)(y0 & 1) * 4u, yl1 = (y0 & 1) ? yl0 + rowb - 4u : yl0 + 4u;
+    const unsigned zl0 = __umul24((unsigned)(z0 >> 1), planeb) + (unsigned)(z0 & 1) * 8u, zl1 = (z0 & 1) ? zl0 + planeb - 8u : zl0 + 8u;
     const float2 *pa = cv.cube + (xl + yl0 + zl0), *pb = cv.cube + (xl + yl1 + zl0), *pc = cv.cube + (xl + yl0 + zl1), *pd = cv.cube + (xl + yl1 + zl1);
     const float2 a0 = pa[0], a1 = pa[1], b0 = pb[0], b1 = pb[1], c0 = pc[0], c1 = pc[1], d0 = pd[0], d1 = pd[1];
     t.a = make_float4(a0.x, a0.y, a1.x, a1.y); t.b = make_float4(b0.x, b0.y, b1.x, b1.y);
