@@ -166,6 +166,9 @@ struct ppm_ref {
     // workspaces (grown on demand, reused across calls)
     DevBuf<double> rows_in, rows_out, dir_theta, dir_phi;
     DevBuf<float> images, wring, cw, C2, nP, nI, cc, mats, ddef;
+    // constrained search (ppm_csp_refine)
+    DevBuf<float2> c_Il, c_band; DevBuf<float> c_cw, c_img, c_wring; DevBuf<double> c_rows, c_N, c_p, c_tl, c_delta, c_s0, c_g0, c_out;
+    DevBuf<int> c_eval, c_rp, c_rt, c_slot; DevBuf<LState> c_states;
     DevBuf<float2> band, Il, Wp, bank, twN;
     DevBuf<float4> rowtw;            // k_global's row-pair twiddles for this reference's current search grid
     DevBuf<int> sh;
@@ -437,7 +440,9 @@ void ppm_reference_destroy(ppm_ref_t *r) {
     if (!r) return;
     if (r->cube) (void)hipFree(r->cube);
     r->rows_in.release(); r->rows_out.release(); r->dir_theta.release(); r->dir_phi.release();
-    r->images.release(); r->wring.release(); r->cw.release(); r->C2.release(); r->nP.release(); r->nI.release(); r->cc.release(); r->mats.release(); r->ddef.release();
+    r->images.release(); r->wring.release(); r->cw.release(); r->C2.release(); r->nP.release(); r->nI.release();
+    r->c_Il.release(); r->c_band.release(); r->c_cw.release(); r->c_img.release(); r->c_wring.release(); r->c_rows.release(); r->c_N.release(); r->c_p.release(); r->c_tl.release();
+    r->c_delta.release(); r->c_s0.release(); r->c_g0.release(); r->c_out.release(); r->c_eval.release(); r->c_rp.release(); r->c_rt.release(); r->c_slot.release(); r->c_states.release(); r->cc.release(); r->mats.release(); r->ddef.release();
     r->band.release(); r->Il.release(); r->Wp.release(); r->bank.release(); r->twN.release(); r->rowtw.release(); r->sh.release(); r->samples.release();
     r->hits.release(); r->states.release(); r->states2.release();
     delete r;
@@ -1114,15 +1119,14 @@ extern "C" int ppm_csp_refine(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const p
     const size_t NN = (size_t)gm.N * gm.N, HW = (size_t)gm.H * gm.W;
     if (int rc = ref->samples.ensure(S_pad)) return rc;
     HIPCHK(hipMemcpyAsync(ref->samples.p, sl.packed.data(), S_pad * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
-    DevBuf<float2> Il, band; DevBuf<float> cw, img; DevBuf<double> d_rows, d_N, d_p, d_tl, d_delta, d_s0, d_g0, d_out;
-    DevBuf<int> d_eval, d_rp, d_rt, d_slot;
-    DevBuf<float> wring; DevBuf<LState> d_states;
+    // scratch of the constrained search lives in the reference handle (grown on demand, freed with it): allocating and freeing
+    // several hundred MB per call cost a third of a call on a 20 k-projection series
+    DevBuf<float2> &Il = ref->c_Il, &band = ref->c_band; DevBuf<float> &cw = ref->c_cw, &img = ref->c_img, &wring = ref->c_wring;
+    DevBuf<double> &d_rows = ref->c_rows, &d_N = ref->c_N, &d_p = ref->c_p, &d_tl = ref->c_tl, &d_delta = ref->c_delta, &d_s0 = ref->c_s0, &d_g0 = ref->c_g0, &d_out = ref->c_out;
+    DevBuf<int> &d_eval = ref->c_eval, &d_rp = ref->c_rp, &d_rt = ref->c_rt, &d_slot = ref->c_slot;
+    DevBuf<LState> &d_states = ref->c_states;
     const bool mode4 = cc->refine_defocus != 0;
     if (mode4 && kind != PPM_CSP_MICROGRAPHS) return fail(-22, "csp: defocus refinement works on tilts (unit = micrographs)");
-    struct Cleanup { std::vector<std::function<void()>> f; ~Cleanup() { for (auto &x : f) x(); } } cleanup;
-    cleanup.f = { [&] { Il.release(); band.release(); cw.release(); img.release(); d_rows.release(); d_N.release(); d_p.release(); d_tl.release();
-                        d_delta.release(); d_s0.release(); d_g0.release(); d_out.release(); d_eval.release(); d_rp.release(); d_rt.release(); d_slot.release();
-                        wring.release(); d_states.release(); } };
     const int CH = (int)std::min<size_t>((size_t)n_proj, std::max<size_t>(64, ((size_t)2 << 30) / (NN * 4 + HW * 8)));
     if (int rc = Il.ensure((size_t)n_proj * S_pad)) return rc;
     if (int rc = cw.ensure((size_t)n_proj * S_pad)) return rc;
