@@ -643,16 +643,20 @@ __global__ void __launch_bounds__(NW * 64) k_insert_bricks(InsertBrickP P) {
         const float a0 = S[0] * q.m[0] + S[1] * q.m[2] + S[2] * q.m[4], a1 = S[0] * q.m[1] + S[1] * q.m[3] + S[2] * q.m[5];
         const float b0 = S[3] * q.m[0] + S[4] * q.m[2] + S[5] * q.m[4], b1 = S[3] * q.m[1] + S[4] * q.m[3] + S[5] * q.m[5];
         const float c0 = S[6] * q.m[0] + S[7] * q.m[2] + S[8] * q.m[4], c1 = S[6] * q.m[1] + S[7] * q.m[3] + S[8] * q.m[5];
+        // sample position along one axis: explicit rounding steps, so that the hit test and the evaluation — two places the compiler
+        // is free to contract differently — agree to the last bit on which brick owns a sample
+        auto pos = [](float u, float v, int kx, int ky) { return __fmaf_rn(u, (float)kx, __fmul_rn(v, (float)ky)); };
         // EVALUATE one queued sample per lane
         auto evaluate = [&](unsigned e, bool on) {
             if (!on) return;
             const int kx = (int)(e & 0xffffu), ky = (int)(e >> 16) - 512;
             const float k2 = (float)(kx * kx + ky * ky);
-            float X = a0 * kx + a1 * ky, Y = b0 * kx + b1 * ky, Z = c0 * kx + c1 * ky;
+            float X = pos(a0, a1, kx, ky), Y = pos(b0, b1, kx, ky), Z = pos(c0, c1, kx, ky);       // bit-identical to the hit test's position
             const bool refl = X < 0.f;
             if (refl) { X = -X; Y = -Y; Z = -Z; }
             const float xf = floorf(X), yf = floorf(Y), zf = floorf(Z);
             const int x0 = (int)xf - x_lo, y0 = (int)yf - y_lo, z0 = (int)zf - z_lo;      // brick-local base tap
+            if ((unsigned)x0 >= (unsigned)BE || (unsigned)y0 >= (unsigned)BE || (unsigned)z0 >= (unsigned)BE) return;   // cannot happen (same arithmetic as the test); never write outside the brick
             const float fx = X - xf, fy = Y - yf, fz = Z - zf;
             const float cv = ctf_eval_fast(q.ctf, kx, ky);
             float w = q.w0 * (q.wexp != 0.f ? expf(q.wexp * k2) : 1.f);
@@ -723,7 +727,7 @@ __global__ void __launch_bounds__(NW * 64) k_insert_bricks(InsertBrickP P) {
                 r = r > 63 ? 63 : r;
                 const int kx = __shfl(base, r, 64) + j, ky = ky0 + r;
                 const float k2 = (float)(kx * kx + ky * ky);
-                float X = a0 * kx + a1 * ky, Y = b0 * kx + b1 * ky, Z = c0 * kx + c1 * ky;
+                float X = pos(a0, a1, kx, ky), Y = pos(b0, b1, kx, ky), Z = pos(c0, c1, kx, ky);
                 const bool refl = X < 0.f;
                 if (refl) { X = -X; Y = -Y; Z = -Z; }
                 const int x0 = (int)floorf(X) - x_lo, y0 = (int)floorf(Y) - y_lo, z0 = (int)floorf(Z) - z_lo;
