@@ -49,8 +49,12 @@ enum {
     PPM_POS = 0, PPM_PSI = 1, PPM_THETA = 2, PPM_PHI = 3, PPM_XSHIFT = 4, PPM_YSHIFT = 5,
     PPM_DF1 = 6, PPM_DF2 = 7, PPM_ANGAST = 8, PPM_PSHIFT = 9, PPM_FILM = 10, PPM_OCC = 11,
     PPM_LOGP = 12, PPM_SIGMA = 13, PPM_SCORE = 14, PPM_PIXEL = 15, PPM_VOLTAGE = 16,
-    PPM_CS = 17, PPM_AMP = 18, PPM_PIND = 26, PPM_TIND = 27
+    PPM_CS = 17, PPM_AMP = 18, PPM_BTX = 19, PPM_BTY = 20, PPM_PIND = 26, PPM_TIND = 27
 };
+/* BEAM_TILT_X / BEAM_TILT_Y (milliradians): every particle spectrum is multiplied by exp(-i phi), phi(s) = 2 pi Cs lambda^2 |s|^2 (s . b), when
+ * it is prepared (k_prep), i.e. the model is compared with, and the reconstruction receives, the image with the beam-tilt phase error
+ * removed.  The sign follows the usual convention (the tilted beam multiplies the image transform by exp(+i phi)); the absent programs'
+ * own convention is not visible: unpinned like the rest of the arithmetic. */
 
 #define PPM_MAX_SHIFT_STEPS 8 /* half-width of the global-search shift window, in search-grid steps */
 #define PPM_MAX_TOP_HITS 64

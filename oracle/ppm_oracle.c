@@ -323,12 +323,20 @@ static double ctf_eval(const ctf_t *c, int kx, int ky) {
 /* `disc` (may be NULL): centre (pixels from the box centre) and radius (pixels) of the mask disc when it is not the centred one
  * of radius mask_radius_A — the focus mask of answers 29-32 / 44 (frealign.py:3846-3849, :3958); the background statistics
  * keep using mask_radius_A. */
-static void preprocess_disc(const float *img, const geom_t *g, double mask_radius_A, double falloff_A,
+/* `row` (may be NULL): BEAM_TILT_X / Y (mrad), voltage and Cs of the particle: its spectrum is multiplied by exp(-i phi),
+ * phi(s) = 2 pi Cs lambda^2 |s|^2 (s . b) (include/ppm.h). */
+static void preprocess_row(const float *img, const geom_t *g, double mask_radius_A, double falloff_A,
                        int normalize, int invert, int do_mask, int whiten, double rband, cpx *out,
-                       double *wring /* B+2 ring weights 1/sqrt(P_b), or NULL */, const double *disc) {
+                       double *wring /* B+2 ring weights 1/sqrt(P_b), or NULL */, const double *disc, const double *row) {
     int N = g->N;
     double Rm = mask_radius_A / g->a, w = falloff_A / g->a;
     const double mcx = disc ? disc[0] : 0.0, mcy = disc ? disc[1] : 0.0, mrad = disc ? disc[2] : Rm;
+    double btx = 0, bty = 0;
+    if (row) {
+        const double v = row[PPM_VOLTAGE] * 1000.0, lam = 12.2639 / sqrt(v + 0.97845e-6 * v * v), na = (double)N * g->a;
+        const double cc = 2.0 * ORC_PI * row[PPM_CS] * 1e7 * lam * lam * 1e-3 / (na * na * na);
+        btx = cc * row[PPM_BTX]; bty = cc * row[PPM_BTY];
+    }
     if (w < 1e-3) w = 1e-3;
     double s1 = 0, s2 = 0; long cnt = 0;
     for (int y = 0; y < N; y++) for (int x = 0; x < N; x++) {
@@ -361,6 +369,11 @@ static void preprocess_disc(const float *img, const geom_t *g, double mask_radiu
         double k2 = (double)kx * kx + (double)ky * ky;
         if (k2 >= r2 || k2 == 0) { o->re = o->im = 0; continue; }   /* DC dropped */
         cpx v = f[(size_t)((ky + N) % N) * N + kx];
+        if (btx != 0 || bty != 0) {
+            const double ph = k2 * (kx * btx + ky * bty), cr = cos(ph), ci = sin(ph);
+            const double vr = v.re * cr + v.im * ci, vi = v.im * cr - v.re * ci;
+            v.re = (float)vr; v.im = (float)vi;
+        }
         double sg = ((kx + ky) & 1) ? -inv : inv;
         o->re = (float)(v.re * sg); o->im = (float)(v.im * sg);
         int b = (int)floor(sqrt(k2));
@@ -385,9 +398,13 @@ static void preprocess_disc(const float *img, const geom_t *g, double mask_radiu
     free(pw); free(pc); free(f);
 }
 
+static void preprocess_disc(const float *img, const geom_t *g, double mask_radius_A, double falloff_A,
+                       int normalize, int invert, int do_mask, int whiten, double rband, cpx *out, double *wring, const double *disc) {
+    preprocess_row(img, g, mask_radius_A, falloff_A, normalize, invert, do_mask, whiten, rband, out, wring, disc, NULL);
+}
 static void preprocess(const float *img, const geom_t *g, double mask_radius_A, double falloff_A,
                        int normalize, int invert, int do_mask, int whiten, double rband, cpx *out, double *wring) {
-    preprocess_disc(img, g, mask_radius_A, falloff_A, normalize, invert, do_mask, whiten, rband, out, wring, NULL);
+    preprocess_row(img, g, mask_radius_A, falloff_A, normalize, invert, do_mask, whiten, rband, out, wring, NULL, NULL);
 }
 
 /* ------------------------------------------------------------------ local score */
@@ -666,14 +683,14 @@ int orc_refine_batch(void *refp, const ppm_refine_cfg *cfg, const float *images,
         cpx *I = (cpx *)malloc(nb * sizeof(cpx));
         double *wr = (double *)malloc((g.B + 2) * sizeof(double)), *wrs = wr, *wrsown = NULL;
         double disc[3]; const int focus_on = focus_disc(cfg, &g, row, disc);
-        preprocess_disc(img, &g, cfg->mask_radius, fall, cfg->normalize, cfg->invert, 1, 1, g.r_hi, I, wr, focus_on ? disc : NULL);
+        preprocess_row(img, &g, cfg->mask_radius, fall, cfg->normalize, cfg->invert, 1, 1, g.r_hi, I, wr, focus_on ? disc : NULL, row);
         long nev = 0; double sev = 0;
         cstate_t best; memset(&best, 0, sizeof(best));
         if (cfg->global_search) {
             cpx *Is = I, *Isown = NULL;
             if (!focus_on && cfg->search_mask_radius > 0 && cfg->search_mask_radius != cfg->mask_radius) {
                 Isown = (cpx *)malloc(nb * sizeof(cpx)); wrsown = (double *)malloc((g.B + 2) * sizeof(double));
-                preprocess(img, &g, cfg->search_mask_radius, fall, cfg->normalize, cfg->invert, 1, 1, g.r_hi, Isown, wrsown);
+                preprocess_row(img, &g, cfg->search_mask_radius, fall, cfg->normalize, cfg->invert, 1, 1, g.r_hi, Isown, wrsown, NULL, row);
                 Is = Isown; wrs = wrsown;
             }
             cpx *Wp = (cpx *)malloc(nb * sizeof(cpx)); float *C2 = (float *)malloc(nb * sizeof(float));
@@ -774,7 +791,7 @@ int orc_score_batch(void *refp, const ppm_refine_cfg *cfg, const float *images, 
         cpx *I = (cpx *)malloc(nb * sizeof(cpx));
         double *wr = (double *)malloc((g.B + 2) * sizeof(double));
         double disc[3]; const int focus_on = focus_disc(cfg, &g, row, disc);
-        preprocess_disc(images + (size_t)ip * g.N * g.N, &g, cfg->mask_radius, fall, cfg->normalize, cfg->invert, 1, 1, g.r_hi, I, wr, focus_on ? disc : NULL);
+        preprocess_row(images + (size_t)ip * g.N * g.N, &g, cfg->mask_radius, fall, cfg->normalize, cfg->invert, 1, 1, g.r_hi, I, wr, focus_on ? disc : NULL, row);
         double M[9], sh[2] = { row[PPM_XSHIFT] / g.a, row[PPM_YSHIFT] / g.a };
         euler_full(row[PPM_PSI], row[PPM_THETA], row[PPM_PHI], M);
         scores[ip] = score_local(r, &g, &c, I, wr, g.r_hi, M, sh);
@@ -918,7 +935,7 @@ int orc_insert_batch(float *acc, long *counts, const ppm_recon_cfg *cfg, const c
         int h = (int)(((key % 2) + 2) % 2);   /* odd keys -> half index 1, even -> 0 */
         float *A = acc + (size_t)h * half_sz;
         counts[h]++;
-        preprocess(images + (size_t)ip * N * N, &g, cfg->mask_radius, 20.0, cfg->normalize, cfg->invert, 0, 0, g.r_hi, I, NULL);
+        preprocess_row(images + (size_t)ip * N * N, &g, cfg->mask_radius, 20.0, cfg->normalize, cfg->invert, 0, 0, g.r_hi, I, NULL, NULL, row);
         ctf_t c; ctf_init(&c, row, N, a);
         double m[6]; euler_cols(row[PPM_PSI], row[PPM_THETA], row[PPM_PHI], m);
         double sx = row[PPM_XSHIFT] / a, sy = row[PPM_YSHIFT] / a, na2 = (double)N * a * N * a;
@@ -1184,7 +1201,7 @@ int orc_csp_refine(void *refp, const ppm_refine_cfg *cfg, const ppm_csp_cfg *cc,
 #pragma omp parallel for schedule(dynamic, 1)
         for (int j = 0; j < n_proj; j++) {
             c.I[j] = (cpx *)malloc(nb * sizeof(cpx)); c.wr[j] = (double *)malloc((g.B + 2) * sizeof(double));
-            preprocess(images + (size_t)j * g.N * g.N, &g, cfg->mask_radius, fall, cfg->normalize, cfg->invert, 1, 1, g.r_hi, c.I[j], c.wr[j]);
+            preprocess_row(images + (size_t)j * g.N * g.N, &g, cfg->mask_radius, fall, cfg->normalize, cfg->invert, 1, 1, g.r_hi, c.I[j], c.wr[j], NULL, rows + (size_t)j * PPM_NCOL);
             ctf_init(&c.ctf[j], rows + (size_t)j * PPM_NCOL, g.N, g.a);
         }
     }

@@ -126,8 +126,8 @@ __global__ void __launch_bounds__(PT, MINW) k_prep(PrepP P) {
     float *ringpw = (float *)(ringc + (B + 2));       // [B+2] ring weights
     double *red = (double *)(((uintptr_t)(ringpw + (B + 2)) + 15) & ~(uintptr_t)15);  // [PW*4 + PW]
     float *stat = (float *)(red + PW * 5);            // mu, scale, fixed-point scale, nI partials
-    float *fmask = stat + 4 + PW;                     // mask disc of this particle: centre (pixels from the box centre) and radius
-    float2 *tw_s = (float2 *)(stat + 8 + PW);         // [N] twiddles and [N] staging positions of the FFT plan, kept in LDS
+    float *fmask = stat + 4 + PW;                     // mask disc of this particle: centre (pixels from the box centre) and radius; [4], [5]: beam-tilt phase coefficients
+    float2 *tw_s = (float2 *)(stat + 12 + PW);        // [N] twiddles and [N] staging positions of the FFT plan, kept in LDS
     unsigned short *perm_s = (unsigned short *)(tw_s + N);
     unsigned short *iperm_s = perm_s + N;             // inverse: the sample that is staged at LDS position d
     for (int i = tid; i < N; i += PT) {
@@ -198,6 +198,12 @@ __global__ void __launch_bounds__(PT, MINW) k_prep(PrepP P) {
             int e2 = 0; (void)frexp(E > 1e-30 ? 4.0 * E : 1.0, &e2);
             int ex = 60 - e2; ex = ex > 120 ? 120 : (ex < -120 ? -120 : ex);
             stat[2] = ldexpf(1.f, ex);
+            {   // beam tilt (milliradians): phi(k) = k^2 (kx c_x + ky c_y) with c = 2 pi Cs lambda^2 b 1e-3 / (N a)^3
+                const double *row = P.rows + (size_t)p * PPM_NCOL;
+                const double v = row[PPM_VOLTAGE] * 1000.0, lam = 12.2639 / sqrt(v + 0.97845e-6 * v * v), na = (double)N * (double)P.a;
+                const double cc = 2.0 * 3.14159265358979323846 * row[PPM_CS] * 1e7 * lam * lam * 1e-3 / (na * na * na);
+                fmask[4] = (float)(cc * row[PPM_BTX]); fmask[5] = (float)(cc * row[PPM_BTY]);
+            }
             // mask disc: centred with radius Rm, or around the projection of the focus sphere at the row's pose
             fmask[0] = 0.f; fmask[1] = 0.f; fmask[2] = P.Rm;
             if (P.focus[3] > 0.f) {
@@ -217,6 +223,8 @@ __global__ void __launch_bounds__(PT, MINW) k_prep(PrepP P) {
     const float mu = stat[0], sc = stat[1];
     const float qscale = stat[2];
     const float mcx = fmask[0], mcy = fmask[1], mrad = fmask[2];
+    const float btx = fmask[4], bty = fmask[5];
+    const bool beam_tilt = btx != 0.f || bty != 0.f;
     for (int i = tid; i < B + 2; i += PT) { ringq[i] = 0ull; ringc[i] = 0u; }
 
     const float wf = P.wfall < 1e-3f ? 1e-3f : P.wfall;
@@ -352,6 +360,11 @@ __global__ void __launch_bounds__(PT, MINW) k_prep(PrepP P) {
                 float2 v = T[c * TS + (ky < 0 ? ky + N : ky)];
                 float sg = ((kx + ky) & 1) ? -invN : invN;
                 o = make_float2(v.x * sg, v.y * sg);
+                if (beam_tilt) {                                 // remove the beam-tilt phase error: x exp(-i phi)
+                    float sn, cs;
+                    sincosf(k2 * ((float)kx * btx + (float)ky * bty), &sn, &cs);
+                    o = make_float2(o.x * cs + o.y * sn, o.y * cs - o.x * sn);
+                }
                 omax = fmaxf(omax, fmaxf(fabsf(o.x), fabsf(o.y)));
                 int b = (int)floorf(sqrtf(k2));
                 float al = kx == 0 ? 1.f : 2.f;

@@ -270,7 +270,7 @@ static int launch_prep(const float *d_images, const double *d_rows, int n_img, c
     if (const char *e = getenv("PPM_PREP_PT")) { const int v = atoi(e); if (v == 512 || v == 1024 || v == 256) PT = v; }
     const int occ3 = !(getenv("PPM_PREP_OCC") && atoi(getenv("PPM_PREP_OCC")) == 2);
     const size_t budget = (PT == 1024 ? 160 : (PT == 256 ? (getenv("PPM_PREP_LDS") ? atoi(getenv("PPM_PREP_LDS")) : (occ3 ? 40 : 52)) : 80)) * 1024;
-    const size_t lds_fixed = (size_t)(gm.B + 2) * 16 + 16 + 5 * (PT / 64) * sizeof(double) + (8 + PT / 64) * sizeof(float) + (size_t)gm.N * 12 + 16;
+    const size_t lds_fixed = (size_t)(gm.B + 2) * 16 + 16 + 5 * (PT / 64) * sizeof(double) + (12 + PT / 64) * sizeof(float) + (size_t)gm.N * 12 + 16;
     P.fast256 = (gm.N == 256 && !getenv("PPM_PREP_GENERIC")) ? 1 : 0;
     P.TS = P.fast256 ? 273 : gm.N + 1; P.WS = P.fast256 ? 272 : gm.N;
     P.L = std::max(1, std::min(8 * PT / gm.N, gm.N / 2));

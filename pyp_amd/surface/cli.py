@@ -68,8 +68,6 @@ def _select(rows, first, last):
     sel = np.where((pos >= first) & (pos <= last))[0]
     if len(sel) == 0:
         _die(f"ERROR: no rows with POSITION_IN_STACK in {first}..{last}")
-    if np.any(rows[sel][:, [C["BEAM_TILT_X"], C["BEAM_TILT_Y"]]] != 0):
-        _die("ERROR: rows carry a beam tilt (BEAM_TILT_X / BEAM_TILT_Y); the beam-tilt phase term of the CTF is not built")
     return sel
 
 

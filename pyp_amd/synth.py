@@ -223,6 +223,14 @@ def render_rows(vol, rows, pixel=1.0, snr=0.05, seed_noise=SEED_NOISE, device="c
         sy = torch.as_tensor(sh[b0:b1, 1], device=dev, dtype=torch.float32).view(-1, 1, 1)
         ramp = torch.exp(-2j * math.pi * (kx[None] * sx + ky[None] * sy) / n)
         spec = spec * ctf * ramp
+        bt = rows[b0:b1][:, [C["BEAM_TILT_X"], C["BEAM_TILT_Y"]]]
+        if np.any(bt != 0):     # tilted beam (mrad): the image transform is multiplied by exp(+i phi), phi = 2 pi Cs lambda^2 |s|^2 (s . b)
+            v = kv * 1000.0
+            lam = 12.2639 / math.sqrt(v + 0.97845e-6 * v * v)
+            cc = 2.0 * math.pi * cs_mm * 1e7 * lam * lam * 1e-3 / (n * pixel) ** 3
+            bx = torch.as_tensor(bt[:, 0] * cc, device=dev, dtype=torch.float32).view(-1, 1, 1)
+            by = torch.as_tensor(bt[:, 1] * cc, device=dev, dtype=torch.float32).view(-1, 1, 1)
+            spec = spec * torch.exp(1j * (kx * kx + ky * ky)[None] * (kx[None] * bx + ky[None] * by))
         img = torch.fft.fftshift(torch.fft.ifft2(torch.fft.ifftshift(spec, dim=(-2, -1))), dim=(-2, -1)).real
         clean[b0:b1] = img
     sig_var = clean.var(dim=(-2, -1), keepdim=True).mean()

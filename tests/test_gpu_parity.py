@@ -96,6 +96,38 @@ def test_matching_projections_match_oracle_and_an_independent_projector(d64, H, 
     assert np.allclose(neg, -got[:2], atol=1e-6)
 
 
+def test_beam_tilt_matches_oracle(H, O):
+    """BEAM_TILT_X / Y columns: k_prep removes the phase term exp(i phi) from every particle spectrum; scores, refinement and
+    insertion then see the corrected image.  HIP = oracle, and the rows' tilt restores the untilted scores."""
+    n, px = 64, 1.5
+    vol = synth.phantom(n)
+    _, _, rows = synth.make_dataset(n, 8, pixel=px, snr=0, vol=vol)
+    C = synth.cistem.COL
+    tilted = rows.copy(); tilted[:, C["BEAM_TILT_X"]] = 1.5; tilted[:, C["BEAM_TILT_Y"]] = -1.0
+    imgs_t = synth.render_rows(vol, tilted, px, snr=0).numpy()
+    g, o = H.Reference(vol, n / 2), O.Reference(vol, n / 2)
+    c = RefineCfg.make(box=n, pixel_size=px, mask_radius=0.4 * n * px, res_high=2.2 * px, global_search=0, local_refine=0)
+    want = O.score_batch(o, c, imgs_t, tilted)
+    got = g.refine(c, imgs_t, tilted)[:, 14] / 100.0
+    assert np.abs(want - got).max() < 2e-5
+    ignored = g.refine(c, imgs_t, rows)[:, 14] / 100.0
+    assert (got - ignored).min() > 0.02                                  # the term matters at 1.5 A / pixel and 1.8 mrad
+    start = synth.perturb_rows(tilted, 2.0, 1.0, 2.0)
+    cl = RefineCfg.make(box=n, pixel_size=px, mask_radius=0.4 * n * px, res_high=2.2 * px, global_search=0, res_signed_cc=30.0)
+    w2, _ = O.refine_batch(o, cl, imgs_t, start)
+    g2 = g.refine(cl, imgs_t, start)
+    assert synth.angular_error_deg(w2, g2).max() < ANG_TOL_DEG and synth.shift_error_px(w2, g2, px).max() < SHIFT_TOL_PX
+    # insertion receives the corrected spectra too
+    rc = ReconCfg(box=n, pixel_size=px, res_limit=2 * px, normalize=1, split_by_pind=0, mask_radius=0.4 * n * px)
+    acc_o = np.zeros(O.accum_floats(n), dtype=np.float32); cnt = np.zeros(2, dtype=np.int64)
+    O.insert_batch(acc_o, cnt, rc, "C1", imgs_t, tilted)
+    acc = H.Accumulator(n, px, "C1")
+    acc.insert(rc, imgs_t, tilted)
+    got_acc = acc.download()
+    acc.close()
+    assert np.linalg.norm(got_acc - acc_o) / np.linalg.norm(acc_o) < 1e-4
+
+
 def test_local_refinement_matches_oracle(d64, H, O):
     vol, imgs, rows, g, o = d64
     start = synth.perturb_rows(rows, 2.0, 1.0, 2.0)

@@ -253,14 +253,13 @@ def test_executables_fail_loudly_without_inputs(tmp_path):
     assert r.returncode != 0 and "ERROR" in r.stdout
 
 
-def test_beam_tilt_rows_are_refused(tmp_path):
-    """BEAM_TILT_X / Y columns (cistem_star_file.py:596-628) would need the beam-tilt phase term: refused, not ignored."""
+def test_beam_tilt_rows_are_accepted(tmp_path):
+    """BEAM_TILT_X / Y columns (cistem_star_file.py:596-628) are honoured by the library (phase term removed in k_prep): rows that
+    carry them pass the range selection like any other."""
     from pyp_amd.formats import cistem
     rows = cistem.default_rows(4, 2.0, 300.0, 2.7, 0.07)
-    assert len(cli._select(rows, 1, 4)) == 4
     rows[2, cistem.COL["BEAM_TILT_X"]] = 0.3
-    with pytest.raises(SystemExit):
-        cli._select(rows, 1, 4)
+    assert len(cli._select(rows, 1, 4)) == 4
 
 
 def test_gpu_lock_serialises_processes(tmp_path, monkeypatch):
