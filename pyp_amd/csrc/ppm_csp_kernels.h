@@ -111,4 +111,16 @@ __global__ void __launch_bounds__(256, 4) k_csp_eval(CspEvalP P) {
     if (tid < ncand) P.out[(size_t)blockIdx.x * ncand + tid] = score[cslot[tid]];
 }
 
+// Mean score of every (active unit, candidate) over the unit's evaluated rows: the rows of a unit are consecutive in the evaluation
+// list (uoff[a] .. uoff[a + 1]) and are added in that order, like the host loop this replaces (2 MB of per-row scores per sweep
+// stay on the device; 50 KB of means go back).
+__global__ void k_csp_unit_means(const double *__restrict__ out, const int *__restrict__ uoff, int n_units, int ncand, double *__restrict__ mean) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_units * ncand) return;
+    const int a = i / ncand, c = i - a * ncand, lo = uoff[a], hi = uoff[a + 1];
+    double s = 0;
+    for (int r = lo; r < hi; r++) s += out[(size_t)r * ncand + c];
+    mean[i] = s / (double)(hi - lo);
+}
+
 }  // namespace ppm

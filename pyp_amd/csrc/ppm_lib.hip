@@ -168,7 +168,7 @@ struct ppm_ref {
     DevBuf<float> images, wring, cw, C2, nP, nI, cc, mats, ddef;
     // constrained search (ppm_csp_refine)
     DevBuf<float2> c_Il, c_band; DevBuf<float> c_cw, c_img, c_wring; DevBuf<double> c_rows, c_N, c_p, c_tl, c_delta, c_s0, c_g0, c_out;
-    DevBuf<int> c_eval, c_rp, c_rt, c_slot; DevBuf<LState> c_states;
+    DevBuf<int> c_eval, c_rp, c_rt, c_slot, c_uoff; DevBuf<LState> c_states; DevBuf<double> c_mean;
     DevBuf<float2> band, Il, Wp, bank, twN;
     DevBuf<float4> rowtw;            // k_global's row-pair twiddles for this reference's current search grid
     DevBuf<int> sh;
@@ -442,7 +442,7 @@ void ppm_reference_destroy(ppm_ref_t *r) {
     r->rows_in.release(); r->rows_out.release(); r->dir_theta.release(); r->dir_phi.release();
     r->images.release(); r->wring.release(); r->cw.release(); r->C2.release(); r->nP.release(); r->nI.release();
     r->c_Il.release(); r->c_band.release(); r->c_cw.release(); r->c_img.release(); r->c_wring.release(); r->c_rows.release(); r->c_N.release(); r->c_p.release(); r->c_tl.release();
-    r->c_delta.release(); r->c_s0.release(); r->c_g0.release(); r->c_out.release(); r->c_eval.release(); r->c_rp.release(); r->c_rt.release(); r->c_slot.release(); r->c_states.release(); r->cc.release(); r->mats.release(); r->ddef.release();
+    r->c_delta.release(); r->c_s0.release(); r->c_g0.release(); r->c_out.release(); r->c_eval.release(); r->c_rp.release(); r->c_rt.release(); r->c_slot.release(); r->c_states.release(); r->c_uoff.release(); r->c_mean.release(); r->cc.release(); r->mats.release(); r->ddef.release();
     r->band.release(); r->Il.release(); r->Wp.release(); r->bank.release(); r->twN.release(); r->rowtw.release(); r->sh.release(); r->samples.release();
     r->hits.release(); r->states.release(); r->states2.release();
     delete r;
@@ -1226,34 +1226,39 @@ extern "C" int ppm_csp_refine(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const p
     EP.kind = kind; EP.eval_rows = d_eval.p; EP.row_part = d_rp.p; EP.row_tilt = d_rt.p; EP.unit_slot = d_slot.p;
     EP.Nmat = d_N.p; EP.pshift = d_p.p; EP.tl = d_tl.p; EP.delta = d_delta.p; EP.s0 = d_s0.p; EP.g0 = d_g0.p; EP.out = d_out.p;
     std::vector<double> hdelta, hout;
-    // one sweep: `ncand` candidates per unit (hdelta laid out [slot][ncand][6]) over `rows_list`; scores -> hout [row][ncand]
-    auto sweep = [&](const std::vector<int> &rows_list, int ncand, double rband) -> int {
+    // evaluation list of the search (the usable rows of the active units, grouped by unit) and the units' offsets in it: uploaded once
+    std::vector<int> uoff(active.size() + 1, 0);
+    for (size_t a = 0; a < active.size(); a++) { int n = 0; for (int j : urows[active[a]]) n += usable[j] ? 1 : 0; uoff[a + 1] = uoff[a] + n; }
+    if (int rc = ref->c_uoff.ensure(uoff.size())) return rc;
+    if (int rc = ref->c_mean.ensure(std::max<size_t>(active.size() * ncand_max, 1))) return rc;
+    HIPCHK(hipMemcpyAsync(ref->c_uoff.p, uoff.data(), uoff.size() * sizeof(int), hipMemcpyHostToDevice, g.stream));
+    const std::vector<int> *uploaded_list = nullptr;
+    // one sweep: `ncand` candidates per unit (hdelta laid out [slot][ncand][6]) over `rows_list`.  unit_means: the per-unit means of
+    // the scores -> `means` [active unit][ncand] (reduced on the device); otherwise the per-row scores -> hout [row][ncand]
+    auto sweep = [&](const std::vector<int> &rows_list, int ncand, double rband, std::vector<double> *means) -> int {
         HIPCHK(hipMemcpyAsync(d_delta.p, hdelta.data(), (size_t)n_slots * ncand * 6 * sizeof(double), hipMemcpyHostToDevice, g.stream));
-        HIPCHK(hipMemcpyAsync(d_eval.p, rows_list.data(), rows_list.size() * sizeof(int), hipMemcpyHostToDevice, g.stream));
+        if (uploaded_list != &rows_list) {
+            HIPCHK(hipMemcpyAsync(d_eval.p, rows_list.data(), rows_list.size() * sizeof(int), hipMemcpyHostToDevice, g.stream));
+            uploaded_list = &rows_list;
+        }
         EP.ncand = ncand; EP.S_used = prefix_of(rband); EP.rmax2 = (float)(rband * rband);
         {
             ProfScope ps(PPM_K_LOCAL);
             hipLaunchKernelGGL(k_csp_eval, dim3((unsigned)rows_list.size()), dim3(256), ring_lds_bytes(4, kMaxCand, nrings), g.stream, EP);
         }
-        HIPCHK(hipGetLastError());
-        hout.resize(rows_list.size() * (size_t)ncand);
-        HIPCHK(hipMemcpyAsync(hout.data(), d_out.p, hout.size() * sizeof(double), hipMemcpyDeviceToHost, g.stream));
+        if (means) {
+            const int nm = (int)active.size() * ncand;
+            hipLaunchKernelGGL(k_csp_unit_means, dim3((nm + 255) / 256), dim3(256), 0, g.stream, d_out.p, ref->c_uoff.p, (int)active.size(), ncand, ref->c_mean.p);
+            HIPCHK(hipGetLastError());
+            means->resize((size_t)nm);
+            HIPCHK(hipMemcpyAsync(means->data(), ref->c_mean.p, (size_t)nm * sizeof(double), hipMemcpyDeviceToHost, g.stream));
+        } else {
+            HIPCHK(hipGetLastError());
+            hout.resize(rows_list.size() * (size_t)ncand);
+            HIPCHK(hipMemcpyAsync(hout.data(), d_out.p, hout.size() * sizeof(double), hipMemcpyDeviceToHost, g.stream));
+        }
         HIPCHK(hipStreamSynchronize(g.stream));
         return 0;
-    };
-    // mean over the usable rows of every active unit, rows in eval_rows order (grouped by unit, ascending row index)
-    auto unit_means = [&](int ncand, std::vector<double> &mean) {
-        mean.assign((size_t)active.size() * ncand, 0.0);
-        size_t pos = 0;
-        for (size_t a = 0; a < active.size(); a++) {
-            int n = 0;
-            for (int j : urows[active[a]]) {
-                if (!usable[j]) continue;
-                for (int c = 0; c < ncand; c++) mean[a * ncand + c] += hout[pos * ncand + c];
-                pos++; n++;
-            }
-            for (int c = 0; c < ncand; c++) mean[a * ncand + c] /= n;
-        }
     };
     if (int rc = upload_units()) return rc;
     double ha = ha0, hs = hs0;
@@ -1267,8 +1272,7 @@ extern "C" int ppm_csp_refine(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const p
         hdelta.assign((size_t)n_slots * ncand * 6, 0.0);
         for (size_t a = 0; a < active.size(); a++)
             for (int c = 1; c < ncand; c++) hdelta[((size_t)unit_slot[active[a]] * ncand + c) * 6 + cand_param[c]] = cand_sign[c] * (cand_param[c] < 3 ? ha : hs);
-        if (int rc = sweep(eval_rows, ncand, rband)) return rc;
-        unit_means(ncand, mean);
+        if (int rc = sweep(eval_rows, ncand, rband, &mean)) return rc;
         // parabolic step per unit (same rule as the oracle's loop and k_local's compass iteration)
         std::vector<double> fpv((size_t)active.size() * 6, -1e300), fmv((size_t)active.size() * 6, -1e300);
         for (size_t a = 0; a < active.size(); a++) {
@@ -1295,8 +1299,7 @@ extern "C" int ppm_csp_refine(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const p
         }
         hdelta.assign((size_t)n_slots * 6, 0.0);
         for (size_t a = 0; a < active.size(); a++) std::memcpy(&hdelta[(size_t)unit_slot[active[a]] * 6], &dtrial[a * 6], 6 * sizeof(double));
-        if (int rc = sweep(eval_rows, 1, rband)) return rc;
-        unit_means(1, tmean);
+        if (int rc = sweep(eval_rows, 1, rband, &tmean)) return rc;
         for (size_t a = 0; a < active.size(); a++) {
             CUnit &s = units[active[a]];
             const double f0 = mean[a * ncand], ft = tmean[a];
@@ -1315,7 +1318,7 @@ extern "C" int ppm_csp_refine(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const p
     }
     // ---- final scores of every row of the refined units at the full band; write-back
     hdelta.assign((size_t)std::max(n_slots, 1) * 6, 0.0);
-    if (int rc = sweep(final_rows, 1, gm.r_hi)) return rc;
+    if (int rc = sweep(final_rows, 1, gm.r_hi, nullptr)) return rc;
     std::vector<double> row_score(n_proj, 0.0);
     for (size_t q = 0; q < final_rows.size(); q++) row_score[final_rows[q]] = hout[q];
     for (int u = 0; u < nu_all; u++) {
