@@ -207,6 +207,22 @@ def test_search_grid_variants_match_oracle(H, O, kw):
     assert synth.angular_error_deg(want, got).max() < ANG_TOL_DEG and synth.shift_error_px(want, got, 2.0).max() < SHIFT_TOL_PX, kw
 
 
+def test_grid_search_at_a_band_between_32_and_64_pixels(H, O):
+    """Box 128, search band 45 px: the slice-norm product (k_slice_norms) then covers a partly filled second half of the bank rows,
+    k_global a W table of 92 rows; five particles leave a short last block.  Same grid point and integer shift as the oracle."""
+    vol, imgs, rows = dataset(128, 5, 1.5, 0.1)
+    g, o = H.Reference(vol, 64), O.Reference(vol, 64)
+    c = RefineCfg.make(box=128, pixel_size=1.5, mask_radius=0.4 * 128 * 1.5, res_high=1.5 * 128 / 45.0, res_search=1.5 * 128 / 45.0,
+                       search_range_x=6.0, search_range_y=6.0, res_signed_cc=30.0, local_refine=0, iters_hit=-1, angular_step=20.0)
+    want, counts = O.refine_batch(o, c, imgs, rows)
+    got = g.refine(c, imgs, rows)
+    assert g.last_counts()["n_global"] == counts[0]
+    assert synth.angular_error_deg(want, got).max() < 1e-4
+    step = 128.0 / 128.0       # search grid Ns = 128 for B_s = 44: one pixel per step
+    assert np.array_equal(np.round(want[:, 4:6] / 1.5 / step), np.round(got[:, 4:6] / 1.5 / step))
+    assert np.abs(want[:, 14] - got[:, 14]).max() < 0.01
+
+
 def test_particle_pairs_of_the_grid_search_do_not_couple(H):
     """k_global works on two particles per block (they share the streamed slice rows): a particle's result must not depend on
     its neighbour, on being the odd one of a short last block, or on where the chunk boundaries fall."""
