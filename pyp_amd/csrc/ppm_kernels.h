@@ -96,6 +96,7 @@ struct PrepP {
     float2 *band;  // [n][H*W] unscaled band spectrum (scratch; the final result for insertion)
     int TS, WS;    // line strides of the column buffer T and of the row work buffer Wk (>= 272 on the 256 fast path)
     int fast256;   // N == 256: register-level 16 x 16 FFT (lds_fft256), natural-order staging
+    int inreg;     // N == 256, k_prep<512, 2> only: the half spectrum stays in registers between the two phases (no global scratch)
     unsigned *band_max; // may be null: bits of max |re|, |im| over the band images of the launch (atomicMax; floats >= 0)
     float2 *spill; // [n][N][W] row-transformed half spectrum (global scratch between the row and the column phase)
     float *wring;  // [n][B+2] ring weights 1/sqrt(mean power), may be null
@@ -117,10 +118,12 @@ __global__ void __launch_bounds__(PT, MINW) k_prep(PrepP P) {
     const int p = blockIdx.x;
     const int TS = P.TS, WS = P.WS;                   // padded line strides (bank spread)
     float2 *T = (float2 *)smem;                       // [nc][TS] column chunk, followed by
-    float2 *Wk = T + (size_t)P.nc * TS;               // [L][WS]  the row work buffer
+    constexpr bool kInreg = PT == 512 && MINW == 2;   // the instantiation that carries the scratch-free path
+    const bool inreg = kInreg && P.inreg;
+    float2 *Wk = inreg ? T : T + (size_t)P.nc * TS;   // [L][WS]  the row work buffer (shares T's storage on the scratch-free path)
     // ring power sums in 64-bit fixed point and integer counts: a ds_add_f32 costs ~190 LDS cycles per wave-instruction on
     // gfx950, ds_add_u64 / ds_add_u32 ~8 / ~5 (scripts/micro/lds_atomic_bench.hip)
-    const size_t regionA = (size_t)P.nc * TS + (size_t)P.L * WS;
+    const size_t regionA = inreg ? ((size_t)P.nc * TS > (size_t)P.L * WS ? (size_t)P.nc * TS : (size_t)P.L * WS) : (size_t)P.nc * TS + (size_t)P.L * WS;
     unsigned long long *ringq = (unsigned long long *)(T + regionA);  // [B+2]
     unsigned *ringc = (unsigned *)(ringq + (B + 2));  // [B+2]
     float *ringpw = (float *)(ringc + (B + 2));       // [B+2] ring weights
@@ -141,7 +144,10 @@ __global__ void __launch_bounds__(PT, MINW) k_prep(PrepP P) {
     // ---- statistics of the background (outside the mask radius); whole image if that is empty
     double s1 = 0, s2 = 0, cnt = 0, t1 = 0, t2 = 0;
     const float Rm2 = P.Rm * P.Rm;
-    {
+    // scratch-free path without a mask: (x - mu) sc only changes the DC term (never used) and the scale, so the statistics are
+    // gathered while the pixels are staged for the row transforms and the scale is applied to the band output: one image read
+    const bool fold = inreg && !P.do_mask;
+    if (!fold) {
         const float invNf = 1.0f / (float)N;
         const float4 *img4 = (const float4 *)img;          // N even: N^2 is a multiple of 4, every image starts 16-byte aligned
         constexpr int UR = 8;                              // independent 16-byte loads in flight per thread
@@ -171,6 +177,7 @@ __global__ void __launch_bounds__(PT, MINW) k_prep(PrepP P) {
             s1 += (double)f1; s2 += (double)f2; cnt += (double)fc; t1 += (double)g1; t2 += (double)g2;
         }
     }
+    auto finish_stats = [&]() {     // block reduction of the partial sums -> stat[0..2] (mean, scale, fixed-point scale) and the mask / beam-tilt constants
     s1 = wave_sum_d(s1); s2 = wave_sum_d(s2); cnt = wave_sum_d(cnt); t1 = wave_sum_d(t1); t2 = wave_sum_d(t2);
     if ((tid & 63) == 0) { int w = tid >> 6; red[w * 4] = s1; red[w * 4 + 1] = s2; red[w * 4 + 2] = cnt; red[w * 4 + 3] = t1; }
     __syncthreads();
@@ -220,16 +227,120 @@ __global__ void __launch_bounds__(PT, MINW) k_prep(PrepP P) {
         }
         __syncthreads();
     }
-    const float mu = stat[0], sc = stat[1];
-    const float qscale = stat[2];
-    const float mcx = fmask[0], mcy = fmask[1], mrad = fmask[2];
-    const float btx = fmask[4], bty = fmask[5];
-    const bool beam_tilt = btx != 0.f || bty != 0.f;
+    };
+    if (!fold) finish_stats();
+    float mu = fold ? 0.f : stat[0], sc = fold ? 1.f : stat[1], qscale = fold ? 1.f : stat[2], oscale = 1.f;    // fold: set after the row passes
+    float mcx = fold ? 0.f : fmask[0], mcy = fold ? 0.f : fmask[1], mrad = fold ? 0.f : fmask[2];
+    float btx = fold ? 0.f : fmask[4], bty = fold ? 0.f : fmask[5];
+    bool beam_tilt = btx != 0.f || bty != 0.f;
     for (int i = tid; i < B + 2; i += PT) { ringq[i] = 0ull; ringc[i] = 0u; }
 
     const float wf = P.wfall < 1e-3f ? 1e-3f : P.wfall;
     float2 *bandp = P.band + (size_t)p * H * W;
     float2 *sp = P.spill + (size_t)p * N * W;         // [N][W] half spectrum after the row pass (global scratch, L2-resident)
+    float omax = 0.f;
+    // band output of `ncol` transformed columns starting at c0 (in T): origin to the box centre, 1 / N, beam-tilt phase, ring power sums
+    auto emit = [&](int c0, int ncol) {
+        const float inv_ncol = 1.0f / (float)ncol, invN = 1.f / (float)N;
+        for (int i = tid; i < ncol * H; i += PT) {
+            const int row = fast_div(i, ncol, inv_ncol), c = i - row * ncol, ky = row - B, kx = c0 + c;
+            float k2 = (float)(kx * kx + ky * ky);
+            float2 o = make_float2(0.f, 0.f);
+            if (k2 < P.r_hi2 && k2 > 0.f) {
+                float2 v = T[c * TS + (ky < 0 ? ky + N : ky)];
+                float sg = ((kx + ky) & 1) ? -invN * oscale : invN * oscale;
+                o = make_float2(v.x * sg, v.y * sg);
+                if (beam_tilt) {                                 // remove the beam-tilt phase error: x exp(-i phi)
+                    float sn, cs;
+                    sincosf(k2 * ((float)kx * btx + (float)ky * bty), &sn, &cs);
+                    o = make_float2(o.x * cs + o.y * sn, o.y * cs - o.x * sn);
+                }
+                omax = fmaxf(omax, fmaxf(fabsf(o.x), fabsf(o.y)));
+                int b = (int)floorf(sqrtf(k2));
+                float al = kx == 0 ? 1.f : 2.f;
+                atomicAdd(&ringq[b], (unsigned long long)__double2ll_rn((double)(al * (o.x * o.x + o.y * o.y)) * (double)qscale));
+                atomicAdd(&ringc[b], kx == 0 ? 1u : 2u);
+            }
+            bandp[row * W + kx] = o;
+        }
+    };
+    auto mask_px = [&](int x, int y) {
+        const float dx = (float)(x - N / 2) - mcx, dy = (float)(y - N / 2) - mcy;
+        const float r = sqrtf(dx * dx + dy * dy);
+        return r >= mrad + 0.5f * wf ? 0.f : (r > mrad - 0.5f * wf ? 0.5f * (1.f + cosf(kPiF * (r - mrad + 0.5f * wf) / wf)) : 1.f);
+    };
+    bool done = false;
+    if constexpr (kInreg) {
+        if (inreg) {
+            // ---- scratch-free path (N = 256, 512 threads): two row passes of 64 row pairs through LDS; thread t then HOLDS column
+            // t & 127 of the half spectrum for the rows 128 pass + 2 ((t >> 7) + 4 it) + {0, 1}: 64 complex values in registers.
+            // The column pass assembles 64 columns at a time in LDS from those registers.  kx = 128 (and everything beyond the
+            // band) is zero in the output, so 128 columns are all that is ever held.
+            float2 holdA[16][2], holdB[16][2];       // pass 0 / pass 1 (two arrays: each small enough to be promoted to registers)
+#pragma unroll
+            for (int pass = 0; pass < 2; pass++) {
+                const int y0 = 128 * pass;
+                lds_barrier();                                   // the previous pass has been read out
+#pragma unroll 2
+                for (int k = 0; k < 8; k++) {                    // 64 row pairs x 64 float4 = 4096 pairs of loads over 512 threads
+                    const int i4 = tid + k * PT, l = i4 >> 6, x = 4 * (i4 & 63), ya = y0 + 2 * l, yb = ya + 1;
+                    const float4 qa = *(const float4 *)(img + ya * N + x), qb = *(const float4 *)(img + yb * N + x);
+                    const float ra[4] = { qa.x, qa.y, qa.z, qa.w }, rb[4] = { qb.x, qb.y, qb.z, qb.w };
+                    float f1 = 0.f, f2 = 0.f, fc = 0.f, g1 = 0.f, g2 = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        float va = (ra[j] - mu) * sc, vb = (rb[j] - mu) * sc;
+                        if (P.do_mask) { va *= mask_px(x + j, ya); vb *= mask_px(x + j, yb); }
+                        Wk[l * WS + x + j] = make_float2(va, vb);
+                        if (fold) {
+                            const float dx = (float)(x + j - N / 2), dya = (float)(ya - N / 2), dyb = dya + 1.f;
+                            g1 += va + vb; g2 = fmaf(va, va, fmaf(vb, vb, g2));
+                            if (dx * dx + dya * dya > Rm2) { f1 += va; f2 = fmaf(va, va, f2); fc += 1.f; }
+                            if (dx * dx + dyb * dyb > Rm2) { f1 += vb; f2 = fmaf(vb, vb, f2); fc += 1.f; }
+                        }
+                    }
+                    if (fold) { s1 += (double)f1; s2 += (double)f2; cnt += (double)fc; t1 += (double)g1; t2 += (double)g2; }
+                }
+                lds_fft256(Wk, 64, WS, tid, PT, tw_s);
+#pragma unroll
+                for (int it = 0; it < 16; it++) {
+                    const int l = (tid >> 7) + 4 * it, kx = tid & 127;
+                    const float2 z = Wk[l * WS + kx], zc = Wk[l * WS + (kx ? N - kx : 0)];
+                    const float2 d = make_float2(z.x - zc.x, z.y + zc.y);
+                    const float2 xa = make_float2(0.5f * (z.x + zc.x), 0.5f * (z.y - zc.y)), xb = make_float2(0.5f * d.y, -0.5f * d.x);
+                    if (pass == 0) { holdA[it][0] = xa; holdA[it][1] = xb; } else { holdB[it][0] = xa; holdB[it][1] = xb; }
+                }
+            }
+            if (fold) {                                          // the statistics are complete: scales for the output
+                lds_barrier();
+                finish_stats();
+                oscale = stat[1]; qscale = stat[2];
+                btx = fmask[4]; bty = fmask[5]; beam_tilt = btx != 0.f || bty != 0.f;
+            }
+            const int ncols = W < 128 ? W : 128;
+            for (int c0 = 0; c0 < ncols; c0 += 64) {
+                const int ncol = ncols - c0 < 64 ? ncols - c0 : 64;
+                lds_barrier();
+                const int kx = tid & 127;
+                if (kx >= c0 && kx < c0 + ncol) {
+#pragma unroll
+                    for (int pass = 0; pass < 2; pass++)
+#pragma unroll
+                        for (int it = 0; it < 16; it++) {
+                            const int y = 128 * pass + 2 * ((tid >> 7) + 4 * it);
+                            T[(kx - c0) * TS + y] = pass == 0 ? holdA[it][0] : holdB[it][0];
+                            T[(kx - c0) * TS + y + 1] = pass == 0 ? holdA[it][1] : holdB[it][1];
+                        }
+                }
+                lds_fft256(T, ncol, TS, tid, PT, tw_s);
+                emit(c0, ncol);
+            }
+            for (int i = tid; i < (W - ncols) * H; i += PT)       // columns the band never reaches (kx = 128)
+                bandp[(i / (W - ncols)) * W + ncols + i % (W - ncols)] = make_float2(0.f, 0.f);
+            done = true;
+        }
+    }
+    if (!done) {
     // ---- row pass: two real rows per complex transform; every row of the half spectrum goes to the scratch
     {
         {
@@ -334,7 +445,6 @@ __global__ void __launch_bounds__(PT, MINW) k_prep(PrepP P) {
         }
     };
     fetch_chunk(0);
-    float omax = 0.f;
     for (int ch = 0; ch < P.nchunks; ch++) {
         const int c0 = ch * P.nc, ncol = (W - c0) < P.nc ? (W - c0) : P.nc;
         const float inv_ncol = 1.0f / (float)ncol;
@@ -351,28 +461,8 @@ __global__ void __launch_bounds__(PT, MINW) k_prep(PrepP P) {
         // ---- column pass
         if (P.fast256) lds_fft256(T, ncol, TS, tid, PT, tw_s);
         else lds_fft(T, P.plan, ncol, TS, false, tid, PT, tw_s);
-        const float invN = 1.f / (float)N;
-        for (int i = tid; i < ncol * H; i += PT) {
-            const int row = fast_div(i, ncol, inv_ncol), c = i - row * ncol, ky = row - B, kx = c0 + c;
-            float k2 = (float)(kx * kx + ky * ky);
-            float2 o = make_float2(0.f, 0.f);
-            if (k2 < P.r_hi2 && k2 > 0.f) {
-                float2 v = T[c * TS + (ky < 0 ? ky + N : ky)];
-                float sg = ((kx + ky) & 1) ? -invN : invN;
-                o = make_float2(v.x * sg, v.y * sg);
-                if (beam_tilt) {                                 // remove the beam-tilt phase error: x exp(-i phi)
-                    float sn, cs;
-                    sincosf(k2 * ((float)kx * btx + (float)ky * bty), &sn, &cs);
-                    o = make_float2(o.x * cs + o.y * sn, o.y * cs - o.x * sn);
-                }
-                omax = fmaxf(omax, fmaxf(fabsf(o.x), fabsf(o.y)));
-                int b = (int)floorf(sqrtf(k2));
-                float al = kx == 0 ? 1.f : 2.f;
-                atomicAdd(&ringq[b], (unsigned long long)__double2ll_rn((double)(al * (o.x * o.x + o.y * o.y)) * (double)qscale));
-                atomicAdd(&ringc[b], kx == 0 ? 1u : 2u);
-            }
-            bandp[row * W + kx] = o;
-        }
+        emit(c0, ncol);
+    }
     }
     if (P.band_max) {
 #pragma unroll
