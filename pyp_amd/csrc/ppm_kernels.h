@@ -256,10 +256,12 @@ __global__ void __launch_bounds__(PT, MINW) k_prep(PrepP P) {
                     o = make_float2(o.x * cs + o.y * sn, o.y * cs - o.x * sn);
                 }
                 omax = fmaxf(omax, fmaxf(fabsf(o.x), fabsf(o.y)));
-                int b = (int)floorf(sqrtf(k2));
-                float al = kx == 0 ? 1.f : 2.f;
-                atomicAdd(&ringq[b], (unsigned long long)__double2ll_rn((double)(al * (o.x * o.x + o.y * o.y)) * (double)qscale));
-                atomicAdd(&ringc[b], kx == 0 ? 1u : 2u);
+                if (P.whiten) {                                  // ring power sums are only read by the whitening weights
+                    int b = (int)floorf(sqrtf(k2));
+                    float al = kx == 0 ? 1.f : 2.f;
+                    atomicAdd(&ringq[b], (unsigned long long)__double2ll_rn((double)(al * (o.x * o.x + o.y * o.y)) * (double)qscale));
+                    atomicAdd(&ringc[b], kx == 0 ? 1u : 2u);
+                }
             }
             bandp[row * W + kx] = o;
         }
