@@ -223,6 +223,30 @@ def test_grid_search_at_a_band_between_32_and_64_pixels(H, O):
     assert np.abs(want[:, 14] - got[:, 14]).max() < 0.01
 
 
+def test_preprocessing_options_at_256_match_oracle(H, O):
+    """Box 256 takes the scratch-free pre-processing path (half spectrum held in registers, statistics folded into the staging pass
+    when no mask is applied): its options against the oracle — scores under invert / no normalisation / a focus mask / a beam tilt,
+    and insertion (no mask: folded statistics) with inverted contrast."""
+    n, px = 256, 1.2
+    vol, imgs, rows = dataset(n, 4, px, 0.2)
+    g, o = H.Reference(vol, 64), O.Reference(vol, 64)
+    C = synth.cistem.COL
+    tilted = rows.copy(); tilted[:, C["BEAM_TILT_X"]] = 0.8; tilted[:, C["BEAM_TILT_Y"]] = -0.5
+    for kw, rr in ((dict(invert=1), rows), (dict(normalize=0), rows), (dict(focus=(20.0, -15.0, 10.0, 60.0)), rows), (dict(), tilted)):
+        c = RefineCfg.make(box=n, pixel_size=px, mask_radius=0.35 * n * px, res_high=px * n / 48.0, global_search=0, local_refine=0, res_signed_cc=30.0, **kw)
+        want = O.score_batch(o, c, imgs, rr)
+        got = g.refine(c, imgs, rr)[:, 14] / 100.0
+        assert np.abs(want - got).max() < 2e-4, kw          # 7 000 samples summed in float32 (both pre-processing paths give the same 1e-4)
+    rc = ReconCfg(box=n, pixel_size=px, res_limit=px * n / 60.0, normalize=1, invert=1, split_by_pind=0, mask_radius=0.35 * n * px)
+    acc_o = np.zeros(O.accum_floats(n), dtype=np.float32); cnt = np.zeros(2, dtype=np.int64)
+    O.insert_batch(acc_o, cnt, rc, "C1", imgs, tilted)
+    acc = H.Accumulator(n, px, "C1")
+    acc.insert(rc, imgs, tilted)
+    got_acc = acc.download()
+    acc.close()
+    assert np.linalg.norm(got_acc - acc_o) / np.linalg.norm(acc_o) < 1e-4
+
+
 def test_particle_pairs_of_the_grid_search_do_not_couple(H):
     """k_global works on two particles per block (they share the streamed slice rows): a particle's result must not depend on
     its neighbour, on being the odd one of a short last block, or on where the chunk boundaries fall."""
