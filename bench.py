@@ -53,7 +53,7 @@ def parse(argv=None):
                          "(configs[2]) and the two next-row blocks 'csp' (configs[3]: constrained tilt-series refinement) and 'sva' "
                          "(configs[4]: sub-tomogram alignment); refine / reconstruct / csp / sva = that workload alone")
     ap.add_argument("--csp-particles", type=int, default=500, help="particles of the tilt series of the csp block (41 tilts, 128^2 boxes)")
-    ap.add_argument("--sva-volumes", type=int, default=256, help="resident 192^3 sub-volumes of the sva block")
+    ap.add_argument("--sva-volumes", type=int, default=512, help="resident 192^3 sub-volumes of the sva block")
     ap.add_argument("--no-next-rows", action="store_true", help="leave the csp / sva blocks out of the default line")
     return ap.parse_args(argv)
 

@@ -11,6 +11,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ppm.h"
@@ -1434,13 +1435,22 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
         return rit < rband ? rit : rband;
     };
     // ---- device buffers (RAII), chunks of sub-volumes
-    const int CH = (int)std::min<size_t>((size_t)n_vol, std::max<size_t>(1, ((size_t)4 << 30) / (n3 * 4 + (size_t)S * 8)));
+    // chunks of sub-volumes: the search kernel runs one block per sub-volume, so a chunk should fill the chip (>= 256 blocks).  Resident
+    // volumes: limited by the band transforms (S float2 each, 4 GB); host volumes: two staging buffers of a chunk each (2 x 7 GB at
+    // 192^3 — small change on a 288 GB device), the next chunk uploaded while this one is searched.
+    int CH = (int)std::min<size_t>((size_t)n_vol, std::max<size_t>(1, ((size_t)4 << 30) / ((size_t)S * 8)));
+    if (!volumes_on_device) {
+        const int hc = getenv("PPM_SVA_CHUNK") ? std::max(1, atoi(getenv("PPM_SVA_CHUNK"))) : (int)std::max<size_t>(1, ((size_t)7 << 30) / (n3 * 4));
+        CH = std::min(CH, hc);
+    }
     DevTmp<uint32_t> d_samples; DevTmp<float> d_bandw, d_vols, d_wedges; DevTmp<float2> d_f, d_F; DevTmp<double> d_stats, d_poses, d_delta, d_out;
     const int KX = std::min(N / 2 + 1, R + 1);          // x coefficients kept; |ky|, |kz| <= R are the lines the later passes touch
-    HIPCHK(d_samples.alloc(S)); HIPCHK(d_bandw.alloc(S)); HIPCHK(d_f.alloc((size_t)N * N * KX)); HIPCHK(d_F.alloc((size_t)CH * S));
+    const int NB = std::min(CH, 32);                     // sub-volumes transformed per launch (work array: NB x N x N x KX complex)
+    HIPCHK(d_samples.alloc(S)); HIPCHK(d_bandw.alloc(S)); HIPCHK(d_f.alloc((size_t)NB * N * N * KX)); HIPCHK(d_F.alloc((size_t)CH * S));
     HIPCHK(d_stats.alloc((size_t)2 * CH)); HIPCHK(d_poses.alloc((size_t)12 * CH)); HIPCHK(d_delta.alloc((size_t)CH * ncand * 6)); HIPCHK(d_out.alloc((size_t)CH * ncand));
     HIPCHK(d_wedges.alloc((size_t)2 * CH));
-    if (!volumes_on_device) HIPCHK(d_vols.alloc((size_t)CH * n3));
+    const bool two_bufs = !volumes_on_device && n_vol > CH;      // host volumes: the next chunk is uploaded by a helper thread while this one is searched
+    if (!volumes_on_device) HIPCHK(d_vols.alloc((size_t)(two_bufs ? 2 : 1) * CH * n3));
     HIPCHK(hipMemcpyAsync(d_samples.p, samples.data(), (size_t)S * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
     HIPCHK(hipMemcpyAsync(d_bandw.p, bandw.data(), (size_t)S * sizeof(float), hipMemcpyHostToDevice, g.stream));
     SvaWin W; for (int k = 0; k < 3; k++) W.w[k] = cfg->window[k]; W.sigma = cfg->window_sigma;
@@ -1450,10 +1460,37 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
     EP.wedges = d_wedges.p; EP.poses = d_poses.p; EP.delta = d_delta.p; EP.out = d_out.p;
     std::vector<float> hw((size_t)2 * CH);
     std::vector<double> hdelta, hout;
-    for (int c0 = 0; c0 < n_vol; c0 += CH) {
+    if (!volumes_on_device) {       // first chunk
+        HIPCHK(hipMemcpyAsync(d_vols.p, volumes, (size_t)std::min(CH, n_vol) * n3 * sizeof(float), hipMemcpyHostToDevice, g.copy));
+        HIPCHK(hipStreamSynchronize(g.copy));
+    }
+    struct Uploader {           // joins on every exit path
+        std::thread t; hipError_t err = hipSuccess;
+        void join() { if (t.joinable()) t.join(); }
+        ~Uploader() { join(); }
+    } up;
+    for (int c0 = 0, ci = 0; c0 < n_vol; c0 += CH, ci++) {
         const int nb = std::min(CH, n_vol - c0);
         const float *dv = (const float *)volumes + (size_t)c0 * n3;
-        if (!volumes_on_device) { HIPCHK(hipMemcpyAsync(d_vols.p, dv, (size_t)nb * n3 * sizeof(float), hipMemcpyHostToDevice, g.stream)); dv = d_vols.p; }
+        if (!volumes_on_device) {
+            up.join();
+            if (up.err != hipSuccess) return fail(-5, std::string("HIP: ") + hipGetErrorString(up.err) + " while uploading sub-volumes");
+            dv = d_vols.p + (size_t)(ci & 1) * (two_bufs ? (size_t)CH * n3 : 0);
+            if (c0 + CH < n_vol) {      // the host drives the search of this chunk (a synchronisation per sweep): the copy of the next one gets its own thread and stream
+                const int nn = std::min(CH, n_vol - (c0 + CH));
+                float *dst = d_vols.p + (size_t)((ci + 1) & 1) * CH * n3;
+                const float *src = (const float *)volumes + (size_t)(c0 + CH) * n3;
+                const size_t bytes = (size_t)nn * n3 * sizeof(float);
+                const int dev = g.device; hipStream_t cs = g.copy;
+                up.err = hipSuccess;
+                up.t = std::thread([&up, dst, src, bytes, dev, cs] {
+                    hipError_t e = hipSetDevice(dev);
+                    if (e == hipSuccess) e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, cs);
+                    if (e == hipSuccess) e = hipStreamSynchronize(cs);
+                    up.err = e;
+                });
+            }
+        }
         for (int v = 0; v < nb; v++) { hw[2 * v] = wedges ? wedges[2 * (size_t)(c0 + v)] : -90.f; hw[2 * v + 1] = wedges ? wedges[2 * (size_t)(c0 + v) + 1] : 90.f; }
         HIPCHK(hipMemcpyAsync(d_wedges.p, hw.data(), (size_t)2 * nb * sizeof(float), hipMemcpyHostToDevice, g.stream));
         HIPCHK(hipMemsetAsync(d_stats.p, 0, (size_t)2 * nb * sizeof(double), g.stream));
@@ -1463,19 +1500,22 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
             if (int rc = ensure_plan(N)) return rc;
             SvaXP XP; XP.stats = nullptr; XP.out = d_f.p; XP.plan = g.plans[N].plan; XP.n = N; XP.KX = KX; XP.nlines = (long)N * N; XP.W = W;
             XP.L = std::max(1, std::min(16, 8192 / N));
-            while (XP.nlines % XP.L) XP.L--;
-            for (int v = 0; v < nb; v++) {
-                // pruned transform (k_sva_xpass): x pass from the real volume into [z][y][KX], y pass on that, z pass on |ky| <= R only
-                XP.vol = dv + (size_t)v * n3; XP.stats = d_stats.p + 2 * v;
+            while (((long)N * N) % XP.L) XP.L--;
+            for (int v0 = 0; v0 < nb; v0 += NB) {
+                // pruned transform of NB sub-volumes per launch (k_sva_xpass): x pass from the real volumes into [vol][z][y][KX], y pass on
+                // that, z pass on |ky| <= R only
+                const int m = std::min(NB, nb - v0);
+                const long NN2 = (long)N * N;
+                XP.vol = dv + (size_t)v0 * n3; XP.stats = d_stats.p + 2 * v0; XP.nlines = (long)m * NN2;
                 hipLaunchKernelGGL(k_sva_xpass, dim3((unsigned)((XP.nlines + XP.L - 1) / XP.L)), dim3(256), (size_t)XP.L * N * sizeof(float2), g.stream, XP);
-                if (int rc = fft_lines_pass(d_f.p, N, (long)N * KX, KX, 1, (long)N * KX, KX, 1, false)) return rc;
+                if (int rc = fft_lines_pass(d_f.p, N, (long)m * N * KX, KX, 1, (long)N * KX, KX, 1, false)) return rc;
                 if (2 * R + 1 >= N) {
-                    if (int rc = fft_lines_pass(d_f.p, N, (long)N * KX, (long)N * KX, 1, 0, (long)N * KX, 1, false)) return rc;
+                    if (int rc = fft_lines_pass(d_f.p, N, (long)m * N * KX, (long)N * KX, 1, NN2 * KX, (long)N * KX, 1, false)) return rc;
                 } else {
-                    if (int rc = fft_lines_pass(d_f.p, N, (long)(R + 1) * KX, (long)(R + 1) * KX, 1, 0, (long)N * KX, 1, false)) return rc;
-                    if (int rc = fft_lines_pass(d_f.p + (size_t)(N - R) * KX, N, (long)R * KX, (long)R * KX, 1, 0, (long)N * KX, 1, false)) return rc;
+                    if (int rc = fft_lines_pass(d_f.p, N, (long)m * (R + 1) * KX, (long)(R + 1) * KX, 1, NN2 * KX, (long)N * KX, 1, false)) return rc;
+                    if (int rc = fft_lines_pass(d_f.p + (size_t)(N - R) * KX, N, (long)m * R * KX, (long)R * KX, 1, NN2 * KX, (long)N * KX, 1, false)) return rc;
                 }
-                hipLaunchKernelGGL(k_sva_gather, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, g.stream, d_f.p, d_samples.p, S, N, KX, d_F.p + (size_t)v * S);
+                hipLaunchKernelGGL(k_sva_gather, dim3((unsigned)((S + 255) / 256), m), dim3(256), 0, g.stream, d_f.p, d_samples.p, S, N, KX, d_F.p + (size_t)v0 * S);
             }
         }
         HIPCHK(hipGetLastError());

@@ -38,7 +38,9 @@ __global__ void __launch_bounds__(256) k_sva_xpass(SvaXP P) {
     const int nl = (int)((P.nlines - l0) < P.L ? (P.nlines - l0) : P.L);
     if (nl <= 0) return;
     const double n3 = (double)n * n * n;
-    const double mu = P.stats[0] / n3, var = P.stats[1] / n3 - mu * mu, sd = var > 0 ? sqrt(var) : 1.0;
+    // P.L divides n * n: the lines of a block belong to one sub-volume of the batch (P.vol / P.out / P.stats point at its first one)
+    const double *st = P.stats + 2 * (l0 / ((long)n * n));
+    const double mu = st[0] / n3, var = st[1] / n3 - mu * mu, sd = var > 0 ? sqrt(var) : 1.0;
     auto win1 = [&](int c, int k) {
         if (!(P.W.w[k] > 0.f)) return 1.f;
         const float d = fabsf((float)c) - P.W.w[k];
@@ -47,7 +49,7 @@ __global__ void __launch_bounds__(256) k_sva_xpass(SvaXP P) {
     for (int i = tid; i < nl * n; i += 256) {
         const int line = i / n, e = i - line * n;
         const long l = l0 + line;
-        const int y = (int)(l % n), z = (int)(l / n);
+        const int y = (int)(l % n), z = (int)((l / n) % n);
         const float wv = win1(e - n / 2, 0) * win1(y - n / 2, 1) * win1(z - n / 2, 2);
         buf[line * n + P.plan.perm[e]] = make_float2((float)(((double)P.vol[l * n + e] - mu) / sd) * wv, 0.f);
     }
@@ -63,9 +65,11 @@ __host__ __device__ __forceinline__ uint32_t sva_pack(int kx, int ky, int kz) { 
 __device__ __forceinline__ void sva_unpack(uint32_t u, int &kx, int &ky, int &kz) { kx = (int)(u & 1023u); ky = (int)((u >> 10) & 2047u) - 512; kz = (int)(u >> 21) - 512; }
 
 // band-limited half-space transform of one sub-volume out of the compact [z][y][KX] array, origin moved to the box centre
+// (grid.y = sub-volume of the batch)
 __global__ void k_sva_gather(const float2 *__restrict__ f, const uint32_t *__restrict__ samples, int S, int N, int KX, float2 *__restrict__ F) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S) return;
+    f += (size_t)blockIdx.y * N * N * KX; F += (size_t)blockIdx.y * S;
     int kx, ky, kz; sva_unpack(samples[i], kx, ky, kz);
     const float2 v = f[((size_t)((kz + N) % N) * N + ((ky + N) % N)) * KX + kx];
     const float sg = ((kx + ky + kz) & 1) ? -1.f : 1.f;

@@ -117,32 +117,59 @@ def cfg_from_xml(xml_path, box, pixel_size=1.0, mode=None):
                        tol_angle=val("out_of_plane_search_range"), tol_shift=val("shifts_tolerance"))
 
 
-def align_table(reference, table, names, cfg, base_dir=".", device=0, chunk=64, max_band_px=None):
+def align_table(reference, table, names, cfg, base_dir=".", device=0, chunk=256, max_band_px=None):
     """Align every sub-volume of a table to `reference` (N^3 array): returns the refined table (matrix columns replaced, the
-    correlation score in cutOffset) and the scores.  Sub-volumes are read chunk by chunk (10 k x 192^3 is 283 GB)."""
+    correlation score in cutOffset) and the scores.  Sub-volumes are read chunk by chunk (10 k x 192^3 is 283 GB) into two
+    page-locked buffers, the next chunk by a reader thread while the current one is aligned; inside a call the library uploads
+    2 GB at a time while it searches the previous 2 GB."""
+    import threading
     from . import host
     n = int(cfg.box)
     ref = host.Reference(reference, n / 2 if max_band_px is None else max_band_px, device=device)
     out = np.array(table, dtype=np.float64, copy=True)
     scores = np.zeros(len(out))
+    chunk = max(1, min(int(chunk), len(out)))
+    bufs = [host.PinnedBuffer(chunk * n ** 3, device) for _ in range(2 if len(out) > chunk else 1)]
+
+    def fill(b, lo, hi):
+        vols = bufs[b].array[:(hi - lo) * n ** 3].reshape(hi - lo, n, n, n)
+        for k in range(lo, hi):
+            fn = names[k] if os.path.isabs(names[k]) else os.path.join(base_dir, names[k])
+            v = mrc.read(fn)
+            if v.shape != (n, n, n):
+                raise ValueError(f"ERROR: {fn} is {v.shape}, expected {n}^3")
+            vols[k - lo] = v
+        return vols
+
     try:
+        cur, b = fill(0, 0, min(chunk, len(out))), 0
         for lo in range(0, len(out), chunk):
             hi = min(lo + chunk, len(out))
-            vols = np.empty((hi - lo, n, n, n), dtype=np.float32)
+            nxt, err, t = [None], [None], None
+            if hi < len(out):
+                def work(bb=1 - b, a=hi, e=min(hi + chunk, len(out))):
+                    try:
+                        nxt[0] = fill(bb, a, e)
+                    except Exception as ex:      # surfaced in the caller's thread below
+                        err[0] = ex
+                t = threading.Thread(target=work)
+                t.start()
             poses = np.zeros((hi - lo, 12))
             for k in range(lo, hi):
-                fn = names[k] if os.path.isabs(names[k]) else os.path.join(base_dir, names[k])
-                v = mrc.read(fn)
-                if v.shape != (n, n, n):
-                    raise ValueError(f"ERROR: {fn} is {v.shape}, expected {n}^3")
-                vols[k - lo] = v
                 N, p = line_to_pose(out[k, 9:12], out[k, 12:28])
                 poses[k - lo, :9], poses[k - lo, 9:] = N.ravel(), p
-            got, sc = ref.sva_align(cfg, vols, out[lo:hi, 1:3].astype(np.float32), poses)
+            got, sc = ref.sva_align(cfg, cur, out[lo:hi, 1:3].astype(np.float32), poses)
             for k in range(lo, hi):
                 out[k, 12:28] = pose_to_matrix(got[k - lo, :9], got[k - lo, 9:], out[k, 9:12])
                 out[k, 31] = sc[k - lo]
             scores[lo:hi] = sc
+            if t is not None:
+                t.join()
+                if err[0] is not None:
+                    raise err[0]
+                cur, b = nxt[0], 1 - b
     finally:
         ref.close()
+        for pb in bufs:
+            pb.close()
     return out, scores

@@ -14,7 +14,19 @@ ref = host.Reference(vol, n / 2)
 ref.sva_align(cfg, vols[:4], wedges[:4], start[:4])
 host.profile(True, True)
 t0 = time.time()
-out, sc = ref.sva_align(cfg, vols, wedges, start)
+mode = sys.argv[3] if len(sys.argv) > 3 else "device"      # "host": pageable host memory; "pinned": page-locked (what sva.align_table reads into)
+src = vols
+if mode == "host":
+    src = vols.cpu().numpy()
+elif mode == "pinned":
+    pb = host.PinnedBuffer(vols.numel())
+    src = pb.array.reshape(tuple(vols.shape))
+    src[...] = vols.cpu().numpy()
+if src is not vols:
+    del vols
+    torch.cuda.empty_cache()
+t0 = time.time()
+out, sc = ref.sva_align(cfg, src, wedges, start)
 dt = time.time() - t0
 prof = host.profile_report()
 print("box %d: %d sub-volumes in %.2f s = %.1f sub-volumes/s; prep %.1f ms, search %.1f ms per sub-volume" % (n, nv, dt, nv / dt, prof["prep"]["ms"] / nv, prof["local"]["ms"] / nv))
