@@ -60,6 +60,22 @@ def test_gpu_alignment_matches_oracle(n, kw):
 
 
 @pytest.mark.gpu
+def test_host_volumes_in_several_chunks_equal_resident_volumes(monkeypatch):
+    """Host volumes are uploaded chunk by chunk, the next chunk by a helper thread while the current one is searched
+    (PPM_SVA_CHUNK forces chunks of 3 here: 11 sub-volumes = 4 chunks, the transforms of a chunk in one batch): same bits as
+    one call on resident volumes."""
+    from pyp_amd import host
+    n = 32
+    vol, vols, poses, wedges = synth.make_subtomograms(n, 11, snr=0.5)
+    start = synth.perturb_poses(poses, 3.0, 1.0)
+    g = host.Reference(vol, n / 2)
+    resident, rsc = g.sva_align(cfg_for(n), vols.cuda(), wedges, start)
+    monkeypatch.setenv("PPM_SVA_CHUNK", "3")
+    chunked, csc = g.sva_align(cfg_for(n), vols.numpy(), wedges, start)
+    assert np.array_equal(resident, chunked) and np.array_equal(rsc, csc)
+
+
+@pytest.mark.gpu
 def test_gpu_alignment_errors_are_loud():
     from pyp_amd import host, lib
     vol, vols, poses, wedges = synth.make_subtomograms(32, 2, snr=0.5)
