@@ -154,15 +154,20 @@ inline void rot_xyz(int k, double deg, double R[9]) {      // right-handed rotat
 }
 // Row pose of the constrained geometry (include/ppm.h, ppm_csp_cfg): M_row = N Ry(-tilt) Rz(axis),
 // g = [Rz(-axis) Ry(tilt) (-p)]_xy + tilt shift (pixels)
-inline void csp_row_pose(const double N[9], const double p[3], double tilt, double axis, double tsx, double tsy, double M[9], double g[2]) {
-    double a[9], b[9], t[9];
-    rot_xyz(1, -tilt, a); rot_xyz(2, axis, b);
-    mat_mul3h(N, a, t); mat_mul3h(t, b, M);
-    rot_xyz(2, -axis, a); rot_xyz(1, tilt, b);
+// the four rotations a tilt contributes to its rows' poses (the trigonometry of csp_row_pose, shared by all rows of the tilt)
+struct TiltRot { double a[9], b[9], ai[9], bi[9]; };     // Ry(-tilt), Rz(axis), Rz(-axis), Ry(tilt)
+inline void tilt_rotations(double tilt, double axis, TiltRot &r) { rot_xyz(1, -tilt, r.a); rot_xyz(2, axis, r.b); rot_xyz(2, -axis, r.ai); rot_xyz(1, tilt, r.bi); }
+inline void csp_row_pose(const double N[9], const double p[3], const TiltRot &r, double tsx, double tsy, double M[9], double g[2]) {
+    double t[9];
+    mat_mul3h(N, r.a, t); mat_mul3h(t, r.b, M);
     double q[3] = { -p[0], -p[1], -p[2] }, u[3], v[3];
-    for (int i = 0; i < 3; i++) u[i] = b[i * 3] * q[0] + b[i * 3 + 1] * q[1] + b[i * 3 + 2] * q[2];
-    for (int i = 0; i < 3; i++) v[i] = a[i * 3] * u[0] + a[i * 3 + 1] * u[1] + a[i * 3 + 2] * u[2];
+    for (int i = 0; i < 3; i++) u[i] = r.bi[i * 3] * q[0] + r.bi[i * 3 + 1] * q[1] + r.bi[i * 3 + 2] * q[2];
+    for (int i = 0; i < 3; i++) v[i] = r.ai[i * 3] * u[0] + r.ai[i * 3 + 1] * u[1] + r.ai[i * 3 + 2] * u[2];
     g[0] = v[0] + tsx; g[1] = v[1] + tsy;
+}
+inline void csp_row_pose(const double N[9], const double p[3], double tilt, double axis, double tsx, double tsy, double M[9], double g[2]) {
+    TiltRot r; tilt_rotations(tilt, axis, r);
+    csp_row_pose(N, p, r, tsx, tsy, M, g);
 }
 
 // Ring-ordered sample list of the half plane kx >= 0, 0 < k^2 < r_hi^2, ring = floor(|k|); every

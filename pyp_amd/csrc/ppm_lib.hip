@@ -12,6 +12,7 @@
 #include <memory>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/ppm.h"
@@ -1044,9 +1045,11 @@ extern "C" int ppm_csp_refine(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const p
     if (gm.B > (ref->B + 1) / ref->pad - 1) return fail(-22, "high-resolution limit exceeds the band the reference was prepared for");
     const int kind = cc->unit;
     // ---- rows -> units
-    std::map<long, int> pmap; std::map<std::pair<long, long>, int> tmap;
+    std::unordered_map<long, int> pmap, tmap;          // tilt key: (TIND, RIND) folded into one integer
+    pmap.reserve((size_t)n_part * 2); tmap.reserve((size_t)n_tilt * 2);
+    auto tkey = [](long tind, long rind) { return tind * 1000003L + rind; };
     for (int i = 0; i < n_part; i++) pmap[(long)particles[(size_t)i * PPM_NPCOL]] = i;
-    for (int i = 0; i < n_tilt; i++) tmap[{ (long)tilts[(size_t)i * PPM_NTCOL], (long)tilts[(size_t)i * PPM_NTCOL + 1] }] = i;
+    for (int i = 0; i < n_tilt; i++) tmap[tkey((long)tilts[(size_t)i * PPM_NTCOL], (long)tilts[(size_t)i * PPM_NTCOL + 1])] = i;
     std::vector<int> row_part(n_proj), row_tilt(n_proj);
     std::vector<unsigned char> usable(n_proj);
     std::vector<CUnit> parts(n_part), tls(n_tilt);
@@ -1060,9 +1063,11 @@ extern "C" int ppm_csp_refine(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const p
         tls[i].tl[0] = T[4]; tls[i].tl[1] = T[5]; tls[i].tl[2] = T[2]; tls[i].tl[3] = T[3];
     }
     std::vector<double> s0((size_t)2 * n_proj), g0((size_t)2 * n_proj);
+    std::vector<TiltRot> trot(n_tilt);                  // one set of rotations per tilt instead of four sin / cos pairs per row
+    for (int i = 0; i < n_tilt; i++) tilt_rotations(tls[i].tl[0], tls[i].tl[1], trot[i]);
     for (int j = 0; j < n_proj; j++) {
         const double *row = rows + (size_t)j * PPM_NCOL;
-        auto ip = pmap.find((long)row[PPM_PIND]); auto it = tmap.find({ (long)row[PPM_TIND], (long)row[28] });
+        auto ip = pmap.find((long)row[PPM_PIND]); auto it = tmap.find(tkey((long)row[PPM_TIND], (long)row[28]));
         if (ip == pmap.end() || it == tmap.end()) return fail(-22, "csp: row " + std::to_string(j + 1) + " refers to a particle or tilt missing from the extended parameters");
         row_part[j] = ip->second; row_tilt[j] = it->second;
         const long tind = (long)row[PPM_TIND];
@@ -1070,7 +1075,7 @@ extern "C" int ppm_csp_refine(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const p
         s0[2 * j] = row[PPM_XSHIFT] / gm.a; s0[2 * j + 1] = row[PPM_YSHIFT] / gm.a;
         double M[9];
         const CUnit &pu = parts[row_part[j]], &tu = tls[row_tilt[j]];
-        csp_row_pose(pu.N, pu.p, tu.tl[0], tu.tl[1], tu.tl[2], tu.tl[3], M, &g0[2 * j]);
+        csp_row_pose(pu.N, pu.p, trot[row_tilt[j]], tu.tl[2], tu.tl[3], M, &g0[2 * j]);
     }
     const int nu_all = kind == PPM_CSP_PARTICLES ? n_part : n_tilt;
     std::vector<CUnit> &units = kind == PPM_CSP_PARTICLES ? parts : tls;
@@ -1332,6 +1337,7 @@ extern "C" int ppm_csp_refine(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const p
     if (int rc = sweep(final_rows, 1, gm.r_hi, nullptr)) return rc;
     std::vector<double> row_score(n_proj, 0.0);
     for (size_t q = 0; q < final_rows.size(); q++) row_score[final_rows[q]] = hout[q];
+    for (int i = 0; i < n_tilt; i++) tilt_rotations(tls[i].tl[0], tls[i].tl[1], trot[i]);       // the tilts may have moved
     for (int u = 0; u < nu_all; u++) {
         if (!refined[u]) continue;
         if (kind == PPM_CSP_PARTICLES) {
@@ -1346,7 +1352,7 @@ extern "C" int ppm_csp_refine(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const p
         for (int j : urows[u]) {
             double *row = rows + (size_t)j * PPM_NCOL, M[9], gq[2];
             const CUnit &pu = parts[row_part[j]], &tu = tls[row_tilt[j]];
-            csp_row_pose(pu.N, pu.p, tu.tl[0], tu.tl[1], tu.tl[2], tu.tl[3], M, gq);
+            csp_row_pose(pu.N, pu.p, trot[row_tilt[j]], tu.tl[2], tu.tl[3], M, gq);
             angles_from_matrix(M, row[PPM_PSI], row[PPM_THETA], row[PPM_PHI]);
             row[PPM_XSHIFT] = (s0[2 * j] + gq[0] - g0[2 * j]) * gm.a; row[PPM_YSHIFT] = (s0[2 * j + 1] + gq[1] - g0[2 * j + 1]) * gm.a;
             const double ccv = row_score[j]; double res = 1.0 - ccv * ccv; if (res < 1e-6) res = 1e-6;
