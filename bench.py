@@ -45,6 +45,7 @@ def parse(argv=None):
     ap.add_argument("--box", type=int, default=256)
     ap.add_argument("--band", type=float, default=64.0, help="search / refinement band limit, Fourier pixels")
     ap.add_argument("--angular-step", type=float, default=15.0)
+    ap.add_argument("--search-range", type=float, default=6.0, help="shift search range of the grid search, pixels (BASELINE config 2: shifts clipped at +-6 px); 0 = the widest window (8 search-grid steps), what PYP's default refine_searchx = 0 asks for")
     ap.add_argument("--unique", type=int, default=0, help="distinct clean projections (0 = one per particle: every particle has its own pose)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of each CPU oracle leg (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -274,7 +275,7 @@ def refine_bench(ctx):
                                         seed_poses=synth.SEED_POSES + rank, seed_noise=synth.SEED_NOISE + rank, batch=32)
     torch.cuda.synchronize()
     res = px * N / a.band
-    srange = 6.0 * px
+    srange = a.search_range * px
     cfg = RefineCfg.make(box=N, pixel_size=px, mask_radius=0.32 * N * px, res_high=res, res_search=res, res_low=0.0,
                          angular_step=a.angular_step, top_hits=20, search_range_x=srange, search_range_y=srange,
                          res_signed_cc=30.0, molecular_mass_kda=500.0)

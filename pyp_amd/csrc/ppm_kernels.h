@@ -910,6 +910,54 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
                         shp[o] = (bsx_ & 0xffff) | (bsy_ << 16);
                     }
                 }
+            } else if constexpr (NS * NS > 64) {
+                // wide windows (R > 3, up to 17 x 17 shifts): the window is reduced ROW BY ROW — the NS values of a window row (both
+                // orientations in the halves of packed registers) go through one halving reduction, lane bitrev6(ix) ends up with the
+                // row's total for shift column ix and keeps a running best over the rows.  (A wave-wide sum per shift — 289 of them per
+                // orientation at R = 8 — kept so many values alive that the kernel spilled 1.8 KB per thread.)
+                const v2f sg2 = { 1.f, -1.f };
+                const int vi = (int)(__brev((unsigned)lane) >> 26), ix = vi;
+                const int ax = ix - R < 0 ? R - ix : ix - R;
+                const bool incol = vi < NS && ax <= P.RSx;
+                float bestv[2] = { -3.0e38f, -3.0e38f }; int besty[2] = { 0, 0 };
+#pragma unroll
+                for (int iy = 0; iy < NS; iy++) {
+                    const int jy = iy - R, ja = jy < 0 ? -jy : jy;
+                    v2f gx, gy;
+                    if (jy == 0) { gx = sax + sg2 * sbx; gy = say + sg2 * sby; }
+                    else {
+                        const v2f ux = uax[ja - 1] + sg2 * ubx[ja - 1], uy = uay[ja - 1] + sg2 * uby[ja - 1];
+                        const v2f vx = vax[ja - 1] + sg2 * vbx[ja - 1], vy = vay[ja - 1] + sg2 * vby[ja - 1];
+                        gx = jy > 0 ? ux - vy : ux + vy; gy = jy > 0 ? uy + vx : uy - vx;
+                    }
+                    v2f val[NS];
+                    val[R] = gx;
+#pragma unroll
+                    for (int j = 1; j <= R; j++) {
+                        const v2f pc = gx * txc[j], qs = gy * txs[j];
+                        val[R + j] = pc - qs;
+                        val[R - j] = pc + qs;
+                    }
+                    const v2f tot = reduce_halving2<NS>(val, lane);
+                    const bool ok = incol && ja <= P.RSy;
+#pragma unroll
+                    for (int e = 0; e < (HALF ? 2 : 1); e++) {
+                        const float cand = ok ? (e ? tot.y : tot.x) : -3.0e38f;
+                        if (cand > bestv[e]) { bestv[e] = cand; besty[e] = iy; }       // strict: the first row wins a tie, like the oracle's scan order
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < (HALF ? 2 : 1); e++) {
+                    const float best = wave_max(bestv[e]);
+                    int ci = wave_min(bestv[e] == best ? besty[e] * NS + vi : 1 << 20);      // ties -> lower (sy, sx) index
+                    if (ci >= NS * NS) ci = R * NS + R;                                       // no comparable value (NaN scores): the centre
+                    const int bsy_ = ci / NS - R, bsx_ = ci - (ci / NS) * NS - R;
+                    if (lane == 0 && (q == 0 || p0 + q < P.n)) {
+                        int o = dir * P.n_psi + ks + e * P.npsi_store;
+                        ccp[o] = best * inv;
+                        shp[o] = (bsx_ & 0xffff) | (bsy_ << 16);
+                    }
+                }
             } else
 #pragma unroll
             for (int e = 0; e < (HALF ? 2 : 1); e++) {
