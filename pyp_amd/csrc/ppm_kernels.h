@@ -643,6 +643,9 @@ constexpr int kRowTwRows = 64;
 #ifndef PPM_GLOBAL_PARTICLES
 #define PPM_GLOBAL_PARTICLES 2
 #endif
+#ifndef PPM_GLOBAL_PAIR_MAXR
+#define PPM_GLOBAL_PAIR_MAXR 8
+#endif
 #ifndef PPM_GLOBAL_THREADS
 #define PPM_GLOBAL_THREADS 512
 #endif
@@ -699,7 +702,7 @@ __device__ __forceinline__ v2f reduce_halving2(v2f (&v)[NV], int lane) {
 // re-read by every block, 141 MB per block at the default grid: with one particle per block the L2 -> L1 path, not the vector
 // unit, set the pace).  Two particles keep W tables of 2 x 64 KB in LDS; 512 threads (two waves per SIMD, 139 registers)
 // measured faster than 768 or 1024.
-constexpr int global_particles(int R) { return R <= 3 ? PPM_GLOBAL_PARTICLES : 1; }
+constexpr int global_particles(int R) { return R <= PPM_GLOBAL_PAIR_MAXR ? PPM_GLOBAL_PARTICLES : 1; }
 constexpr int global_threads(int R) { return R <= 3 ? PPM_GLOBAL_THREADS : 512; }   // wider windows need > 128 VGPRs
 constexpr int global_unroll(int R) { return R <= 3 ? PPM_GLOBAL_UNROLL : 4; }         // rows in flight per wave (prefetch depth), even
 

@@ -252,10 +252,10 @@ def test_particle_pairs_of_the_grid_search_do_not_couple(H):
     its neighbour, on being the odd one of a short last block, or on where the chunk boundaries fall."""
     vol, imgs, rows = dataset(64, 9, 2.0, 0.1)
     g = H.Reference(vol, 32)
-    c = cfg_for(64, 2.0)
-    full = g.refine(c, imgs, rows)
-    for sel in ([0], [8], [0, 1, 2], [1, 0], [3, 7, 5, 2, 8]):
-        assert np.array_equal(g.refine(c, imgs[sel], rows[sel]), full[sel]), sel
+    for c in (cfg_for(64, 2.0), cfg_for(64, 2.0, search_range_x=0.0, search_range_y=0.0)):      # 7 x 7 and 17 x 17 shift windows
+        full = g.refine(c, imgs, rows)
+        for sel in ([0], [8], [0, 1, 2], [1, 0], [3, 7, 5, 2, 8]):
+            assert np.array_equal(g.refine(c, imgs[sel], rows[sel]), full[sel]), sel
 
 
 def test_two_live_references_with_different_search_grids(H, O):
