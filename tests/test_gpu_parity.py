@@ -188,7 +188,8 @@ def test_fine_angular_steps_select_top_hits_correctly(H, O, step):
 
 @pytest.mark.parametrize("kw", [dict(angular_step=24.0), dict(angular_step=40.0),                       # odd psi counts: no psi / psi + 180 pairing
                                 dict(search_range_x=10.0, search_range_y=10.0), dict(search_range_x=0.0, search_range_y=0.0),   # shift windows of 5 and 8 steps
-                                dict(search_range_x=4.0, search_range_y=14.0), dict(search_range_x=2.0, search_range_y=2.0)])
+                                dict(search_range_x=4.0, search_range_y=14.0), dict(search_range_x=2.0, search_range_y=2.0),
+                                dict(angular_step=24.0, search_range_x=0.0, search_range_y=0.0)])          # odd psi count AND the widest window
 def test_search_grid_variants_match_oracle(H, O, kw):
     """Code paths of the grid search the default configuration never takes: an odd number of in-plane angles (every slice
     stored, no conjugate pairing), shift windows wider than 3 steps (512-thread kernel, per-shift wave sums), anisotropic and
