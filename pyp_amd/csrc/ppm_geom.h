@@ -28,6 +28,8 @@ struct Geom {
     double step = 0;              // global-search shift grid: Ns points over the box, step = N/Ns pixels
     int n_theta = 0, n_psi = 0, n_dir = 0, n_orient = 0, npsi_store = 0, half = 0;
     double dpsi = 0, dstep = 0, phi_max = 360, theta_max = 180;
+    double range_asked_px = 0;    // largest shift search range the caller asked for, pixels (0: 'mask radius' / unlimited)
+    bool range_capped = false;    // the window of the grid search is narrower than that
     double r_s_asked = 0;         // search band the caller asked for (> r_s when the 64-pixel cap of the grid search applied)
 };
 
@@ -93,6 +95,8 @@ inline bool geom_init(Geom &g, const ppm_refine_cfg &c, std::string &err) {
     double rx = c.search_range_x / g.a, ry = c.search_range_y / g.a;
     g.RSx = rx > 0 ? (int)std::ceil(rx / g.step) : PPM_MAX_SHIFT_STEPS;
     g.RSy = ry > 0 ? (int)std::ceil(ry / g.step) : PPM_MAX_SHIFT_STEPS;
+    g.range_asked_px = (rx > 0 && ry > 0) ? std::max(rx, ry) : 0.0;
+    g.range_capped = !(rx > 0) || !(ry > 0) || g.RSx > PPM_MAX_SHIFT_STEPS || g.RSy > PPM_MAX_SHIFT_STEPS;
     if (g.RSx > PPM_MAX_SHIFT_STEPS) g.RSx = PPM_MAX_SHIFT_STEPS;
     if (g.RSy > PPM_MAX_SHIFT_STEPS) g.RSy = PPM_MAX_SHIFT_STEPS;
     g.dstep = c.angular_step > 0 ? c.angular_step : 15.0;

@@ -535,6 +535,13 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
                       gm.N * gm.a / gm.r_s, gm.N * gm.a / gm.r_s_asked);
         ref->note = b;
     }
+    if (cfg->global_search && gm.range_capped) {
+        char b[320];
+        std::snprintf(b, sizeof(b), "%sNOTE: shift window of the grid search: +-%.0f x +-%.0f pixels (%d x %d search-grid steps of %.1f pixels; asked: %s); the refinement of "
+                      "the hits is not limited to it", ref->note.empty() ? "" : "\n", gm.RSx * gm.step, gm.RSy * gm.step, gm.RSx, gm.RSy, gm.step,
+                      gm.range_asked_px > 0 ? (std::to_string((int)std::lround(gm.range_asked_px)) + " pixels").c_str() : "0 = the mask radius");
+        ref->note += b;
+    }
     if (gm.B > (ref->B + 1) / ref->pad - 1) return fail(-22, "high-resolution limit exceeds the band the reference was prepared for");
     if (cfg->global_search && gm.Bs + 1 > 64)
         return fail(-22, "global search band wider than 64 Fourier pixels is not supported; lower the 'resolution limit for search'");

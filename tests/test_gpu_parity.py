@@ -248,6 +248,20 @@ def test_preprocessing_options_at_256_match_oracle(H, O):
     assert np.linalg.norm(got_acc - acc_o) / np.linalg.norm(acc_o) < 1e-4
 
 
+def test_capped_search_band_and_shift_window_are_reported(H):
+    """A search band above 64 Fourier pixels and a shift range beyond 8 search-grid steps (or PYP's default 0 = 'mask radius') are
+    capped by the grid search, not refused: ppm_refine_note (the refine3d log) says what was done."""
+    vol, imgs, rows = dataset(256, 2, 1.0, 0.2)
+    g = H.Reference(vol, 128)
+    base = dict(box=256, pixel_size=1.0, mask_radius=82.0, res_high=3.0, res_search=3.0, angular_step=40.0, iters_hit=-1, local_refine=0)
+    g.refine(RefineCfg.make(search_range_x=6.0, search_range_y=6.0, **base), imgs, rows)
+    assert "band lowered from 85.3 to 64.0" in g.note() and "shift window" not in g.note()
+    g.refine(RefineCfg.make(search_range_x=0.0, search_range_y=0.0, **base), imgs, rows)
+    assert "shift window of the grid search: +-16 x +-16 pixels" in g.note() and "mask radius" in g.note()
+    g.refine(RefineCfg.make(search_range_x=6.0, search_range_y=6.0, res_high=6.0, res_search=6.0, **{k: v for k, v in base.items() if not k.startswith("res_")}), imgs, rows)
+    assert g.note() == ""
+
+
 def test_particle_pairs_of_the_grid_search_do_not_couple(H):
     """k_global works on two particles per block (they share the streamed slice rows): a particle's result must not depend on
     its neighbour, on being the odd one of a short last block, or on where the chunk boundaries fall."""
