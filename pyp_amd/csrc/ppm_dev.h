@@ -53,6 +53,15 @@ __device__ __forceinline__ float wave_max(float v) {
     w = v; lane_swap<32>(v, w); return max_raw(v, w);
 }
 __device__ __forceinline__ float wave_min(float v) { return -wave_max(-v); }
+// the same inside each half of the wave (lanes 0-31 / 32-63 separately)
+__device__ __forceinline__ float half_max(float v) {
+    v = max_raw(v, dpp_mov<kDppXor1>(v)); v = max_raw(v, dpp_mov<kDppXor2>(v)); v = max_raw(v, dpp_mov<kDppHalfMirror>(v)); v = max_raw(v, dpp_mov<kDppMirror>(v));
+    float w = v; lane_swap<16>(v, w); return max_raw(v, w);
+}
+__device__ __forceinline__ int half_min(int v) {
+    v = min(v, dpp_mov<kDppXor1>(v)); v = min(v, dpp_mov<kDppXor2>(v)); v = min(v, dpp_mov<kDppHalfMirror>(v)); v = min(v, dpp_mov<kDppMirror>(v));
+    int w = v; lane_swap<16>(v, w); return min(v, w);
+}
 __device__ __forceinline__ int wave_min(int v) {
     v = min(v, dpp_mov<kDppXor1>(v)); v = min(v, dpp_mov<kDppXor2>(v)); v = min(v, dpp_mov<kDppHalfMirror>(v)); v = min(v, dpp_mov<kDppMirror>(v));
     int w = v; lane_swap<16>(v, w); v = min(v, w);

@@ -698,6 +698,25 @@ __device__ __forceinline__ v2f reduce_halving2(v2f (&v)[NV], int lane) {
     return halve_pair2<1>(a5[0], (n5 > 1) ? a5[1] : z, lane);
 }
 
+// The same inside each half of the wave (no stage across the halves): NV <= 32 values, lane l of a half ends up with the total of
+// value index bitrev5(l & 31) over the half's 32 lanes.
+template <int NV>
+__device__ __forceinline__ v2f reduce_halving2h(v2f (&v)[NV], int lane) {
+    static_assert(NV <= 32, "one output register pair per half");
+    constexpr int n2 = (NV + 1) / 2, n3 = (n2 + 1) / 2, n4 = (n3 + 1) / 2, n5 = (n4 + 1) / 2;
+    const v2f z = { 0.f, 0.f };
+    v2f a2[n2], a3[n3], a4[n4], a5[n5];
+#pragma unroll
+    for (int i = 0; i < n2; i++) a2[i] = halve_pair2<16>(v[2 * i], (2 * i + 1 < NV) ? v[2 * i + 1] : z, lane);
+#pragma unroll
+    for (int i = 0; i < n3; i++) a3[i] = halve_pair2<8>(a2[2 * i], (2 * i + 1 < n2) ? a2[2 * i + 1] : z, lane);
+#pragma unroll
+    for (int i = 0; i < n4; i++) a4[i] = halve_pair2<4>(a3[2 * i], (2 * i + 1 < n3) ? a3[2 * i + 1] : z, lane);
+#pragma unroll
+    for (int i = 0; i < n5; i++) a5[i] = halve_pair2<2>(a4[2 * i], (2 * i + 1 < n4) ? a4[2 * i + 1] : z, lane);
+    return halve_pair2<1>(a5[0], (n5 > 1) ? a5[1] : z, lane);
+}
+
 // Particles per block: every slice row a wave streams from the bank is used for NQ particles from registers (the bank is
 // re-read by every block, 141 MB per block at the default grid: with one particle per block the L2 -> L1 path, not the vector
 // unit, set the pace).  Two particles keep W tables of 2 x 64 KB in LDS; 512 threads (two waves per SIMD, 139 registers)
@@ -745,11 +764,14 @@ __device__ __forceinline__ float reduce_halving(float (&v)[NV], int lane) {
 // row pair: sum_ky Q e^{i 2 pi ky j/Ns} = sum_t (Q(+t) + Q(-t)) cos + i (Q(+t) - Q(-t)) sin, accumulated in the
 // (A, Bq) basis — 8 FMA per shift row j and row PAIR for both orientations — and recombined once per slice;
 // the sum over kx of the shift window is a wavefront halving reduction.
-template <int R, bool HALF>
+// TWO (search bands of at most 32 pixels, e.g. PYP's default 10 A limit on a 256 box): a wave takes TWO slices at once, lanes 0-31 one,
+// lanes 32-63 the other (kx = lane & 31), so that no lane sits beyond the band; every cross-lane step then stays inside a half.
+template <int R, bool HALF, bool TWO>
 __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
     constexpr int NT = global_threads(R), NW = NT / 64, U = global_unroll(R), NS = 2 * R + 1, NQ = global_particles(R);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, p0 = blockIdx.x * NQ;
+    const int sub = TWO ? lane >> 5 : 0, kxl = TWO ? lane & 31 : lane;       // which of the wave's two slices, and the column, this lane works on
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: slice addresses stay in SGPRs
     const int Hs = P.Hs, HsP = P.HsP, Bs = P.Bs, Ns = P.Ns, nsampP = HsP * 64;
     const int nslices = P.n_dir * P.npsi_store;
@@ -778,7 +800,7 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
     float txc[R + 1], txs[R + 1];      // per-lane x twiddles e^{+2 pi i kx j / Ns}
 #pragma unroll
     for (int j = 0; j <= R; j++) {
-        float2 t = P.twN[(lane * j) & (Ns - 1)];
+        float2 t = P.twN[(kxl * j) & (Ns - 1)];
         txc[j] = t.x; txs[j] = t.y;
     }
     const RowTwPtr c_rowtw = (RowTwPtr)P.rowtw;
@@ -786,14 +808,18 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
     // here): no load stall at a slice start, and the prefetch of every step is unconditional (a conditional one made the
     // compiler copy the 8 row registers of the untouched set on every step).
     float2 pv[U], pn[U];
-    if (wave < nslices) {
-        const float2 *P0 = P.bank + (size_t)wave * nsampP;
+    const int nsl = TWO ? (nslices + 1) / 2 : nslices;             // trips of the slice loop over all waves
+    auto my_slice = [&](int s) { return TWO ? min(2 * s + sub, nslices - 1) : s; };     // the slice this lane reads on trip s (an odd last one is read twice)
+    if (wave < nsl) {
+        const float2 *P0 = P.bank + (size_t)my_slice(wave) * nsampP;
 #pragma unroll
-        for (int u = 0; u < U; u++) pv[u] = P0[u * 64 + lane];
+        for (int u = 0; u < U; u++) pv[u] = P0[u * 64 + kxl];
     }
-    for (int sl = wave; sl < nslices; sl += NW) {
-        const float2 *Pp = P.bank + (size_t)sl * nsampP;          // wave-uniform base, lane added as a 32-bit offset
-        const float2 *Pnext = P.bank + (size_t)(sl + NW < nslices ? sl + NW : sl) * nsampP;
+    for (int sl = wave; sl < nsl; sl += NW) {
+        const int msl = my_slice(sl);
+        const bool live = !TWO || 2 * sl + sub < nslices;
+        const float2 *Pp = P.bank + (size_t)msl * nsampP;         // wave-uniform base (per half when TWO), column added as a 32-bit offset
+        const float2 *Pnext = P.bank + (size_t)my_slice(sl + NW < nsl ? sl + NW : sl) * nsampP;
         // accumulators (packed re/im pairs) per particle: s* = sum over rows (shift row 0); per j: even part x cos (ua, ub),
         // odd part x sin (va, vb)
         v2f sa[NQ], sb[NQ], ua[NQ][R], ub[NQ][R], va[NQ][R], vb[NQ][R];
@@ -810,7 +836,7 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
             {
                 const float2 *np = (row0 + U < HsP) ? Pp + (row0 + U) * 64 : Pnext;     // scalar base; the row offsets below fit the 12-bit immediate
 #pragma unroll
-                for (int u = 0; u < U; u++) nxt[u] = np[u * 64 + lane];
+                for (int u = 0; u < U; u++) nxt[u] = np[u * 64 + kxl];
             }
             // the (wave-uniform) twiddles of the NEXT row pair are requested before this pair is consumed
             v4f tw[R], twn[R];
@@ -819,7 +845,7 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
             // ... and so are the particles' W rows (LDS) of the next pair
             float2 wa[NQ], wb[NQ];
 #pragma unroll
-            for (int q = 0; q < NQ; q++) { wa[q] = Wl[q * nsampP + row0 * 64 + lane]; wb[q] = Wl[q * nsampP + (row0 + 1) * 64 + lane]; }
+            for (int q = 0; q < NQ; q++) { wa[q] = Wl[q * nsampP + row0 * 64 + kxl]; wb[q] = Wl[q * nsampP + (row0 + 1) * 64 + kxl]; }
 #pragma unroll
             for (int u = 0; u < U; u += 2) {
                 const int ra = row0 + u, tp = ra >> 1;
@@ -830,7 +856,7 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
 #pragma unroll
                     for (int j = 0; j < R; j++) twn[j] = c_rowtw[(tp + 1) * PPM_MAX_SHIFT_STEPS + j];
 #pragma unroll
-                    for (int q = 0; q < NQ; q++) { wan[q] = Wl[q * nsampP + (ra + 2) * 64 + lane]; wbn[q] = Wl[q * nsampP + (ra + 3) * 64 + lane]; }
+                    for (int q = 0; q < NQ; q++) { wan[q] = Wl[q * nsampP + (ra + 2) * 64 + kxl]; wbn[q] = Wl[q * nsampP + (ra + 3) * 64 + kxl]; }
                 }
                 const float pax = cur[u].x, pay = cur[u].y, pbx = cur[u + 1].x, pby = cur[u + 1].y;
 #pragma unroll
@@ -857,10 +883,10 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
         __builtin_amdgcn_s_setprio(3);
         for (int row0 = 0; row0 < HsP; row0 += 2 * U) { step(row0, pv, pn); step(row0 + U, pn, pv); }      // HsP is a multiple of 2 U
         __builtin_amdgcn_s_setprio(0);          // the reduction tail is a chain of dependent cross-lane steps: let it issue first
-        const int dir = sl / P.npsi_store, ks = sl - dir * P.npsi_store;
+        const int dir = msl / P.npsi_store, ks = msl - dir * P.npsi_store;
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
-            const float nP = c_nP[q][sl];
+            const float nP = c_nP[q][msl];
             const float sax = sa[q].x, say = sa[q].y, sbx = sb[q].y, sby = -sb[q].x;
             float uax[R], uay[R], ubx[R], uby[R], vax[R], vay[R], vbx[R], vby[R];
 #pragma unroll
@@ -870,7 +896,7 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
             }
             const float inv = (nP > 0.f && nI[q] > 0.f) ? rsqrtf(nP * nI[q]) : 0.f;
             float *ccp = P.cc + (size_t)pq[q] * P.n_orient; int *shp = P.sh + (size_t)pq[q] * P.n_orient;
-            if constexpr (HALF && NS * NS <= 64) {
+            if constexpr (!TWO && HALF && NS * NS <= 64) {
                 // both orientations of the stored slice at once, in the halves of packed registers (.x: psi, sg = +1; .y: psi + 180 deg,
                 // sg = -1): Q = A + sg Bq, U = ua + sg ub, V = va + sg vb; G(+j) = U + iV, G(-j) = U - iV;
                 // value(iy, ix) = Re(G[iy] e^{+2 pi i kx (ix-R)/Ns})
@@ -913,13 +939,13 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
                         shp[o] = (bsx_ & 0xffff) | (bsy_ << 16);
                     }
                 }
-            } else if constexpr (NS * NS > 64) {
+            } else if constexpr (TWO || NS * NS > 64) {
                 // wide windows (R > 3, up to 17 x 17 shifts): the window is reduced ROW BY ROW — the NS values of a window row (both
                 // orientations in the halves of packed registers) go through one halving reduction, lane bitrev6(ix) ends up with the
                 // row's total for shift column ix and keeps a running best over the rows.  (A wave-wide sum per shift — 289 of them per
                 // orientation at R = 8 — kept so many values alive that the kernel spilled 1.8 KB per thread.)
                 const v2f sg2 = { 1.f, -1.f };
-                const int vi = (int)(__brev((unsigned)lane) >> 26), ix = vi;
+                const int vi = TWO ? (int)(__brev((unsigned)kxl) >> 27) : (int)(__brev((unsigned)lane) >> 26), ix = vi;
                 const int ax = ix - R < 0 ? R - ix : ix - R;
                 const bool incol = vi < NS && ax <= P.RSx;
                 float bestv[2] = { -3.0e38f, -3.0e38f }; int besty[2] = { 0, 0 };
@@ -941,7 +967,8 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
                         val[R + j] = pc - qs;
                         val[R - j] = pc + qs;
                     }
-                    const v2f tot = reduce_halving2<NS>(val, lane);
+                    v2f tot;
+                    if constexpr (TWO) tot = reduce_halving2h<NS>(val, lane); else tot = reduce_halving2<NS>(val, lane);
                     const bool ok = incol && ja <= P.RSy;
 #pragma unroll
                     for (int e = 0; e < (HALF ? 2 : 1); e++) {
@@ -951,11 +978,12 @@ __global__ void __launch_bounds__(global_threads(R)) k_global(GlobP P) {
                 }
 #pragma unroll
                 for (int e = 0; e < (HALF ? 2 : 1); e++) {
-                    const float best = wave_max(bestv[e]);
-                    int ci = wave_min(bestv[e] == best ? besty[e] * NS + vi : 1 << 20);      // ties -> lower (sy, sx) index
+                    const float best = TWO ? half_max(bestv[e]) : wave_max(bestv[e]);
+                    const int key = bestv[e] == best ? besty[e] * NS + vi : 1 << 20;
+                    int ci = TWO ? half_min(key) : wave_min(key);                              // ties -> lower (sy, sx) index
                     if (ci >= NS * NS) ci = R * NS + R;                                       // no comparable value (NaN scores): the centre
                     const int bsy_ = ci / NS - R, bsx_ = ci - (ci / NS) * NS - R;
-                    if (lane == 0 && (q == 0 || p0 + q < P.n)) {
+                    if (kxl == 0 && live && (q == 0 || p0 + q < P.n)) {
                         int o = dir * P.n_psi + ks + e * P.npsi_store;
                         ccp[o] = best * inv;
                         shp[o] = (bsx_ & 0xffff) | (bsy_ << 16);

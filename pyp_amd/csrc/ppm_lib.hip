@@ -326,19 +326,20 @@ static int launch_prep(const float *d_images, const double *d_rows, int n_img, c
     return 0;
 }
 
-template <int R>
-static int launch_global_r(const GlobP &P, int n_img, bool half, size_t lds) {
-    if (half) {
-        static bool set = false;
-        if (!set) { HIPCHK(hipFuncSetAttribute((const void *)k_global<R, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; }
-        hipLaunchKernelGGL((k_global<R, true>), dim3((n_img + global_particles(R) - 1) / global_particles(R)), dim3(global_threads(R)), lds, g.stream, P);
-    } else {
-        static bool set = false;
-        if (!set) { HIPCHK(hipFuncSetAttribute((const void *)k_global<R, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; }
-        hipLaunchKernelGGL((k_global<R, false>), dim3((n_img + global_particles(R) - 1) / global_particles(R)), dim3(global_threads(R)), lds, g.stream, P);
-    }
+template <int R, bool HALF, bool TWO>
+static int launch_global_k(const GlobP &P, int n_img, size_t lds) {
+    static bool set = false;
+    if (!set) { HIPCHK(hipFuncSetAttribute((const void *)k_global<R, HALF, TWO>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; }
+    hipLaunchKernelGGL((k_global<R, HALF, TWO>), dim3((n_img + global_particles(R) - 1) / global_particles(R)), dim3(global_threads(R)), lds, g.stream, P);
     HIPCHK(hipGetLastError());
     return 0;
+}
+template <int R>
+static int launch_global_r(const GlobP &P, int n_img, bool half, size_t lds) {
+    // search bands of at most 32 pixels: two slices per wave (k_global<.., TWO>); PPM_GLOBAL_TWO=0 keeps one
+    const bool two = P.Bs <= 31 && !(getenv("PPM_GLOBAL_TWO") && atoi(getenv("PPM_GLOBAL_TWO")) == 0);
+    if (two) return half ? launch_global_k<R, true, true>(P, n_img, lds) : launch_global_k<R, false, true>(P, n_img, lds);
+    return half ? launch_global_k<R, true, false>(P, n_img, lds) : launch_global_k<R, false, false>(P, n_img, lds);
 }
 
 static int launch_global(GlobP &P, int n_img, bool half, int R) {
