@@ -2,7 +2,8 @@
 mean score of the projections taken at that exposure, the side files `reconstruct3d` exchanges with the caller.
 
 compute_global_weights restates src/pyp/inout/metadata/core.py:3039-3075: one float per exposure index (TIND, scanning
-order) = mean SCORE of the rows with OCC > 0 at that index, -1.0 where there are none.  How the absent reconstruct3d turns
+order) = mean SCORE of the rows with OCC > 0 at that index, -1.0 where there are none; pinned by the reference's own output
+(tests/golden/golden_r03.json "global_weights", tests/test_golden_r03.py).  How the absent reconstruct3d turns
 them into frequency weights is not visible in the reference; the rule used here is stated in include/ppm.h (ppm_recon_cfg):
 exposure t is attenuated by q_t ^ (F min(1, (s / (transition s_Nyquist))^2)) with q_t = weight_t / max weight - build-defined,
 parity unpinned.

@@ -1,14 +1,14 @@
-"""Score-based particle selection between refinement and reconstruction (SURVEY.md §8f-2), numpy only.
+"""Score-based particle selection between refinement and reconstruction (SURVEY.md §8f-2, H9), numpy only.
 
-Restates the single-particle branch of `shape_phase_residuals` (src/pyp/analysis/scores.py:300-761, called with
-`scores=True` by `call_shape_phase_residuals`, :764-825): particles whose SCORE falls below a per-(orientation, defocus)-group
-threshold, or outside the score / defocus / azimuth / frame windows, get OCCUPANCY 0, which is how `reconstruct3d`
-(`ppm_insert_batch`) is told to skip them.  PARITY UNPINNED: the reference module cannot be imported under Python 3.10
-(its import chain reaches an f-string that needs 3.12) and the tree holds no fixture for it; the tests check the rule on
-hand-made tables.  The bimodal automatic threshold (`threshold == 0`, `optimal_threshold` of
-src/pyp/analysis/statistics.py:10-150) IS pinned: that module imports, and tests/golden/golden_r02.json holds its output on
-seeded samples.  The tomography branch (per-particle mean scores over the low tilts, scores.py:437-462, :480-495, :572-607) is
-restated from the text.  Not restated: match-stack sorting, the consistency filter and the plots.
+Restates `shape_phase_residuals` (src/pyp/analysis/scores.py:300-761, called with `scores=True` by
+`call_shape_phase_residuals`, :764-825): particles whose SCORE falls below a per-(orientation, defocus)-group threshold, or
+outside the score / defocus / azimuth / frame / tilt windows, get OCCUPANCY 0, which is how `reconstruct3d`
+(`ppm_insert_batch`) is told to skip them.  PINNED: tests/golden/gen_golden_r03.py runs the reference's own function on
+240 single-particle rows and 336 tomography rows (thresholds 0 / fraction / 1, groups, every window, odd / even, pooled
+particle indices); tests/test_golden_r03.py reproduces its OCCUPANCY column exactly and POSITION_IN_STACK as it leaves it.
+The bimodal automatic threshold (`threshold == 0`, `optimal_threshold` of src/pyp/analysis/statistics.py:10-150) is pinned
+on its own by tests/golden/golden_r02.json.  Not restated: match-stack sorting, the consistency filter (both off in
+`call_shape_phase_residuals`) and the plots.
 """
 import math
 
@@ -71,6 +71,24 @@ def optimal_threshold(samples, criteria="optimal"):
     if "min" in criteria:
         return float(minimum)
     return float(np.mean(gmm.means_))
+
+
+def tilt_angles_from_table(rows, table):
+    """Per-row tilt angle from the `<job>_rNN.json` side-car (`{film: {TIND: angle}}`, particle_cspt.py:434-456) the way
+    scores.py:340-377 does it: the data set counts as tomography when any angle of the FIRST film of the table is non-zero;
+    otherwise every row gets 0.  Rows whose film or TIND is missing from the table get NaN (pandas' map), which no window keeps."""
+    rows = np.asarray(rows, dtype=np.float64)
+    first = next(iter(table.values())) if table else {}
+    if not any(abs(float(v)) > 0 for v in first.values()):
+        return np.zeros(rows.shape[0])
+    film = rows[:, COL["IMAGE_IS_ACTIVE"]].astype(np.int64)
+    tind = rows[:, C_TIND].astype(np.int64)
+    out = np.full(rows.shape[0], np.nan)
+    for f in np.unique(film):
+        ang = {int(k): float(v) for k, v in table.get(str(int(f)), {}).items()}
+        m = film == f
+        out[m] = [ang.get(int(t), np.nan) for t in tind[m]]
+    return out
 
 
 def _mean_by_particle(scores, pind):
@@ -156,6 +174,7 @@ def select_particles(rows, threshold, angles=1, defocuses=1, mindefocus=0.0, max
         occ[::2] = 0.0
     if even:
         occ[1::2] = 0.0
-    if renumber:      # the reference assigns POSITION_IN_STACK after it has already stored the table (:755-759): off by default
+    if renumber:      # what the reference does when the output name ends in `_used.cistem` (:755-759; set_data keeps a view, so the
+        # assignment after it still lands in the table that is written — seen in the generated fixtures)
         out[:, C_POS] = np.arange(1, M + 1)
     return out

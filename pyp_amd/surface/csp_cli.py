@@ -8,10 +8,15 @@ The program reads its settings from `.pyp_config.toml` in the working directory,
 config/pyp_config.toml:6241-6641) and the current map from $PYP_SCRATCH/<data_set>_frames_CSP_01.mrc (align/core.py:916-931).
 
 Modes (src/pyp/align/core.py:1015-1023 and the 2 -> 5, 3 -> 6 remaps of local_run.py:332-335, :413, :428):
-   -2  extract the projections of particles first..last from the tilt series into <stack>
-    1 / 2 / 5  particle rotations / 3-D shifts / both, particles first..last (PIND)
+   -2  extract the projections of particles first..last from the tilt series (<images> = .mrc) or from the movies of a
+       frame list (<images> = frames_csp.txt, one movie per tilt: section FIND of movie IMIND) into <stack>
+    1 / 2 / 5  particle rotations / 3-D shifts / both, particles first..last (PIND); 8 / 7 = 1 / 2 (the caller's region codes)
     0 / 3 / 6  tilt angle + axis / image shifts / both, tilts first..last (TIND; last = -1: up to the end)
     4  one defocus offset per tilt (csp_ToleranceMicrographDefocus1 either side, 50 A steps), tilts first..last
+Region-based ("patch") refinement (align/core.py:1106-1151, local_run.py:327-404): <param> is one of the
+`<name>_regionNNNN.cistem` files of particle_cspt.split_parameter_file — the rows of the region's particles with RIND = the
+region's index, the tilts of its extended file re-keyed (TIND, RIND) — and every job refines ONE particle (mode 5, first =
+last = PIND) or ONE tilt of the region (modes 6 / 3 / 4, first = last = TIND), scored on the region's rows only.
 Outputs of a refinement mode: <param>_<first:06d>_<last:06d>.cistem with the rows of the refined units only and its
 _extended twin holding only the refined units' block entries (the caller merges them over the original,
 src/pyp/refine/csp/particle_cspt.py:96-138 -> cistem_star_file.py:655-692).
@@ -85,16 +90,53 @@ def _out_names(param_file, first, last):
     return "%s_%06d_%06d.cistem" % (base, first, last), "%s_%06d_%06d_extended.cistem" % (base, first, last)
 
 
+def split_command(command):
+    """'<csp> a b c … > <log>' as create_csp_split_commands formats it (local_run.py:364-376, :392-404, :451-463) ->
+    (argv incl. the program, log file)."""
+    left, _, log = command.partition(" > ")
+    return left.split(), log.strip()
+
+
+def parse_argv(argv):
+    """The eight positional arguments; raises ValueError with an ERROR line."""
+    if len(argv) != 8:
+        raise ValueError("ERROR: csp: usage: csp <param.cistem> <param_extended.cistem> <mode> <first> <last> <flag> <images> <stack>")
+    param_file, ext_file, mode_s, first_s, last_s, flag, images, stack = argv
+    try:
+        mode, first, last = float(mode_s), int(first_s), int(last_s)
+    except ValueError:
+        raise ValueError(f"ERROR: csp: mode / first / last must be numbers, got {mode_s} {first_s} {last_s}")
+    return dict(param_file=param_file, ext_file=ext_file, mode=int(mode) if mode == int(mode) else mode, first=first, last=last, flag=flag,
+                images=images, stack=stack)
+
+
+def merge_alignment_parameters(outputs, outputs_extended):
+    """What the caller does with the per-job files (particle_cspt.py:96-138 -> cistem_star_file.py:655-692): rows of the
+    outputs in the given (sorted) order stacked and sorted by POSITION_IN_STACK; particle entries and (TIND, RIND) tilt entries
+    of the extended files merged in order, later files overwriting earlier ones (the ORIGINAL extended file goes first).
+    Returns (rows, particles [P, 12], tilts [T, 6]) with the blocks in first-seen key order, as the dictionaries keep them."""
+    rows = np.vstack([cistem.read_parameters(f) for f in outputs])
+    rows = rows[np.argsort(rows[:, C["POSITION_IN_STACK"]])]
+    particles, tilts = {}, {}
+    for f in outputs_extended:
+        e = cistem.read_extended(f)
+        for p in e["particles"]:
+            particles[int(p[0])] = p
+        for t in e["tilts"]:
+            tilts.setdefault(int(t[0]), {})[int(t[1])] = t
+    pb = np.array(list(particles.values())).reshape(-1, len(cistem.PARTICLE_COLUMNS))
+    tb = np.array([t for d in tilts.values() for t in d.values()]).reshape(-1, len(cistem.TILT_COLUMNS))
+    return rows, pb, tb
+
+
 def csp_main(argv=None):
     t0 = time.time()
     argv = list(sys.argv[1:] if argv is None else argv)
-    if len(argv) != 8:
-        _die("ERROR: csp: usage: csp <param.cistem> <param_extended.cistem> <mode> <first> <last> <flag> <images> <stack>")
-    param_file, ext_file, mode_s, first_s, last_s, flag, images, stack = argv
     try:
-        mode, first, last = int(float(mode_s)), int(first_s), int(last_s)
-    except ValueError:
-        _die(f"ERROR: csp: mode / first / last must be integers, got {mode_s} {first_s} {last_s}")
+        a = parse_argv(argv)
+    except ValueError as e:
+        _die(str(e))
+    param_file, ext_file, mode, first, last, flag, images, stack = (a[k] for k in ("param_file", "ext_file", "mode", "first", "last", "flag", "images", "stack"))
     print("\n        **   Welcome to CSP (MI355X / libpypmatch)   **\n")
     print(f"parameters {param_file}\nextended   {ext_file}\nmode {mode}  first {first}  last {last}  flag {flag}\nimages {images}\nstack  {stack}")
     for pth in (param_file, ext_file, ".pyp_config.toml"):
@@ -108,6 +150,11 @@ def csp_main(argv=None):
     particles, tilts = ext["particles"], ext["tilts"]
     if mode == -2:
         return _extract(s, rows, first, last, images, stack, t0)
+    if mode == -2.1:
+        _die("ERROR: csp: mode -2.1 (running frame averages, frealign/<name>_stack_weighted_average.mrc, align/core.py:1000-1001, :1170) is not built")
+    # the caller's own codes for region-based refinement (align/core.py:1121-1133: 7 = particle shifts, 8 = particle rotations)
+    # normally arrive already mapped to 2 / 1 (and then 2 -> 5 by local_run.py:334-335); accepted as given as well
+    mode = {7: 2, 8: 1}.get(mode, mode)
     if mode not in (0, 1, 2, 3, 4, 5, 6):
         _die(f"ERROR: csp: unknown mode {mode}")
     unit = CSP_PARTICLES if mode in (1, 2, 5) else CSP_MICROGRAPHS
@@ -170,10 +217,8 @@ def csp_main(argv=None):
 def _extract(s, rows, first, last, images, stack, t0):
     """Mode -2: boxes of `extract_box` pixels around (ORIGINAL_X_POSITION, ORIGINAL_Y_POSITION) of section IMIND of the tilt
     series, normalised like every PYP particle stack (src/pyp/analysis/image.py:406-417), written in row order."""
-    if not str(images).endswith(".mrc"):
-        _die("ERROR: csp: frame lists (frames_csp.txt) are not supported; give the tilt-series .mrc")
     if not os.path.exists(images):
-        _die(f"ERROR: csp: tilt series {images} does not exist")
+        _die(f"ERROR: csp: {'frame list' if str(images).endswith('.txt') else 'tilt series'} {images} does not exist")
     if s["extract_bin"] != 1:
         _die("ERROR: csp: extract_bin other than 1 is not supported")
     hi = last if last >= 0 else np.inf
@@ -181,6 +226,8 @@ def _extract(s, rows, first, last, images, stack, t0):
     if len(sel) == 0:
         _die(f"ERROR: csp: no rows with PIND in {first}..{last}")
     r = rows[sel]
+    if str(images).endswith(".txt"):
+        return _extract_frames(s, r, first, last, images, stack, t0)
     series = mrc.mmap(images)
     if series.ndim == 2:
         series = series[None]
@@ -201,5 +248,45 @@ def _extract(s, rows, first, last, images, stack, t0):
         _die(str(e))
     mrc.write(out, stack, pixel_size=px)
     print(f"\nExtracted {len(r)} projections of particles {first}..{last} into {stack} in {time.time() - t0:.1f} s")
+    print("\nCSP: Normal termination\n", flush=True)
+    return 0
+
+
+def _extract_frames(s, r, first, last, images, stack, t0):
+    """Mode -2 from a frame list (`frames_csp.txt`, written by src/pyp/extract/core.py:620-625: one movie file per line, in
+    tilt-series order): a row is cut out of section FIND of movie IMIND, at (ORIGINAL_X_POSITION + FSHIFT_X, ORIGINAL_Y_POSITION
+    + FSHIFT_Y) rounded down like the box corner itself.  The reference's own use of the list lives in the absent binary; this
+    assignment of the IMIND / FIND / FSHIFT columns (cistem_star_file.py:596-628) is build-defined."""
+    with open(images) as f:
+        movies = [ln.strip() for ln in f if ln.strip()]
+    if not movies:
+        _die(f"ERROR: csp: frame list {images} is empty")
+    box, px = s["box"], s["pixel"]
+    from .. import host, lib
+    dev = int(os.environ.get("PPM_DEVICE", "0"))
+    out = np.empty((len(r), box, box), dtype=np.float32)
+    im_all, fr_all = r[:, C["IMIND"]].astype(np.int64), r[:, C["FIND"]].astype(np.int64)
+    try:
+        with gpu_lock(dev):
+            lib.init(dev)
+            for im in np.unique(im_all):
+                if im < 0 or im >= len(movies):
+                    _die(f"ERROR: csp: row asks for movie {im}, {images} lists {len(movies)}")
+                if not os.path.exists(movies[im]):
+                    _die(f"ERROR: csp: movie {movies[im]} of {images} does not exist")
+                mv = mrc.mmap(movies[im])
+                if mv.ndim == 2:
+                    mv = mv[None]
+                for fr in np.unique(fr_all[im_all == im]):
+                    if fr < 0 or fr >= mv.shape[0]:
+                        _die(f"ERROR: csp: row asks for frame {fr}, {movies[im]} has {mv.shape[0]}")
+                    idx = np.where((im_all == im) & (fr_all == fr))[0]
+                    coords = np.stack([r[idx, C["ORIGINAL_X_POSITION"]] + r[idx, C["FSHIFT_X"]],
+                                       r[idx, C["ORIGINAL_Y_POSITION"]] + r[idx, C["FSHIFT_Y"]]], axis=1)
+                    out[idx] = host.extract_boxes(np.ascontiguousarray(mv[fr], dtype=np.float32), coords, box, s["radius"], px, device=dev)
+    except (lib.PpmError, ValueError) as e:
+        _die(str(e))
+    mrc.write(out, stack, pixel_size=px)
+    print(f"\nExtracted {len(r)} frame projections of particles {first}..{last} from {len(movies)} movies into {stack} in {time.time() - t0:.1f} s")
     print("\nCSP: Normal termination\n", flush=True)
     return 0

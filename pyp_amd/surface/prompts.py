@@ -24,6 +24,18 @@ def read_answers(stream):
     return out
 
 
+def split_heredoc(command):
+    """A command string exactly as PYP builds it — '<dir>/<program> << eot >> <logfile> 2>&1\n<answer>\n...eot\n'
+    (frealign.py:3918-3994, :1780-1824, :1878-1888, :2075-2093) — taken apart into (program, logfile, answers)."""
+    head, _, rest = command.lstrip("\n").partition("\n")
+    prog, sep, tail = head.partition("<<")
+    if not sep:
+        raise PromptError(f"ERROR: not a here-doc command: '{head}'")
+    log = tail.split(">>", 1)[1].replace("2>&1", "").strip() if ">>" in tail else ""
+    import io
+    return prog.strip(), log, read_answers(io.StringIO(rest))
+
+
 def _bool(s, what):
     t = s.strip().lower()
     if t in ("yes", "y", "true", "1"):
@@ -103,7 +115,7 @@ def parse_refine3d(answers):
 
 
 def parse_reconstruct3d(answers):
-    """40 answers, or 44 when dose weighting is switched on (its answer expands to five lines,
+    """39 answers, or 43 when dose weighting is switched on (its answer expands to five lines,
     frealign.py:1731-1753)."""
     a = list(answers)
     head = [("stack", str), ("input_params", str), ("global_stats", str), ("reference", str), ("map1", str), ("map2", str),

@@ -175,3 +175,126 @@ def test_csp_executable_extracts_then_refines_like_the_caller_drives_it(tmp_path
     assert csp(par, ext, 4, 0, 0, 1, "frealign/ts.mrc", "frealign/ts_stack.mrc", log="csp4.log") == 0
     assert csp(par, ext, 9, 0, 0, 1, "frealign/ts.mrc", "frealign/ts_stack.mrc", log="csp9.log") != 0
     assert "ERROR" in (tmp_path / "csp9.log").read_text()
+
+
+def test_region_split_2x2x1_end_to_end_like_the_caller(tmp_path):
+    """Region-based refinement as csp_run_refinement drives it (align/core.py:1106-1151): the series is split into a 2 x 2 x 1
+    grid (regions.split_parameter_file = particle_cspt.py:141-208), `csp` runs once per (region, particle) in mode 5 and once per
+    (region, tilt) in mode 6 with the command lines of create_csp_split_commands (local_run.py:327-404), the outputs match the
+    caller's glob `_region????_??????_??????` and merge through Parameters.merge's rule; every job equals the ORACLE run on the
+    region's rows.  A frame list (`frames_csp.txt`) feeds the same extraction as the tilt-series file."""
+    import fnmatch
+    from oracle import oracle as O
+    from pyp_amd import regions
+    from pyp_amd.surface import csp_cli
+    n, px = 64, 2.0
+    vol, stack, rows, parts, tilts = synth.make_tilt_series(n, 6, np.arange(-40, 41, 20.0), pixel=px, snr=0.3, seed=11)
+    imgs = stack.numpy()
+    p2 = _perturb_particles(parts)
+    rng = np.random.default_rng(8)
+    t2 = tilts.copy()
+    t2[:, 2:4] += rng.normal(0, 1.0, (len(t2), 2))
+    rows2 = synth.csp_rows_from_params(rows, parts, tilts, p2, t2)
+    (tmp_path / "frealign" / "maps").mkdir(parents=True)
+    scratch = tmp_path / "scratch"; scratch.mkdir()
+    mrc.write(vol, str(scratch / "tomo_frames_CSP_01.mrc"), pixel_size=px)
+    mrc.write(imgs, str(tmp_path / "frealign" / "ts_stack.mrc"), pixel_size=px)
+    par = "frealign/maps/ts_r01_02.cistem"
+    cistem.write_parameters(str(tmp_path / par), rows2)
+    cistem.write_extended(str(tmp_path / par.replace(".cistem", "_extended.cistem")), p2, t2)
+    (tmp_path / ".pyp_config.toml").write_text(
+        'data_set = "tomo"\nscope_pixel = 2.0\ndata_bin = 1\nextract_bin = 1\nextract_box = 64\nparticle_rad = 51.2\nparticle_mw = 300\n'
+        'refine_iter = 2\nrefine_rlref = 0.0\nrefine_rhref = "5.3333333:4"\nrefine_fboost = false\ncsp_UseImagesForRefinementMin = 0\n'
+        'csp_UseImagesForRefinementMax = -1\ncsp_ToleranceParticlesPsi = 8.0\ncsp_ToleranceParticlesTheta = 8.0\ncsp_ToleranceParticlesPhi = 8.0\n'
+        'csp_ToleranceParticlesShifts = 8.0\ncsp_ToleranceMicrographTiltAngles = 1.5\ncsp_ToleranceMicrographTiltAxisAngles = 1.0\n'
+        'csp_ToleranceMicrographShifts = 8.0\ncsp_OptimizerStepTolerance = 0.01\nreconstruct_norm = true\nrefine_invert = false\n')
+    env = dict(os.environ, PYP_SCRATCH=str(scratch))
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        bl, tr = regions.find_specimen_bounds(p2, [1000, 1000, 1000])
+        corners, size = regions.divide_regions(bl, tr, split_x=2, split_y=2, split_z=1)
+        split = regions.split_parameter_file(rows2, p2, t2, par, regions.sort_particles_regions(p2, corners, size))
+    finally:
+        os.chdir(cwd)
+    assert 2 <= len(split) <= 4 and sorted(int(p) for s in split for p in s[1]) == list(range(6))
+    cfg = RefineCfg.make(box=n, pixel_size=px, molecular_mass_kda=300, mask_radius=51.2, res_high=5.3333333, res_signed_cc=30.0, global_search=0)
+    oref = O.Reference(vol, n / 2)
+
+    def run_all(cmds, log):
+        for c in cmds:
+            argv, _ = csp_cli.split_command(c)
+            r = subprocess.run(f"{' '.join(argv)} >> {log} 2>&1", shell=True, cwd=tmp_path, env=env)
+            assert r.returncode == 0, (tmp_path / log).read_text()[-1500:]
+
+    # ---- outer mode 7 -> 2 -> argv mode 5: one job per particle of every region
+    cmds, _ = regions.csp_split_commands(f"{BIN}/csp", split, 2, "ts_r01_02", "frealign/ts_stack.mrc", list(range(6)), list(range(5)))
+    assert len(cmds) == 6 and all(" 5 " in c for c in cmds)
+    run_all(cmds, "csp5.log")
+    outs = sorted(str(p) for p in (tmp_path / "frealign/maps").glob("ts_r01_02_region????_??????_??????.cistem"))
+    assert len(outs) == 6 and all(fnmatch.fnmatch(os.path.basename(o), "ts_r01_02_region????_??????_??????.cistem") for o in outs)
+    outs_ext = [str(tmp_path / par.replace(".cistem", "_extended.cistem"))] + [o.replace(".cistem", "_extended.cistem") for o in outs]
+    rows_m, pm, tm = csp_cli.merge_alignment_parameters(outs, outs_ext)
+    assert rows_m.shape == rows2.shape and np.array_equal(rows_m[:, 0], rows2[:, 0]) and len(pm) == 6
+    # the oracle on each region file, particle by particle
+    for fn, pinds, tinds in split:
+        rr = cistem.read_parameters(str(tmp_path / fn))
+        ee = cistem.read_extended(str(tmp_path / fn.replace(".cistem", "_extended.cistem")))
+        ri = imgs[rr[:, 0].astype(int) - 1]
+        for p in pinds:
+            cc = CspCfg.make(CSP_PARTICLES, tol_angle=(8, 8, 8), tol_shift=4.0, first=int(p), last=int(p))
+            sel = rr[:, 26] == p
+            wr, wp, wt, _ = O.csp_refine(oref, cfg, cc, ri[sel], rr[sel], ee["particles"], ee["tilts"])
+            got_p = pm[pm[:, 0] == p]
+            want_p = wp[wp[:, 0] == p]
+            assert _particle_angle_err(want_p, got_p).max() < 0.1 and np.abs(want_p[:, 1:4] - got_p[:, 1:4]).max() < 0.5
+            gr = rows_m[np.isin(rows_m[:, 0], rr[sel][:, 0])]
+            assert synth.angular_error_deg(wr, gr).max() < 0.1 and synth.shift_error_px(wr, gr, px).max() < 0.5
+    assert _particle_angle_err(pm, parts).mean() < 0.5 * _particle_angle_err(p2, parts).mean()
+    # the merged rows carry RIND = their region, so the (TIND, region) tilt entries must come along with the particle jobs' outputs
+    assert len(tm) == len(t2) * (1 + len(split)) and set(rows_m[:, 28].astype(int)) == set(range(len(split)))
+    # ---- outer mode 5 -> 3 -> argv mode 6: one job per (region, tilt); merged tilts are keyed (TIND, region)
+    for f in outs:
+        os.remove(f); os.remove(f.replace(".cistem", "_extended.cistem"))
+    cmds, _ = regions.csp_split_commands(f"{BIN}/csp", split, 3, "ts_r01_02", "frealign/ts_stack.mrc", list(range(6)), list(range(5)))
+    assert len(cmds) == 5 * len(split) and all(" 6 " in c for c in cmds)
+    run_all(cmds, "csp6.log")
+    outs = sorted(str(p) for p in (tmp_path / "frealign/maps").glob("ts_r01_02_region????_??????_??????.cistem"))
+    assert len(outs) == 5 * len(split)
+    outs_ext = [str(tmp_path / par.replace(".cistem", "_extended.cistem"))] + [o.replace(".cistem", "_extended.cistem") for o in outs]
+    rows_t, pt, tt = csp_cli.merge_alignment_parameters(outs, outs_ext)
+    assert rows_t.shape == rows2.shape and np.array_equal(rows_t[:, 0], rows2[:, 0])
+    keys = sorted((int(t[0]), int(t[1])) for t in tt)
+    assert keys == sorted({(t, 0) for t in range(5)} | {(t, k) for k in range(len(split)) for t in range(5)})
+    fn, pinds, tinds = split[-1]
+    k = len(split) - 1
+    rr = cistem.read_parameters(str(tmp_path / fn))
+    ee = cistem.read_extended(str(tmp_path / fn.replace(".cistem", "_extended.cistem")))
+    ri = imgs[rr[:, 0].astype(int) - 1]
+    for t in (0, 3):
+        cm = CspCfg.make(CSP_MICROGRAPHS, tol_angle=(1.5, 1.0, 0), tol_shift=4.0, first=t, last=t)
+        sel = rr[:, 27] == t
+        wr, wp, wt, _ = O.csp_refine(oref, cfg, cm, ri[sel], rr[sel], ee["particles"], ee["tilts"])
+        want_t = wt[(wt[:, 0] == t) & (wt[:, 1] == k)][0]
+        got_t = tt[(tt[:, 0] == t) & (tt[:, 1] == k)][0]
+        assert np.abs(want_t[4:6] - got_t[4:6]).max() < 0.1 and np.abs(want_t[2:4] - got_t[2:4]).max() < 0.5
+    log = (tmp_path / "csp6.log").read_text() + (tmp_path / "csp5.log").read_text()
+    assert "ERROR" not in log and log.count("CSP: Normal termination") == 6 + 5 * len(split)
+    # ---- frames: the list names one movie per tilt; the same boxes come out as from the tilt-series file
+    series_img, rows_p = synth.paste_tilt_series(stack, rows, len(tilts), (256, 512))
+    mrc.write(series_img, str(tmp_path / "frealign" / "ts.mrc"), pixel_size=px)
+    for t in range(len(tilts)):
+        mrc.write(np.stack([series_img[t] * 0, series_img[t]]), str(tmp_path / "frealign" / f"ts_{t:03d}.mrc"), pixel_size=px)
+    (tmp_path / "frames_csp.txt").write_text("\n".join(f"frealign/ts_{t:03d}.mrc" for t in range(len(tilts))))
+    rows_f = rows_p.copy()
+    rows_f[:, 29] = 1                                           # FIND: the second section of every movie holds the image
+    cistem.write_parameters(str(tmp_path / "frealign/maps/fr_r01_02.cistem"), rows_f)
+    cistem.write_extended(str(tmp_path / "frealign/maps/fr_r01_02_extended.cistem"), parts, tilts)
+    cistem.write_parameters(str(tmp_path / "frealign/maps/ser_r01_02.cistem"), rows_p)
+    cistem.write_extended(str(tmp_path / "frealign/maps/ser_r01_02_extended.cistem"), parts, tilts)
+    run_all([f"{BIN}/csp frealign/maps/fr_r01_02.cistem frealign/maps/fr_r01_02_extended.cistem -2 0 5 1 frames_csp.txt frealign/fr_stack.mrc",
+             f"{BIN}/csp frealign/maps/ser_r01_02.cistem frealign/maps/ser_r01_02_extended.cistem -2 0 5 1 frealign/ts.mrc frealign/ser_stack.mrc"], "csp_frames.log")
+    assert np.array_equal(mrc.read(str(tmp_path / "frealign/fr_stack.mrc")), mrc.read(str(tmp_path / "frealign/ser_stack.mrc")))
+    r = subprocess.run(f"{BIN}/csp frealign/maps/fr_r01_02.cistem frealign/maps/fr_r01_02_extended.cistem -2 0 5 1 missing_frames.txt x.mrc", shell=True,
+                       cwd=tmp_path, env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and "ERROR" in r.stdout and "missing_frames.txt" in r.stdout

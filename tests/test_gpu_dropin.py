@@ -280,8 +280,9 @@ def test_reconstruct3d_likelihood_blurring_and_crop_answers(project):
 
 
 def test_refine3d_verbatim_default_script_matches_oracle(tmp_path):
-    """The script exactly as PYP's default iteration writes it (tests/test_surface_cpu.py:REFINE_CISTEM: global = yes,
-    local = no, 20 hits to refine, D7, 143 particles; frealign.py:3866-3871, :3918-3994) fed through the shell; the
+    """The script exactly as PYP's default iteration writes it — the string frealign.mrefine_version itself produced
+    (tests/golden/golden_r03.json "dropin_box64": global = yes, local = no, 20 hits to refine, D7, 143 particles;
+    frealign.py:3866-3871, :3918-3994) — fed through the shell; the
     refined poses are sub-grid and agree with the oracle run on the parsed answers."""
     import io
     from oracle import oracle
@@ -292,21 +293,21 @@ def test_refine3d_verbatim_default_script_matches_oracle(tmp_path):
     work.mkdir()
     vol = synth.phantom_sym(n, oracle.symmetry_ops("D7"))
     _, stack, truth = synth.make_dataset(n, m, pixel=px, snr=0.3, vol=vol, particle_rad_frac=85.0 / (n * px))
-    mrc.write(stack.numpy(), str(tmp_path / "ds_stack.mrc"), pixel_size=px)
-    mrc.write(vol, str(work / "name_r01.mrc"), pixel_size=px)
+    mrc.write(stack.numpy(), str(tmp_path / "t20s_stack.mrc"), pixel_size=px)
+    mrc.write(vol, str(work / "t20s_r01_01.mrc"), pixel_size=px)
     start = cistem.default_rows(m, px, 300.0, 2.7, 0.07)
     for c in ("DEFOCUS_1", "DEFOCUS_2", "DEFOCUS_ANGLE"):
         start[:, cistem.COL[c]] = truth[:, cistem.COL[c]]
-    cistem.write_parameters(str(work / "name_r01.cistem"), start)
+    cistem.write_parameters(str(work / "t20s_r01_01.cistem"), start)
     assert run("refine3d", REFINE_CISTEM.replace("eot\n", ""), work, "msearch.log") == 0
     log = open(work / "msearch.log").read()
     assert "Refine3D: Normal termination" in log and "ERROR" not in log
-    got = cistem.read_parameters(str(work / "name_r01_0000001_0000143.cistem"))
+    got = cistem.read_parameters(str(work / "t20s_r01_01_0000001_0000143.cistem"))
     assert got.shape == (m, 32)
     d = prompts.parse_refine3d(prompts.read_answers(io.StringIO(REFINE_CISTEM)))
     cfg = cli.refine_cfg_from_answers(d, n)
     assert cfg.global_search == 1 and cfg.local_refine == 0 and cfg.top_hits == 20
-    rin = cistem.read_parameters(str(work / "name_r01.cistem"))
+    rin = cistem.read_parameters(str(work / "t20s_r01_01.cistem"))
     want, counts = oracle.refine_batch(oracle.Reference(vol, n / 2), cfg, stack.numpy(), rin)
     assert counts[1] == 20 * 2 * 12 + 1                       # 20 hits x 2 compass iterations x 12 scores, one final score
     # D7 reference: a grid point on the edge of the asymmetric unit and its symmetry mate score the same up to round-off,

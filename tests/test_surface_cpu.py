@@ -2,6 +2,7 @@
 (src/pyp/refine/frealign/frealign.py:3918-3994, :1780-1824, :1878-1888, :2075-2093;
 src/pyp/system/wrapper_functions.py:512-561), dump files, log table format, error behaviour."""
 import io
+import json
 import os
 import subprocess
 import sys
@@ -13,58 +14,17 @@ from pyp_amd.surface import cli, prompts
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-REFINE_CISTEM = """../ds_stack.mrc
-name_r01.cistem
-null
-name_r01.mrc
-statistics_r01.txt
-no
-no
-name_r01_match.mrc_0000001_0000143
-name_r01_0000001_0000143.cistem
-name_r01_0000001_0000143_changes.cistem
-D7
-1
-143
-1
-4.32
-700
-0
-85
-100.0
-8
-30.0
-8.0
-127.5
-8
-20.0
-20
-0.0
-0.0
-0
-0
-0
-0
-500
-50.0
-1
-yes
-no
-yes
-yes
-yes
-yes
-yes
-no
-no
-no
-no
-no
-no
-no
-no
-eot
-"""
+GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_r03.json")))
+
+
+def golden_script(group, case):
+    """The answer lines of a here-doc the reference's own string builder produced (tests/golden/gen_golden_r03.py)."""
+    cmd = next(c for c in GOLD[group] if c["case"] == case)["script"]
+    return cmd.split("\n", 1)[1]
+
+
+# frealign.mrefine_version with PYP's defaults at box 64 / 4.32 A (frealign.py:3918-3994), generated, not typed
+REFINE_CISTEM = golden_script("refine3d_scripts", "dropin_box64")
 
 # verbatim from src/pyp/system/wrapper_functions.py:512-561
 REFINE_PAR = """../spr_frames_00_04_stack.mrc
@@ -114,55 +74,13 @@ no
 no
 """
 
-RECON = """/scratch/ds_stack.mrc
-name_r01_used.cistem
-null
-name_r01.mrc
-name_r01_map1.mrc
-name_r01_map2.mrc
-output.mrc
-name_r01_n1.res
-C1
-1
-5000
-1.08
-700
-0
-138.24
-2.16
-0
-2.0
-no
-0
--1
-{dose}
-0
-1
-1
-no
-yes
-no
-no
-no
-yes
-yes
-no
-no
-no
-yes
-/scratch/name_r01_map1_n1.mrc
-/scratch/name_r01_map2_n1.mrc
-1
-"""
-
-
 def test_refine3d_cistem_script():
     d = prompts.parse_refine3d(prompts.read_answers(io.StringIO(REFINE_CISTEM)))
     assert d["surface"] == "cistem" and d["symmetry"] == "D7" and (d["first"], d["last"]) == (1, 143)
     assert d["pixel_size"] == 4.32 and d["outer_radius"] == 85 and d["res_high"] == 8 and d["res_search"] == 8
     assert d["angular_step"] == 20.0 and d["top_hits"] == 20 and d["global_search"] and not d["local_refine"]
     assert d["refine_psi"] and d["refine_y"] and not d["invert"] and d["search_mask_radius"] == 127.5
-    assert d["output_params"] == "name_r01_0000001_0000143.cistem"
+    assert d["output_params"] == "t20s_r01_01_0000001_0000143.cistem"
 
 
 def test_focus_mask_answers_reach_the_library_configuration():
@@ -190,11 +108,12 @@ def test_refine3d_par_script_verbatim_from_reference():
 
 
 def test_reconstruct3d_script_with_and_without_dose_weighting():
-    d = prompts.parse_reconstruct3d(prompts.read_answers(io.StringIO(RECON.format(dose="no"))))
-    assert not d["dose_weighting"] and d["res_limit"] == 2.16 and d["score_bfactor"] == 2.0 and d["threads"] == 1
+    """split_reconstruction's own strings (frealign.py:1780-1824); every variant is checked in tests/test_golden_r03.py."""
+    d = prompts.parse_reconstruct3d(prompts.read_answers(io.StringIO(golden_script("reconstruct3d_scripts", "defaults"))))
+    assert not d["dose_weighting"] and d["res_limit"] == 4.32 and d["score_bfactor"] == 2.0 and d["threads"] == 1
     assert d["dump_1"].endswith("_map1_n1.mrc") and d["split_even_odd"] and d["per_particle_splitting"] and d["adjust_scores"]
-    d = prompts.parse_reconstruct3d(prompts.read_answers(io.StringIO(RECON.format(dose="yes\n/scratch/not_provided\nyes\n0.5\n4.0"))))
-    assert d["dose_weighting"] and d["dose_fraction"] == 0.5 and d["dump_2"].endswith("_map2_n1.mrc") and d["threads"] == 1
+    d = prompts.parse_reconstruct3d(prompts.read_answers(io.StringIO(golden_script("reconstruct3d_scripts", "dose_weighting_no_file"))))
+    assert d["dose_weighting"] and d["dose_fraction"] == 0.5 and d["dump_2"].endswith("_map2_n3.mrc") and d["threads"] == 1
 
 
 def test_short_or_bad_scripts_raise():
@@ -246,7 +165,7 @@ def test_merge_log_table_parses_like_the_caller(tmp_path):
 
 def test_executables_fail_loudly_without_inputs(tmp_path):
     """Non-zero exit, a line containing ERROR, and no output file (SURVEY.md §8b 'Errors')."""
-    script = REFINE_CISTEM.replace("name_r01_0000001_0000143.cistem", str(tmp_path / "out.cistem"))
+    script = REFINE_CISTEM.replace("t20s_r01_01_0000001_0000143.cistem", str(tmp_path / "out.cistem"))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bin", "refine3d")], input=script, capture_output=True, text=True, cwd=tmp_path)
     assert r.returncode != 0 and "ERROR" in r.stdout and not (tmp_path / "out.cistem").exists()
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bin", "merge3d")], input="a\nb\n", capture_output=True, text=True, cwd=tmp_path)
