@@ -39,7 +39,10 @@ template <int M> __device__ __forceinline__ void lane_swap(int &a, int &b) {
     else { auto r = __builtin_amdgcn_permlane16_swap((unsigned)a, (unsigned)b, false, false); a = (int)r[0]; b = (int)r[1]; }
 }
 
-// wave64 all-lanes sum / max / min (every lane gets the result)
+// wave64 all-lanes sum / max / min (every lane gets the result).  FULL EXEC REQUIRED: the DPP moves read 0 from an inactive
+// source lane (old = 0, bound_ctrl off) and the permlane swaps exchange whole rows, so these must be called with all 64 lanes
+// active, outside lane-divergent branches — a silently injected 0 would also win a max over negative scores.  Every caller
+// in ppm_kernels*.h sits at wave-uniform control flow.
 __device__ __forceinline__ float wave_sum(float v) {
     v += dpp_mov<kDppXor1>(v); v += dpp_mov<kDppXor2>(v); v += dpp_mov<kDppHalfMirror>(v); v += dpp_mov<kDppMirror>(v);
     float w = v; lane_swap<16>(v, w); v += w;

@@ -75,4 +75,6 @@ def write_scores_txt(path, weights):
     w = np.asarray(weights, dtype=np.float64)
     ok = w > 0
     out = np.where(ok, w / (w[ok].max() if ok.any() else 1.0), -1.0)
-    np.savetxt(path, out.reshape(-1, 1), fmt="%.6f")
+    tmp = path + ".tmp%d" % os.getpid()
+    np.savetxt(tmp, out.reshape(-1, 1), fmt="%.6f")
+    os.replace(tmp, path)

@@ -112,3 +112,23 @@ def mmap(filename):
     h = read_header(filename)
     return np.memmap(filename, dtype=h["dtype"], mode="r", offset=h["data_offset"],
                      shape=(h["nz"], h["ny"], h["nx"]))
+
+
+def create(filename, shape, pixel_size=None, dtype=np.float32):
+    """Pre-size a new MRC file and return a writable memory map of its data block (fill it section by section, `flush()`,
+    then `set_statistics`): a stack larger than host memory is written without ever being held."""
+    h = make_header(shape, dtype, pixel_size)
+    shape = tuple(int(s) for s in shape)
+    with open(filename, "wb") as f:
+        f.write(h.tobytes())
+        f.truncate(1024 + int(np.prod(shape)) * np.dtype(dtype).itemsize)
+    return np.memmap(filename, dtype=np.dtype(dtype).newbyteorder("<"), mode="r+", offset=1024, shape=shape)
+
+
+def set_statistics(filename, amin, amax, amean, rms):
+    """Fill amin / amax / amean / rms of an existing file's header (after a streamed `create`)."""
+    with open(filename, "r+b") as f:
+        h = np.frombuffer(bytearray(f.read(1024)), dtype=_HEADER).copy()
+        h["amin"], h["amax"], h["amean"], h["rms"] = amin, amax, amean, rms
+        f.seek(0)
+        f.write(h.tobytes())

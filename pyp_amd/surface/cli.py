@@ -112,6 +112,14 @@ def _iter_image_chunks(mm, positions, device, chunk=None):
             list(pool.map(lambda ae: part(*ae), zip(cuts[:-1], cuts[1:])))
         return dst
 
+    t, err = None, [None]
+
+    def fill_next(b, lo, hi, slot):
+        try:
+            slot[0] = fill(b, lo, hi)
+        except BaseException as e:          # handed to the consumer: a reader failure must end in the ERROR line, not a traceback
+            err[0] = e
+
     try:
         cur = fill(0, 0, min(chunk, n))
         lo, b = 0, 0
@@ -119,14 +127,20 @@ def _iter_image_chunks(mm, positions, device, chunk=None):
             hi = min(lo + chunk, n)
             nxt, t = [None], None
             if hi < n:
-                t = threading.Thread(target=lambda: nxt.__setitem__(0, fill(1 - b, hi, min(hi + chunk, n))))
+                t = threading.Thread(target=fill_next, args=(1 - b, hi, min(hi + chunk, n), nxt))
                 t.start()
             yield lo, hi, cur
             if t is not None:
                 t.join()
+                t = None
+                if err[0] is not None:
+                    raise ValueError(f"ERROR: reading the particle stack failed: {err[0]}")
                 cur, b = nxt[0], 1 - b
             lo = hi
     finally:
+        # the consumer may have raised inside the loop body: the reader must be done with the pinned buffers before they are freed
+        if t is not None:
+            t.join()
         if pool is not None:
             pool.shutdown(wait=True)
         for pb in bufs:
@@ -218,14 +232,27 @@ def refine3d_main(argv=None, stdin=None):
             for lo, hi, imgs in _iter_image_chunks(mm, rin[:, C["POSITION_IN_STACK"]], dev):
                 rout[lo:hi] = ref.refine(cfg, imgs, rin[lo:hi])
             note = ref.note()
+            match_tmp = None
             if d["calc_match"]:         # answers 8 / 43: the model of every particle of the range at its refined pose, one section each
+                # streamed chunk by chunk into a pre-sized file under a temporary name (a 500 k x 256^2 range is 131 GB); the name the
+                # caller looks for appears only after the parameter outputs are written
                 step = max(1, (256 << 20) // (box * box * 4))
-                match = np.empty((len(rout), box, box), dtype=np.float32)
+                match_tmp = d["match_out"] + ".tmp%d" % os.getpid()
+                out_mm = mrc.create(match_tmp, (len(rout), box, box), pixel_size=px)
+                amin, amax, asum, asq = np.inf, -np.inf, 0.0, 0.0
                 for lo in range(0, len(rout), step):
-                    match[lo:lo + step] = ref.match_projections(cfg, rout[lo:lo + step])
-                mrc.write(match, d["match_out"], pixel_size=px)
+                    m = ref.match_projections(cfg, rout[lo:lo + step])
+                    out_mm[lo:lo + len(m)] = m
+                    amin, amax = min(amin, float(m.min())), max(amax, float(m.max()))
+                    asum += float(m.sum(dtype=np.float64)); asq += float((m.astype(np.float64) ** 2).sum())
+                out_mm.flush()
+                del out_mm
+                cnt = float(len(rout)) * box * box
+                mrc.set_statistics(match_tmp, amin, amax, asum / cnt, float(np.sqrt(max(0.0, asq / cnt - (asum / cnt) ** 2))))
             ref.close()
     except (lib.PpmError, ValueError) as e:
+        if "match_tmp" in locals() and match_tmp and os.path.exists(match_tmp):
+            os.remove(match_tmp)
         _die(str(e))
     if note:
         print("\n" + note)
@@ -242,6 +269,8 @@ def refine3d_main(argv=None, stdin=None):
         cistem.write_parameters(d["output_params"], rout)
         if d["output_changes"] not in ("/dev/null", "null"):
             cistem.write_parameters(d["output_changes"], changes)
+    if match_tmp:
+        os.replace(match_tmp, d["match_out"])
     print("\n   NO     PSI   THETA     PHI       SHX       SHY     SCORE   CHANGE")
     for r, c in zip(rout[:50], changes[:50]):
         print("%7d%8.2f%8.2f%8.2f%10.2f%10.2f%10.4f%9.4f" % (r[0], r[1], r[2], r[3], r[4], r[5], r[C["SCORE"]], c[C["SCORE"]]))
@@ -327,8 +356,9 @@ def reconstruct3d_main(argv=None, stdin=None):
         frames = max(1, len(np.unique(rows[:, C["FIND"]]))) if d["dose_multiply"] else 1
         q = dose.normalised(gw)
         rc.set_dose_weights(q, d["dose_fraction"] * frames, d["dose_transition"])
-        dose.write_weights_txt("weights.txt", q, box, d["dose_fraction"] * frames, d["dose_transition"])
-        dose.write_scores_txt("scores.txt", gw)
+        if d["first"] == 1:      # PYP runs many ranges in one directory: the side files depend on the whole table only, the first range writes them
+            dose.write_weights_txt("weights.txt", q, box, d["dose_fraction"] * frames, d["dose_transition"])
+            dose.write_scores_txt("scores.txt", gw)
         print(f"dose weighting: {int((q > 0).sum())} exposures, exponent {d['dose_fraction'] * frames:g}, transition {d['dose_transition']:g}")
     from .. import host, lib
     dev = int(os.environ.get("PPM_DEVICE", "0"))

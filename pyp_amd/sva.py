@@ -141,6 +141,7 @@ def align_table(reference, table, names, cfg, base_dir=".", device=0, chunk=256,
             vols[k - lo] = v
         return vols
 
+    t = None
     try:
         cur, b = fill(0, 0, min(chunk, len(out))), 0
         for lo in range(0, len(out), chunk):
@@ -165,10 +166,13 @@ def align_table(reference, table, names, cfg, base_dir=".", device=0, chunk=256,
             scores[lo:hi] = sc
             if t is not None:
                 t.join()
+                t = None
                 if err[0] is not None:
                     raise err[0]
                 cur, b = nxt[0], 1 - b
     finally:
+        if t is not None:           # an error above: the reader must be done with the pinned buffers before they are freed
+            t.join()
         ref.close()
         for pb in bufs:
             pb.close()
