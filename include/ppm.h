@@ -260,6 +260,19 @@ int ppm_accum_add(ppm_accum_t *acc, const float *host);
 long ppm_accum_count(ppm_accum_t *acc, int half); /* particles inserted so far */
 void ppm_accum_set_count(ppm_accum_t *acc, int half, long count);
 
+/* Multi-GPU reconstruction: every rank (one process per GPU) inserts its particle shard into its own accumulator;
+ * ONE sum over the ranks replaces the dump files + local_merge3d + the summation of merge3d (frealign.py:1838-1903, :2075-2093).
+ * ppm_accum_reduce sums the accumulator (ppm_accum_floats(box) floats, in place on the device) and the two particle counters over
+ * the communicator with RCCL on the library's stream: root >= 0 -> ncclReduce to that rank, root < 0 -> ncclAllReduce.  `comm` is
+ * an ncclComm_t: the caller's own, or one made by ppm_comm_create (rank 0 calls ppm_comm_unique_id and hands the 128 bytes to the
+ * other ranks by any means - MPI, a file, torch.distributed - then every rank calls ppm_comm_create; collective, blocks until all
+ * ranks have joined).  librccl is opened on first use; if it cannot be, these calls fail with a message (no other transport). */
+typedef struct ppm_comm_id { char bytes[128]; } ppm_comm_id; /* = ncclUniqueId */
+int ppm_comm_unique_id(ppm_comm_id *id);
+void *ppm_comm_create(int n_ranks, int rank, const ppm_comm_id *id);
+void ppm_comm_destroy(void *comm);
+int ppm_accum_reduce(ppm_accum_t *acc, void *comm, int root);
+
 /* half1/half2/filtered: box^3 floats each (host).  stats: (box/2) * PPM_STATS_COLS doubles. */
 int ppm_finalize(ppm_accum_t *acc, const ppm_final_cfg *cfg, float *half1, float *half2,
                  float *filtered, double *stats);

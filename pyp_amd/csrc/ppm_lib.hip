@@ -1,6 +1,7 @@
 // ppm_lib.hip — C-ABI entry points of libpypmatch.so (include/ppm.h) for MI355X (gfx950).
 // Host glue only: workspace management, launch sequencing on one HIP stream, event timing.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -50,6 +51,7 @@ struct Ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t copy = nullptr;     // uploads of the next chunk's images overlap the current chunk's kernels
+    hipStream_t upload = nullptr;   // ppm_device_upload (may be called from a helper thread of the caller)
     struct PlanDev { FftPlan plan; bool ready = false; };
     PlanDev plans[513];             // FFT plans by length (tables live in device memory)
     bool prof_on = false;
@@ -383,6 +385,7 @@ int ppm_init(int device) {
         return fail(-19, std::string("device is ") + prop.gcnArchName + ", libpypmatch is built for gfx950 only");
     if (!g.stream) HIPCHK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     if (!g.copy) HIPCHK(hipStreamCreateWithFlags(&g.copy, hipStreamNonBlocking));
+    if (!g.upload) HIPCHK(hipStreamCreateWithFlags(&g.upload, hipStreamNonBlocking));
     g.device = device; g.inited = true;
     return 0;
 }
@@ -399,7 +402,14 @@ int ppm_profile_get(int id, double *ms, long *n) {
 
 void *ppm_device_alloc(size_t bytes) { void *p = nullptr; if (hipMalloc(&p, bytes) != hipSuccess) { g_err = "ERROR: device allocation failed"; return nullptr; } return p; }
 void ppm_device_free(void *p) { if (p) (void)hipFree(p); }
-int ppm_device_upload(void *dst, const void *src, size_t bytes) { HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return 0; }
+// own stream: a helper thread of the caller may upload the next chunk while another thread's library call computes (and uses
+// g.copy for its internal double buffering); returns when the copy has completed
+int ppm_device_upload(void *dst, const void *src, size_t bytes) {
+    if (!g.inited) return fail(-1, "ppm_init has not been called");
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, g.upload));
+    HIPCHK(hipStreamSynchronize(g.upload));
+    return 0;
+}
 void *ppm_host_alloc(size_t bytes) { void *p = nullptr; if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { g_err = "ERROR: pinned host allocation failed"; return nullptr; } return p; }
 void ppm_host_free(void *p) { if (p) (void)hipHostFree(p); }
 int ppm_device_sync(void) { if (g.stream) HIPCHK(hipStreamSynchronize(g.stream)); HIPCHK(hipDeviceSynchronize()); return 0; }
@@ -931,6 +941,89 @@ int ppm_accum_add(ppm_accum_t *a, const float *host) {
     hipLaunchKernelGGL(k_axpy, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, g.stream, a->acc, tmp.p, nf);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(g.stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ the one collective of the path (RCCL)
+// librccl is opened on first use (dlopen), not linked: the single-GPU executables never pay for loading it.  Only the plain C
+// entry points of rccl.h are used; their prototypes are restated here so that the library builds without the RCCL headers.
+namespace {
+struct Rccl {
+    void *h = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, ppm_comm_id, int) = nullptr;      // ncclUniqueId is passed by value: 128 opaque bytes
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*Reduce)(const void *, void *, size_t, int, int, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    std::string err;
+};
+static Rccl &rccl() {
+    static Rccl r;
+    if (r.h || !r.err.empty()) return r;
+    const char *names[] = { getenv("PPM_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+    for (const char *n : names) { if (!n) continue; r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (r.h) break; }
+    if (!r.h) { r.err = std::string("librccl could not be opened: ") + dlerror(); return r; }
+    auto sym = [&](const char *n) { void *p = dlsym(r.h, n); if (!p && r.err.empty()) r.err = std::string("librccl lacks ") + n; return p; };
+    r.GetUniqueId = (int (*)(void *))sym("ncclGetUniqueId");
+    r.CommInitRank = (int (*)(void **, int, ppm_comm_id, int))sym("ncclCommInitRank");
+    r.CommDestroy = (int (*)(void *))sym("ncclCommDestroy");
+    r.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))sym("ncclAllReduce");
+    r.Reduce = (int (*)(const void *, void *, size_t, int, int, int, void *, hipStream_t))sym("ncclReduce");
+    r.GetErrorString = (const char *(*)(int))sym("ncclGetErrorString");
+    return r;
+}
+constexpr int kNcclInt64 = 4, kNcclFloat32 = 7, kNcclSum = 0;      // ncclDataType_t / ncclRedOp_t values of rccl.h
+int rccl_fail(Rccl &r, int rc, const char *what) {
+    return fail(-5, std::string(what) + " failed: " + (r.GetErrorString ? r.GetErrorString(rc) : "RCCL error") + " (" + std::to_string(rc) + ")");
+}
+}  // namespace
+
+int ppm_comm_unique_id(ppm_comm_id *id) {
+    if (!id) return fail(-22, "null argument");
+    Rccl &r = rccl();
+    if (!r.err.empty()) return fail(-38, r.err);
+    static_assert(sizeof(ppm_comm_id) == 128, "ncclUniqueId is 128 bytes");
+    if (int rc = r.GetUniqueId(id)) return rccl_fail(r, rc, "ncclGetUniqueId");
+    return 0;
+}
+
+void *ppm_comm_create(int n_ranks, int rank, const ppm_comm_id *id) {
+    if (!g.inited) { fail(-1, "ppm_init has not been called"); return nullptr; }
+    if (!id || n_ranks < 1 || rank < 0 || rank >= n_ranks) { fail(-22, "bad communicator arguments"); return nullptr; }
+    Rccl &r = rccl();
+    if (!r.err.empty()) { fail(-38, r.err); return nullptr; }
+    void *comm = nullptr;
+    if (int rc = r.CommInitRank(&comm, n_ranks, *id, rank)) { rccl_fail(r, rc, "ncclCommInitRank"); return nullptr; }
+    return comm;
+}
+
+void ppm_comm_destroy(void *comm) {
+    Rccl &r = rccl();
+    if (comm && r.CommDestroy) (void)r.CommDestroy(comm);
+}
+
+int ppm_accum_reduce(ppm_accum_t *a, void *comm, int root) {
+    if (!g.inited) return fail(-1, "ppm_init has not been called");
+    if (!a || !comm) return fail(-22, "null argument");
+    Rccl &r = rccl();
+    if (!r.err.empty()) return fail(-38, r.err);
+    const size_t nf = ppm_accum_floats(a->N);
+    // the particle counters travel with the sums: brought up to date on the device, reduced as two int64
+    unsigned long long c[2] = { (unsigned long long)a->counts[0], (unsigned long long)a->counts[1] };
+    HIPCHK(hipMemcpyAsync(a->d_counts, c, sizeof(c), hipMemcpyHostToDevice, g.stream));
+    int rc;
+    if (root < 0) {
+        rc = r.AllReduce(a->acc, a->acc, nf, kNcclFloat32, kNcclSum, comm, g.stream);
+        if (!rc) rc = r.AllReduce(a->d_counts, a->d_counts, 2, kNcclInt64, kNcclSum, comm, g.stream);
+    } else {
+        rc = r.Reduce(a->acc, a->acc, nf, kNcclFloat32, kNcclSum, root, comm, g.stream);
+        if (!rc) rc = r.Reduce(a->d_counts, a->d_counts, 2, kNcclInt64, kNcclSum, root, comm, g.stream);
+    }
+    if (rc) return rccl_fail(r, rc, root < 0 ? "ncclAllReduce" : "ncclReduce");
+    HIPCHK(hipMemcpyAsync(c, a->d_counts, sizeof(c), hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    a->counts[0] = (long)c[0]; a->counts[1] = (long)c[1];      // on ranks other than a root the values are undefined, as ncclReduce leaves them
     return 0;
 }
 

@@ -22,7 +22,8 @@ def _images_arg(images, n_img, box):
         if not images.is_cuda:
             images = images.numpy()
         else:
-            _sync_producer(images)
+            if not getattr(images, "ready", False):      # a torch tensor: wait for whatever torch queued on it (cli.DeviceImages arrives finished)
+                _sync_producer(images)
             if str(images.dtype) != "torch.float32" or not images.is_contiguous():
                 raise ValueError("ERROR: device image stack must be contiguous float32")
             if images.numel() != n_img * box * box:

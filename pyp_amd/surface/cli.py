@@ -80,71 +80,132 @@ def _open_stack(stack_path, positions):
     return mm
 
 
+class DeviceImages:
+    """A chunk of particle images already in device memory (what host._images_arg accepts besides numpy / torch arrays)."""
+    is_cuda, dtype, ready = True, "torch.float32", True       # ready: the upload has completed before the chunk is handed out
+
+    def __init__(self, ptr, n, box):
+        self.ptr, self.n, self.box = ptr, n, box
+
+    def data_ptr(self):
+        return self.ptr
+
+    def is_contiguous(self):
+        return True
+
+    def numel(self):
+        return self.n * self.box * self.box
+
+    @property
+    def device(self):
+        return None
+
+
 def _iter_image_chunks(mm, positions, device, chunk=None):
-    """Yield (lo, hi, images[hi - lo, N, N]) over the range: the particle images are read from the memory-mapped stack chunk by
-    chunk into two page-locked buffers, the next chunk by a reader thread while the caller computes on the current one, so
-    the host never holds more than two chunks (a 500 k x 256^2 range is 131 GB) and uploads overlap the kernels."""
+    """Yield (lo, hi, images) over the range, `images` = hi - lo particle images ALREADY ON THE DEVICE.  A producer thread
+    reads the next chunk from the stack file into one of two page-locked buffers (pread by several reader threads: one
+    kernel copy out of the page cache, no page faults, the GIL released) and uploads it into one of two device buffers on
+    the library's upload stream, while the caller computes on the other: the host never holds more than two chunks (a
+    500 k x 256^2 range is 131 GB), and reads, uploads and kernels overlap."""
+    import queue
     import threading
     from concurrent.futures import ThreadPoolExecutor
-    from .. import host
+    from .. import host, lib
     n, box = len(positions), mm.shape[1]
-    if chunk is None:       # 512 MB per pinned buffer (2 048 images of 256^2): pinning more costs start-up time, 0.9 s of a 2.6 s run with 2 GB buffers
+    if chunk is None:       # 512 MB per buffer (2 048 images of 256^2): pinning more costs start-up time (0.9 s of a 2.6 s run with 2 GB buffers)
         chunk = int(os.environ.get("PPM_IO_CHUNK", str(max(256, min(16384, (512 << 20) // (box * box * 4))))))
     chunk = max(1, min(chunk, n))
     idx = positions.astype(np.int64) - 1
     contiguous = bool(np.all(np.diff(idx) == 1))
-    bufs = [host.PinnedBuffer(chunk * box * box, device) for _ in range(2 if n > chunk else 1)]
-
-    nread = max(1, min(8, int(os.environ.get("PPM_IO_THREADS", "4"))))
+    nslot = 2 if n > chunk else 1
+    L = lib.load()
+    sec = box * box * 4
+    pinned = [host.PinnedBuffer(chunk * box * box, device) for _ in range(nslot)]
+    dev = []
+    for _ in range(nslot):
+        p = L.ppm_device_alloc(chunk * sec)
+        if not p:
+            for pb in pinned:
+                pb.close()
+            for q in dev:
+                L.ppm_device_free(q)
+            raise lib.PpmError(lib.last_error())
+        dev.append(p)
+    nread = max(1, min(16, int(os.environ.get("PPM_IO_THREADS", "8"))))
     pool = ThreadPoolExecutor(nread) if nread > 1 else None
+    # pread straight from the file when the data block is plain little-endian float32 (what PYP writes); otherwise through the map
+    fd = None
+    if contiguous and mm.dtype == np.dtype("<f4") and getattr(mm, "filename", None):
+        fd = os.open(mm.filename, os.O_RDONLY)
+    off0 = int(getattr(mm, "offset", 0))
 
-    def fill(b, lo, hi):
-        # several reader threads share a chunk (numpy copies release the GIL): one thread moves ~14 GB/s out of the page cache,
-        # less than the GPU consumes at 256^2
-        dst = bufs[b].array[:(hi - lo) * box * box].reshape(hi - lo, box, box)
+    def fill(slot, lo, hi):
+        dst = pinned[slot].array[:(hi - lo) * box * box].reshape(hi - lo, box, box)
 
         def part(a, e):
-            dst[a - lo:e - lo] = mm[idx[a]:idx[a] + (e - a)] if contiguous else mm[idx[a:e]]
+            if fd is None:
+                dst[a - lo:e - lo] = mm[idx[a]:idx[a] + (e - a)] if contiguous else mm[idx[a:e]]
+                return
+            view = memoryview(dst[a - lo:e - lo]).cast("B")
+            pos, want, done = off0 + int(idx[a]) * sec, (e - a) * sec, 0
+            while done < want:
+                got = os.preadv(fd, [view[done:min(want, done + (256 << 20))]], pos + done)
+                if got <= 0:
+                    raise IOError(f"ERROR: short read from the particle stack at byte {pos + done}")
+                done += got
         cuts = np.linspace(lo, hi, (nread if hi - lo >= 4 * nread else 1) + 1).astype(int)
         if pool is None or len(cuts) == 2:
             part(lo, hi)
         else:
             list(pool.map(lambda ae: part(*ae), zip(cuts[:-1], cuts[1:])))
-        return dst
 
-    t, err = None, [None]
+    ready, free = queue.Queue(), [threading.Event() for _ in range(nslot)]
+    for ev in free:
+        ev.set()
+    stop = threading.Event()
 
-    def fill_next(b, lo, hi, slot):
+    def producer():
         try:
-            slot[0] = fill(b, lo, hi)
+            k = 0
+            for lo in range(0, n, chunk):
+                hi, slot = min(lo + chunk, n), k % nslot
+                while not free[slot].wait(0.05):
+                    if stop.is_set():
+                        return
+                if stop.is_set():
+                    return
+                free[slot].clear()
+                fill(slot, lo, hi)
+                if L.ppm_device_upload(dev[slot], pinned[slot].ptr, (hi - lo) * sec) != 0:
+                    raise lib.PpmError(lib.last_error())
+                ready.put((lo, hi, slot, None))
+                k += 1
         except BaseException as e:          # handed to the consumer: a reader failure must end in the ERROR line, not a traceback
-            err[0] = e
+            ready.put((0, 0, 0, e))
 
+    t = threading.Thread(target=producer, daemon=True)
+    t.start()
     try:
-        cur = fill(0, 0, min(chunk, n))
-        lo, b = 0, 0
+        lo = 0
         while lo < n:
-            hi = min(lo + chunk, n)
-            nxt, t = [None], None
-            if hi < n:
-                t = threading.Thread(target=fill_next, args=(1 - b, hi, min(hi + chunk, n), nxt))
-                t.start()
-            yield lo, hi, cur
-            if t is not None:
-                t.join()
-                t = None
-                if err[0] is not None:
-                    raise ValueError(f"ERROR: reading the particle stack failed: {err[0]}")
-                cur, b = nxt[0], 1 - b
+            a, hi, slot, err = ready.get()
+            if err is not None:
+                raise ValueError(f"ERROR: reading the particle stack failed: {err}")
+            yield a, hi, DeviceImages(dev[slot], hi - a, box)
+            free[slot].set()
             lo = hi
     finally:
-        # the consumer may have raised inside the loop body: the reader must be done with the pinned buffers before they are freed
-        if t is not None:
-            t.join()
+        # the consumer may have raised inside the loop body: the producer must be done with the buffers before they are freed
+        stop.set()
+        t.join()
         if pool is not None:
             pool.shutdown(wait=True)
-        for pb in bufs:
+        if fd is not None:
+            os.close(fd)
+        for pb in pinned:
             pb.close()
+        for q in dev:
+            L.ppm_device_free(q)
 
 
 def _ssnr_ring_weights(n, stats_path, pixel):
@@ -223,14 +284,17 @@ def refine3d_main(argv=None, stdin=None):
     cfg = refine_cfg_from_answers(d, box)
     from .. import host, lib
     dev = int(os.environ.get("PPM_DEVICE", "0"))
+    t1 = time.time()
     try:
         with gpu_lock(dev):
             if box * pad > 512:
                 _die(f"ERROR: refine3d: padding factor {pad} needs a padded box of {box * pad} > 512")
             ref = host.Reference(vol, box / 2, device=dev, pad=pad, ring_weight=ring_w)
+            t2 = time.time()
             rout = np.empty_like(rin)
             for lo, hi, imgs in _iter_image_chunks(mm, rin[:, C["POSITION_IN_STACK"]], dev):
                 rout[lo:hi] = ref.refine(cfg, imgs, rin[lo:hi])
+            t3 = time.time()
             note = ref.note()
             match_tmp = None
             if d["calc_match"]:         # answers 8 / 43: the model of every particle of the range at its refined pose, one section each
@@ -275,6 +339,7 @@ def refine3d_main(argv=None, stdin=None):
     for r, c in zip(rout[:50], changes[:50]):
         print("%7d%8.2f%8.2f%8.2f%10.2f%10.2f%10.4f%9.4f" % (r[0], r[1], r[2], r[3], r[4], r[5], r[C["SCORE"]], c[C["SCORE"]]))
     print(f"\nRefined {len(rout)} particles in {time.time() - t0:.1f} s; mean score {rout[:, C['SCORE']].mean():.4f}")
+    print(f"Timing: inputs {t1 - t0:.2f} s, device + reference {t2 - t1:.2f} s, particles {t3 - t2:.2f} s, outputs {time.time() - t3:.2f} s")
     print("\nRefine3D: Normal termination\n", flush=True)
     return 0
 
@@ -362,9 +427,11 @@ def reconstruct3d_main(argv=None, stdin=None):
         print(f"dose weighting: {int((q > 0).sum())} exposures, exponent {d['dose_fraction'] * frames:g}, transition {d['dose_transition']:g}")
     from .. import host, lib
     dev = int(os.environ.get("PPM_DEVICE", "0"))
+    t1 = time.time()
     try:
         with gpu_lock(dev):
             acc = host.Accumulator(box, px, d["symmetry"], device=dev)
+            t2 = time.time()
             blur_ref = None
             if d["likelihood_blurring"]:
                 vol = mrc.read(d["reference"]).astype(np.float32)
@@ -382,6 +449,7 @@ def reconstruct3d_main(argv=None, stdin=None):
                 ok = (rin[:, C["OCCUPANCY"]] > 0) & ~(rin[:, C["SCORE"]] < d["score_threshold"])
                 key = rin[:, C["PIND"] if d["per_particle_splitting"] else C["POSITION_IN_STACK"]].astype(np.int64) % 2
                 acc.set_counts(int((ok & (key == 0)).sum()), int((ok & (key == 1)).sum()))      # particles, not inserted copies
+            t3 = time.time()
             data = acc.download()
             counts = acc.counts()
             acc.close()
@@ -393,6 +461,9 @@ def reconstruct3d_main(argv=None, stdin=None):
     with open(d["res_file"], "w") as f:
         f.write("C Reconstruct3D (libpypmatch): particles %d..%d, inserted %d + %d\n" % (d["first"], d["last"], counts[1], counts[0]))
     print(f"\nInserted {counts[0] + counts[1]} of {len(rin)} particles in {time.time() - t0:.1f} s")
+    print(f"Timing: inputs {t1 - t0:.2f} s, device {t2 - t1:.2f} s, particles {t3 - t2:.2f} s, dumps {time.time() - t3:.2f} s")
+    print("NOTE: the dump files are in libpypmatch's own format (PPMDUMP1): only this build's local_merge3d / merge3d read them "
+          "(frealign.py:1852 consumers must be replaced together, INTEGRATION.md 1)")
     print("\nNormal termination, intermediate files dumped")
     print("\nReconstruct3D: Normal termination\n", flush=True)
     return 0

@@ -6,7 +6,7 @@ for round in 1 2; do
     if [ "$W" = "reconstruct" ]; then
       echo "== $(basename $f) round $round: $(timeout -k 10 200 python bench.py --workload reconstruct --particles 50000 --steps 1 --warmup 1 2>&1 | grep -o '"value": [0-9.]*\|"prep": [0-9.]*\|"insert": [0-9.]*' | tr '\n' ' ')"
     else
-      echo "== $(basename $f) round $round: $(timeout -k 10 200 python bench.py --particles 20000 --steps 1 --warmup 1 --no-cpu 2>&1 | grep -o '"value": [0-9.]*\|"global": [0-9.]*\|"local": [0-9.]*' | tr '\n' ' ')"
+      echo "== $(basename $f) round $round: $(timeout -k 10 200 python bench.py --particles 20000 --steps 1 --warmup 1 --no-cpu --no-dropin 2>&1 | grep -o '"value": [0-9.]*\|"global": [0-9.]*\|"local": [0-9.]*' | tr '\n' ' ')"
     fi
   done
 done

@@ -4,6 +4,6 @@
 for round in 1 2; do
   for f in ab/*.so; do
     cp $f pyp_amd/libpypmatch.so
-    echo "== $(basename $f) round $round: $(timeout -k 10 300 python bench.py --workload refine --particles ${1:-28672} --steps 1 --warmup 1 --no-cpu 2>&1 | grep -o '"value": [0-9.]*\|"global": [0-9.]*\|"norms": [0-9.]*\|"local": [0-9.]*\|ERROR.*' | tr '\n' ' ')"
+    echo "== $(basename $f) round $round: $(timeout -k 10 300 python bench.py --workload refine --particles ${1:-28672} --steps 1 --warmup 1 --no-cpu --no-dropin 2>&1 | grep -o '"value": [0-9.]*\|"global": [0-9.]*\|"norms": [0-9.]*\|"local": [0-9.]*\|ERROR.*' | tr '\n' ' ')"
   done
 done

@@ -1,7 +1,7 @@
 set -e
 export TMPDIR=/tmp
 rm -rf /tmp/prof_kl; mkdir -p /tmp/prof_kl
-rocprofv3 --kernel-trace -d /tmp/prof_kl -o kl --output-format csv -- python3 bench.py --particles 16000 --steps 1 --warmup 0 --no-cpu > /tmp/prof_kl/out.txt 2>&1
+rocprofv3 --kernel-trace -d /tmp/prof_kl -o kl --output-format csv -- python3 bench.py --particles 16000 --steps 1 --warmup 0 --no-cpu --no-dropin > /tmp/prof_kl/out.txt 2>&1
 f=$(find /tmp/prof_kl -name "*kernel_trace.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys

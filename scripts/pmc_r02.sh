@@ -8,14 +8,14 @@ W=${1:-refine}; N=${2:-8192}; OUT=${3:-gpurun_out/r02_pmc_$W.json}
 export TMPDIR=/tmp
 R=/tmp/pmc_r02_$W; rm -rf $R; mkdir -p $R
 if [ "$W" = "reconstruct" ]; then
-  ARGS="--workload reconstruct --recon-particles $N --steps 1 --warmup 0 --no-cpu"
+  ARGS="--workload reconstruct --recon-particles $N --steps 1 --warmup 0 --no-cpu --no-dropin"
   GROUPS_=("SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE" \
            "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
            "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" \
            "FETCH_SIZE" "WRITE_SIZE")
 else
-  ARGS="--workload refine --particles $N --steps 1 --warmup 0 --no-cpu"
+  ARGS="--workload refine --particles $N --steps 1 --warmup 0 --no-cpu --no-dropin"
   GROUPS_=("SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE" \
            "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \

@@ -11,7 +11,7 @@ for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
            "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE" \
            "TCC_EA0_ATOMIC_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $grp -d $R/g$i -o g$i --output-format csv -- python3 bench.py --workload reconstruct --particles $N --steps 1 --warmup 0 --no-cpu > $R/log$i.txt 2>&1 || { echo "group $i failed"; tail -5 $R/log$i.txt; }
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $grp -d $R/g$i -o g$i --output-format csv -- python3 bench.py --workload reconstruct --particles $N --steps 1 --warmup 0 --no-cpu --no-dropin > $R/log$i.txt 2>&1 || { echo "group $i failed"; tail -5 $R/log$i.txt; }
 done
 python3 scripts/pmc_summary.py $R > $OUT
 echo done

@@ -6,7 +6,7 @@ W=${1:-reconstruct}; N=${2:-16000}; OUT=${3:-gpurun_out/pmc_traffic.json}
 export TMPDIR=/tmp
 R=/tmp/pmc_traffic; rm -rf $R; mkdir -p $R
 ARGS="--particles $N --steps 1 --warmup 0"
-if [ "$W" = "reconstruct" ]; then ARGS="--workload reconstruct $ARGS"; else ARGS="$ARGS --no-cpu"; fi
+if [ "$W" = "reconstruct" ]; then ARGS="--workload reconstruct $ARGS"; else ARGS="$ARGS --no-cpu --no-dropin"; fi
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))

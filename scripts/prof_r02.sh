@@ -5,7 +5,7 @@ set -e
 export TMPDIR=/tmp
 T=${1:-r02_x}; shift || true
 rm -rf /tmp/prof_r02; mkdir -p /tmp/prof_r02 gpurun_out
-rocprofv3 --kernel-trace --stats -d /tmp/prof_r02 -o p --output-format csv -- python3 bench.py --no-cpu "$@" > gpurun_out/${T}_bench_line.json 2> /tmp/prof_r02/err.txt || { tail -5 /tmp/prof_r02/err.txt; exit 1; }
+rocprofv3 --kernel-trace --stats -d /tmp/prof_r02 -o p --output-format csv -- python3 bench.py --no-cpu --no-dropin "$@" > gpurun_out/${T}_bench_line.json 2> /tmp/prof_r02/err.txt || { tail -5 /tmp/prof_r02/err.txt; exit 1; }
 f=$(find /tmp/prof_r02 -name "*kernel_stats.csv" | head -1)
 head -1 $f > gpurun_out/${T}_kernel_stats.csv; grep "ppm::" $f >> gpurun_out/${T}_kernel_stats.csv
 cut -c1-130 gpurun_out/${T}_kernel_stats.csv | head -8

@@ -3,7 +3,7 @@
 for cfg in "96 24 8000" "128 48 8000" "192 64 4000" "320 64 2000" "384 96 1500"; do
   set -- $cfg
   echo "== box $1 band $2"
-  timeout -k 10 300 python bench.py --box $1 --band $2 --particles $3 --recon-particles $((4*$3)) --steps 1 --warmup 1 --no-cpu --no-next-rows 2>&1 | python -c "
+  timeout -k 10 300 python bench.py --box $1 --band $2 --particles $3 --recon-particles $((4*$3)) --steps 1 --warmup 1 --no-cpu --no-dropin --no-next-rows 2>&1 | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):

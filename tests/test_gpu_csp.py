@@ -252,7 +252,8 @@ def test_region_split_2x2x1_end_to_end_like_the_caller(tmp_path):
             assert synth.angular_error_deg(wr, gr).max() < 0.1 and synth.shift_error_px(wr, gr, px).max() < 0.5
     assert _particle_angle_err(pm, parts).mean() < 0.5 * _particle_angle_err(p2, parts).mean()
     # the merged rows carry RIND = their region, so the (TIND, region) tilt entries must come along with the particle jobs' outputs
-    assert len(tm) == len(t2) * (1 + len(split)) and set(rows_m[:, 28].astype(int)) == set(range(len(split)))
+    # (region 0's entries take the place of the original (TIND, 0) ones: Parameters.merge keys tilts by (TIND, RIND))
+    assert len(tm) == len(t2) * len(split) and set(rows_m[:, 28].astype(int)) == set(range(len(split)))
     # ---- outer mode 5 -> 3 -> argv mode 6: one job per (region, tilt); merged tilts are keyed (TIND, region)
     for f in outs:
         os.remove(f); os.remove(f.replace(".cistem", "_extended.cistem"))
