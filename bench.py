@@ -417,7 +417,9 @@ def dropin_bench(a, vol, stack, start_rows, truth, px, res, srange):
                 out[prog] = {"error": log[-600:]}
                 break
             timing = [ln for ln in log.splitlines() if ln.startswith("Timing:")]
-            out[prog] = {"value": round(M / dt, 1), "unit": "particles/s", "wall_s": round(dt, 2), "phases": timing[0][8:] if timing else None}
+            pipe = [ln for ln in log.splitlines() if ln.startswith("Pipeline:")]
+            out[prog] = {"value": round(M / dt, 1), "unit": "particles/s", "wall_s": round(dt, 2), "phases": timing[0][8:] if timing else None,
+                         "pipeline": pipe[0][10:] if pipe else None}
         if "value" in out.get("refine3d", {}):
             got = cistem.read_parameters(os.path.join(d, f"p_r01_{rng}.cistem"))
             k = min(M, 2000)
@@ -451,10 +453,17 @@ def reconstruct_bench(ctx):
                   normalize=1, invert=0, split_by_pind=0, mask_radius=0.32 * N * px)
     barrier = make_barrier(world)
 
+    # the one collective: through the C ABI (ppm_accum_reduce, the library's own RCCL communicator) when the ranks have a GPU
+    # each; PPM_REDUCE=torch (or a gloo rehearsal with shared devices) sums the same tensor with torch.distributed instead
+    import torch.distributed as tdist
+    via_abi = world > 1 and tdist.get_backend() == "nccl" and os.environ.get("PPM_REDUCE", "abi") == "abi"
+
     def step():
         acc_t.zero_()
         acc.set_counts(0, 0)
         acc.insert(rc, stack, rows)
+        if via_abi:
+            return pdist.reduce_accumulator_handle(acc, local)
         return pdist.reduce_accumulators(acc_t, acc.counts())[1]
 
     counts = None
@@ -508,7 +517,8 @@ def reconstruct_bench(ctx):
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "3D reconstruction: Fourier-insert %dk %d^2 particles/GPU (resident stack, %.0f GB) -> %d^3 half-maps, C1, "
                                    "one all-reduce" % (M // 1000, N, M * N * N * 4 / 1e9, N),
-                       "particles_per_gpu": M, "box": N, "parallelism": "particle-sharded x%d" % world},
+                       "particles_per_gpu": M, "box": N, "parallelism": "particle-sharded x%d" % world,
+                       "collective": "none (one rank)" if world == 1 else ("ppm_accum_reduce (RCCL all-reduce, C ABI)" if via_abi else "torch.distributed all_reduce")},
             "roofline": roof, "kernels_ms": {k2: round(v["ms"], 2) for k2, v in prof.items() if v["launches"]},
             "kernels_us_per_particle": per_us, "compulsory_bytes_per_particle": 4 * N * N,
             "path_hbm_frac_compulsory": round(world * M * a.steps * 4.0 * N * N / dt / 1e9 / PEAK_HBM_GBPS / world, 4),
@@ -584,7 +594,7 @@ def csp_bench(ctx):
         from oracle import oracle
         cores = host_cores()
         _omp_threads(cores)
-        k = max(1, min(npart, cores // 2))                      # a bounded sample of particle units with all their projections
+        k = max(1, min(npart, cores))                           # a bounded sample of particle units with all their projections
         from pyp_amd.formats import cistem
         sel = np.where(np.isin(rows2[:, cistem.COL["PIND"]], p2[:k, 0]))[0]
         t0 = time.time()
@@ -650,7 +660,7 @@ def sva_bench(ctx):
         from oracle import oracle
         cores = host_cores()
         _omp_threads(cores)
-        k = 4
+        k = min(nv, 16)
         t0 = time.time()
         oref = oracle.Reference(vol, n / 2)
         t1 = time.time()
@@ -697,7 +707,7 @@ def cpu_baseline(vol, stack, start_rows, cfg, N, seconds):
     from oracle import oracle
     cores = host_cores()
     gomp = ctypes.CDLL("libgomp.so.1")
-    imgs = stack[:max(2 * cores, 8)].cpu().numpy()
+    imgs = stack[:min(len(stack), max(64 * cores, 256))].cpu().numpy()      # pool the timed sample is drawn from: the --cpu-seconds budget decides how many are used
     t0 = time.time()
     oref = oracle.Reference(vol, N / 2)
     t_prep = time.time() - t0
@@ -717,7 +727,7 @@ def cpu_baseline(vol, stack, start_rows, cfg, N, seconds):
     oracle.refine_batch(oref, cfg, imgs[:n], start_rows[:n], ccf_mode=1)
     t2 = time.time() - t0
     if t2 < 0.5 * seconds and len(imgs) > n:
-        n2 = max(cores, (int(min(len(imgs), n / t2 * seconds)) // cores) * cores)
+        n2 = max(cores, (int(min(len(imgs), max(256, n / t2 * seconds))) // cores) * cores)       # at least 256 particles (SURVEY 8d asks for a stable sample)
         t0 = time.time()
         oracle.refine_batch(oref, cfg, imgs[:n2], start_rows[:n2], ccf_mode=1)
         t2, n = time.time() - t0, n2

@@ -378,6 +378,12 @@ int ppm_init(int device) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(-19, "no HIP device visible; libpypmatch has no CPU path");
     if (device < 0 || device >= count) return fail(-22, "device index out of range");
+    // how a host thread waits for the device: PPM_SYNC=block sleeps on an interrupt instead of spinning (the drop-in executables
+    // set it: their reader threads need the cores a spinning wait would burn); default = the runtime's own choice
+    if (const char *e = getenv("PPM_SYNC")) {
+        const std::string v(e);
+        (void)hipSetDeviceFlags(v == "block" ? hipDeviceScheduleBlockingSync : (v == "yield" ? hipDeviceScheduleYield : (v == "spin" ? hipDeviceScheduleSpin : hipDeviceScheduleAuto)));
+    }
     HIPCHK(hipSetDevice(device));
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
@@ -400,17 +406,19 @@ int ppm_profile_get(int id, double *ms, long *n) {
     return 0;
 }
 
-void *ppm_device_alloc(size_t bytes) { void *p = nullptr; if (hipMalloc(&p, bytes) != hipSuccess) { g_err = "ERROR: device allocation failed"; return nullptr; } return p; }
+// (the current device is a per-thread setting of the runtime: helper threads of the caller get the library's device here)
+void *ppm_device_alloc(size_t bytes) { if (g.inited) (void)hipSetDevice(g.device); void *p = nullptr; if (hipMalloc(&p, bytes) != hipSuccess) { g_err = "ERROR: device allocation failed"; return nullptr; } return p; }
 void ppm_device_free(void *p) { if (p) (void)hipFree(p); }
 // own stream: a helper thread of the caller may upload the next chunk while another thread's library call computes (and uses
 // g.copy for its internal double buffering); returns when the copy has completed
 int ppm_device_upload(void *dst, const void *src, size_t bytes) {
     if (!g.inited) return fail(-1, "ppm_init has not been called");
+    HIPCHK(hipSetDevice(g.device));
     HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, g.upload));
     HIPCHK(hipStreamSynchronize(g.upload));
     return 0;
 }
-void *ppm_host_alloc(size_t bytes) { void *p = nullptr; if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { g_err = "ERROR: pinned host allocation failed"; return nullptr; } return p; }
+void *ppm_host_alloc(size_t bytes) { if (g.inited) (void)hipSetDevice(g.device); void *p = nullptr; if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { g_err = "ERROR: pinned host allocation failed"; return nullptr; } return p; }
 void ppm_host_free(void *p) { if (p) (void)hipHostFree(p); }
 int ppm_device_sync(void) { if (g.stream) HIPCHK(hipStreamSynchronize(g.stream)); HIPCHK(hipDeviceSynchronize()); return 0; }
 

@@ -44,6 +44,38 @@ def gather_rows(local_rows, n_total, world, rank, group=None):
     return np.concatenate([o[:s].cpu().numpy() for o, s in zip(outs, sizes)], axis=0)
 
 
+_COMM = {}
+
+
+def library_comm(device, group=None):
+    """The library's own RCCL communicator for this process group (made once): rank 0 draws the id, torch.distributed only carries
+    the 128 bytes; the data path itself is ppm_accum_reduce (no torch types at the boundary, include/ppm.h)."""
+    import torch
+    import torch.distributed as dist
+    from . import host
+    key = (id(group), int(device))
+    if key in _COMM:
+        return _COMM[key]
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    on = torch.device("cuda", int(device)) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    t = torch.zeros(128, dtype=torch.uint8, device=on)
+    if rank == 0:
+        t.copy_(torch.frombuffer(bytearray(host.comm_unique_id()), dtype=torch.uint8))
+    dist.broadcast(t, src=0, group=group)
+    _COMM[key] = host.make_comm(world, rank, bytes(t.cpu().numpy().tobytes()), device=int(device))
+    return _COMM[key]
+
+
+def reduce_accumulator_handle(acc, device, group=None, root=-1):
+    """Sum an `host.Accumulator` over the ranks through the C ABI (ppm_accum_reduce over the library's communicator); counters
+    included.  One process per GPU with distinct devices (RCCL refuses two ranks on one device)."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return acc.counts()
+    acc.reduce(library_comm(device, group), root)
+    return acc.counts()
+
+
 def reduce_accumulators(acc_tensor, counts, group=None):
     """Sum the half-map accumulators (a flat float32 tensor of ppm_accum_floats(box) elements, on the
     GPU for RCCL) and the two particle counters over all ranks, in place."""

@@ -158,6 +158,13 @@ class Accumulator:
         lib.load().ppm_accum_set_count(self.h, 0, int(c0))
         lib.load().ppm_accum_set_count(self.h, 1, int(c1))
 
+    def reduce(self, comm, root=-1):
+        """Sum this rank's accumulator and particle counters over the communicator (ppm_accum_reduce: RCCL on the library's
+        stream; root < 0 = all-reduce).  `comm` comes from `make_comm` (or is the caller's own ncclComm_t pointer)."""
+        if self._ext is not None:
+            _sync_producer(self._ext)
+        lib.check(lib.load().ppm_accum_reduce(self.h, C.c_void_p(comm), int(root)))
+
     def download(self):
         a = np.empty(self.nfloats, dtype=np.float32)
         if self._ext is not None:
@@ -194,6 +201,30 @@ class Accumulator:
             self.close()
         except Exception:
             pass
+
+
+def comm_unique_id():
+    """128 opaque bytes (ncclUniqueId) made by ONE rank; hand them to the others by any means."""
+    buf = (C.c_char * 128)()
+    lib.check(lib.load().ppm_comm_unique_id(buf))
+    return bytes(buf)
+
+
+def make_comm(n_ranks, rank, unique_id, device=0):
+    """An RCCL communicator over the ranks' GPUs (ppm_comm_create; collective: returns when all ranks have joined)."""
+    lib.init(device)
+    if len(unique_id) != 128:
+        raise ValueError("ERROR: the communicator id must be 128 bytes")
+    buf = (C.c_char * 128).from_buffer_copy(unique_id)
+    h = lib.load().ppm_comm_create(int(n_ranks), int(rank), buf)
+    if not h:
+        raise lib.PpmError(lib.last_error())
+    return h
+
+
+def destroy_comm(comm):
+    if comm:
+        lib.load().ppm_comm_destroy(C.c_void_p(comm))
 
 
 def extract_boxes(micrograph, coords, box, radius_A, pixel_size, coordinate_binning=1, normalize=True, fix_empty=True,

@@ -102,11 +102,12 @@ class DeviceImages:
 
 
 def _iter_image_chunks(mm, positions, device, chunk=None):
-    """Yield (lo, hi, images) over the range, `images` = hi - lo particle images ALREADY ON THE DEVICE.  A producer thread
-    reads the next chunk from the stack file into one of two page-locked buffers (pread by several reader threads: one
-    kernel copy out of the page cache, no page faults, the GIL released) and uploads it into one of two device buffers on
-    the library's upload stream, while the caller computes on the other: the host never holds more than two chunks (a
-    500 k x 256^2 range is 131 GB), and reads, uploads and kernels overlap."""
+    """Yield (lo, hi, images) over the range, `images` = hi - lo particle images ALREADY ON THE DEVICE.  Three stages run
+    concurrently: a reader thread fills page-locked buffers from the stack file (pread by several worker threads: one kernel copy
+    out of the page cache, no page faults, the GIL released), an upload thread moves them into one of two device buffers on the
+    library's upload stream, and the caller computes on the other device buffer.  The host never holds more than three chunks (a
+    500 k x 256^2 range is 131 GB).  Buffers beyond the first are allocated by the threads themselves, while the first chunk is
+    already on its way (page-locking 512 MB costs ~0.1 s)."""
     import queue
     import threading
     from concurrent.futures import ThreadPoolExecutor
@@ -115,22 +116,14 @@ def _iter_image_chunks(mm, positions, device, chunk=None):
     if chunk is None:       # 512 MB per buffer (2 048 images of 256^2): pinning more costs start-up time (0.9 s of a 2.6 s run with 2 GB buffers)
         chunk = int(os.environ.get("PPM_IO_CHUNK", str(max(256, min(16384, (512 << 20) // (box * box * 4))))))
     chunk = max(1, min(chunk, n))
+    nchunks = (n + chunk - 1) // chunk
     idx = positions.astype(np.int64) - 1
     contiguous = bool(np.all(np.diff(idx) == 1))
-    nslot = 2 if n > chunk else 1
     L = lib.load()
+    lib.init(device)
     sec = box * box * 4
-    pinned = [host.PinnedBuffer(chunk * box * box, device) for _ in range(nslot)]
-    dev = []
-    for _ in range(nslot):
-        p = L.ppm_device_alloc(chunk * sec)
-        if not p:
-            for pb in pinned:
-                pb.close()
-            for q in dev:
-                L.ppm_device_free(q)
-            raise lib.PpmError(lib.last_error())
-        dev.append(p)
+    npin, ndev = min(3, nchunks), min(2, nchunks)
+    pinned, dev = [None] * npin, [None] * ndev
     nread = max(1, min(16, int(os.environ.get("PPM_IO_THREADS", "8"))))
     pool = ThreadPoolExecutor(nread) if nread > 1 else None
     # pread straight from the file when the data block is plain little-endian float32 (what PYP writes); otherwise through the map
@@ -139,8 +132,8 @@ def _iter_image_chunks(mm, positions, device, chunk=None):
         fd = os.open(mm.filename, os.O_RDONLY)
     off0 = int(getattr(mm, "offset", 0))
 
-    def fill(slot, lo, hi):
-        dst = pinned[slot].array[:(hi - lo) * box * box].reshape(hi - lo, box, box)
+    def fill(buf, lo, hi):
+        dst = buf.array[:(hi - lo) * box * box].reshape(hi - lo, box, box)
 
         def part(a, e):
             if fd is None:
@@ -159,53 +152,107 @@ def _iter_image_chunks(mm, positions, device, chunk=None):
         else:
             list(pool.map(lambda ae: part(*ae), zip(cuts[:-1], cuts[1:])))
 
-    ready, free = queue.Queue(), [threading.Event() for _ in range(nslot)]
-    for ev in free:
+    stats = _iter_image_chunks.stats = {"read": 0.0, "upload": 0.0, "wait_pinned": 0.0, "wait_device": 0.0, "wait_data": 0.0, "compute": 0.0, "chunks": 0}
+    filled, ready = queue.Queue(), queue.Queue()
+    pin_free = [threading.Event() for _ in range(npin)]
+    dev_free = [threading.Event() for _ in range(ndev)]
+    for ev in pin_free + dev_free:
         ev.set()
     stop = threading.Event()
 
-    def producer():
+    def wait(ev):
+        while not ev.wait(0.05):
+            if stop.is_set():
+                return False
+        return not stop.is_set()
+
+    def reader():
+        try:
+            for k, lo in enumerate(range(0, n, chunk)):
+                hi, slot = min(lo + chunk, n), k % npin
+                ta = time.time()
+                if not wait(pin_free[slot]):
+                    return
+                pin_free[slot].clear()
+                if pinned[slot] is None:
+                    pinned[slot] = host.PinnedBuffer(chunk * box * box, device)
+                tb = time.time()
+                fill(pinned[slot], lo, hi)
+                stats["wait_pinned"] += tb - ta; stats["read"] += time.time() - tb
+                filled.put((lo, hi, slot, None))
+            filled.put(None)
+        except BaseException as e:          # handed on: a reader failure must end in the ERROR line, not a traceback
+            filled.put((0, 0, 0, e))
+
+    def uploader():
         try:
             k = 0
-            for lo in range(0, n, chunk):
-                hi, slot = min(lo + chunk, n), k % nslot
-                while not free[slot].wait(0.05):
-                    if stop.is_set():
-                        return
-                if stop.is_set():
+            while True:
+                item = filled.get()
+                if item is None:
                     return
-                free[slot].clear()
-                fill(slot, lo, hi)
-                if L.ppm_device_upload(dev[slot], pinned[slot].ptr, (hi - lo) * sec) != 0:
+                lo, hi, pslot, err = item
+                if err is not None:
+                    ready.put((0, 0, 0, err))
+                    return
+                dslot = k % ndev
+                ta = time.time()
+                if not wait(dev_free[dslot]):
+                    return
+                dev_free[dslot].clear()
+                if dev[dslot] is None:
+                    dev[dslot] = L.ppm_device_alloc(chunk * sec)
+                    if not dev[dslot]:
+                        raise lib.PpmError(lib.last_error())
+                tb = time.time()
+                if L.ppm_device_upload(dev[dslot], pinned[pslot].ptr, (hi - lo) * sec) != 0:
                     raise lib.PpmError(lib.last_error())
-                ready.put((lo, hi, slot, None))
+                pin_free[pslot].set()
+                stats["wait_device"] += tb - ta; stats["upload"] += time.time() - tb
+                ready.put((lo, hi, dslot, None))
                 k += 1
-        except BaseException as e:          # handed to the consumer: a reader failure must end in the ERROR line, not a traceback
+        except BaseException as e:
             ready.put((0, 0, 0, e))
 
-    t = threading.Thread(target=producer, daemon=True)
-    t.start()
+    threads = [threading.Thread(target=reader, daemon=True), threading.Thread(target=uploader, daemon=True)]
+    for t in threads:
+        t.start()
     try:
         lo = 0
         while lo < n:
+            ta = time.time()
             a, hi, slot, err = ready.get()
             if err is not None:
                 raise ValueError(f"ERROR: reading the particle stack failed: {err}")
+            tb = time.time()
             yield a, hi, DeviceImages(dev[slot], hi - a, box)
-            free[slot].set()
+            dev_free[slot].set()
+            stats["wait_data"] += tb - ta; stats["compute"] += time.time() - tb; stats["chunks"] += 1
             lo = hi
     finally:
-        # the consumer may have raised inside the loop body: the producer must be done with the buffers before they are freed
+        # the consumer may have raised inside the loop body: the threads must be done with the buffers before they are freed
         stop.set()
-        t.join()
+        filled.put(None)
+        for t in threads:
+            t.join()
         if pool is not None:
             pool.shutdown(wait=True)
         if fd is not None:
             os.close(fd)
         for pb in pinned:
-            pb.close()
+            if pb is not None:
+                pb.close()
         for q in dev:
-            L.ppm_device_free(q)
+            if q:
+                L.ppm_device_free(q)
+
+
+def _pipeline_stats():
+    st = getattr(_iter_image_chunks, "stats", None)
+    if not st:
+        return "-"
+    return ("%d chunks; reader: read %.2f s, waited for a buffer %.2f s; uploader: copied %.2f s, waited for a buffer %.2f s; main thread: computed %.2f s, "
+            "waited for data %.2f s" % (st["chunks"], st["read"], st["wait_pinned"], st["upload"], st["wait_device"], st["compute"], st["wait_data"]))
 
 
 def _ssnr_ring_weights(n, stats_path, pixel):
@@ -244,6 +291,7 @@ def refine_cfg_from_answers(d, box):
 
 def refine3d_main(argv=None, stdin=None):
     t0 = time.time()
+    os.environ.setdefault("PPM_SYNC", "block")      # a spinning device wait starves the reader threads (measured: 29 k -> 53 k particles/s)
     try:
         d = prompts.parse_refine3d(prompts.read_answers(stdin or sys.stdin))
     except prompts.PromptError as e:
@@ -340,6 +388,7 @@ def refine3d_main(argv=None, stdin=None):
         print("%7d%8.2f%8.2f%8.2f%10.2f%10.2f%10.4f%9.4f" % (r[0], r[1], r[2], r[3], r[4], r[5], r[C["SCORE"]], c[C["SCORE"]]))
     print(f"\nRefined {len(rout)} particles in {time.time() - t0:.1f} s; mean score {rout[:, C['SCORE']].mean():.4f}")
     print(f"Timing: inputs {t1 - t0:.2f} s, device + reference {t2 - t1:.2f} s, particles {t3 - t2:.2f} s, outputs {time.time() - t3:.2f} s")
+    print("Pipeline: " + _pipeline_stats())
     print("\nRefine3D: Normal termination\n", flush=True)
     return 0
 
@@ -369,6 +418,7 @@ def read_dump(path):
 # ------------------------------------------------------------------------------------------ reconstruct3d
 def reconstruct3d_main(argv=None, stdin=None):
     t0 = time.time()
+    os.environ.setdefault("PPM_SYNC", "block")
     try:
         d = prompts.parse_reconstruct3d(prompts.read_answers(stdin or sys.stdin))
     except prompts.PromptError as e:
@@ -462,6 +512,7 @@ def reconstruct3d_main(argv=None, stdin=None):
         f.write("C Reconstruct3D (libpypmatch): particles %d..%d, inserted %d + %d\n" % (d["first"], d["last"], counts[1], counts[0]))
     print(f"\nInserted {counts[0] + counts[1]} of {len(rin)} particles in {time.time() - t0:.1f} s")
     print(f"Timing: inputs {t1 - t0:.2f} s, device {t2 - t1:.2f} s, particles {t3 - t2:.2f} s, dumps {time.time() - t3:.2f} s")
+    print("Pipeline: " + _pipeline_stats())
     print("NOTE: the dump files are in libpypmatch's own format (PPMDUMP1): only this build's local_merge3d / merge3d read them "
           "(frealign.py:1852 consumers must be replaced together, INTEGRATION.md 1)")
     print("\nNormal termination, intermediate files dumped")

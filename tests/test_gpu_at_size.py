@@ -1,0 +1,141 @@
+"""BASELINE.json configs 4 and 5 AT THEIR OWN SIZES on the GPU (the oracle-sized cases live in test_gpu_csp.py / test_sva.py):
+sub-tomogram alignment at 192^3 (the mixed-radix 2^6 x 3 transform, pruned, 32 sub-volumes per launch), extraction from 4096^2
+tilt images, constrained refinement at 128^2 boxes x 41 tilts.  Oracle comparisons on bounded samples (seconds of CPU); the rest
+through properties.  Tolerances: BASELINE.json's 0.1 deg / 0.5 px."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from pyp_amd import synth
+from pyp_amd.abi import CSP_PARTICLES, CspCfg, RefineCfg, SvaCfg
+from pyp_amd.formats import cistem, mrc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "bin")
+
+
+def _sva_cfg(n):      # the settings of bench.py's `sva` block = the 3DAVG refine protocol's band (src/pyp/refine/3DAVG/iteration_002_mode_3.xml)
+    return SvaCfg.make(n, window=(0.33 * n, 0.33 * n, 0.33 * n), window_sigma=4.0, highpass=(0.05, 0.01), lowpass=(0.125, 0.05), tol_angle=10.0, tol_shift=10.0)
+
+
+def test_sva_align_at_192_matches_oracle_on_four_sub_volumes():
+    from oracle import oracle as O
+    from pyp_amd import host
+    n = 192
+    vol, vols, poses, wedges = synth.make_subtomograms(n, 4, snr=0.1, device="cuda")
+    cfg = _sva_cfg(n)
+    start = synth.perturb_poses(poses, 3.0, 2.0)
+    want, wsc, _ = O.sva_align(O.Reference(vol, n / 2), cfg, vols.cpu().numpy(), wedges, start)
+    g = host.Reference(vol, n / 2)
+    got, gsc = g.sva_align(cfg, vols, wedges, start)
+    assert synth.pose_angle_error(want, got).max() < 0.1 and np.abs(want[:, 9:] - got[:, 9:]).max() < 0.5
+    assert np.abs(wsc - gsc).max() < 2e-3
+    assert synth.pose_angle_error(got, poses).mean() < 0.3 * synth.pose_angle_error(start, poses).mean()
+    got_h, gsc_h = g.sva_align(cfg, vols.cpu().numpy(), wedges, start)              # host volumes: same bits as resident ones
+    assert np.array_equal(got, got_h) and np.array_equal(gsc, gsc_h)
+
+
+def test_sva_align_at_192_properties_on_64_sub_volumes():
+    """Two launches of 32 sub-volumes: every alignment improves, the batch result does not depend on the batch it ran in, repeat
+    runs are bit-identical, and the bounds of the protocol hold."""
+    from pyp_amd import host
+    n, nv = 192, 64
+    vol, vols, poses, wedges = synth.make_subtomograms(n, nv, snr=0.1, device="cuda")
+    cfg = _sva_cfg(n)
+    start = synth.perturb_poses(poses, 3.0, 2.0)
+    g = host.Reference(vol, n / 2)
+    out, sc = g.sva_align(cfg, vols, wedges, start)
+    e0, e1 = synth.pose_angle_error(start, poses), synth.pose_angle_error(out, poses)
+    assert np.median(e1) < 0.1 and e1.max() < 0.5 and np.median(e1) < 0.05 * np.median(e0)
+    assert np.median(np.linalg.norm(out[:, 9:] - poses[:, 9:], axis=1)) < 0.1
+    _, sc0 = g.sva_align(SvaCfg.make(n, window=(0.33 * n,) * 3, window_sigma=4.0, highpass=(0.05, 0.01), lowpass=(0.125, 0.05), tol_angle=0.0, tol_shift=0.0),
+                         vols, wedges, start)
+    assert (sc >= sc0 - 1e-6).all() and sc.mean() > sc0.mean() + 0.02
+    again, sc2 = g.sva_align(cfg, vols, wedges, start)
+    assert np.array_equal(out, again) and np.array_equal(sc, sc2)
+    part, scp = g.sva_align(cfg, vols[40:50], wedges[40:50], start[40:50])
+    assert np.array_equal(part, out[40:50]) and np.array_equal(scp, sc[40:50])
+    assert np.abs(out[:, 9:] - start[:, 9:]).max() <= 10.0 + 1e-6
+
+
+def test_csp_extraction_from_4096_square_tilt_images(tmp_path):
+    """`csp` mode -2 on a 41 x 4096^2 tilt series (config 4's image size; 2.7 GB): every box equals the numpy restatement of
+    extract_particles_non_mpi + normalize_image (oracle/extract_oracle.py, pinned by reference-run fixtures), incl. boxes that
+    hang over the image edges."""
+    from oracle import extract_oracle as xo
+    nt, size, box, px = 41, 4096, 128, 2.0
+    rng = np.random.default_rng(41)
+    series = rng.normal(5.0, 2.0, (nt, size, size)).astype(np.float32)
+    npart = 24
+    xy = rng.uniform(200, size - 200, (npart, 2))
+    xy[0], xy[1], xy[2] = (10.0, 2000.0), (4090.0, 30.0), (2048.5, 4095.0)           # over the left / top-right / bottom edges
+    rows = cistem.default_rows(npart * nt, px, 300.0, 2.7, 0.07)
+    C = cistem.COL
+    rows[:, C["PIND"]] = np.repeat(np.arange(npart), nt)
+    rows[:, C["TIND"]] = rows[:, C["IMIND"]] = np.tile(np.arange(nt), npart)
+    drift = rng.normal(0, 3.0, (nt, 2))
+    rows[:, C["ORIGINAL_X_POSITION"]] = np.floor(np.repeat(xy[:, 0], nt) + np.tile(drift[:, 0], npart))
+    rows[:, C["ORIGINAL_Y_POSITION"]] = np.floor(np.repeat(xy[:, 1], nt) + np.tile(drift[:, 1], npart))
+    (tmp_path / "frealign" / "maps").mkdir(parents=True)
+    mrc.write(series, str(tmp_path / "frealign" / "ts.mrc"), pixel_size=px)
+    par = "frealign/maps/ts_r01_02.cistem"
+    cistem.write_parameters(str(tmp_path / par), rows)
+    parts = np.zeros((npart, 12)); parts[:, 0] = np.arange(npart); parts[:, 11] = 100.0
+    tilts = np.zeros((nt, 6)); tilts[:, 0] = np.arange(nt); tilts[:, 4] = np.linspace(-60, 60, nt); tilts[:, 5] = 85.0
+    cistem.write_extended(str(tmp_path / par.replace(".cistem", "_extended.cistem")), parts, tilts)
+    (tmp_path / ".pyp_config.toml").write_text('data_set = "tomo"\nscope_pixel = 2.0\ndata_bin = 1\nextract_bin = 1\nextract_box = 128\nparticle_rad = 80.0\n'
+                                               'refine_iter = 2\nrefine_rhref = "8"\n')
+    outs = []
+    for first, last in ((0, 11), (12, 23)):                    # two particle ranges like the caller's fan-out (local_run.py:441-464)
+        out = "frealign/ts_stack_%04d_%04d.mrc" % (first, last)
+        r = subprocess.run(f"{BIN}/csp {par} {par.replace('.cistem', '_extended.cistem')} -2 {first} {last} 1 frealign/ts.mrc {out}", shell=True, cwd=tmp_path,
+                           capture_output=True, text=True)
+        assert r.returncode == 0 and "CSP: Normal termination" in r.stdout, r.stdout[-1500:] + r.stderr[-500:]
+        outs.append(mrc.read(str(tmp_path / out)))
+    got = np.concatenate(outs)
+    assert got.shape == (npart * nt, box, box)
+    check = list(range(0, 3 * nt, 5)) + list(rng.choice(npart * nt, 40, replace=False))
+    for j in check:
+        t = int(rows[j, C["IMIND"]])
+        want, empty = xo.extract(series[t].astype(np.float64), [(rows[j, C["ORIGINAL_X_POSITION"]], rows[j, C["ORIGINAL_Y_POSITION"]])], box, 80.0, px)
+        assert not empty[0] and np.abs(got[j] - want[0]).max() < 5e-5, j
+    inner = rows[:, C["PIND"]] >= 3
+    bg = got[inner].reshape(inner.sum(), -1)
+    assert abs(bg.mean()) < 0.01 and abs(bg.std() - 1.0) < 0.01         # every box normalised on its own background ring
+
+
+def test_csp_refine_at_128_box_and_41_tilts_matches_oracle_on_eight_units():
+    """The geometry of bench.py's `csp` block (128^2 boxes, 41 tilts of -60..60 degrees, band 0.25 N): 8 particle units x 41
+    projections against the oracle; then 64 units through properties (refined closer to the truth, deterministic, units independent)."""
+    from oracle import oracle as O
+    from pyp_amd import host
+    from test_csp_cpu import _particle_angle_err, _perturb_particles
+    n, px = 128, 2.0
+    tl = np.linspace(-60, 60, 41)
+    cfg = RefineCfg.make(box=n, pixel_size=px, mask_radius=0.32 * n * px, res_high=px * n / (0.25 * n), res_signed_cc=30.0, global_search=0)
+    vol, stack, rows, parts, tilts = synth.make_tilt_series(n, 8, tl, pixel=px, snr=0.1, device="cuda")
+    imgs = stack.cpu().numpy()
+    p2 = _perturb_particles(parts)
+    rows2 = synth.csp_rows_from_params(rows, parts, tilts, p2, tilts)
+    cc = CspCfg.make(CSP_PARTICLES, tol_angle=(8, 8, 8), tol_shift=4.0)
+    wr, wp, wt, _ = O.csp_refine(O.Reference(vol, n / 2), cfg, cc, imgs, rows2, p2, tilts)
+    g = host.Reference(vol, n / 2)
+    gr, gp, gt = g.csp_refine(cfg, cc, imgs, rows2, p2, tilts)
+    assert _particle_angle_err(wp, gp).max() < 0.1 and np.abs(wp[:, 1:4] - gp[:, 1:4]).max() < 0.5
+    assert synth.angular_error_deg(wr, gr).max() < 0.1 and synth.shift_error_px(wr, gr, px).max() < 0.5
+    assert np.abs(wr[:, 14] - gr[:, 14]).max() < 0.05 and np.array_equal(gt, tilts)
+    assert _particle_angle_err(gp, parts).mean() < 0.3 * _particle_angle_err(p2, parts).mean()
+    # 64 units, resident stack
+    vol, stack, rows, parts, tilts = synth.make_tilt_series(n, 64, tl, pixel=px, snr=0.1, device="cuda", vol=vol, seed=7)
+    p2 = _perturb_particles(parts)
+    rows2 = synth.csp_rows_from_params(rows, parts, tilts, p2, tilts)
+    r1, q1, _ = g.csp_refine(cfg, cc, stack, rows2, p2, tilts)
+    assert np.median(_particle_angle_err(q1, parts)) < 0.25 and np.median(_particle_angle_err(q1, parts)) < 0.1 * np.median(_particle_angle_err(p2, parts))
+    r2, q2, _ = g.csp_refine(cfg, cc, stack, rows2, p2, tilts)
+    assert np.array_equal(r1, r2) and np.array_equal(q1, q2)
+    sub = CspCfg.make(CSP_PARTICLES, tol_angle=(8, 8, 8), tol_shift=4.0, first=10, last=19)
+    r3, q3, _ = g.csp_refine(cfg, sub, stack, rows2, p2, tilts)
+    assert np.array_equal(q3[10:20], q1[10:20]) and np.array_equal(q3[:10], p2[:10]) and np.array_equal(q3[20:], p2[20:])

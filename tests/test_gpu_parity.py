@@ -620,6 +620,31 @@ def test_external_accumulator_tensor_and_reduce(H, O):
         H.Accumulator(n, px, ext_tensor=torch.zeros(7, device="cuda"))
 
 
+def test_accum_reduce_through_the_c_abi_on_one_rank(H, O):
+    """ppm_comm_unique_id / ppm_comm_create / ppm_accum_reduce (include/ppm.h): librccl is opened on first use and
+    a one-rank communicator sums the accumulator with itself = identity, as all-reduce and as a reduce to root 0; counters
+    travel along.  More than one rank needs one GPU per rank (RCCL refuses two ranks on a device): world-size-2 logic is
+    covered with gloo in tests/test_dist_cpu.py."""
+    n, px = 32, 3.0
+    vol, imgs, rows = dataset(n, 12, px, 0.2)
+    rc = ReconCfg(box=n, pixel_size=px, res_limit=2 * px, normalize=1, mask_radius=0.4 * n * px)
+    acc = H.Accumulator(n, px)
+    acc.insert(rc, imgs, rows)
+    before, counts = acc.download(), acc.counts()
+    uid = H.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    comm = H.make_comm(1, 0, uid)
+    try:
+        acc.reduce(comm)                   # all-reduce
+        assert np.array_equal(acc.download(), before) and acc.counts() == counts and sum(counts) == 12
+        acc.reduce(comm, root=0)
+        assert np.array_equal(acc.download(), before) and acc.counts() == counts
+    finally:
+        H.destroy_comm(comm)
+    with pytest.raises(ValueError):
+        H.make_comm(1, 0, b"short")
+
+
 def test_largest_box_512_properties(H):
     """N = 512 (the largest supported box): no oracle at this size; the true pose must outscore perturbed poses and a
     local refinement from a perturbed start must move towards it."""
