@@ -110,6 +110,15 @@ typedef struct ppm_refine_cfg {
                                  mask of every particle image by a cosine-edged disc of that radius around the sphere's projection at the
                                  row's INPUT pose: centre = (M^T c)_xy + shift (M = Rz(phi) Ry(theta) Rz(psi)).  The background
                                  statistics keep using mask_radius.  Radius <= 0: off */
+    int use_priors;           /* 7 "use priors" (refine_priors, frealign.py:3841-3844, :3927) with the statistics of answer 3
+                                 (`<name>_stat.cistem`: row 0 = column means, row 1 = column variances over the data set,
+                                 src/pyp_main.py:2667-2674): every score the compass search compares is lowered by a Gaussian restraint
+                                 sum_i (p_i - mean_i)^2 / (2 var_i n_s) over the REFINED parameters with var_i > 0, angles wrapped to
+                                 +-180 degrees, n_s = pi (r_hi^2 - r_lo^2) the in-band samples of the full plane (so the restraint is a
+                                 log-prior in the units of LOGP).  SCORE / LOGP / SIGMA stay those of the data term alone.  Build-defined
+                                 (the absent program's rule is not visible); 0 = off */
+    float prior_mean[5];      /* psi, theta, phi (degrees), x, y (Angstrom) */
+    float prior_var[5];       /* their variances (degrees^2, Angstrom^2); <= 0 leaves that parameter unrestrained */
 } ppm_refine_cfg;
 
 /* Reconstruction settings = numeric answers of the reconstruct3d script (frealign.py:1780-1824). */
@@ -238,6 +247,17 @@ typedef struct ppm_sva_cfg {
     float step_tolerance;   /* smallest compass step (default 0.05 degrees / pixels) */
     int max_iterations;     /* 0 = until the step falls below step_tolerance, at most 12 */
     float band_factor;      /* frequency marching like the band_factor field of the refinement settings (0 = default 3, < 0 = off) */
+    int search_mode;        /* metric/alignment_mode of the protocol (iteration_002_mode_3.xml:29-38).  0 = rotation and translation REFINEMENT
+                               within the tolerances (the protocol's mode 1); 1 = GLOBAL rotation and translation search (the protocol's
+                               mode 0): the start rotation times every rotation of a grid of step `global_step` over the whole of SO(3)
+                               (theta_i = 180 i / (n - 1), n_phi = round(360 sin theta / step), n_psi = round(360 / step)), each scored at the
+                               27 shifts {-t, 0, t}^3 around the start (t = min(tol_shift, box / (4 r_g))) on the coarse band r_g the step
+                               allows (frequency marching with probe Delta / 2); the `n_candidates` best (rotation, shift) pairs get two
+                               compass iterations each (bounds: +-step about the grid rotation, +-tol_shift about the start shift), the best
+                               of them at the full band continues down to step_tolerance; 2 = translation only (the protocol's mode 2).
+                               Build-defined: the absent program ranks peaks of a spherical-harmonics correlation instead */
+    float global_step;      /* degrees; 0 = 15 */
+    int n_candidates;       /* metric/number_of_candidate_peaks_to_search; 0 = 25, at most 64 */
 } ppm_sva_cfg;
 /* volumes: n_vol * box^3 floats (x fastest); wedges: n_vol x {lwedge, uwedge} tilt limits in degrees (tilt axis = y);
  * poses: n_vol x 12 doubles {N row-major (9), shift x y z (pixels)}, start values in, refined values out; scores: n_vol. */

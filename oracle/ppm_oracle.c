@@ -157,11 +157,13 @@ static int geom_init(geom_t *g, const ppm_refine_cfg *c) {
     int Bs = (int)ceil(g->r_s) - 1;
     g->Ns = 2; while (g->Ns < 2 * (Bs + 1)) g->Ns <<= 1;
     g->step = (double)g->N / g->Ns;
-    double rx = c->search_range_x / g->a, ry = c->search_range_y / g->a;
-    g->RSx = rx > 0 ? (int)ceil(rx / g->step) : PPM_MAX_SHIFT_STEPS;
-    g->RSy = ry > 0 ? (int)ceil(ry / g->step) : PPM_MAX_SHIFT_STEPS;
-    if (g->RSx > PPM_MAX_SHIFT_STEPS) g->RSx = PPM_MAX_SHIFT_STEPS;
-    if (g->RSy > PPM_MAX_SHIFT_STEPS) g->RSy = PPM_MAX_SHIFT_STEPS;
+    /* answers 27 / 28: 0 = the mask radius (config/pyp_config.toml:5338-5343); limited only by the search grid (Ns / 2 - 1 steps) */
+    double rx = (c->search_range_x > 0 ? c->search_range_x : c->mask_radius) / g->a, ry = (c->search_range_y > 0 ? c->search_range_y : c->mask_radius) / g->a;
+    g->RSx = (int)ceil(rx / g->step); g->RSy = (int)ceil(ry / g->step);
+    if (g->RSx < 1) g->RSx = 1;
+    if (g->RSy < 1) g->RSy = 1;
+    if (g->RSx > g->Ns / 2 - 1) g->RSx = g->Ns / 2 - 1;
+    if (g->RSy > g->Ns / 2 - 1) g->RSy = g->Ns / 2 - 1;
     double d = c->angular_step > 0 ? c->angular_step : 15.0;
     sym_limits(c->symmetry, &g->phi_max, &g->theta_max);
     g->n_theta = (int)floor(g->theta_max / d + 0.5) + 1;
@@ -511,8 +513,34 @@ static double iter_band(const geom_t *g, double rm_px, double bf, const int en[5
     return rit < rcap ? rit : rcap;
 }
 
+/* answer 7 "use priors" (include/ppm.h, ppm_refine_cfg.use_priors): Gaussian restraint on the refined parameters */
+typedef struct { int on; double mean[5], w[5]; } prior_t;       /* w = 1 / (2 var n_s), shifts in pixels; 0 = unrestrained */
+static void prior_init(prior_t *p, const ppm_refine_cfg *cfg, const geom_t *g, const int en[5]) {
+    memset(p, 0, sizeof(*p));
+    if (!cfg->use_priors) return;
+    const double ns = ORC_PI * (g->r_hi * g->r_hi - g->r_lo * g->r_lo);
+    for (int i = 0; i < 5; i++) {
+        double var = cfg->prior_var[i], mean = cfg->prior_mean[i];
+        if (i >= 3) { mean /= g->a; var /= g->a * g->a; }
+        p->mean[i] = mean;
+        if (en[i] && var > 0 && ns > 0) { p->w[i] = 1.0 / (2.0 * var * ns); p->on = 1; }
+    }
+}
+static double prior_pen(const prior_t *p, const double M[9], const double sh[2]) {
+    if (!p || !p->on) return 0.0;
+    double v[5]; angles_from_matrix(M, &v[0], &v[1], &v[2]); v[3] = sh[0]; v[4] = sh[1];
+    double pen = 0;
+    for (int i = 0; i < 5; i++) {
+        if (!(p->w[i] > 0)) continue;
+        double d = v[i] - p->mean[i];
+        if (i < 3) { d = fmod(d, 360.0); if (d > 180.0) d -= 360.0; if (d < -180.0) d += 360.0; }
+        pen += p->w[i] * d * d;
+    }
+    return pen;
+}
+
 static void compass_iter(const oref_t *r, const geom_t *g, const ctf_t *c, const cpx *I, const double *wr,
-                         double rcap, double rm_px, double bf, const int en[5], cstate_t *s, long *nevals, double *sevals) {
+                         double rcap, double rm_px, double bf, const int en[5], cstate_t *s, long *nevals, double *sevals, const prior_t *pr) {
     /* en[]: psi, theta, phi, x, y.  rotational slots: 0 <- psi; 1,2 <- tilts if both theta and phi are
      * free, else slot 1 <- theta, slot 2 <- phi as Euler steps.  Every score of one iteration (centre,
      * 2 per free parameter, trial) is taken at the iteration's band. */
@@ -524,7 +552,7 @@ static void compass_iter(const oref_t *r, const geom_t *g, const ctf_t *c, const
     if (nfree) {
         double rmax = iter_band(g, rm_px, bf, en, s->ha, s->hs, rcap);
         double sper = floor(ORC_PI * rmax * rmax / 2);
-        double f0 = score_local(r, g, c, I, wr, rmax, s->M, s->sh); *nevals += 1; *sevals += sper;
+        double f0 = score_local(r, g, c, I, wr, rmax, s->M, s->sh) - prior_pen(pr, s->M, s->sh); *nevals += 1; *sevals += sper;
         for (int i = 0; i < 5; i++) {
             d[i] = 0; fp[i] = fm[i] = -1e300;
             if (!on[i]) continue;
@@ -533,7 +561,7 @@ static void compass_iter(const oref_t *r, const geom_t *g, const ctf_t *c, const
                 double hh = sg ? -h : h;
                 memcpy(Mq, s->M, sizeof(Mq)); shq[0] = s->sh[0]; shq[1] = s->sh[1];
                 if (i < 3) rot_step(s->M, i, tilt, hh, Mq); else shq[i - 3] += hh;
-                double v = score_local(r, g, c, I, wr, rmax, Mq, shq);
+                double v = score_local(r, g, c, I, wr, rmax, Mq, shq) - prior_pen(pr, Mq, shq);
                 if (sg) fm[i] = v; else fp[i] = v;
             }
             *nevals += 2; *sevals += 2 * sper; any = 1;
@@ -551,7 +579,7 @@ static void compass_iter(const oref_t *r, const geom_t *g, const ctf_t *c, const
             memcpy(Mt, s->M, sizeof(Mt));
             for (int i = 0; i < 3; i++) if (on[i] && d[i] != 0) { rot_step(Mt, i, tilt, d[i], T); memcpy(Mt, T, sizeof(T)); }
             shq[0] = s->sh[0] + d[3]; shq[1] = s->sh[1] + d[4];
-            double ft = score_local(r, g, c, I, wr, rmax, Mt, shq); *nevals += 1; *sevals += sper;
+            double ft = score_local(r, g, c, I, wr, rmax, Mt, shq) - prior_pen(pr, Mt, shq); *nevals += 1; *sevals += sper;
             int bi = -1, bs = 0; double fb = f0;
             for (int i = 0; i < 5; i++) {
                 if (!on[i]) continue;
@@ -655,6 +683,7 @@ int orc_refine_batch(void *refp, const ppm_refine_cfg *cfg, const float *images,
     double dstep = cfg->angular_step > 0 ? cfg->angular_step : 15.0;
     int en[5] = { cfg->refine_psi, cfg->refine_theta, cfg->refine_phi, cfg->refine_x, cfg->refine_y };
     const double bf = cfg->band_factor == 0 ? 3.0 : cfg->band_factor, rm_px = cfg->mask_radius / g.a;
+    prior_t pr; prior_init(&pr, cfg, &g, en);
     size_t nb = (size_t)g.H * g.W;
     int half = (g.n_psi % 2 == 0);                 /* psi and psi+180 share a slice (conjugate) */
     int npsi_store = half ? g.n_psi / 2 : g.n_psi;
@@ -729,12 +758,12 @@ int orc_refine_batch(void *refp, const ppm_refine_cfg *cfg, const float *images,
                 s.sh[0] = hits[a].sx * g.step; s.sh[1] = hits[a].sy * g.step;
                 s.ha = 0.5 * dstep; s.hs = g.step;
                 if (Tb > 0) {
-                    for (int t = 0; t < Tb; t++) compass_iter(r, &g, &c, I, wr, g.r_s, rm_px, bf, en, &s, &nev, &sev);
+                    for (int t = 0; t < Tb; t++) compass_iter(r, &g, &c, I, wr, g.r_s, rm_px, bf, en, &s, &nev, &sev, &pr);
                 } else s.f = hits[a].cc;
                 if (!have || s.f > best.f) { best = s; have = 1; }
             }
             if (cfg->local_refine)         /* the best hit continues at the full band */
-                for (int t = 0; t < Tc; t++) compass_iter(r, &g, &c, I, wr, g.r_hi, rm_px, bf, en, &best, &nev, &sev);
+                for (int t = 0; t < Tc; t++) compass_iter(r, &g, &c, I, wr, g.r_hi, rm_px, bf, en, &best, &nev, &sev, &pr);
             best.f = score_local(r, &g, &c, I, wr, g.r_hi, best.M, best.sh); nev++; sev += floor(ORC_PI * g.r_hi * g.r_hi / 2);
             free(hits); free(work); free(Wp); free(C2); free(Isown); free(wrsown);
         } else {
@@ -742,7 +771,7 @@ int orc_refine_batch(void *refp, const ppm_refine_cfg *cfg, const float *images,
             best.sh[0] = row[PPM_XSHIFT] / g.a; best.sh[1] = row[PPM_YSHIFT] / g.a;
             best.ha = cfg->local_angle_step > 0 ? cfg->local_angle_step : 2.5;
             best.hs = cfg->local_shift_step > 0 ? cfg->local_shift_step : 2.0;
-            if (cfg->local_refine) for (int t = 0; t < Tb + Tc; t++) compass_iter(r, &g, &c, I, wr, g.r_hi, rm_px, bf, en, &best, &nev, &sev);
+            if (cfg->local_refine) for (int t = 0; t < Tb + Tc; t++) compass_iter(r, &g, &c, I, wr, g.r_hi, rm_px, bf, en, &best, &nev, &sev, &pr);
             best.f = score_local(r, &g, &c, I, wr, g.r_hi, best.M, best.sh); nev++; sev += floor(ORC_PI * g.r_hi * g.r_hi / 2);
         }
         /* defocus refinement (answers 33, 34, 45; frealign.py:3960-3961, :3978): offsets scored at the final pose */
@@ -1412,6 +1441,74 @@ static double sva_score(const oref_t *r, const svs_t *sl, int ns, const cpx *F, 
     return (B > 0 && C > 0) ? A / sqrt(B * C) : 0.0;
 }
 
+/* `T` compass iterations of one sub-volume's pose (rotations about the specimen axes + 3-D shift, bounded by +-tol about where
+ * s->acc started), steps ha / hs halved after every iteration; frequency marching under the cap `rband`. */
+static void sva_compass(const oref_t *r, const svs_t *sl, int ns, const cpx *F, int N, double rband, double rm_px, double bf,
+                        const int en[6], const double tol[6], cunit_t *sp, double *hap, double *hsp, int T, long *nevp) {
+    cunit_t s = *sp;
+    double ha = *hap, hs = *hsp;
+    long nev = 0;
+    int en5[5] = { en[0], 0, 0, en[3], 0 };
+    geom_t g; memset(&g, 0, sizeof(g)); g.N = N;
+    for (int it = 0; it < T && ns > 0; it++) {
+        const double rmax = iter_band(&g, rm_px, bf, en5, ha, hs, rband);
+        const double f0 = sva_score(r, sl, ns, F, N, rmax, s.N, s.p); nev++;
+        double fp[6], fm[6], d[6]; int okp[6], okm[6];
+        for (int i = 0; i < 6; i++) {
+            d[i] = 0; fp[i] = fm[i] = -1e300; okp[i] = okm[i] = 0;
+            if (!en[i]) continue;
+            const double h = i < 3 ? ha : hs;
+            for (int sg = 0; sg < 2; sg++) {
+                double dd[6] = { 0, 0, 0, 0, 0, 0 }; dd[i] = sg ? -h : h;
+                cunit_t q; csp_apply(PPM_CSP_PARTICLES, &s, dd, &q);
+                const int ok = fabs(q.acc[i]) <= tol[i] + 1e-9;
+                const double val = sva_score(r, sl, ns, F, N, rmax, q.N, q.p); nev++;
+                if (sg) { fm[i] = ok ? val : -1e300; okm[i] = ok; } else { fp[i] = ok ? val : -1e300; okp[i] = ok; }
+            }
+            if (okp[i] && okm[i]) {
+                const double den = 2.0 * f0 - fp[i] - fm[i];
+                if (den > 1e-12) { double t = 0.5 * h * (fp[i] - fm[i]) / den; d[i] = t > h ? h : (t < -h ? -h : t); }
+                else { const double best = fp[i] > fm[i] ? fp[i] : fm[i]; d[i] = best > f0 ? (fp[i] > fm[i] ? h : -h) : 0.0; }
+            } else if (okp[i]) d[i] = fp[i] > f0 ? h : 0.0;
+            else if (okm[i]) d[i] = fm[i] > f0 ? -h : 0.0;
+            if (s.acc[i] + d[i] > tol[i]) d[i] = tol[i] - s.acc[i];
+            if (s.acc[i] + d[i] < -tol[i]) d[i] = -tol[i] - s.acc[i];
+        }
+        cunit_t tr; csp_apply(PPM_CSP_PARTICLES, &s, d, &tr);
+        const double ft = sva_score(r, sl, ns, F, N, rmax, tr.N, tr.p); nev++;
+        int bi = -1, bs = 0; double fb = f0;
+        for (int i = 0; i < 6; i++) {
+            if (!en[i]) continue;
+            if (fp[i] > fb) { fb = fp[i]; bi = i; bs = 1; }
+            if (fm[i] > fb) { fb = fm[i]; bi = i; bs = -1; }
+        }
+        if (ft > f0 && ft >= fb) s = tr;
+        else if (bi >= 0) { double dd[6] = { 0, 0, 0, 0, 0, 0 }; dd[bi] = bs * (bi < 3 ? ha : hs); cunit_t q; csp_apply(PPM_CSP_PARTICLES, &s, dd, &q); s = q; }
+        ha *= 0.5; hs *= 0.5;
+    }
+    *sp = s; *hap = ha; *hsp = hs; *nevp += nev;
+}
+
+/* rotations of the global grid (include/ppm.h, ppm_sva_cfg.search_mode): G = Rz(phi) Ry(theta) Rz(psi) for grid point `idx` */
+static int sva_grid_size(double step, int *n_theta, int *n_psi) {
+    *n_theta = (int)floor(180.0 / step + 0.5) + 1; if (*n_theta < 2) *n_theta = 2;
+    *n_psi = (int)floor(360.0 / step + 0.5); if (*n_psi < 1) *n_psi = 1;
+    int nd = 0;
+    for (int i = 0; i < *n_theta; i++) { int np = (int)floor(360.0 * sin(ORC_PI * i / (*n_theta - 1)) / step + 0.5); if (np < 1) np = 1; nd += np; }
+    return nd * *n_psi;
+}
+static void sva_grid_rotation(double step, int n_theta, int n_psi, int idx, double G[9]) {
+    int dir = idx / n_psi, k = idx - dir * n_psi, acc = 0;
+    double th = 0, ph = 0;
+    for (int i = 0; i < n_theta; i++) {
+        double t = 180.0 * i / (n_theta - 1);
+        int np = (int)floor(360.0 * sin(t * ORC_PI / 180.0) / step + 0.5); if (np < 1) np = 1;
+        if (dir < acc + np) { th = t; ph = 360.0 * (dir - acc) / np; break; }
+        acc += np;
+    }
+    euler_full(k * 360.0 / n_psi, th, ph, G);
+}
+
 int orc_sva_align(void *refp, const ppm_sva_cfg *cfg, const float *volumes, int n_vol, const float *wedges, double *poses, double *scores,
                   long *eval_count) {
     fft_tables();
@@ -1429,7 +1526,12 @@ int orc_sva_align(void *refp, const ppm_sva_cfg *cfg, const float *volumes, int 
     int T = cfg->max_iterations;
     if (T <= 0) { double m = ha0 > hs0 ? ha0 : hs0; T = m > steptol ? (int)ceil(log(m / steptol) / log(2.0)) : 1; if (T > 12) T = 12; if (T < 1) T = 1; }
     int en[6]; double tol[6];
-    for (int k = 0; k < 3; k++) { en[k] = cfg->tol_angle > 0; tol[k] = cfg->tol_angle; en[3 + k] = cfg->tol_shift > 0; tol[3 + k] = cfg->tol_shift; }
+    for (int k = 0; k < 3; k++) { en[k] = cfg->tol_angle > 0 && cfg->search_mode != 2; tol[k] = cfg->tol_angle; en[3 + k] = cfg->tol_shift > 0; tol[3 + k] = cfg->tol_shift; }
+    const int global = cfg->search_mode == 1;
+    const double gstep = cfg->global_step > 0 ? cfg->global_step : 15.0;
+    int g_nth = 0, g_nps = 0;
+    const int n_grid = global ? sva_grid_size(gstep, &g_nth, &g_nps) : 0;
+    int K = cfg->n_candidates > 0 ? cfg->n_candidates : 25; if (K > 64) K = 64; if (K > n_grid) K = n_grid;
     long nev = 0;
     int err = 0;
 #pragma omp parallel for schedule(dynamic, 1) reduction(+ : nev)
@@ -1473,44 +1575,52 @@ int orc_sva_align(void *refp, const ppm_sva_cfg *cfg, const float *volumes, int 
         free(f);
         cunit_t s; memset(&s, 0, sizeof(s));
         memcpy(s.N, poses + (size_t)v * 12, 9 * sizeof(double)); memcpy(s.p, poses + (size_t)v * 12 + 9, 3 * sizeof(double));
-        double ha = ha0, hs = hs0;
-        int en5[5] = { en[0], 0, 0, en[3], 0 };
-        geom_t g; memset(&g, 0, sizeof(g)); g.N = N;
-        for (int it = 0; it < T && ns > 0; it++) {
-            const double rmax = iter_band(&g, rm_px, bf, en5, ha, hs, rband);
-            const double f0 = sva_score(r, sl, ns, F, N, rmax, s.N, s.p); nev++;
-            double fp[6], fm[6], d[6]; int okp[6], okm[6];
-            for (int i = 0; i < 6; i++) {
-                d[i] = 0; fp[i] = fm[i] = -1e300; okp[i] = okm[i] = 0;
-                if (!en[i]) continue;
-                const double h = i < 3 ? ha : hs;
-                for (int sg = 0; sg < 2; sg++) {
-                    double dd[6] = { 0, 0, 0, 0, 0, 0 }; dd[i] = sg ? -h : h;
-                    cunit_t q; csp_apply(PPM_CSP_PARTICLES, &s, dd, &q);
-                    const int ok = fabs(q.acc[i]) <= tol[i] + 1e-9;
-                    const double val = sva_score(r, sl, ns, F, N, rmax, q.N, q.p); nev++;
-                    if (sg) { fm[i] = ok ? val : -1e300; okm[i] = ok; } else { fp[i] = ok ? val : -1e300; okp[i] = ok; }
+        if (!global) {
+            double ha = ha0, hs = hs0;
+            sva_compass(r, sl, ns, F, N, rband, rm_px, bf, en, tol, &s, &ha, &hs, T, &nev);
+        } else if (ns > 0) {
+            /* coarse band of the grid step, coarse shift probe */
+            geom_t g; memset(&g, 0, sizeof(g)); g.N = N;
+            const int enr[5] = { 1, 0, 0, 0, 0 };
+            const double rg = iter_band(&g, rm_px, bf, enr, 0.5 * gstep, 0.0, rband);
+            double tsh = cfg->tol_shift > 0 ? N / (4.0 * rg) : 0.0; if (tsh > cfg->tol_shift) tsh = cfg->tol_shift;
+            const int nshift = tsh > 0 ? 27 : 1;
+            double *gs = (double *)malloc((size_t)n_grid * sizeof(double)); int *gi = (int *)malloc((size_t)n_grid * sizeof(int));
+            for (int q = 0; q < n_grid; q++) {
+                double G[9], Nq[9]; sva_grid_rotation(gstep, g_nth, g_nps, q, G); mat_mul3(s.N, G, Nq);
+                double best = -1e300; int bsi = 0;
+                for (int si = 0; si < nshift; si++) {
+                    double pq[3] = { s.p[0], s.p[1], s.p[2] };
+                    if (nshift > 1) { pq[0] += (si % 3 - 1) * tsh; pq[1] += ((si / 3) % 3 - 1) * tsh; pq[2] += (si / 9 - 1) * tsh; }
+                    const double val = sva_score(r, sl, ns, F, N, rg, Nq, pq); nev++;
+                    if (val > best) { best = val; bsi = si; }
                 }
-                if (okp[i] && okm[i]) {
-                    const double den = 2.0 * f0 - fp[i] - fm[i];
-                    if (den > 1e-12) { double t = 0.5 * h * (fp[i] - fm[i]) / den; d[i] = t > h ? h : (t < -h ? -h : t); }
-                    else { const double best = fp[i] > fm[i] ? fp[i] : fm[i]; d[i] = best > f0 ? (fp[i] > fm[i] ? h : -h) : 0.0; }
-                } else if (okp[i]) d[i] = fp[i] > f0 ? h : 0.0;
-                else if (okm[i]) d[i] = fm[i] > f0 ? -h : 0.0;
-                if (s.acc[i] + d[i] > tol[i]) d[i] = tol[i] - s.acc[i];
-                if (s.acc[i] + d[i] < -tol[i]) d[i] = -tol[i] - s.acc[i];
+                gs[q] = best; gi[q] = bsi;
             }
-            cunit_t tr; csp_apply(PPM_CSP_PARTICLES, &s, d, &tr);
-            const double ft = sva_score(r, sl, ns, F, N, rmax, tr.N, tr.p); nev++;
-            int bi = -1, bs = 0; double fb = f0;
-            for (int i = 0; i < 6; i++) {
-                if (!en[i]) continue;
-                if (fp[i] > fb) { fb = fp[i]; bi = i; bs = 1; }
-                if (fm[i] > fb) { fb = fm[i]; bi = i; bs = -1; }
+            /* top-K (ties -> lower grid index), two compass iterations each, the best at the full band continues */
+            const double tolg[6] = { gstep, gstep, gstep, tol[3], tol[4], tol[5] };
+            const int eng[6] = { 1, 1, 1, en[3], en[4], en[5] };
+            cunit_t bestc; double bestf = -1e300, bha = 0, bhs = 0; int have = 0;
+            for (int a2 = 0; a2 < K; a2++) {
+                int bq = -1;
+                for (int q = 0; q < n_grid; q++) if (gi[q] >= 0 && (bq < 0 || gs[q] > gs[bq])) bq = q;
+                if (bq < 0) break;
+                cunit_t c = s; double G[9], Nq[9]; sva_grid_rotation(gstep, g_nth, g_nps, bq, G); mat_mul3(s.N, G, Nq); memcpy(c.N, Nq, sizeof(Nq));
+                const int si = gi[bq];
+                if (nshift > 1) { const double dd[3] = { (si % 3 - 1) * tsh, ((si / 3) % 3 - 1) * tsh, (si / 9 - 1) * tsh }; for (int k = 0; k < 3; k++) { c.p[k] += dd[k]; c.acc[3 + k] = dd[k]; } }
+                gi[bq] = -1;
+                double ha = 0.5 * gstep, hs = 0.5 * tsh;
+                sva_compass(r, sl, ns, F, N, rband, rm_px, bf, eng, tolg, &c, &ha, &hs, 2, &nev);
+                const double fc = sva_score(r, sl, ns, F, N, rband, c.N, c.p); nev++;
+                if (!have || fc > bestf) { bestc = c; bestf = fc; bha = ha; bhs = hs; have = 1; }
             }
-            if (ft > f0 && ft >= fb) s = tr;
-            else if (bi >= 0) { double dd[6] = { 0, 0, 0, 0, 0, 0 }; dd[bi] = bs * (bi < 3 ? ha : hs); cunit_t q; csp_apply(PPM_CSP_PARTICLES, &s, dd, &q); s = q; }
-            ha *= 0.5; hs *= 0.5;
+            free(gs); free(gi);
+            if (have) {
+                s = bestc;
+                double m = bha > bhs ? bha : bhs;
+                int Tf = m > steptol ? (int)ceil(log(m / steptol) / log(2.0)) : 0; if (Tf > 12) Tf = 12;
+                sva_compass(r, sl, ns, F, N, rband, rm_px, bf, eng, tolg, &s, &bha, &bhs, Tf, &nev);
+            }
         }
         memcpy(poses + (size_t)v * 12, s.N, 9 * sizeof(double)); memcpy(poses + (size_t)v * 12 + 9, s.p, 3 * sizeof(double));
         if (scores) { scores[v] = ns > 0 ? sva_score(r, sl, ns, F, N, rband, s.N, s.p) : 0.0; nev++; }

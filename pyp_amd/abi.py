@@ -19,11 +19,13 @@ class RefineCfg(C.Structure):
         ("local_angle_step", C.c_float), ("local_shift_step", C.c_float), ("symmetry", C.c_char * 8), ("band_factor", C.c_float),
         ("refine_defocus", C.c_int), ("defocus_range", C.c_float), ("defocus_step", C.c_float),
         ("focus", C.c_float * 4),
+        ("use_priors", C.c_int), ("prior_mean", C.c_float * 5), ("prior_var", C.c_float * 5),
     ]
 
     @classmethod
     def make(cls, **kw):
         focus = kw.pop("focus", None)
+        priors = kw.pop("priors", None)          # (mean[5], var[5]) of psi, theta, phi (degrees), x, y (Angstrom)
         d = dict(molecular_mass_kda=0.0, res_low=0.0, res_signed_cc=0.0, search_mask_radius=0.0, res_search=0.0,
                  angular_step=15.0, top_hits=20, search_range_x=0.0, search_range_y=0.0, global_search=1,
                  local_refine=1, refine_psi=1, refine_theta=1, refine_phi=1, refine_x=1, refine_y=1, normalize=1,
@@ -40,6 +42,10 @@ class RefineCfg(C.Structure):
         c = cls(**d)
         if focus is not None:
             c.focus[:] = [float(v) for v in focus]
+        if priors is not None:
+            c.use_priors = 1
+            c.prior_mean[:] = [float(v) for v in priors[0]]
+            c.prior_var[:] = [float(v) for v in priors[1]]
         return c
 
 
@@ -88,15 +94,16 @@ class SvaCfg(C.Structure):
     _fields_ = [("box", C.c_int), ("pixel_size", C.c_float), ("window", C.c_float * 3), ("window_sigma", C.c_float),
                 ("highpass_cutoff", C.c_float), ("highpass_decay", C.c_float), ("lowpass_cutoff", C.c_float), ("lowpass_decay", C.c_float),
                 ("use_missing_wedge", C.c_int), ("tol_angle", C.c_float), ("tol_shift", C.c_float), ("step_tolerance", C.c_float),
-                ("max_iterations", C.c_int), ("band_factor", C.c_float)]
+                ("max_iterations", C.c_int), ("band_factor", C.c_float), ("search_mode", C.c_int), ("global_step", C.c_float), ("n_candidates", C.c_int)]
 
     @classmethod
     def make(cls, box, pixel_size=1.0, window=(0, 0, 0), window_sigma=0.0, highpass=(0.0, 0.0), lowpass=(0.25, 0.05), use_missing_wedge=1,
-             tol_angle=10.0, tol_shift=5.0, step_tolerance=0.05, max_iterations=0, band_factor=0.0):
+             tol_angle=10.0, tol_shift=5.0, step_tolerance=0.05, max_iterations=0, band_factor=0.0, search_mode=0, global_step=0.0, n_candidates=0):
         return cls(box=int(box), pixel_size=float(pixel_size), window=(C.c_float * 3)(*[float(x) for x in window]), window_sigma=float(window_sigma),
                    highpass_cutoff=float(highpass[0]), highpass_decay=float(highpass[1]), lowpass_cutoff=float(lowpass[0]),
                    lowpass_decay=float(lowpass[1]), use_missing_wedge=int(use_missing_wedge), tol_angle=float(tol_angle),
-                   tol_shift=float(tol_shift), step_tolerance=float(step_tolerance), max_iterations=int(max_iterations), band_factor=float(band_factor))
+                   tol_shift=float(tol_shift), step_tolerance=float(step_tolerance), max_iterations=int(max_iterations), band_factor=float(band_factor),
+                   search_mode=int(search_mode), global_step=float(global_step), n_candidates=int(n_candidates))
 
 
 class FinalCfg(C.Structure):

@@ -92,13 +92,18 @@ inline bool geom_init(Geom &g, const ppm_refine_cfg &c, std::string &err) {
     if (g.B < 2) { err = "resolution limits leave fewer than 3 Fourier pixels"; return false; }
     g.Ns = 2; while (g.Ns < 2 * (g.Bs + 1)) g.Ns <<= 1;
     g.step = (double)g.N / g.Ns;
-    double rx = c.search_range_x / g.a, ry = c.search_range_y / g.a;
-    g.RSx = rx > 0 ? (int)std::ceil(rx / g.step) : PPM_MAX_SHIFT_STEPS;
-    g.RSy = ry > 0 ? (int)std::ceil(ry / g.step) : PPM_MAX_SHIFT_STEPS;
-    g.range_asked_px = (rx > 0 && ry > 0) ? std::max(rx, ry) : 0.0;
-    g.range_capped = !(rx > 0) || !(ry > 0) || g.RSx > PPM_MAX_SHIFT_STEPS || g.RSy > PPM_MAX_SHIFT_STEPS;
-    if (g.RSx > PPM_MAX_SHIFT_STEPS) g.RSx = PPM_MAX_SHIFT_STEPS;
-    if (g.RSy > PPM_MAX_SHIFT_STEPS) g.RSy = PPM_MAX_SHIFT_STEPS;
+    // answers 27 / 28: 0 means the mask radius ("0.0 = mask radius", config/pyp_config.toml:5338-5343); the window is limited
+    // only by the search grid itself (shifts beyond Ns / 2 - 1 steps alias).  Windows wider than PPM_MAX_SHIFT_STEPS steps
+    // either side are searched as overlapping tiles of that half-width (ppm_refine_batch).
+    double rx = (c.search_range_x > 0 ? c.search_range_x : c.mask_radius) / g.a, ry = (c.search_range_y > 0 ? c.search_range_y : c.mask_radius) / g.a;
+    g.RSx = (int)std::ceil(rx / g.step); g.RSy = (int)std::ceil(ry / g.step);
+    if (g.RSx < 1) g.RSx = 1;
+    if (g.RSy < 1) g.RSy = 1;
+    g.range_asked_px = std::max(rx, ry);
+    const int rs_max = g.Ns / 2 - 1;
+    g.range_capped = g.RSx > rs_max || g.RSy > rs_max;
+    if (g.RSx > rs_max) g.RSx = rs_max;
+    if (g.RSy > rs_max) g.RSy = rs_max;
     g.dstep = c.angular_step > 0 ? c.angular_step : 15.0;
     char symbuf[9]; std::memcpy(symbuf, c.symmetry, 8); symbuf[8] = 0;
     sym_limits(symbuf, g.phi_max, g.theta_max);

@@ -633,6 +633,46 @@ __global__ void __launch_bounds__(256, 2) k_slice_norms(NormP P) {
 // ---------------------------------------------------------------------------------- global search
 struct Hit { float cc; int orient; int sx, sy; };
 
+// Shift windows wider than the kernel's (tiles, ppm_refine_batch): the search tables of a chunk are multiplied by the phase ramp
+// e^{+2 pi i (kx dcx + ky dcy) / Ns}, which moves the window's centre by (dcx, dcy) search-grid steps.  Wp: [n][Hs][64].
+__global__ void __launch_bounds__(256) k_wp_ramp(float2 *Wp, size_t total, int Bs, int Ns, int dcx, int dcy, const float2 *twN) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int kx = (int)(i & 63), ky = (int)((i >> 6) % (size_t)(2 * Bs + 1)) - Bs;
+    const int t = (((kx * dcx + ky * dcy) % Ns) + Ns) % Ns;
+    const float2 w = twN[t], v = Wp[i];
+    Wp[i] = make_float2(v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x);
+}
+
+// Top-K of the union of the tiles' top-K lists (tiles: [ntiles][n][K], shifts relative to the tile centres cx / cy): an
+// orientation's score is its best over the tiles; ties -> lower orientation index, like the single-window selection.  The true
+// top-K of the whole window is contained in the union (an orientation that beats fewer than K others overall beats fewer than K
+// in the tile that holds its maximum).  One thread per particle.
+__global__ void k_merge_hits(Hit *tiles, Hit *out, int n, int K, int ntiles, const int *cx, const int *cy) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    for (int k = 0; k < K; k++) {
+        int bt = -1, bj = -1; float bc = -3.0e38f; int bo = 0x7fffffff;
+        for (int t = 0; t < ntiles; t++) {
+            const Hit *h = tiles + ((size_t)t * n + p) * K;
+            for (int j = 0; j < K; j++) {
+                if (h[j].orient < 0) continue;
+                if (h[j].cc > bc || (h[j].cc == bc && h[j].orient < bo)) { bc = h[j].cc; bo = h[j].orient; bt = t; bj = j; }
+            }
+        }
+        Hit o; o.cc = 0.f; o.orient = 0; o.sx = 0; o.sy = 0;
+        if (bt >= 0) {
+            o = tiles[((size_t)bt * n + p) * K + bj];
+            o.sx += cx[bt]; o.sy += cy[bt];
+            for (int t = 0; t < ntiles; t++) {          // strike the orientation out everywhere
+                Hit *h = tiles + ((size_t)t * n + p) * K;
+                for (int j = 0; j < K; j++) if (h[j].orient == bo) h[j].orient = -1;
+            }
+        }
+        out[(size_t)p * K + k] = o;
+    }
+}
+
 // Pair twiddles e^{+2 pi i t j / Ns}, [t][j-1] for the row pair ky = +-t: wave-uniform, fetched with scalar loads.
 // Stored as {cos, cos, sin, sin} so that a scalar load delivers the two operand pairs of the packed FMAs as they are.
 // The table belongs to the reference handle (two references with different search grids may be live at once); it is read

@@ -86,7 +86,23 @@ struct LocalP {
     // frequency marching: band (squared) and sample-list prefix of every iteration, and of the final score
     float rmax2_it[kMaxIters]; int S_it[kMaxIters];
     float rmax2_final; int S_final;
+    // answer 7 "use priors" (include/ppm.h): Gaussian restraint on the refined parameters; w = 1 / (2 var n_s), shifts in pixels
+    int use_priors; double pmean[5], pw[5];
 };
+
+// restraint of one pose (k_local's compass; same expression as the oracle's prior_pen)
+__device__ inline double d_prior_pen(const LocalP &P, const double *M, double shx, double shy) {
+    double v[5]; d_angles(M, v[0], v[1], v[2]); v[3] = shx; v[4] = shy;
+    double pen = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        if (!(P.pw[i] > 0)) continue;
+        double d = v[i] - P.pmean[i];
+        if (i < 3) { d = fmod(d, 360.0); if (d > 180.0) d -= 360.0; if (d < -180.0) d += 360.0; }
+        pen += P.pw[i] * d * d;
+    }
+    return pen;
+}
 
 constexpr int kMaxCand = 13;   // scores per sweep: 2 per free parameter + the centre (k_local: 11; constrained particle search: 13), or 1
 constexpr int kMaxGroup = 7;   // gathers per sweep: 6 angular neighbours + the centre (shared with the 4 shift neighbours)
@@ -220,6 +236,7 @@ __global__ void __launch_bounds__(256, 5) k_local(LocalP P) {
     __shared__ double score[kMaxCand];
     __shared__ LState st;
     __shared__ double sfp[5], sfm[5], sd[5], sMt[9], sshq[2], sf0;
+    __shared__ double spen[kMaxCand];                 // restraint of every slot's pose (use_priors)
     const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;      // 128 or 256 threads (few samples per sweep: smaller blocks)
     const int nw = nthr >> 6, wave = tid >> 6, nr = P.nr;
     float *const ringA = lsm, *const sumB = lsm + kMaxCand * nw * nr, *const sumC = sumB + kMaxCand * nw;
@@ -262,11 +279,13 @@ __global__ void __launch_bounds__(256, 5) k_local(LocalP P) {
                     d_rot_step(st.M, i, tilt, sg ? -st.ha : st.ha, Mq);
                     set_rot(g, Mq); plan.nv[g] = 1; plan.slot0[g] = g;
                     plan.sh[g][0] = (float)st.sh[0]; plan.sh[g][1] = (float)st.sh[1];
+                    if (P.use_priors) spen[g] = d_prior_pen(P, Mq, st.sh[0], st.sh[1]);
                 }
             } else if (tid == 6) {
                 int q = nang, g = nang;
                 set_rot(g, st.M); plan.slot0[g] = q;
                 plan.sh[q][0] = (float)st.sh[0]; plan.sh[q][1] = (float)st.sh[1];
+                if (P.use_priors) spen[q] = d_prior_pen(P, st.M, st.sh[0], st.sh[1]);
                 q++;
                 int nv = 1;
                 for (int i = 3; i < 5; i++) {
@@ -275,6 +294,7 @@ __global__ void __launch_bounds__(256, 5) k_local(LocalP P) {
                         double shq[2] = { st.sh[0], st.sh[1] };
                         shq[i - 3] += sg ? -st.hs : st.hs;
                         plan.sh[q][0] = (float)shq[0]; plan.sh[q][1] = (float)shq[1];
+                        if (P.use_priors) spen[q] = d_prior_pen(P, st.M, shq[0], shq[1]);
                         q++; nv++;
                     }
                 }
@@ -288,6 +308,7 @@ __global__ void __launch_bounds__(256, 5) k_local(LocalP P) {
             if (tid == 0) {
                 int q = 0, qc = 0;
                 for (int i = 0; i < 3; i++) qc += P.en[i] ? 2 : 0;
+                if (P.use_priors) for (int k = 0; k < plan.nslots; k++) score[k] -= spen[k];
                 const double f0 = score[qc];
                 sf0 = f0;
                 for (int i = 0; i < 5; i++) {
@@ -314,7 +335,7 @@ __global__ void __launch_bounds__(256, 5) k_local(LocalP P) {
             __syncthreads();
             sweep();
             if (tid == 0) {
-                const double ft = score[0], f0 = sf0;
+                const double ft = score[0] - (P.use_priors ? d_prior_pen(P, sMt, sshq[0], sshq[1]) : 0.0), f0 = sf0;
                 int bi = -1, bs = 0; double fb = f0;
                 for (int i = 0; i < 5; i++) {
                     if (!P.en[i]) continue;

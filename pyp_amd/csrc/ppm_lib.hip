@@ -177,7 +177,8 @@ struct ppm_ref {
     DevBuf<float4> rowtw;            // k_global's row-pair twiddles for this reference's current search grid
     DevBuf<int> sh;
     DevBuf<uint32_t> samples;
-    DevBuf<Hit> hits;
+    DevBuf<Hit> hits, hits_t;        // hits_t: per-tile top-K lists of a shift window wider than the kernel's
+    DevBuf<int> tile_c;
     DevBuf<LState> states, states2;
     std::string bank_key;
     long last_counts[4] = { 0, 0, 0, 0 };
@@ -556,9 +557,9 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
     }
     if (cfg->global_search && gm.range_capped) {
         char b[320];
-        std::snprintf(b, sizeof(b), "%sNOTE: shift window of the grid search: +-%.0f x +-%.0f pixels (%d x %d search-grid steps of %.1f pixels; asked: %s); the refinement of "
-                      "the hits is not limited to it", ref->note.empty() ? "" : "\n", gm.RSx * gm.step, gm.RSy * gm.step, gm.RSx, gm.RSy, gm.step,
-                      gm.range_asked_px > 0 ? (std::to_string((int)std::lround(gm.range_asked_px)) + " pixels").c_str() : "0 = the mask radius");
+        std::snprintf(b, sizeof(b), "%sNOTE: shift window of the grid search: +-%.0f x +-%.0f pixels (%d x %d search-grid steps of %.1f pixels, the most the "
+                      "search grid of %d points holds; asked: %.0f pixels); the refinement of the hits is not limited to it", ref->note.empty() ? "" : "\n",
+                      gm.RSx * gm.step, gm.RSy * gm.step, gm.RSx, gm.RSy, gm.step, gm.Ns, gm.range_asked_px);
         ref->note += b;
     }
     if (gm.B > (ref->B + 1) / ref->pad - 1) return fail(-22, "high-resolution limit exceeds the band the reference was prepared for");
@@ -586,7 +587,18 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
     HIPCHK(hipMemcpyAsync(ref->samples.p, sl.packed.data(), S_pad * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
 
     const size_t NN = (size_t)gm.N * gm.N, HW = (size_t)gm.H * gm.W, HS = (size_t)gm.Hs * 64;
-    const int Rwin = std::max(gm.RSx, gm.RSy);
+    // shift window: the kernel searches +-PPM_MAX_SHIFT_STEPS steps; a wider window is covered by overlapping tiles of that
+    // half-width whose union is exactly [-RS, RS] (centres cxs / cys, in steps)
+    const int Rtx = std::min(gm.RSx, PPM_MAX_SHIFT_STEPS), Rty = std::min(gm.RSy, PPM_MAX_SHIFT_STEPS);
+    auto tile_centres = [](int RS, int Rt) {
+        const int T = (2 * RS + 1 + 2 * Rt) / (2 * Rt + 1);
+        std::vector<int> c(T, 0);
+        for (int i = 0; i < T && T > 1; i++) c[i] = -RS + Rt + (int)(((long)i * 2 * (RS - Rt)) / (T - 1));
+        return c;
+    };
+    const std::vector<int> cxs = tile_centres(gm.RSx, Rtx), cys = tile_centres(gm.RSy, Rty);
+    const int ntiles = (int)(cxs.size() * cys.size());
+    const int Rwin = std::max(Rtx, Rty);
     // bank rows per slice in the paired order of k_global: row 0 = ky 0, row 1 = empty, rows 2t / 2t+1 = ky +t / -t
     const int HsP = ((2 * (gm.Bs + 1) + 2 * global_unroll(Rwin) - 1) / (2 * global_unroll(Rwin))) * (2 * global_unroll(Rwin));   // k_global walks 2 U rows per trip
     const size_t HSP = (size_t)HsP * 64;
@@ -691,6 +703,17 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
     LP.cv = cv; LP.samples = ref->samples.p; LP.Il = ref->Il.p; LP.cw = ref->cw.p; LP.S_pad = S_pad; LP.nrings = nrings; LP.N = gm.N;
     LP.rlo2 = (float)(gm.r_lo * gm.r_lo); LP.ring_signed = (float)std::min(gm.ring_signed, 1e30);
     LP.en[0] = cfg->refine_psi; LP.en[1] = cfg->refine_theta; LP.en[2] = cfg->refine_phi; LP.en[3] = cfg->refine_x; LP.en[4] = cfg->refine_y;
+    LP.use_priors = 0;
+    for (int i = 0; i < 5; i++) { LP.pmean[i] = 0; LP.pw[i] = 0; }
+    if (cfg->use_priors) {          // Gaussian restraint on the refined parameters (include/ppm.h; same numbers as the oracle's prior_init)
+        const double ns = kPi * (gm.r_hi * gm.r_hi - gm.r_lo * gm.r_lo);
+        for (int i = 0; i < 5; i++) {
+            double var = cfg->prior_var[i], mean = cfg->prior_mean[i];
+            if (i >= 3) { mean /= gm.a; var /= gm.a * gm.a; }
+            LP.pmean[i] = mean;
+            if (LP.en[i] && var > 0 && ns > 0) { LP.pw[i] = 1.0 / (2.0 * var * ns); LP.use_priors = 1; }
+        }
+    }
 
     const int nfree = (cfg->refine_psi != 0) + (cfg->refine_theta != 0) + (cfg->refine_phi != 0) + (cfg->refine_x != 0) + (cfg->refine_y != 0);
     const int per_iter = nfree ? 2 * nfree + 2 : 0;     // centre + 2 per free parameter + trial
@@ -725,14 +748,35 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
             GlobP GP;
             GP.bank = ref->bank.p; GP.Wp = ref->Wp.p; GP.nP = ref->nP.p; GP.nI = ref->nI.p; GP.twN = ref->twN.p; GP.rowtw = ref->rowtw.p;
             GP.cc = ref->cc.p; GP.sh = ref->sh.p; GP.hits = ref->hits.p;
-            GP.Bs = gm.Bs; GP.Hs = gm.Hs; GP.HsP = HsP; GP.Ns = gm.Ns; GP.RSx = gm.RSx; GP.RSy = gm.RSy;
+            GP.Bs = gm.Bs; GP.Hs = gm.Hs; GP.HsP = HsP; GP.Ns = gm.Ns; GP.RSx = Rtx; GP.RSy = Rty;
             GP.n_dir = gm.n_dir; GP.n_psi = gm.n_psi; GP.npsi_store = gm.npsi_store; GP.n_orient = gm.n_orient; GP.K = K;
             {
                 ProfScope ps(PPM_K_NORMS);
                 NormP NP; NP.C2 = ref->C2.p; NP.bank = ref->bank.p; NP.nP = ref->nP.p; NP.n = nb; NP.nslices = nslices; NP.Bs = gm.Bs; NP.Hs = gm.Hs; NP.HsP = HsP;
                 hipLaunchKernelGGL(k_slice_norms, dim3((nb + 127) / 128, (nslices + 127) / 128), dim3(256), 0, g.stream, NP);
             }
-            if (int rc = launch_global(GP, nb, gm.half != 0, Rwin)) return rc;
+            if (ntiles == 1) {
+                if (int rc = launch_global(GP, nb, gm.half != 0, Rwin)) return rc;
+            } else {
+                // tiles of the shift window: ramp the search tables to the tile's centre, search, keep the tile's top-K; then merge
+                if (int rc = ref->hits_t.ensure((size_t)ntiles * nb * K)) return rc;
+                if (int rc = ref->tile_c.ensure((size_t)2 * ntiles)) return rc;
+                std::vector<int> tc(2 * ntiles);
+                for (int ty = 0, t = 0; ty < (int)cys.size(); ty++) for (int tx = 0; tx < (int)cxs.size(); tx++, t++) { tc[t] = cxs[tx]; tc[ntiles + t] = cys[ty]; }
+                HIPCHK(hipMemcpyAsync(ref->tile_c.p, tc.data(), tc.size() * sizeof(int), hipMemcpyHostToDevice, g.stream));
+                int px = 0, py = 0;
+                const size_t tot = (size_t)nb * HS;
+                for (int t = 0; t < ntiles; t++) {
+                    const int dcx = tc[t] - px, dcy = tc[ntiles + t] - py;
+                    if (dcx || dcy) hipLaunchKernelGGL(k_wp_ramp, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, g.stream, ref->Wp.p, tot, gm.Bs, gm.Ns, dcx, dcy, ref->twN.p);
+                    px = tc[t]; py = tc[ntiles + t];
+                    GP.hits = ref->hits_t.p + (size_t)t * nb * K;
+                    if (int rc = launch_global(GP, nb, gm.half != 0, Rwin)) return rc;
+                }
+                GP.hits = ref->hits.p;
+                hipLaunchKernelGGL(k_merge_hits, dim3((nb + 127) / 128), dim3(128), 0, g.stream, ref->hits_t.p, ref->hits.p, nb, K, ntiles, ref->tile_c.p, ref->tile_c.p + ntiles);
+                HIPCHK(hipStreamSynchronize(g.stream));      // the host vector of the centres goes out of scope
+            }
             {
                 ProfScope ps(PPM_K_TOPK);
                 hipLaunchKernelGGL(k_states_from_hits, dim3((nb * K + 255) / 256), dim3(256), 0, g.stream, ref->hits.p, ref->states.p, nb, K,
@@ -1529,8 +1573,28 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
     auto prefix_of = [&](double rb) { int rg = (int)std::ceil(rb); if (rg > R + 1) rg = R + 1; return shell_off[rg]; };
     // ---- search plan (the particle unit of the constrained search: rotations about the specimen axes + 3-D shift)
     int en[6]; double tol[6];
-    for (int k = 0; k < 3; k++) { en[k] = cfg->tol_angle > 0; tol[k] = cfg->tol_angle; en[3 + k] = cfg->tol_shift > 0; tol[3 + k] = cfg->tol_shift; }
-    const int nrot = en[0] ? 6 : 0, nsh = en[3] ? 6 : 0, ncand = 1 + nrot + nsh;
+    for (int k = 0; k < 3; k++) { en[k] = cfg->tol_angle > 0 && cfg->search_mode != 2; tol[k] = cfg->tol_angle; en[3 + k] = cfg->tol_shift > 0; tol[3 + k] = cfg->tol_shift; }
+    // global rotation + translation search (ppm_sva_cfg.search_mode 1, include/ppm.h)
+    const bool global = cfg->search_mode == 1;
+    const double gstep = cfg->global_step > 0 ? cfg->global_step : 15.0;
+    std::vector<double> grid_d; int n_grid = 0;
+    if (global) {
+        int n_theta = (int)std::floor(180.0 / gstep + 0.5) + 1; if (n_theta < 2) n_theta = 2;
+        int n_psi = (int)std::floor(360.0 / gstep + 0.5); if (n_psi < 1) n_psi = 1;
+        for (int i = 0; i < n_theta; i++) {
+            const double th = 180.0 * i / (n_theta - 1);
+            int np = (int)std::floor(360.0 * std::sin(th * kPi / 180.0) / gstep + 0.5); if (np < 1) np = 1;
+            for (int j = 0; j < np; j++) for (int k = 0; k < n_psi; k++) {
+                double G[9]; euler_matrix(k * 360.0 / n_psi, th, 360.0 * j / np, G);
+                grid_d.insert(grid_d.end(), G, G + 9);
+            }
+        }
+        n_grid = (int)(grid_d.size() / 9);
+    }
+    int Kc = cfg->n_candidates > 0 ? cfg->n_candidates : 25; Kc = std::min(std::min(Kc, 64), std::max(n_grid, 1));
+    const int eng[6] = { 1, 1, 1, en[3], en[4], en[5] };
+    const double tolg[6] = { gstep, gstep, gstep, tol[3], tol[4], tol[5] };
+    const int nrot = (en[0] || global) ? 6 : 0, nsh = en[3] ? 6 : 0, ncand = 1 + nrot + nsh;
     const double steptol = cfg->step_tolerance > 0 ? cfg->step_tolerance : 0.05;
     const double ha0 = 0.5 * cfg->tol_angle, hs0 = 0.5 * cfg->tol_shift;
     int T = cfg->max_iterations;
@@ -1539,6 +1603,13 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
     const double bf = cfg->band_factor == 0 ? 3.0 : cfg->band_factor;
     double rm_px = std::max(cfg->window[0], std::max(cfg->window[1], cfg->window[2]));
     if (!(rm_px > 0)) rm_px = 0.4 * N;
+    // coarse band the grid step allows (probe Delta / 2, rotations only) and the coarse shift probe
+    double rg = rband, tsh = 0.0;
+    if (global) {
+        if (bf >= 0) { const double d = rm_px * 0.5 * gstep * kPi / 180.0; double rit = bf * N / (2.0 * kPi * d); if (rit < 4.0) rit = 4.0; rg = std::min(rit, rband); }
+        tsh = cfg->tol_shift > 0 ? std::min((double)cfg->tol_shift, N / (4.0 * rg)) : 0.0;
+    }
+    const int nshift = tsh > 0 ? 27 : 1;
     auto iter_band = [&](double ha, double hs) {
         if (bf < 0) return rband;
         double d = 0;
@@ -1558,11 +1629,19 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
         const int hc = getenv("PPM_SVA_CHUNK") ? std::max(1, atoi(getenv("PPM_SVA_CHUNK"))) : (int)std::max<size_t>(1, ((size_t)7 << 30) / (n3 * 4));
         CH = std::min(CH, hc);
     }
-    DevTmp<uint32_t> d_samples; DevTmp<float> d_bandw, d_vols, d_wedges; DevTmp<float2> d_f, d_F; DevTmp<double> d_stats, d_poses, d_delta, d_out;
+    DevTmp<uint32_t> d_samples; DevTmp<float> d_bandw, d_vols, d_wedges, d_grid, d_gscore; DevTmp<float2> d_f, d_F; DevTmp<double> d_stats, d_poses, d_delta, d_out;
+    DevTmp<int> d_vmap, d_gshift;
     const int KX = std::min(N / 2 + 1, R + 1);          // x coefficients kept; |ky|, |kz| <= R are the lines the later passes touch
     const int NB = std::min(CH, 32);                     // sub-volumes transformed per launch (work array: NB x N x N x KX complex)
     HIPCHK(d_samples.alloc(S)); HIPCHK(d_bandw.alloc(S)); HIPCHK(d_f.alloc((size_t)NB * N * N * KX)); HIPCHK(d_F.alloc((size_t)CH * S));
-    HIPCHK(d_stats.alloc((size_t)2 * CH)); HIPCHK(d_poses.alloc((size_t)12 * CH)); HIPCHK(d_delta.alloc((size_t)CH * ncand * 6)); HIPCHK(d_out.alloc((size_t)CH * ncand));
+    const size_t CHS = (size_t)CH * (global ? Kc : 1);       // states per chunk: the global search refines Kc candidates per sub-volume
+    HIPCHK(d_stats.alloc((size_t)2 * CH)); HIPCHK(d_poses.alloc((size_t)12 * CHS)); HIPCHK(d_delta.alloc(CHS * ncand * 6)); HIPCHK(d_out.alloc(CHS * ncand));
+    HIPCHK(d_vmap.alloc(CHS));
+    if (global) {
+        std::vector<float> gf(grid_d.begin(), grid_d.end());
+        HIPCHK(d_grid.alloc(gf.size())); HIPCHK(d_gscore.alloc((size_t)CH * n_grid)); HIPCHK(d_gshift.alloc((size_t)CH * n_grid));
+        HIPCHK(hipMemcpy(d_grid.p, gf.data(), gf.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     HIPCHK(d_wedges.alloc((size_t)2 * CH));
     const bool two_bufs = !volumes_on_device && n_vol > CH;      // host volumes: the next chunk is uploaded by a helper thread while this one is searched
     if (!volumes_on_device) HIPCHK(d_vols.alloc((size_t)(two_bufs ? 2 : 1) * CH * n3));
@@ -1572,7 +1651,7 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
     SvaEvalP EP;
     EP.cv.cube = ref->cube; EP.cv.NBX = ref->NBX; EP.cv.NBY = ref->NBY; EP.cv.LB = ref->LB; EP.cv.off = ref->B + 1; EP.cv.scale = 1.f;
     EP.samples = d_samples.p; EP.bandw = d_bandw.p; EP.F = d_F.p; EP.S = S; EP.N = N; EP.use_wedge = cfg->use_missing_wedge != 0;
-    EP.wedges = d_wedges.p; EP.poses = d_poses.p; EP.delta = d_delta.p; EP.out = d_out.p;
+    EP.wedges = d_wedges.p; EP.poses = d_poses.p; EP.delta = d_delta.p; EP.out = d_out.p; EP.vmap = nullptr;
     std::vector<float> hw((size_t)2 * CH);
     std::vector<double> hdelta, hout;
     if (!volumes_on_device) {       // first chunk
@@ -1636,76 +1715,146 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
         HIPCHK(hipGetLastError());
         std::vector<CUnit> st(nb);
         for (int v = 0; v < nb; v++) { std::memcpy(st[v].N, poses + (size_t)(c0 + v) * 12, 9 * sizeof(double)); std::memcpy(st[v].p, poses + (size_t)(c0 + v) * 12 + 9, 3 * sizeof(double)); }
-        std::vector<double> hp((size_t)12 * nb);
-        auto upload_poses = [&]() -> int {
-            for (int v = 0; v < nb; v++) { std::memcpy(&hp[(size_t)12 * v], st[v].N, 9 * sizeof(double)); std::memcpy(&hp[(size_t)12 * v + 9], st[v].p, 3 * sizeof(double)); }
+        std::vector<double> hp;
+        // states -> device (poses are per STATE; `vm` maps a state to its sub-volume, null = identity)
+        auto upload_states = [&](const std::vector<CUnit> &S_, const std::vector<int> *vm) -> int {
+            const int ns_ = (int)S_.size();
+            hp.resize((size_t)12 * ns_);
+            for (int v = 0; v < ns_; v++) { std::memcpy(&hp[(size_t)12 * v], S_[v].N, 9 * sizeof(double)); std::memcpy(&hp[(size_t)12 * v + 9], S_[v].p, 3 * sizeof(double)); }
             HIPCHK(hipMemcpyAsync(d_poses.p, hp.data(), hp.size() * sizeof(double), hipMemcpyHostToDevice, g.stream));
+            if (vm) HIPCHK(hipMemcpyAsync(d_vmap.p, vm->data(), vm->size() * sizeof(int), hipMemcpyHostToDevice, g.stream));
+            EP.vmap = vm ? d_vmap.p : nullptr;
             return 0;
         };
-        auto sweep = [&](int nc, int nr_, double rb) -> int {
-            HIPCHK(hipMemcpyAsync(d_delta.p, hdelta.data(), (size_t)nb * nc * 6 * sizeof(double), hipMemcpyHostToDevice, g.stream));
+        auto sweep = [&](int ns_, int nc, int nr_, double rb) -> int {
+            HIPCHK(hipMemcpyAsync(d_delta.p, hdelta.data(), (size_t)ns_ * nc * 6 * sizeof(double), hipMemcpyHostToDevice, g.stream));
             EP.ncand = nc; EP.nrot = nr_; EP.S_used = prefix_of(rb); EP.rmax2 = (float)(rb * rb);
-            { ProfScope ps(PPM_K_LOCAL); hipLaunchKernelGGL(k_sva_eval, dim3(nb), dim3(256), 0, g.stream, EP); }
+            { ProfScope ps(PPM_K_LOCAL); hipLaunchKernelGGL(k_sva_eval, dim3(ns_), dim3(256), 0, g.stream, EP); }
             HIPCHK(hipGetLastError());
-            hout.resize((size_t)nb * nc);
+            hout.resize((size_t)ns_ * nc);
             HIPCHK(hipMemcpyAsync(hout.data(), d_out.p, hout.size() * sizeof(double), hipMemcpyDeviceToHost, g.stream));
             HIPCHK(hipStreamSynchronize(g.stream));
             return 0;
         };
-        if (int rc = upload_poses()) return rc;
-        double ha = ha0, hs = hs0;
-        std::vector<double> mean, dtrial((size_t)nb * 6), fpv((size_t)nb * 6), fmv((size_t)nb * 6);
-        auto cand_of = [&](int i, int sign) { return i < 3 ? 1 + 2 * i + (sign < 0) : 1 + nrot + 2 * (i - 3) + (sign < 0); };
-        for (int it = 0; it < T; it++) {
-            const double rb = iter_band(ha, hs);
-            hdelta.assign((size_t)nb * ncand * 6, 0.0);
-            for (int v = 0; v < nb; v++) for (int i = 0; i < 6; i++) if (en[i]) {
-                const double h = i < 3 ? ha : hs;
-                hdelta[((size_t)v * ncand + cand_of(i, 1)) * 6 + i] = h; hdelta[((size_t)v * ncand + cand_of(i, -1)) * 6 + i] = -h;
-            }
-            if (int rc = sweep(ncand, nrot, rb)) return rc;
-            mean = hout;
-            for (int v = 0; v < nb; v++) {
-                const CUnit &s = st[v];
-                const double f0 = mean[(size_t)v * ncand];
-                double *d = &dtrial[(size_t)v * 6];
-                for (int i = 0; i < 6; i++) {
-                    d[i] = 0; fpv[(size_t)v * 6 + i] = fmv[(size_t)v * 6 + i] = -1e300;
-                    if (!en[i]) continue;
+        // `Tn` compass iterations of all states at once (two launches per iteration), steps halved after each
+        auto compass = [&](std::vector<CUnit> &S_, const std::vector<int> *vm, const int *en_, const double *tol_, double &ha, double &hs, int Tn) -> int {
+            const int ns_ = (int)S_.size();
+            const int nrot_ = en_[0] ? 6 : 0, nsh_ = en_[3] ? 6 : 0, nc_ = 1 + nrot_ + nsh_;
+            if (nc_ == 1 || ns_ == 0) return 0;
+            if (int rc = upload_states(S_, vm)) return rc;
+            std::vector<double> mean, dtrial((size_t)ns_ * 6), fpv((size_t)ns_ * 6), fmv((size_t)ns_ * 6);
+            auto cand_of = [&](int i, int sign) { return i < 3 ? 1 + 2 * i + (sign < 0) : 1 + nrot_ + 2 * (i - 3) + (sign < 0); };
+            auto band_of = [&](double ha_, double hs_) {
+                if (bf < 0) return rband;
+                double d = 0;
+                if (en_[0]) d = rm_px * ha_ * kPi / 180.0;
+                if (en_[3] && hs_ > d) d = hs_;
+                if (!(d > 0)) return rband;
+                double rit = bf * N / (2.0 * kPi * d);
+                if (rit < 4.0) rit = 4.0;
+                return rit < rband ? rit : rband;
+            };
+            for (int it = 0; it < Tn; it++) {
+                const double rb = band_of(ha, hs);
+                hdelta.assign((size_t)ns_ * nc_ * 6, 0.0);
+                for (int v = 0; v < ns_; v++) for (int i = 0; i < 6; i++) if (en_[i]) {
                     const double h = i < 3 ? ha : hs;
-                    const bool okp = std::fabs(s.acc[i] + h) <= tol[i] + 1e-9, okm = std::fabs(s.acc[i] - h) <= tol[i] + 1e-9;
-                    const double fp = okp ? mean[(size_t)v * ncand + cand_of(i, 1)] : -1e300, fm = okm ? mean[(size_t)v * ncand + cand_of(i, -1)] : -1e300;
-                    fpv[(size_t)v * 6 + i] = fp; fmv[(size_t)v * 6 + i] = fm;
-                    if (okp && okm) {
-                        const double den = 2.0 * f0 - fp - fm;
-                        if (den > 1e-12) { double t = 0.5 * h * (fp - fm) / den; d[i] = t > h ? h : (t < -h ? -h : t); }
-                        else { const double best = fp > fm ? fp : fm; d[i] = best > f0 ? (fp > fm ? h : -h) : 0.0; }
-                    } else if (okp) d[i] = fp > f0 ? h : 0.0;
-                    else if (okm) d[i] = fm > f0 ? -h : 0.0;
-                    if (s.acc[i] + d[i] > tol[i]) d[i] = tol[i] - s.acc[i];
-                    if (s.acc[i] + d[i] < -tol[i]) d[i] = -tol[i] - s.acc[i];
+                    hdelta[((size_t)v * nc_ + cand_of(i, 1)) * 6 + i] = h; hdelta[((size_t)v * nc_ + cand_of(i, -1)) * 6 + i] = -h;
                 }
+                if (int rc = sweep(ns_, nc_, nrot_, rb)) return rc;
+                mean = hout;
+                for (int v = 0; v < ns_; v++) {
+                    const CUnit &u = S_[v];
+                    const double f0 = mean[(size_t)v * nc_];
+                    double *d = &dtrial[(size_t)v * 6];
+                    for (int i = 0; i < 6; i++) {
+                        d[i] = 0; fpv[(size_t)v * 6 + i] = fmv[(size_t)v * 6 + i] = -1e300;
+                        if (!en_[i]) continue;
+                        const double h = i < 3 ? ha : hs;
+                        const bool okp = std::fabs(u.acc[i] + h) <= tol_[i] + 1e-9, okm = std::fabs(u.acc[i] - h) <= tol_[i] + 1e-9;
+                        const double fp = okp ? mean[(size_t)v * nc_ + cand_of(i, 1)] : -1e300, fm = okm ? mean[(size_t)v * nc_ + cand_of(i, -1)] : -1e300;
+                        fpv[(size_t)v * 6 + i] = fp; fmv[(size_t)v * 6 + i] = fm;
+                        if (okp && okm) {
+                            const double den = 2.0 * f0 - fp - fm;
+                            if (den > 1e-12) { double t = 0.5 * h * (fp - fm) / den; d[i] = t > h ? h : (t < -h ? -h : t); }
+                            else { const double best = fp > fm ? fp : fm; d[i] = best > f0 ? (fp > fm ? h : -h) : 0.0; }
+                        } else if (okp) d[i] = fp > f0 ? h : 0.0;
+                        else if (okm) d[i] = fm > f0 ? -h : 0.0;
+                        if (u.acc[i] + d[i] > tol_[i]) d[i] = tol_[i] - u.acc[i];
+                        if (u.acc[i] + d[i] < -tol_[i]) d[i] = -tol_[i] - u.acc[i];
+                    }
+                }
+                hdelta = dtrial;
+                if (int rc = sweep(ns_, 1, 0, rb)) return rc;
+                for (int v = 0; v < ns_; v++) {
+                    CUnit &u = S_[v];
+                    const double f0 = mean[(size_t)v * nc_], ft = hout[v];
+                    int bi = -1, bs = 0; double fb = f0;
+                    for (int i = 0; i < 6; i++) {
+                        if (!en_[i]) continue;
+                        if (fpv[(size_t)v * 6 + i] > fb) { fb = fpv[(size_t)v * 6 + i]; bi = i; bs = 1; }
+                        if (fmv[(size_t)v * 6 + i] > fb) { fb = fmv[(size_t)v * 6 + i]; bi = i; bs = -1; }
+                    }
+                    CUnit q;
+                    if (ft > f0 && ft >= fb) { csp_apply(PPM_CSP_PARTICLES, u, &dtrial[(size_t)v * 6], q); u = q; }
+                    else if (bi >= 0) { double dd[6] = { 0, 0, 0, 0, 0, 0 }; dd[bi] = bs * (bi < 3 ? ha : hs); csp_apply(PPM_CSP_PARTICLES, u, dd, q); u = q; }
+                }
+                if (int rc = upload_states(S_, vm)) return rc;
+                ha *= 0.5; hs *= 0.5;
             }
-            hdelta = dtrial;
-            if (int rc = sweep(1, 0, rb)) return rc;
+            return 0;
+        };
+        // scores of all states at the full band -> hout[state]
+        auto final_scores = [&](std::vector<CUnit> &S_, const std::vector<int> *vm) -> int {
+            if (int rc = upload_states(S_, vm)) return rc;
+            hdelta.assign((size_t)S_.size() * 6, 0.0);
+            return sweep((int)S_.size(), 1, 0, rband);
+        };
+        if (!global) {
+            double ha = ha0, hs = hs0;
+            if (int rc = compass(st, nullptr, en, tol, ha, hs, T)) return rc;
+        } else {
+            // ---- grid scores at the coarse band, 27 coarse shifts each (k_sva_global)
+            HIPCHK(hipMemcpyAsync(d_poses.p, [&]() { hp.resize((size_t)12 * nb); for (int v = 0; v < nb; v++) { std::memcpy(&hp[(size_t)12 * v], st[v].N, 9 * sizeof(double)); std::memcpy(&hp[(size_t)12 * v + 9], st[v].p, 3 * sizeof(double)); } return hp.data(); }(),
+                                  (size_t)12 * nb * sizeof(double), hipMemcpyHostToDevice, g.stream));
+            SvaGlobalP GP;
+            GP.cv = EP.cv; GP.samples = d_samples.p; GP.bandw = d_bandw.p; GP.F = d_F.p; GP.S = S; GP.N = N; GP.S_used = prefix_of(rg); GP.rmax2 = (float)(rg * rg);
+            GP.use_wedge = EP.use_wedge; GP.wedges = d_wedges.p; GP.poses = d_poses.p; GP.grid = d_grid.p; GP.n_grid = n_grid; GP.RC = 8; GP.nshift = nshift; GP.tsh = (float)tsh;
+            GP.score = d_gscore.p; GP.shift = d_gshift.p;
+            { ProfScope ps(PPM_K_GLOBAL); hipLaunchKernelGGL(k_sva_global, dim3((n_grid + GP.RC - 1) / GP.RC, nb), dim3(256), 0, g.stream, GP); }
+            HIPCHK(hipGetLastError());
+            std::vector<float> gsc((size_t)nb * n_grid); std::vector<int> gsh((size_t)nb * n_grid);
+            HIPCHK(hipMemcpyAsync(gsc.data(), d_gscore.p, gsc.size() * sizeof(float), hipMemcpyDeviceToHost, g.stream));
+            HIPCHK(hipMemcpyAsync(gsh.data(), d_gshift.p, gsh.size() * sizeof(int), hipMemcpyDeviceToHost, g.stream));
+            HIPCHK(hipStreamSynchronize(g.stream));
+            // ---- top-K per sub-volume (ties -> lower grid index) as states of their own
+            std::vector<CUnit> cand; std::vector<int> vm; cand.reserve((size_t)nb * Kc); vm.reserve((size_t)nb * Kc);
+            std::vector<int> order(n_grid);
             for (int v = 0; v < nb; v++) {
-                CUnit &s = st[v];
-                const double f0 = mean[(size_t)v * ncand], ft = hout[v];
-                int bi = -1, bs = 0; double fb = f0;
-                for (int i = 0; i < 6; i++) {
-                    if (!en[i]) continue;
-                    if (fpv[(size_t)v * 6 + i] > fb) { fb = fpv[(size_t)v * 6 + i]; bi = i; bs = 1; }
-                    if (fmv[(size_t)v * 6 + i] > fb) { fb = fmv[(size_t)v * 6 + i]; bi = i; bs = -1; }
+                const float *sc_ = &gsc[(size_t)v * n_grid];
+                for (int q = 0; q < n_grid; q++) order[q] = q;
+                std::partial_sort(order.begin(), order.begin() + Kc, order.end(), [&](int x, int y) { return sc_[x] > sc_[y] || (sc_[x] == sc_[y] && x < y); });
+                for (int k = 0; k < Kc; k++) {
+                    const int q = order[k], si = gsh[(size_t)v * n_grid + q];
+                    CUnit c = st[v];
+                    double Nq[9]; mat_mul3h(st[v].N, &grid_d[(size_t)q * 9], Nq); std::memcpy(c.N, Nq, sizeof(Nq));
+                    if (nshift > 1) { const double dd[3] = { (si % 3 - 1) * tsh, ((si / 3) % 3 - 1) * tsh, (si / 9 - 1) * tsh }; for (int j = 0; j < 3; j++) { c.p[j] += dd[j]; c.acc[3 + j] = dd[j]; } }
+                    cand.push_back(c); vm.push_back(v);
                 }
-                CUnit q;
-                if (ft > f0 && ft >= fb) { csp_apply(PPM_CSP_PARTICLES, s, &dtrial[(size_t)v * 6], q); s = q; }
-                else if (bi >= 0) { double dd[6] = { 0, 0, 0, 0, 0, 0 }; dd[bi] = bs * (bi < 3 ? ha : hs); csp_apply(PPM_CSP_PARTICLES, s, dd, q); s = q; }
             }
-            if (int rc = upload_poses()) return rc;
-            ha *= 0.5; hs *= 0.5;
+            double ha = 0.5 * gstep, hs = 0.5 * tsh;
+            if (int rc = compass(cand, &vm, eng, tolg, ha, hs, 2)) return rc;
+            if (int rc = final_scores(cand, &vm)) return rc;
+            for (int v = 0; v < nb; v++) {
+                int bk = 0;
+                for (int k = 1; k < Kc; k++) if (hout[(size_t)v * Kc + k] > hout[(size_t)v * Kc + bk]) bk = k;
+                st[v] = cand[(size_t)v * Kc + bk];
+            }
+            const double m = std::max(ha, hs);
+            int Tf = m > steptol ? (int)std::ceil(std::log(m / steptol) / std::log(2.0)) : 0; Tf = std::min(12, Tf);
+            if (int rc = compass(st, nullptr, eng, tolg, ha, hs, Tf)) return rc;
         }
-        hdelta.assign((size_t)nb * 6, 0.0);
-        if (int rc = sweep(1, 0, rband)) return rc;
+        if (int rc = final_scores(st, nullptr)) return rc;
         for (int v = 0; v < nb; v++) {
             std::memcpy(poses + (size_t)(c0 + v) * 12, st[v].N, 9 * sizeof(double)); std::memcpy(poses + (size_t)(c0 + v) * 12 + 9, st[v].p, 3 * sizeof(double));
             if (scores) scores[c0 + v] = hout[v];

@@ -84,6 +84,7 @@ struct SvaEvalP {
     const double *poses;          // [n_vol][12] N row-major + shift
     const double *delta;          // [n_vol][ncand][6]
     double *out;                  // [n_vol][ncand]
+    const int *vmap;              // null, or [n_states]: the sub-volume (transform, wedge) a state belongs to; poses / delta / out are per STATE
 };
 
 // Block = one sub-volume: thread q < ncand derives candidate q's pose in double precision (rotations about the specimen
@@ -94,9 +95,9 @@ struct SvaEvalP {
 __global__ void __launch_bounds__(256) k_sva_eval(SvaEvalP P) {
     __shared__ float cm[kMaxCand][9], csh[kMaxCand][3];
     __shared__ float red[4][2 * kMaxCand + 1];
-    const int v = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ncand = P.ncand, nrot = P.nrot;
+    const int st = blockIdx.x, v = P.vmap ? P.vmap[st] : st, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ncand = P.ncand, nrot = P.nrot;
     if (tid < ncand) {
-        const double *d = P.delta + ((size_t)v * ncand + tid) * 6, *pose = P.poses + (size_t)v * 12;
+        const double *d = P.delta + ((size_t)st * ncand + tid) * 6, *pose = P.poses + (size_t)st * 12;
         double Nm[9];
 #pragma unroll
         for (int k = 0; k < 9; k++) Nm[k] = pose[k];
@@ -159,7 +160,104 @@ __global__ void __launch_bounds__(256) k_sva_eval(SvaEvalP P) {
         const double a = (((double)red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
         const double b = (((double)red[0][kMaxCand + g] + red[1][kMaxCand + g]) + red[2][kMaxCand + g]) + red[3][kMaxCand + g];
         const double c = (((double)red[0][2 * kMaxCand] + red[1][2 * kMaxCand]) + red[2][2 * kMaxCand]) + red[3][2 * kMaxCand];
-        P.out[(size_t)v * ncand + tid] = (b > 0 && c > 0) ? a / sqrt(b * c) : 0.0;
+        P.out[(size_t)st * ncand + tid] = (b > 0 && c > 0) ? a / sqrt(b * c) : 0.0;
+    }
+}
+
+// Global rotational + translational grid (ppm_sva_cfg.search_mode 1, include/ppm.h): block = (sub-volume, run of RC grid
+// rotations).  For every rotation the reference is gathered once per coarse-band sample and correlated at the 27 shifts
+// {-t, 0, t}^3 around the start shift (phase factors e^{i 2 pi k_x t / N} etc. are built once per sample and combined);
+// the best shift (first maximum in the order x fastest, z slowest: the oracle's scan order) and its score go out per rotation.
+struct SvaGlobalP {
+    CubeView cv; const uint32_t *samples; const float *bandw; const float2 *F; int S, N, S_used; float rmax2; int use_wedge;
+    const float *wedges; const double *poses;     // [n_vol][2], [n_vol][12]
+    const float *grid;                            // [n_grid][9] grid rotations G (row-major)
+    int n_grid, RC, nshift; float tsh;            // nshift = 27 or 1
+    float *score; int *shift;                     // [n_vol][n_grid]
+};
+
+__global__ void __launch_bounds__(256) k_sva_global(SvaGlobalP P) {
+    __shared__ float Nq[9], red[4][30];
+    __shared__ float p0[3], N0[9];
+    const int v = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 9) N0[tid] = (float)P.poses[(size_t)v * 12 + tid];
+    if (tid < 3) p0[tid] = (float)P.poses[(size_t)v * 12 + 9 + tid];
+    const float lw = P.wedges[2 * v], uw = P.wedges[2 * v + 1], invN = 1.0f / (float)P.N;
+    const float2 *F = P.F + (size_t)v * P.S;
+    const int q0 = blockIdx.x * P.RC, q1 = min(q0 + P.RC, P.n_grid);
+    for (int q = q0; q < q1; q++) {
+        __syncthreads();
+        if (tid < 9) {                       // Nq = N0 G in double, like the oracle
+            const int i = tid / 3, j = tid % 3;
+            double a = 0;
+            for (int k = 0; k < 3; k++) a += P.poses[(size_t)v * 12 + i * 3 + k] * (double)P.grid[(size_t)q * 9 + k * 3 + j];
+            Nq[tid] = (float)a;
+        }
+        __syncthreads();
+        float A[27], B = 0.f, Csum = 0.f;
+#pragma unroll
+        for (int c = 0; c < 27; c++) A[c] = 0.f;
+        for (int s = tid; s < P.S_used; s += 256) {
+            int kx, ky, kz; sva_unpack(P.samples[s], kx, ky, kz);
+            float w = P.bandw[s];
+            if (!((float)(kx * kx + ky * ky + kz * kz) < P.rmax2)) w = 0.f;
+            if (P.use_wedge && !(kx == 0 && kz == 0)) {
+                float a = atan2f((float)kz, (float)kx) * 57.29577951308232f;
+                if (a > 90.f) a -= 180.f;
+                if (a <= -90.f) a += 180.f;
+                if (!(a >= lw && a <= uw)) w = 0.f;
+            }
+            const float2 iv = F[s];
+            const float fkx = (float)kx, fky = (float)ky, fkz = (float)kz;
+            const float wx = w * iv.x, wy = w * iv.y;
+            Csum += wx * iv.x + wy * iv.y;
+            const float2 p = sample_cube(P.cv, Nq[0] * fkx + Nq[1] * fky + Nq[2] * fkz, Nq[3] * fkx + Nq[4] * fky + Nq[5] * fkz, Nq[6] * fkx + Nq[7] * fky + Nq[8] * fkz);
+            B += w * (p.x * p.x + p.y * p.y);
+            // corr(shift) = Re(z e^{i phi}), z = (u, -v), u = Re(conj(wF) p)..., phi = 2 pi k.(p0 + shift) / N
+            float rev = (fkx * p0[0] + fky * p0[1] + fkz * p0[2]) * invN; rev -= floorf(rev);
+            const float sn0 = __sinf(6.283185307179586f * rev), cs0 = __cosf(6.283185307179586f * rev);
+            const float pr = p.x * cs0 - p.y * sn0, pi = p.x * sn0 + p.y * cs0;
+            const float zr = wx * pr + wy * pi, zi = wx * pi - wy * pr;          // z = conj(wF) m0, m0 = p e^{i phi0}
+            if (P.nshift == 1) { A[13] += zr; continue; }
+            float ex[2], ey[2], ez[2];
+            { float r = fkx * P.tsh * invN; r -= floorf(r); ex[1] = __sinf(6.283185307179586f * r); ex[0] = __cosf(6.283185307179586f * r); }
+            { float r = fky * P.tsh * invN; r -= floorf(r); ey[1] = __sinf(6.283185307179586f * r); ey[0] = __cosf(6.283185307179586f * r); }
+            { float r = fkz * P.tsh * invN; r -= floorf(r); ez[1] = __sinf(6.283185307179586f * r); ez[0] = __cosf(6.283185307179586f * r); }
+            // (zr + i zi) e^{i a tx} for a = -1, 0, 1
+            float xr[3], xi[3];
+            xr[1] = zr; xi[1] = zi;
+            xr[2] = zr * ex[0] - zi * ex[1]; xi[2] = zr * ex[1] + zi * ex[0];
+            xr[0] = zr * ex[0] + zi * ex[1]; xi[0] = zi * ex[0] - zr * ex[1];
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                float yr[3], yi[3];
+                yr[1] = xr[a]; yi[1] = xi[a];
+                yr[2] = xr[a] * ey[0] - xi[a] * ey[1]; yi[2] = xr[a] * ey[1] + xi[a] * ey[0];
+                yr[0] = xr[a] * ey[0] + xi[a] * ey[1]; yi[0] = xi[a] * ey[0] - xr[a] * ey[1];
+#pragma unroll
+                for (int b = 0; b < 3; b++) {
+                    A[a + 3 * b + 9 * 1] += yr[b];
+                    A[a + 3 * b + 9 * 2] += yr[b] * ez[0] - yi[b] * ez[1];
+                    A[a + 3 * b + 9 * 0] += yr[b] * ez[0] + yi[b] * ez[1];
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 27; c++) { const float t = wave_sum(A[c]); if (lane == 0) red[wave][c] = t; }
+        { const float t = wave_sum(B); if (lane == 0) red[wave][27] = t; }
+        { const float t = wave_sum(Csum); if (lane == 0) red[wave][28] = t; }
+        __syncthreads();
+        if (tid == 0) {
+            const double b = (((double)red[0][27] + red[1][27]) + red[2][27]) + red[3][27], c = (((double)red[0][28] + red[1][28]) + red[2][28]) + red[3][28];
+            double best = -1e300; int bs = 13;
+            for (int si = 0; si < 27; si++) {
+                if (P.nshift == 1 && si != 13) continue;
+                const double a = (((double)red[0][si] + red[1][si]) + red[2][si]) + red[3][si];
+                const double val = (b > 0 && c > 0) ? a / sqrt(b * c) : 0.0;
+                if (val > best) { best = val; bs = si; }
+            }
+            P.score[(size_t)v * P.n_grid + q] = (float)best; P.shift[(size_t)v * P.n_grid + q] = bs;
+        }
     }
 }
 

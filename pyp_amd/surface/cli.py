@@ -299,8 +299,7 @@ def refine3d_main(argv=None, stdin=None):
     print("\n        **   Welcome to Refine3D (MI355X / libpypmatch)   **\n")
     for k, v in d.items():
         print(f"{k:28s}: {v}")
-    _unsupported(d, [("use_priors", True),
-                     ("exclude_edges", True), ("normalize_reference", True), ("threshold_reference", True)], "refine3d")
+    _unsupported(d, [("exclude_edges", True), ("normalize_reference", True), ("threshold_reference", True)], "refine3d")
     pad = int(round(d["padding"]))
     if abs(d["padding"] - pad) > 1e-6 or pad not in (1, 2, 4):
         _die("ERROR: refine3d: padding factor must be 1, 2 or 4")
@@ -330,6 +329,19 @@ def refine3d_main(argv=None, stdin=None):
             _die(f"ERROR: refine3d: statistics file {d['statistics']} does not exist")
         ring_w = _ssnr_ring_weights(box, d["statistics"], px)
     cfg = refine_cfg_from_answers(d, box)
+    if d["use_priors"]:
+        # answer 7 with the statistics of answer 3 (`<name>_stat.cistem`: means and variances of every column over the data set,
+        # src/pyp_main.py:2667-2674): a Gaussian restraint on the refined parameters (include/ppm.h, ppm_refine_cfg.use_priors)
+        if d["global_stats"] in ("null", "") or not os.path.exists(d["global_stats"]):
+            _die(f"ERROR: refine3d: use priors = yes needs the global statistics file (answer 3), got '{d['global_stats']}'")
+        st = cistem.read_parameters(d["global_stats"])
+        if st.shape[0] < 2:
+            _die(f"ERROR: refine3d: {d['global_stats']} must hold two rows (means, variances)")
+        cols = [C["PSI"], C["THETA"], C["PHI"], C["X_SHIFT"], C["Y_SHIFT"]]
+        cfg.use_priors = 1
+        cfg.prior_mean[:] = [float(v) for v in st[0, cols]]
+        cfg.prior_var[:] = [float(v) for v in st[1, cols]]
+        print("priors: mean psi theta phi x y = %s, variance = %s" % (np.round(st[0, cols], 3).tolist(), np.round(st[1, cols], 3).tolist()))
     from .. import host, lib
     dev = int(os.environ.get("PPM_DEVICE", "0"))
     t1 = time.time()

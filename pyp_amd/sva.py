@@ -110,11 +110,19 @@ def cfg_from_xml(xml_path, box, pixel_size=1.0, mode=None):
         e = sec.find(f"{sec_name}_{tag}")
         return float(e.text) if e is not None and e.text not in (None, "") else default
     metric = gen.find("metric")
-    wedge = int(metric.find("use_missing_wedge").text) if metric is not None and metric.find("use_missing_wedge") is not None else 1
+
+    def mval(tag, default):
+        e = metric.find(tag) if metric is not None else None
+        return int(float(e.text)) if e is not None and e.text not in (None, "") else default
+    wedge = mval("use_missing_wedge", 1)
+    # metric/alignment_mode (iteration_002_mode_3.xml:29-38): 0 = global rotation and translation search, 1 = refinement only,
+    # 2 = translation only -> ppm_sva_cfg.search_mode 1 / 0 / 2; a protocol without the field refines
+    search_mode = {0: 1, 1: 0, 2: 2}.get(mval("alignment_mode", 1), 0)
     return SvaCfg.make(box, pixel_size, window=(val("image_window_x"), val("image_window_y"), val("image_window_z")),
                        window_sigma=val("image_window_sigma"), highpass=(val("high_pass_cutoff"), val("high_pass_decay")),
                        lowpass=(val("low_pass_cutoff"), val("low_pass_decay")), use_missing_wedge=wedge,
-                       tol_angle=val("out_of_plane_search_range"), tol_shift=val("shifts_tolerance"))
+                       tol_angle=val("out_of_plane_search_range"), tol_shift=val("shifts_tolerance"),
+                       search_mode=search_mode, n_candidates=mval("number_of_candidate_peaks_to_search", 25))
 
 
 def align_table(reference, table, names, cfg, base_dir=".", device=0, chunk=256, max_band_px=None):

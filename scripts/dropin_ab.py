@@ -28,8 +28,8 @@ try:
               0, 0, 0, 0, 500, 50.0, 1, "yes", "no", "yes", "yes", "yes", "yes", "yes", "no", "no", "no", "yes", "no", "no", "no", "no"]
     recon = ["p_stack.mrc", f"p_r01_{rng}.cistem", "null", "p_r01.mrc", "p_map1.mrc", "p_map2.mrc", "output.mrc", "p_n1.res", "C1", 1, M, PX, 300, 0, 0.45 * N * PX,
              2 * PX, 0, 0, "no", 0, -1, "no", 0, 1, 1, "yes", "no", "no", "no", "no", "yes", "no", "no", "no", "no", "yes", "dump1.bin", "dump2.bin", 1]
-    envs = [{}, {"PPM_SYNC": "block"}, {"PPM_SYNC": "block", "PPM_IO_THREADS": "4"}, {"PPM_SYNC": "block", "PPM_IO_THREADS": "12"},
-            {"PPM_SYNC": "block", "PPM_IO_CHUNK": "4096"}, {"PPM_SYNC": "yield"}]
+    import json
+    envs = json.loads(os.environ.get("PPM_AB_ENVS", '[{}, {"PPM_IO_CHUNK": "1024"}, {"PPM_IO_THREADS": "12"}, {"PPM_SYNC": "spin"}]'))
     for e in envs:
         for prog, script in (("refine3d", refine), ("reconstruct3d", recon)):
             t0 = time.time()

@@ -159,9 +159,19 @@ def test_reconstruct_merge_pipeline(project):
 def test_unsupported_options_fail_loudly(project):
     d, vol, imgs, truth, start = project
     s = refine_script(1, 10, True, out="bad_out.cistem").split("\n")
-    s[6] = "yes"                                      # use priors
+    s[6] = "yes"                                      # use priors without the statistics file of answer 3 ("null")
     assert run("refine3d", "\n".join(s), d, "bad.log") != 0
-    assert "ERROR" in open(d / "bad.log").read() and not (d / "bad_out.cistem").exists()
+    assert "ERROR" in open(d / "bad.log").read() and "statistics" in open(d / "bad.log").read() and not (d / "bad_out.cistem").exists()
+    # with `<name>_stat.cistem` (means, variances: src/pyp_main.py:2667-2674) the answer is honoured
+    stat = np.vstack([truth.mean(axis=0), truth.var(axis=0)])
+    cistem.write_parameters(str(d / "p_r01_stat.cistem"), stat)
+    s = refine_script(1, 10, True, out="prior_out.cistem").split("\n")
+    s[2], s[6] = "p_r01_stat.cistem", "yes"
+    assert run("refine3d", "\n".join(s), d, "prior.log") == 0, open(d / "prior.log").read()[-1500:]
+    log = open(d / "prior.log").read()
+    assert "priors: mean psi theta phi x y" in log and "Refine3D: Normal termination" in log
+    got = cistem.read_parameters(str(d / "prior_out.cistem"))
+    assert np.median(synth.angular_error_deg(got, truth[:10])) < 3.0
     s = refine_script(1, 10, True, out="def_out.cistem").split("\n")
     s[44] = "yes"                                     # refine defocus: supported, columns 6 / 7 move on the 50 A grid
     assert run("refine3d", "\n".join(s), d, "def.log") == 0 and (d / "def_out.cistem").exists()

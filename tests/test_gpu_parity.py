@@ -249,17 +249,47 @@ def test_preprocessing_options_at_256_match_oracle(H, O):
 
 
 def test_capped_search_band_and_shift_window_are_reported(H):
-    """A search band above 64 Fourier pixels and a shift range beyond 8 search-grid steps (or PYP's default 0 = 'mask radius') are
-    capped by the grid search, not refused: ppm_refine_note (the refine3d log) says what was done."""
+    """A search band above 64 Fourier pixels is capped by the grid search, not refused, and ppm_refine_note (the refine3d log) says
+    so; a shift range of 0 (PYP's default, "0.0 = mask radius", config/pyp_config.toml:5338-5343) or beyond 8 search-grid steps is
+    HONOURED (tiles of the window) and only a range beyond what the search grid can hold without aliasing is reported."""
     vol, imgs, rows = dataset(256, 2, 1.0, 0.2)
     g = H.Reference(vol, 128)
     base = dict(box=256, pixel_size=1.0, mask_radius=82.0, res_high=3.0, res_search=3.0, angular_step=40.0, iters_hit=-1, local_refine=0)
     g.refine(RefineCfg.make(search_range_x=6.0, search_range_y=6.0, **base), imgs, rows)
     assert "band lowered from 85.3 to 64.0" in g.note() and "shift window" not in g.note()
-    g.refine(RefineCfg.make(search_range_x=0.0, search_range_y=0.0, **base), imgs, rows)
-    assert "shift window of the grid search: +-16 x +-16 pixels" in g.note() and "mask radius" in g.note()
+    g.refine(RefineCfg.make(search_range_x=0.0, search_range_y=0.0, **base), imgs, rows)         # +-82 px = 41 steps of 2 px: 5 x 5 tiles
+    assert "shift window" not in g.note()
+    g.refine(RefineCfg.make(search_range_x=200.0, search_range_y=6.0, **base), imgs, rows)       # 100 steps > Ns / 2 - 1 = 63
+    assert "shift window of the grid search: +-126 x +-6 pixels" in g.note() and "asked: 200 pixels" in g.note()
     g.refine(RefineCfg.make(search_range_x=6.0, search_range_y=6.0, res_high=6.0, res_search=6.0, **{k: v for k, v in base.items() if not k.startswith("res_")}), imgs, rows)
     assert g.note() == ""
+
+
+def test_wide_shift_window_is_searched_in_tiles_like_the_oracle(H, O):
+    """Particles up to +-11 px off centre, window +-24 px = 12 search-grid steps (2 x 2 tiles of the kernel's 17 x 17 window): the
+    grid search alone (hits left on the grid) gives the oracle's orientation and integer shift for every particle; with PYP's
+    range 0 the window is the mask radius (13 steps here)."""
+    n, px = 64, 2.0
+    vol, stack, rows = synth.make_dataset(n, 10, pixel=px, snr=0.3, shift_sigma=6.0, shift_clip=11.0)
+    imgs = stack.numpy()
+    assert np.abs(rows[:, 4:6]).max() / px > 8.5
+    g, o = H.Reference(vol, n / 2), O.Reference(vol, n / 2)
+    for sr in ((24.0, 24.0), (0.0, 30.0), (0.0, 0.0)):
+        c = cfg_for(n, px, search_range_x=sr[0] * px if sr[0] else 0.0, search_range_y=sr[1] * px if sr[1] else 0.0, iters_hit=-1, local_refine=0)
+        want, cw = O.refine_batch(o, c, imgs, rows)
+        got = g.refine(c, imgs, rows)
+        assert synth.angular_error_deg(want, got).max() < 1e-3 and synth.shift_error_px(want, got, px).max() < 1e-3, sr
+        assert np.abs(want[:, 14] - got[:, 14]).max() < 0.02
+    # and refined from there: on the truth
+    c = cfg_for(n, px, search_range_x=0.0, search_range_y=0.0)
+    want, _ = O.refine_batch(o, c, imgs, rows)
+    got = g.refine(c, imgs, rows)
+    assert synth.angular_error_deg(want, got).max() < ANG_TOL_DEG and synth.shift_error_px(want, got, px).max() < SHIFT_TOL_PX
+    assert np.median(synth.shift_error_px(got, rows, px)) < 0.5 and np.median(synth.angular_error_deg(got, rows)) < 2.0
+    # the old +-8-step window could not have found the largest shifts
+    narrow = g.refine(cfg_for(n, px, search_range_x=16.0, search_range_y=16.0, iters_hit=-1, local_refine=0), imgs, rows)
+    far = np.abs(rows[:, 4:6]).max(axis=1) / px > 8.2              # beyond the narrow window of +-8 px
+    assert far.any() and synth.shift_error_px(narrow[far], rows[far], px).min() > 1.0
 
 
 def test_particle_pairs_of_the_grid_search_do_not_couple(H):
@@ -716,3 +746,34 @@ def test_full_size_properties_256(H):
     o2 = g.refine(c, rot, rows[:8])
     d = synth.angular_error_deg(o2, out[:8])
     assert np.median(np.abs(d - 90.0)) < 2.0
+
+
+def test_priors_restrain_the_search_like_the_oracle(d64, H, O):
+    """Answer 7 "use priors" (frealign.py:3841-3844, :3927; include/ppm.h ppm_refine_cfg.use_priors): GPU = oracle with the
+    restraint switched on; a flat prior changes nothing; a tight prior around the start keeps the poses there."""
+    vol, imgs, rows, g, o = d64
+    n, px = 64, 2.0
+    start = rows.copy()
+    rng = np.random.default_rng(9)
+    start[:, 1:4] += rng.normal(0, 1.5, (len(rows), 3)); start[:, 4:6] += rng.normal(0, 1.0, (len(rows), 2)) * px
+    base = dict(box=n, pixel_size=px, mask_radius=0.4 * n * px, res_high=px * n / 24, res_signed_cc=30.0, global_search=0)
+    free = g.refine(RefineCfg.make(**base), imgs, start)
+    mean = [180.0, 90.0, 180.0, 0.0, 0.0]
+    flat = g.refine(RefineCfg.make(priors=(mean, [1e12] * 5), **base), imgs, start)
+    assert synth.angular_error_deg(free, flat).max() < 1e-3 and synth.shift_error_px(free, flat, px).max() < 1e-3
+    # per-particle tight priors are not what the file carries (one mean for the data set): take one particle and restrain it to its start
+    for j in (0, 3):
+        pri = ([start[j, 1], start[j, 2], start[j, 3], start[j, 4], start[j, 5]], [1e-3, 1e-3, 1e-3, 1e-3, 1e-3])
+        cfg = RefineCfg.make(priors=pri, **base)
+        want, _ = O.refine_batch(o, cfg, imgs[j:j + 1], start[j:j + 1])
+        got = g.refine(cfg, imgs[j:j + 1], start[j:j + 1])
+        assert synth.angular_error_deg(want, got).max() < 0.1 and synth.shift_error_px(want, got, px).max() < 0.5
+        assert synth.angular_error_deg(got, start[j:j + 1]).max() < 0.25 * synth.angular_error_deg(free[j:j + 1], start[j:j + 1]).max()
+        assert abs(want[0, 14] - got[0, 14]) < 0.05                   # SCORE is the data term alone, at the restrained pose
+    # a realistic data-set prior (broad angles, shifts within a few Angstrom): GPU = oracle on all particles
+    pri = ([180.0, 90.0, 180.0, 0.0, 0.0], [1.0e4, 2.5e3, 1.0e4, 4.0, 4.0])
+    cfg = RefineCfg.make(priors=pri, **base)
+    want, _ = O.refine_batch(o, cfg, imgs, start)
+    got = g.refine(cfg, imgs, start)
+    assert synth.angular_error_deg(want, got).max() < 0.1 and synth.shift_error_px(want, got, px).max() < 0.5
+    assert np.abs(want[:, 14] - got[:, 14]).max() < 0.05

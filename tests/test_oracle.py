@@ -263,3 +263,29 @@ def test_beam_tilt_phase_is_removed_before_scoring():
     s_ignored = oracle.score_batch(ref, c, imgs_t, rows)
     assert np.abs(s_ok - s_ref).max() < 0.01
     assert (s_ref - s_ignored).min() > 0.05
+
+
+def test_priors_restrain_the_local_search():
+    """ppm_refine_cfg.use_priors (answer 7 of refine3d): a flat prior leaves the search alone, a tight one pins the pose, and
+    SCORE stays the data term (evaluated at the restrained pose)."""
+    from pyp_amd import synth
+    from pyp_amd.abi import RefineCfg
+    from oracle import oracle as O
+    n, px = 32, 3.0
+    vol, stack, rows = synth.make_dataset(n, 3, pixel=px, snr=0.3)
+    imgs = stack.numpy()
+    start = rows.copy()
+    rng = np.random.default_rng(1)
+    start[:, 1:4] += rng.normal(0, 2, (3, 3)); start[:, 4:6] += rng.normal(0, 1, (3, 2)) * px
+    base = dict(box=n, pixel_size=px, mask_radius=0.4 * n * px, res_high=px * n / 12, global_search=0)
+    o = O.Reference(vol, n / 2)
+    free, _ = O.refine_batch(o, RefineCfg.make(**base), imgs, start)
+    flat, _ = O.refine_batch(o, RefineCfg.make(priors=([0] * 5, [1e12] * 5), **base), imgs, start)
+    assert np.abs(free - flat).max() < 1e-6
+    pri = (list(start[0, 1:6]), [1e-3] * 5)
+    tight, _ = O.refine_batch(o, RefineCfg.make(priors=pri, **base), imgs[:1], start[:1])
+    assert synth.angular_error_deg(tight, start[:1]).max() < 0.05 < synth.angular_error_deg(free[:1], start[:1]).max()
+    at_start, _ = O.refine_batch(o, RefineCfg.make(local_refine=0, **base), imgs[:1], tight)
+    assert abs(at_start[0, 14] - tight[0, 14]) < 1e-6
+    only_shifts, _ = O.refine_batch(o, RefineCfg.make(priors=(list(start[0, 1:6]), [0, 0, 0, 1e-3, 1e-3]), **base), imgs[:1], start[:1])
+    assert synth.shift_error_px(only_shifts, start[:1], px).max() < 0.05 and synth.angular_error_deg(only_shifts, start[:1]).max() > 0.3    # angles stay free

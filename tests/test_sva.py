@@ -59,6 +59,52 @@ def test_gpu_alignment_matches_oracle(n, kw):
         assert synth.pose_angle_error(got, poses).mean() < 0.4 * synth.pose_angle_error(start, poses).mean()
 
 
+def test_oracle_global_search_finds_alignments_from_random_starts(subtomos):
+    """ppm_sva_cfg.search_mode 1 (the protocol's alignment_mode 0, iteration_002_mode_3.xml:29-38): from rotations anywhere on SO(3)
+    the coarse grid + 25 refined candidates land on the true alignment; the refinement mode alone cannot; mode 2 moves shifts only."""
+    n, vol, vols, poses, wedges, O, ref = subtomos
+    rng = np.random.default_rng(0)
+    start = poses[:3].copy()
+    for v in range(3):
+        R = synth.euler_matrix(rng.uniform(0, 360), np.degrees(np.arccos(rng.uniform(-1, 1))), rng.uniform(0, 360))
+        start[v, :9] = (poses[v, :9].reshape(3, 3) @ R).ravel()
+        start[v, 9:] += rng.normal(0, 1.5, 3)
+    assert synth.pose_angle_error(start, poses[:3]).min() > 60
+    out, sc, _ = O.sva_align(ref, cfg_for(n, search_mode=1, global_step=20.0), vols[:3], wedges[:3], start)
+    assert synth.pose_angle_error(out, poses[:3]).max() < 1.2 and np.linalg.norm(out[:, 9:] - poses[:3, 9:], axis=1).max() < 0.2 and sc.min() > 0.8
+    loc, lsc, _ = O.sva_align(ref, cfg_for(n), vols[:3], wedges[:3], start)
+    assert synth.pose_angle_error(loc, poses[:3]).min() > 50 and lsc.max() < 0.7
+    tr, _, _ = O.sva_align(ref, cfg_for(n, search_mode=2), vols[:3], wedges[:3], start)
+    assert np.array_equal(tr[:, :9], start[:, :9]) and not np.array_equal(tr[:, 9:], start[:, 9:])
+
+
+@pytest.mark.gpu
+def test_gpu_global_search_matches_oracle():
+    """The grid scores (k_sva_global), the candidates and their refinement against the oracle: same poses within BASELINE's tolerance."""
+    from oracle import oracle as O
+    from pyp_amd import host
+    n = 32
+    vol, vols, poses, wedges = synth.make_subtomograms(n, 6, snr=0.5, wedge=(-54.0, 60.0))
+    rng = np.random.default_rng(4)
+    start = poses.copy()
+    for v in range(len(start)):
+        R = synth.euler_matrix(rng.uniform(0, 360), np.degrees(np.arccos(rng.uniform(-1, 1))), rng.uniform(0, 360))
+        start[v, :9] = (poses[v, :9].reshape(3, 3) @ R).ravel()
+        start[v, 9:] += rng.normal(0, 1.5, 3)
+    for kw in (dict(search_mode=1, global_step=20.0), dict(search_mode=1, global_step=30.0, n_candidates=8, tol_shift=0.0), dict(search_mode=2)):
+        c = cfg_for(n, **kw)
+        s0 = start if kw.get("tol_shift", 1) else np.concatenate([start[:, :9], poses[:, 9:]], axis=1)
+        want, wsc, _ = O.sva_align(O.Reference(vol, n / 2), c, vols.numpy(), wedges, s0)
+        g = host.Reference(vol, n / 2)
+        got, gsc = g.sva_align(c, vols.numpy(), wedges, s0)
+        assert synth.pose_angle_error(want, got).max() < 0.1 and np.abs(want[:, 9:] - got[:, 9:]).max() < 0.5, kw
+        assert np.abs(wsc - gsc).max() < 2e-3
+        if kw["search_mode"] == 1:
+            assert synth.pose_angle_error(got, poses).max() < 1.5 and gsc.min() > 0.8, kw
+        got2, gsc2 = g.sva_align(c, vols.cuda(), wedges, s0)
+        assert np.array_equal(got, got2) and np.array_equal(gsc, gsc2)
+
+
 @pytest.mark.gpu
 def test_host_volumes_in_several_chunks_equal_resident_volumes(monkeypatch):
     """Host volumes are uploaded chunk by chunk, the next chunk by a helper thread while the current one is searched
@@ -125,6 +171,10 @@ def test_volumes_table_roundtrip_and_protocol_fields(tmp_path):
     c = sva.cfg_from_xml(str(xml), 96)
     assert (c.box, list(c.window), c.window_sigma) == (96, [32.0, 32.0, 28.0], 4.0)
     assert abs(c.lowpass_cutoff - 0.125) < 1e-7 and abs(c.highpass_decay - 0.01) < 1e-7 and c.tol_angle == 15.0 and c.tol_shift == 10.0 and c.use_missing_wedge == 1
+    assert c.search_mode == 0 and c.n_candidates == 25                      # no alignment_mode in the protocol: refinement
+    xml.write_text(xml.read_text().replace("<metric>", "<metric><alignment_mode>0</alignment_mode><number_of_candidate_peaks_to_search>12</number_of_candidate_peaks_to_search>"))
+    c = sva.cfg_from_xml(str(xml), 96)
+    assert c.search_mode == 1 and c.n_candidates == 12                      # the protocol's 0 = global search
 
 
 @pytest.mark.gpu
