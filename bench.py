@@ -340,6 +340,19 @@ def refine_bench(ctx):
                               "achieved": round(fl_n / (ms_n * 1e-3) / 1e12, 2), "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s",
                               "frac": round(fl_n / (ms_n * 1e-3) / 1e12 / PEAK_VALU_TFLOPS, 4),
                               "note": "v_mfma_f32_32x32x2_f32: the fp32 matrix peak equals the fp32 vector peak (256 flop / cycle / CU)"}
+    roof["in_band_only_frac"] = round(tf / PEAK_VALU_TFLOPS * S_g / (64.0 * HsP), 4)      # `frac` counts masked lanes (they execute); this is the share of the peak spent on in-band samples
+    # k_local (second kernel of the step): one trilinear gather of the reference per (sample, rotation) - 4 x 16-byte loads served by
+    # L2 / L1 - and ~70 fp32 operations on it (position 12, seven complex interpolations 42, CTF 2, |m|^2 3, phase 6, dot 4, ring sums 1)
+    if prof.get("local", {}).get("launches"):
+        ms_l = prof["local"]["ms"] / (M * a.steps) * 1e-3                                  # seconds per particle
+        gathers = counts["samples_local"]                                                   # gathered samples per particle (every evaluation at its marching band)
+        fl_l = 70.0 * gathers
+        roof["local"] = {"kernel": "k_local", "bound": "valu_fp32", "us_per_particle": round(ms_l * 1e6, 3), "gathered_samples_per_particle": gathers,
+                         "achieved": round(fl_l / ms_l / 1e12, 2), "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s", "frac": round(fl_l / ms_l / 1e12 / PEAK_VALU_TFLOPS, 4),
+                         "flop_model": "70 fp32 operations per gathered sample (useful arithmetic; the kernel issues ~130 vector instructions per gathered "
+                                       "sample, most of them gather addressing and 16-lane ring reductions)",
+                         "gather_GBps_from_cache": round(64.0 * gathers / ms_l / 1e9, 1),
+                         "note": "vector-issue-bound (VALU ~90 % busy) with the texture-address path ~60 % busy: 4 x 16 B per lane and gather"}
     pv = pmc_valu("r02_pmc_refine.json", "k_global", n_slices)
     if pv:
         pv["model_flops_per_lane_instruction"] = round(fl_slice / (pv["SQ_INSTS_VALU_per_slice"] * 64.0), 3)
