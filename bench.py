@@ -124,6 +124,13 @@ def kernels_sha16():
     return h.hexdigest()[:16]
 
 
+def pmc_latest(workload):
+    """The newest committed PMC summary of a workload (profiles/rNN_pmc_<workload>.json)."""
+    import glob
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", "r??_pmc_%s.json" % workload)))
+    return os.path.basename(c[-1]) if c else "r02_pmc_%s.json" % workload
+
+
 def pmc_entry(summary, kernel):
     """One kernel's counters from a committed rocprofv3 --pmc summary (scripts/pmc_r02.sh -> scripts/pmc_summary.py).
     Returns (entry, meta) or (None, None)."""
@@ -319,7 +326,7 @@ def refine_bench(ctx):
     tf = flops_g / (ms_g * 1e-3) / 1e12
     bytes_model = ppl * counts["n_global"] * 8.0 * S_g                        # SURVEY §8(d) streaming model
     gbps_model = bytes_model / (ms_g * 1e-3) / 1e9
-    traffic, traffic_src = pmc_traffic("r02_pmc_refine.json", "k_global", ppl)
+    traffic, traffic_src = pmc_traffic(pmc_latest("refine"), "k_global", ppl)
     roof = {"bound": "valu_fp32", "kernel": "k_global", "achieved": round(tf, 2), "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tf / PEAK_VALU_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(ms_g, 3),
             "particles_per_launch": round(ppl, 1), "flops_per_launch": flops_g,
@@ -353,7 +360,7 @@ def refine_bench(ctx):
                                        "sample, most of them gather addressing and 16-lane ring reductions)",
                          "gather_GBps_from_cache": round(64.0 * gathers / ms_l / 1e9, 1),
                          "note": "vector-issue-bound (VALU ~90 % busy) with the texture-address path ~60 % busy: 4 x 16 B per lane and gather"}
-    pv = pmc_valu("r02_pmc_refine.json", "k_global", n_slices)
+    pv = pmc_valu(pmc_latest("refine"), "k_global", n_slices)
     if pv:
         pv["model_flops_per_lane_instruction"] = round(fl_slice / (pv["SQ_INSTS_VALU_per_slice"] * 64.0), 3)
         roof["pmc"] = pv
@@ -521,7 +528,7 @@ def reconstruct_bench(ctx):
     ms = prof[dom]["ms"] / nl
     ppl = M * a.steps / nl
     kname = "k_prep" if dom == "prep" else "k_insert_bricks"
-    traffic, traffic_src = pmc_traffic("r02_pmc_reconstruct.json", kname, ppl)
+    traffic, traffic_src = pmc_traffic(pmc_latest("reconstruct"), kname, ppl)
     if dom == "prep":
         B = N // 2 - 1
         alg = ppl * (4.0 * N * N + 8.0 * (2 * B + 1) * (B + 1))       # image read once + band spectrum written once
