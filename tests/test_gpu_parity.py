@@ -289,7 +289,7 @@ def test_wide_shift_window_is_searched_in_tiles_like_the_oracle(H, O):
     # the old +-8-step window could not have found the largest shifts
     narrow = g.refine(cfg_for(n, px, search_range_x=16.0, search_range_y=16.0, iters_hit=-1, local_refine=0), imgs, rows)
     far = np.abs(rows[:, 4:6]).max(axis=1) / px > 8.2              # beyond the narrow window of +-8 px
-    assert far.any() and synth.shift_error_px(narrow[far], rows[far], px).min() > 1.0
+    assert far.any() and synth.shift_error_px(narrow[far], rows[far], px).min() > 0.5 > np.median(synth.shift_error_px(got[far], rows[far], px))
 
 
 def test_particle_pairs_of_the_grid_search_do_not_couple(H):
