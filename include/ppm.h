@@ -24,13 +24,14 @@
  * device memory.  No torch types cross this boundary.
  *
  * Process model: one process per GPU.  ppm_init binds the process to one device (a second call with another index
- * fails); every call runs on the library's own HIP stream and its workspaces (FFT plans, scratch, event pools) are
- * process-wide, so calls must be SERIALISED by the caller - the library is not thread-safe, also across different
- * handles.  Several reference / accumulator handles may be alive and used alternately (each keeps its own search-grid
- * tables).
+ * fails).  Thread-compatible per handle: every reference / accumulator handle owns its HIP streams and workspaces, so calls on
+ * DIFFERENT handles may be made concurrently from different threads (two class references refined side by side, an insertion
+ * running next to a refinement); calls on ONE handle must be serialised by the caller.  Process-wide tables (FFT plans, the
+ * profiling counters) are guarded inside the library.  Entry points without a handle (ppm_extract_boxes, ppm_device_*,
+ * ppm_host_*) are thread-safe; ppm_extract_boxes calls share one stream and are serialised on the device.
  *
  * Stream ordering: device buffers handed in (resident particle stacks, an external accumulator buffer, extraction
- * outputs) are read / written on the library's stream, which is NOT ordered against any stream of the caller: finish
+ * outputs) are read / written on the handle's stream, which is NOT ordered against any stream of the caller: finish
  * (or synchronise) the work that produces them before the call; every entry point returns only after its own device
  * work has completed, so results may be used on any stream afterwards.
  */

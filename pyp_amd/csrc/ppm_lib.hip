@@ -11,6 +11,7 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -62,11 +63,27 @@ struct Ctx {
     std::vector<hipEvent_t> pool;
 } g;
 
+// Streams are per HANDLE (ppm_reference / ppm_accum own a compute and a copy stream each): an entry point that takes a handle makes
+// them the calling thread's current streams for its duration (StreamScope), everything below launches on cur_stream().  Calls
+// on DIFFERENT handles may therefore run concurrently from different threads; process-wide state (FFT plan tables, the profiling
+// event lists) is guarded by g_mu.  Entry points without a handle use the library's own pair of streams.
+thread_local hipStream_t tl_stream = nullptr, tl_copy = nullptr;
+std::mutex g_mu;
+inline hipStream_t cur_stream() { return tl_stream ? tl_stream : g.stream; }
+inline hipStream_t cur_copy() { return tl_copy ? tl_copy : g.copy; }
+struct StreamScope {
+    hipStream_t ps, pc;
+    StreamScope(hipStream_t s_, hipStream_t c_) : ps(tl_stream), pc(tl_copy) { tl_stream = s_; tl_copy = c_; if (g.inited) (void)hipSetDevice(g.device); }
+    ~StreamScope() { tl_stream = ps; tl_copy = pc; }
+};
+
 hipEvent_t ev_get() {
+    std::lock_guard<std::mutex> lk(g_mu);
     if (!g.pool.empty()) { hipEvent_t e = g.pool.back(); g.pool.pop_back(); return e; }
     hipEvent_t e; (void)hipEventCreate(&e); return e;
 }
 void prof_flush() {
+    std::lock_guard<std::mutex> lk(g_mu);
     for (auto &p : g.pending) {
         (void)hipEventSynchronize(p.b);
         float ms = 0; (void)hipEventElapsedTime(&ms, p.a, p.b);
@@ -77,12 +94,13 @@ void prof_flush() {
 }
 struct ProfScope {
     int id; hipEvent_t a = nullptr;
-    explicit ProfScope(int id_) : id(id_) { if (g.prof_on) { a = ev_get(); (void)hipEventRecord(a, g.stream); } }
-    ~ProfScope() { if (a) { hipEvent_t b = ev_get(); (void)hipEventRecord(b, g.stream); g.pending.push_back({ id, a, b }); } }
+    explicit ProfScope(int id_) : id(id_) { if (g.prof_on) { a = ev_get(); (void)hipEventRecord(a, cur_stream()); } }
+    ~ProfScope() { if (a) { hipEvent_t b = ev_get(); (void)hipEventRecord(b, cur_stream()); std::lock_guard<std::mutex> lk(g_mu); g.pending.push_back({ id, a, b }); } }
 };
 
 int ensure_plan(int n) {
     if (n < 2 || n > 512) return fail(-22, "FFT length out of range");
+    std::lock_guard<std::mutex> lk(g_mu);
     if (g.plans[n].ready) return 0;
     std::vector<int> fac; std::vector<unsigned short> perm;
     fft_factors(n, fac, perm);
@@ -115,7 +133,7 @@ int fft3d(float2 *d, int n, bool inverse) {
         else if (pass == 1) { P.inner = n; P.inner_stride = 1; P.outer_stride = (long)n * n; P.elem_stride = n; P.line_major = 1; }
         else { P.inner = nlines; P.inner_stride = 1; P.outer_stride = 0; P.elem_stride = (long)n * n; P.line_major = 1; }
         unsigned blocks = (unsigned)((nlines + L - 1) / L);
-        hipLaunchKernelGGL(k_fft_lines, dim3(blocks), dim3(256), (size_t)L * n * sizeof(float2), g.stream, P);
+        hipLaunchKernelGGL(k_fft_lines, dim3(blocks), dim3(256), (size_t)L * n * sizeof(float2), cur_stream(), P);
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -130,7 +148,7 @@ static int fft_lines_pass(float2 *d, int n, long nlines, long inner, long inner_
     FftLinesP P;
     P.data = d; P.plan = g.plans[n].plan; P.n = n; P.inverse = inverse ? 1 : 0; P.L = L; P.nlines = nlines;
     P.inner = inner; P.inner_stride = inner_stride; P.outer_stride = outer_stride; P.elem_stride = elem_stride; P.line_major = line_major;
-    hipLaunchKernelGGL(k_fft_lines, dim3((unsigned)((nlines + L - 1) / L)), dim3(256), (size_t)L * n * sizeof(float2), g.stream, P);
+    hipLaunchKernelGGL(k_fft_lines, dim3((unsigned)((nlines + L - 1) / L)), dim3(256), (size_t)L * n * sizeof(float2), cur_stream(), P);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -160,11 +178,12 @@ struct DevTmp {
     hipError_t alloc(size_t n) { return hipMalloc(&p, n * sizeof(T)); }
 };
 
-DevBuf<float2> g_prep_spill;     // k_prep: the half spectrum between the row and the column phase, [n][N][W]
+thread_local DevBuf<float2> g_prep_spill;     // (per calling thread) k_prep: the half spectrum between the row and the column phase, [n][N][W]
 
 }  // namespace
 
 struct ppm_ref {
+    hipStream_t stream = nullptr, copy = nullptr;       // this handle's compute and copy streams (StreamScope)
     int N = 0, B = 0, CX = 0, CY = 0, NBX = 0, NBY = 0, pad = 1; unsigned LB = 0;   // B, CX, CY count samples of the padded transform
     float2 *cube = nullptr;
     // workspaces (grown on demand, reused across calls)
@@ -186,6 +205,7 @@ struct ppm_ref {
 };
 
 struct ppm_accum {
+    hipStream_t stream = nullptr, copy = nullptr;       // this handle's compute and copy streams (StreamScope)
     int N = 0; float pixel = 1.f;
     float *acc = nullptr; bool external = false;
     std::vector<double> symops; int nsym = 1;
@@ -245,8 +265,8 @@ static int build_brick_items(ppm_accum *a, const Geom &gm, int BE, int nb) {
     std::vector<BrickItem> items(v.size());
     for (size_t i = 0; i < v.size(); i++) items[i] = v[i].it;
     if (int rc = a->items.ensure(items.size())) return rc;
-    HIPCHK(hipMemcpyAsync(a->items.p, items.data(), items.size() * sizeof(BrickItem), hipMemcpyHostToDevice, g.stream));
-    HIPCHK(hipStreamSynchronize(g.stream));
+    HIPCHK(hipMemcpyAsync(a->items.p, items.data(), items.size() * sizeof(BrickItem), hipMemcpyHostToDevice, cur_stream()));
+    HIPCHK(hipStreamSynchronize(cur_stream()));
     a->n_items = (int)items.size(); a->items_cap = cap * 1000 + smax_env;
     return 0;
 }
@@ -310,6 +330,7 @@ static int launch_prep(const float *d_images, const double *d_rows, int n_img, c
     } else
     if (lds > budget) return fail(-12, "pre-processing kernel: LDS plan exceeds its budget");
     static bool attr_set = false;
+    std::unique_lock<std::mutex> lk_attr(g_mu);
     if (!attr_set) {
         HIPCHK(hipFuncSetAttribute((const void *)k_prep<512, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void *)k_prep<512, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
@@ -318,13 +339,14 @@ static int launch_prep(const float *d_images, const double *d_rows, int n_img, c
         HIPCHK(hipFuncSetAttribute((const void *)k_prep<256, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         attr_set = true;
     }
+    lk_attr.unlock();
     const bool two_blocks = getenv("PPM_PREP_OCC") && atoi(getenv("PPM_PREP_OCC")) == 4;
     ProfScope ps(PPM_K_PREP);
-    if (PT == 512 && two_blocks && !inreg) hipLaunchKernelGGL((k_prep<512, 4>), dim3(n_img), dim3(512), lds, g.stream, P);
-    else if (PT == 512) hipLaunchKernelGGL((k_prep<512, 2>), dim3(n_img), dim3(512), lds, g.stream, P);
-    else if (PT == 256 && occ3) hipLaunchKernelGGL((k_prep<256, 3>), dim3(n_img), dim3(256), lds, g.stream, P);
-    else if (PT == 256) hipLaunchKernelGGL((k_prep<256, 2>), dim3(n_img), dim3(256), lds, g.stream, P);
-    else hipLaunchKernelGGL((k_prep<1024, 1>), dim3(n_img), dim3(1024), lds, g.stream, P);
+    if (PT == 512 && two_blocks && !inreg) hipLaunchKernelGGL((k_prep<512, 4>), dim3(n_img), dim3(512), lds, cur_stream(), P);
+    else if (PT == 512) hipLaunchKernelGGL((k_prep<512, 2>), dim3(n_img), dim3(512), lds, cur_stream(), P);
+    else if (PT == 256 && occ3) hipLaunchKernelGGL((k_prep<256, 3>), dim3(n_img), dim3(256), lds, cur_stream(), P);
+    else if (PT == 256) hipLaunchKernelGGL((k_prep<256, 2>), dim3(n_img), dim3(256), lds, cur_stream(), P);
+    else hipLaunchKernelGGL((k_prep<1024, 1>), dim3(n_img), dim3(1024), lds, cur_stream(), P);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -332,8 +354,8 @@ static int launch_prep(const float *d_images, const double *d_rows, int n_img, c
 template <int R, bool HALF, bool TWO>
 static int launch_global_k(const GlobP &P, int n_img, size_t lds) {
     static bool set = false;
-    if (!set) { HIPCHK(hipFuncSetAttribute((const void *)k_global<R, HALF, TWO>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; }
-    hipLaunchKernelGGL((k_global<R, HALF, TWO>), dim3((n_img + global_particles(R) - 1) / global_particles(R)), dim3(global_threads(R)), lds, g.stream, P);
+    { std::lock_guard<std::mutex> lk_attr(g_mu); if (!set) { HIPCHK(hipFuncSetAttribute((const void *)k_global<R, HALF, TWO>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } }
+    hipLaunchKernelGGL((k_global<R, HALF, TWO>), dim3((n_img + global_particles(R) - 1) / global_particles(R)), dim3(global_threads(R)), lds, cur_stream(), P);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -411,7 +433,7 @@ int ppm_profile_get(int id, double *ms, long *n) {
 void *ppm_device_alloc(size_t bytes) { if (g.inited) (void)hipSetDevice(g.device); void *p = nullptr; if (hipMalloc(&p, bytes) != hipSuccess) { g_err = "ERROR: device allocation failed"; return nullptr; } return p; }
 void ppm_device_free(void *p) { if (p) (void)hipFree(p); }
 // own stream: a helper thread of the caller may upload the next chunk while another thread's library call computes (and uses
-// g.copy for its internal double buffering); returns when the copy has completed
+// cur_copy() for its internal double buffering); returns when the copy has completed
 int ppm_device_upload(void *dst, const void *src, size_t bytes) {
     if (!g.inited) return fail(-1, "ppm_init has not been called");
     HIPCHK(hipSetDevice(g.device));
@@ -421,7 +443,7 @@ int ppm_device_upload(void *dst, const void *src, size_t bytes) {
 }
 void *ppm_host_alloc(size_t bytes) { if (g.inited) (void)hipSetDevice(g.device); void *p = nullptr; if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { g_err = "ERROR: pinned host allocation failed"; return nullptr; } return p; }
 void ppm_host_free(void *p) { if (p) (void)hipHostFree(p); }
-int ppm_device_sync(void) { if (g.stream) HIPCHK(hipStreamSynchronize(g.stream)); HIPCHK(hipDeviceSynchronize()); return 0; }
+int ppm_device_sync(void) { if (cur_stream()) HIPCHK(hipStreamSynchronize(cur_stream())); HIPCHK(hipDeviceSynchronize()); return 0; }
 
 // ------------------------------------------------------------------------------ reference
 ppm_ref_t *ppm_reference_create_weighted(const float *vol, int n, float max_band_px, int pad, const float *ring_weight, int n_weight) {
@@ -438,15 +460,17 @@ ppm_ref_t *ppm_reference_create_weighted(const float *vol, int n, float max_band
     HIPCHKP(t_f.alloc(np3));
     float *d_vol = t_vol.p; float2 *d_f = t_f.p;
     HIPCHKP(hipMemcpy(d_vol, vol, n3 * sizeof(float), hipMemcpyHostToDevice));
-    if (pad > 1) HIPCHKP(hipMemsetAsync(d_f, 0, np3 * sizeof(float2), g.stream));
+    if (pad > 1) HIPCHKP(hipMemsetAsync(d_f, 0, np3 * sizeof(float2), cur_stream()));
     float *d_w = nullptr;
     if (ring_weight && n_weight > 0) {
         HIPCHKP(t_w.alloc((size_t)n_weight));
         d_w = t_w.p;
-        HIPCHKP(hipMemcpyAsync(d_w, ring_weight, (size_t)n_weight * sizeof(float), hipMemcpyHostToDevice, g.stream));
+        HIPCHKP(hipMemcpyAsync(d_w, ring_weight, (size_t)n_weight * sizeof(float), hipMemcpyHostToDevice, cur_stream()));
     }
     std::unique_ptr<ppm_ref, void (*)(ppm_ref_t *)> guard(new ppm_ref(), ppm_reference_destroy);     // freed on every error return
     ppm_ref *r = guard.get();
+    HIPCHKP(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
+    HIPCHKP(hipStreamCreateWithFlags(&r->copy, hipStreamNonBlocking));
     r->N = n; r->pad = pad; r->B = B; r->CX = B + 2; r->CY = 2 * B + 3;
     size_t cube_n = (size_t)r->CX * r->CY * r->CY;
     r->NBX = (r->CX + 3) / 4; r->NBY = (r->CY + 1) / 2;
@@ -454,14 +478,14 @@ ppm_ref_t *ppm_reference_create_weighted(const float *vol, int n, float max_band
     if (2 * copy_n >= ((size_t)1 << 32)) { fail(-22, "reference cube too large"); return nullptr; }
     r->LB = (unsigned)copy_n;
     if (hipMalloc(&r->cube, 2 * copy_n * sizeof(float2)) != hipSuccess) { r->cube = nullptr; fail(-12, "out of device memory for the reference cube"); return nullptr; }
-    HIPCHKP(hipMemsetAsync(r->cube, 0, 2 * copy_n * sizeof(float2), g.stream));
+    HIPCHKP(hipMemsetAsync(r->cube, 0, 2 * copy_n * sizeof(float2), cur_stream()));
     {
         ProfScope ps(PPM_K_BANK);
-        hipLaunchKernelGGL(k_ref_load, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, g.stream, d_vol, d_f, n, np);
+        hipLaunchKernelGGL(k_ref_load, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, cur_stream(), d_vol, d_f, n, np);
         if (fft3d(d_f, np, false)) return nullptr;
-        hipLaunchKernelGGL(k_ref_crop, dim3((unsigned)((cube_n + 255) / 256)), dim3(256), 0, g.stream, d_f, r->cube, np, n, B, r->CX, r->CY, r->NBX, r->NBY, r->LB, d_w, n_weight);
+        hipLaunchKernelGGL(k_ref_crop, dim3((unsigned)((cube_n + 255) / 256)), dim3(256), 0, cur_stream(), d_f, r->cube, np, n, B, r->CX, r->CY, r->NBX, r->NBY, r->LB, d_w, n_weight);
     }
-    if (hipStreamSynchronize(g.stream) != hipSuccess || hipGetLastError() != hipSuccess) { fail(-5, "reference preparation failed on the device"); return nullptr; }
+    if (hipStreamSynchronize(cur_stream()) != hipSuccess || hipGetLastError() != hipSuccess) { fail(-5, "reference preparation failed on the device"); return nullptr; }
     return guard.release();
 }
 
@@ -477,6 +501,8 @@ void ppm_reference_destroy(ppm_ref_t *r) {
     r->c_delta.release(); r->c_s0.release(); r->c_g0.release(); r->c_out.release(); r->c_eval.release(); r->c_rp.release(); r->c_rt.release(); r->c_slot.release(); r->c_states.release(); r->c_uoff.release(); r->c_mean.release(); r->cc.release(); r->mats.release(); r->ddef.release();
     r->band.release(); r->Il.release(); r->Wp.release(); r->bank.release(); r->twN.release(); r->rowtw.release(); r->sh.release(); r->samples.release();
     r->hits.release(); r->states.release(); r->states2.release();
+    if (r->stream) (void)hipStreamDestroy(r->stream);
+    if (r->copy) (void)hipStreamDestroy(r->copy);
     delete r;
 }
 
@@ -491,7 +517,7 @@ static int fft2d_batch(float2 *d, int n, long nimg, bool inverse) {
         P.data = d; P.plan = g.plans[n].plan; P.n = n; P.inverse = inverse ? 1 : 0; P.L = L; P.nlines = nlines;
         if (pass == 0) { P.inner = nlines; P.inner_stride = n; P.outer_stride = 0; P.elem_stride = 1; P.line_major = 0; }
         else { P.inner = n; P.inner_stride = 1; P.outer_stride = (long)n * n; P.elem_stride = n; P.line_major = 1; }
-        hipLaunchKernelGGL(k_fft_lines, dim3((unsigned)((nlines + L - 1) / L)), dim3(256), (size_t)L * n * sizeof(float2), g.stream, P);
+        hipLaunchKernelGGL(k_fft_lines, dim3((unsigned)((nlines + L - 1) / L)), dim3(256), (size_t)L * n * sizeof(float2), cur_stream(), P);
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -501,6 +527,7 @@ static int fft2d_batch(float2 *d, int n, long nimg, bool inverse) {
 int ppm_match_projections(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const double *rows, int n_rows, float *out) {
     if (!g.inited) return fail(-1, "ppm_init has not been called");
     if (!ref || !cfg || !rows || !out) return fail(-22, "null argument");
+    StreamScope ss_(ref->stream, ref->copy);
     if (n_rows <= 0) return 0;
     ppm_refine_cfg c2 = *cfg; c2.global_search = 0;          // only box, pixel size and the high-resolution limit matter here
     Geom gm; std::string err;
@@ -526,14 +553,14 @@ int ppm_match_projections(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const doubl
             q.sx = (float)(row[PPM_XSHIFT] / gm.a); q.sy = (float)(row[PPM_YSHIFT] / gm.a);
             q.ctf = ctf_from_row(row, gm.N, gm.a);
         }
-        HIPCHK(hipMemcpyAsync(d_rows.p, hr.data(), (size_t)nb * sizeof(MatchRow), hipMemcpyHostToDevice, g.stream));
+        HIPCHK(hipMemcpyAsync(d_rows.p, hr.data(), (size_t)nb * sizeof(MatchRow), hipMemcpyHostToDevice, cur_stream()));
         MP.n = nb;
-        hipLaunchKernelGGL(k_match_fill, dim3((unsigned)((NN * nb + 255) / 256)), dim3(256), 0, g.stream, MP);
+        hipLaunchKernelGGL(k_match_fill, dim3((unsigned)((NN * nb + 255) / 256)), dim3(256), 0, cur_stream(), MP);
         if (int rc = fft2d_batch(d_f.p, gm.N, nb, true)) return rc;
-        hipLaunchKernelGGL(k_match_real, dim3((unsigned)((NN * nb + 255) / 256)), dim3(256), 0, g.stream, d_f.p, d_o.p, NN * nb, scale);
+        hipLaunchKernelGGL(k_match_real, dim3((unsigned)((NN * nb + 255) / 256)), dim3(256), 0, cur_stream(), d_f.p, d_o.p, NN * nb, scale);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(out + (size_t)c0 * NN, d_o.p, NN * nb * sizeof(float), hipMemcpyDeviceToHost, g.stream));
-        HIPCHK(hipStreamSynchronize(g.stream));            // `hr` is reused by the next chunk
+        HIPCHK(hipMemcpyAsync(out + (size_t)c0 * NN, d_o.p, NN * nb * sizeof(float), hipMemcpyDeviceToHost, cur_stream()));
+        HIPCHK(hipStreamSynchronize(cur_stream()));            // `hr` is reused by the next chunk
     }
     return 0;
 }
@@ -543,6 +570,7 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
                      int n_img, const double *rows_in, double *rows_out) {
     if (!g.inited) return fail(-1, "ppm_init has not been called");
     if (!ref || !cfg || !images || !rows_in || !rows_out) return fail(-22, "null argument");
+    StreamScope ss_(ref->stream, ref->copy);
     if (n_img <= 0) return 0;
     Geom gm; std::string err;
     if (!geom_init(gm, *cfg, err)) return fail(-22, err);
@@ -584,7 +612,7 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
     int ring_s = (int)std::ceil(gm.r_s); if (ring_s > gm.B + 1) ring_s = gm.B + 1;
     (void)ring_s;
     if (int rc = ref->samples.ensure(S_pad)) return rc;
-    HIPCHK(hipMemcpyAsync(ref->samples.p, sl.packed.data(), S_pad * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemcpyAsync(ref->samples.p, sl.packed.data(), S_pad * sizeof(uint32_t), hipMemcpyHostToDevice, cur_stream()));
 
     const size_t NN = (size_t)gm.N * gm.N, HW = (size_t)gm.H * gm.W, HS = (size_t)gm.Hs * 64;
     // shift window: the kernel searches +-PPM_MAX_SHIFT_STEPS steps; a wider window is covered by overlapping tiles of that
@@ -651,10 +679,10 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
             if (int rc = ref->dir_phi.ensure(gm.n_dir)) return rc;
             if (int rc = ref->twN.ensure(gm.Ns)) return rc;
             if (int rc = ref->bank.ensure((size_t)nslices * HSP)) return rc;
-            HIPCHK(hipMemcpyAsync(ref->mats.p, mats.data(), mats.size() * sizeof(float), hipMemcpyHostToDevice, g.stream));
-            HIPCHK(hipMemcpyAsync(ref->dir_theta.p, dth.data(), dth.size() * sizeof(double), hipMemcpyHostToDevice, g.stream));
-            HIPCHK(hipMemcpyAsync(ref->dir_phi.p, dph.data(), dph.size() * sizeof(double), hipMemcpyHostToDevice, g.stream));
-            HIPCHK(hipMemcpyAsync(ref->twN.p, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice, g.stream));
+            HIPCHK(hipMemcpyAsync(ref->mats.p, mats.data(), mats.size() * sizeof(float), hipMemcpyHostToDevice, cur_stream()));
+            HIPCHK(hipMemcpyAsync(ref->dir_theta.p, dth.data(), dth.size() * sizeof(double), hipMemcpyHostToDevice, cur_stream()));
+            HIPCHK(hipMemcpyAsync(ref->dir_phi.p, dph.data(), dph.size() * sizeof(double), hipMemcpyHostToDevice, cur_stream()));
+            HIPCHK(hipMemcpyAsync(ref->twN.p, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice, cur_stream()));
             // row twiddles of the shift window (scalar loads in k_global)
             {
                 std::vector<float4> rt((size_t)kRowTwRows * PPM_MAX_SHIFT_STEPS, make_float4(1.f, 1.f, 0.f, 0.f));
@@ -664,22 +692,22 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
                     rt[(size_t)tp * PPM_MAX_SHIFT_STEPS + j - 1] = make_float4(c, c, sn, sn);
                 }
                 if (int rc = ref->rowtw.ensure(rt.size())) return rc;
-                HIPCHK(hipMemcpyAsync(ref->rowtw.p, rt.data(), rt.size() * sizeof(float4), hipMemcpyHostToDevice, g.stream));
-                HIPCHK(hipStreamSynchronize(g.stream));
+                HIPCHK(hipMemcpyAsync(ref->rowtw.p, rt.data(), rt.size() * sizeof(float4), hipMemcpyHostToDevice, cur_stream()));
+                HIPCHK(hipStreamSynchronize(cur_stream()));
             }
             BankP BP; BP.cv = cv; BP.mats = ref->mats.p; BP.bank = ref->bank.p; BP.nslices = nslices; BP.Bs = gm.Bs; BP.Hs = HsP;
             BP.r_s2 = (float)(gm.r_s * gm.r_s);
             {
                 ProfScope ps(PPM_K_BANK);
                 size_t tot = (size_t)nslices * HSP;
-                hipLaunchKernelGGL(k_bank, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, g.stream, BP);
+                hipLaunchKernelGGL(k_bank, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, cur_stream(), BP);
             }
             HIPCHK(hipGetLastError());
-            HIPCHK(hipStreamSynchronize(g.stream));   // host vectors go out of scope
+            HIPCHK(hipStreamSynchronize(cur_stream()));   // host vectors go out of scope
             ref->bank_key = key;
         }
     }
-    HIPCHK(hipStreamSynchronize(g.stream));
+    HIPCHK(hipStreamSynchronize(cur_stream()));
 
     // frequency marching: band of a compass iteration from its probe displacement (same rule as the oracle's iter_band)
     const double bf = cfg->band_factor == 0 ? 3.0 : cfg->band_factor, rm_px = cfg->mask_radius / gm.a;
@@ -729,12 +757,12 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
     };
     LP.rmax2_final = (float)(gm.r_hi * gm.r_hi); LP.S_final = S_pad;
     if (!images_on_device) {        // first chunk's images
-        HIPCHK(hipMemcpyAsync(ref->images.p, images, (size_t)std::min(CH, n_img) * NN * sizeof(float), hipMemcpyHostToDevice, g.copy));
-        HIPCHK(hipStreamSynchronize(g.copy));
+        HIPCHK(hipMemcpyAsync(ref->images.p, images, (size_t)std::min(CH, n_img) * NN * sizeof(float), hipMemcpyHostToDevice, cur_copy()));
+        HIPCHK(hipStreamSynchronize(cur_copy()));
     }
     for (int c0 = 0, ci = 0; c0 < n_img; c0 += CH, ci++) {
         const int nb = std::min(CH, n_img - c0);
-        HIPCHK(hipMemcpyAsync(ref->rows_in.p, rows_in + (size_t)c0 * PPM_NCOL, (size_t)nb * PPM_NCOL * sizeof(double), hipMemcpyHostToDevice, g.stream));
+        HIPCHK(hipMemcpyAsync(ref->rows_in.p, rows_in + (size_t)c0 * PPM_NCOL, (size_t)nb * PPM_NCOL * sizeof(double), hipMemcpyHostToDevice, cur_stream()));
         const float *d_img = images_on_device ? (const float *)images + (size_t)c0 * NN : ref->images.p + (size_t)(ci & 1) * CH * NN;
         // refinement spectra (+ search tables when the same mask serves both)
         if (int rc = launch_prep(d_img, ref->rows_in.p, nb, gm, Rm_px, fall_px, cfg->normalize, cfg->invert, 1, 1, ref->band.p, ref->wring.p,
@@ -753,7 +781,7 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
             {
                 ProfScope ps(PPM_K_NORMS);
                 NormP NP; NP.C2 = ref->C2.p; NP.bank = ref->bank.p; NP.nP = ref->nP.p; NP.n = nb; NP.nslices = nslices; NP.Bs = gm.Bs; NP.Hs = gm.Hs; NP.HsP = HsP;
-                hipLaunchKernelGGL(k_slice_norms, dim3((nb + 127) / 128, (nslices + 127) / 128), dim3(256), 0, g.stream, NP);
+                hipLaunchKernelGGL(k_slice_norms, dim3((nb + 127) / 128, (nslices + 127) / 128), dim3(256), 0, cur_stream(), NP);
             }
             if (ntiles == 1) {
                 if (int rc = launch_global(GP, nb, gm.half != 0, Rwin)) return rc;
@@ -763,23 +791,23 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
                 if (int rc = ref->tile_c.ensure((size_t)2 * ntiles)) return rc;
                 std::vector<int> tc(2 * ntiles);
                 for (int ty = 0, t = 0; ty < (int)cys.size(); ty++) for (int tx = 0; tx < (int)cxs.size(); tx++, t++) { tc[t] = cxs[tx]; tc[ntiles + t] = cys[ty]; }
-                HIPCHK(hipMemcpyAsync(ref->tile_c.p, tc.data(), tc.size() * sizeof(int), hipMemcpyHostToDevice, g.stream));
+                HIPCHK(hipMemcpyAsync(ref->tile_c.p, tc.data(), tc.size() * sizeof(int), hipMemcpyHostToDevice, cur_stream()));
                 int px = 0, py = 0;
                 const size_t tot = (size_t)nb * HS;
                 for (int t = 0; t < ntiles; t++) {
                     const int dcx = tc[t] - px, dcy = tc[ntiles + t] - py;
-                    if (dcx || dcy) hipLaunchKernelGGL(k_wp_ramp, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, g.stream, ref->Wp.p, tot, gm.Bs, gm.Ns, dcx, dcy, ref->twN.p);
+                    if (dcx || dcy) hipLaunchKernelGGL(k_wp_ramp, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, cur_stream(), ref->Wp.p, tot, gm.Bs, gm.Ns, dcx, dcy, ref->twN.p);
                     px = tc[t]; py = tc[ntiles + t];
                     GP.hits = ref->hits_t.p + (size_t)t * nb * K;
                     if (int rc = launch_global(GP, nb, gm.half != 0, Rwin)) return rc;
                 }
                 GP.hits = ref->hits.p;
-                hipLaunchKernelGGL(k_merge_hits, dim3((nb + 127) / 128), dim3(128), 0, g.stream, ref->hits_t.p, ref->hits.p, nb, K, ntiles, ref->tile_c.p, ref->tile_c.p + ntiles);
-                HIPCHK(hipStreamSynchronize(g.stream));      // the host vector of the centres goes out of scope
+                hipLaunchKernelGGL(k_merge_hits, dim3((nb + 127) / 128), dim3(128), 0, cur_stream(), ref->hits_t.p, ref->hits.p, nb, K, ntiles, ref->tile_c.p, ref->tile_c.p + ntiles);
+                HIPCHK(hipStreamSynchronize(cur_stream()));      // the host vector of the centres goes out of scope
             }
             {
                 ProfScope ps(PPM_K_TOPK);
-                hipLaunchKernelGGL(k_states_from_hits, dim3((nb * K + 255) / 256), dim3(256), 0, g.stream, ref->hits.p, ref->states.p, nb, K,
+                hipLaunchKernelGGL(k_states_from_hits, dim3((nb * K + 255) / 256), dim3(256), 0, cur_stream(), ref->hits.p, ref->states.p, nb, K,
                                    ref->dir_theta.p, ref->dir_phi.p, gm.n_psi, gm.dpsi, gm.step, 0.5 * gm.dstep, gm.step);
             }
             sample_evals = 0;
@@ -789,28 +817,28 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
                 fill_schedule(0.5 * gm.dstep, gm.step, 0, Tb, gm.r_s, (double)K);
                 ProfScope ps(PPM_K_LOCAL);
                 // 128-thread blocks for the hit stage (<= ~800 samples per sweep: two waves waste less on the serial steps), 256 below
-                hipLaunchKernelGGL(k_local, dim3(nb * K), dim3(128), ring_lds_bytes(2, kMaxCand, LP.nr), g.stream, LP);
+                hipLaunchKernelGGL(k_local, dim3(nb * K), dim3(128), ring_lds_bytes(2, kMaxCand, LP.nr), cur_stream(), LP);
             }
             {
                 ProfScope ps(PPM_K_TOPK);
-                hipLaunchKernelGGL(k_select_best, dim3((nb + 255) / 256), dim3(256), 0, g.stream, ref->states.p, ref->states2.p, nb, K);
+                hipLaunchKernelGGL(k_select_best, dim3((nb + 255) / 256), dim3(256), 0, cur_stream(), ref->states.p, ref->states2.p, nb, K);
             }
             {
                 LP.states = ref->states2.p; LP.T = cfg->local_refine ? Tc : 0; LP.final_rescore = 1; LP.nr = nrings;
                 fill_schedule(0.5 * gm.dstep / (double)(1 << Tb), gm.step / (double)(1 << Tb), Tb, LP.T, gm.r_hi, 1.0);
                 sample_evals += std::floor(kPi * gm.r_hi * gm.r_hi / 2);
                 ProfScope ps(PPM_K_LOCAL);
-                hipLaunchKernelGGL(k_local, dim3(nb), dim3(256), ring_lds_bytes(4, kMaxCand, LP.nr), g.stream, LP);
+                hipLaunchKernelGGL(k_local, dim3(nb), dim3(256), ring_lds_bytes(4, kMaxCand, LP.nr), cur_stream(), LP);
             }
         } else {
             double ha0 = cfg->local_angle_step > 0 ? cfg->local_angle_step : 2.5, hs0 = cfg->local_shift_step > 0 ? cfg->local_shift_step : 2.0;
-            hipLaunchKernelGGL(k_states_from_rows, dim3((nb + 255) / 256), dim3(256), 0, g.stream, ref->rows_in.p, ref->states2.p, nb, gm.a, ha0, hs0);
+            hipLaunchKernelGGL(k_states_from_rows, dim3((nb + 255) / 256), dim3(256), 0, cur_stream(), ref->rows_in.p, ref->states2.p, nb, gm.a, ha0, hs0);
             sample_evals = 0;
             LP.states = ref->states2.p; LP.T = cfg->local_refine ? Tb + Tc : 0; LP.final_rescore = 1; LP.nr = nrings;
             fill_schedule(ha0, hs0, 0, LP.T, gm.r_hi, 1.0);
             sample_evals += std::floor(kPi * gm.r_hi * gm.r_hi / 2);
             ProfScope ps(PPM_K_LOCAL);
-            hipLaunchKernelGGL(k_local, dim3(nb), dim3(256), ring_lds_bytes(4, kMaxCand, LP.nr), g.stream, LP);
+            hipLaunchKernelGGL(k_local, dim3(nb), dim3(256), ring_lds_bytes(4, kMaxCand, LP.nr), cur_stream(), LP);
         }
         const float *d_ddef = nullptr;
         if (ndef > 0) {                                 // defocus offsets at the final pose
@@ -822,19 +850,19 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
             const int T = 2 * ndef + 1;
             DP.tchunk = std::max(1, std::min(T, (int)(60000 / (16 * (size_t)nrings))));      // per-wave ring tables of one pass stay below 64 KB
             ProfScope ps(PPM_K_LOCAL);
-            hipLaunchKernelGGL(k_defocus, dim3(nb), dim3(256), ring_lds_bytes(4, DP.tchunk, nrings), g.stream, DP);
+            hipLaunchKernelGGL(k_defocus, dim3(nb), dim3(256), ring_lds_bytes(4, DP.tchunk, nrings), cur_stream(), DP);
             d_ddef = ref->ddef.p;
         }
-        hipLaunchKernelGGL(k_rows_out, dim3((nb + 255) / 256), dim3(256), 0, g.stream, final_states, ref->rows_in.p, ref->rows_out.p, nb, gm.a, gm.r_hi, gm.r_lo, d_ddef);
+        hipLaunchKernelGGL(k_rows_out, dim3((nb + 255) / 256), dim3(256), 0, cur_stream(), final_states, ref->rows_in.p, ref->rows_out.p, nb, gm.a, gm.r_hi, gm.r_lo, d_ddef);
         HIPCHK(hipGetLastError());
         if (!images_on_device && c0 + CH < n_img) {     // next chunk's images travel while this chunk computes
             const int nn = std::min(CH, n_img - (c0 + CH));
             HIPCHK(hipMemcpyAsync(ref->images.p + (size_t)((ci + 1) & 1) * CH * NN, (const float *)images + (size_t)(c0 + CH) * NN,
-                                  (size_t)nn * NN * sizeof(float), hipMemcpyHostToDevice, g.copy));
+                                  (size_t)nn * NN * sizeof(float), hipMemcpyHostToDevice, cur_copy()));
         }
-        HIPCHK(hipMemcpyAsync(rows_out + (size_t)c0 * PPM_NCOL, ref->rows_out.p, (size_t)nb * PPM_NCOL * sizeof(double), hipMemcpyDeviceToHost, g.stream));
-        HIPCHK(hipStreamSynchronize(g.stream));
-        HIPCHK(hipStreamSynchronize(g.copy));
+        HIPCHK(hipMemcpyAsync(rows_out + (size_t)c0 * PPM_NCOL, ref->rows_out.p, (size_t)nb * PPM_NCOL * sizeof(double), hipMemcpyDeviceToHost, cur_stream()));
+        HIPCHK(hipStreamSynchronize(cur_stream()));
+        HIPCHK(hipStreamSynchronize(cur_copy()));
     }
     // evaluation counts per particle, for the roofline's algorithmic bytes
     long nl;
@@ -868,6 +896,8 @@ ppm_accum_t *ppm_accum_create(int box, float pixel_size, const char *symmetry, v
     if (!box_ok(box) || !(pixel_size > 0)) { fail(-22, "box must be even, 32..512, with prime factors 2, 3, 5, and the pixel size positive"); return nullptr; }
     std::unique_ptr<ppm_accum, void (*)(ppm_accum_t *)> guard(new ppm_accum(), ppm_accum_destroy);      // freed on every error return
     ppm_accum *a = guard.get();
+    HIPCHKP(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
+    HIPCHKP(hipStreamCreateWithFlags(&a->copy, hipStreamNonBlocking));
     a->N = box; a->pixel = pixel_size;
     a->nsym = symmetry_ops(symmetry, a->symops);
     if (a->nsym < 1) { fail(-22, std::string("unknown symmetry symbol '") + (symmetry ? symmetry : "") + "'"); return nullptr; }
@@ -884,6 +914,7 @@ ppm_accum_t *ppm_accum_create(int box, float pixel_size, const char *symmetry, v
     HIPCHKP(hipMemset(a->d_counts, 0, 2 * sizeof(unsigned long long)));
     HIPCHKP(hipMalloc(&a->d_max, 2 * sizeof(unsigned)));
     static bool attr_set = false;
+    std::lock_guard<std::mutex> lk_attr(g_mu);
     if (!attr_set) { HIPCHKP(hipFuncSetAttribute((const void *)k_insert_bricks<16, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 17 * (17 * 52 + 3) * 8)); attr_set = true; }
     return guard.release();
 }
@@ -895,12 +926,15 @@ void ppm_accum_destroy(ppm_accum_t *a) {
     if (a->d_counts) (void)hipFree(a->d_counts);
     if (a->d_max) (void)hipFree(a->d_max);
     a->rows.release(); a->images.release(); a->dose.release(); a->band.release(); a->pp.release(); a->cull.release(); a->items.release();
+    if (a->stream) (void)hipStreamDestroy(a->stream);
+    if (a->copy) (void)hipStreamDestroy(a->copy);
     delete a;
 }
 
 int ppm_insert_batch(ppm_accum_t *a, const ppm_recon_cfg *cfg, const void *images, int images_on_device, int n_img, const double *rows) {
     if (!g.inited) return fail(-1, "ppm_init has not been called");
     if (!a || !cfg || !images || !rows) return fail(-22, "null argument");
+    StreamScope ss_(a->stream, a->copy);
     if (cfg->box != a->N) return fail(-22, "box differs from the accumulator's");
     if (n_img <= 0) return 0;
     ppm_refine_cfg rc; std::memset(&rc, 0, sizeof(rc));
@@ -919,27 +953,27 @@ int ppm_insert_batch(ppm_accum_t *a, const ppm_recon_cfg *cfg, const void *image
     float dose_cap2 = 1.f;
     if (cfg->dose_weights && cfg->n_dose_weights > 0 && cfg->dose_exponent > 0) {
         if (int r = a->dose.ensure(cfg->n_dose_weights)) return r;
-        HIPCHK(hipMemcpyAsync(a->dose.p, cfg->dose_weights, (size_t)cfg->n_dose_weights * sizeof(float), hipMemcpyHostToDevice, g.stream));
+        HIPCHK(hipMemcpyAsync(a->dose.p, cfg->dose_weights, (size_t)cfg->n_dose_weights * sizeof(float), hipMemcpyHostToDevice, cur_stream()));
         d_dose = a->dose.p;
         const float tr = cfg->dose_transition > 0 && cfg->dose_transition <= 1 ? cfg->dose_transition : 1.f;
         dose_cap2 = (tr * gm.N / 2) * (tr * gm.N / 2);
     }
     if (!images_on_device) {
-        HIPCHK(hipMemcpyAsync(a->images.p, images, (size_t)std::min(CH, n_img) * NN * sizeof(float), hipMemcpyHostToDevice, g.copy));
-        HIPCHK(hipStreamSynchronize(g.copy));
+        HIPCHK(hipMemcpyAsync(a->images.p, images, (size_t)std::min(CH, n_img) * NN * sizeof(float), hipMemcpyHostToDevice, cur_copy()));
+        HIPCHK(hipStreamSynchronize(cur_copy()));
     }
     for (int c0 = 0, ci = 0; c0 < n_img; c0 += CH, ci++) {
         const int nb = std::min(CH, n_img - c0);
-        HIPCHK(hipMemcpyAsync(a->rows.p, rows + (size_t)c0 * PPM_NCOL, (size_t)nb * PPM_NCOL * sizeof(double), hipMemcpyHostToDevice, g.stream));
+        HIPCHK(hipMemcpyAsync(a->rows.p, rows + (size_t)c0 * PPM_NCOL, (size_t)nb * PPM_NCOL * sizeof(double), hipMemcpyHostToDevice, cur_stream()));
         const float *d_img = images_on_device ? (const float *)images + (size_t)c0 * NN : a->images.p + (size_t)(ci & 1) * CH * NN;
         // the chunk's value bounds ([0] max |band| from k_prep, [1] max weight from k_insert_params) scale the fixed point
-        HIPCHK(hipMemsetAsync(a->d_max, 0, 2 * sizeof(unsigned), g.stream));
+        HIPCHK(hipMemsetAsync(a->d_max, 0, 2 * sizeof(unsigned), cur_stream()));
         if (int prc = launch_prep(d_img, a->rows.p, nb, gm, cfg->mask_radius / cfg->pixel_size, 1.f, cfg->normalize, cfg->invert, 0, 0,
                                   a->band.p, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, a->d_max)) return prc;
         // per-particle constants, then one block per (brick, particle slice, half)
         if (int r = a->pp.ensure(nb)) return r;
         if (int r = a->cull.ensure((size_t)nb * a->nsym)) return r;
-        hipLaunchKernelGGL(k_insert_params, dim3((nb + 255) / 256), dim3(256), 0, g.stream, a->rows.p, a->pp.p, a->cull.p, a->d_sym, a->nsym, nb, gm.N, (double)cfg->pixel_size,
+        hipLaunchKernelGGL(k_insert_params, dim3((nb + 255) / 256), dim3(256), 0, cur_stream(), a->rows.p, a->pp.p, a->cull.p, a->d_sym, a->nsym, nb, gm.N, (double)cfg->pixel_size,
                            (double)cfg->score_weight_bfactor, (double)cfg->score_average, (double)cfg->score_threshold, cfg->split_by_pind,
                            gm.r_hi * gm.r_hi, a->d_counts, a->d_max, d_dose, cfg->n_dose_weights, cfg->dose_exponent, dose_cap2);
         const int BE = gm.N >= 128 ? 16 : 8;
@@ -951,17 +985,17 @@ int ppm_insert_batch(ppm_accum_t *a, const ppm_recon_cfg *cfg, const void *image
         {
             ProfScope ps(PPM_K_INSERT);
             dim3 grid((unsigned)a->n_items, 2);
-            if (BE == 16) hipLaunchKernelGGL((k_insert_bricks<16, 16>), grid, dim3(1024), 17 * (17 * 52 + 3) * sizeof(long long), g.stream, IP);
-            else hipLaunchKernelGGL((k_insert_bricks<8, 4>), grid, dim3(256), 9 * (9 * 28 + 3) * sizeof(long long), g.stream, IP);
+            if (BE == 16) hipLaunchKernelGGL((k_insert_bricks<16, 16>), grid, dim3(1024), 17 * (17 * 52 + 3) * sizeof(long long), cur_stream(), IP);
+            else hipLaunchKernelGGL((k_insert_bricks<8, 4>), grid, dim3(256), 9 * (9 * 28 + 3) * sizeof(long long), cur_stream(), IP);
         }
         HIPCHK(hipGetLastError());
         if (!images_on_device && c0 + CH < n_img) {
             const int nn = std::min(CH, n_img - (c0 + CH));
             HIPCHK(hipMemcpyAsync(a->images.p + (size_t)((ci + 1) & 1) * CH * NN, (const float *)images + (size_t)(c0 + CH) * NN,
-                                  (size_t)nn * NN * sizeof(float), hipMemcpyHostToDevice, g.copy));
+                                  (size_t)nn * NN * sizeof(float), hipMemcpyHostToDevice, cur_copy()));
         }
-        HIPCHK(hipStreamSynchronize(g.stream));
-        HIPCHK(hipStreamSynchronize(g.copy));
+        HIPCHK(hipStreamSynchronize(cur_stream()));
+        HIPCHK(hipStreamSynchronize(cur_copy()));
     }
     unsigned long long c[2];
     HIPCHK(hipMemcpy(c, a->d_counts, sizeof(c), hipMemcpyDeviceToHost));
@@ -979,20 +1013,22 @@ void ppm_accum_set_count(ppm_accum_t *a, int half, long count) {
 
 int ppm_accum_download(ppm_accum_t *a, float *host) {
     if (!a || !host) return fail(-22, "null argument");
-    HIPCHK(hipStreamSynchronize(g.stream));
+    StreamScope ss_(a->stream, a->copy);
+    HIPCHK(hipStreamSynchronize(cur_stream()));
     HIPCHK(hipMemcpy(host, a->acc, ppm_accum_floats(a->N) * sizeof(float), hipMemcpyDeviceToHost));
     return 0;
 }
 
 int ppm_accum_add(ppm_accum_t *a, const float *host) {
     if (!a || !host) return fail(-22, "null argument");
+    StreamScope ss_(a->stream, a->copy);
     size_t nf = ppm_accum_floats(a->N);
     DevTmp<float> tmp;
     HIPCHK(tmp.alloc(nf));
     HIPCHK(hipMemcpy(tmp.p, host, nf * sizeof(float), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_axpy, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, g.stream, a->acc, tmp.p, nf);
+    hipLaunchKernelGGL(k_axpy, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, cur_stream(), a->acc, tmp.p, nf);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(g.stream));
+    HIPCHK(hipStreamSynchronize(cur_stream()));
     return 0;
 }
 
@@ -1058,23 +1094,24 @@ void ppm_comm_destroy(void *comm) {
 int ppm_accum_reduce(ppm_accum_t *a, void *comm, int root) {
     if (!g.inited) return fail(-1, "ppm_init has not been called");
     if (!a || !comm) return fail(-22, "null argument");
+    StreamScope ss_(a->stream, a->copy);
     Rccl &r = rccl();
     if (!r.err.empty()) return fail(-38, r.err);
     const size_t nf = ppm_accum_floats(a->N);
     // the particle counters travel with the sums: brought up to date on the device, reduced as two int64
     unsigned long long c[2] = { (unsigned long long)a->counts[0], (unsigned long long)a->counts[1] };
-    HIPCHK(hipMemcpyAsync(a->d_counts, c, sizeof(c), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemcpyAsync(a->d_counts, c, sizeof(c), hipMemcpyHostToDevice, cur_stream()));
     int rc;
     if (root < 0) {
-        rc = r.AllReduce(a->acc, a->acc, nf, kNcclFloat32, kNcclSum, comm, g.stream);
-        if (!rc) rc = r.AllReduce(a->d_counts, a->d_counts, 2, kNcclInt64, kNcclSum, comm, g.stream);
+        rc = r.AllReduce(a->acc, a->acc, nf, kNcclFloat32, kNcclSum, comm, cur_stream());
+        if (!rc) rc = r.AllReduce(a->d_counts, a->d_counts, 2, kNcclInt64, kNcclSum, comm, cur_stream());
     } else {
-        rc = r.Reduce(a->acc, a->acc, nf, kNcclFloat32, kNcclSum, root, comm, g.stream);
-        if (!rc) rc = r.Reduce(a->d_counts, a->d_counts, 2, kNcclInt64, kNcclSum, root, comm, g.stream);
+        rc = r.Reduce(a->acc, a->acc, nf, kNcclFloat32, kNcclSum, root, comm, cur_stream());
+        if (!rc) rc = r.Reduce(a->d_counts, a->d_counts, 2, kNcclInt64, kNcclSum, root, comm, cur_stream());
     }
     if (rc) return rccl_fail(r, rc, root < 0 ? "ncclAllReduce" : "ncclReduce");
-    HIPCHK(hipMemcpyAsync(c, a->d_counts, sizeof(c), hipMemcpyDeviceToHost, g.stream));
-    HIPCHK(hipStreamSynchronize(g.stream));
+    HIPCHK(hipMemcpyAsync(c, a->d_counts, sizeof(c), hipMemcpyDeviceToHost, cur_stream()));
+    HIPCHK(hipStreamSynchronize(cur_stream()));
     a->counts[0] = (long)c[0]; a->counts[1] = (long)c[1];      // on ranks other than a root the values are undefined, as ncclReduce leaves them
     return 0;
 }
@@ -1095,22 +1132,23 @@ int ppm_extract_boxes(const void *image, int image_on_device, int rows, int cols
     if (out_on_device) d_out = (float *)out; else { HIPCHK(t_out.alloc(nout)); d_out = t_out.p; }
     HIPCHK(t_xy.alloc((size_t)m * 2));
     double *d_xy = t_xy.p;
-    HIPCHK(hipMemcpyAsync(d_xy, coords, (size_t)m * 2 * sizeof(double), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemcpyAsync(d_xy, coords, (size_t)m * 2 * sizeof(double), hipMemcpyHostToDevice, cur_stream()));
     ExtractP P; P.image = d_img; P.rows = rows; P.cols = cols; P.coords = d_xy; P.box = box; P.cbin = coordinate_binning;
     P.radius2 = (float)(radius_px * radius_px); P.normalize = normalize; P.fix_empty = fix_empty; P.out = d_out;
     {
         ProfScope ps(PPM_K_EXTRACT);
-        hipLaunchKernelGGL(k_extract, dim3(m), dim3(256), 0, g.stream, P);
+        hipLaunchKernelGGL(k_extract, dim3(m), dim3(256), 0, cur_stream(), P);
     }
     HIPCHK(hipGetLastError());
-    if (!out_on_device) HIPCHK(hipMemcpyAsync(out, d_out, nout * sizeof(float), hipMemcpyDeviceToHost, g.stream));
-    HIPCHK(hipStreamSynchronize(g.stream));
+    if (!out_on_device) HIPCHK(hipMemcpyAsync(out, d_out, nout * sizeof(float), hipMemcpyDeviceToHost, cur_stream()));
+    HIPCHK(hipStreamSynchronize(cur_stream()));
     return 0;
 }
 
 int ppm_finalize(ppm_accum_t *a, const ppm_final_cfg *cfg, float *half1, float *half2, float *filtered, double *stats) {
     if (!g.inited) return fail(-1, "ppm_init has not been called");
     if (!a || !cfg) return fail(-22, "null argument");
+    StreamScope ss_(a->stream, a->copy);
     const int N = a->N, ns = N / 2;
     const double px = a->pixel;
     const size_t nf = ppm_accum_floats(N), n3 = (size_t)N * N * N, tot = (size_t)N * N * (N / 2 + 1);
@@ -1119,16 +1157,16 @@ int ppm_finalize(ppm_accum_t *a, const ppm_final_cfg *cfg, float *half1, float *
     HIPCHK(t_s.alloc((size_t)8 * ns));
     float *tmp = t_tmp.p; double *d_s = t_s.p;
     HIPCHK(hipMemset(d_s, 0, 8 * ns * sizeof(double)));
-    HIPCHK(hipMemcpyAsync(tmp, a->acc, nf * sizeof(float), hipMemcpyDeviceToDevice, g.stream));
+    HIPCHK(hipMemcpyAsync(tmp, a->acc, nf * sizeof(float), hipMemcpyDeviceToDevice, cur_stream()));
     {
     ProfScope ps(PPM_K_FINAL);
-    hipLaunchKernelGGL(k_fold_plane, dim3((unsigned)(((size_t)2 * N * N + 255) / 256)), dim3(256), 0, g.stream, a->acc, tmp, N);
-    hipLaunchKernelGGL(k_shell_den, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, g.stream, tmp, d_s, N);
-    hipLaunchKernelGGL(k_shell_fsc, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, g.stream, tmp, d_s, d_s + 4 * ns, N);
+    hipLaunchKernelGGL(k_fold_plane, dim3((unsigned)(((size_t)2 * N * N + 255) / 256)), dim3(256), 0, cur_stream(), a->acc, tmp, N);
+    hipLaunchKernelGGL(k_shell_den, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, cur_stream(), tmp, d_s, N);
+    hipLaunchKernelGGL(k_shell_fsc, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, cur_stream(), tmp, d_s, d_s + 4 * ns, N);
     }
     std::vector<double> hs(8 * ns);
-    HIPCHK(hipMemcpyAsync(hs.data(), d_s, 8 * ns * sizeof(double), hipMemcpyDeviceToHost, g.stream));
-    HIPCHK(hipStreamSynchronize(g.stream));
+    HIPCHK(hipMemcpyAsync(hs.data(), d_s, 8 * ns * sizeof(double), hipMemcpyDeviceToHost, cur_stream()));
+    HIPCHK(hipStreamSynchronize(cur_stream()));
     double vfrac = cfg->molecular_mass_kda > 0 ? (cfg->molecular_mass_kda * 1000.0 / 0.81) / std::pow(N * px, 3.0) : 1.0;
     vfrac = std::min(1.0, std::max(1e-6, vfrac));
     std::vector<double> kap(ns);
@@ -1155,14 +1193,14 @@ int ppm_finalize(ppm_accum_t *a, const ppm_final_cfg *cfg, float *half1, float *
         if (!outs[which]) continue;
         {
             ProfScope p2(PPM_K_FINAL);
-            HIPCHK(hipMemsetAsync(d_f, 0, n3 * sizeof(float2), g.stream));
-            hipLaunchKernelGGL(k_wiener, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, g.stream, tmp, d_s, d_f, N, which);
+            HIPCHK(hipMemsetAsync(d_f, 0, n3 * sizeof(float2), cur_stream()));
+            hipLaunchKernelGGL(k_wiener, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, cur_stream(), tmp, d_s, d_f, N, which);
             if (int rc = fft3d(d_f, N, true)) return rc;
-            hipLaunchKernelGGL(k_map_post, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, g.stream, d_f, d_out, N, rout, rin, fo);
+            hipLaunchKernelGGL(k_map_post, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, cur_stream(), d_f, d_out, N, rout, rin, fo);
         }
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(outs[which], d_out, n3 * sizeof(float), hipMemcpyDeviceToHost, g.stream));
-        HIPCHK(hipStreamSynchronize(g.stream));
+        HIPCHK(hipMemcpyAsync(outs[which], d_out, n3 * sizeof(float), hipMemcpyDeviceToHost, cur_stream()));
+        HIPCHK(hipStreamSynchronize(cur_stream()));
     }
     return 0;
 }
@@ -1188,6 +1226,7 @@ extern "C" int ppm_csp_refine(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const p
                               int n_proj, double *rows, double *particles, int n_part, double *tilts, int n_tilt) {
     if (!g.inited) return fail(-1, "ppm_init has not been called");
     if (!ref || !cfg || !cc || !images || !rows || !particles || !tilts) return fail(-22, "null argument");
+    StreamScope ss_(ref->stream, ref->copy);
     if (cc->unit != PPM_CSP_PARTICLES && cc->unit != PPM_CSP_MICROGRAPHS) return fail(-22, "csp: unit must be particles (1) or micrographs (2)");
     if (n_proj <= 0) return 0;
     if (n_part <= 0 || n_tilt <= 0) return fail(-22, "csp: the extended parameters hold no particles or no tilts");
@@ -1287,7 +1326,7 @@ extern "C" int ppm_csp_refine(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const p
     auto prefix_of = [&](double rband) { int rg = (int)std::ceil(rband); if (rg > gm.B + 1) rg = gm.B + 1; return sl.ring_off[rg]; };
     const size_t NN = (size_t)gm.N * gm.N, HW = (size_t)gm.H * gm.W;
     if (int rc = ref->samples.ensure(S_pad)) return rc;
-    HIPCHK(hipMemcpyAsync(ref->samples.p, sl.packed.data(), S_pad * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemcpyAsync(ref->samples.p, sl.packed.data(), S_pad * sizeof(uint32_t), hipMemcpyHostToDevice, cur_stream()));
     // scratch of the constrained search lives in the reference handle (grown on demand, freed with it): allocating and freeing
     // several hundred MB per call cost a third of a call on a 20 k-projection series
     DevBuf<float2> &Il = ref->c_Il, &band = ref->c_band; DevBuf<float> &cw = ref->c_cw, &img = ref->c_img, &wring = ref->c_wring;
@@ -1303,18 +1342,18 @@ extern "C" int ppm_csp_refine(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const p
     if (int rc = d_rows.ensure((size_t)n_proj * PPM_NCOL)) return rc;
     if (mode4) if (int rc = wring.ensure((size_t)n_proj * (gm.B + 2))) return rc;
     if (!images_on_device) if (int rc = img.ensure((size_t)CH * NN)) return rc;
-    HIPCHK(hipMemcpyAsync(d_rows.p, rows, (size_t)n_proj * PPM_NCOL * sizeof(double), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemcpyAsync(d_rows.p, rows, (size_t)n_proj * PPM_NCOL * sizeof(double), hipMemcpyHostToDevice, cur_stream()));
     const double fall = cfg->mask_falloff > 0 ? cfg->mask_falloff : 20.0;
     for (int c0 = 0; c0 < n_proj; c0 += CH) {
         const int nb = std::min(CH, n_proj - c0);
         const float *d_img = (const float *)images + (size_t)c0 * NN;
         if (!images_on_device) {
-            HIPCHK(hipMemcpyAsync(img.p, (const float *)images + (size_t)c0 * NN, (size_t)nb * NN * sizeof(float), hipMemcpyHostToDevice, g.stream));
+            HIPCHK(hipMemcpyAsync(img.p, (const float *)images + (size_t)c0 * NN, (size_t)nb * NN * sizeof(float), hipMemcpyHostToDevice, cur_stream()));
             d_img = img.p;
         }
         if (int rc = launch_prep(d_img, d_rows.p + (size_t)c0 * PPM_NCOL, nb, gm, (float)rm_px, (float)(fall / gm.a), cfg->normalize, cfg->invert, 1, 1,
                                  band.p, mode4 ? wring.p + (size_t)c0 * (gm.B + 2) : nullptr, ref->samples.p, S_pad, Il.p + (size_t)c0 * S_pad, cw.p + (size_t)c0 * S_pad, nullptr, nullptr, nullptr)) return rc;
-        HIPCHK(hipStreamSynchronize(g.stream));
+        HIPCHK(hipStreamSynchronize(cur_stream()));
     }
     if (mode4) {
         // ---- csp mode 4: every row's score for every defocus offset in one sweep (k_defocus), averaged per tilt on the host
@@ -1324,7 +1363,7 @@ extern "C" int ppm_csp_refine(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const p
         const int Tn = 2 * nt + 1;
         if (int rc = d_states.ensure(n_proj)) return rc;
         if (int rc = d_out.ensure((size_t)n_proj * Tn)) return rc;
-        hipLaunchKernelGGL(k_states_from_rows, dim3((n_proj + 255) / 256), dim3(256), 0, g.stream, d_rows.p, d_states.p, n_proj, gm.a, 1.0, 1.0);
+        hipLaunchKernelGGL(k_states_from_rows, dim3((n_proj + 255) / 256), dim3(256), 0, cur_stream(), d_rows.p, d_states.p, n_proj, gm.a, 1.0, 1.0);
         DefocusP DP;
         DP.cv.cube = ref->cube; DP.cv.NBX = ref->NBX; DP.cv.NBY = ref->NBY; DP.cv.LB = ref->LB; DP.cv.off = ref->B + 1; DP.cv.scale = (float)ref->pad;
         DP.samples = ref->samples.p; DP.Il = Il.p; DP.wring = wring.p; DP.S_pad = S_pad; DP.nrings = nrings; DP.N = gm.N; DP.B = gm.B;
@@ -1333,12 +1372,12 @@ extern "C" int ppm_csp_refine(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const p
         DP.tchunk = std::max(1, std::min(Tn, (int)(60000 / (16 * (size_t)nrings))));
         {
             ProfScope ps(PPM_K_LOCAL);
-            hipLaunchKernelGGL(k_defocus, dim3(n_proj), dim3(256), ring_lds_bytes(4, DP.tchunk, nrings), g.stream, DP);
+            hipLaunchKernelGGL(k_defocus, dim3(n_proj), dim3(256), ring_lds_bytes(4, DP.tchunk, nrings), cur_stream(), DP);
         }
         HIPCHK(hipGetLastError());
         std::vector<double> sc((size_t)n_proj * Tn);
-        HIPCHK(hipMemcpyAsync(sc.data(), d_out.p, sc.size() * sizeof(double), hipMemcpyDeviceToHost, g.stream));
-        HIPCHK(hipStreamSynchronize(g.stream));
+        HIPCHK(hipMemcpyAsync(sc.data(), d_out.p, sc.size() * sizeof(double), hipMemcpyDeviceToHost, cur_stream()));
+        HIPCHK(hipStreamSynchronize(cur_stream()));
         for (int u = 0; u < n_tilt; u++) {
             if (!refined[u]) continue;
             double best = -1e300; int bt = nt;
@@ -1373,19 +1412,19 @@ extern "C" int ppm_csp_refine(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const p
     if (int rc = d_delta.ensure((size_t)std::max(n_slots, 1) * ncand_max * 6)) return rc;
     if (int rc = d_eval.ensure(std::max(eval_rows.size(), final_rows.size()))) return rc;
     if (int rc = d_out.ensure(std::max(eval_rows.size() * ncand_max, final_rows.size()))) return rc;
-    HIPCHK(hipMemcpyAsync(d_rp.p, row_part.data(), n_proj * sizeof(int), hipMemcpyHostToDevice, g.stream));
-    HIPCHK(hipMemcpyAsync(d_rt.p, row_tilt.data(), n_proj * sizeof(int), hipMemcpyHostToDevice, g.stream));
-    HIPCHK(hipMemcpyAsync(d_slot.p, unit_slot.data(), nu_all * sizeof(int), hipMemcpyHostToDevice, g.stream));
-    HIPCHK(hipMemcpyAsync(d_s0.p, s0.data(), s0.size() * sizeof(double), hipMemcpyHostToDevice, g.stream));
-    HIPCHK(hipMemcpyAsync(d_g0.p, g0.data(), g0.size() * sizeof(double), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemcpyAsync(d_rp.p, row_part.data(), n_proj * sizeof(int), hipMemcpyHostToDevice, cur_stream()));
+    HIPCHK(hipMemcpyAsync(d_rt.p, row_tilt.data(), n_proj * sizeof(int), hipMemcpyHostToDevice, cur_stream()));
+    HIPCHK(hipMemcpyAsync(d_slot.p, unit_slot.data(), nu_all * sizeof(int), hipMemcpyHostToDevice, cur_stream()));
+    HIPCHK(hipMemcpyAsync(d_s0.p, s0.data(), s0.size() * sizeof(double), hipMemcpyHostToDevice, cur_stream()));
+    HIPCHK(hipMemcpyAsync(d_g0.p, g0.data(), g0.size() * sizeof(double), hipMemcpyHostToDevice, cur_stream()));
     std::vector<double> hN((size_t)9 * n_part), hp((size_t)3 * n_part), htl((size_t)4 * n_tilt);
     auto upload_units = [&]() -> int {
         for (int i = 0; i < n_part; i++) { std::memcpy(&hN[(size_t)9 * i], parts[i].N, 9 * sizeof(double)); std::memcpy(&hp[(size_t)3 * i], parts[i].p, 3 * sizeof(double)); }
         for (int i = 0; i < n_tilt; i++) std::memcpy(&htl[(size_t)4 * i], tls[i].tl, 4 * sizeof(double));
-        HIPCHK(hipMemcpyAsync(d_N.p, hN.data(), hN.size() * sizeof(double), hipMemcpyHostToDevice, g.stream));
-        HIPCHK(hipMemcpyAsync(d_p.p, hp.data(), hp.size() * sizeof(double), hipMemcpyHostToDevice, g.stream));
-        HIPCHK(hipMemcpyAsync(d_tl.p, htl.data(), htl.size() * sizeof(double), hipMemcpyHostToDevice, g.stream));
-        HIPCHK(hipStreamSynchronize(g.stream));
+        HIPCHK(hipMemcpyAsync(d_N.p, hN.data(), hN.size() * sizeof(double), hipMemcpyHostToDevice, cur_stream()));
+        HIPCHK(hipMemcpyAsync(d_p.p, hp.data(), hp.size() * sizeof(double), hipMemcpyHostToDevice, cur_stream()));
+        HIPCHK(hipMemcpyAsync(d_tl.p, htl.data(), htl.size() * sizeof(double), hipMemcpyHostToDevice, cur_stream()));
+        HIPCHK(hipStreamSynchronize(cur_stream()));
         return 0;
     };
     CspEvalP EP;
@@ -1400,33 +1439,33 @@ extern "C" int ppm_csp_refine(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const p
     for (size_t a = 0; a < active.size(); a++) { int n = 0; for (int j : urows[active[a]]) n += usable[j] ? 1 : 0; uoff[a + 1] = uoff[a] + n; }
     if (int rc = ref->c_uoff.ensure(uoff.size())) return rc;
     if (int rc = ref->c_mean.ensure(std::max<size_t>(active.size() * ncand_max, 1))) return rc;
-    HIPCHK(hipMemcpyAsync(ref->c_uoff.p, uoff.data(), uoff.size() * sizeof(int), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemcpyAsync(ref->c_uoff.p, uoff.data(), uoff.size() * sizeof(int), hipMemcpyHostToDevice, cur_stream()));
     const std::vector<int> *uploaded_list = nullptr;
     // one sweep: `ncand` candidates per unit (hdelta laid out [slot][ncand][6]) over `rows_list`.  unit_means: the per-unit means of
     // the scores -> `means` [active unit][ncand] (reduced on the device); otherwise the per-row scores -> hout [row][ncand]
     auto sweep = [&](const std::vector<int> &rows_list, int ncand, double rband, std::vector<double> *means) -> int {
-        HIPCHK(hipMemcpyAsync(d_delta.p, hdelta.data(), (size_t)n_slots * ncand * 6 * sizeof(double), hipMemcpyHostToDevice, g.stream));
+        HIPCHK(hipMemcpyAsync(d_delta.p, hdelta.data(), (size_t)n_slots * ncand * 6 * sizeof(double), hipMemcpyHostToDevice, cur_stream()));
         if (uploaded_list != &rows_list) {
-            HIPCHK(hipMemcpyAsync(d_eval.p, rows_list.data(), rows_list.size() * sizeof(int), hipMemcpyHostToDevice, g.stream));
+            HIPCHK(hipMemcpyAsync(d_eval.p, rows_list.data(), rows_list.size() * sizeof(int), hipMemcpyHostToDevice, cur_stream()));
             uploaded_list = &rows_list;
         }
         EP.ncand = ncand; EP.S_used = prefix_of(rband); EP.rmax2 = (float)(rband * rband);
         {
             ProfScope ps(PPM_K_LOCAL);
-            hipLaunchKernelGGL(k_csp_eval, dim3((unsigned)rows_list.size()), dim3(256), ring_lds_bytes(4, kMaxCand, nrings), g.stream, EP);
+            hipLaunchKernelGGL(k_csp_eval, dim3((unsigned)rows_list.size()), dim3(256), ring_lds_bytes(4, kMaxCand, nrings), cur_stream(), EP);
         }
         if (means) {
             const int nm = (int)active.size() * ncand;
-            hipLaunchKernelGGL(k_csp_unit_means, dim3((nm + 255) / 256), dim3(256), 0, g.stream, d_out.p, ref->c_uoff.p, (int)active.size(), ncand, ref->c_mean.p);
+            hipLaunchKernelGGL(k_csp_unit_means, dim3((nm + 255) / 256), dim3(256), 0, cur_stream(), d_out.p, ref->c_uoff.p, (int)active.size(), ncand, ref->c_mean.p);
             HIPCHK(hipGetLastError());
             means->resize((size_t)nm);
-            HIPCHK(hipMemcpyAsync(means->data(), ref->c_mean.p, (size_t)nm * sizeof(double), hipMemcpyDeviceToHost, g.stream));
+            HIPCHK(hipMemcpyAsync(means->data(), ref->c_mean.p, (size_t)nm * sizeof(double), hipMemcpyDeviceToHost, cur_stream()));
         } else {
             HIPCHK(hipGetLastError());
             hout.resize(rows_list.size() * (size_t)ncand);
-            HIPCHK(hipMemcpyAsync(hout.data(), d_out.p, hout.size() * sizeof(double), hipMemcpyDeviceToHost, g.stream));
+            HIPCHK(hipMemcpyAsync(hout.data(), d_out.p, hout.size() * sizeof(double), hipMemcpyDeviceToHost, cur_stream()));
         }
-        HIPCHK(hipStreamSynchronize(g.stream));
+        HIPCHK(hipStreamSynchronize(cur_stream()));
         return 0;
     };
     if (int rc = upload_units()) return rc;
@@ -1539,6 +1578,7 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
                              double *poses, double *scores) {
     if (!g.inited) return fail(-1, "ppm_init has not been called");
     if (!ref || !cfg || !volumes || !poses) return fail(-22, "null argument");
+    StreamScope ss_(ref->stream, ref->copy);
     if (n_vol <= 0) return 0;
     const int N = cfg->box;
     if (!box_ok(N) || N != ref->N) return fail(-22, "sub-volume box differs from the reference box (even, 32..512, prime factors 2, 3, 5)");
@@ -1645,8 +1685,8 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
     HIPCHK(d_wedges.alloc((size_t)2 * CH));
     const bool two_bufs = !volumes_on_device && n_vol > CH;      // host volumes: the next chunk is uploaded by a helper thread while this one is searched
     if (!volumes_on_device) HIPCHK(d_vols.alloc((size_t)(two_bufs ? 2 : 1) * CH * n3));
-    HIPCHK(hipMemcpyAsync(d_samples.p, samples.data(), (size_t)S * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
-    HIPCHK(hipMemcpyAsync(d_bandw.p, bandw.data(), (size_t)S * sizeof(float), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemcpyAsync(d_samples.p, samples.data(), (size_t)S * sizeof(uint32_t), hipMemcpyHostToDevice, cur_stream()));
+    HIPCHK(hipMemcpyAsync(d_bandw.p, bandw.data(), (size_t)S * sizeof(float), hipMemcpyHostToDevice, cur_stream()));
     SvaWin W; for (int k = 0; k < 3; k++) W.w[k] = cfg->window[k]; W.sigma = cfg->window_sigma;
     SvaEvalP EP;
     EP.cv.cube = ref->cube; EP.cv.NBX = ref->NBX; EP.cv.NBY = ref->NBY; EP.cv.LB = ref->LB; EP.cv.off = ref->B + 1; EP.cv.scale = 1.f;
@@ -1655,8 +1695,8 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
     std::vector<float> hw((size_t)2 * CH);
     std::vector<double> hdelta, hout;
     if (!volumes_on_device) {       // first chunk
-        HIPCHK(hipMemcpyAsync(d_vols.p, volumes, (size_t)std::min(CH, n_vol) * n3 * sizeof(float), hipMemcpyHostToDevice, g.copy));
-        HIPCHK(hipStreamSynchronize(g.copy));
+        HIPCHK(hipMemcpyAsync(d_vols.p, volumes, (size_t)std::min(CH, n_vol) * n3 * sizeof(float), hipMemcpyHostToDevice, cur_copy()));
+        HIPCHK(hipStreamSynchronize(cur_copy()));
     }
     struct Uploader {           // joins on every exit path
         std::thread t; hipError_t err = hipSuccess;
@@ -1675,7 +1715,7 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
                 float *dst = d_vols.p + (size_t)((ci + 1) & 1) * CH * n3;
                 const float *src = (const float *)volumes + (size_t)(c0 + CH) * n3;
                 const size_t bytes = (size_t)nn * n3 * sizeof(float);
-                const int dev = g.device; hipStream_t cs = g.copy;
+                const int dev = g.device; hipStream_t cs = cur_copy();
                 up.err = hipSuccess;
                 up.t = std::thread([&up, dst, src, bytes, dev, cs] {
                     hipError_t e = hipSetDevice(dev);
@@ -1686,11 +1726,11 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
             }
         }
         for (int v = 0; v < nb; v++) { hw[2 * v] = wedges ? wedges[2 * (size_t)(c0 + v)] : -90.f; hw[2 * v + 1] = wedges ? wedges[2 * (size_t)(c0 + v) + 1] : 90.f; }
-        HIPCHK(hipMemcpyAsync(d_wedges.p, hw.data(), (size_t)2 * nb * sizeof(float), hipMemcpyHostToDevice, g.stream));
-        HIPCHK(hipMemsetAsync(d_stats.p, 0, (size_t)2 * nb * sizeof(double), g.stream));
+        HIPCHK(hipMemcpyAsync(d_wedges.p, hw.data(), (size_t)2 * nb * sizeof(float), hipMemcpyHostToDevice, cur_stream()));
+        HIPCHK(hipMemsetAsync(d_stats.p, 0, (size_t)2 * nb * sizeof(double), cur_stream()));
         {
             ProfScope ps(PPM_K_PREP);
-            hipLaunchKernelGGL(k_sva_stats, dim3(64, nb), dim3(256), 0, g.stream, dv, n3, d_stats.p);
+            hipLaunchKernelGGL(k_sva_stats, dim3(64, nb), dim3(256), 0, cur_stream(), dv, n3, d_stats.p);
             if (int rc = ensure_plan(N)) return rc;
             SvaXP XP; XP.stats = nullptr; XP.out = d_f.p; XP.plan = g.plans[N].plan; XP.n = N; XP.KX = KX; XP.nlines = (long)N * N; XP.W = W;
             XP.L = std::max(1, std::min(16, 8192 / N));
@@ -1701,7 +1741,7 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
                 const int m = std::min(NB, nb - v0);
                 const long NN2 = (long)N * N;
                 XP.vol = dv + (size_t)v0 * n3; XP.stats = d_stats.p + 2 * v0; XP.nlines = (long)m * NN2;
-                hipLaunchKernelGGL(k_sva_xpass, dim3((unsigned)((XP.nlines + XP.L - 1) / XP.L)), dim3(256), (size_t)XP.L * N * sizeof(float2), g.stream, XP);
+                hipLaunchKernelGGL(k_sva_xpass, dim3((unsigned)((XP.nlines + XP.L - 1) / XP.L)), dim3(256), (size_t)XP.L * N * sizeof(float2), cur_stream(), XP);
                 if (int rc = fft_lines_pass(d_f.p, N, (long)m * N * KX, KX, 1, (long)N * KX, KX, 1, false)) return rc;
                 if (2 * R + 1 >= N) {
                     if (int rc = fft_lines_pass(d_f.p, N, (long)m * N * KX, (long)N * KX, 1, NN2 * KX, (long)N * KX, 1, false)) return rc;
@@ -1709,7 +1749,7 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
                     if (int rc = fft_lines_pass(d_f.p, N, (long)m * (R + 1) * KX, (long)(R + 1) * KX, 1, NN2 * KX, (long)N * KX, 1, false)) return rc;
                     if (int rc = fft_lines_pass(d_f.p + (size_t)(N - R) * KX, N, (long)m * R * KX, (long)R * KX, 1, NN2 * KX, (long)N * KX, 1, false)) return rc;
                 }
-                hipLaunchKernelGGL(k_sva_gather, dim3((unsigned)((S + 255) / 256), m), dim3(256), 0, g.stream, d_f.p, d_samples.p, S, N, KX, d_F.p + (size_t)v0 * S);
+                hipLaunchKernelGGL(k_sva_gather, dim3((unsigned)((S + 255) / 256), m), dim3(256), 0, cur_stream(), d_f.p, d_samples.p, S, N, KX, d_F.p + (size_t)v0 * S);
             }
         }
         HIPCHK(hipGetLastError());
@@ -1721,19 +1761,19 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
             const int ns_ = (int)S_.size();
             hp.resize((size_t)12 * ns_);
             for (int v = 0; v < ns_; v++) { std::memcpy(&hp[(size_t)12 * v], S_[v].N, 9 * sizeof(double)); std::memcpy(&hp[(size_t)12 * v + 9], S_[v].p, 3 * sizeof(double)); }
-            HIPCHK(hipMemcpyAsync(d_poses.p, hp.data(), hp.size() * sizeof(double), hipMemcpyHostToDevice, g.stream));
-            if (vm) HIPCHK(hipMemcpyAsync(d_vmap.p, vm->data(), vm->size() * sizeof(int), hipMemcpyHostToDevice, g.stream));
+            HIPCHK(hipMemcpyAsync(d_poses.p, hp.data(), hp.size() * sizeof(double), hipMemcpyHostToDevice, cur_stream()));
+            if (vm) HIPCHK(hipMemcpyAsync(d_vmap.p, vm->data(), vm->size() * sizeof(int), hipMemcpyHostToDevice, cur_stream()));
             EP.vmap = vm ? d_vmap.p : nullptr;
             return 0;
         };
         auto sweep = [&](int ns_, int nc, int nr_, double rb) -> int {
-            HIPCHK(hipMemcpyAsync(d_delta.p, hdelta.data(), (size_t)ns_ * nc * 6 * sizeof(double), hipMemcpyHostToDevice, g.stream));
+            HIPCHK(hipMemcpyAsync(d_delta.p, hdelta.data(), (size_t)ns_ * nc * 6 * sizeof(double), hipMemcpyHostToDevice, cur_stream()));
             EP.ncand = nc; EP.nrot = nr_; EP.S_used = prefix_of(rb); EP.rmax2 = (float)(rb * rb);
-            { ProfScope ps(PPM_K_LOCAL); hipLaunchKernelGGL(k_sva_eval, dim3(ns_), dim3(256), 0, g.stream, EP); }
+            { ProfScope ps(PPM_K_LOCAL); hipLaunchKernelGGL(k_sva_eval, dim3(ns_), dim3(256), 0, cur_stream(), EP); }
             HIPCHK(hipGetLastError());
             hout.resize((size_t)ns_ * nc);
-            HIPCHK(hipMemcpyAsync(hout.data(), d_out.p, hout.size() * sizeof(double), hipMemcpyDeviceToHost, g.stream));
-            HIPCHK(hipStreamSynchronize(g.stream));
+            HIPCHK(hipMemcpyAsync(hout.data(), d_out.p, hout.size() * sizeof(double), hipMemcpyDeviceToHost, cur_stream()));
+            HIPCHK(hipStreamSynchronize(cur_stream()));
             return 0;
         };
         // `Tn` compass iterations of all states at once (two launches per iteration), steps halved after each
@@ -1816,17 +1856,17 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
         } else {
             // ---- grid scores at the coarse band, 27 coarse shifts each (k_sva_global)
             HIPCHK(hipMemcpyAsync(d_poses.p, [&]() { hp.resize((size_t)12 * nb); for (int v = 0; v < nb; v++) { std::memcpy(&hp[(size_t)12 * v], st[v].N, 9 * sizeof(double)); std::memcpy(&hp[(size_t)12 * v + 9], st[v].p, 3 * sizeof(double)); } return hp.data(); }(),
-                                  (size_t)12 * nb * sizeof(double), hipMemcpyHostToDevice, g.stream));
+                                  (size_t)12 * nb * sizeof(double), hipMemcpyHostToDevice, cur_stream()));
             SvaGlobalP GP;
             GP.cv = EP.cv; GP.samples = d_samples.p; GP.bandw = d_bandw.p; GP.F = d_F.p; GP.S = S; GP.N = N; GP.S_used = prefix_of(rg); GP.rmax2 = (float)(rg * rg);
             GP.use_wedge = EP.use_wedge; GP.wedges = d_wedges.p; GP.poses = d_poses.p; GP.grid = d_grid.p; GP.n_grid = n_grid; GP.RC = 8; GP.nshift = nshift; GP.tsh = (float)tsh;
             GP.score = d_gscore.p; GP.shift = d_gshift.p;
-            { ProfScope ps(PPM_K_GLOBAL); hipLaunchKernelGGL(k_sva_global, dim3((n_grid + GP.RC - 1) / GP.RC, nb), dim3(256), 0, g.stream, GP); }
+            { ProfScope ps(PPM_K_GLOBAL); hipLaunchKernelGGL(k_sva_global, dim3((n_grid + GP.RC - 1) / GP.RC, nb), dim3(256), 0, cur_stream(), GP); }
             HIPCHK(hipGetLastError());
             std::vector<float> gsc((size_t)nb * n_grid); std::vector<int> gsh((size_t)nb * n_grid);
-            HIPCHK(hipMemcpyAsync(gsc.data(), d_gscore.p, gsc.size() * sizeof(float), hipMemcpyDeviceToHost, g.stream));
-            HIPCHK(hipMemcpyAsync(gsh.data(), d_gshift.p, gsh.size() * sizeof(int), hipMemcpyDeviceToHost, g.stream));
-            HIPCHK(hipStreamSynchronize(g.stream));
+            HIPCHK(hipMemcpyAsync(gsc.data(), d_gscore.p, gsc.size() * sizeof(float), hipMemcpyDeviceToHost, cur_stream()));
+            HIPCHK(hipMemcpyAsync(gsh.data(), d_gshift.p, gsh.size() * sizeof(int), hipMemcpyDeviceToHost, cur_stream()));
+            HIPCHK(hipStreamSynchronize(cur_stream()));
             // ---- top-K per sub-volume (ties -> lower grid index) as states of their own
             std::vector<CUnit> cand; std::vector<int> vm; cand.reserve((size_t)nb * Kc); vm.reserve((size_t)nb * Kc);
             std::vector<int> order(n_grid);

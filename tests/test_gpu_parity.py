@@ -777,3 +777,42 @@ def test_priors_restrain_the_search_like_the_oracle(d64, H, O):
     got = g.refine(cfg, imgs, start)
     assert synth.angular_error_deg(want, got).max() < 0.1 and synth.shift_error_px(want, got, px).max() < 0.5
     assert np.abs(want[:, 14] - got[:, 14]).max() < 0.05
+
+
+def test_two_handles_driven_from_two_threads_equal_serial_runs(H, O):
+    """include/ppm.h "Thread-compatible per handle": two references (two classes) refined concurrently from two threads, and an
+    insertion running next to them, give bit for bit what the same calls give one after the other."""
+    import threading
+    n, px = 64, 2.0
+    vol, imgs, rows = dataset(n, 64, px, 0.2)
+    vol2 = np.ascontiguousarray(vol[::-1, :, :])                     # a second, different reference
+    cfg = cfg_for(n, px)
+    rc = ReconCfg(box=n, pixel_size=px, res_limit=2 * px, normalize=1, mask_radius=0.4 * n * px)
+    a, b = H.Reference(vol, n / 2), H.Reference(vol2, n / 2)
+    acc = H.Accumulator(n, px)
+    want_a, want_b = a.refine(cfg, imgs, rows), b.refine(cfg, imgs, rows)
+    acc.insert(rc, imgs, rows)
+    want_acc = acc.download()
+    acc2 = H.Accumulator(n, px)
+    out, errs = {}, []
+
+    def run(key, fn):
+        try:
+            for _ in range(3):
+                out[key] = fn()
+        except Exception as e:          # noqa: BLE001
+            errs.append(e)
+    def ins():
+        acc2.set_counts(0, 0)
+        t = H.Accumulator(n, px)
+        t.insert(rc, imgs, rows)
+        r = t.download(); t.close()
+        return r
+    ts = [threading.Thread(target=run, args=("a", lambda: a.refine(cfg, imgs, rows))),
+          threading.Thread(target=run, args=("b", lambda: b.refine(cfg, imgs, rows))),
+          threading.Thread(target=run, args=("acc", ins))]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert not errs, errs
+    assert np.array_equal(out["a"], want_a) and np.array_equal(out["b"], want_b)
+    assert np.linalg.norm(out["acc"] - want_acc) / np.linalg.norm(want_acc) < 1e-6       # global float atomics of the halo write-back
+    assert not np.array_equal(want_a[:, 1:4], want_b[:, 1:4])
