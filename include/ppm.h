@@ -251,11 +251,13 @@ typedef struct ppm_sva_cfg {
     int search_mode;        /* metric/alignment_mode of the protocol (iteration_002_mode_3.xml:29-38).  0 = rotation and translation REFINEMENT
                                within the tolerances (the protocol's mode 1); 1 = GLOBAL rotation and translation search (the protocol's
                                mode 0): the start rotation times every rotation of a grid of step `global_step` over the whole of SO(3)
-                               (theta_i = 180 i / (n - 1), n_phi = round(360 sin theta / step), n_psi = round(360 / step)), each scored at the
-                               27 shifts {-t, 0, t}^3 around the start (t = min(tol_shift, box / (4 r_g))) on the coarse band r_g the step
-                               allows (frequency marching with probe Delta / 2); the `n_candidates` best (rotation, shift) pairs get two
-                               compass iterations each (bounds: +-step about the grid rotation, +-tol_shift about the start shift), the best
-                               of them at the full band continues down to step_tolerance; 2 = translation only (the protocol's mode 2).
+                               (theta_i = 180 i / (n - 1), n_phi = round(360 sin theta / step), n_psi = round(360 / step)) is ranked by the
+                               correlation of the AMPLITUDES |F(k)| and |Ref(N k)| - a shift only moves phases, so the ranking does not
+                               depend on how well the sub-volume is centred - on the coarse band the step allows (frequency marching with
+                               probe Delta / 2); the `n_candidates` best rotations get two compass iterations each from the start shift
+                               (first steps Delta / 2 and tol_shift / 2; bounds +-step about the grid rotation, +-tol_shift about the start
+                               shift), and the best of them at the full band is refined again from Delta / 4 and tol_shift / 4 down to
+                               step_tolerance; 2 = translation only (the protocol's mode 2).
                                Build-defined: the absent program ranks peaks of a spherical-harmonics correlation instead */
     float global_step;      /* degrees; 0 = 15 */
     int n_candidates;       /* metric/number_of_candidate_peaks_to_search; 0 = 25, at most 64 */

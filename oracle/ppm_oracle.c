@@ -1509,6 +1509,20 @@ static void sva_grid_rotation(double step, int n_theta, int n_psi, int idx, doub
     euler_full(k * 360.0 / n_psi, th, ph, G);
 }
 
+/* translation-invariant score of a rotation: correlation of the AMPLITUDES |F(k)| and |Ref(N k)| (a shift only changes phases) */
+static double sva_score_amp(const oref_t *r, const svs_t *sl, int ns, const cpx *F, double rmax, const double Nm[9]) {
+    double A = 0, B = 0, C = 0, r2 = rmax * rmax;
+    for (int i = 0; i < ns; i++) {
+        const int kx = sl[i].kx, ky = sl[i].ky, kz = sl[i].kz;
+        if ((double)kx * kx + (double)ky * ky + (double)kz * kz >= r2) continue;
+        double pr, pi;
+        sample_cube(r, Nm[0] * kx + Nm[1] * ky + Nm[2] * kz, Nm[3] * kx + Nm[4] * ky + Nm[5] * kz, Nm[6] * kx + Nm[7] * ky + Nm[8] * kz, &pr, &pi);
+        const double m2 = pr * pr + pi * pi, f2 = (double)F[i].re * F[i].re + (double)F[i].im * F[i].im, w = sl[i].w;
+        A += w * sqrt(m2 * f2); B += w * m2; C += w * f2;
+    }
+    return (B > 0 && C > 0) ? A / sqrt(B * C) : 0.0;
+}
+
 int orc_sva_align(void *refp, const ppm_sva_cfg *cfg, const float *volumes, int n_vol, const float *wedges, double *poses, double *scores,
                   long *eval_count) {
     fft_tables();
@@ -1579,47 +1593,39 @@ int orc_sva_align(void *refp, const ppm_sva_cfg *cfg, const float *volumes, int 
             double ha = ha0, hs = hs0;
             sva_compass(r, sl, ns, F, N, rband, rm_px, bf, en, tol, &s, &ha, &hs, T, &nev);
         } else if (ns > 0) {
-            /* coarse band of the grid step, coarse shift probe */
+            /* rotations ranked by the translation-invariant AMPLITUDE correlation on the coarse band the grid step allows */
             geom_t g; memset(&g, 0, sizeof(g)); g.N = N;
             const int enr[5] = { 1, 0, 0, 0, 0 };
             const double rg = iter_band(&g, rm_px, bf, enr, 0.5 * gstep, 0.0, rband);
-            double tsh = cfg->tol_shift > 0 ? N / (4.0 * rg) : 0.0; if (tsh > cfg->tol_shift) tsh = cfg->tol_shift;
-            const int nshift = tsh > 0 ? 27 : 1;
-            double *gs = (double *)malloc((size_t)n_grid * sizeof(double)); int *gi = (int *)malloc((size_t)n_grid * sizeof(int));
+            double *gs = (double *)malloc((size_t)n_grid * sizeof(double)); char *used = (char *)calloc((size_t)n_grid, 1);
             for (int q = 0; q < n_grid; q++) {
                 double G[9], Nq[9]; sva_grid_rotation(gstep, g_nth, g_nps, q, G); mat_mul3(s.N, G, Nq);
-                double best = -1e300; int bsi = 0;
-                for (int si = 0; si < nshift; si++) {
-                    double pq[3] = { s.p[0], s.p[1], s.p[2] };
-                    if (nshift > 1) { pq[0] += (si % 3 - 1) * tsh; pq[1] += ((si / 3) % 3 - 1) * tsh; pq[2] += (si / 9 - 1) * tsh; }
-                    const double val = sva_score(r, sl, ns, F, N, rg, Nq, pq); nev++;
-                    if (val > best) { best = val; bsi = si; }
-                }
-                gs[q] = best; gi[q] = bsi;
+                gs[q] = sva_score_amp(r, sl, ns, F, rg, Nq); nev++;
             }
-            /* top-K (ties -> lower grid index), two compass iterations each, the best at the full band continues */
+            /* top-K (ties -> lower grid index): two compass iterations each from the start shift (first steps Delta / 2 and half the
+             * shift tolerance, bounds +-Delta about the grid rotation and +-tolerance about the start shift); the best of them at
+             * the full band is refined again from Delta / 4 and a quarter of the shift tolerance down to the step tolerance */
             const double tolg[6] = { gstep, gstep, gstep, tol[3], tol[4], tol[5] };
             const int eng[6] = { 1, 1, 1, en[3], en[4], en[5] };
-            cunit_t bestc; double bestf = -1e300, bha = 0, bhs = 0; int have = 0;
+            cunit_t bestc; double bestf = -1e300; int have = 0;
             for (int a2 = 0; a2 < K; a2++) {
                 int bq = -1;
-                for (int q = 0; q < n_grid; q++) if (gi[q] >= 0 && (bq < 0 || gs[q] > gs[bq])) bq = q;
+                for (int q = 0; q < n_grid; q++) if (!used[q] && (bq < 0 || gs[q] > gs[bq])) bq = q;
                 if (bq < 0) break;
+                used[bq] = 1;
                 cunit_t c = s; double G[9], Nq[9]; sva_grid_rotation(gstep, g_nth, g_nps, bq, G); mat_mul3(s.N, G, Nq); memcpy(c.N, Nq, sizeof(Nq));
-                const int si = gi[bq];
-                if (nshift > 1) { const double dd[3] = { (si % 3 - 1) * tsh, ((si / 3) % 3 - 1) * tsh, (si / 9 - 1) * tsh }; for (int k = 0; k < 3; k++) { c.p[k] += dd[k]; c.acc[3 + k] = dd[k]; } }
-                gi[bq] = -1;
-                double ha = 0.5 * gstep, hs = 0.5 * tsh;
+                double ha = 0.5 * gstep, hs = 0.5 * cfg->tol_shift;
                 sva_compass(r, sl, ns, F, N, rband, rm_px, bf, eng, tolg, &c, &ha, &hs, 2, &nev);
                 const double fc = sva_score(r, sl, ns, F, N, rband, c.N, c.p); nev++;
-                if (!have || fc > bestf) { bestc = c; bestf = fc; bha = ha; bhs = hs; have = 1; }
+                if (!have || fc > bestf) { bestc = c; bestf = fc; have = 1; }
             }
-            free(gs); free(gi);
+            free(gs); free(used);
             if (have) {
                 s = bestc;
-                double m = bha > bhs ? bha : bhs;
+                double ha = 0.25 * gstep, hs = 0.25 * cfg->tol_shift;
+                const double m = ha > hs ? ha : hs;
                 int Tf = m > steptol ? (int)ceil(log(m / steptol) / log(2.0)) : 0; if (Tf > 12) Tf = 12;
-                sva_compass(r, sl, ns, F, N, rband, rm_px, bf, eng, tolg, &s, &bha, &bhs, Tf, &nev);
+                sva_compass(r, sl, ns, F, N, rband, rm_px, bf, eng, tolg, &s, &ha, &hs, Tf, &nev);
             }
         }
         memcpy(poses + (size_t)v * 12, s.N, 9 * sizeof(double)); memcpy(poses + (size_t)v * 12 + 9, s.p, 3 * sizeof(double));

@@ -1643,23 +1643,9 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
     const double bf = cfg->band_factor == 0 ? 3.0 : cfg->band_factor;
     double rm_px = std::max(cfg->window[0], std::max(cfg->window[1], cfg->window[2]));
     if (!(rm_px > 0)) rm_px = 0.4 * N;
-    // coarse band the grid step allows (probe Delta / 2, rotations only) and the coarse shift probe
-    double rg = rband, tsh = 0.0;
-    if (global) {
-        if (bf >= 0) { const double d = rm_px * 0.5 * gstep * kPi / 180.0; double rit = bf * N / (2.0 * kPi * d); if (rit < 4.0) rit = 4.0; rg = std::min(rit, rband); }
-        tsh = cfg->tol_shift > 0 ? std::min((double)cfg->tol_shift, N / (4.0 * rg)) : 0.0;
-    }
-    const int nshift = tsh > 0 ? 27 : 1;
-    auto iter_band = [&](double ha, double hs) {
-        if (bf < 0) return rband;
-        double d = 0;
-        if (en[0]) d = rm_px * ha * kPi / 180.0;
-        if (en[3] && hs > d) d = hs;
-        if (!(d > 0)) return rband;
-        double rit = bf * N / (2.0 * kPi * d);
-        if (rit < 4.0) rit = 4.0;
-        return rit < rband ? rit : rband;
-    };
+    // coarse band the grid step allows (probe Delta / 2, rotations only)
+    double rg = rband;
+    if (global && bf >= 0) { const double d = rm_px * 0.5 * gstep * kPi / 180.0; double rit = bf * N / (2.0 * kPi * d); if (rit < 4.0) rit = 4.0; rg = std::min(rit, rband); }
     // ---- device buffers (RAII), chunks of sub-volumes
     // chunks of sub-volumes: the search kernel runs one block per sub-volume, so a chunk should fill the chip (>= 256 blocks).  Resident
     // volumes: limited by the band transforms (S float2 each, 4 GB); host volumes: two staging buffers of a chunk each (2 x 7 GB at
@@ -1670,7 +1656,7 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
         CH = std::min(CH, hc);
     }
     DevTmp<uint32_t> d_samples; DevTmp<float> d_bandw, d_vols, d_wedges, d_grid, d_gscore; DevTmp<float2> d_f, d_F; DevTmp<double> d_stats, d_poses, d_delta, d_out;
-    DevTmp<int> d_vmap, d_gshift;
+    DevTmp<int> d_vmap;
     const int KX = std::min(N / 2 + 1, R + 1);          // x coefficients kept; |ky|, |kz| <= R are the lines the later passes touch
     const int NB = std::min(CH, 32);                     // sub-volumes transformed per launch (work array: NB x N x N x KX complex)
     HIPCHK(d_samples.alloc(S)); HIPCHK(d_bandw.alloc(S)); HIPCHK(d_f.alloc((size_t)NB * N * N * KX)); HIPCHK(d_F.alloc((size_t)CH * S));
@@ -1679,7 +1665,7 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
     HIPCHK(d_vmap.alloc(CHS));
     if (global) {
         std::vector<float> gf(grid_d.begin(), grid_d.end());
-        HIPCHK(d_grid.alloc(gf.size())); HIPCHK(d_gscore.alloc((size_t)CH * n_grid)); HIPCHK(d_gshift.alloc((size_t)CH * n_grid));
+        HIPCHK(d_grid.alloc(gf.size())); HIPCHK(d_gscore.alloc((size_t)CH * n_grid));
         HIPCHK(hipMemcpy(d_grid.p, gf.data(), gf.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     HIPCHK(d_wedges.alloc((size_t)2 * CH));
@@ -1854,20 +1840,19 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
             double ha = ha0, hs = hs0;
             if (int rc = compass(st, nullptr, en, tol, ha, hs, T)) return rc;
         } else {
-            // ---- grid scores at the coarse band, 27 coarse shifts each (k_sva_global)
-            HIPCHK(hipMemcpyAsync(d_poses.p, [&]() { hp.resize((size_t)12 * nb); for (int v = 0; v < nb; v++) { std::memcpy(&hp[(size_t)12 * v], st[v].N, 9 * sizeof(double)); std::memcpy(&hp[(size_t)12 * v + 9], st[v].p, 3 * sizeof(double)); } return hp.data(); }(),
-                                  (size_t)12 * nb * sizeof(double), hipMemcpyHostToDevice, cur_stream()));
+            // ---- rotations ranked by the amplitude correlation on the coarse band (k_sva_global)
+            hp.resize((size_t)12 * nb);
+            for (int v = 0; v < nb; v++) { std::memcpy(&hp[(size_t)12 * v], st[v].N, 9 * sizeof(double)); std::memcpy(&hp[(size_t)12 * v + 9], st[v].p, 3 * sizeof(double)); }
+            HIPCHK(hipMemcpyAsync(d_poses.p, hp.data(), (size_t)12 * nb * sizeof(double), hipMemcpyHostToDevice, cur_stream()));
             SvaGlobalP GP;
             GP.cv = EP.cv; GP.samples = d_samples.p; GP.bandw = d_bandw.p; GP.F = d_F.p; GP.S = S; GP.N = N; GP.S_used = prefix_of(rg); GP.rmax2 = (float)(rg * rg);
-            GP.use_wedge = EP.use_wedge; GP.wedges = d_wedges.p; GP.poses = d_poses.p; GP.grid = d_grid.p; GP.n_grid = n_grid; GP.RC = 8; GP.nshift = nshift; GP.tsh = (float)tsh;
-            GP.score = d_gscore.p; GP.shift = d_gshift.p;
+            GP.use_wedge = EP.use_wedge; GP.wedges = d_wedges.p; GP.poses = d_poses.p; GP.grid = d_grid.p; GP.n_grid = n_grid; GP.RC = 8; GP.score = d_gscore.p;
             { ProfScope ps(PPM_K_GLOBAL); hipLaunchKernelGGL(k_sva_global, dim3((n_grid + GP.RC - 1) / GP.RC, nb), dim3(256), 0, cur_stream(), GP); }
             HIPCHK(hipGetLastError());
-            std::vector<float> gsc((size_t)nb * n_grid); std::vector<int> gsh((size_t)nb * n_grid);
+            std::vector<float> gsc((size_t)nb * n_grid);
             HIPCHK(hipMemcpyAsync(gsc.data(), d_gscore.p, gsc.size() * sizeof(float), hipMemcpyDeviceToHost, cur_stream()));
-            HIPCHK(hipMemcpyAsync(gsh.data(), d_gshift.p, gsh.size() * sizeof(int), hipMemcpyDeviceToHost, cur_stream()));
             HIPCHK(hipStreamSynchronize(cur_stream()));
-            // ---- top-K per sub-volume (ties -> lower grid index) as states of their own
+            // ---- top-K per sub-volume (ties -> lower grid index) as states of their own, from the start shift
             std::vector<CUnit> cand; std::vector<int> vm; cand.reserve((size_t)nb * Kc); vm.reserve((size_t)nb * Kc);
             std::vector<int> order(n_grid);
             for (int v = 0; v < nb; v++) {
@@ -1875,14 +1860,12 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
                 for (int q = 0; q < n_grid; q++) order[q] = q;
                 std::partial_sort(order.begin(), order.begin() + Kc, order.end(), [&](int x, int y) { return sc_[x] > sc_[y] || (sc_[x] == sc_[y] && x < y); });
                 for (int k = 0; k < Kc; k++) {
-                    const int q = order[k], si = gsh[(size_t)v * n_grid + q];
                     CUnit c = st[v];
-                    double Nq[9]; mat_mul3h(st[v].N, &grid_d[(size_t)q * 9], Nq); std::memcpy(c.N, Nq, sizeof(Nq));
-                    if (nshift > 1) { const double dd[3] = { (si % 3 - 1) * tsh, ((si / 3) % 3 - 1) * tsh, (si / 9 - 1) * tsh }; for (int j = 0; j < 3; j++) { c.p[j] += dd[j]; c.acc[3 + j] = dd[j]; } }
+                    double Nq[9]; mat_mul3h(st[v].N, &grid_d[(size_t)order[k] * 9], Nq); std::memcpy(c.N, Nq, sizeof(Nq));
                     cand.push_back(c); vm.push_back(v);
                 }
             }
-            double ha = 0.5 * gstep, hs = 0.5 * tsh;
+            double ha = 0.5 * gstep, hs = 0.5 * cfg->tol_shift;
             if (int rc = compass(cand, &vm, eng, tolg, ha, hs, 2)) return rc;
             if (int rc = final_scores(cand, &vm)) return rc;
             for (int v = 0; v < nb; v++) {
@@ -1890,6 +1873,7 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
                 for (int k = 1; k < Kc; k++) if (hout[(size_t)v * Kc + k] > hout[(size_t)v * Kc + bk]) bk = k;
                 st[v] = cand[(size_t)v * Kc + bk];
             }
+            ha = 0.25 * gstep; hs = 0.25 * cfg->tol_shift;
             const double m = std::max(ha, hs);
             int Tf = m > steptol ? (int)std::ceil(std::log(m / steptol) / std::log(2.0)) : 0; Tf = std::min(12, Tf);
             if (int rc = compass(st, nullptr, eng, tolg, ha, hs, Tf)) return rc;

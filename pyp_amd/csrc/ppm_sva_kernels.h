@@ -164,25 +164,21 @@ __global__ void __launch_bounds__(256) k_sva_eval(SvaEvalP P) {
     }
 }
 
-// Global rotational + translational grid (ppm_sva_cfg.search_mode 1, include/ppm.h): block = (sub-volume, run of RC grid
-// rotations).  For every rotation the reference is gathered once per coarse-band sample and correlated at the 27 shifts
-// {-t, 0, t}^3 around the start shift (phase factors e^{i 2 pi k_x t / N} etc. are built once per sample and combined);
-// the best shift (first maximum in the order x fastest, z slowest: the oracle's scan order) and its score go out per rotation.
+// Global rotational grid (ppm_sva_cfg.search_mode 1, include/ppm.h): block = (sub-volume, run of RC grid rotations).  A rotation's
+// rank is the correlation of the AMPLITUDES |F(k)| and |Ref(N k)| over the coarse band (a shift only moves phases): one gather
+// per sample and rotation, three sums.
 struct SvaGlobalP {
     CubeView cv; const uint32_t *samples; const float *bandw; const float2 *F; int S, N, S_used; float rmax2; int use_wedge;
     const float *wedges; const double *poses;     // [n_vol][2], [n_vol][12]
     const float *grid;                            // [n_grid][9] grid rotations G (row-major)
-    int n_grid, RC, nshift; float tsh;            // nshift = 27 or 1
-    float *score; int *shift;                     // [n_vol][n_grid]
+    int n_grid, RC;
+    float *score;                                 // [n_vol][n_grid]
 };
 
 __global__ void __launch_bounds__(256) k_sva_global(SvaGlobalP P) {
-    __shared__ float Nq[9], red[4][30];
-    __shared__ float p0[3], N0[9];
+    __shared__ float Nq[9], red[4][3];
     const int v = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < 9) N0[tid] = (float)P.poses[(size_t)v * 12 + tid];
-    if (tid < 3) p0[tid] = (float)P.poses[(size_t)v * 12 + 9 + tid];
-    const float lw = P.wedges[2 * v], uw = P.wedges[2 * v + 1], invN = 1.0f / (float)P.N;
+    const float lw = P.wedges[2 * v], uw = P.wedges[2 * v + 1];
     const float2 *F = P.F + (size_t)v * P.S;
     const int q0 = blockIdx.x * P.RC, q1 = min(q0 + P.RC, P.n_grid);
     for (int q = q0; q < q1; q++) {
@@ -194,9 +190,7 @@ __global__ void __launch_bounds__(256) k_sva_global(SvaGlobalP P) {
             Nq[tid] = (float)a;
         }
         __syncthreads();
-        float A[27], B = 0.f, Csum = 0.f;
-#pragma unroll
-        for (int c = 0; c < 27; c++) A[c] = 0.f;
+        float A = 0.f, B = 0.f, Csum = 0.f;
         for (int s = tid; s < P.S_used; s += 256) {
             int kx, ky, kz; sva_unpack(P.samples[s], kx, ky, kz);
             float w = P.bandw[s];
@@ -209,54 +203,16 @@ __global__ void __launch_bounds__(256) k_sva_global(SvaGlobalP P) {
             }
             const float2 iv = F[s];
             const float fkx = (float)kx, fky = (float)ky, fkz = (float)kz;
-            const float wx = w * iv.x, wy = w * iv.y;
-            Csum += wx * iv.x + wy * iv.y;
             const float2 p = sample_cube(P.cv, Nq[0] * fkx + Nq[1] * fky + Nq[2] * fkz, Nq[3] * fkx + Nq[4] * fky + Nq[5] * fkz, Nq[6] * fkx + Nq[7] * fky + Nq[8] * fkz);
-            B += w * (p.x * p.x + p.y * p.y);
-            // corr(shift) = Re(z e^{i phi}), z = (u, -v), u = Re(conj(wF) p)..., phi = 2 pi k.(p0 + shift) / N
-            float rev = (fkx * p0[0] + fky * p0[1] + fkz * p0[2]) * invN; rev -= floorf(rev);
-            const float sn0 = __sinf(6.283185307179586f * rev), cs0 = __cosf(6.283185307179586f * rev);
-            const float pr = p.x * cs0 - p.y * sn0, pi = p.x * sn0 + p.y * cs0;
-            const float zr = wx * pr + wy * pi, zi = wx * pi - wy * pr;          // z = conj(wF) m0, m0 = p e^{i phi0}
-            if (P.nshift == 1) { A[13] += zr; continue; }
-            float ex[2], ey[2], ez[2];
-            { float r = fkx * P.tsh * invN; r -= floorf(r); ex[1] = __sinf(6.283185307179586f * r); ex[0] = __cosf(6.283185307179586f * r); }
-            { float r = fky * P.tsh * invN; r -= floorf(r); ey[1] = __sinf(6.283185307179586f * r); ey[0] = __cosf(6.283185307179586f * r); }
-            { float r = fkz * P.tsh * invN; r -= floorf(r); ez[1] = __sinf(6.283185307179586f * r); ez[0] = __cosf(6.283185307179586f * r); }
-            // (zr + i zi) e^{i a tx} for a = -1, 0, 1
-            float xr[3], xi[3];
-            xr[1] = zr; xi[1] = zi;
-            xr[2] = zr * ex[0] - zi * ex[1]; xi[2] = zr * ex[1] + zi * ex[0];
-            xr[0] = zr * ex[0] + zi * ex[1]; xi[0] = zi * ex[0] - zr * ex[1];
-#pragma unroll
-            for (int a = 0; a < 3; a++) {
-                float yr[3], yi[3];
-                yr[1] = xr[a]; yi[1] = xi[a];
-                yr[2] = xr[a] * ey[0] - xi[a] * ey[1]; yi[2] = xr[a] * ey[1] + xi[a] * ey[0];
-                yr[0] = xr[a] * ey[0] + xi[a] * ey[1]; yi[0] = xi[a] * ey[0] - xr[a] * ey[1];
-#pragma unroll
-                for (int b = 0; b < 3; b++) {
-                    A[a + 3 * b + 9 * 1] += yr[b];
-                    A[a + 3 * b + 9 * 2] += yr[b] * ez[0] - yi[b] * ez[1];
-                    A[a + 3 * b + 9 * 0] += yr[b] * ez[0] + yi[b] * ez[1];
-                }
-            }
+            const float m2 = p.x * p.x + p.y * p.y, f2 = iv.x * iv.x + iv.y * iv.y;
+            A += w * sqrtf(m2 * f2); B += w * m2; Csum += w * f2;
         }
-#pragma unroll
-        for (int c = 0; c < 27; c++) { const float t = wave_sum(A[c]); if (lane == 0) red[wave][c] = t; }
-        { const float t = wave_sum(B); if (lane == 0) red[wave][27] = t; }
-        { const float t = wave_sum(Csum); if (lane == 0) red[wave][28] = t; }
+        { float t = wave_sum(A); if (lane == 0) red[wave][0] = t; t = wave_sum(B); if (lane == 0) red[wave][1] = t; t = wave_sum(Csum); if (lane == 0) red[wave][2] = t; }
         __syncthreads();
         if (tid == 0) {
-            const double b = (((double)red[0][27] + red[1][27]) + red[2][27]) + red[3][27], c = (((double)red[0][28] + red[1][28]) + red[2][28]) + red[3][28];
-            double best = -1e300; int bs = 13;
-            for (int si = 0; si < 27; si++) {
-                if (P.nshift == 1 && si != 13) continue;
-                const double a = (((double)red[0][si] + red[1][si]) + red[2][si]) + red[3][si];
-                const double val = (b > 0 && c > 0) ? a / sqrt(b * c) : 0.0;
-                if (val > best) { best = val; bs = si; }
-            }
-            P.score[(size_t)v * P.n_grid + q] = (float)best; P.shift[(size_t)v * P.n_grid + q] = bs;
+            const double a = (((double)red[0][0] + red[1][0]) + red[2][0]) + red[3][0], b = (((double)red[0][1] + red[1][1]) + red[2][1]) + red[3][1],
+                         c = (((double)red[0][2] + red[1][2]) + red[2][2]) + red[3][2];
+            P.score[(size_t)v * P.n_grid + q] = (b > 0 && c > 0) ? (float)(a / sqrt(b * c)) : 0.f;
         }
     }
 }

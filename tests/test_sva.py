@@ -61,7 +61,8 @@ def test_gpu_alignment_matches_oracle(n, kw):
 
 def test_oracle_global_search_finds_alignments_from_random_starts(subtomos):
     """ppm_sva_cfg.search_mode 1 (the protocol's alignment_mode 0, iteration_002_mode_3.xml:29-38): from rotations anywhere on SO(3)
-    the coarse grid + 25 refined candidates land on the true alignment; the refinement mode alone cannot; mode 2 moves shifts only."""
+    the amplitude-ranked grid + 25 refined candidates land on the true alignment; the refinement mode alone cannot; mode 2 moves
+    shifts only."""
     n, vol, vols, poses, wedges, O, ref = subtomos
     rng = np.random.default_rng(0)
     start = poses[:3].copy()
@@ -99,9 +100,9 @@ def test_gpu_global_search_matches_oracle():
         got, gsc = g.sva_align(c, vols.numpy(), wedges, s0)
         assert synth.pose_angle_error(want, got).max() < 0.1 and np.abs(want[:, 9:] - got[:, 9:]).max() < 0.5, kw
         assert np.abs(wsc - gsc).max() < 2e-3
-        if kw["search_mode"] == 1:         # most starts reach the true alignment (a 20 - 30 degree grid can end in a pseudo-symmetric optimum of the phantom)
+        if kw["search_mode"] == 1:         # from anywhere on SO(3) and shifts a few pixels off: (nearly) all starts reach the true alignment
             err = synth.pose_angle_error(got, poses)
-            assert (err < 1.5).sum() >= len(err) - 1 and np.median(gsc) > 0.8, (kw, err)
+            assert (err < 1.5).sum() >= len(err) - 1 and err.max() < 8.0 and gsc.min() > 0.8, (kw, err)
         got2, gsc2 = g.sva_align(c, vols.cuda(), wedges, s0)
         assert np.array_equal(got, got2) and np.array_equal(gsc, gsc2)
 
