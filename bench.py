@@ -675,6 +675,26 @@ def sva_bench(ctx):
     dt = max_over_ranks(time.perf_counter() - t0, world, dev)
     prof = host.profile_report()
     host.profile(False, False)
+    # the protocol's global search (alignment_mode 0) from rotations anywhere on SO(3), on a bounded sample (outside the timed region above)
+    glob = None
+    if rank == 0:
+        ng = min(nv, 64)
+        rng = np.random.default_rng(12)
+        gstart = poses[:ng].copy()
+        for v in range(ng):
+            R = synth.euler_matrix(rng.uniform(0, 360), np.degrees(np.arccos(rng.uniform(-1, 1))), rng.uniform(0, 360))
+            gstart[v, :9] = (poses[v, :9].reshape(3, 3) @ R).ravel()
+            gstart[v, 9:] += rng.normal(0, 2.0, 3)
+        gcfg = SvaCfg.make(n, window=(0.33 * n, 0.33 * n, 0.33 * n), window_sigma=4.0, highpass=(0.05, 0.01), lowpass=(0.125, 0.05), tol_angle=10.0, tol_shift=10.0,
+                           search_mode=1, global_step=15.0, n_candidates=25)
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
+        gout, gsc = ref.sva_align(gcfg, vols[:ng], wedges[:ng], gstart)
+        tg = time.perf_counter() - tg
+        gerr = synth.pose_angle_error(gout, poses[:ng])
+        glob = {"value": round(ng / tg, 1), "unit": "sub-volumes/s", "sample": "%d sub-volumes, random start rotations, shifts +-2 px; 15 deg grid (4 416 rotations), 25 candidates" % ng,
+                "median_deg_before": round(float(np.median(synth.pose_angle_error(gstart, poses[:ng]))), 1), "median_deg_after": round(float(np.median(gerr)), 3),
+                "frac_within_1deg": round(float((gerr < 1.0).mean()), 3)}
     ref.close()
     if rank != 0:
         return None
@@ -695,7 +715,8 @@ def sva_bench(ctx):
            "accuracy_vs_truth": {"median_deg_before": round(float(np.median(synth.pose_angle_error(start, poses))), 3),
                                  "median_deg_after": round(float(np.median(synth.pose_angle_error(out, poses))), 3),
                                  "median_shift_px_after": round(float(np.median(np.linalg.norm(out[:, 9:] - poses[:, 9:], axis=1))), 3),
-                                 "mean_score": round(float(sc.mean()), 4)}}
+                                 "mean_score": round(float(sc.mean()), 4)},
+           "global_search": glob}
     if world == 1 and not a.no_cpu and a.cpu_seconds > 0:
         from oracle import oracle
         cores = host_cores()
