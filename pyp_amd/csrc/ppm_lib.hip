@@ -2,12 +2,15 @@
 // Host glue only: workspace management, launch sequencing on one HIP stream, event timing.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cerrno>
+#include <condition_variable>
 #include <functional>
 #include <map>
 #include <memory>
@@ -389,6 +392,7 @@ static int launch_global(GlobP &P, int n_img, bool half, int R) {
     }
 }
 
+static __global__ void k_noop() {}
 
 extern "C" {
 
@@ -396,7 +400,9 @@ const char *ppm_last_error(void) { return g_err.c_str(); }
 const char *ppm_version(void) { return "pypmatch 0.1 (gfx950)"; }
 
 int ppm_init(int device) {
-    if (g.inited && g.device == device) return 0;
+    static std::mutex init_mu;                       // a caller may start the device from a helper thread and call again from its main thread
+    std::lock_guard<std::mutex> lk(init_mu);
+    if (g.inited && g.device == device) { (void)hipSetDevice(device); return 0; }      // the current device is a per-thread setting
     if (g.inited) return fail(-16, "libpypmatch is bound to device " + std::to_string(g.device) + " in this process (one process per GPU); start another process for device " + std::to_string(device));
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(-19, "no HIP device visible; libpypmatch has no CPU path");
@@ -415,6 +421,10 @@ int ppm_init(int device) {
     if (!g.stream) HIPCHK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     if (!g.copy) HIPCHK(hipStreamCreateWithFlags(&g.copy, hipStreamNonBlocking));
     if (!g.upload) HIPCHK(hipStreamCreateWithFlags(&g.upload, hipStreamNonBlocking));
+    // the code object is loaded at the first launch (tens of ms): here, where a caller can overlap it with its own start-up
+    hipLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, g.stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(g.stream));
     g.device = device; g.inited = true;
     return 0;
 }
@@ -443,6 +453,70 @@ int ppm_device_upload(void *dst, const void *src, size_t bytes) {
 }
 void *ppm_host_alloc(size_t bytes) { if (g.inited) (void)hipSetDevice(g.device); void *p = nullptr; if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { g_err = "ERROR: pinned host allocation failed"; return nullptr; } return p; }
 void ppm_host_free(void *p) { if (p) (void)hipHostFree(p); }
+// ---- file reads for the executables' reader stage: a persistent pool, one pread loop per part
+namespace {
+struct ReadPool {
+    std::mutex mu;                      // one ppm_host_read at a time
+    std::mutex qmu;
+    std::condition_variable wake, done;
+    std::vector<std::thread> threads;
+    struct Part { int fd; long long off; char *dst; size_t bytes; };
+    std::vector<Part> parts;
+    size_t next = 0, pending = 0;
+    int err = 0;
+    bool quit = false;
+    void worker() {
+        std::unique_lock<std::mutex> lk(qmu);
+        for (;;) {
+            wake.wait(lk, [&] { return quit || next < parts.size(); });
+            if (quit) return;
+            Part p = parts[next++];
+            lk.unlock();
+            int e = 0;
+            size_t got = 0;
+            while (got < p.bytes) {
+                ssize_t r = pread(p.fd, p.dst + got, std::min(p.bytes - got, (size_t)64 << 20), p.off + (long long)got);
+                if (r < 0) { if (errno == EINTR) continue; e = -errno; break; }
+                if (r == 0) { e = -5; break; }
+                got += (size_t)r;
+            }
+            lk.lock();
+            if (e && !err) err = e;
+            if (--pending == 0) done.notify_all();
+        }
+    }
+    int run(int fd, long long off, char *dst, size_t bytes, int nt) {
+        std::lock_guard<std::mutex> one(mu);
+        nt = std::max(1, std::min(nt, 16));
+        std::unique_lock<std::mutex> lk(qmu);
+        while ((int)threads.size() < nt) threads.emplace_back([this] { worker(); });
+        // parts of whole MB so that every pread starts on a page boundary of the destination
+        const size_t per = std::max((size_t)1 << 20, ((bytes + nt - 1) / nt + ((size_t)1 << 20) - 1) >> 20 << 20);
+        parts.clear(); next = 0; err = 0;
+        for (size_t a = 0; a < bytes; a += per) parts.push_back({fd, off + (long long)a, dst + a, std::min(per, bytes - a)});
+        pending = parts.size();
+        if (!pending) return 0;
+        wake.notify_all();
+        done.wait(lk, [&] { return pending == 0; });
+        parts.clear(); next = 0;
+        return err;
+    }
+    ~ReadPool() {
+        { std::lock_guard<std::mutex> lk(qmu); quit = true; }
+        wake.notify_all();
+        for (auto &t : threads) t.join();
+    }
+};
+ReadPool &read_pool() { static ReadPool *p = new ReadPool(); return *p; }      // leaked on purpose: no joins at process exit
+}
+int ppm_host_read(int fd, long long offset, void *dst, size_t bytes, int n_threads) {
+    if (fd < 0 || offset < 0 || (!dst && bytes)) return fail(-22, "ppm_host_read: bad argument");
+    int e = read_pool().run(fd, offset, (char *)dst, bytes, n_threads);
+    if (e == -5) return fail(-5, "short read from the particle stack");
+    if (e) return fail(e, std::string("reading the particle stack failed: ") + strerror(-e));
+    return 0;
+}
+
 int ppm_device_sync(void) { if (cur_stream()) HIPCHK(hipStreamSynchronize(cur_stream())); HIPCHK(hipDeviceSynchronize()); return 0; }
 
 // ------------------------------------------------------------------------------ reference

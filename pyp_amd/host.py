@@ -263,10 +263,11 @@ def extract_boxes(micrograph, coords, box, radius_A, pixel_size, coordinate_binn
 class PinnedBuffer:
     """Page-locked host memory as a float32 numpy array (ppm_host_alloc): staging for uploads that overlap compute."""
 
-    def __init__(self, n_floats, device=0):
+    def __init__(self, n_floats, device=0, ptr=None):
+        """ptr: memory already page-locked by ppm_host_alloc (surface/warm.py hands over what it prepared); owned from here on."""
         lib.init(device)
         self.n = int(n_floats)
-        self.ptr = lib.load().ppm_host_alloc(self.n * 4)
+        self.ptr = ptr or lib.load().ppm_host_alloc(self.n * 4)
         if not self.ptr:
             raise lib.PpmError(lib.last_error())
         self.array = np.ctypeslib.as_array((C.c_float * self.n).from_address(self.ptr))

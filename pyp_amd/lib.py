@@ -15,7 +15,7 @@ EXPORTS = [
     "ppm_refine_batch", "ppm_refine_last_counts", "ppm_refine_note", "ppm_match_projections", "ppm_csp_refine", "ppm_sva_align", "ppm_accum_floats", "ppm_accum_create", "ppm_accum_destroy",
     "ppm_insert_batch", "ppm_accum_download", "ppm_accum_add", "ppm_accum_count", "ppm_accum_set_count",
     "ppm_finalize", "ppm_profile_enable", "ppm_profile_reset", "ppm_profile_get", "ppm_device_alloc",
-    "ppm_device_free", "ppm_device_upload", "ppm_device_sync", "ppm_extract_boxes", "ppm_host_alloc", "ppm_host_free",
+    "ppm_device_free", "ppm_device_upload", "ppm_device_sync", "ppm_extract_boxes", "ppm_host_alloc", "ppm_host_free", "ppm_host_read",
     "ppm_comm_unique_id", "ppm_comm_create", "ppm_comm_destroy", "ppm_accum_reduce",
 ]
 
@@ -68,6 +68,7 @@ def load():
     L.ppm_device_sync.argtypes = []; L.ppm_device_sync.restype = ci
     L.ppm_host_alloc.argtypes = [C.c_size_t]; L.ppm_host_alloc.restype = vp
     L.ppm_host_free.argtypes = [vp]; L.ppm_host_free.restype = None
+    L.ppm_host_read.argtypes = [ci, C.c_longlong, vp, C.c_size_t, ci]; L.ppm_host_read.restype = ci
     L.ppm_extract_boxes.argtypes = [vp, ci, ci, ci, vp, ci, ci, C.c_double, C.c_double, ci, ci, vp, ci]; L.ppm_extract_boxes.restype = ci
     L.ppm_comm_unique_id.argtypes = [vp]; L.ppm_comm_unique_id.restype = ci
     L.ppm_comm_create.argtypes = [ci, ci, vp]; L.ppm_comm_create.restype = vp
@@ -92,6 +93,10 @@ _inited = None
 def init(device=0):
     global _inited
     if _inited != device:
+        import sys
+        w = sys.modules.get("pyp_amd.surface.warm")      # the executables start the device in a background thread (surface/warm.py)
+        if w is not None:
+            w.join_init()
         check(load().ppm_init(int(device)))
         _inited = device
 

@@ -54,7 +54,14 @@ def _die(msg):
     if "ERROR" not in msg:
         msg = "ERROR: " + msg
     print(msg, flush=True)
+    _release_warm()
     sys.exit(1)
+
+
+def _release_warm():
+    w = sys.modules.get("pyp_amd.surface.warm")
+    if w:
+        w.release()
 
 
 def _unsupported(d, keys, prog):
@@ -101,23 +108,32 @@ class DeviceImages:
         return None
 
 
-def _iter_image_chunks(mm, positions, device, chunk=None, group=1):
+def _iter_image_chunks(mm, positions, device, chunk=None, group=1, call_mb=0, chunk_mb=256):
     """Yield (lo, hi, images) over the range, `images` = hi - lo particle images ALREADY ON THE DEVICE.  Three stages run
     concurrently: a reader thread fills page-locked buffers from the stack file (pread by several worker threads: one kernel copy
     out of the page cache, no page faults, the GIL released), an upload thread moves them into one of two device buffers on the
     library's upload stream, and the caller computes on the other device buffer.  The host never holds more than three chunks (a
-    500 k x 256^2 range is 131 GB).  Buffers beyond the first are allocated by the threads themselves, while the first chunk is
-    already on its way (page-locking 512 MB costs ~0.1 s).  `group` > 1: that many uploaded chunks are handed out together, as
-    one contiguous device array (the insertion kernels want ~8 k particles per call: a call on 2 048 costs 11 ms instead of 1.4)."""
+    500 k x 256^2 range is 131 GB).  The page-locked buffers hold `chunk_mb` MB each (PPM_IO_CHUNK_MB overrides; page-locking costs
+    ~0.27 s per GB): the executables' start-up thread (surface/warm.py) prepares them while the inputs are parsed, otherwise the
+    reader allocates them as it goes.  `call_mb`: that many MB of uploaded chunks are handed out together, as one contiguous device
+    array (the insertion kernels want ~8 k particles per call: a call on 2 048 costs 11 ms instead of 1.4); `group` says the same
+    as a number of chunks.  Measured at 100 k x 256^2 (scripts/dropin_ab.py): refine3d (compute-bound) is fastest with 64 MB
+    chunks, reconstruct3d (I/O-bound: 8 reader threads want large requests) with 256 MB."""
     import queue
     import threading
     from concurrent.futures import ThreadPoolExecutor
     from .. import host, lib
     n, box = len(positions), mm.shape[1]
-    if chunk is None:       # 256 MB per page-locked buffer (1 024 images of 256^2): pinning costs ~0.2 s per GB and sits in front of the first chunks
-        chunk = int(os.environ.get("PPM_IO_CHUNK", str(max(256, min(16384, (256 << 20) // (box * box * 4))))))
+    try:
+        chunk_mb = max(1, int(os.environ.get("PPM_IO_CHUNK_MB", chunk_mb)))
+    except ValueError:
+        pass
+    if chunk is None:       # page-locked buffers of PPM_IO_CHUNK_MB: pinning costs ~0.27 s per GB and sits in front of the first chunks
+        chunk = int(os.environ.get("PPM_IO_CHUNK", str(max(16, (chunk_mb << 20) // (box * box * 4)))))
     chunk = max(1, min(chunk, n))
     nchunks = (n + chunk - 1) // chunk
+    if call_mb:             # the device call's size in MB instead of a chunk count
+        group = int(os.environ.get("PPM_IO_GROUP", str(max(1, (call_mb << 20) // max(1, chunk * box * box * 4)))))
     group = max(1, min(int(group), nchunks))
     idx = positions.astype(np.int64) - 1
     contiguous = bool(np.all(np.diff(idx) == 1))
@@ -125,16 +141,25 @@ def _iter_image_chunks(mm, positions, device, chunk=None, group=1):
     lib.init(device)
     sec = box * box * 4
     npin, ndev = min(3, nchunks), min(2, (nchunks + group - 1) // group)
+    warm = sys.modules.get("pyp_amd.surface.warm")
+    if warm:
+        warm.limit(npin)
     pinned, dev = [None] * npin, [None] * ndev
     nread = max(1, min(16, int(os.environ.get("PPM_IO_THREADS", "8"))))
-    pool = ThreadPoolExecutor(nread) if nread > 1 else None
     # pread straight from the file when the data block is plain little-endian float32 (what PYP writes); otherwise through the map
     fd = None
     if contiguous and mm.dtype == np.dtype("<f4") and getattr(mm, "filename", None):
         fd = os.open(mm.filename, os.O_RDONLY)
+    pool = ThreadPoolExecutor(nread) if nread > 1 else None
     off0 = int(getattr(mm, "offset", 0))
 
+    native = os.environ.get("PPM_IO_READER", "native") != "python"
+
     def fill(buf, lo, hi):
+        if fd is not None and native:      # the library's reader pool: nread concurrent preads into the page-locked buffer, the GIL released
+            if L.ppm_host_read(fd, off0 + int(idx[lo]) * sec, buf.ptr, (hi - lo) * sec, nread) != 0:
+                raise IOError(lib.last_error())
+            return
         dst = buf.array[:(hi - lo) * box * box].reshape(hi - lo, box, box)
 
         def part(a, e):
@@ -176,8 +201,8 @@ def _iter_image_chunks(mm, positions, device, chunk=None, group=1):
                 if not wait(pin_free[slot]):
                     return
                 pin_free[slot].clear()
-                if pinned[slot] is None:
-                    pinned[slot] = host.PinnedBuffer(chunk * box * box, device)
+                if pinned[slot] is None:        # one the start-up thread page-locked while the inputs were read, else our own
+                    pinned[slot] = host.PinnedBuffer(chunk * box * box, device, ptr=warm.take(chunk * sec) if warm else None)
                 tb = time.time()
                 fill(pinned[slot], lo, hi)
                 stats["wait_pinned"] += tb - ta; stats["read"] += time.time() - tb
@@ -357,7 +382,7 @@ def refine3d_main(argv=None, stdin=None):
             ref = host.Reference(vol, box / 2, device=dev, pad=pad, ring_weight=ring_w)
             t2 = time.time()
             rout = np.empty_like(rin)
-            for lo, hi, imgs in _iter_image_chunks(mm, rin[:, C["POSITION_IN_STACK"]], dev, group=int(os.environ.get("PPM_IO_GROUP", "2"))):
+            for lo, hi, imgs in _iter_image_chunks(mm, rin[:, C["POSITION_IN_STACK"]], dev, call_mb=512, chunk_mb=64):
                 rout[lo:hi] = ref.refine(cfg, imgs, rin[lo:hi])
             t3 = time.time()
             note = ref.note()
@@ -406,16 +431,33 @@ def refine3d_main(argv=None, stdin=None):
     print(f"\nRefined {len(rout)} particles in {time.time() - t0:.1f} s; mean score {rout[:, C['SCORE']].mean():.4f}")
     print(f"Timing: inputs {t1 - t0:.2f} s, device + reference {t2 - t1:.2f} s, particles {t3 - t2:.2f} s, outputs {time.time() - t3:.2f} s")
     print("Pipeline: " + _pipeline_stats())
+    _release_warm()
     print("\nRefine3D: Normal termination\n", flush=True)
     return 0
 
 
 # ------------------------------------------------------------------------------------------ dumps
 def write_dump(path, box, pixel, count, data):
+    """One accumulator half under a temporary name, renamed when complete.  The data block (201 MB at 256^3) is written by four
+    threads at their own offsets, straight from the array (no intermediate bytes object)."""
+    from concurrent.futures import ThreadPoolExecutor
     tmp = path + ".tmp%d" % os.getpid()
-    with open(tmp, "wb") as f:
-        f.write(DUMP_MAGIC + struct.pack("<ifq", box, pixel, count))
-        f.write(np.ascontiguousarray(data, dtype="<f4").tobytes())
+    data = np.ascontiguousarray(data, dtype="<f4")
+    view = memoryview(data).cast("B")
+    head = DUMP_MAGIC + struct.pack("<ifq", box, pixel, count)
+    fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o666)
+    try:
+        os.pwrite(fd, head, 0)
+        os.ftruncate(fd, len(head) + len(view))
+
+        def part(a, e):
+            while a < e:
+                a += os.pwrite(fd, view[a:min(e, a + (64 << 20))], len(head) + a)
+        cuts = [len(view) * k // 4 for k in range(5)]
+        with ThreadPoolExecutor(4) as ex:
+            list(ex.map(lambda ae: part(*ae), zip(cuts[:-1], cuts[1:])))
+    finally:
+        os.close(fd)
     os.replace(tmp, path)
 
 
@@ -505,7 +547,7 @@ def reconstruct3d_main(argv=None, stdin=None):
                 if vol.shape != (box, box, box):
                     _die(f"ERROR: reconstruct3d: reference is {vol.shape}, particles are {box}^2")
                 blur_ref = host.Reference(vol, box / 2, device=dev)
-            for lo, hi, imgs in _iter_image_chunks(mm, rin[:, C["POSITION_IN_STACK"]], dev, group=1 if d["likelihood_blurring"] else int(os.environ.get("PPM_IO_GROUP", "8"))):
+            for lo, hi, imgs in _iter_image_chunks(mm, rin[:, C["POSITION_IN_STACK"]], dev, group=1, call_mb=0 if d["likelihood_blurring"] else 2048):
                 if blur_ref is None:
                     acc.insert(rc, imgs, rin[lo:hi])
                 else:
@@ -523,8 +565,13 @@ def reconstruct3d_main(argv=None, stdin=None):
     except (lib.PpmError, ValueError) as e:
         _die(str(e))
     half = data.size // 2
+    import threading
+    w2 = threading.Thread(target=write_dump, args=(d["dump_2"], box, px, counts[0], data[:half]))      # even keys -> map 2
+    w2.start()
     write_dump(d["dump_1"], box, px, counts[1], data[half:])      # odd keys  -> map 1
-    write_dump(d["dump_2"], box, px, counts[0], data[:half])      # even keys -> map 2
+    w2.join()
+    if not os.path.exists(d["dump_2"]):
+        _die(f"ERROR: reconstruct3d: could not write {d['dump_2']}")
     with open(d["res_file"], "w") as f:
         f.write("C Reconstruct3D (libpypmatch): particles %d..%d, inserted %d + %d\n" % (d["first"], d["last"], counts[1], counts[0]))
     print(f"\nInserted {counts[0] + counts[1]} of {len(rin)} particles in {time.time() - t0:.1f} s")
@@ -533,6 +580,7 @@ def reconstruct3d_main(argv=None, stdin=None):
     print("NOTE: the dump files are in libpypmatch's own format (PPMDUMP1): only this build's local_merge3d / merge3d read them "
           "(frealign.py:1852 consumers must be replaced together, INTEGRATION.md 1)")
     print("\nNormal termination, intermediate files dumped")
+    _release_warm()
     print("\nReconstruct3D: Normal termination\n", flush=True)
     return 0
 

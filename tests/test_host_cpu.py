@@ -135,3 +135,26 @@ def test_score_selection_rules():
     assert 0.3 < (g[:, 11] > 0).mean() < 0.8
     auto = select.select_particles(rows, threshold=0)          # reconstruct_cutoff = 0: the bimodal automatic threshold
     assert auto.shape == rows.shape and 0 < (auto[:, 11] > 0).sum() <= len(rows)
+
+
+def test_host_read_fills_a_buffer_from_a_file_with_any_thread_count(tmp_path):
+    """ppm_host_read (the executables' reader stage): no device call, so it runs here.  Parts start at MB boundaries; offsets and
+    lengths that are not multiples of anything; a short file and an empty request."""
+    import os
+    from pyp_amd import lib
+    L = lib.load()
+    a = np.random.default_rng(0).integers(0, 255, (9 << 20) + 12345, dtype=np.uint8)
+    p = tmp_path / "blob.bin"
+    p.write_bytes(a.tobytes())
+    fd = os.open(p, os.O_RDONLY)
+    try:
+        for nt in (1, 3, 8, 16, 99):
+            out = np.zeros(len(a) - 1001, np.uint8)
+            assert L.ppm_host_read(fd, 1001, out.ctypes.data, out.size, nt) == 0
+            assert np.array_equal(out, a[1001:])
+        out = np.zeros(len(a) + 10, np.uint8)
+        assert L.ppm_host_read(fd, 0, out.ctypes.data, out.size, 4) == -5 and "short read" in lib.last_error()
+        assert L.ppm_host_read(fd, 0, None, 0, 4) == 0
+        assert L.ppm_host_read(-1, 0, out.ctypes.data, 10, 4) == -22
+    finally:
+        os.close(fd)
