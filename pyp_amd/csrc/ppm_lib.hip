@@ -1677,8 +1677,17 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
             if (w < 1e-3) continue;
             sh_s[sh].push_back(sva_pack(kx, ky, kz)); sh_w[sh].push_back((float)w);
         }
+        // inside a shell the samples follow a Z-order curve: the 64 lanes of a wave gather from a compact patch of the reference
+        // cube instead of a ring around it (fewer cache lines per gather)
+        auto spread = [](uint32_t v) { uint64_t x = v & 0x3ffu; x = (x | x << 16) & 0x30000ffull; x = (x | x << 8) & 0x300f00full; x = (x | x << 4) & 0x30c30c3ull; x = (x | x << 2) & 0x9249249ull; return x; };
         for (int sh = 0; sh <= R; sh++) {
-            samples.insert(samples.end(), sh_s[sh].begin(), sh_s[sh].end()); bandw.insert(bandw.end(), sh_w[sh].begin(), sh_w[sh].end());
+            std::vector<std::pair<uint64_t, int>> key(sh_s[sh].size());
+            for (size_t i = 0; i < key.size(); i++) {
+                int kx, ky, kz; sva_unpack(sh_s[sh][i], kx, ky, kz);
+                key[i] = { spread((uint32_t)kx) | spread((uint32_t)(ky + R)) << 1 | spread((uint32_t)(kz + R)) << 2, (int)i };
+            }
+            std::sort(key.begin(), key.end());
+            for (const auto &k : key) { samples.push_back(sh_s[sh][k.second]); bandw.push_back(sh_w[sh][k.second]); }
             shell_off[sh + 1] = (int)samples.size();
         }
     }
@@ -1729,14 +1738,14 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
         const int hc = getenv("PPM_SVA_CHUNK") ? std::max(1, atoi(getenv("PPM_SVA_CHUNK"))) : (int)std::max<size_t>(1, ((size_t)7 << 30) / (n3 * 4));
         CH = std::min(CH, hc);
     }
-    DevTmp<uint32_t> d_samples; DevTmp<float> d_bandw, d_vols, d_wedges, d_grid, d_gscore; DevTmp<float2> d_f, d_F; DevTmp<double> d_stats, d_poses, d_delta, d_out;
+    DevTmp<uint32_t> d_samples; DevTmp<float> d_bandw, d_vols, d_wedges, d_grid, d_gscore; DevTmp<float2> d_f, d_F; DevTmp<double> d_stats, d_poses, d_delta, d_out, d_partial;
     DevTmp<int> d_vmap;
     const int KX = std::min(N / 2 + 1, R + 1);          // x coefficients kept; |ky|, |kz| <= R are the lines the later passes touch
     const int NB = std::min(CH, 32);                     // sub-volumes transformed per launch (work array: NB x N x N x KX complex)
     HIPCHK(d_samples.alloc(S)); HIPCHK(d_bandw.alloc(S)); HIPCHK(d_f.alloc((size_t)NB * N * N * KX)); HIPCHK(d_F.alloc((size_t)CH * S));
     const size_t CHS = (size_t)CH * (global ? Kc : 1);       // states per chunk: the global search refines Kc candidates per sub-volume
     HIPCHK(d_stats.alloc((size_t)2 * CH)); HIPCHK(d_poses.alloc((size_t)12 * CHS)); HIPCHK(d_delta.alloc(CHS * ncand * 6)); HIPCHK(d_out.alloc(CHS * ncand));
-    HIPCHK(d_vmap.alloc(CHS));
+    HIPCHK(d_vmap.alloc(CHS)); HIPCHK(d_partial.alloc(CHS * kSvaParts * (2 * kMaxCand + 1)));
     if (global) {
         std::vector<float> gf(grid_d.begin(), grid_d.end());
         HIPCHK(d_grid.alloc(gf.size())); HIPCHK(d_gscore.alloc((size_t)CH * n_grid));
@@ -1751,7 +1760,7 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
     SvaEvalP EP;
     EP.cv.cube = ref->cube; EP.cv.NBX = ref->NBX; EP.cv.NBY = ref->NBY; EP.cv.LB = ref->LB; EP.cv.off = ref->B + 1; EP.cv.scale = 1.f;
     EP.samples = d_samples.p; EP.bandw = d_bandw.p; EP.F = d_F.p; EP.S = S; EP.N = N; EP.use_wedge = cfg->use_missing_wedge != 0;
-    EP.wedges = d_wedges.p; EP.poses = d_poses.p; EP.delta = d_delta.p; EP.out = d_out.p; EP.vmap = nullptr;
+    EP.wedges = d_wedges.p; EP.poses = d_poses.p; EP.delta = d_delta.p; EP.out = d_out.p; EP.vmap = nullptr; EP.partial = d_partial.p;
     std::vector<float> hw((size_t)2 * CH);
     std::vector<double> hdelta, hout;
     if (!volumes_on_device) {       // first chunk
@@ -1829,7 +1838,11 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
         auto sweep = [&](int ns_, int nc, int nr_, double rb) -> int {
             HIPCHK(hipMemcpyAsync(d_delta.p, hdelta.data(), (size_t)ns_ * nc * 6 * sizeof(double), hipMemcpyHostToDevice, cur_stream()));
             EP.ncand = nc; EP.nrot = nr_; EP.S_used = prefix_of(rb); EP.rmax2 = (float)(rb * rb);
-            { ProfScope ps(PPM_K_LOCAL); hipLaunchKernelGGL(k_sva_eval, dim3(ns_), dim3(256), 0, cur_stream(), EP); }
+            {
+                ProfScope ps(PPM_K_LOCAL);
+                hipLaunchKernelGGL(k_sva_eval, dim3(ns_, kSvaParts), dim3(256), 0, cur_stream(), EP);
+                hipLaunchKernelGGL(k_sva_finish, dim3((unsigned)((ns_ * nc + 255) / 256)), dim3(256), 0, cur_stream(), EP.partial, ns_, nc, nr_, d_out.p);
+            }
             HIPCHK(hipGetLastError());
             hout.resize((size_t)ns_ * nc);
             HIPCHK(hipMemcpyAsync(hout.data(), d_out.p, hout.size() * sizeof(double), hipMemcpyDeviceToHost, cur_stream()));

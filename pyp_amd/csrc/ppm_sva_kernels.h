@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(256) k_sva_xpass(SvaXP P) {
 
 // packed sample: kx (10 bits) | ky + 512 (11 bits) << 10 | kz + 512 (11 bits) << 21
 __host__ __device__ __forceinline__ uint32_t sva_pack(int kx, int ky, int kz) { return (uint32_t)kx | ((uint32_t)(ky + 512) << 10) | ((uint32_t)(kz + 512) << 21); }
-__device__ __forceinline__ void sva_unpack(uint32_t u, int &kx, int &ky, int &kz) { kx = (int)(u & 1023u); ky = (int)((u >> 10) & 2047u) - 512; kz = (int)(u >> 21) - 512; }
+__host__ __device__ __forceinline__ void sva_unpack(uint32_t u, int &kx, int &ky, int &kz) { kx = (int)(u & 1023u); ky = (int)((u >> 10) & 2047u) - 512; kz = (int)(u >> 21) - 512; }
 
 // band-limited half-space transform of one sub-volume out of the compact [z][y][KX] array, origin moved to the box centre
 // (grid.y = sub-volume of the batch)
@@ -85,7 +85,11 @@ struct SvaEvalP {
     const double *delta;          // [n_vol][ncand][6]
     double *out;                  // [n_vol][ncand]
     const int *vmap;              // null, or [n_states]: the sub-volume (transform, wedge) a state belongs to; poses / delta / out are per STATE
+    double *partial;              // [n_states][kSvaParts][2 kMaxCand + 1]: every block's sums (k_sva_finish combines them in part order)
 };
+// A state's samples are dealt out over kSvaParts blocks (grid.y): one block per sub-volume left the chip at two waves per SIMD
+// with every gather's latency exposed.  The number is a constant, so a sub-volume's result does not depend on its batch.
+constexpr int kSvaParts = 4;
 
 // Block = one sub-volume: thread q < ncand derives candidate q's pose in double precision (rotations about the specimen
 // axes, then the shift, exactly like a particle unit of k_csp_eval).  Candidate layout (host): 0 = the unit's own pose (or the
@@ -95,7 +99,7 @@ struct SvaEvalP {
 __global__ void __launch_bounds__(256) k_sva_eval(SvaEvalP P) {
     __shared__ float cm[kMaxCand][9], csh[kMaxCand][3];
     __shared__ float red[4][2 * kMaxCand + 1];
-    const int st = blockIdx.x, v = P.vmap ? P.vmap[st] : st, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ncand = P.ncand, nrot = P.nrot;
+    const int st = blockIdx.x, part = blockIdx.y, v = P.vmap ? P.vmap[st] : st, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ncand = P.ncand, nrot = P.nrot;
     if (tid < ncand) {
         const double *d = P.delta + ((size_t)st * ncand + tid) * 6, *pose = P.poses + (size_t)st * 12;
         double Nm[9];
@@ -115,7 +119,7 @@ __global__ void __launch_bounds__(256) k_sva_eval(SvaEvalP P) {
     for (int c = 0; c < kMaxCand; c++) A[c] = 0.f;
 #pragma unroll
     for (int g = 0; g < kMaxGroup; g++) B[g] = 0.f;
-    for (int s = tid; s < P.S_used; s += 256) {
+    for (int s = part * 256 + tid; s < P.S_used; s += 256 * kSvaParts) {
         int kx, ky, kz; sva_unpack(P.samples[s], kx, ky, kz);
         float w = P.bandw[s];
         if (!((float)(kx * kx + ky * ky + kz * kz) < P.rmax2)) w = 0.f;
@@ -155,13 +159,19 @@ __global__ void __launch_bounds__(256) k_sva_eval(SvaEvalP P) {
     for (int g = 0; g < kMaxGroup; g++) { const float t = wave_sum(B[g]); if (lane == 0) red[wave][kMaxCand + g] = t; }
     { const float t = wave_sum(Csum); if (lane == 0) red[wave][2 * kMaxCand] = t; }
     __syncthreads();
-    if (tid < ncand) {
-        const int g = (tid >= 1 && tid <= nrot) ? tid : 0;
-        const double a = (((double)red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
-        const double b = (((double)red[0][kMaxCand + g] + red[1][kMaxCand + g]) + red[2][kMaxCand + g]) + red[3][kMaxCand + g];
-        const double c = (((double)red[0][2 * kMaxCand] + red[1][2 * kMaxCand]) + red[2][2 * kMaxCand]) + red[3][2 * kMaxCand];
-        P.out[(size_t)st * ncand + tid] = (b > 0 && c > 0) ? a / sqrt(b * c) : 0.0;
-    }
+    if (tid < 2 * kMaxCand + 1)
+        P.partial[((size_t)st * kSvaParts + part) * (2 * kMaxCand + 1) + tid] = (((double)red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+}
+
+// scores of k_sva_eval's candidates from the kSvaParts partial sums of every state, added in part order
+__global__ void k_sva_finish(const double *__restrict__ partial, int n_states, int ncand, int nrot, double *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_states * ncand) return;
+    const int st = i / ncand, q = i - st * ncand, g = (q >= 1 && q <= nrot) ? q : 0;
+    const double *p = partial + (size_t)st * kSvaParts * (2 * kMaxCand + 1);
+    double a = 0, b = 0, c = 0;
+    for (int k = 0; k < kSvaParts; k++, p += 2 * kMaxCand + 1) { a += p[q]; b += p[kMaxCand + g]; c += p[2 * kMaxCand]; }
+    out[i] = (b > 0 && c > 0) ? a / sqrt(b * c) : 0.0;
 }
 
 // Global rotational grid (ppm_sva_cfg.search_mode 1, include/ppm.h): block = (sub-volume, run of RC grid rotations).  A rotation's
