@@ -24,25 +24,31 @@ struct FftLinesP {
 
 __global__ void __launch_bounds__(256) k_fft_lines(FftLinesP P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ long lbase[16];                       // first element of every line of the block (P.L <= 16)
+    __shared__ float2 tw_s[512];
     float2 *buf = (float2 *)smem;
-    const int tid = threadIdx.x, n = P.n;
+    const int tid = threadIdx.x, n = P.n, LS = n + 1;      // odd line stride: line-major passes touch 16 lines at the same element
     long l0 = (long)blockIdx.x * P.L;
     int nl = (int)((P.nlines - l0) < P.L ? (P.nlines - l0) : P.L);
     if (nl <= 0) return;
-    for (int i = tid; i < nl * n; i += 256) {
-        int line, e;
-        if (P.line_major) { line = i % nl; e = i / nl; } else { line = i / n; e = i % n; }
-        long l = l0 + line;
-        long base = (l / P.inner) * P.outer_stride + (l % P.inner) * P.inner_stride;
-        buf[line * n + P.plan.perm[e]] = P.data[base + e * P.elem_stride];
+    if (tid < nl) { const long l = l0 + tid; lbase[tid] = (l / P.inner) * P.outer_stride + (l % P.inner) * P.inner_stride; }
+    for (int i = tid; i < n; i += 256) tw_s[i] = P.plan.tw[i];       // the stages' twiddles from LDS instead of dependent global loads
+    __syncthreads();
+    // (line, e) of element i = tid, tid + 256, ... without a division per element
+    const int dl = P.line_major ? 256 % nl : 256 / n, de = P.line_major ? 256 / nl : 256 % n;
+    const int line0 = P.line_major ? tid % nl : tid / n, e0 = P.line_major ? tid / nl : tid % n;
+    auto next = [&](int &line, int &e) {
+        line += dl; e += de;
+        if (P.line_major) { if (line >= nl) { line -= nl; e++; } } else if (e >= n) { e -= n; line++; }
+    };
+    {
+        int line = line0, e = e0;
+        for (int i = tid; i < nl * n; i += 256, next(line, e)) buf[line * LS + P.plan.perm[e]] = P.data[lbase[line] + e * P.elem_stride];
     }
-    lds_fft(buf, P.plan, nl, n, P.inverse != 0, tid, 256);
-    for (int i = tid; i < nl * n; i += 256) {
-        int line, e;
-        if (P.line_major) { line = i % nl; e = i / nl; } else { line = i / n; e = i % n; }
-        long l = l0 + line;
-        long base = (l / P.inner) * P.outer_stride + (l % P.inner) * P.inner_stride;
-        P.data[base + e * P.elem_stride] = buf[line * n + e];
+    lds_fft(buf, P.plan, nl, LS, P.inverse != 0, tid, 256, tw_s);
+    {
+        int line = line0, e = e0;
+        for (int i = tid; i < nl * n; i += 256, next(line, e)) P.data[lbase[line] + e * P.elem_stride] = buf[line * LS + e];
     }
 }
 

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <cerrno>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <map>
@@ -101,6 +102,17 @@ struct ProfScope {
     ~ProfScope() { if (a) { hipEvent_t b = ev_get(); (void)hipEventRecord(b, cur_stream()); std::lock_guard<std::mutex> lk(g_mu); g.pending.push_back({ id, a, b }); } }
 };
 
+// PPM_TRACE=1: wall-clock marks of a call on stderr (the device is synchronised at every mark, so the phases do not overlap when tracing)
+struct Trace {
+    const char *who; bool on; std::chrono::steady_clock::time_point t0;
+    explicit Trace(const char *w) : who(w), on(getenv("PPM_TRACE") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    void mark(const char *what) const {
+        if (!on) return;
+        (void)hipStreamSynchronize(cur_stream());
+        fprintf(stderr, "%s: %8.2f ms  %s\n", who, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), what);
+    }
+};
+
 int ensure_plan(int n) {
     if (n < 2 || n > 512) return fail(-22, "FFT length out of range");
     std::lock_guard<std::mutex> lk(g_mu);
@@ -126,7 +138,7 @@ int ensure_plan(int n) {
 // 3-D FFT of an n^3 complex array in place (three strided passes through LDS)
 int fft3d(float2 *d, int n, bool inverse) {
     if (int rc = ensure_plan(n)) return rc;
-    int L = std::max(1, std::min(16, 8192 / n));
+    int L = std::max(1, std::min(16, 7600 / (n + 1)));
     while (((long)n * n) % L) L--;
     long nlines = (long)n * n;
     for (int pass = 0; pass < 3; pass++) {
@@ -136,7 +148,7 @@ int fft3d(float2 *d, int n, bool inverse) {
         else if (pass == 1) { P.inner = n; P.inner_stride = 1; P.outer_stride = (long)n * n; P.elem_stride = n; P.line_major = 1; }
         else { P.inner = nlines; P.inner_stride = 1; P.outer_stride = 0; P.elem_stride = (long)n * n; P.line_major = 1; }
         unsigned blocks = (unsigned)((nlines + L - 1) / L);
-        hipLaunchKernelGGL(k_fft_lines, dim3(blocks), dim3(256), (size_t)L * n * sizeof(float2), cur_stream(), P);
+        hipLaunchKernelGGL(k_fft_lines, dim3(blocks), dim3(256), (size_t)L * (n + 1) * sizeof(float2), cur_stream(), P);
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -146,12 +158,12 @@ int fft3d(float2 *d, int n, bool inverse) {
 static int fft_lines_pass(float2 *d, int n, long nlines, long inner, long inner_stride, long outer_stride, long elem_stride, int line_major, bool inverse) {
     if (nlines <= 0) return 0;
     if (int rc = ensure_plan(n)) return rc;
-    int L = std::max(1, std::min(16, 8192 / n));
+    int L = std::max(1, std::min(16, 7600 / (n + 1)));
     while (nlines % L) L--;
     FftLinesP P;
     P.data = d; P.plan = g.plans[n].plan; P.n = n; P.inverse = inverse ? 1 : 0; P.L = L; P.nlines = nlines;
     P.inner = inner; P.inner_stride = inner_stride; P.outer_stride = outer_stride; P.elem_stride = elem_stride; P.line_major = line_major;
-    hipLaunchKernelGGL(k_fft_lines, dim3((unsigned)((nlines + L - 1) / L)), dim3(256), (size_t)L * n * sizeof(float2), cur_stream(), P);
+    hipLaunchKernelGGL(k_fft_lines, dim3((unsigned)((nlines + L - 1) / L)), dim3(256), (size_t)L * (n + 1) * sizeof(float2), cur_stream(), P);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -195,6 +207,11 @@ struct ppm_ref {
     // constrained search (ppm_csp_refine)
     DevBuf<float2> c_Il, c_band; DevBuf<float> c_cw, c_img, c_wring; DevBuf<double> c_rows, c_N, c_p, c_tl, c_delta, c_s0, c_g0, c_out;
     DevBuf<int> c_eval, c_rp, c_rt, c_slot, c_uoff; DevBuf<LState> c_states; DevBuf<double> c_mean;
+    // sub-tomogram alignment (ppm_sva_align): the transforms' work array, the band-limited transforms of a chunk, staged host volumes
+    // (GBs: allocating and freeing them on every call cost ~20 ms of a 120 ms call)
+    DevBuf<float2> s_f, s_F; DevBuf<float> s_vols;
+    // the band's sample list (built and sorted on the host: ~25 ms at 192^3 / 452 k samples) is kept while the band-pass settings stay
+    struct { bool valid = false; float key[5] = { 0, 0, 0, 0, 0 }; int S = 0; std::vector<int> shell_off; DevBuf<uint32_t> samples; DevBuf<float> bandw; } s_plan;
     DevBuf<float2> band, Il, Wp, bank, twN;
     DevBuf<float4> rowtw;            // k_global's row-pair twiddles for this reference's current search grid
     DevBuf<int> sh;
@@ -571,6 +588,7 @@ void ppm_reference_destroy(ppm_ref_t *r) {
     if (r->cube) (void)hipFree(r->cube);
     r->rows_in.release(); r->rows_out.release(); r->dir_theta.release(); r->dir_phi.release();
     r->images.release(); r->wring.release(); r->cw.release(); r->C2.release(); r->nP.release(); r->nI.release();
+    r->s_f.release(); r->s_F.release(); r->s_vols.release(); r->s_plan.samples.release(); r->s_plan.bandw.release();
     r->c_Il.release(); r->c_band.release(); r->c_cw.release(); r->c_img.release(); r->c_wring.release(); r->c_rows.release(); r->c_N.release(); r->c_p.release(); r->c_tl.release();
     r->c_delta.release(); r->c_s0.release(); r->c_g0.release(); r->c_out.release(); r->c_eval.release(); r->c_rp.release(); r->c_rt.release(); r->c_slot.release(); r->c_states.release(); r->c_uoff.release(); r->c_mean.release(); r->cc.release(); r->mats.release(); r->ddef.release();
     r->band.release(); r->Il.release(); r->Wp.release(); r->bank.release(); r->twN.release(); r->rowtw.release(); r->sh.release(); r->samples.release();
@@ -583,7 +601,7 @@ void ppm_reference_destroy(ppm_ref_t *r) {
 // 2-D FFTs of `nimg` complex n x n images in place (rows, then columns)
 static int fft2d_batch(float2 *d, int n, long nimg, bool inverse) {
     if (int rc = ensure_plan(n)) return rc;
-    int L = std::max(1, std::min(16, 8192 / n));
+    int L = std::max(1, std::min(16, 7600 / (n + 1)));
     const long nlines = nimg * n;
     while (nlines % L) L--;
     for (int pass = 0; pass < 2; pass++) {
@@ -591,7 +609,7 @@ static int fft2d_batch(float2 *d, int n, long nimg, bool inverse) {
         P.data = d; P.plan = g.plans[n].plan; P.n = n; P.inverse = inverse ? 1 : 0; P.L = L; P.nlines = nlines;
         if (pass == 0) { P.inner = nlines; P.inner_stride = n; P.outer_stride = 0; P.elem_stride = 1; P.line_major = 0; }
         else { P.inner = n; P.inner_stride = 1; P.outer_stride = (long)n * n; P.elem_stride = n; P.line_major = 1; }
-        hipLaunchKernelGGL(k_fft_lines, dim3((unsigned)((nlines + L - 1) / L)), dim3(256), (size_t)L * n * sizeof(float2), cur_stream(), P);
+        hipLaunchKernelGGL(k_fft_lines, dim3((unsigned)((nlines + L - 1) / L)), dim3(256), (size_t)L * (n + 1) * sizeof(float2), cur_stream(), P);
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -1394,6 +1412,8 @@ extern "C" int ppm_csp_refine(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const p
         return rit < gm.r_hi ? rit : gm.r_hi;
     };
 
+    const Trace trace_("ppm_csp_refine");
+    trace_.mark("host tables");
     // ---- device: sample list, prepared spectra of all rows
     SampleList sl; build_samples(gm, sl);
     const int S_pad = (int)sl.packed.size(), nrings = gm.B + 2;
@@ -1543,6 +1563,7 @@ extern "C" int ppm_csp_refine(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const p
         return 0;
     };
     if (int rc = upload_units()) return rc;
+    trace_.mark("spectra prepared, units uploaded");
     double ha = ha0, hs = hs0;
     std::vector<double> mean, tmean, dtrial((size_t)active.size() * 6);
     std::vector<int> cand_param, cand_sign;      // candidate c >= 1 moves parameter cand_param[c] by cand_sign[c] h
@@ -1598,9 +1619,11 @@ extern "C" int ppm_csp_refine(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const p
         if (int rc = upload_units()) return rc;
         ha *= 0.5; hs *= 0.5;
     }
+    trace_.mark("searched");
     // ---- final scores of every row of the refined units at the full band; write-back
     hdelta.assign((size_t)std::max(n_slots, 1) * 6, 0.0);
     if (int rc = sweep(final_rows, 1, gm.r_hi, nullptr)) return rc;
+    trace_.mark("final scores");
     std::vector<double> row_score(n_proj, 0.0);
     for (size_t q = 0; q < final_rows.size(); q++) row_score[final_rows[q]] = hout[q];
     for (int i = 0; i < n_tilt; i++) tilt_rotations(tls[i].tl[0], tls[i].tl[1], trot[i]);       // the tilts may have moved
@@ -1654,6 +1677,8 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
     if (!ref || !cfg || !volumes || !poses) return fail(-22, "null argument");
     StreamScope ss_(ref->stream, ref->copy);
     if (n_vol <= 0) return 0;
+    const Trace trace_("ppm_sva_align");
+    auto mark = [&](const char *what) { trace_.mark(what); };
     const int N = cfg->box;
     if (!box_ok(N) || N != ref->N) return fail(-22, "sub-volume box differs from the reference box (even, 32..512, prime factors 2, 3, 5)");
     if (ref->pad != 1) return fail(-22, "sub-tomogram alignment needs a reference prepared with padding 1");
@@ -1663,7 +1688,10 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
     // ---- sample list of the band (half space, shell by shell), common to all sub-volumes; the wedge is applied per volume
     const int R = (int)std::ceil(rband);
     std::vector<uint32_t> samples; std::vector<float> bandw; std::vector<int> shell_off(R + 2, 0);
-    {
+    const float plan_key[5] = { (float)N, cfg->highpass_cutoff, cfg->highpass_decay, cfg->lowpass_cutoff, cfg->lowpass_decay };
+    const bool plan_cached = ref->s_plan.valid && std::memcmp(plan_key, ref->s_plan.key, sizeof(plan_key)) == 0;
+    if (plan_cached) shell_off = ref->s_plan.shell_off;
+    else {
         // one pass over the half space, bucketed by shell (the order inside a shell is the scan order kz, ky, kx)
         std::vector<std::vector<uint32_t>> sh_s(R + 1); std::vector<std::vector<float>> sh_w(R + 1);
         for (int kz = -R; kz <= R; kz++) for (int ky = -R; ky <= R; ky++) for (int kx = 0; kx <= R; kx++) {
@@ -1677,21 +1705,27 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
             if (w < 1e-3) continue;
             sh_s[sh].push_back(sva_pack(kx, ky, kz)); sh_w[sh].push_back((float)w);
         }
-        // inside a shell the samples follow a Z-order curve: the 64 lanes of a wave gather from a compact patch of the reference
-        // cube instead of a ring around it (fewer cache lines per gather)
+        // inside a shell the samples are grouped by tilt angle and follow a Z-order curve inside a group: the 64 lanes of a wave gather
+        // from a compact patch of the reference cube
         auto spread = [](uint32_t v) { uint64_t x = v & 0x3ffu; x = (x | x << 16) & 0x30000ffull; x = (x | x << 8) & 0x300f00full; x = (x | x << 4) & 0x30c30c3ull; x = (x | x << 2) & 0x9249249ull; return x; };
         for (int sh = 0; sh <= R; sh++) {
             std::vector<std::pair<uint64_t, int>> key(sh_s[sh].size());
             for (size_t i = 0; i < key.size(); i++) {
                 int kx, ky, kz; sva_unpack(sh_s[sh][i], kx, ky, kz);
-                key[i] = { spread((uint32_t)kx) | spread((uint32_t)(ky + R)) << 1 | spread((uint32_t)(kz + R)) << 2, (int)i };
+                // major key: the tilt angle of the sample's (kx, kz) direction in 4-degree bins, so that the samples a missing wedge
+                // removes are whole waves (k_sva_eval skips zero weights)
+                double ang = (kx == 0 && kz == 0) ? 0.0 : std::atan2((double)kz, (double)kx) * 180.0 / kPi;
+                if (ang > 90.0) ang -= 180.0;
+                if (ang <= -90.0) ang += 180.0;
+                const uint64_t bin = (uint64_t)std::floor((ang + 90.0) / 4.0);
+                key[i] = { bin << 40 | spread((uint32_t)kx) | spread((uint32_t)(ky + R)) << 1 | spread((uint32_t)(kz + R)) << 2, (int)i };
             }
             std::sort(key.begin(), key.end());
             for (const auto &k : key) { samples.push_back(sh_s[sh][k.second]); bandw.push_back(sh_w[sh][k.second]); }
             shell_off[sh + 1] = (int)samples.size();
         }
     }
-    const int S = (int)samples.size();
+    const int S = plan_cached ? ref->s_plan.S : (int)samples.size();
     if (S == 0) return fail(-22, "the band-pass filter leaves no Fourier samples");
     auto prefix_of = [&](double rb) { int rg = (int)std::ceil(rb); if (rg > R + 1) rg = R + 1; return shell_off[rg]; };
     // ---- search plan (the particle unit of the constrained search: rotations about the specimen axes + 3-D shift)
@@ -1738,11 +1772,26 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
         const int hc = getenv("PPM_SVA_CHUNK") ? std::max(1, atoi(getenv("PPM_SVA_CHUNK"))) : (int)std::max<size_t>(1, ((size_t)7 << 30) / (n3 * 4));
         CH = std::min(CH, hc);
     }
-    DevTmp<uint32_t> d_samples; DevTmp<float> d_bandw, d_vols, d_wedges, d_grid, d_gscore; DevTmp<float2> d_f, d_F; DevTmp<double> d_stats, d_poses, d_delta, d_out, d_partial;
+    struct { uint32_t *p; } d_samples{nullptr}; struct { float *p; } d_bandw{nullptr};       // the handle's cached sample plan
+    DevTmp<float> d_wedges, d_grid, d_gscore; DevTmp<double> d_stats, d_poses, d_delta, d_out, d_partial;
+    struct { float2 *p; } d_f{nullptr}, d_F{nullptr};       // views of the handle's cached work arrays
+    struct { float *p; } d_vols{nullptr};
     DevTmp<int> d_vmap;
     const int KX = std::min(N / 2 + 1, R + 1);          // x coefficients kept; |ky|, |kz| <= R are the lines the later passes touch
     const int NB = std::min(CH, 32);                     // sub-volumes transformed per launch (work array: NB x N x N x KX complex)
-    HIPCHK(d_samples.alloc(S)); HIPCHK(d_bandw.alloc(S)); HIPCHK(d_f.alloc((size_t)NB * N * N * KX)); HIPCHK(d_F.alloc((size_t)CH * S));
+    if (!plan_cached) {
+        ref->s_plan.valid = false;
+        if (int rc = ref->s_plan.samples.ensure(S)) return rc;
+        if (int rc = ref->s_plan.bandw.ensure(S)) return rc;
+        HIPCHK(hipMemcpyAsync(ref->s_plan.samples.p, samples.data(), (size_t)S * sizeof(uint32_t), hipMemcpyHostToDevice, cur_stream()));
+        HIPCHK(hipMemcpyAsync(ref->s_plan.bandw.p, bandw.data(), (size_t)S * sizeof(float), hipMemcpyHostToDevice, cur_stream()));
+        HIPCHK(hipStreamSynchronize(cur_stream()));        // the host vectors go out of use here
+        std::memcpy(ref->s_plan.key, plan_key, sizeof(plan_key)); ref->s_plan.S = S; ref->s_plan.shell_off = shell_off; ref->s_plan.valid = true;
+    }
+    d_samples.p = ref->s_plan.samples.p; d_bandw.p = ref->s_plan.bandw.p;
+    if (int rc = ref->s_f.ensure((size_t)NB * N * N * KX)) return rc;
+    if (int rc = ref->s_F.ensure((size_t)CH * S)) return rc;
+    d_f.p = ref->s_f.p; d_F.p = ref->s_F.p;
     const size_t CHS = (size_t)CH * (global ? Kc : 1);       // states per chunk: the global search refines Kc candidates per sub-volume
     HIPCHK(d_stats.alloc((size_t)2 * CH)); HIPCHK(d_poses.alloc((size_t)12 * CHS)); HIPCHK(d_delta.alloc(CHS * ncand * 6)); HIPCHK(d_out.alloc(CHS * ncand));
     HIPCHK(d_vmap.alloc(CHS)); HIPCHK(d_partial.alloc(CHS * kSvaParts * (2 * kMaxCand + 1)));
@@ -1753,9 +1802,7 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
     }
     HIPCHK(d_wedges.alloc((size_t)2 * CH));
     const bool two_bufs = !volumes_on_device && n_vol > CH;      // host volumes: the next chunk is uploaded by a helper thread while this one is searched
-    if (!volumes_on_device) HIPCHK(d_vols.alloc((size_t)(two_bufs ? 2 : 1) * CH * n3));
-    HIPCHK(hipMemcpyAsync(d_samples.p, samples.data(), (size_t)S * sizeof(uint32_t), hipMemcpyHostToDevice, cur_stream()));
-    HIPCHK(hipMemcpyAsync(d_bandw.p, bandw.data(), (size_t)S * sizeof(float), hipMemcpyHostToDevice, cur_stream()));
+    if (!volumes_on_device) { if (int rc = ref->s_vols.ensure((size_t)(two_bufs ? 2 : 1) * CH * n3)) return rc; d_vols.p = ref->s_vols.p; }
     SvaWin W; for (int k = 0; k < 3; k++) W.w[k] = cfg->window[k]; W.sigma = cfg->window_sigma;
     SvaEvalP EP;
     EP.cv.cube = ref->cube; EP.cv.NBX = ref->NBX; EP.cv.NBY = ref->NBY; EP.cv.LB = ref->LB; EP.cv.off = ref->B + 1; EP.cv.scale = 1.f;
@@ -1763,6 +1810,7 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
     EP.wedges = d_wedges.p; EP.poses = d_poses.p; EP.delta = d_delta.p; EP.out = d_out.p; EP.vmap = nullptr; EP.partial = d_partial.p;
     std::vector<float> hw((size_t)2 * CH);
     std::vector<double> hdelta, hout;
+    mark("set up");
     if (!volumes_on_device) {       // first chunk
         HIPCHK(hipMemcpyAsync(d_vols.p, volumes, (size_t)std::min(CH, n_vol) * n3 * sizeof(float), hipMemcpyHostToDevice, cur_copy()));
         HIPCHK(hipStreamSynchronize(cur_copy()));
@@ -1802,7 +1850,7 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
             hipLaunchKernelGGL(k_sva_stats, dim3(64, nb), dim3(256), 0, cur_stream(), dv, n3, d_stats.p);
             if (int rc = ensure_plan(N)) return rc;
             SvaXP XP; XP.stats = nullptr; XP.out = d_f.p; XP.plan = g.plans[N].plan; XP.n = N; XP.KX = KX; XP.nlines = (long)N * N; XP.W = W;
-            XP.L = std::max(1, std::min(16, 8192 / N));
+            XP.L = std::max(1, std::min(16, 7000 / N));
             while (((long)N * N) % XP.L) XP.L--;
             for (int v0 = 0; v0 < nb; v0 += NB) {
                 // pruned transform of NB sub-volumes per launch (k_sva_xpass): x pass from the real volumes into [vol][z][y][KX], y pass on
@@ -1822,6 +1870,7 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
             }
         }
         HIPCHK(hipGetLastError());
+        mark("chunk pre-processed");
         std::vector<CUnit> st(nb);
         for (int v = 0; v < nb; v++) { std::memcpy(st[v].N, poses + (size_t)(c0 + v) * 12, 9 * sizeof(double)); std::memcpy(st[v].p, poses + (size_t)(c0 + v) * 12 + 9, 3 * sizeof(double)); }
         std::vector<double> hp;
@@ -1965,6 +2014,7 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
             int Tf = m > steptol ? (int)std::ceil(std::log(m / steptol) / std::log(2.0)) : 0; Tf = std::min(12, Tf);
             if (int rc = compass(st, nullptr, eng, tolg, ha, hs, Tf)) return rc;
         }
+        mark("chunk searched");
         if (int rc = final_scores(st, nullptr)) return rc;
         for (int v = 0; v < nb; v++) {
             std::memcpy(poses + (size_t)(c0 + v) * 12, st[v].N, 9 * sizeof(double)); std::memcpy(poses + (size_t)(c0 + v) * 12 + 9, st[v].p, 3 * sizeof(double));

@@ -32,6 +32,8 @@ struct SvaXP { const float *vol; const double *stats; float2 *out; FftPlan plan;
 
 __global__ void __launch_bounds__(256) k_sva_xpass(SvaXP P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ float wx[512], wyz[16];               // window along x; window of every line's (y, z) (P.L <= 16, n <= 512)
+    __shared__ float2 tw_s[512];
     float2 *buf = (float2 *)smem;
     const int tid = threadIdx.x, n = P.n;
     const long l0 = (long)blockIdx.x * P.L;
@@ -41,22 +43,35 @@ __global__ void __launch_bounds__(256) k_sva_xpass(SvaXP P) {
     // P.L divides n * n: the lines of a block belong to one sub-volume of the batch (P.vol / P.out / P.stats point at its first one)
     const double *st = P.stats + 2 * (l0 / ((long)n * n));
     const double mu = st[0] / n3, var = st[1] / n3 - mu * mu, sd = var > 0 ? sqrt(var) : 1.0;
+    const float fmu = (float)mu, finv = (float)(1.0 / sd);
     auto win1 = [&](int c, int k) {
         if (!(P.W.w[k] > 0.f)) return 1.f;
         const float d = fabsf((float)c) - P.W.w[k];
         return d > 0.f ? (P.W.sigma > 0.f ? expf(-d * d / (2.f * P.W.sigma * P.W.sigma)) : 0.f) : 1.f;
     };
-    for (int i = tid; i < nl * n; i += 256) {
-        const int line = i / n, e = i - line * n;
-        const long l = l0 + line;
-        const int y = (int)(l % n), z = (int)((l / n) % n);
-        const float wv = win1(e - n / 2, 0) * win1(y - n / 2, 1) * win1(z - n / 2, 2);
-        buf[line * n + P.plan.perm[e]] = make_float2((float)(((double)P.vol[l * n + e] - mu) / sd) * wv, 0.f);
+    for (int e = tid; e < n; e += 256) { wx[e] = win1(e - n / 2, 0); tw_s[e] = P.plan.tw[e]; }
+    if (tid < nl) { const long l = l0 + tid; wyz[tid] = win1((int)(l % n) - n / 2, 1) * win1((int)((l / n) % n) - n / 2, 2); }
+    __syncthreads();
+    {   // (line, e) of element i = tid, tid + 256, ... without a division per element
+        const int dl = 256 / n, de = 256 % n;
+        int line = tid / n, e = tid % n;
+        const float *src = P.vol + l0 * n;
+        for (int i = tid; i < nl * n; i += 256) {
+            buf[line * n + P.plan.perm[e]] = make_float2((src[i] - fmu) * finv * (wx[e] * wyz[line]), 0.f);
+            line += dl; e += de;
+            if (e >= n) { e -= n; line++; }
+        }
     }
-    lds_fft(buf, P.plan, nl, n, false, tid, 256);
-    for (int i = tid; i < nl * P.KX; i += 256) {
-        const int line = i / P.KX, e = i - line * P.KX;
-        P.out[(l0 + line) * P.KX + e] = buf[line * n + e];
+    lds_fft(buf, P.plan, nl, n, false, tid, 256, tw_s);
+    {
+        const int KX = P.KX, dl = 256 / KX, de = 256 % KX;
+        int line = tid / KX, e = tid % KX;
+        float2 *dst = P.out + l0 * KX;
+        for (int i = tid; i < nl * KX; i += 256) {
+            dst[i] = buf[line * n + e];
+            line += dl; e += de;
+            if (e >= KX) { e -= KX; line++; }
+        }
     }
 }
 
@@ -129,6 +144,7 @@ __global__ void __launch_bounds__(256) k_sva_eval(SvaEvalP P) {
             if (a <= -90.f) a += 180.f;
             if (!(a >= lw && a <= uw)) w = 0.f;
         }
+        if (w == 0.f) continue;         // adds exact zeros; a wave's 64 consecutive samples are a compact patch of a shell (Z-order), so whole waves skip the missing wedge
         const float2 iv = F[s];
         const float fkx = (float)kx, fky = (float)ky, fkz = (float)kz;
         const float wx = w * iv.x, wy = w * iv.y;
@@ -211,6 +227,7 @@ __global__ void __launch_bounds__(256) k_sva_global(SvaGlobalP P) {
                 if (a <= -90.f) a += 180.f;
                 if (!(a >= lw && a <= uw)) w = 0.f;
             }
+            if (w == 0.f) continue;
             const float2 iv = F[s];
             const float fkx = (float)kx, fky = (float)ky, fkz = (float)kz;
             const float2 p = sample_cube(P.cv, Nq[0] * fkx + Nq[1] * fky + Nq[2] * fkz, Nq[3] * fkx + Nq[4] * fky + Nq[5] * fkz, Nq[6] * fkx + Nq[7] * fky + Nq[8] * fkz);
