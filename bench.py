@@ -510,8 +510,21 @@ def reconstruct_bench(ctx):
             return pdist.reduce_accumulator_handle(acc, local)
         return pdist.reduce_accumulators(acc_t, acc.counts())[1]
 
+    abi_note = None
     if via_abi:
-        pdist.library_comm(local)          # the communicator is made once, outside the timed region (collective)
+        # the communicator is made once, outside the timed region (collective).  RCCL has never seen more than one rank of this
+        # library on the development pool (one GPU per box): if creating the communicator fails on any rank, every rank falls back
+        # to torch.distributed's all-reduce of the same tensor and the line says so
+        ok = 1
+        try:
+            pdist.library_comm(local)
+        except Exception as e:          # noqa: BLE001
+            ok, abi_note = 0, "ppm_comm_create failed (%s): torch.distributed all_reduce used instead" % str(e)[:200]
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        tdist.all_reduce(flag, op=tdist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            via_abi = False
+            abi_note = abi_note or "ppm_comm_create failed on another rank: torch.distributed all_reduce used instead"
     counts = None
     for _ in range(a.warmup):
         counts = step()
@@ -564,7 +577,7 @@ def reconstruct_bench(ctx):
             "config": {"workload": "3D reconstruction: Fourier-insert %dk %d^2 particles/GPU (resident stack, %.0f GB) -> %d^3 half-maps, C1, "
                                    "one all-reduce" % (M // 1000, N, M * N * N * 4 / 1e9, N),
                        "particles_per_gpu": M, "box": N, "parallelism": "particle-sharded x%d" % world,
-                       "collective": "none (one rank)" if world == 1 else ("ppm_accum_reduce (RCCL all-reduce, C ABI)" if via_abi else "torch.distributed all_reduce")},
+                       "collective": "none (one rank)" if world == 1 else ("ppm_accum_reduce (RCCL all-reduce, C ABI)" if via_abi else (abi_note or "torch.distributed all_reduce"))},
             "roofline": roof, "kernels_ms": {k2: round(v["ms"], 2) for k2, v in prof.items() if v["launches"]},
             "kernels_us_per_particle": per_us, "compulsory_bytes_per_particle": 4 * N * N,
             "path_hbm_frac_compulsory": round(world * M * a.steps * 4.0 * N * N / dt / 1e9 / PEAK_HBM_GBPS / world, 4),
