@@ -719,17 +719,23 @@ def sva_bench(ctx):
         return None
     n3 = float(n) ** 3
     ms_prep = prof["prep"]["ms"] / (nv * a.steps)
+    R_ = int(np.ceil(min(0.5, 0.125 + 3.7169 * 0.05) * n))          # band radius of the protocol's low-pass (weights >= 1e-3), Fourier pixels
+    KX_, KY_ = min(n // 2 + 1, R_ + 1), min(n, 2 * R_ + 1)
+    moved = 2 * 4.0 * n3 + 2 * 8.0 * n * n * KX_ + 4 * 8.0 * n * KX_ * KY_
     blk = {"metric": "sub-volumes/sec sub-tomogram alignment, 192^3 box", "value": round(world * nv * a.steps / dt, 1), "unit": "sub-volumes/s",
            "n_gpus": world, "steps": a.steps, "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
            "dtype": "f32", "data": "synthetic",
            "config": {"workload": "%d resident 192^3 sub-volumes per GPU (%.1f GB), +-10 deg / +-10 px, missing wedge +-60 deg, band 0.125 cycles/pixel" % (nv, nv * n3 * 4 / 1e9),
                       "sub_volumes_per_gpu": nv, "parallelism": "row-sharded x%d, no collective" % world},
            "device_ms_per_sub_volume": {"pre_processing": round(ms_prep, 3), "search": round(prof["local"]["ms"] / (nv * a.steps), 3)},
-           "roofline": {"bound": "hbm", "kernel": "sub-volume pre-processing (k_sva_xpass + pruned k_fft_lines passes + k_sva_gather)",
+           "roofline": {"bound": "hbm", "kernel": "sub-volume pre-processing (k_sva_stats + k_sva_x16 + two k_sva_yz16 passes + k_sva_gather16)",
                         "achieved": round(4.0 * n3 / (ms_prep * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                         "frac": round(4.0 * n3 / (ms_prep * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4), "traffic": None,
-                        "algorithmic_bytes": "4 n^3: the sub-volume read once (the pruned transform keeps kx <= R, |ky|, |kz| <= R: its compact work "
-                                             "array, 8 n^2 (R + 1) bytes, stays in L2 / Infinity Cache); the passes are bound by the LDS FFT stages, not by HBM"},
+                        "algorithmic_bytes": "4 n^3: the sub-volume read once",
+                        "moved_bytes_model": {"bytes_per_sub_volume": round(moved), "GBps": round(moved / (ms_prep * 1e-3) / 1e9, 1),
+                                              "note": "the volume is read twice (statistics, x pass); the pruned transform (kx <= R, |ky|, |kz| <= R) writes and "
+                                                      "reads A[z][kx][y] once and B[kx][ky][z] twice; 32 sub-volumes per launch, so the work arrays (0.9 GB) "
+                                                      "live in HBM; the passes are bound by their LDS transforms (DESIGN.md 9)"}},
            "pcie_bound_note": "config 5's 10 k sub-volumes (283 GB) stream from the host: 28 MB each, i.e. ~1.9 k sub-volumes/s at PCIe Gen5 rates",
            "accuracy_vs_truth": {"median_deg_before": round(float(np.median(synth.pose_angle_error(start, poses))), 3),
                                  "median_deg_after": round(float(np.median(synth.pose_angle_error(out, poses))), 3),

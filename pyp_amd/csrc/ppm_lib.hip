@@ -209,7 +209,7 @@ struct ppm_ref {
     DevBuf<int> c_eval, c_rp, c_rt, c_slot, c_uoff; DevBuf<LState> c_states; DevBuf<double> c_mean;
     // sub-tomogram alignment (ppm_sva_align): the transforms' work array, the band-limited transforms of a chunk, staged host volumes
     // (GBs: allocating and freeing them on every call cost ~20 ms of a 120 ms call)
-    DevBuf<float2> s_f, s_F; DevBuf<float> s_vols;
+    DevBuf<float2> s_f, s_g, s_F; DevBuf<float> s_vols;
     // the band's sample list (built and sorted on the host: ~25 ms at 192^3 / 452 k samples) is kept while the band-pass settings stay
     struct { bool valid = false; float key[5] = { 0, 0, 0, 0, 0 }; int S = 0; std::vector<int> shell_off; DevBuf<uint32_t> samples; DevBuf<float> bandw; } s_plan;
     DevBuf<float2> band, Il, Wp, bank, twN;
@@ -588,7 +588,7 @@ void ppm_reference_destroy(ppm_ref_t *r) {
     if (r->cube) (void)hipFree(r->cube);
     r->rows_in.release(); r->rows_out.release(); r->dir_theta.release(); r->dir_phi.release();
     r->images.release(); r->wring.release(); r->cw.release(); r->C2.release(); r->nP.release(); r->nI.release();
-    r->s_f.release(); r->s_F.release(); r->s_vols.release(); r->s_plan.samples.release(); r->s_plan.bandw.release();
+    r->s_f.release(); r->s_g.release(); r->s_F.release(); r->s_vols.release(); r->s_plan.samples.release(); r->s_plan.bandw.release();
     r->c_Il.release(); r->c_band.release(); r->c_cw.release(); r->c_img.release(); r->c_wring.release(); r->c_rows.release(); r->c_N.release(); r->c_p.release(); r->c_tl.release();
     r->c_delta.release(); r->c_s0.release(); r->c_g0.release(); r->c_out.release(); r->c_eval.release(); r->c_rp.release(); r->c_rt.release(); r->c_slot.release(); r->c_states.release(); r->c_uoff.release(); r->c_mean.release(); r->cc.release(); r->mats.release(); r->ddef.release();
     r->band.release(); r->Il.release(); r->Wp.release(); r->bank.release(); r->twN.release(); r->rowtw.release(); r->sh.release(); r->samples.release();
@@ -1792,6 +1792,10 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
     if (int rc = ref->s_f.ensure((size_t)NB * N * N * KX)) return rc;
     if (int rc = ref->s_F.ensure((size_t)CH * S)) return rc;
     d_f.p = ref->s_f.p; d_F.p = ref->s_F.p;
+    // box sizes that are multiples of 16 take the two-step transforms (k_sva_x16 / k_sva_yz16): a second work array B[kx][kyi][z]
+    const bool fast16 = N % 16 == 0 && getenv("PPM_SVA_GENERIC_FFT") == nullptr;
+    const int KY = std::min(N, 2 * R + 1);
+    if (fast16) { if (int rc = ref->s_g.ensure((size_t)NB * KX * KY * N)) return rc; }
     const size_t CHS = (size_t)CH * (global ? Kc : 1);       // states per chunk: the global search refines Kc candidates per sub-volume
     HIPCHK(d_stats.alloc((size_t)2 * CH)); HIPCHK(d_poses.alloc((size_t)12 * CHS)); HIPCHK(d_delta.alloc(CHS * ncand * 6)); HIPCHK(d_out.alloc(CHS * ncand));
     HIPCHK(d_vmap.alloc(CHS)); HIPCHK(d_partial.alloc(CHS * kSvaParts * (2 * kMaxCand + 1)));
@@ -1857,6 +1861,19 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
                 // that, z pass on |ky| <= R only
                 const int m = std::min(NB, nb - v0);
                 const long NN2 = (long)N * N;
+                if (fast16) {
+                    const int L16 = N <= 256 ? 16 : 8;
+                    const size_t lds = (size_t)L16 * (N + 1) * sizeof(float2);
+                    SvaX16P X; X.vol = dv + (size_t)v0 * n3; X.stats = d_stats.p + 2 * v0; X.A = d_f.p; X.tw = g.plans[N].plan.tw; X.n = N; X.L = L16; X.KX = KX;
+                    X.nlines = (long)m * NN2; X.W = W;
+                    hipLaunchKernelGGL(k_sva_x16, dim3((unsigned)(X.nlines / L16)), dim3(256), lds, cur_stream(), X);
+                    SvaYZ16P Y; Y.A = d_f.p; Y.B = ref->s_g.p; Y.tw = X.tw; Y.n = N; Y.L = L16; Y.KX = KX; Y.KY = KY; Y.R = R; Y.in_place = 0; Y.nlines = 0;
+                    hipLaunchKernelGGL(k_sva_yz16, dim3((unsigned)((long)m * KX * (N / L16))), dim3(256), lds, cur_stream(), Y);
+                    Y.in_place = 1; Y.nlines = (long)m * KX * KY;
+                    hipLaunchKernelGGL(k_sva_yz16, dim3((unsigned)((Y.nlines + L16 - 1) / L16)), dim3(256), lds, cur_stream(), Y);
+                    hipLaunchKernelGGL(k_sva_gather16, dim3((unsigned)((S + 255) / 256), m), dim3(256), 0, cur_stream(), ref->s_g.p, d_samples.p, S, N, KX, KY, d_F.p + (size_t)v0 * S);
+                    continue;
+                }
                 XP.vol = dv + (size_t)v0 * n3; XP.stats = d_stats.p + 2 * v0; XP.nlines = (long)m * NN2;
                 hipLaunchKernelGGL(k_sva_xpass, dim3((unsigned)((XP.nlines + XP.L - 1) / XP.L)), dim3(256), (size_t)XP.L * N * sizeof(float2), cur_stream(), XP);
                 if (int rc = fft_lines_pass(d_f.p, N, (long)m * N * KX, KX, 1, (long)N * KX, KX, 1, false)) return rc;

@@ -79,6 +79,170 @@ __global__ void __launch_bounds__(256) k_sva_xpass(SvaXP P) {
 __host__ __device__ __forceinline__ uint32_t sva_pack(int kx, int ky, int kz) { return (uint32_t)kx | ((uint32_t)(ky + 512) << 10) | ((uint32_t)(kz + 512) << 21); }
 __host__ __device__ __forceinline__ void sva_unpack(uint32_t u, int &kx, int &ky, int &kz) { kx = (int)(u & 1023u); ky = (int)((u >> 10) & 2047u) - 512; kz = (int)(u >> 21) - 512; }
 
+// ---- box sizes that are multiples of 16 (192 = 16 x 12): two-step transforms, N = 16 M.  Step 1: thread (line, t) holds
+// x[t + M j], j = 0 .. 15, in registers, transforms them (dft16), multiplies by W_N^(t k2) and puts Y[k2][t] back into the
+// line; step 2: thread (k2, line) sums the M-point transform over t for the outputs k = 16 k1 + k2 that are kept — the band's
+// pruning removes most of them, so the direct sum costs less than a staged transform and needs no bit reversal.  The line buffer
+// is reused between the steps (all loads of step 1 precede its stores); odd line stride: step 2 walks 16 lines at one offset.
+// The arrays are laid out so that every pass reads whole lines and writes runs of L values:
+//   x pass: real volume [z][y][x] -> A[z][kx][y], kx < KX;   y pass: A -> B[kx][kyi][z], |ky| <= R (kyi = ky, or ky - N + KY below
+//   zero);   z pass: B in place, |kz| <= R;   k_sva_gather16 picks the band's samples out of B.
+// MT = M at compile time (the line of step 2 is read once into registers and the loops unroll), or 0 for any M.
+template <int MT, typename Need, typename Emit>
+__device__ __forceinline__ void fft16m(float2 *buf, int nl, int N, int LS, const float2 *tw, int tid, Need need, Emit emit) {
+    const int M = MT ? MT : N >> 4;
+    {
+        const int line = tid / M, t = tid - line * M;            // nl * M <= 256 tasks: one per thread
+        const bool on = tid < nl * M;
+        float2 x[16];
+        if (on) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) x[j] = buf[line * LS + t + M * j];
+        }
+        __syncthreads();
+        if (on) {
+            dft16(x);
+#pragma unroll
+            for (int k2 = 0; k2 < 16; k2++) {
+                float2 v = x[k2];
+                if (k2 > 0) { const float2 w = tw[t * k2]; v = cmul(v, make_float2(w.x, -w.y)); }
+                buf[line * LS + k2 * M + t] = v;
+            }
+        }
+        __syncthreads();
+    }
+    for (int task = tid; task < nl * 16; task += 256) {
+        const int k2 = task / nl, line = task - k2 * nl;          // line fastest: a wave's stores are runs of nl values
+        const float2 *row = buf + line * LS + k2 * M;
+        if constexpr (MT > 0) {
+            float2 v[MT];
+#pragma unroll
+            for (int t = 0; t < MT; t++) v[t] = row[t];
+#pragma unroll
+            for (int k1 = 0; k1 < MT; k1++) {
+                const int k = 16 * k1 + k2;
+                if (!need(k)) continue;
+                float ar = v[0].x, ai = v[0].y;
+#pragma unroll
+                for (int t = 1; t < MT; t++) {
+                    const float2 w = tw[((t * k1) % MT) << 4];    // compile-time index: W_M^(t k1) = conj(tw[16 (t k1 mod M)])
+                    ar += v[t].x * w.x + v[t].y * w.y; ai += v[t].y * w.x - v[t].x * w.y;
+                }
+                emit(line, k, make_float2(ar, ai));
+            }
+        } else {
+            for (int k1 = 0; k1 < M; k1++) {
+                const int k = 16 * k1 + k2;
+                if (!need(k)) continue;
+                float ar = 0.f, ai = 0.f;
+                int idx = 0;                                      // (t k1) mod M
+                for (int t = 0; t < M; t++) {
+                    const float2 v = row[t], w = tw[idx << 4];    // W_M^(t k1) = conj(tw[16 idx])
+                    ar += v.x * w.x + v.y * w.y; ai += v.y * w.x - v.x * w.y;
+                    idx += k1; if (idx >= M) idx -= M;
+                }
+                emit(line, k, make_float2(ar, ai));
+            }
+        }
+    }
+}
+// (Instantiating M at compile time for the common boxes — the line of step 2 in registers, unrolled sums — ran 1.5 x SLOWER at
+// 192^3: the kernels' register count is the largest of all instances.  The loop form is the one used.)
+template <typename Need, typename Emit>
+__device__ __forceinline__ void fft16m_any(float2 *buf, int nl, int N, int LS, const float2 *tw, int tid, Need need, Emit emit) {
+    fft16m<0>(buf, nl, N, LS, tw, tid, need, emit);
+}
+
+struct SvaX16P { const float *vol; const double *stats; float2 *A; const float2 *tw; int n, L, KX; long nlines; SvaWin W; };
+
+__global__ void __launch_bounds__(256) k_sva_x16(SvaX16P P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ float wx[512], wyz[16];
+    __shared__ float2 tw_s[512];
+    float2 *buf = (float2 *)smem;
+    const int tid = threadIdx.x, n = P.n, LS = n + 1;
+    const long l0 = (long)blockIdx.x * P.L;
+    const int nl = (int)((P.nlines - l0) < P.L ? (P.nlines - l0) : P.L);
+    if (nl <= 0) return;
+    const double n3 = (double)n * n * n;
+    const long nn = (long)n * n, v = l0 / nn;                    // P.L divides n: a block's lines share the sub-volume and z
+    const double *st = P.stats + 2 * v;
+    const double mu = st[0] / n3, var = st[1] / n3 - mu * mu, sd = var > 0 ? sqrt(var) : 1.0;
+    const float fmu = (float)mu, finv = (float)(1.0 / sd);
+    auto win1 = [&](int c, int k) {
+        if (!(P.W.w[k] > 0.f)) return 1.f;
+        const float d = fabsf((float)c) - P.W.w[k];
+        return d > 0.f ? (P.W.sigma > 0.f ? expf(-d * d / (2.f * P.W.sigma * P.W.sigma)) : 0.f) : 1.f;
+    };
+    for (int e = tid; e < n; e += 256) { wx[e] = win1(e - n / 2, 0); tw_s[e] = P.tw[e]; }
+    const int y0 = (int)(l0 % n), z = (int)((l0 / n) % n);
+    if (tid < nl) wyz[tid] = win1(y0 + tid - n / 2, 1) * win1(z - n / 2, 2);
+    __syncthreads();
+    {
+        const int dl = 256 / n, de = 256 % n;
+        int line = tid / n, e = tid % n;
+        const float *src = P.vol + l0 * n;
+        for (int i = tid; i < nl * n; i += 256) {
+            buf[line * LS + e] = make_float2((src[i] - fmu) * finv * (wx[e] * wyz[line]), 0.f);
+            line += dl; e += de;
+            if (e >= n) { e -= n; line++; }
+        }
+    }
+    __syncthreads();
+    const int KX = P.KX;
+    float2 *dst = P.A + ((v * n + z) * KX) * (long)n + y0;
+    fft16m_any(buf, nl, n, LS, tw_s, tid, [&](int k) { return k < KX; }, [&](int line, int k, float2 val) { dst[(long)k * n + line] = val; });
+}
+
+// y pass: block = L lines z0 .. z0 + L - 1 of one (sub-volume, kx); z pass (in_place): block = L consecutive lines of B
+struct SvaYZ16P { const float2 *A; float2 *B; const float2 *tw; int n, L, KX, KY, R, in_place; long nlines; };
+
+__global__ void __launch_bounds__(256) k_sva_yz16(SvaYZ16P P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ float2 tw_s[512];
+    float2 *buf = (float2 *)smem;
+    const int tid = threadIdx.x, n = P.n, LS = n + 1, KX = P.KX, KY = P.KY, R = P.R;
+    for (int e = tid; e < n; e += 256) tw_s[e] = P.tw[e];
+    const bool prune = KY < n;
+    auto need = [&](int k) { return !prune || k <= R || k >= n - R; };
+    if (P.in_place) {
+        const long l0 = (long)blockIdx.x * P.L;
+        const int nl = (int)((P.nlines - l0) < P.L ? (P.nlines - l0) : P.L);
+        if (nl <= 0) return;
+        float2 *base = P.B + l0 * n;
+        for (int i = tid; i < nl * n; i += 256) { const int line = i / n, e = i - line * n; buf[line * LS + e] = base[i]; }
+        __syncthreads();
+        fft16m_any(buf, nl, n, LS, tw_s, tid, need, [&](int line, int k, float2 val) { base[(long)line * n + k] = val; });
+    } else {
+        const int zblocks = n / P.L;
+        const int zb = blockIdx.x % zblocks, kx = (blockIdx.x / zblocks) % KX;
+        const long v = blockIdx.x / ((long)zblocks * KX);
+        const int z0 = zb * P.L, nl = P.L;
+        for (int i = tid; i < nl * n; i += 256) {
+            const int line = i / n, e = i - line * n;
+            buf[line * LS + e] = P.A[((v * n + z0 + line) * KX + kx) * (long)n + e];
+        }
+        __syncthreads();
+        float2 *dst = P.B + ((v * KX + kx) * KY) * (long)n + z0;
+        fft16m_any(buf, nl, n, LS, tw_s, tid, need, [&](int line, int k, float2 val) {
+            const int kyi = (!prune || k <= R) ? k : k - n + KY;
+            dst[(long)kyi * n + line] = val;
+        });
+    }
+}
+
+// band-limited half-space transform of one sub-volume out of B[kx][kyi][kz] (grid.y = sub-volume of the batch)
+__global__ void k_sva_gather16(const float2 *__restrict__ B, const uint32_t *__restrict__ samples, int S, int N, int KX, int KY, float2 *__restrict__ F) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S) return;
+    B += (size_t)blockIdx.y * KX * KY * N; F += (size_t)blockIdx.y * S;
+    int kx, ky, kz; sva_unpack(samples[i], kx, ky, kz);
+    const int kyi = ky >= 0 ? ky : ky + KY;
+    const float2 v = B[((size_t)kx * KY + kyi) * N + ((kz + N) % N)];
+    const float sg = ((kx + ky + kz) & 1) ? -1.f : 1.f;
+    F[i] = make_float2(v.x * sg, v.y * sg);
+}
+
 // band-limited half-space transform of one sub-volume out of the compact [z][y][KX] array, origin moved to the box centre
 // (grid.y = sub-volume of the batch)
 __global__ void k_sva_gather(const float2 *__restrict__ f, const uint32_t *__restrict__ samples, int S, int N, int KX, float2 *__restrict__ F) {

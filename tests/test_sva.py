@@ -212,3 +212,24 @@ def test_sva_align_executable_refines_a_table(tmp_path):
     assert np.linalg.norm(got[:, 9:] - poses[:, 9:], axis=1).max() < 0.2 and (out[:, 31] > 0.8).all() and np.array_equal(out[:, 9:12], tab[:, 9:12])
     r = subprocess.run([sys.executable, exe, "p.xml", "missing.txt", "ref.mrc", "o.txt"], cwd=tmp_path, capture_output=True, text=True)
     assert r.returncode != 0 and "ERROR" in r.stdout and not (tmp_path / "o.txt").exists()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [32, 48, 80, 96])
+def test_gpu_two_step_transforms_equal_the_staged_ones(n, monkeypatch):
+    """Boxes that are multiples of 16 go through k_sva_x16 / k_sva_yz16 (N = 16 M, M = 2, 3, 5, 6 here; other layout of the work arrays); PPM_SVA_GENERIC_FFT=1 forces the staged line transforms every other box takes.
+    Same scores and poses to rounding."""
+    from pyp_amd import host
+    vol, vols, poses, wedges = synth.make_subtomograms(n, 5, snr=0.5, wedge=(-50.0, 62.0))
+    start = synth.perturb_poses(poses, 3.0, 1.5)
+    for kw in (dict(), dict(lowpass=(0.45, 0.05)), dict(tol_angle=0.0, tol_shift=0.0)):          # pruned band; band beyond N/2 - 1 (no pruning); scores only
+        c = cfg_for(n, **kw)
+        g = host.Reference(vol, n / 2)
+        monkeypatch.delenv("PPM_SVA_GENERIC_FFT", raising=False)
+        fast, fsc = g.sva_align(c, vols.numpy(), wedges, start)
+        monkeypatch.setenv("PPM_SVA_GENERIC_FFT", "1")
+        slow, ssc = g.sva_align(c, vols.numpy(), wedges, start)
+        monkeypatch.delenv("PPM_SVA_GENERIC_FFT", raising=False)
+        assert np.abs(fsc - ssc).max() < 2e-5, (n, kw)
+        assert synth.pose_angle_error(fast, slow).max() < 0.02 and np.abs(fast[:, 9:] - slow[:, 9:]).max() < 0.02, (n, kw)
+        g.close()
