@@ -456,8 +456,15 @@ def write_dump(path, box, pixel, count, data):
         cuts = [len(view) * k // 4 for k in range(5)]
         with ThreadPoolExecutor(4) as ex:
             list(ex.map(lambda ae: part(*ae), zip(cuts[:-1], cuts[1:])))
-    finally:
+    except BaseException:
         os.close(fd)
+        fd = None
+        if os.path.exists(tmp):
+            os.remove(tmp)
+        raise
+    finally:
+        if fd is not None:
+            os.close(fd)
     os.replace(tmp, path)
 
 
@@ -566,12 +573,22 @@ def reconstruct3d_main(argv=None, stdin=None):
         _die(str(e))
     half = data.size // 2
     import threading
-    w2 = threading.Thread(target=write_dump, args=(d["dump_2"], box, px, counts[0], data[:half]))      # even keys -> map 2
+    failed = []
+
+    def dump(path, count, part):          # a full disk must end in the ERROR line, from either thread
+        try:
+            write_dump(path, box, px, count, part)
+        except OSError as e:
+            failed.append(f"ERROR: reconstruct3d: could not write {path}: {e}")
+    w2 = threading.Thread(target=dump, args=(d["dump_2"], counts[0], data[:half]))      # even keys -> map 2
     w2.start()
-    write_dump(d["dump_1"], box, px, counts[1], data[half:])      # odd keys  -> map 1
+    dump(d["dump_1"], counts[1], data[half:])                                           # odd keys  -> map 1
     w2.join()
-    if not os.path.exists(d["dump_2"]):
-        _die(f"ERROR: reconstruct3d: could not write {d['dump_2']}")
+    if failed:
+        for pth in (d["dump_1"], d["dump_2"]):
+            if os.path.exists(pth):
+                os.remove(pth)
+        _die(failed[0])
     with open(d["res_file"], "w") as f:
         f.write("C Reconstruct3D (libpypmatch): particles %d..%d, inserted %d + %d\n" % (d["first"], d["last"], counts[1], counts[0]))
     print(f"\nInserted {counts[0] + counts[1]} of {len(rin)} particles in {time.time() - t0:.1f} s")
