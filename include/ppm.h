@@ -279,6 +279,9 @@ int ppm_insert_batch(ppm_accum_t *acc, const ppm_recon_cfg *cfg, const void *ima
 /* host copies of the accumulators: ppm_accum_floats(box) floats laid out
  * [half 0..1][kz][ky][kx 0..box/2]{re, im, weight} */
 int ppm_accum_download(ppm_accum_t *acc, float *host);
+/* `count` floats from float index `first` of the same layout (one half map = ppm_accum_floats(box) / 2 floats): lets a caller
+ * download each half into a page-locked buffer of its own and write the two dump files (frealign.py:1820-1822) from there */
+int ppm_accum_download_range(ppm_accum_t *acc, float *host, size_t first, size_t count);
 int ppm_accum_add(ppm_accum_t *acc, const float *host);
 long ppm_accum_count(ppm_accum_t *acc, int half); /* particles inserted so far */
 void ppm_accum_set_count(ppm_accum_t *acc, int half, long count);

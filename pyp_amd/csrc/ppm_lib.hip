@@ -1111,6 +1111,15 @@ int ppm_accum_download(ppm_accum_t *a, float *host) {
     return 0;
 }
 
+int ppm_accum_download_range(ppm_accum_t *a, float *host, size_t first, size_t count) {
+    if (!a || !host) return fail(-22, "null argument");
+    if (first > ppm_accum_floats(a->N) || count > ppm_accum_floats(a->N) - first) return fail(-22, "range beyond the accumulators");
+    StreamScope ss_(a->stream, a->copy);
+    HIPCHK(hipStreamSynchronize(cur_stream()));
+    HIPCHK(hipMemcpy(host, a->acc + first, count * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int ppm_accum_add(ppm_accum_t *a, const float *host) {
     if (!a || !host) return fail(-22, "null argument");
     StreamScope ss_(a->stream, a->copy);

@@ -13,7 +13,7 @@ SO_PATH = os.path.join(_HERE, "libpypmatch.so")
 EXPORTS = [
     "ppm_init", "ppm_last_error", "ppm_version", "ppm_reference_create", "ppm_reference_create_padded", "ppm_reference_create_weighted", "ppm_reference_destroy",
     "ppm_refine_batch", "ppm_refine_last_counts", "ppm_refine_note", "ppm_match_projections", "ppm_csp_refine", "ppm_sva_align", "ppm_accum_floats", "ppm_accum_create", "ppm_accum_destroy",
-    "ppm_insert_batch", "ppm_accum_download", "ppm_accum_add", "ppm_accum_count", "ppm_accum_set_count",
+    "ppm_insert_batch", "ppm_accum_download", "ppm_accum_download_range", "ppm_accum_add", "ppm_accum_count", "ppm_accum_set_count",
     "ppm_finalize", "ppm_profile_enable", "ppm_profile_reset", "ppm_profile_get", "ppm_device_alloc",
     "ppm_device_free", "ppm_device_upload", "ppm_device_sync", "ppm_extract_boxes", "ppm_host_alloc", "ppm_host_free", "ppm_host_read",
     "ppm_comm_unique_id", "ppm_comm_create", "ppm_comm_destroy", "ppm_accum_reduce",
@@ -55,6 +55,7 @@ def load():
     L.ppm_accum_destroy.argtypes = [vp]; L.ppm_accum_destroy.restype = None
     L.ppm_insert_batch.argtypes = [vp, vp, vp, ci, ci, vp]; L.ppm_insert_batch.restype = ci
     L.ppm_accum_download.argtypes = [vp, vp]; L.ppm_accum_download.restype = ci
+    L.ppm_accum_download_range.argtypes = [vp, vp, C.c_size_t, C.c_size_t]; L.ppm_accum_download_range.restype = ci
     L.ppm_accum_add.argtypes = [vp, vp]; L.ppm_accum_add.restype = ci
     L.ppm_accum_count.argtypes = [vp, ci]; L.ppm_accum_count.restype = cl
     L.ppm_accum_set_count.argtypes = [vp, ci, cl]; L.ppm_accum_set_count.restype = None

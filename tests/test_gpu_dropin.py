@@ -413,3 +413,49 @@ def test_bench_two_ranks_share_one_gpu_over_gloo():
     assert d["roofline"]["bound"] == "valu_fp32" and 0 < d["roofline"]["frac"] <= 1
     rec = d["reconstruct"]
     assert rec["n_gpus"] == 2 and rec["value"] > 0 and 0 < rec["roofline"]["frac"] <= 1 and rec["map_cc_vs_truth"] > 0.5
+
+
+def test_native_reconstruct3d_equals_the_python_implementation(project, monkeypatch):
+    """bin/reconstruct3d is the compiled fast path (pyp_amd/csrc/reconstruct3d_main.cpp) and hands everything it does not cover to
+    bin/reconstruct3d.py before the GPU is touched: the same range through both (PPM_NATIVE=0 forces the hand-over) must give the same
+    dump files — with score weighting, the defocus regression of the scores, a statistics file and PIND splitting switched on —
+    and an input the fast path does not take (scattered positions) must still work."""
+    d, vol, imgs, truth, start = project
+    rows = truth.copy()
+    rng = np.random.default_rng(5)
+    rows[:, cistem.COL["SCORE"]] = 20.0 + rng.normal(0, 3, len(rows)) + 1e-4 * (rows[:, cistem.COL["DEFOCUS_1"]] - rows[:, cistem.COL["DEFOCUS_1"]].mean())
+    rows[7, cistem.COL["OCCUPANCY"]] = 0.0
+    rows[:, cistem.COL["PIND"]] = np.arange(len(rows)) // 2
+    cistem.write_parameters(str(d / "n_r01_used.cistem"), rows)
+    stat = np.vstack([rows.mean(axis=0), rows.var(axis=0)])
+    cistem.write_parameters(str(d / "n_r01_stat.cistem"), stat)
+
+    def script(tag, params="n_r01_used.cistem", stats="n_r01_stat.cistem", first=3, last=52):
+        lines = ["p_stack.mrc", params, stats, "p_r01.mrc", "n_map1.mrc", "n_map2.mrc", "output.mrc", f"n_{tag}.res", "C2", first, last, PX, 300, 0,
+                 PX * N / 2, 2 * PX, 0, 2.0, "yes", 0, -1, "no", 12.0, 1, 1, "yes", "yes", "no", "no", "yes", "yes", "yes", "no", "no", "no", "yes",
+                 f"{d}/n_{tag}_map1_n1.mrc", f"{d}/n_{tag}_map2_n1.mrc", 1]
+        return "\n".join(str(x) for x in lines) + "\n"
+    assert run("reconstruct3d", script("nat"), d, "rec_nat.log") == 0
+    monkeypatch.setenv("PPM_NATIVE", "0")
+    assert run("reconstruct3d", script("py"), d, "rec_py.log") == 0
+    monkeypatch.delenv("PPM_NATIVE")
+    ln, lp = open(d / "rec_nat.log").read(), open(d / "rec_py.log").read()
+    assert "libpypmatch, native" in ln and "libpypmatch, native" not in lp and "Reconstruct3D: Normal termination" in ln and "Reconstruct3D: Normal termination" in lp
+    ins = [ln_ for ln_ in ln.splitlines() if ln_.startswith("Inserted")][0].split(" in ")[0]
+    assert ins == [l_ for l_ in lp.splitlines() if l_.startswith("Inserted")][0].split(" in ")[0]
+    for k in (1, 2):
+        a, b = open(d / f"n_nat_map{k}_n1.mrc", "rb").read(), open(d / f"n_py_map{k}_n1.mrc", "rb").read()
+        assert a[:24] == b[:24]
+        fa, fb = np.frombuffer(a, "<f4", offset=24), np.frombuffer(b, "<f4", offset=24)
+        assert np.abs(fa - fb).max() <= 2e-5 * np.abs(fb).max()          # the score regression's slope is summed in another order
+    assert open(d / "n_nat.res").read() == open(d / "n_py.res").read()
+    # scattered positions: not the fast path's business, the same executable still serves them
+    sc = rows[[3, 9, 10, 30, 31, 44]].copy()
+    cistem.write_parameters(str(d / "n_r01_scattered.cistem"), sc)
+    assert run("reconstruct3d", script("sc", params="n_r01_scattered.cistem", stats="null", first=1, last=60), d, "rec_sc.log") == 0
+    lsc = open(d / "rec_sc.log").read()
+    assert "Reconstruct3D: Normal termination" in lsc and "Inserted 6 of 6" in lsc
+    # a missing stack ends in the Python implementation's ERROR line and no output
+    bad = script("bad").replace("p_stack.mrc", "no_such_stack.mrc")
+    assert run("reconstruct3d", bad, d, "rec_bad.log") != 0
+    assert "ERROR" in open(d / "rec_bad.log").read() and not (d / "n_bad_map1_n1.mrc").exists()
