@@ -289,7 +289,8 @@ int main() {
     const size_t sec = (size_t)box * box * 4;
     long chunk_mb = 256, call_mb = 2048;
     if (const char *e = getenv("PPM_IO_CHUNK_MB")) chunk_mb = std::max(1L, atol(e));
-    const size_t pin_bytes = std::max((size_t)16, ((size_t)chunk_mb << 20) / sec) * sec;       // one staging buffer (whole images)
+    // one staging buffer: whole images, no larger than the range can fill (page-locking costs ~0.2 s per GB)
+    const size_t pin_bytes = std::min(std::max((size_t)16, ((size_t)chunk_mb << 20) / sec), (size_t)(ilast - ifirst + 1)) * sec;
     ppm_accum_t *acc = nullptr;
     void *pinned[3] = { nullptr, nullptr, nullptr };
     std::mutex up_m; std::condition_variable up_cv; int up_stage = 0; std::string up_err;      // up_stage: 1 = accumulator ready, 2 + k = pinned[k] ready
