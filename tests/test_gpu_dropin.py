@@ -459,3 +459,39 @@ def test_native_reconstruct3d_equals_the_python_implementation(project, monkeypa
     bad = script("bad").replace("p_stack.mrc", "no_such_stack.mrc")
     assert run("reconstruct3d", bad, d, "rec_bad.log") != 0
     assert "ERROR" in open(d / "rec_bad.log").read() and not (d / "n_bad_map1_n1.mrc").exists()
+
+
+@pytest.mark.parametrize("env", [{"PPM_IO_CHUNK_MB": "1", "PPM_IO_THREADS": "3"}, {"PPM_IO_CHUNK_MB": "1", "PPM_IO_READER": "python", "PPM_NATIVE": "0"},
+                                 {"PPM_IO_CHUNK_MB": "4096"}])
+def test_executables_give_the_same_files_whatever_the_pipeline_chunking(project, monkeypatch, env):
+    """The read / upload / compute pipeline of refine3d and reconstruct3d (native and Python) with staging buffers of 1 MB (16
+    images of 64^2 per chunk: 4 chunks, groups, a ragged tail) and of 4 GB (one chunk), odd reader-thread counts, the Python reader:
+    the outputs of a range that starts in the middle of the stack do not depend on any of it (parameters to the bit, accumulators to rounding)."""
+    d, vol, imgs, truth, start = project
+    used = truth.copy()
+    used[:, cistem.COL["SCORE"]] = 20.0
+    cistem.write_parameters(str(d / "c_r01_used.cistem"), used)
+
+    def rec(tag):
+        lines = ["p_stack.mrc", "c_r01_used.cistem", "null", "p_r01.mrc", "c_map1.mrc", "c_map2.mrc", "output.mrc", f"c_{tag}.res", "C1", 7, 55, PX, 300, 0,
+                 PX * N / 2, 2 * PX, 0, 2.0, "no", 0, -1, "no", 0, 1, 1, "yes", "no", "no", "no", "no", "yes", "no", "no", "no", "no", "yes",
+                 f"{d}/c_{tag}_map1_n1.mrc", f"{d}/c_{tag}_map2_n1.mrc", 1]
+        return "\n".join(str(x) for x in lines) + "\n"
+
+    def ref(tag):
+        s = refine_script(7, 55, False, out=f"c_{tag}_0000007_0000055.cistem")
+        return s
+    tag = "base"
+    if not (d / "c_base_map1_n1.mrc").exists():
+        assert run("reconstruct3d", rec(tag), d, "c_rec.log") == 0 and run("refine3d", ref(tag), d, "c_ref.log") == 0
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    tag = "v%d" % (abs(hash(tuple(sorted(env.items())))) % 100000)
+    assert run("reconstruct3d", rec(tag), d, "c_rec.log") == 0 and run("refine3d", ref(tag), d, "c_ref.log") == 0
+    for k in (1, 2):          # insertion sums chunk by chunk in single precision: equal to rounding, not to the bit
+        x, y = open(d / f"c_{tag}_map{k}_n1.mrc", "rb").read(), open(d / f"c_base_map{k}_n1.mrc", "rb").read()
+        assert x[:24] == y[:24] and len(x) == len(y)
+        fx, fy = np.frombuffer(x, "<f4", offset=24), np.frombuffer(y, "<f4", offset=24)
+        assert np.abs(fx - fy).max() <= 2e-6 * np.abs(fy).max()
+    a, b = cistem.read_parameters(str(d / f"c_{tag}_0000007_0000055.cistem")), cistem.read_parameters(str(d / "c_base_0000007_0000055.cistem"))
+    assert a.shape == (49, 32) and np.array_equal(a, b)
