@@ -148,9 +148,10 @@ __device__ __forceinline__ void fft16m(float2 *buf, int nl, int N, int LS, const
 }
 // (Instantiating M at compile time for the common boxes — the line of step 2 in registers, unrolled sums — ran 1.5 x SLOWER at
 // 192^3: the kernels' register count is the largest of all instances.  The loop form is the one used.)
-template <typename Need, typename Emit>
+template <bool SPECIAL192, typename Need, typename Emit>
 __device__ __forceinline__ void fft16m_any(float2 *buf, int nl, int N, int LS, const float2 *tw, int tid, Need need, Emit emit) {
-    fft16m<0>(buf, nl, N, LS, tw, tid, need, emit);
+    if (SPECIAL192 && N == 192) fft16m<12>(buf, nl, N, LS, tw, tid, need, emit);      // BASELINE config 5's box, x pass only (92 registers; the y / z passes would need 196)
+    else fft16m<0>(buf, nl, N, LS, tw, tid, need, emit);
 }
 
 struct SvaX16P { const float *vol; const double *stats; float2 *A; const float2 *tw; int n, L, KX; long nlines; SvaWin W; };
@@ -191,7 +192,7 @@ __global__ void __launch_bounds__(256) k_sva_x16(SvaX16P P) {
     __syncthreads();
     const int KX = P.KX;
     float2 *dst = P.A + ((v * n + z) * KX) * (long)n + y0;
-    fft16m_any(buf, nl, n, LS, tw_s, tid, [&](int k) { return k < KX; }, [&](int line, int k, float2 val) { dst[(long)k * n + line] = val; });
+    fft16m_any<true>(buf, nl, n, LS, tw_s, tid, [&](int k) { return k < KX; }, [&](int line, int k, float2 val) { dst[(long)k * n + line] = val; });
 }
 
 // y pass: block = L lines z0 .. z0 + L - 1 of one (sub-volume, kx); z pass (in_place): block = L consecutive lines of B
@@ -212,7 +213,7 @@ __global__ void __launch_bounds__(256) k_sva_yz16(SvaYZ16P P) {
         float2 *base = P.B + l0 * n;
         for (int i = tid; i < nl * n; i += 256) { const int line = i / n, e = i - line * n; buf[line * LS + e] = base[i]; }
         __syncthreads();
-        fft16m_any(buf, nl, n, LS, tw_s, tid, need, [&](int line, int k, float2 val) { base[(long)line * n + k] = val; });
+        fft16m_any<false>(buf, nl, n, LS, tw_s, tid, need, [&](int line, int k, float2 val) { base[(long)line * n + k] = val; });
     } else {
         const int zblocks = n / P.L;
         const int zb = blockIdx.x % zblocks, kx = (blockIdx.x / zblocks) % KX;
@@ -224,7 +225,7 @@ __global__ void __launch_bounds__(256) k_sva_yz16(SvaYZ16P P) {
         }
         __syncthreads();
         float2 *dst = P.B + ((v * KX + kx) * KY) * (long)n + z0;
-        fft16m_any(buf, nl, n, LS, tw_s, tid, need, [&](int line, int k, float2 val) {
+        fft16m_any<false>(buf, nl, n, LS, tw_s, tid, need, [&](int line, int k, float2 val) {
             const int kyi = (!prune || k <= R) ? k : k - n + KY;
             dst[(long)kyi * n + line] = val;
         });
