@@ -379,10 +379,32 @@ def refine3d_main(argv=None, stdin=None):
         with gpu_lock(dev):
             if box * pad > 512:
                 _die(f"ERROR: refine3d: padding factor {pad} needs a padded box of {box * pad} > 512")
-            ref = host.Reference(vol, box / 2, device=dev, pad=pad, ring_weight=ring_w)
-            t2 = time.time()
+            # the reference is prepared (upload, 3-D transform, slice bank) by a thread of its own while the pipeline below reads and
+            # uploads the first images: different handles and streams (include/ppm.h)
+            import threading
+            made = {}
+
+            def make_reference():
+                try:
+                    made["ref"] = host.Reference(vol, box / 2, device=dev, pad=pad, ring_weight=ring_w)
+                except BaseException as e:         # noqa: BLE001 - reported by the main thread
+                    made["err"] = e
+            maker = threading.Thread(target=make_reference)
+            maker.start()
             rout = np.empty_like(rin)
-            for lo, hi, imgs in _iter_image_chunks(mm, rin[:, C["POSITION_IN_STACK"]], dev, call_mb=512, chunk_mb=64):
+            chunks = _iter_image_chunks(mm, rin[:, C["POSITION_IN_STACK"]], dev, call_mb=512, chunk_mb=64)
+            try:
+                first = next(chunks)               # starts the reader / uploader threads and waits for the first images
+            finally:
+                maker.join()
+            if "err" in made:
+                chunks.close()
+                raise made["err"]
+            ref = made["ref"]
+            t2 = time.time()
+            lo, hi, imgs = first
+            rout[lo:hi] = ref.refine(cfg, imgs, rin[lo:hi])
+            for lo, hi, imgs in chunks:
                 rout[lo:hi] = ref.refine(cfg, imgs, rin[lo:hi])
             t3 = time.time()
             note = ref.note()
