@@ -90,7 +90,7 @@ __host__ __device__ __forceinline__ void sva_unpack(uint32_t u, int &kx, int &ky
 // MT = M at compile time (the line of step 2 is read once into registers and the loops unroll), or 0 for any M.
 template <int MT, typename Need, typename Emit>
 __device__ __forceinline__ void fft16m(float2 *buf, int nl, int N, int LS, const float2 *tw, int tid, Need need, Emit emit) {
-    const int M = MT ? MT : N >> 4;
+    const int M = MT > 0 ? MT : (MT < 0 ? -MT : N >> 4);
     {
         const int line = tid / M, t = tid - line * M;            // nl * M <= 256 tasks: one per thread
         const bool on = tid < nl * M;
@@ -130,6 +130,25 @@ __device__ __forceinline__ void fft16m(float2 *buf, int nl, int N, int LS, const
                 }
                 emit(line, k, make_float2(ar, ai));
             }
+        } else if constexpr (MT < 0) {                            // the line in registers, the outputs in a loop (fewer registers than MT > 0)
+            constexpr int MR = -MT;
+            float2 v[MR];
+#pragma unroll
+            for (int t = 0; t < MR; t++) v[t] = row[t];
+#pragma unroll 1
+            for (int k1 = 0; k1 < MR; k1++) {
+                const int k = 16 * k1 + k2;
+                if (!need(k)) continue;
+                float ar = v[0].x, ai = v[0].y;
+                int idx = 0;
+#pragma unroll
+                for (int t = 1; t < MR; t++) {
+                    idx += k1; if (idx >= MR) idx -= MR;
+                    const float2 w = tw[idx << 4];
+                    ar += v[t].x * w.x + v[t].y * w.y; ai += v[t].y * w.x - v[t].x * w.y;
+                }
+                emit(line, k, make_float2(ar, ai));
+            }
         } else {
             for (int k1 = 0; k1 < M; k1++) {
                 const int k = 16 * k1 + k2;
@@ -151,6 +170,7 @@ __device__ __forceinline__ void fft16m(float2 *buf, int nl, int N, int LS, const
 template <bool SPECIAL192, typename Need, typename Emit>
 __device__ __forceinline__ void fft16m_any(float2 *buf, int nl, int N, int LS, const float2 *tw, int tid, Need need, Emit emit) {
     if (SPECIAL192 && N == 192) fft16m<12>(buf, nl, N, LS, tw, tid, need, emit);      // BASELINE config 5's box, x pass only (92 registers; the y / z passes would need 196)
+    else if (N == 192) fft16m<-12>(buf, nl, N, LS, tw, tid, need, emit);             // y / z passes of that box: the line in registers only
     else fft16m<0>(buf, nl, N, LS, tw, tid, need, emit);
 }
 
