@@ -1183,6 +1183,7 @@ void *ppm_comm_create(int n_ranks, int rank, const ppm_comm_id *id) {
     Rccl &r = rccl();
     if (!r.err.empty()) { fail(-38, r.err); return nullptr; }
     void *comm = nullptr;
+    (void)hipSetDevice(g.device);                    // the communicator binds to the calling thread's current device
     if (int rc = r.CommInitRank(&comm, n_ranks, *id, rank)) { rccl_fail(r, rc, "ncclCommInitRank"); return nullptr; }
     return comm;
 }
