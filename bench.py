@@ -115,11 +115,14 @@ def so_sha16():
     return hashlib.sha256(open(p, "rb").read()).hexdigest()[:16] if os.path.exists(p) else None
 
 
-def kernels_sha16():
+KERNEL_SOURCES_MAIN = ("ppm_dev.h", "ppm_kernels.h", "ppm_kernels2.h")      # the refinement and insertion kernels (what the PMC summaries profile)
+
+
+def kernels_sha16(files=KERNEL_SOURCES):
     """Identity of the DEVICE code (the kernel headers): a PMC summary stays valid across host-only changes of the library."""
     import hashlib
     h = hashlib.sha256()
-    for f in KERNEL_SOURCES:
+    for f in files:
         h.update(open(os.path.join(ROOT, "pyp_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -152,9 +155,14 @@ def pmc_traffic(summary, kernel, particles_per_launch):
     if not e or "FETCH_SIZE" not in e or "WRITE_SIZE" not in e or not meta.get("particles"):
         return None, "no FETCH_SIZE / WRITE_SIZE summary for %s under profiles/%s" % (kernel, summary)
     per_particle = (2.0 * e["FETCH_SIZE"]["sum"] + e["WRITE_SIZE"]["sum"]) * 1024.0 / meta["particles"]
-    same = meta.get("kernels_sha16") == kernels_sha16()
+    # compared on the headers of the refinement / insertion kernels when the summary names them (changes of the csp / sva kernels
+    # do not make these counters stale), else on all kernel headers
+    if meta.get("kernels_main_sha16"):
+        had, now = meta["kernels_main_sha16"], kernels_sha16(KERNEL_SOURCES_MAIN)
+    else:
+        had, now = meta.get("kernels_sha16", "?"), kernels_sha16()
     src = "profiles/%s (%d particles, 2 x FETCH_SIZE + WRITE_SIZE, KB; kernel sources %s%s)" % (
-        summary, meta["particles"], meta.get("kernels_sha16", "?"), " = the timed ones" if same else ", the timed ones are " + kernels_sha16())
+        summary, meta["particles"], had, " = the timed ones" if had == now else ", the timed ones are " + now)
     return per_particle * particles_per_launch, src
 
 

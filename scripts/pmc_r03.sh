@@ -30,5 +30,6 @@ for grp in "${GROUPS_[@]}"; do
 done
 SHA=$(python3 -c "import bench; print(bench.so_sha16())")
 KSHA=$(python3 -c "import bench; print(bench.kernels_sha16())")
-python3 scripts/pmc_summary.py $R --meta particles=$N workload=$W so_sha16=$SHA kernels_sha16=$KSHA "command=bench.py $ARGS" > $OUT
+MSHA=$(python3 -c "import bench; print(bench.kernels_sha16(bench.KERNEL_SOURCES_MAIN))")
+python3 scripts/pmc_summary.py $R --meta particles=$N workload=$W so_sha16=$SHA kernels_sha16=$KSHA kernels_main_sha16=$MSHA "command=bench.py $ARGS" > $OUT
 echo done $OUT
