@@ -755,19 +755,19 @@ def sva_bench(ctx):
     ms_prep = prof["prep"]["ms"] / (nv * a.steps)
     R_ = int(np.ceil(min(0.5, 0.125 + 3.7169 * 0.05) * n))          # band radius of the protocol's low-pass (weights >= 1e-3), Fourier pixels
     KX_, KY_ = min(n // 2 + 1, R_ + 1), min(n, 2 * R_ + 1)
-    moved = 2 * 4.0 * n3 + 2 * 8.0 * n * n * KX_ + 4 * 8.0 * n * KX_ * KY_
+    moved = 4.0 * n3 + 2 * 8.0 * n * n * KX_ + 4 * 8.0 * n * KX_ * KY_
     blk = {"metric": "sub-volumes/sec sub-tomogram alignment, 192^3 box", "value": round(world * nv * a.steps / dt, 1), "unit": "sub-volumes/s",
            "n_gpus": world, "steps": a.steps, "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
            "dtype": "f32", "data": "synthetic",
            "config": {"workload": "%d resident 192^3 sub-volumes per GPU (%.1f GB), +-10 deg / +-10 px, missing wedge +-60 deg, band 0.125 cycles/pixel" % (nv, nv * n3 * 4 / 1e9),
                       "sub_volumes_per_gpu": nv, "parallelism": "row-sharded x%d, no collective" % world},
            "device_ms_per_sub_volume": {"pre_processing": round(ms_prep, 3), "search": round(prof["local"]["ms"] / (nv * a.steps), 3)},
-           "roofline": {"bound": "hbm", "kernel": "sub-volume pre-processing (k_sva_stats + k_sva_x16 + two k_sva_yz16 passes + k_sva_gather16)",
+           "roofline": {"bound": "hbm", "kernel": "sub-volume pre-processing (k_sva_x16 + k_sva_stats_sum + two k_sva_yz16 passes + k_sva_gather16)",
                         "achieved": round(4.0 * n3 / (ms_prep * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                         "frac": round(4.0 * n3 / (ms_prep * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4), "traffic": None,
                         "algorithmic_bytes": "4 n^3: the sub-volume read once",
                         "moved_bytes_model": {"bytes_per_sub_volume": round(moved), "GBps": round(moved / (ms_prep * 1e-3) / 1e9, 1),
-                                              "note": "the volume is read twice (statistics, x pass); the pruned transform (kx <= R, |ky|, |kz| <= R) writes and "
+                                              "note": "the volume is read once (the x pass gathers the statistics, the normalisation is applied at the samples); the pruned transform (kx <= R, |ky|, |kz| <= R) writes and "
                                                       "reads A[z][kx][y] once and B[kx][ky][z] twice; 32 sub-volumes per launch, so the work arrays (0.9 GB) "
                                                       "live in HBM; the passes are bound by their LDS transforms (DESIGN.md 9)"}},
            "pcie_bound_note": "config 5's 10 k sub-volumes (283 GB) stream from the host: 28 MB each, i.e. ~1.9 k sub-volumes/s at PCIe Gen5 rates",

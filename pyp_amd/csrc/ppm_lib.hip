@@ -211,7 +211,7 @@ struct ppm_ref {
     // (GBs: allocating and freeing them on every call cost ~20 ms of a 120 ms call)
     DevBuf<float2> s_f, s_g, s_F; DevBuf<float> s_vols;
     // the band's sample list (built and sorted on the host: ~25 ms at 192^3 / 452 k samples) is kept while the band-pass settings stay
-    struct { bool valid = false; float key[5] = { 0, 0, 0, 0, 0 }; int S = 0; std::vector<int> shell_off; DevBuf<uint32_t> samples; DevBuf<float> bandw; } s_plan;
+    struct { bool valid = false; float key[5] = { 0, 0, 0, 0, 0 }; int S = 0; std::vector<int> shell_off; DevBuf<uint32_t> samples; DevBuf<float> bandw; DevBuf<float2> Fw; bool fw_valid = false; float wkey[4] = { 0, 0, 0, 0 }; } s_plan;    // Fw: the window's transform at the samples
     DevBuf<float2> band, Il, Wp, bank, twN;
     DevBuf<float4> rowtw;            // k_global's row-pair twiddles for this reference's current search grid
     DevBuf<int> sh;
@@ -588,7 +588,7 @@ void ppm_reference_destroy(ppm_ref_t *r) {
     if (r->cube) (void)hipFree(r->cube);
     r->rows_in.release(); r->rows_out.release(); r->dir_theta.release(); r->dir_phi.release();
     r->images.release(); r->wring.release(); r->cw.release(); r->C2.release(); r->nP.release(); r->nI.release();
-    r->s_f.release(); r->s_g.release(); r->s_F.release(); r->s_vols.release(); r->s_plan.samples.release(); r->s_plan.bandw.release();
+    r->s_f.release(); r->s_g.release(); r->s_F.release(); r->s_vols.release(); r->s_plan.samples.release(); r->s_plan.bandw.release(); r->s_plan.Fw.release();
     r->c_Il.release(); r->c_band.release(); r->c_cw.release(); r->c_img.release(); r->c_wring.release(); r->c_rows.release(); r->c_N.release(); r->c_p.release(); r->c_tl.release();
     r->c_delta.release(); r->c_s0.release(); r->c_g0.release(); r->c_out.release(); r->c_eval.release(); r->c_rp.release(); r->c_rt.release(); r->c_slot.release(); r->c_states.release(); r->c_uoff.release(); r->c_mean.release(); r->cc.release(); r->mats.release(); r->ddef.release();
     r->band.release(); r->Il.release(); r->Wp.release(); r->bank.release(); r->twN.release(); r->rowtw.release(); r->sh.release(); r->samples.release();
@@ -1790,7 +1790,7 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
     const int KX = std::min(N / 2 + 1, R + 1);          // x coefficients kept; |ky|, |kz| <= R are the lines the later passes touch
     const int NB = std::min(CH, 32);                     // sub-volumes transformed per launch (work array: NB x N x N x KX complex)
     if (!plan_cached) {
-        ref->s_plan.valid = false;
+        ref->s_plan.valid = false; ref->s_plan.fw_valid = false;
         if (int rc = ref->s_plan.samples.ensure(S)) return rc;
         if (int rc = ref->s_plan.bandw.ensure(S)) return rc;
         HIPCHK(hipMemcpyAsync(ref->s_plan.samples.p, samples.data(), (size_t)S * sizeof(uint32_t), hipMemcpyHostToDevice, cur_stream()));
@@ -1805,7 +1805,11 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
     // box sizes that are multiples of 16 take the two-step transforms (k_sva_x16 / k_sva_yz16): a second work array B[kx][kyi][z]
     const bool fast16 = N % 16 == 0 && getenv("PPM_SVA_GENERIC_FFT") == nullptr;
     const int KY = std::min(N, 2 * R + 1);
-    if (fast16) { if (int rc = ref->s_g.ensure((size_t)NB * KX * KY * N)) return rc; }
+    DevTmp<double> d_spart;                              // per-block partial sums of the two-step x pass
+    if (fast16) {
+        if (int rc = ref->s_g.ensure((size_t)NB * KX * KY * N)) return rc;
+        HIPCHK(d_spart.alloc((size_t)2 * NB * ((size_t)N * N / (N <= 256 ? 16 : 8))));
+    }
     const size_t CHS = (size_t)CH * (global ? Kc : 1);       // states per chunk: the global search refines Kc candidates per sub-volume
     HIPCHK(d_stats.alloc((size_t)2 * CH)); HIPCHK(d_poses.alloc((size_t)12 * CHS)); HIPCHK(d_delta.alloc(CHS * ncand * 6)); HIPCHK(d_out.alloc(CHS * ncand));
     HIPCHK(d_vmap.alloc(CHS)); HIPCHK(d_partial.alloc(CHS * kSvaParts * (2 * kMaxCand + 1)));
@@ -1861,7 +1865,7 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
         HIPCHK(hipMemsetAsync(d_stats.p, 0, (size_t)2 * nb * sizeof(double), cur_stream()));
         {
             ProfScope ps(PPM_K_PREP);
-            hipLaunchKernelGGL(k_sva_stats, dim3(64, nb), dim3(256), 0, cur_stream(), dv, n3, d_stats.p);
+            if (!fast16) hipLaunchKernelGGL(k_sva_stats, dim3(64, nb), dim3(256), 0, cur_stream(), dv, n3, d_stats.p);       // (the two-step x pass gathers the statistics itself)
             if (int rc = ensure_plan(N)) return rc;
             SvaXP XP; XP.stats = nullptr; XP.out = d_f.p; XP.plan = g.plans[N].plan; XP.n = N; XP.KX = KX; XP.nlines = (long)N * N; XP.W = W;
             XP.L = std::max(1, std::min(16, 7000 / N));
@@ -1874,14 +1878,25 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
                 if (fast16) {
                     const int L16 = N <= 256 ? 16 : 8;
                     const size_t lds = (size_t)L16 * (N + 1) * sizeof(float2);
-                    SvaX16P X; X.vol = dv + (size_t)v0 * n3; X.stats = d_stats.p + 2 * v0; X.A = d_f.p; X.tw = g.plans[N].plan.tw; X.n = N; X.L = L16; X.KX = KX;
-                    X.nlines = (long)m * NN2; X.W = W;
-                    hipLaunchKernelGGL(k_sva_x16, dim3((unsigned)(X.nlines / L16)), dim3(256), lds, cur_stream(), X);
-                    SvaYZ16P Y; Y.A = d_f.p; Y.B = ref->s_g.p; Y.tw = X.tw; Y.n = N; Y.L = L16; Y.KX = KX; Y.KY = KY; Y.R = R; Y.in_place = 0; Y.nlines = 0;
-                    hipLaunchKernelGGL(k_sva_yz16, dim3((unsigned)((long)m * KX * (N / L16))), dim3(256), lds, cur_stream(), Y);
-                    Y.in_place = 1; Y.nlines = (long)m * KX * KY;
-                    hipLaunchKernelGGL(k_sva_yz16, dim3((unsigned)((Y.nlines + L16 - 1) / L16)), dim3(256), lds, cur_stream(), Y);
-                    hipLaunchKernelGGL(k_sva_gather16, dim3((unsigned)((S + 255) / 256), m), dim3(256), 0, cur_stream(), ref->s_g.p, d_samples.p, S, N, KX, KY, d_F.p + (size_t)v0 * S);
+                    // mode 1 / 2 of k_sva_x16 for mv sub-volumes, the two k_sva_yz16 passes, the samples picked out of B
+                    auto transform = [&](int mode, const float *vols_, double *stats_, int mv, float2 *F_, const double *gstats, const float2 *Fw_) {
+                        SvaX16P X; X.vol = vols_; X.stats = stats_; X.A = d_f.p; X.tw = g.plans[N].plan.tw; X.n = N; X.L = L16; X.KX = KX; X.mode = mode;
+                        X.nlines = (long)mv * NN2; X.W = W;
+                        hipLaunchKernelGGL(k_sva_x16, dim3((unsigned)(X.nlines / L16)), dim3(256), lds, cur_stream(), X);
+                        if (mode == 1) hipLaunchKernelGGL(k_sva_stats_sum, dim3(mv), dim3(64), 0, cur_stream(), stats_, (int)(NN2 / L16), (double *)gstats);
+                        SvaYZ16P Y; Y.A = d_f.p; Y.B = ref->s_g.p; Y.tw = X.tw; Y.n = N; Y.L = L16; Y.KX = KX; Y.KY = KY; Y.R = R; Y.in_place = 0; Y.nlines = 0;
+                        hipLaunchKernelGGL(k_sva_yz16, dim3((unsigned)((long)mv * KX * (N / L16))), dim3(256), lds, cur_stream(), Y);
+                        Y.in_place = 1; Y.nlines = (long)mv * KX * KY;
+                        hipLaunchKernelGGL(k_sva_yz16, dim3((unsigned)((Y.nlines + L16 - 1) / L16)), dim3(256), lds, cur_stream(), Y);
+                        hipLaunchKernelGGL(k_sva_gather16, dim3((unsigned)((S + 255) / 256), mv), dim3(256), 0, cur_stream(), ref->s_g.p, d_samples.p, S, N, KX, KY, F_, gstats, Fw_);
+                    };
+                    const float wkey[4] = { W.w[0], W.w[1], W.w[2], W.sigma };
+                    if (!ref->s_plan.fw_valid || std::memcmp(wkey, ref->s_plan.wkey, sizeof(wkey)) != 0) {     // the window's own transform, once per window
+                        if (int rc = ref->s_plan.Fw.ensure(S)) return rc;
+                        transform(2, dv, nullptr, 1, ref->s_plan.Fw.p, nullptr, nullptr);
+                        std::memcpy(ref->s_plan.wkey, wkey, sizeof(wkey)); ref->s_plan.fw_valid = true;
+                    }
+                    transform(1, dv + (size_t)v0 * n3, d_spart.p, m, d_F.p + (size_t)v0 * S, d_stats.p + 2 * v0, ref->s_plan.Fw.p);
                     continue;
                 }
                 XP.vol = dv + (size_t)v0 * n3; XP.stats = d_stats.p + 2 * v0; XP.nlines = (long)m * NN2;

@@ -174,7 +174,10 @@ __device__ __forceinline__ void fft16m_any(float2 *buf, int nl, int N, int LS, c
     else fft16m<0>(buf, nl, N, LS, tw, tid, need, emit);
 }
 
-struct SvaX16P { const float *vol; const double *stats; float2 *A; const float2 *tw; int n, L, KX; long nlines; SvaWin W; };
+// mode 0: (v - mean) / sigma from `stats` (k_sva_stats ran before); mode 1: the raw windowed volume, and the block leaves its sum
+// and sum of squares in `stats`[2 block .. ] for k_sva_stats_sum (the transform is linear: k_sva_gather16 subtracts mean x the window's transform and divides by
+// sigma, so the volume is read once instead of twice); mode 2: the window itself (v = 1, nothing read)
+struct SvaX16P { const float *vol; double *stats; float2 *A; const float2 *tw; int n, L, KX, mode; long nlines; SvaWin W; };
 
 __global__ void __launch_bounds__(256) k_sva_x16(SvaX16P P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -187,9 +190,12 @@ __global__ void __launch_bounds__(256) k_sva_x16(SvaX16P P) {
     if (nl <= 0) return;
     const double n3 = (double)n * n * n;
     const long nn = (long)n * n, v = l0 / nn;                    // P.L divides n: a block's lines share the sub-volume and z
-    const double *st = P.stats + 2 * v;
-    const double mu = st[0] / n3, var = st[1] / n3 - mu * mu, sd = var > 0 ? sqrt(var) : 1.0;
-    const float fmu = (float)mu, finv = (float)(1.0 / sd);
+    float fmu = 0.f, finv = 1.f;
+    if (P.mode == 0) {
+        const double *st = P.stats + 2 * v;
+        const double mu = st[0] / n3, var = st[1] / n3 - mu * mu, sd = var > 0 ? sqrt(var) : 1.0;
+        fmu = (float)mu; finv = (float)(1.0 / sd);
+    }
     auto win1 = [&](int c, int k) {
         if (!(P.W.w[k] > 0.f)) return 1.f;
         const float d = fabsf((float)c) - P.W.w[k];
@@ -203,16 +209,39 @@ __global__ void __launch_bounds__(256) k_sva_x16(SvaX16P P) {
         const int dl = 256 / n, de = 256 % n;
         int line = tid / n, e = tid % n;
         const float *src = P.vol + l0 * n;
+        double s1 = 0, s2 = 0;
         for (int i = tid; i < nl * n; i += 256) {
-            buf[line * LS + e] = make_float2((src[i] - fmu) * finv * (wx[e] * wyz[line]), 0.f);
+            const float x = P.mode == 2 ? 1.f : src[i];
+            if (P.mode == 1) { s1 += (double)x; s2 += (double)x * (double)x; }
+            buf[line * LS + e] = make_float2((x - fmu) * finv * (wx[e] * wyz[line]), 0.f);
             line += dl; e += de;
             if (e >= n) { e -= n; line++; }
+        }
+        if (P.mode == 1) {
+            __shared__ double r1[4], r2[4];
+            s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+            if ((tid & 63) == 0) { r1[tid >> 6] = s1; r2[tid >> 6] = s2; }
+            __syncthreads();
+            if (tid == 0) {                                      // per-block partial sums; k_sva_stats_sum adds them in block order
+                P.stats[2 * (size_t)blockIdx.x] = ((r1[0] + r1[1]) + r1[2]) + r1[3];
+                P.stats[2 * (size_t)blockIdx.x + 1] = ((r2[0] + r2[1]) + r2[2]) + r2[3];
+            }
         }
     }
     __syncthreads();
     const int KX = P.KX;
     float2 *dst = P.A + ((v * n + z) * KX) * (long)n + y0;
     fft16m_any<true>(buf, nl, n, LS, tw_s, tid, [&](int k) { return k < KX; }, [&](int line, int k, float2 val) { dst[(long)k * n + line] = val; });
+}
+
+// sum and sum of squares of every sub-volume from the partial sums of its `per_vol` k_sva_x16 blocks, added in block order
+// (one wave per sub-volume; lane l adds blocks l, l + 64, ...)
+__global__ void __launch_bounds__(64) k_sva_stats_sum(const double *__restrict__ part, int per_vol, double *__restrict__ stats) {
+    const double *p = part + 2 * (size_t)blockIdx.x * per_vol;
+    double s1 = 0, s2 = 0;
+    for (int b = threadIdx.x; b < per_vol; b += 64) { s1 += p[2 * b]; s2 += p[2 * b + 1]; }
+    s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+    if (threadIdx.x == 0) { stats[2 * blockIdx.x] = s1; stats[2 * blockIdx.x + 1] = s2; }
 }
 
 // y pass: block = L lines z0 .. z0 + L - 1 of one (sub-volume, kx); z pass (in_place): block = L consecutive lines of B
@@ -253,7 +282,10 @@ __global__ void __launch_bounds__(256) k_sva_yz16(SvaYZ16P P) {
 }
 
 // band-limited half-space transform of one sub-volume out of B[kx][kyi][kz] (grid.y = sub-volume of the batch)
-__global__ void k_sva_gather16(const float2 *__restrict__ B, const uint32_t *__restrict__ samples, int S, int N, int KX, int KY, float2 *__restrict__ F) {
+// stats / Fw (may be null): the sub-volume's sum and sum of squares and the window's own transform at the samples — the
+// transform in B is that of the raw windowed volume (k_sva_x16 mode 1), the normalised one is (B - mean Fw) / sigma
+__global__ void k_sva_gather16(const float2 *__restrict__ B, const uint32_t *__restrict__ samples, int S, int N, int KX, int KY, float2 *__restrict__ F,
+                               const double *__restrict__ stats, const float2 *__restrict__ Fw) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S) return;
     B += (size_t)blockIdx.y * KX * KY * N; F += (size_t)blockIdx.y * S;
@@ -261,7 +293,14 @@ __global__ void k_sva_gather16(const float2 *__restrict__ B, const uint32_t *__r
     const int kyi = ky >= 0 ? ky : ky + KY;
     const float2 v = B[((size_t)kx * KY + kyi) * N + ((kz + N) % N)];
     const float sg = ((kx + ky + kz) & 1) ? -1.f : 1.f;
-    F[i] = make_float2(v.x * sg, v.y * sg);
+    float2 o = make_float2(v.x * sg, v.y * sg);
+    if (stats) {
+        const double n3 = (double)N * N * N, mu = stats[2 * blockIdx.y] / n3, var = stats[2 * blockIdx.y + 1] / n3 - mu * mu, sd = var > 0 ? sqrt(var) : 1.0;
+        const float fmu = (float)mu, finv = (float)(1.0 / sd);
+        const float2 w = Fw[i];
+        o = make_float2((o.x - fmu * w.x) * finv, (o.y - fmu * w.y) * finv);
+    }
+    F[i] = o;
 }
 
 // band-limited half-space transform of one sub-volume out of the compact [z][y][KX] array, origin moved to the box centre
