@@ -233,3 +233,24 @@ def test_gpu_two_step_transforms_equal_the_staged_ones(n, monkeypatch):
         assert np.abs(fsc - ssc).max() < 2e-5, (n, kw)
         assert synth.pose_angle_error(fast, slow).max() < 0.02 and np.abs(fast[:, 9:] - slow[:, 9:]).max() < 0.02, (n, kw)
         g.close()
+
+
+@pytest.mark.gpu
+def test_gpu_normalisation_through_the_transform_holds_for_a_large_density_offset():
+    """The two-step x pass transforms the RAW windowed sub-volume and the normalisation is applied at the samples,
+    (F - mean F_window) / sigma.  Sub-volumes whose mean is 40 standard deviations away from zero (unnormalised tomogram densities)
+    must still give the oracle's scores and poses, and the same as their normalised copies to rounding."""
+    from oracle import oracle as O
+    from pyp_amd import host
+    n = 48
+    vol, vols, poses, wedges = synth.make_subtomograms(n, 5, snr=0.5, wedge=(-55.0, 58.0))
+    raw = (vols.numpy() * 7.0 + 280.0).astype(np.float32)
+    start = synth.perturb_poses(poses, 3.0, 1.0)
+    c = cfg_for(n)
+    want, wsc, _ = O.sva_align(O.Reference(vol, n / 2), c, raw, wedges, start)
+    g = host.Reference(vol, n / 2)
+    got, gsc = g.sva_align(c, raw, wedges, start)
+    assert synth.pose_angle_error(want, got).max() < 0.1 and np.abs(want[:, 9:] - got[:, 9:]).max() < 0.5 and np.abs(wsc - gsc).max() < 2e-3
+    ref_, rsc = g.sva_align(c, vols.numpy(), wedges, start)
+    assert np.abs(rsc - gsc).max() < 5e-4 and synth.pose_angle_error(ref_, got).max() < 0.05
+    g.close()
