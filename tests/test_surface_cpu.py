@@ -195,3 +195,38 @@ def test_gpu_lock_serialises_processes(tmp_path, monkeypatch):
     [p.start() for p in ps]; [p.join() for p in ps]
     a, b = sorted([q.get(), q.get()], key=lambda r: r[1])
     assert b[1] >= a[2] - 1e-3
+
+
+def _gpu_present():
+    try:
+        import torch
+        return torch.cuda.device_count() > 0
+    except Exception:          # noqa: BLE001
+        return False
+
+
+@pytest.mark.skipif(_gpu_present(), reason="the no-device message needs a host without a GPU")
+def test_native_reconstruct3d_hands_over_and_fails_loudly_without_a_device(tmp_path):
+    """bin/reconstruct3d (compiled, pyp_amd/csrc/reconstruct3d_main.cpp): anything outside its fast path reaches bin/reconstruct3d.py
+    with the same stdin (here: an answer that is not yes / no, and too few answers - the Python parser's own messages); its fast
+    path on a host without a GPU ends in the library's ERROR line, a non-zero exit and no output file."""
+    import subprocess
+    from pyp_amd.formats import cistem, mrc
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bin", "reconstruct3d")
+    if not os.path.exists(exe):
+        pytest.skip("bin/reconstruct3d is built by __graft_entry__.build()")
+    rows = cistem.default_rows(6, 2.0, 300.0, 2.7, 0.07)
+    cistem.write_parameters(str(tmp_path / "p.cistem"), rows)
+    mrc.write(np.zeros((6, 32, 32), np.float32), str(tmp_path / "s.mrc"), pixel_size=2.0)
+    lines = ["s.mrc", "p.cistem", "null", "ref.mrc", "m1.mrc", "m2.mrc", "out.mrc", "r.res", "C1", 1, 6, 2.0, 300, 0, 30.0, 4.0, 0, 2.0, "no", 0, -1, "no", 0, 1, 1,
+             "yes", "no", "no", "no", "no", "yes", "no", "no", "no", "no", "yes", "d1.mrc", "d2.mrc", 1]
+
+    def run(ls):
+        return subprocess.run([exe], input="\n".join(str(x) for x in ls) + "\n", cwd=tmp_path, capture_output=True, text=True)
+    r = run(lines)
+    assert r.returncode != 0 and "ERROR" in r.stdout and "native" in r.stdout and not (tmp_path / "d1.mrc").exists()
+    bad = list(lines); bad[25] = "maybe"
+    r = run(bad)
+    assert r.returncode != 0 and "must be yes or no" in r.stdout and "native" not in r.stdout
+    r = run(lines[:10])
+    assert r.returncode != 0 and "expected 22 answers" in r.stdout
