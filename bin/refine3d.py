@@ -1,5 +1,5 @@
 #!/usr/bin/python3
-"""Drop-in `refine3d` for PYP (point frealign_paths["cistem2"] at this directory)."""
+"""Drop-in `refine3d` for PYP, the full implementation (bin/refine3d, the compiled front end of the default call, hands everything else here; point frealign_paths["cistem2"] at this directory)."""
 import os
 import sys
 

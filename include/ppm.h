@@ -120,6 +120,12 @@ typedef struct ppm_refine_cfg {
                                  (the absent program's rule is not visible); 0 = off */
     float prior_mean[5];      /* psi, theta, phi (degrees), x, y (Angstrom) */
     float prior_var[5];       /* their variances (degrees^2, Angstrom^2); <= 0 leaves that parameter unrestrained */
+    float res_classification; /* 22 "classification resolution limit" (class_rhcls, frealign.py:3945; default 8 A,
+                                 config/pyp_config.toml:5091-5095): LOGP and SIGMA of the output row - what the occupancy update of
+                                 3-D classification reads (src/pyp/analysis/occupancies.py:67-252) - are evaluated at the final pose
+                                 over res_low .. this limit instead of res_low .. res_high; SCORE stays that of the full band.
+                                 0, or a limit beyond res_high = res_high.  ppm_csp_refine ignores it (the csp program has no such
+                                 setting) */
 } ppm_refine_cfg;
 
 /* Reconstruction settings = numeric answers of the reconstruct3d script (frealign.py:1780-1824). */

@@ -124,6 +124,7 @@ static int box_ok(int n) { return n >= 16 && n <= 512 && n % 2 == 0 && fft_size_
 typedef struct {
     int N; double a;
     double r_hi, r_lo, r_s, ring_signed;
+    double r_cls;           /* band of LOGP / SIGMA (answer 22, ppm_refine_cfg.res_classification); = r_hi when unset */
     int B, W, H;            /* band half-width, row width B+1, rows 2B+1 */
     int Ns, RSx, RSy; double step; /* global-search shift grid: Ns points over the box, step = N/Ns pixels */
     int n_theta, n_psi, n_dir, n_orient;
@@ -153,6 +154,9 @@ static int geom_init(geom_t *g, const ppm_refine_cfg *c) {
     g->r_s = c->res_search > 0 ? na / c->res_search : g->r_hi; if (g->r_s > g->r_hi) g->r_s = g->r_hi;
     if (c->global_search && g->r_s > 64.0) g->r_s = 64.0;   /* the grid search never uses more than 64 Fourier pixels (ppm.h) */
     g->ring_signed = c->res_signed_cc > 0 ? na / c->res_signed_cc : 1e30;
+    /* answer 22 (frealign.py:3945): 0, beyond res_high, or a band of less than one Fourier pixel above r_lo -> the full band */
+    g->r_cls = c->res_classification > 0 ? na / c->res_classification : g->r_hi;
+    if (g->r_cls > g->r_hi || g->r_cls < g->r_lo + 1.0) g->r_cls = g->r_hi;
     g->B = (int)ceil(g->r_hi) - 1; g->W = g->B + 1; g->H = 2 * g->B + 1;
     int Bs = (int)ceil(g->r_s) - 1;
     g->Ns = 2; while (g->Ns < 2 * (Bs + 1)) g->Ns <<= 1;
@@ -774,6 +778,7 @@ int orc_refine_batch(void *refp, const ppm_refine_cfg *cfg, const float *images,
             if (cfg->local_refine) for (int t = 0; t < Tb + Tc; t++) compass_iter(r, &g, &c, I, wr, g.r_hi, rm_px, bf, en, &best, &nev, &sev, &pr);
             best.f = score_local(r, &g, &c, I, wr, g.r_hi, best.M, best.sh); nev++; sev += floor(ORC_PI * g.r_hi * g.r_hi / 2);
         }
+        ctf_t cfin = c;             /* the CTF the output row carries (moved by the defocus refinement) */
         /* defocus refinement (answers 33, 34, 45; frealign.py:3960-3961, :3978): offsets scored at the final pose */
         if (cfg->refine_defocus && cfg->defocus_step > 0 && cfg->defocus_range >= cfg->defocus_step) {
             int nt = (int)floor(cfg->defocus_range / cfg->defocus_step + 1e-6); if (nt > PPM_MAX_DEFOCUS_STEPS) nt = PPM_MAX_DEFOCUS_STEPS;
@@ -786,16 +791,21 @@ int orc_refine_batch(void *refp, const ppm_refine_cfg *cfg, const float *images,
                 if (f > bestf) { bestf = f; bt = t; }
             }
             best.f = bestf;
+            cfin.df1 += bt * (double)cfg->defocus_step; cfin.df2 += bt * (double)cfg->defocus_step;
             out[PPM_DF1] = row[PPM_DF1] + bt * (double)cfg->defocus_step; out[PPM_DF2] = row[PPM_DF2] + bt * (double)cfg->defocus_step;
         }
         tot_l += nev; tot_s += sev;
         angles_from_matrix(best.M, &out[PPM_PSI], &out[PPM_THETA], &out[PPM_PHI]);
         out[PPM_XSHIFT] = best.sh[0] * g.a; out[PPM_YSHIFT] = best.sh[1] * g.a;
-        double cc = best.f, res = 1.0 - cc * cc; if (res < 1e-6) res = 1e-6;
+        double cc = best.f;
         out[PPM_SCORE] = 100.0 * cc;
+        /* answer 22 "classification resolution limit" (frealign.py:3945): LOGP / SIGMA come from the final pose scored over
+         * r_lo .. r_cls (what the occupancy update of 3-D classification compares between class references) */
+        if (g.r_cls < g.r_hi) { cc = score_local(r, &g, &cfin, I, wr, g.r_cls, best.M, best.sh); tot_l += 1; tot_s += floor(ORC_PI * g.r_cls * g.r_cls / 2); }
+        double res = 1.0 - cc * cc; if (res < 1e-6) res = 1e-6;
         /* whitened image against the best model: residual variance 1 - cc^2 per sample, n = in-band samples of the
          * full plane; LogP = Gaussian log-likelihood at the maximum-likelihood sigma */
-        double nsamp = ORC_PI * (g.r_hi * g.r_hi - g.r_lo * g.r_lo);
+        double nsamp = ORC_PI * (g.r_cls * g.r_cls - g.r_lo * g.r_lo);
         out[PPM_SIGMA] = sqrt(res);
         out[PPM_LOGP] = -0.5 * nsamp * (log(2.0 * ORC_PI * res) + 1.0);
         free(I); free(wr);

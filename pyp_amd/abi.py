@@ -20,6 +20,7 @@ class RefineCfg(C.Structure):
         ("refine_defocus", C.c_int), ("defocus_range", C.c_float), ("defocus_step", C.c_float),
         ("focus", C.c_float * 4),
         ("use_priors", C.c_int), ("prior_mean", C.c_float * 5), ("prior_var", C.c_float * 5),
+        ("res_classification", C.c_float),
     ]
 
     @classmethod
@@ -30,7 +31,7 @@ class RefineCfg(C.Structure):
                  angular_step=15.0, top_hits=20, search_range_x=0.0, search_range_y=0.0, global_search=1,
                  local_refine=1, refine_psi=1, refine_theta=1, refine_phi=1, refine_x=1, refine_y=1, normalize=1,
                  invert=0, mask_falloff=0.0, iters_hit=0, iters_final=0, local_angle_step=0.0, local_shift_step=0.0,
-                 band_factor=0.0, symmetry=b"C1", refine_defocus=0, defocus_range=500.0, defocus_step=50.0)
+                 band_factor=0.0, symmetry=b"C1", refine_defocus=0, defocus_range=500.0, defocus_step=50.0, res_classification=0.0)
         d.update(kw)
         for req in ("box", "pixel_size", "mask_radius", "res_high"):
             if req not in d:

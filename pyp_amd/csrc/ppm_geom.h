@@ -22,6 +22,7 @@ struct Geom {
     int N = 0;
     double a = 0;
     double r_hi = 0, r_lo = 0, r_s = 0, ring_signed = 0;
+    double r_cls = 0;             // band of LOGP / SIGMA (answer 22, ppm_refine_cfg.res_classification); = r_hi when unset
     int B = 0, W = 0, H = 0;      // full band: half-width, row width B+1, rows 2B+1
     int Bs = 0, Hs = 0;           // search band
     int Ns = 0, RSx = 0, RSy = 0;
@@ -87,6 +88,9 @@ inline bool geom_init(Geom &g, const ppm_refine_cfg &c, std::string &err) {
     if (c.global_search && g.r_s > 64.0) g.r_s = 64.0;   // the grid-search kernel covers 64 Fourier pixels (lane = kx); finer
                                                          // detail only enters through the refinement of the hits
     g.ring_signed = c.res_signed_cc > 0 ? na / c.res_signed_cc : 1e30;
+    // answer 22 (frealign.py:3945): 0, beyond res_high, or a band of less than one Fourier pixel above r_lo -> the full band
+    g.r_cls = c.res_classification > 0 ? na / c.res_classification : g.r_hi;
+    if (g.r_cls > g.r_hi || g.r_cls < g.r_lo + 1.0) g.r_cls = g.r_hi;
     g.B = (int)std::ceil(g.r_hi) - 1; g.W = g.B + 1; g.H = 2 * g.B + 1;
     g.Bs = (int)std::ceil(g.r_s) - 1; g.Hs = 2 * g.Bs + 1;
     if (g.B < 2) { err = "resolution limits leave fewer than 3 Fourier pixels"; return false; }

@@ -6,7 +6,7 @@ namespace ppm {
 
 // ---------------------------------------------------------------------------------- local refinement
 // One refinement trajectory.  M = Rz(phi) Ry(theta) Rz(psi) row-major; shifts in pixels.
-struct LState { double M[9]; double sh[2]; double f, ha, hs; int particle; int pad; };
+struct LState { double M[9]; double sh[2]; double f, ha, hs; int particle; int pad; double fc; };   // fc: score over the classification band (answer 22), set by the final launch
 
 __device__ inline void d_mat_mul3(const double *a, const double *b, double *c) {
     double t[9];
@@ -86,6 +86,7 @@ struct LocalP {
     // frequency marching: band (squared) and sample-list prefix of every iteration, and of the final score
     float rmax2_it[kMaxIters]; int S_it[kMaxIters];
     float rmax2_final; int S_final;
+    float rmax2_class; int S_class;     // answer 22: band of LOGP / SIGMA (S_class = 0: the full band, no extra sweep)
     // answer 7 "use priors" (include/ppm.h): Gaussian restraint on the refined parameters; w = 1 / (2 var n_s), shifts in pixels
     int use_priors; double pmean[5], pw[5];
 };
@@ -360,8 +361,15 @@ __global__ void __launch_bounds__(256, 5) k_local(LocalP P) {
         if (tid == 0) { single(st.M, st.sh); plan.S_used = P.S_final; plan.rmax2 = P.rmax2_final; }
         __syncthreads();
         sweep();
-        if (tid == 0) st.f = score[0];
+        if (tid == 0) st.f = st.fc = score[0];
         __syncthreads();
+        if (P.S_class > 0) {                          // the same pose over the classification band: LOGP / SIGMA of the row
+            if (tid == 0) { plan.S_used = P.S_class; plan.rmax2 = P.rmax2_class; }
+            __syncthreads();
+            sweep();
+            if (tid == 0) st.fc = score[0];
+            __syncthreads();
+        }
     }
     if (tid == 0) P.states[blockIdx.x] = st;
 }
@@ -376,7 +384,7 @@ __global__ void k_states_from_hits(const Hit *hits, LState *states, int n, int K
     int dir = h.orient / n_psi, k = h.orient - dir * n_psi;
     d_euler(k * dpsi, dir_theta[dir], dir_phi[dir], s.M);
     s.sh[0] = h.sx * step; s.sh[1] = h.sy * step;
-    s.f = h.cc; s.ha = ha0; s.hs = hs0; s.particle = i / K; s.pad = 0;
+    s.f = h.cc; s.fc = h.cc; s.ha = ha0; s.hs = hs0; s.particle = i / K; s.pad = 0;
     states[i] = s;
 }
 
@@ -387,7 +395,7 @@ __global__ void k_states_from_rows(const double *rows, LState *states, int n, do
     LState s;
     d_euler(r[PPM_PSI], r[PPM_THETA], r[PPM_PHI], s.M);
     s.sh[0] = r[PPM_XSHIFT] / a; s.sh[1] = r[PPM_YSHIFT] / a;
-    s.f = 0; s.ha = ha0; s.hs = hs0; s.particle = i; s.pad = 0;
+    s.f = 0; s.fc = 0; s.ha = ha0; s.hs = hs0; s.particle = i; s.pad = 0;
     states[i] = s;
 }
 
@@ -411,6 +419,7 @@ struct DefocusP {
     int nt; float step;
     int tchunk;            // offsets scored per pass over the samples (sizes the dynamic LDS)
     double *all_scores;    // null, or [n][2 nt + 1]: every offset's score is written out and nothing is chosen (constrained search)
+    float rcls2;           // > 0: the chosen offset is scored once more over the classification band (answer 22) -> states[p].fc
 };
 
 __global__ void __launch_bounds__(256) k_defocus(DefocusP P) {
@@ -433,8 +442,7 @@ __global__ void __launch_bounds__(256) k_defocus(DefocusP P) {
     const float invN = 1.0f / (float)P.N;
     // offsets are scored TC at a time (the per-wave ring tables of all 2 nt + 1 offsets do not fit the LDS at wide bands);
     // every chunk gathers the projection again
-    for (int t0 = 0; t0 < T; t0 += TC) {
-        const int tn = min(TC, T - t0);
+    auto score_offsets = [&](const int t0, const int tn, const float rmax2) {      // offsets t0 .. t0 + tn - 1 over k^2 < rmax2 -> score[t0 ..]
         for (int i = tid; i < tn * NW * nr + TC * NW; i += 256) { if (i < tn * NW * nr) ringA[i] = 0.f; else sumB[i - tn * NW * nr] = 0.f; }
         __syncthreads();
         float *const myA = ringA + wave * nr, *const myB = sumB + wave;
@@ -446,7 +454,7 @@ __global__ void __launch_bounds__(256) k_defocus(DefocusP P) {
             if (s < P.S_pad) {
                 unpack_sample(P.samples[s], kx, ky, al, ring);
                 const float k2 = (float)(kx * kx + ky * ky);
-                if (!(k2 < P.rmax2 && k2 >= P.rlo2)) al = 0;
+                if (!(k2 < rmax2 && k2 >= P.rlo2)) al = 0;
                 iv = Il[s];
             }
             const float fal = (float)al, fkx = (float)kx, fky = (float)ky;
@@ -485,21 +493,30 @@ __global__ void __launch_bounds__(256) k_defocus(DefocusP P) {
             }
         }
         __syncthreads();
-    }
+    };
+    for (int t0 = 0; t0 < T; t0 += TC) score_offsets(t0, min(TC, T - t0), P.rmax2);
     if (P.all_scores) {
         if (tid < T) P.all_scores[(size_t)p * T + tid] = score[tid];
         return;
     }
+    __shared__ int s_bt;
     if (tid == 0) {
         int bt = P.nt; double bf = score[P.nt];                  // the unshifted CTF is the incumbent
         for (int t = 0; t < T; t++) if (t != P.nt && score[t] > bf) { bf = score[t]; bt = t; }
-        P.states[p].f = bf;
+        P.states[p].f = P.states[p].fc = bf;
         P.ddef[p] = (float)(bt - P.nt) * P.step;
+        s_bt = bt;
+    }
+    if (P.rcls2 > 0.f) {                                         // LOGP / SIGMA: the chosen CTF over the classification band
+        __syncthreads();
+        const int bt = s_bt;
+        score_offsets(bt, 1, P.rcls2);
+        if (tid == 0) P.states[p].fc = score[bt];
     }
 }
 
 __global__ void k_rows_out(const LState *states, const double *rows_in, double *rows_out, int n, double a,
-                           double r_hi, double r_lo, const float *ddef) {
+                           double r_cls, double r_lo, const float *ddef) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const LState &s = states[i];
@@ -510,10 +527,11 @@ __global__ void k_rows_out(const LState *states, const double *rows_in, double *
     o[PPM_PSI] = psi; o[PPM_THETA] = th; o[PPM_PHI] = ph;
     o[PPM_XSHIFT] = s.sh[0] * a; o[PPM_YSHIFT] = s.sh[1] * a;
     if (ddef) { o[PPM_DF1] = r[PPM_DF1] + (double)ddef[i]; o[PPM_DF2] = r[PPM_DF2] + (double)ddef[i]; }
-    double cc = s.f, res = 1.0 - cc * cc; if (res < 1e-6) res = 1e-6;
-    o[PPM_SCORE] = 100.0 * cc;
+    o[PPM_SCORE] = 100.0 * s.f;
+    // LOGP / SIGMA over r_lo .. r_cls (answer 22; r_cls = r_hi and fc = f when no classification limit applies)
+    double cc = s.fc, res = 1.0 - cc * cc; if (res < 1e-6) res = 1e-6;
     o[PPM_SIGMA] = sqrt(res);
-    o[PPM_LOGP] = -0.5 * (3.14159265358979323846 * (r_hi * r_hi - r_lo * r_lo)) * (log(2.0 * 3.14159265358979323846 * res) + 1.0);
+    o[PPM_LOGP] = -0.5 * (3.14159265358979323846 * (r_cls * r_cls - r_lo * r_lo)) * (log(2.0 * 3.14159265358979323846 * res) + 1.0);
 }
 
 // ---------------------------------------------------------------------------------- brick-binned insertion

@@ -848,6 +848,9 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
         (void)t0;
     };
     LP.rmax2_final = (float)(gm.r_hi * gm.r_hi); LP.S_final = S_pad;
+    // answer 22: LOGP / SIGMA over r_lo .. r_cls; without a defocus refinement the final k_local launch scores it, with one k_defocus does
+    const bool cls_on = gm.r_cls < gm.r_hi;
+    LP.rmax2_class = (float)(gm.r_cls * gm.r_cls); LP.S_class = (cls_on && ndef == 0) ? prefix_of(gm.r_cls) : 0;
     if (!images_on_device) {        // first chunk's images
         HIPCHK(hipMemcpyAsync(ref->images.p, images, (size_t)std::min(CH, n_img) * NN * sizeof(float), hipMemcpyHostToDevice, cur_copy()));
         HIPCHK(hipStreamSynchronize(cur_copy()));
@@ -939,13 +942,14 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
             DP.cv = cv; DP.samples = ref->samples.p; DP.Il = ref->Il.p; DP.wring = ref->wring.p; DP.S_pad = S_pad; DP.nrings = nrings; DP.N = gm.N; DP.B = gm.B;
             DP.rlo2 = (float)(gm.r_lo * gm.r_lo); DP.rmax2 = (float)(gm.r_hi * gm.r_hi); DP.ring_signed = LP.ring_signed; DP.a = (float)gm.a;
             DP.rows = ref->rows_in.p; DP.states = final_states; DP.ddef = ref->ddef.p; DP.nt = ndef; DP.step = cfg->defocus_step; DP.all_scores = nullptr;
+            DP.rcls2 = cls_on ? (float)(gm.r_cls * gm.r_cls) : 0.f;
             const int T = 2 * ndef + 1;
             DP.tchunk = std::max(1, std::min(T, (int)(60000 / (16 * (size_t)nrings))));      // per-wave ring tables of one pass stay below 64 KB
             ProfScope ps(PPM_K_LOCAL);
             hipLaunchKernelGGL(k_defocus, dim3(nb), dim3(256), ring_lds_bytes(4, DP.tchunk, nrings), cur_stream(), DP);
             d_ddef = ref->ddef.p;
         }
-        hipLaunchKernelGGL(k_rows_out, dim3((nb + 255) / 256), dim3(256), 0, cur_stream(), final_states, ref->rows_in.p, ref->rows_out.p, nb, gm.a, gm.r_hi, gm.r_lo, d_ddef);
+        hipLaunchKernelGGL(k_rows_out, dim3((nb + 255) / 256), dim3(256), 0, cur_stream(), final_states, ref->rows_in.p, ref->rows_out.p, nb, gm.a, gm.r_cls, gm.r_lo, d_ddef);
         HIPCHK(hipGetLastError());
         if (!images_on_device && c0 + CH < n_img) {     // next chunk's images travel while this chunk computes
             const int nn = std::min(CH, n_img - (c0 + CH));
@@ -961,7 +965,8 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
     if (cfg->global_search) nl = (long)K * Tb * per_iter + (cfg->local_refine ? (long)Tc * per_iter : 0) + 1;
     else nl = 1 + (cfg->local_refine ? (long)(Tb + Tc) * per_iter : 0);
     ref->last_counts[0] = cfg->global_search ? gm.n_orient : 0;
-    nl += 2L * ndef;
+    nl += 2L * ndef + (cls_on ? 1 : 0);
+    if (cls_on) sample_evals += std::floor(kPi * gm.r_cls * gm.r_cls / 2);
     sample_evals += 2.0 * ndef * std::floor(kPi * gm.r_hi * gm.r_hi / 2);
     ref->last_counts[1] = nl;
     ref->last_counts[2] = (long)std::floor(kPi * gm.r_s * gm.r_s / 2);
@@ -1472,7 +1477,7 @@ extern "C" int ppm_csp_refine(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const p
         DP.cv.cube = ref->cube; DP.cv.NBX = ref->NBX; DP.cv.NBY = ref->NBY; DP.cv.LB = ref->LB; DP.cv.off = ref->B + 1; DP.cv.scale = (float)ref->pad;
         DP.samples = ref->samples.p; DP.Il = Il.p; DP.wring = wring.p; DP.S_pad = S_pad; DP.nrings = nrings; DP.N = gm.N; DP.B = gm.B;
         DP.rlo2 = (float)(gm.r_lo * gm.r_lo); DP.rmax2 = (float)(gm.r_hi * gm.r_hi); DP.ring_signed = (float)std::min(gm.ring_signed, 1e30); DP.a = (float)gm.a;
-        DP.rows = d_rows.p; DP.states = d_states.p; DP.ddef = nullptr; DP.nt = nt; DP.step = (float)step; DP.all_scores = d_out.p;
+        DP.rows = d_rows.p; DP.states = d_states.p; DP.ddef = nullptr; DP.nt = nt; DP.step = (float)step; DP.all_scores = d_out.p; DP.rcls2 = 0.f;
         DP.tchunk = std::max(1, std::min(Tn, (int)(60000 / (16 * (size_t)nrings))));
         {
             ProfScope ps(PPM_K_LOCAL);

@@ -10,193 +10,15 @@
 // run that moves 26 GB in half a second (bench.py, "dropin").
 //
 // Built by pyp_amd/csrc/Makefile into bin/reconstruct3d (g++, no HIP: the C ABI only).
-#include <algorithm>
-#include <atomic>
-#include <chrono>
-#include <cmath>
-#include <condition_variable>
-#include <cstdint>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <deque>
-#include <fcntl.h>
-#include <mutex>
-#include <string>
-#include <sys/file.h>
-#include <sys/mman.h>
-#include <sys/stat.h>
-#include <thread>
-#include <unistd.h>
-#include <vector>
+#include "dropin_common.h"
 
-#include "../../include/ppm.h"
+using namespace dropin;
 
 namespace {
 
-using Clock = std::chrono::steady_clock;
-double since(Clock::time_point t) { return std::chrono::duration<double>(Clock::now() - t).count(); }
-
-std::string self_dir() {
-    char buf[4096];
-    ssize_t n = readlink("/proc/self/exe", buf, sizeof buf - 1);
-    if (n <= 0) return ".";
-    buf[n] = 0;
-    std::string s(buf);
-    size_t p = s.rfind('/');
-    return p == std::string::npos ? "." : s.substr(0, p);
-}
-
-// hand the call to the Python implementation with the same stdin (nothing has touched the GPU yet)
-[[noreturn]] void fall_back(const std::string &input) {
-    int fd = memfd_create("reconstruct3d_stdin", 0);
-    if (fd >= 0) {
-        size_t done = 0;
-        while (done < input.size()) {
-            ssize_t w = write(fd, input.data() + done, input.size() - done);
-            if (w <= 0) break;
-            done += (size_t)w;
-        }
-        lseek(fd, 0, SEEK_SET);
-        dup2(fd, 0);
-        close(fd);
-    }
-    const std::string script = self_dir() + "/reconstruct3d.py";
-    const char *py = getenv("PPM_PYTHON");
-    if (!py || !*py) py = "/usr/bin/python3";
-    char *const argv[] = { (char *)py, (char *)script.c_str(), nullptr };
-    execv(py, argv);
-    printf("ERROR: reconstruct3d: cannot start %s %s\n", py, script.c_str());
-    fflush(stdout);
-    _exit(1);
-}
-
-[[noreturn]] void die(const std::string &msg) {
-    printf("%s\n", msg.rfind("ERROR", 0) == 0 || msg.find("ERROR") != std::string::npos ? msg.c_str() : ("ERROR: " + msg).c_str());
-    fflush(stdout);
-    _exit(1);          // no destructors: helper threads may still be inside the library
-}
-
-std::string strip(const std::string &s) {
-    size_t a = 0, b = s.size();
-    while (a < b && isspace((unsigned char)s[a])) a++;
-    while (b > a && isspace((unsigned char)s[b - 1])) b--;
-    return s.substr(a, b - a);
-}
-
-bool parse_bool(const std::string &s, bool &v) {
-    std::string t;
-    for (char c : s) t += (char)tolower((unsigned char)c);
-    if (t == "yes" || t == "y" || t == "true" || t == "1") { v = true; return true; }
-    if (t == "no" || t == "n" || t == "false" || t == "0") { v = false; return true; }
-    return false;
-}
-bool parse_num(const std::string &s, double &v) {
-    if (s.empty()) return false;
-    char *end = nullptr;
-    v = strtod(s.c_str(), &end);
-    return end && *end == 0 && end != s.c_str();
-}
-bool exists(const std::string &p) { struct stat st; return stat(p.c_str(), &st) == 0; }
-bool ends_with(const std::string &s, const char *suf) { size_t n = strlen(suf); return s.size() >= n && s.compare(s.size() - n, n, suf) == 0; }
-
-// the 32 standard columns of a .cistem table in file order (src/pyp/inout/metadata/cistem_star_file.py:596-628): code, type
-// (2 = int32, 3 = float32, 9 = uint32)
-const long long kCodes[32] = { 1, 4, 4194304, 8388608, 8, 16, 32, 64, 128, 256, 2, 512, 1024, 2048, 4096, 16384, 32768, 65536, 131072, 262144,
-                               524288, 1048576, 2097152, 8589934592LL, 17179869184LL, 20, 15, 35, 70, 55, 11, 121 };
-const int kTypes[32] = { 9, 3, 3, 3, 3, 3, 3, 3, 3, 3, 2, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 2, 2, 2, 2, 2, 3, 3 };
 enum { C_POS = 0, C_DF1 = 6, C_DF2 = 7, C_OCC = 11, C_SCORE = 14, C_PIND = 26 };
 
-// rows of a .cistem file as doubles (what Parameters.get_data() holds); false = not the plain standard layout (-> Python)
-bool read_cistem(const std::string &path, std::vector<double> &rows, long &n) {
-    int fd = open(path.c_str(), O_RDONLY);
-    if (fd < 0) return false;
-    struct stat st;
-    if (fstat(fd, &st) != 0 || st.st_size < 8) { close(fd); return false; }
-    std::vector<unsigned char> buf((size_t)st.st_size);
-    size_t done = 0;
-    while (done < buf.size()) {
-        ssize_t r = pread(fd, buf.data() + done, buf.size() - done, (off_t)done);
-        if (r <= 0) { close(fd); return false; }
-        done += (size_t)r;
-    }
-    close(fd);
-    int32_t ncols, nrows;
-    memcpy(&ncols, buf.data(), 4); memcpy(&nrows, buf.data() + 4, 4);
-    if (ncols != 32 || nrows <= 0) return false;
-    size_t pos = 8;
-    if (buf.size() < pos + 9u * 32u) return false;
-    for (int c = 0; c < 32; c++) {
-        int64_t code; int8_t ty;
-        memcpy(&code, buf.data() + pos, 8); ty = (int8_t)buf[pos + 8]; pos += 9;
-        if (code != kCodes[c] || ty != kTypes[c]) return false;
-    }
-    if (buf.size() - pos < (size_t)nrows * 128u) return false;
-    n = nrows;
-    rows.resize((size_t)nrows * 32);
-    const unsigned char *p = buf.data() + pos;
-    for (long i = 0; i < nrows; i++)
-        for (int c = 0; c < 32; c++, p += 4) {
-            double v;
-            if (kTypes[c] == 3) { float f; memcpy(&f, p, 4); v = f; }
-            else if (kTypes[c] == 2) { int32_t q; memcpy(&q, p, 4); v = q; }
-            else { uint32_t q; memcpy(&q, p, 4); v = q; }
-            rows[(size_t)i * 32 + c] = v;
-        }
-    return true;
-}
-
-// the cheap part of the same test: 32 standard columns in file order
-bool cistem_is_standard(const std::string &path) {
-    int fd = open(path.c_str(), O_RDONLY);
-    if (fd < 0) return false;
-    unsigned char b[8 + 9 * 32];
-    const bool got = pread(fd, b, sizeof b, 0) == (ssize_t)sizeof b;
-    close(fd);
-    if (!got) return false;
-    int32_t ncols, nrows;
-    memcpy(&ncols, b, 4); memcpy(&nrows, b + 4, 4);
-    if (ncols != 32 || nrows <= 0) return false;
-    for (int c = 0; c < 32; c++) {
-        int64_t code;
-        memcpy(&code, b + 8 + 9 * c, 8);
-        if (code != kCodes[c] || (int8_t)b[8 + 9 * c + 8] != kTypes[c]) return false;
-    }
-    return true;
-}
-
-struct MrcHead { int nx, ny, nz, mode; long offset; };
-bool read_mrc_head(const std::string &path, MrcHead &h) {
-    int fd = open(path.c_str(), O_RDONLY);
-    if (fd < 0) return false;
-    unsigned char b[1024];
-    bool ok = pread(fd, b, 1024, 0) == 1024;
-    struct stat st;
-    ok = ok && fstat(fd, &st) == 0;
-    close(fd);
-    if (!ok) return false;
-    int32_t w[56];
-    memcpy(w, b, sizeof w);
-    h.nx = w[0]; h.ny = w[1]; h.nz = w[2]; h.mode = w[3];
-    const int nsymbt = w[23];
-    if (h.nx <= 0 || h.ny <= 0 || h.nz <= 0 || nsymbt < 0 || h.nx > 65536 || h.ny > 65536) return false;
-    if (!(b[212] == 0x44 && (b[213] == 0x44 || b[213] == 0x41)) && !(b[212] == 0 && b[213] == 0)) return false;     // little-endian stamp (or none)
-    h.offset = 1024 + nsymbt;
-    return (long long)st.st_size >= h.offset + (long long)h.nx * h.ny * h.nz * 4;
-}
-
-// ---- a tiny blocking queue / flag set for the three pipeline stages
-template <typename T> struct Queue {
-    std::mutex m; std::condition_variable cv; std::deque<T> q;
-    void put(const T &v) { { std::lock_guard<std::mutex> lk(m); q.push_back(v); } cv.notify_one(); }
-    T get() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return !q.empty(); }); T v = q.front(); q.pop_front(); return v; }
-};
-struct Flag {
-    std::mutex m; std::condition_variable cv; bool on = true;
-    void set() { { std::lock_guard<std::mutex> lk(m); on = true; } cv.notify_all(); }
-    void wait_clear() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return on; }); on = false; }
-};
-struct Item { long lo, hi; int slot; int err; };
+[[noreturn]] void fall_back(const std::string &input) { hand_to_python("reconstruct3d.py", input); }
 
 int write_dump(const std::string &path, int box, float pixel, long long count, const float *data, size_t nfloat) {
     const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
@@ -227,39 +49,25 @@ int write_dump(const std::string &path, int box, float pixel, long long count, c
 
 int main() {
     const auto t0 = Clock::now();
-    std::string input;
-    {
-        char buf[65536];
-        ssize_t r;
-        while ((r = read(0, buf, sizeof buf)) > 0) input.append(buf, (size_t)r);
-    }
+    const std::string input = read_all_stdin();
     if (const char *e = getenv("PPM_NATIVE")) if (!strcmp(e, "0")) fall_back(input);
     // ---- the answers (pyp_amd/surface/prompts.py: read_answers, parse_reconstruct3d)
-    std::vector<std::string> a;
-    {
-        size_t p = 0;
-        while (p <= input.size()) {
-            size_t q = input.find('\n', p);
-            if (q == std::string::npos) q = input.size();
-            std::string s = strip(input.substr(p, q - p));
-            if (s == "eot") break;
-            a.push_back(s);
-            p = q + 1;
-        }
-        while (!a.empty() && a.back().empty()) a.pop_back();
-    }
+    const std::vector<std::string> a = read_answers(input);
     if (a.size() < 39) fall_back(input);
     const std::string stack = a[0], params = a[1], gstats = a[2], symmetry = a[8], res_file = a[7];
     double first, last, px, outer_radius, res_limit, bfac, thr, padding;
     bool score_weighting, dose, normalize, adjust, invert, excl, crop, split_eo, by_pind, center, blur, thrref, dump;
     bool ok = parse_num(a[9], first) && parse_num(a[10], last) && parse_num(a[11], px) && parse_num(a[14], outer_radius) && parse_num(a[15], res_limit) &&
               parse_num(a[17], bfac) && parse_bool(a[18], score_weighting) && parse_bool(a[21], dose);
-    double dummy;
-    ok = ok && parse_num(a[12], dummy) && parse_num(a[13], dummy) && parse_num(a[16], dummy) && parse_num(a[19], dummy) && parse_num(a[20], dummy);
+    // answers this build refuses or treats specially unless they carry the value PYP always sends (frealign.py:1763-1770, :1796-1808):
+    // the Python implementation owns the messages and the tilt window, so anything else goes there
+    double mass, inner_radius, res_reference, tilt_lo, tilt_hi, smoothing, threads;
+    ok = ok && parse_num(a[12], mass) && parse_num(a[13], inner_radius) && parse_num(a[16], res_reference) && parse_num(a[19], tilt_lo) && parse_num(a[20], tilt_hi);
     if (!ok || dose) fall_back(input);                 // dose weighting: five more answers, side files, a table over the whole file
-    ok = parse_num(a[22], thr) && parse_num(a[23], dummy) && parse_num(a[24], padding) && parse_bool(a[25], normalize) && parse_bool(a[26], adjust) &&
+    ok = parse_num(a[22], thr) && parse_num(a[23], smoothing) && parse_num(a[24], padding) && parse_bool(a[25], normalize) && parse_bool(a[26], adjust) &&
          parse_bool(a[27], invert) && parse_bool(a[28], excl) && parse_bool(a[29], crop) && parse_bool(a[30], split_eo) && parse_bool(a[31], by_pind) &&
-         parse_bool(a[32], center) && parse_bool(a[33], blur) && parse_bool(a[34], thrref) && parse_bool(a[35], dump) && parse_num(a[38], dummy);
+         parse_bool(a[32], center) && parse_bool(a[33], blur) && parse_bool(a[34], thrref) && parse_bool(a[35], dump) && parse_num(a[38], threads);
+    ok = ok && inner_radius == 0.0 && res_reference == 0.0 && smoothing == 1.0 && tilt_lo <= 0.0 && tilt_hi < 0.0;
     for (int k = 0; k < 9; k++) ok = ok && !a[k].empty();
     ok = ok && !a[36].empty() && !a[37].empty();
     const std::string dump1 = a[36], dump2 = a[37];
@@ -276,15 +84,7 @@ int main() {
     setenv("PPM_SYNC", "block", 0);
     const int dev = getenv("PPM_DEVICE") ? atoi(getenv("PPM_DEVICE")) : 0;
     // advisory per-GPU lock: PYP may start several processes per node (src/pyp/system/mpi.py:104)
-    int lockfd = -1;
-    {
-        const char *ld = getenv("PPM_LOCK_DIR");
-        const std::string lp = std::string(ld && *ld ? ld : "/tmp") + "/pyp_amd_gpu" + std::to_string(dev) + ".lock";
-        mode_t old = umask(0);
-        lockfd = open(lp.c_str(), O_RDWR | O_CREAT, 0666);
-        umask(old);
-        if (lockfd >= 0) flock(lockfd, LOCK_EX);
-    }
+    const int lockfd = gpu_lock(dev);
     const int box = mh.nx;
     const size_t sec = (size_t)box * box * 4;
     long chunk_mb = 256, call_mb = 2048;
@@ -292,7 +92,8 @@ int main() {
     // one staging buffer: whole images, no larger than the range can fill (page-locking costs ~0.2 s per GB)
     const size_t pin_bytes = std::min(std::max((size_t)16, ((size_t)chunk_mb << 20) / sec), (size_t)(ilast - ifirst + 1)) * sec;
     ppm_accum_t *acc = nullptr;
-    void *pinned[3] = { nullptr, nullptr, nullptr };
+    Stream st;
+    void **pinned = st.pinned;
     std::mutex up_m; std::condition_variable up_cv; int up_stage = 0; std::string up_err;      // up_stage: 1 = accumulator ready, 2 + k = pinned[k] ready
     std::atomic<int> want_pinned{3};
     auto t_dev = Clock::now();
@@ -379,65 +180,34 @@ int main() {
     const long chunk = std::max(1L, std::min(n, (long)(pin_bytes / sec)));
     const long nchunks = (n + chunk - 1) / chunk;
     const long group = std::max(1L, std::min(nchunks, (long)(((size_t)call_mb << 20) / ((size_t)chunk * sec))));
-    const int npin = (int)std::min(3L, nchunks), ndev = (int)std::min(2L, (nchunks + group - 1) / group);
-    want_pinned = npin;
-    const int nread = getenv("PPM_IO_THREADS") ? std::max(1, std::min(16, atoi(getenv("PPM_IO_THREADS")))) : 8;
-    const int fd = open(stack.c_str(), O_RDONLY);
-    if (fd < 0) bail("ERROR: reconstruct3d: cannot open " + stack);
-    auto img_off = [&](long i) { return mh.offset + (long long)((long)rin[(size_t)i * 32 + C_POS] - 1) * (long long)sec; };
-    void *dbuf[2] = { nullptr, nullptr };
-    Flag pin_free[3], dev_free[2];
-    Queue<Item> filled, ready;
-    double t_read = 0, t_up = 0, w_pin = 0, w_dev = 0;
-    std::thread reader([&] {
-        for (long k = 0, lo = 0; lo < n; k++, lo += chunk) {
-            const long hi = std::min(lo + chunk, n); const int slot = (int)(k % npin);
-            auto ta = Clock::now();
-            pin_free[slot].wait_clear();
-            if (!wait_stage(2 + slot)) { filled.put({ 0, 0, 0, 1 }); return; }          // page-locked by the start-up thread
-            auto tb = Clock::now();
-            if (contiguous) {
-                if (ppm_host_read(fd, img_off(lo), pinned[slot], (size_t)(hi - lo) * sec, nread) != 0) { filled.put({ 0, 0, 0, 1 }); return; }
-            } else {
-                for (long i = lo; i < hi; i++)                                                 // scattered rows: image by image
-                    if (ppm_host_read(fd, img_off(i), (char *)pinned[slot] + (size_t)(i - lo) * sec, sec, 1) != 0) { filled.put({ 0, 0, 0, 1 }); return; }
-            }
-            w_pin += std::chrono::duration<double>(tb - ta).count(); t_read += since(tb);
-            filled.put({ lo, hi, slot, 0 });
-        }
-        filled.put({ -1, -1, 0, 0 });
-    });
-    std::thread uploader([&] {
-        long k = 0, glo = 0;
-        for (;;) {
-            Item it = filled.get();
-            if (it.err) { ready.put(it); return; }
-            if (it.lo < 0) return;
-            const int dslot = (int)((k / group) % ndev); const long part = k % group;
-            auto ta = Clock::now();
-            if (part == 0) { dev_free[dslot].wait_clear(); glo = it.lo; }
-            if (!dbuf[dslot]) { dbuf[dslot] = ppm_device_alloc((size_t)group * chunk * sec); if (!dbuf[dslot]) { ready.put({ 0, 0, 0, 1 }); return; } }
-            auto tb = Clock::now();
-            if (ppm_device_upload((char *)dbuf[dslot] + (size_t)part * chunk * sec, pinned[it.slot], (size_t)(it.hi - it.lo) * sec) != 0) { ready.put({ 0, 0, 0, 1 }); return; }
-            pin_free[it.slot].set();
-            w_dev += std::chrono::duration<double>(tb - ta).count(); t_up += since(tb);
-            if (part == group - 1 || it.hi == n) ready.put({ glo, it.hi, dslot, 0 });
-            k++;
-        }
-    });
+    st.n = n; st.chunk = chunk; st.group = group; st.sec = sec; st.contiguous = contiguous;
+    st.npin = (int)std::min(3L, nchunks); st.ndev = (int)std::min(2L, (nchunks + group - 1) / group);
+    want_pinned = st.npin;
+    st.nread = getenv("PPM_IO_THREADS") ? std::max(1, std::min(16, atoi(getenv("PPM_IO_THREADS")))) : 8;
+    st.fd = open(stack.c_str(), O_RDONLY);
+    if (st.fd < 0) bail("ERROR: reconstruct3d: cannot open " + stack);
+    st.img_off = [&](long i) { return mh.offset + (long long)((long)rin[(size_t)i * 32 + C_POS] - 1) * (long long)sec; };
+    st.wait_pinned = [&](int slot) { return wait_stage(2 + slot); };          // page-locked by the start-up thread
+    st.start();
     double t_comp = 0, w_data = 0; long ncalls = 0;
     for (long lo = 0; lo < n;) {
         auto ta = Clock::now();
-        Item it = ready.get();
-        if (it.err) { reader.join(); uploader.join(); starter.join(); die(!up_err.empty() ? up_err : "ERROR: reconstruct3d: reading or uploading the particle stack failed"); }
+        Stream::Item it;
+        if (!st.next(it)) {
+            // a stage failed: the stream is aborted (no thread waits for a buffer any more); only the start-up thread is joined - it
+            // may be inside the runtime - and the process leaves through _exit
+            starter.join();
+            die(!up_err.empty() ? up_err : (!st.err.empty() ? st.err : std::string("ERROR: reconstruct3d: reading or uploading the particle stack failed")));
+        }
         auto tb = Clock::now();
-        if (ppm_insert_batch(acc, &rc, dbuf[it.slot], 1, (int)(it.hi - it.lo), rin.data() + (size_t)it.lo * 32) != 0) die(ppm_last_error());
-        dev_free[it.slot].set();
-        w_data += std::chrono::duration<double>(tb - ta).count(); t_comp += since(tb); ncalls++;
+        if (ppm_insert_batch(acc, &rc, st.dbuf[it.slot], 1, (int)(it.hi - it.lo), rin.data() + (size_t)it.lo * 32) != 0) { st.abort(); starter.join(); die(ppm_last_error()); }
+        st.release(it.slot);
+        w_data += secs(ta, tb); t_comp += since(tb); ncalls++;
         lo = it.hi;
     }
-    reader.join(); uploader.join(); starter.join();
-    close(fd);
+    st.join(); starter.join();
+    close(st.fd);
+    const double t_read = st.t_read, t_up = st.t_up, w_pin = st.w_pin, w_dev = st.w_dev;
     const auto t3 = Clock::now();
     const size_t nf = ppm_accum_floats(box);
     const size_t half = nf / 2;
@@ -452,8 +222,8 @@ int main() {
     if (ppm_accum_download_range(acc, h_even, 0, half) != 0 || ppm_accum_download_range(acc, h_odd, half, half) != 0) die(ppm_last_error());
     const long c0 = ppm_accum_count(acc, 0), c1 = ppm_accum_count(acc, 1);
     ppm_accum_destroy(acc);
-    for (void *p : dbuf) if (p) ppm_device_free(p);
-    if (lockfd >= 0) { flock(lockfd, LOCK_UN); close(lockfd); }
+    for (void *p : st.dbuf) if (p) ppm_device_free(p);
+    gpu_unlock(lockfd);
     int e1 = 0, e2 = 0;
     std::thread w2([&] { e2 = write_dump(dump2, box, (float)px, c0, h_even, half); });                   // even keys -> map 2
     e1 = write_dump(dump1, box, (float)px, c1, h_odd, half);                                            // odd keys  -> map 1

@@ -27,11 +27,17 @@ class gpu_lock:
     time owns the device memory (SURVEY.md §8b 'Threading')."""
 
     def __init__(self, device):
+        self.device = int(device)
         self.path = os.path.join(os.environ.get("PPM_LOCK_DIR", "/tmp"), "pyp_amd_gpu%d.lock" % int(device))
         self.fd = None
 
     def __enter__(self):
         import fcntl
+        w = sys.modules.get("pyp_amd.surface.warm")      # the start-up thread takes the lock before it creates the GPU context
+        if w is not None:
+            self.fd = w.adopt_lock(self.device)
+            if self.fd is not None:
+                return self
         try:        # world-writable lock file: several users may share the node's GPUs
             old = os.umask(0)
             try:
@@ -68,6 +74,25 @@ def _unsupported(d, keys, prog):
     for k, bad in keys:
         if d.get(k) == bad:
             _die(f"ERROR: {prog}: option '{k}' = {d[k]} is not supported by this build")
+
+
+def _refuse_unless(d, prog, defaults):
+    """Answers this build neither uses nor can honour: any value other than the one PYP always sends ends the run with ERROR
+    (fail loudly, never silently).  defaults: (key, the accepted value, what the answer would ask for)."""
+    for key, accepted, what in defaults:
+        if abs(float(d[key]) - accepted) > 1e-9:
+            _die(f"ERROR: {prog}: answer '{key}' = {d[key]:g} is not supported by this build ({what}); only {accepted:g} is accepted")
+
+
+def fraction_mask(positions, fraction):
+    """refine3d answer 14 "fraction of particles to use" (frealign.py:3934 always sends 1): the particles that get refined.  A row is
+    used when a fixed hash of its POSITION_IN_STACK, mapped to [0, 1), lies below the fraction, so the choice does not depend on how
+    PYP splits the particle ranges; the others are written out unchanged.  Build-defined (the absent program draws random numbers)."""
+    x = np.asarray(positions, dtype=np.uint64) & np.uint64(0xFFFFFFFF)
+    x = (x ^ (x >> np.uint64(16))) * np.uint64(0x7FEB352D) & np.uint64(0xFFFFFFFF)
+    x = (x ^ (x >> np.uint64(15))) * np.uint64(0x846CA68B) & np.uint64(0xFFFFFFFF)
+    x = x ^ (x >> np.uint64(16))
+    return (x.astype(np.float64) / 4294967296.0) < float(fraction)
 
 
 def _select(rows, first, last):
@@ -316,7 +341,7 @@ def refine_cfg_from_answers(d, box):
         refine_psi=int(d["refine_psi"]), refine_theta=int(d["refine_theta"]), refine_phi=int(d["refine_phi"]),
         refine_x=int(d["refine_x"]), refine_y=int(d["refine_y"]), normalize=int(d["normalize"]), invert=int(d["invert"]),
         symmetry=d["symmetry"][:7], refine_defocus=int(d["refine_defocus"]), defocus_range=d["defocus_range"],
-        defocus_step=d["defocus_step"])
+        defocus_step=d["defocus_step"], res_classification=d["res_classification"])
 
 
 def refine3d_main(argv=None, stdin=None):
@@ -330,6 +355,11 @@ def refine3d_main(argv=None, stdin=None):
     for k, v in d.items():
         print(f"{k:28s}: {v}")
     _unsupported(d, [("exclude_edges", True), ("normalize_reference", True), ("threshold_reference", True)], "refine3d")
+    _refuse_unless(d, "refine3d", [("inner_radius", 0.0, "an inner mask radius")])
+    if not 0.0 < d["fraction"] <= 1.0:
+        _die(f"ERROR: refine3d: fraction of particles to use must be in (0, 1], got {d['fraction']:g}")
+    if d["res_classification"] < 0:
+        _die(f"ERROR: refine3d: classification resolution limit must be >= 0, got {d['res_classification']:g}")
     pad = int(round(d["padding"]))
     if abs(d["padding"] - pad) > 1e-6 or pad not in (1, 2, 4):
         _die("ERROR: refine3d: padding factor must be 1, 2 or 4")
@@ -347,7 +377,13 @@ def refine3d_main(argv=None, stdin=None):
     else:
         rows = cistem.read_parameters(d["input_params"])
     sel = _select(rows, d["first"], d["last"])
-    rin = rows[sel]
+    rall = rows[sel]                        # every row of the range is written out; `use` marks the ones that are refined (answer 14)
+    use = fraction_mask(rall[:, C["POSITION_IN_STACK"]], d["fraction"]) if d["fraction"] < 1.0 else np.ones(len(rall), dtype=bool)
+    if not use.any():
+        _die(f"ERROR: refine3d: fraction {d['fraction']:g} leaves no particle of {d['first']}..{d['last']} to refine")
+    rin = rall[use]
+    if d["fraction"] < 1.0:
+        print(f"fraction of particles to use = {d['fraction']:g}: {len(rin)} of {len(rall)} rows are refined, the others are copied")
     mm = _open_stack(d["stack"], rin[:, C["POSITION_IN_STACK"]])
     box = mm.shape[1]
     vol = mrc.read(d["reference"]).astype(np.float32)
@@ -432,6 +468,10 @@ def refine3d_main(argv=None, stdin=None):
         _die(str(e))
     if note:
         print("\n" + note)
+    if not use.all():                       # the rows that were not drawn keep their input values
+        full = rall.copy()
+        full[use] = rout
+        rout, rin = full, rall
     changes = rout - rin
     changes[:, C["POSITION_IN_STACK"]] = rin[:, C["POSITION_IN_STACK"]]
     if d["surface"] == "par":
@@ -504,6 +544,18 @@ def read_dump(path):
 
 
 # ------------------------------------------------------------------------------------------ reconstruct3d
+def apply_tilt_window(rows, lo, hi):
+    """reconstruct3d answers 20 / 21 "min / max tilt-particle score": PYP's script sends 0 and -1 ("we just use occ as limit") and shows,
+    commented out next to them, what the pair carries: csp_UseImagesForRefinementMin / Max, the window of tilt-image indices that enter
+    (src/pyp/refine/frealign/frealign.py:1763-1766).  Rows whose TIND lies below `lo`, or above `hi` when hi >= 0, get OCCUPANCY 0
+    here (in place) - the same window ppm_csp_cfg.tind_min / tind_max applies to the refinement.  Returns the number switched off."""
+    t = rows[:, C["TIND"]]
+    off = (t < lo) | ((t > hi) if hi >= 0 else np.zeros(len(rows), dtype=bool))
+    off &= rows[:, C["OCCUPANCY"]] > 0
+    rows[off, C["OCCUPANCY"]] = 0.0
+    return int(off.sum())
+
+
 def reconstruct3d_main(argv=None, stdin=None):
     t0 = time.time()
     os.environ.setdefault("PPM_SYNC", "block")
@@ -518,6 +570,8 @@ def reconstruct3d_main(argv=None, stdin=None):
                      ("threshold_reference", True), ("exclude_edges", True), ("split_even_odd", False), ("dump", False)], "reconstruct3d")
     if abs(d["padding"] - 1.0) > 1e-6:
         _die("ERROR: reconstruct3d: only padding factor 1 is supported")
+    _refuse_unless(d, "reconstruct3d", [("inner_radius", 0.0, "an inner mask radius"), ("res_reference", 0.0, "a resolution limit for the input reconstruction"),
+                                        ("smoothing", 1.0, "a smoothing factor")])
     if not d["input_params"].endswith(".cistem"):
         _die("ERROR: reconstruct3d: input parameters must be a .cistem file")
     if d["crop"]:
@@ -533,6 +587,9 @@ def reconstruct3d_main(argv=None, stdin=None):
     sel = _select(rows, d["first"], d["last"])
     rin = rows[sel].copy()
     px = d["pixel_size"]
+    n_off = apply_tilt_window(rin, d["min_tilt_score"], d["max_tilt_score"])
+    if n_off:
+        print(f"tilt window {d['min_tilt_score']:g}..{d['max_tilt_score']:g}: {n_off} rows left out")
     used = rin[:, C["OCCUPANCY"]] > 0
     if d["adjust_scores"] and used.sum() > 10:
         # score vs defocus regression, removed before thresholding / weighting

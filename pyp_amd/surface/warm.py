@@ -8,6 +8,9 @@ import os
 import threading
 
 PIN_BYTES = 256 << 20          # one staging buffer of cli._iter_image_chunks (set by start())
+_lock_dev = None               # device whose advisory lock this thread takes BEFORE it creates the context (cli.gpu_lock adopts it)
+_lock_fd = None
+_lock_done = threading.Event()
 _thread = None
 _lock = threading.Lock()
 _pool = []                     # page-locked buffers nobody has taken yet
@@ -22,7 +25,7 @@ def chunk_mb(default):
         return int(default)
 
 
-def start(pinned=3, mb=256):
+def start(pinned=3, mb=256, lock=True):
     """pinned: how many staging buffers of `mb` MB (PPM_IO_CHUNK_MB overrides) to page-lock ahead: refine3d / reconstruct3d stream
     the stack through three."""
     global _thread, _want, PIN_BYTES
@@ -37,9 +40,29 @@ def start(pinned=3, mb=256):
         return
     _want = pinned
 
+    global _lock_dev
+    _lock_dev = dev if lock else None
+
     def run():
-        global _lib
+        global _lib, _lock_fd
         try:
+            # the per-GPU lock first (PYP starts several processes per node, src/pyp/system/mpi.py:104): a process that waits for
+            # the device holds neither a GPU context nor page-locked memory meanwhile - like the compiled executables
+            try:
+                if not lock:
+                    raise OSError("no lock asked for")
+                import fcntl
+                old = os.umask(0)
+                try:
+                    fd = os.open(os.path.join(os.environ.get("PPM_LOCK_DIR", "/tmp"), "pyp_amd_gpu%d.lock" % dev), os.O_CREAT | os.O_RDWR, 0o666)
+                finally:
+                    os.umask(old)
+                fcntl.flock(fd, fcntl.LOCK_EX)
+                _lock_fd = fd
+            except OSError:
+                pass                                 # cli.gpu_lock reports what is wrong with the lock file
+            finally:
+                _lock_done.set()
             L = ctypes.CDLL(so)                      # the same dlopen handle pyp_amd.lib.load() gets later; ppm_init is idempotent
             if L.ppm_init(dev) != 0:
                 return
@@ -60,6 +83,16 @@ def start(pinned=3, mb=256):
             pass
     _thread = threading.Thread(target=run)          # not a daemon: the interpreter waits for it rather than exit in the middle of hipInit
     _thread.start()
+
+
+def adopt_lock(device):
+    """The lock this thread took for `device` (a file descriptor the caller now owns and must unlock + close), or None."""
+    global _lock_fd
+    if _thread is None or _lock_dev != int(device):
+        return None
+    _lock_done.wait()
+    fd, _lock_fd = _lock_fd, None
+    return fd
 
 
 def join_init():
@@ -93,3 +126,10 @@ def release():
     with _lock:
         while _pool:
             _lib.ppm_host_free(_pool.pop())
+    global _lock_fd
+    if _lock_fd is not None:            # nobody adopted the lock (the run ended before it reached the device)
+        try:
+            os.close(_lock_fd)
+        except OSError:
+            pass
+        _lock_fd = None

@@ -495,3 +495,67 @@ def test_executables_give_the_same_files_whatever_the_pipeline_chunking(project,
         assert np.abs(fx - fy).max() <= 2e-6 * np.abs(fy).max()
     a, b = cistem.read_parameters(str(d / f"c_{tag}_0000007_0000055.cistem")), cistem.read_parameters(str(d / "c_base_0000007_0000055.cistem"))
     assert a.shape == (49, 32) and np.array_equal(a, b)
+
+
+def test_native_refine3d_equals_the_python_implementation(project, monkeypatch):
+    """bin/refine3d is the compiled front end of the default call (pyp_amd/csrc/refine3d_main.cpp) and hands everything else to
+    bin/refine3d.py: the same range through both (PPM_NATIVE=0 forces the hand-over) must give the same parameter and changes files
+    to the byte; the log carries the classification limit (answer 22) and LOGP differs from a run with another limit."""
+    d, vol, imgs, truth, start = project
+    assert run("refine3d", refine_script(4, 40, True, out="nat_out.cistem").replace("p_r01_0000004_0000040_changes", "nat_changes"), d, "ref_nat.log") == 0
+    monkeypatch.setenv("PPM_NATIVE", "0")
+    assert run("refine3d", refine_script(4, 40, True, out="py_out.cistem").replace("p_r01_0000004_0000040_changes", "py_changes"), d, "ref_py.log") == 0
+    monkeypatch.delenv("PPM_NATIVE")
+    ln, lp = open(d / "ref_nat.log").read(), open(d / "ref_py.log").read()
+    assert "libpypmatch, native" in ln and "libpypmatch, native" not in lp and "Refine3D: Normal termination" in ln and "Refine3D: Normal termination" in lp
+    assert open(d / "nat_out.cistem", "rb").read() == open(d / "py_out.cistem", "rb").read()
+    assert open(d / "nat_changes.cistem", "rb").read() == open(d / "py_changes.cistem", "rb").read()
+    tab = lambda s: [x for x in s.splitlines() if len(x) == 70 and x[:7].strip().isdigit()]
+    assert tab(ln) == tab(lp) and len(tab(ln)) == 37
+    # answer 22: the classification limit moves LOGP / SIGMA and nothing else
+    lines = refine_script(4, 40, True, out="nat_cls.cistem").splitlines()
+    lines[21] = str(PX * N / 12)
+    assert run("refine3d", "\n".join(lines) + "\n", d, "ref_cls.log") == 0
+    a, b = cistem.read_parameters(str(d / "nat_out.cistem")), cistem.read_parameters(str(d / "nat_cls.cistem"))
+    C = cistem.COL
+    same = [c for c in range(32) if c not in (C["LOGP"], C["SIGMA"])]
+    assert np.array_equal(a[:, same], b[:, same]) and not np.allclose(a[:, C["LOGP"]], b[:, C["LOGP"]])
+
+
+def test_refine3d_fraction_refines_a_subset_and_copies_the_rest(project):
+    """Answer 14 (frealign.py:3934 sends 1): with 0.5 about half of the range is refined, the other rows come out as they went in."""
+    d, vol, imgs, truth, start = project
+    lines = refine_script(1, M, True, out="frac_out.cistem").splitlines()
+    lines[13] = "0.5"
+    assert run("refine3d", "\n".join(lines) + "\n", d, "frac.log") == 0, open(d / "frac.log").read()[-1500:]
+    out = cistem.read_parameters(str(d / "frac_out.cistem"))
+    from pyp_amd.surface import cli
+    use = cli.fraction_mask(start[:, 0], 0.5)
+    assert 0 < use.sum() < M and out.shape == start.shape
+    assert np.array_equal(out[~use], cistem.read_parameters(str(d / "p_r01.cistem"))[~use])
+    assert np.all(out[use, cistem.COL["SCORE"]] != start[use, cistem.COL["SCORE"]])
+    assert "of %d rows are refined" % M in open(d / "frac.log").read()
+
+
+@pytest.mark.parametrize("prog", ["reconstruct3d", "refine3d"])
+def test_native_executables_end_with_error_when_an_upload_fails(project, monkeypatch, prog):
+    """A failing uploader (PPM_TEST_FAIL_UPLOAD=k: the k-th upload fails like a device error) used to leave the reader waiting for a
+    page-locked buffer for ever, with PYP waiting on the process: the run must end in an ERROR line, a non-zero exit and no output."""
+    d, vol, imgs, truth, start = project
+    used = truth.copy()
+    cistem.write_parameters(str(d / "f_used.cistem"), used)
+    monkeypatch.setenv("PPM_IO_CHUNK_MB", "1")          # 16 images per chunk: four chunks, three staging buffers
+    monkeypatch.setenv("PPM_IO_GROUP", "1")
+    monkeypatch.setenv("PPM_TEST_FAIL_UPLOAD", "1")
+    if prog == "reconstruct3d":
+        lines = ["p_stack.mrc", "f_used.cistem", "null", "p_r01.mrc", "f_map1.mrc", "f_map2.mrc", "output.mrc", "f.res", "C1", 1, M, PX, 300, 0,
+                 PX * N / 2, 2 * PX, 0, 2.0, "no", 0, -1, "no", 0, 1, 1, "yes", "no", "no", "no", "no", "yes", "no", "no", "no", "no", "yes",
+                 f"{d}/f_map1_n1.mrc", f"{d}/f_map2_n1.mrc", 1]
+        script, outs = "\n".join(str(x) for x in lines) + "\n", ["f_map1_n1.mrc", "f_map2_n1.mrc"]
+    else:
+        script, outs = refine_script(1, M, False, out="f_out.cistem"), ["f_out.cistem"]
+    cmd = f"{BIN}/{prog} << eot >> fail_{prog}.log 2>&1\n{script}eot\n"
+    r = subprocess.run(cmd, shell=True, cwd=d, timeout=120)              # a hang fails the test through the timeout
+    log = open(d / f"fail_{prog}.log").read()
+    assert r.returncode != 0 and "ERROR" in log and "PPM_TEST_FAIL_UPLOAD" in log and "native" in log
+    assert not any((d / o).exists() for o in outs)

@@ -816,3 +816,30 @@ def test_two_handles_driven_from_two_threads_equal_serial_runs(H, O):
     assert np.array_equal(out["a"], want_a) and np.array_equal(out["b"], want_b)
     assert np.linalg.norm(out["acc"] - want_acc) / np.linalg.norm(want_acc) < 1e-6       # global float atomics of the halo write-back
     assert not np.array_equal(want_a[:, 1:4], want_b[:, 1:4])
+
+
+@pytest.mark.parametrize("kw", [dict(global_search=0), dict(global_search=1, local_refine=0),
+                                dict(global_search=0, refine_defocus=1, defocus_range=200.0, defocus_step=50.0)])
+def test_classification_limit_moves_logp_and_sigma_like_the_oracle(H, O, kw):
+    """Answer 22 (class_rhcls, frealign.py:3945): LOGP / SIGMA over res_low .. res_classification at the final pose (and the final
+    CTF when the defocus is refined), SCORE and the pose as without it; evaluation counts include the extra sweep."""
+    n, px, m = 64, 2.0, 10
+    vol, imgs, rows = dataset(n, m, px, 0.2)
+    rows = rows.copy(); rows[:, 6] += 100.0; rows[:, 7] += 100.0
+    o, g = O.Reference(vol, n / 2), H.Reference(vol, n / 2)
+    c0 = cfg_for(n, px, **kw)
+    c1 = cfg_for(n, px, res_classification=px * n / 12, **kw)
+    w0, _ = O.refine_batch(o, c0, imgs, rows)
+    w1, cw = O.refine_batch(o, c1, imgs, rows)
+    g0, g1 = g.refine(c0, imgs, rows), g.refine(c1, imgs, rows)
+    lc = g.last_counts()
+    assert (lc["n_local"], lc["samples_local"]) == (cw[1], cw[2])
+    keep = [c for c in range(32) if c not in (12, 13)]
+    assert np.array_equal(g0[:, keep], g1[:, keep])                      # only LOGP (12) and SIGMA (13) move
+    assert not np.allclose(g0[:, 12], g1[:, 12])
+    assert synth.angular_error_deg(w1, g1).max() < ANG_TOL_DEG and synth.shift_error_px(w1, g1, px).max() < SHIFT_TOL_PX
+    assert np.abs(w1[:, 13] - g1[:, 13]).max() < 2e-4 and np.abs(w1[:, 12] - g1[:, 12]).max() < 2e-3 * np.abs(w1[:, 12]).max()
+    assert np.abs(w0[:, 13] - g0[:, 13]).max() < 2e-4
+    # a limit at or beyond res_high is the full band
+    g2 = g.refine(cfg_for(n, px, res_classification=1.0, **kw), imgs, rows)
+    assert np.array_equal(g2, g0)
