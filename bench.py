@@ -45,7 +45,7 @@ def parse(argv=None):
     ap.add_argument("--box", type=int, default=256)
     ap.add_argument("--band", type=float, default=64.0, help="search / refinement band limit, Fourier pixels")
     ap.add_argument("--angular-step", type=float, default=15.0)
-    ap.add_argument("--search-range", type=float, default=6.0, help="shift search range of the grid search, pixels (BASELINE config 2: shifts clipped at +-6 px); 0 = the widest window (8 search-grid steps), what PYP's default refine_searchx = 0 asks for")
+    ap.add_argument("--search-range", type=float, default=6.0, help="shift search range of the grid search, pixels (BASELINE config 2: shifts clipped at +-6 px); 0 = the mask radius, what PYP's default refine_searchx = 0 asks for (covered by overlapping tiles of 17 x 17 search-grid steps, one k_global launch each)")
     ap.add_argument("--unique", type=int, default=0, help="distinct clean projections (0 = one per particle: every particle has its own pose)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of each CPU oracle leg (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -180,7 +180,7 @@ def pmc_valu(summary, kernel, slices_per_particle):
     return out
 
 
-def global_flops_per_slice(band, search_range_px, box):
+def global_flops_per_slice(band, search_range_px, box, mask_radius_px):
     """Executed fp32 operations of k_global per STORED slice (it serves psi and psi + 180): per lane and row PAIR
     16 R FMA-flops for the shift rows (4 R packed FMAs on 2-vectors), 20 for the even / odd (A, Bq) parts and 4 for the
     two row sums; about 800 per lane for the window reduction and the recombination.  (The model norm sum C2 |P|^2 is a
@@ -191,10 +191,15 @@ def global_flops_per_slice(band, search_range_px, box):
     Ns = 2
     while Ns < 2 * (Bs + 1):
         Ns *= 2
-    R = max(1, min(8, int(np.ceil(search_range_px / (box / Ns))))) if search_range_px > 0 else 8
+    # the window in search-grid steps as ppm_geom.h derives it: range 0 = the mask radius, at most Ns / 2 - 1 steps; windows wider
+    # than 8 steps either side are searched as ntiles overlapping tiles of 17 x 17 steps, one k_global launch each (ppm_refine_batch)
+    rng_px = search_range_px if search_range_px > 0 else mask_radius_px
+    RS = max(1, min(int(np.ceil(rng_px / (box / Ns))), Ns // 2 - 1))
+    R = min(RS, 8)
+    tiles_1d = (2 * RS + 1 + 2 * R) // (2 * R + 1)
     trip = 16 if R <= 3 else 8
     HsP = ((2 * (Bs + 1) + trip - 1) // trip) * trip
-    return 64 * (HsP // 2) * (16 * R + 20 + 4) + 64 * 800, R, HsP
+    return (64 * (HsP // 2) * (16 * R + 20 + 4) + 64 * 800) * tiles_1d * tiles_1d, R, HsP, tiles_1d * tiles_1d
 
 
 # --------------------------------------------------------------------------------------------- main
@@ -326,20 +331,20 @@ def refine_bench(ctx):
     # around every launch of the timed region
     S_g = counts["samples_global"]
     launches_g = max(prof["global"]["launches"], 1)
-    ppl = M * a.steps / launches_g                                            # particles per k_global launch
+    ppl = M * a.steps / launches_g                                            # particles per k_global launch (a tiled shift window launches once per tile: see below)
     ms_g = prof["global"]["ms"] / launches_g
-    fl_slice, R, HsP = global_flops_per_slice(a.band, srange / px, N)
+    fl_slice, R, HsP, ntiles = global_flops_per_slice(a.band, srange / px, N, 0.32 * N)
     n_slices = counts["n_global"] / 2.0                                        # stored slices (psi and psi + 180 share one)
     flops_g = ppl * n_slices * fl_slice
     tf = flops_g / (ms_g * 1e-3) / 1e12
-    bytes_model = ppl * counts["n_global"] * 8.0 * S_g                        # SURVEY §8(d) streaming model
+    bytes_model = ppl * counts["n_global"] * 8.0 * S_g * ntiles               # SURVEY §8(d) streaming model (every tile of the shift window streams the bank again)
     gbps_model = bytes_model / (ms_g * 1e-3) / 1e9
     traffic, traffic_src = pmc_traffic(pmc_latest("refine"), "k_global", ppl)
     roof = {"bound": "valu_fp32", "kernel": "k_global", "achieved": round(tf, 2), "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tf / PEAK_VALU_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(ms_g, 3),
-            "particles_per_launch": round(ppl, 1), "flops_per_launch": flops_g,
+            "particles_per_launch": round(ppl * ntiles, 1), "shift_window_tiles": ntiles, "flops_per_launch": flops_g,
             "flop_model": "stored slices (%d) x [64 lanes x %d row pairs x (16 R + 24) + 64 x 800], R = %d shift rows; executed fp32 "
-                          "operations incl. masked lanes (DESIGN.md §4)" % (int(n_slices), HsP // 2, R),
+                          "operations incl. masked lanes (DESIGN.md §4)%s" % (int(n_slices), HsP // 2, R, "" if ntiles == 1 else " x %d tiles of the shift window" % ntiles),
             "in_band_fraction_of_lane_rows": round(S_g / (64.0 * HsP), 3),
             "hbm_streaming_model": {"bytes_per_launch": bytes_model, "GBps": round(gbps_model, 1),
                                     "frac_clamped": round(min(1.0, gbps_model / PEAK_HBM_GBPS), 4), "exceeds_peak": bool(gbps_model > PEAK_HBM_GBPS),
@@ -394,7 +399,7 @@ def refine_bench(ctx):
                               "median_shift_px": round(float(np.median(shf)), 3)},
     }
     if world == 1 and not a.no_cpu and a.cpu_seconds > 0:
-        line["cpu_baseline"] = cpu_baseline(vol, stack, start_rows, cfg, N, a.cpu_seconds)
+        line["cpu_baseline"], line["parity_vs_oracle"] = cpu_baseline(vol, stack, start_rows, cfg, N, a.cpu_seconds, out, px)
     if world == 1 and not a.no_dropin:
         try:                    # side figures: a failure is reported in the line
             line["dropin"] = dropin_bench(a, vol, stack, start_rows, rows, px, res, srange)
@@ -582,7 +587,13 @@ def reconstruct_bench(ctx):
     h1, h2, fl, stats = acc.finalize(FinalCfg(molecular_mass_kda=500.0, inner_radius=0.0, outer_radius=0.45 * N * px, mask_falloff=0.0))
     acc.close()
     cc = float(np.corrcoef(fl.ravel(), vol.ravel())[0, 1])
-    return {"metric": "particles/sec Fourier insertion, 256^2 box", "value": round(world * M * a.steps / dt, 1), "unit": "particles/s",
+    extra = {}
+    if world == 1 and not a.no_cpu and a.cpu_seconds > 0:
+        try:                    # side figures: a failure is reported in the line
+            extra["parity_vs_oracle"], extra["cpu_baseline"] = recon_parity(stack, rows, rc, N, px, local)
+        except Exception as e:          # noqa: BLE001
+            extra["parity_vs_oracle"] = {"error": str(e)[:300]}
+    return {**extra, "metric": "particles/sec Fourier insertion, 256^2 box", "value": round(world * M * a.steps / dt, 1), "unit": "particles/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "3D reconstruction: Fourier-insert %dk %d^2 particles/GPU (resident stack, %.0f GB) -> %d^3 half-maps, C1, "
@@ -593,6 +604,37 @@ def reconstruct_bench(ctx):
             "kernels_us_per_particle": per_us, "compulsory_bytes_per_particle": 4 * N * N,
             "path_hbm_frac_compulsory": round(world * M * a.steps * 4.0 * N * N / dt / 1e9 / PEAK_HBM_GBPS / world, 4),
             "map_cc_vs_truth": round(cc, 4), "fsc_at_half_nyquist": round(float(stats[N // 4 - 1, 3]), 4)}
+
+
+def recon_parity(stack, rows, rc, N, px, local, want=2000, budget_s=30.0):
+    """The first `want` particles of the timed stack inserted by the oracle (oracle.insert_batch, OpenMP) and by the HIP path into
+    fresh accumulators: relative L2 distance of the two accumulators (value channels and weight channel), particle counts.
+    The oracle runs in pieces of 250 particles and stops after `budget_s` seconds; both sides insert the same particles."""
+    from oracle import oracle
+    from pyp_amd import host
+    cores = host_cores()
+    _omp_threads(cores)
+    acc_o, cnt_o = np.zeros(oracle.accum_floats(N), np.float32), np.zeros(2, np.int64)
+    done, t0 = 0, time.time()
+    while done < min(want, len(rows)):
+        hi = min(done + 250, want, len(rows))
+        oracle.insert_batch(acc_o, cnt_o, rc, "C1", stack[done:hi].cpu().numpy(), rows[done:hi])
+        done = hi
+        if time.time() - t0 > budget_s:
+            break
+    tc = time.time() - t0
+    acc = host.Accumulator(N, px, "C1", device=local)
+    acc.insert(rc, stack[:done], rows[:done])
+    g, cnt_g = acc.download(), acc.counts()
+    acc.close()
+    go, gg = acc_o.reshape(-1, 3).astype(np.float64), g.reshape(-1, 3).astype(np.float64)
+    rel = lambda x, y: float(np.linalg.norm(x - y) / max(np.linalg.norm(y), 1e-300))
+    par = {"n": int(done), "rel_l2_accumulator": float("%.3g" % rel(gg, go)), "rel_l2_values": float("%.3g" % rel(gg[:, :2], go[:, :2])),
+           "rel_l2_weights": float("%.3g" % rel(gg[:, 2], go[:, 2])), "max_abs_diff_over_max": float("%.3g" % (np.abs(gg - go).max() / np.abs(go).max())),
+           "counts_equal": bool(list(cnt_g) == [int(cnt_o[0]), int(cnt_o[1])]),
+           "sample": "the first %d particles of the timed stack into fresh accumulators: HIP path against oracle.insert_batch" % done}
+    cpu = {"value": round(done / tc, 2), "unit": "particles/s", "cores": cores, "kind": "port", "sample": "%d particles, %.1f s wall, OpenMP" % (done, tc)}
+    return par, cpu
 
 
 # --------------------------------------------------------------------------------------------- next rows (SURVEY.md §8f)
@@ -705,11 +747,19 @@ def csp_bench(ctx):
         oref = oracle.Reference(vol, n / 2)
         cc1 = CspCfg.make(CSP_PARTICLES, tol_angle=(8, 8, 8), tol_shift=4.0, first=int(p2[0, 0]), last=int(p2[k - 1, 0]))
         t1 = time.time()
-        oracle.csp_refine(oref, cfg, cc1, stack.cpu().numpy(), rows2, p2, tilts)
+        orow, opart, _, _ = oracle.csp_refine(oref, cfg, cc1, stack.cpu().numpy(), rows2, p2, tilts)
         tc = time.time() - t1
         oref.close()
         blk["cpu_baseline"] = {"value": round(len(sel) / tc, 2), "unit": "projections/s", "cores": cores, "kind": "port",
                                "sample": "%d particle units (%d projections), %.1f s wall, OpenMP; reference preparation %.1f s excluded" % (k, len(sel), tc, t1 - t0)}
+        # the same units in the timed GPU run: particle parameters (rotation, 3-D shift) and the scores of their projections
+        dang = perr(out[1][:k], opart[:k])
+        dsh = np.linalg.norm(out[1][:k, 1:4] - opart[:k, 1:4], axis=1)
+        dsc = np.abs(out[0][sel, 14] - orow[sel, 14])
+        blk["parity_vs_oracle"] = {"n_units": int(k), "n_projections": int(len(sel)), "max_deg": round(float(dang.max()), 4), "median_deg": round(float(np.median(dang)), 5),
+                                   "max_shift_px": round(float(dsh.max()), 4), "median_shift_px": round(float(np.median(dsh)), 5),
+                                   "max_abs_dSCORE": round(float(dsc.max()), 4), "tolerance": "0.1 deg / 0.5 px",
+                                   "sample": "the first %d particle units of the timed series: GPU against oracle.csp_refine" % k}
     return blk
 
 
@@ -798,9 +848,15 @@ def sva_bench(ctx):
         t0 = time.time()
         oref = oracle.Reference(vol, n / 2)
         t1 = time.time()
-        oracle.sva_align(oref, cfg, vols[:k].cpu().numpy(), wedges[:k], start[:k])
+        opose, osc, _ = oracle.sva_align(oref, cfg, vols[:k].cpu().numpy(), wedges[:k], start[:k])
         tc = time.time() - t1
         oref.close()
+        dang = synth.pose_angle_error(out[:k], opose)
+        dsh = np.linalg.norm(out[:k, 9:] - opose[:, 9:], axis=1)
+        blk["parity_vs_oracle"] = {"n": int(k), "max_deg": round(float(dang.max()), 4), "median_deg": round(float(np.median(dang)), 5),
+                                   "max_shift_px": round(float(dsh.max()), 4), "median_shift_px": round(float(np.median(dsh)), 5),
+                                   "max_abs_dscore": round(float(np.abs(sc[:k] - osc).max()), 5), "tolerance": "0.1 deg / 0.5 px",
+                                   "sample": "the first %d sub-volumes of the timed batch: GPU against oracle.sva_align" % k}
         blk["cpu_baseline"] = {"value": round(k / tc, 3), "unit": "sub-volumes/s", "cores": cores, "kind": "port",
                                "sample": "%d sub-volumes, %.1f s wall, OpenMP; reference preparation %.1f s excluded" % (k, tc, t1 - t0)}
     return blk
@@ -831,11 +887,25 @@ def host_cores():
     return n
 
 
-def cpu_baseline(vol, stack, start_rows, cfg, N, seconds):
+def pose_parity(want, got, px, what):
+    """GPU rows against the oracle's rows of the same particles: the north-star tolerance is 0.1 deg / 0.5 px."""
+    from pyp_amd import synth
+    ang, shf = synth.angular_error_deg(want, got), synth.shift_error_px(want, got, px)
+    dsc = np.abs(want[:, 14] - got[:, 14])
+    return {"n": int(len(want)), "max_deg": round(float(ang.max()), 4), "median_deg": round(float(np.median(ang)), 5),
+            "max_shift_px": round(float(shf.max()), 4), "median_shift_px": round(float(np.median(shf)), 5),
+            "max_abs_dSCORE": round(float(dsc.max()), 4), "median_abs_dSCORE": round(float(np.median(dsc)), 5),
+            "frac_within_0.1deg_0.5px": round(float(((ang < 0.1) & (shf < 0.5)).mean()), 4), "tolerance": "0.1 deg / 0.5 px (BASELINE.json north_star)",
+            "sample": what}
+
+
+def cpu_baseline(vol, stack, start_rows, cfg, N, seconds, gpu_rows=None, px=1.0):
     """The CPU oracle (kind "port": the reference binaries are absent) on bounded samples of the SAME stack,
     three ways: all host cores through OpenMP (the headline `value`), one thread, and P independent
     single-thread processes that each prepare the reference themselves - the reference's process model
-    (one refine3d per particle range with OMP_NUM_THREADS=1, src/pyp/refine/frealign/frealign.py:3183)."""
+    (one refine3d per particle range with OMP_NUM_THREADS=1, src/pyp/refine/frealign/frealign.py:3183).
+    Returns (cpu_baseline block, parity block): the rows the OpenMP leg computes are compared with the GPU rows of the same
+    particles of the timed run (`gpu_rows`) - the at-size parity figure of the line."""
     import ctypes
     import tempfile
     from oracle import oracle
@@ -846,28 +916,33 @@ def cpu_baseline(vol, stack, start_rows, cfg, N, seconds):
     oref = oracle.Reference(vol, N / 2)
     t_prep = time.time() - t0
     legs = {}
-    # ---- one thread, one particle (+ its own reference preparation)
+    # ---- one thread, eight particles (+ its own reference preparation)
+    mode = "oracle ccf_mode=1 (pruned separable transform of the shift window)"
     gomp.omp_set_num_threads(1)
+    n1 = min(8, len(imgs))
     t0 = time.time()
-    oracle.refine_batch(oref, cfg, imgs[:1], start_rows[:1], ccf_mode=1)
-    t1 = time.time() - t0
+    oracle.refine_batch(oref, cfg, imgs[:n1], start_rows[:n1], ccf_mode=1)
+    t1 = (time.time() - t0) / n1                         # seconds per particle on one thread
     legs["single_thread"] = {"value": round(1.0 / t1, 4), "unit": "particles/s", "cores": 1,
-                             "value_incl_reference_prep": round(1.0 / (t1 + t_prep), 4),
-                             "sample": "1 particle, %.1f s; reference preparation %.1f s" % (t1, t_prep)}
+                             "value_incl_reference_prep": round(n1 / (t1 * n1 + t_prep), 4),
+                             "sample": "%d particles, %.1f s; reference preparation %.1f s; %s" % (n1, t1 * n1, t_prep, mode)}
     # ---- all cores, OpenMP over particles
     gomp.omp_set_num_threads(cores)
     n = cores
     t0 = time.time()
-    oracle.refine_batch(oref, cfg, imgs[:n], start_rows[:n], ccf_mode=1)
+    orows, _ = oracle.refine_batch(oref, cfg, imgs[:n], start_rows[:n], ccf_mode=1)
     t2 = time.time() - t0
     if t2 < 0.5 * seconds and len(imgs) > n:
         n2 = max(cores, (int(min(len(imgs), max(256, n / t2 * seconds))) // cores) * cores)       # at least 256 particles (SURVEY 8d asks for a stable sample)
         t0 = time.time()
-        oracle.refine_batch(oref, cfg, imgs[:n2], start_rows[:n2], ccf_mode=1)
+        orows, _ = oracle.refine_batch(oref, cfg, imgs[:n2], start_rows[:n2], ccf_mode=1)
         t2, n = time.time() - t0, n2
     legs["openmp_all_cores"] = {"value": round(n / t2, 3), "unit": "particles/s", "cores": cores,
                                 "speedup_over_one_thread": round(n / t2 * t1, 1),
-                                "sample": "%d particles, %.1f s wall, OpenMP over particles; reference preparation %.1f s excluded" % (n, t2, t_prep)}
+                                "sample": "%d particles, %.1f s wall, OpenMP over particles; reference preparation %.1f s excluded; %s" % (n, t2, t_prep, mode)}
+    parity = None
+    if gpu_rows is not None:
+        parity = pose_parity(orows, gpu_rows[:n], px, "the first %d particles of the timed stack: rows of the timed GPU run against the oracle's OpenMP leg" % n)
     oref.close()
     # ---- P single-thread processes, one particle range each, reference prepared per process
     P = max(1, min(cores, 64))
@@ -895,7 +970,7 @@ def cpu_baseline(vol, stack, start_rows, cfg, N, seconds):
                                            "sample": "%d processes x %d particle(s), OMP_NUM_THREADS=1, each prepares the reference itself "
                                                      "(frealign.py:3183 process model), %.1f s wall" % (P, per, t3)}
     best = legs["openmp_all_cores"]
-    return {"value": best["value"], "unit": "particles/s", "cores": cores, "kind": "port", "sample": best["sample"], "legs": legs}
+    return {"value": best["value"], "unit": "particles/s", "cores": cores, "kind": "port", "sample": best["sample"], "legs": legs}, parity
 
 
 if __name__ == "__main__":

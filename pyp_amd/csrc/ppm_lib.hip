@@ -193,7 +193,6 @@ struct DevTmp {
     hipError_t alloc(size_t n) { return hipMalloc(&p, n * sizeof(T)); }
 };
 
-thread_local DevBuf<float2> g_prep_spill;     // (per calling thread) k_prep: the half spectrum between the row and the column phase, [n][N][W]
 
 }  // namespace
 
@@ -213,6 +212,7 @@ struct ppm_ref {
     // the band's sample list (built and sorted on the host: ~25 ms at 192^3 / 452 k samples) is kept while the band-pass settings stay
     struct { bool valid = false; float key[5] = { 0, 0, 0, 0, 0 }; int S = 0; std::vector<int> shell_off; DevBuf<uint32_t> samples; DevBuf<float> bandw; DevBuf<float2> Fw; bool fw_valid = false; float wkey[4] = { 0, 0, 0, 0 }; } s_plan;    // Fw: the window's transform at the samples
     DevBuf<float2> band, Il, Wp, bank, twN;
+    DevBuf<float2> spill;            // k_prep outside the scratch-free path: the half spectrum between the row and the column phase, [n][N][W]
     DevBuf<float4> rowtw;            // k_global's row-pair twiddles for this reference's current search grid
     DevBuf<int> sh;
     DevBuf<uint32_t> samples;
@@ -233,7 +233,7 @@ struct ppm_accum {
     unsigned long long *d_counts = nullptr;
     unsigned *d_max = nullptr;       // chunk maxima for the fixed-point scales of k_insert_bricks
     long counts[2] = { 0, 0 };
-    DevBuf<double> rows; DevBuf<float> images, dose; DevBuf<float2> band; DevBuf<PartIns> pp; DevBuf<CullEnt> cull; DevBuf<BrickItem> items;
+    DevBuf<double> rows; DevBuf<float> images, dose; DevBuf<float2> band, spill; DevBuf<PartIns> pp; DevBuf<CullEnt> cull; DevBuf<BrickItem> items;
     std::vector<float> brick_load; float load_r = -1.f; int n_items = 0, items_cap = -1;
 };
 
@@ -292,7 +292,7 @@ static int build_brick_items(ppm_accum *a, const Geom &gm, int BE, int nb) {
 }
 
 // ------------------------------------------------------------------------------ pre-processing launch
-static int launch_prep(const float *d_images, const double *d_rows, int n_img, const Geom &gm, float Rm_px, float fall_px,
+static int launch_prep(DevBuf<float2> &spill /* the calling handle's scratch */, const float *d_images, const double *d_rows, int n_img, const Geom &gm, float Rm_px, float fall_px,
                        int normalize, int invert, int do_mask, int whiten, float2 *band, float *wring,
                        const uint32_t *samples, int S_pad, float2 *Il, float *cw, float2 *Wp, float *C2, float *nI,
                        unsigned *band_max = nullptr /* insertion: receives the chunk's largest |band| component */,
@@ -336,8 +336,8 @@ static int launch_prep(const float *d_images, const double *d_rows, int n_img, c
     P.nchunks = (gm.W + P.nc - 1) / P.nc;
     P.nc = (gm.W + P.nchunks - 1) / P.nchunks;       // even chunks
     if (getenv("PPM_PREP_NCH")) { P.nchunks = std::max(P.nchunks, atoi(getenv("PPM_PREP_NCH"))); P.nc = (gm.W + P.nchunks - 1) / P.nchunks; P.nchunks = (gm.W + P.nc - 1) / P.nc; }
-    if (!inreg) if (int rc = g_prep_spill.ensure((size_t)n_img * gm.N * gm.W)) return rc;
-    P.spill = g_prep_spill.p;
+    if (!inreg) if (int rc = spill.ensure((size_t)n_img * gm.N * gm.W)) return rc;
+    P.spill = spill.p;
     P.band_max = band_max;
     P.band = band; P.wring = wring; P.samples = samples; P.S_pad = S_pad; P.Il = Il; P.cw = cw;
     P.Wp = Wp; P.C2 = C2; P.nI = nI; P.Bs = gm.Bs; P.Hs = gm.Hs;
@@ -546,6 +546,11 @@ ppm_ref_t *ppm_reference_create_weighted(const float *vol, int n, float max_band
     int B = (int)std::ceil((double)max_band_px * pad) - 1;
     if (B > np / 2 - 1) B = np / 2 - 1;
     size_t n3 = (size_t)n * n * n, np3 = (size_t)np * np * np;
+    std::unique_ptr<ppm_ref, void (*)(ppm_ref_t *)> guard(new ppm_ref(), ppm_reference_destroy);     // freed on every error return
+    ppm_ref *r = guard.get();
+    HIPCHKP(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
+    HIPCHKP(hipStreamCreateWithFlags(&r->copy, hipStreamNonBlocking));
+    StreamScope ss_(r->stream, r->copy);          // the preparation runs on the new handle's own stream: references may be made concurrently
     DevTmp<float> t_vol, t_w; DevTmp<float2> t_f;
     HIPCHKP(t_vol.alloc(n3));
     HIPCHKP(t_f.alloc(np3));
@@ -558,10 +563,6 @@ ppm_ref_t *ppm_reference_create_weighted(const float *vol, int n, float max_band
         d_w = t_w.p;
         HIPCHKP(hipMemcpyAsync(d_w, ring_weight, (size_t)n_weight * sizeof(float), hipMemcpyHostToDevice, cur_stream()));
     }
-    std::unique_ptr<ppm_ref, void (*)(ppm_ref_t *)> guard(new ppm_ref(), ppm_reference_destroy);     // freed on every error return
-    ppm_ref *r = guard.get();
-    HIPCHKP(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
-    HIPCHKP(hipStreamCreateWithFlags(&r->copy, hipStreamNonBlocking));
     r->N = n; r->pad = pad; r->B = B; r->CX = B + 2; r->CY = 2 * B + 3;
     size_t cube_n = (size_t)r->CX * r->CY * r->CY;
     r->NBX = (r->CX + 3) / 4; r->NBY = (r->CY + 1) / 2;
@@ -591,7 +592,7 @@ void ppm_reference_destroy(ppm_ref_t *r) {
     r->s_f.release(); r->s_g.release(); r->s_F.release(); r->s_vols.release(); r->s_plan.samples.release(); r->s_plan.bandw.release(); r->s_plan.Fw.release();
     r->c_Il.release(); r->c_band.release(); r->c_cw.release(); r->c_img.release(); r->c_wring.release(); r->c_rows.release(); r->c_N.release(); r->c_p.release(); r->c_tl.release();
     r->c_delta.release(); r->c_s0.release(); r->c_g0.release(); r->c_out.release(); r->c_eval.release(); r->c_rp.release(); r->c_rt.release(); r->c_slot.release(); r->c_states.release(); r->c_uoff.release(); r->c_mean.release(); r->cc.release(); r->mats.release(); r->ddef.release();
-    r->band.release(); r->Il.release(); r->Wp.release(); r->bank.release(); r->twN.release(); r->rowtw.release(); r->sh.release(); r->samples.release();
+    r->band.release(); r->spill.release(); r->Il.release(); r->Wp.release(); r->bank.release(); r->twN.release(); r->rowtw.release(); r->sh.release(); r->samples.release();
     r->hits.release(); r->states.release(); r->states2.release();
     if (r->stream) (void)hipStreamDestroy(r->stream);
     if (r->copy) (void)hipStreamDestroy(r->copy);
@@ -860,11 +861,11 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
         HIPCHK(hipMemcpyAsync(ref->rows_in.p, rows_in + (size_t)c0 * PPM_NCOL, (size_t)nb * PPM_NCOL * sizeof(double), hipMemcpyHostToDevice, cur_stream()));
         const float *d_img = images_on_device ? (const float *)images + (size_t)c0 * NN : ref->images.p + (size_t)(ci & 1) * CH * NN;
         // refinement spectra (+ search tables when the same mask serves both)
-        if (int rc = launch_prep(d_img, ref->rows_in.p, nb, gm, Rm_px, fall_px, cfg->normalize, cfg->invert, 1, 1, ref->band.p, ref->wring.p,
+        if (int rc = launch_prep(ref->spill, d_img, ref->rows_in.p, nb, gm, Rm_px, fall_px, cfg->normalize, cfg->invert, 1, 1, ref->band.p, ref->wring.p,
                                  ref->samples.p, S_pad, ref->Il.p, ref->cw.p,
                                  (cfg->global_search && !sep_search) ? ref->Wp.p : nullptr, ref->C2.p, ref->nI.p, nullptr, focus_on ? focus_px : nullptr)) return rc;
         if (sep_search)
-            if (int rc = launch_prep(d_img, ref->rows_in.p, nb, gm, (float)(cfg->search_mask_radius / gm.a), fall_px, cfg->normalize, cfg->invert, 1, 1,
+            if (int rc = launch_prep(ref->spill, d_img, ref->rows_in.p, nb, gm, (float)(cfg->search_mask_radius / gm.a), fall_px, cfg->normalize, cfg->invert, 1, 1,
                                      ref->band.p, nullptr, nullptr, 0, nullptr, nullptr, ref->Wp.p, ref->C2.p, ref->nI.p)) return rc;
         LState *final_states = ref->states2.p;
         if (cfg->global_search) {
@@ -1022,7 +1023,7 @@ void ppm_accum_destroy(ppm_accum_t *a) {
     if (a->d_sym) (void)hipFree(a->d_sym);
     if (a->d_counts) (void)hipFree(a->d_counts);
     if (a->d_max) (void)hipFree(a->d_max);
-    a->rows.release(); a->images.release(); a->dose.release(); a->band.release(); a->pp.release(); a->cull.release(); a->items.release();
+    a->rows.release(); a->images.release(); a->dose.release(); a->band.release(); a->spill.release(); a->pp.release(); a->cull.release(); a->items.release();
     if (a->stream) (void)hipStreamDestroy(a->stream);
     if (a->copy) (void)hipStreamDestroy(a->copy);
     delete a;
@@ -1065,7 +1066,7 @@ int ppm_insert_batch(ppm_accum_t *a, const ppm_recon_cfg *cfg, const void *image
         const float *d_img = images_on_device ? (const float *)images + (size_t)c0 * NN : a->images.p + (size_t)(ci & 1) * CH * NN;
         // the chunk's value bounds ([0] max |band| from k_prep, [1] max weight from k_insert_params) scale the fixed point
         HIPCHK(hipMemsetAsync(a->d_max, 0, 2 * sizeof(unsigned), cur_stream()));
-        if (int prc = launch_prep(d_img, a->rows.p, nb, gm, cfg->mask_radius / cfg->pixel_size, 1.f, cfg->normalize, cfg->invert, 0, 0,
+        if (int prc = launch_prep(a->spill, d_img, a->rows.p, nb, gm, cfg->mask_radius / cfg->pixel_size, 1.f, cfg->normalize, cfg->invert, 0, 0,
                                   a->band.p, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, a->d_max)) return prc;
         // per-particle constants, then one block per (brick, particle slice, half)
         if (int r = a->pp.ensure(nb)) return r;
@@ -1152,12 +1153,10 @@ struct Rccl {
     const char *(*GetErrorString)(int) = nullptr;
     std::string err;
 };
-static Rccl &rccl() {
-    static Rccl r;
-    if (r.h || !r.err.empty()) return r;
+static void rccl_load(Rccl &r) {
     const char *names[] = { getenv("PPM_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
     for (const char *n : names) { if (!n) continue; r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (r.h) break; }
-    if (!r.h) { r.err = std::string("librccl could not be opened: ") + dlerror(); return r; }
+    if (!r.h) { r.err = std::string("librccl could not be opened: ") + dlerror(); return; }
     auto sym = [&](const char *n) { void *p = dlsym(r.h, n); if (!p && r.err.empty()) r.err = std::string("librccl lacks ") + n; return p; };
     r.GetUniqueId = (int (*)(void *))sym("ncclGetUniqueId");
     r.CommInitRank = (int (*)(void **, int, ppm_comm_id, int))sym("ncclCommInitRank");
@@ -1165,6 +1164,11 @@ static Rccl &rccl() {
     r.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))sym("ncclAllReduce");
     r.Reduce = (int (*)(const void *, void *, size_t, int, int, int, void *, hipStream_t))sym("ncclReduce");
     r.GetErrorString = (const char *(*)(int))sym("ncclGetErrorString");
+}
+static Rccl &rccl() {           // opened once, whichever thread asks first (the handle-less entry points are thread-safe, include/ppm.h)
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, rccl_load, std::ref(r));
     return r;
 }
 constexpr int kNcclInt64 = 4, kNcclFloat32 = 7, kNcclSum = 0;      // ncclDataType_t / ncclRedOp_t values of rccl.h
@@ -1460,7 +1464,7 @@ extern "C" int ppm_csp_refine(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const p
             HIPCHK(hipMemcpyAsync(img.p, (const float *)images + (size_t)c0 * NN, (size_t)nb * NN * sizeof(float), hipMemcpyHostToDevice, cur_stream()));
             d_img = img.p;
         }
-        if (int rc = launch_prep(d_img, d_rows.p + (size_t)c0 * PPM_NCOL, nb, gm, (float)rm_px, (float)(fall / gm.a), cfg->normalize, cfg->invert, 1, 1,
+        if (int rc = launch_prep(ref->spill, d_img, d_rows.p + (size_t)c0 * PPM_NCOL, nb, gm, (float)rm_px, (float)(fall / gm.a), cfg->normalize, cfg->invert, 1, 1,
                                  band.p, mode4 ? wring.p + (size_t)c0 * (gm.B + 2) : nullptr, ref->samples.p, S_pad, Il.p + (size_t)c0 * S_pad, cw.p + (size_t)c0 * S_pad, nullptr, nullptr, nullptr)) return rc;
         HIPCHK(hipStreamSynchronize(cur_stream()));
     }
