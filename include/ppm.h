@@ -12,6 +12,8 @@
  *   ppm_accum_download
  *   ppm_finalize          replaces `merge3d` (frealign.py:2075-2093): FSC / part-FSC / SSNR table,
  *                         Wiener-filtered map and the two half maps.
+*   ppm_sva_align /       replace the alignment and averaging steps of `external/TOMO/MPI_Classification`
+ *   ppm_sva_insert        (src/pyp/refine/tomo_avg/sub_tomo_avg.py:468-555, src/pyp_main.py:3007-3107).
  *   ppm_reference_create  is the "input reconstruction" preparation both binaries do at start-up
  *                         (answer 4 of the refine3d script, frealign.py:3923).
  *
@@ -304,6 +306,21 @@ int ppm_comm_unique_id(ppm_comm_id *id);
 void *ppm_comm_create(int n_ranks, int rank, const ppm_comm_id *id);
 void ppm_comm_destroy(void *comm);
 int ppm_accum_reduce(ppm_accum_t *acc, void *comm, int root);
+
+/* Sub-tomogram AVERAGE (BASELINE config 5 is "sub-tomogram averaging": a 3DAVG iteration ends in averaged maps,
+ * `<dataset>_iteration_%03d_refined_selected_average_0.mrc` + `..._filtered.mrc`, src/pyp/refine/tomo_avg/sub_tomo_avg.py:79-94,
+ * src/pyp_main.py:3076-3100; the next iteration aligns to them): the 3-D analogue of ppm_insert_batch.  Every sub-volume's transform
+ * ((v - mean) / sigma, the whole box: no window, no band-pass) is brought into the reference frame by its aligned pose - the
+ * convention of ppm_sva_align: F_v(k) = Ref(N k) e^{+2 pi i k.p / box} - and added to the accumulator of the half-map it belongs to
+ * (parity of index[v], or of v when index is NULL; odd -> half 1), with its missing-wedge mask as the weight:
+ *     num_h(q) += m_v(k) F_v(k) e^{-2 pi i k.p / box} / box,    den_h(q) += m_v(k),    k = N^T q  (trilinear interpolation of F_v)
+ * for |q| < box/2 - 1, m_v = 1 where the tilt angle of (k_x, k_z) lies in the sub-volume's lwedge .. uwedge (cfg->use_missing_wedge)
+ * and everywhere otherwise.  `acc` = ppm_accum_create(box, pixel, "C1", ...); ppm_accum_count counts sub-volumes; shards on several
+ * GPUs are summed with ppm_accum_reduce; ppm_finalize turns the sums into the two half-maps, the FSC-weighted average and the
+ * statistics table exactly as for a reconstruction.  Of cfg only box and use_missing_wedge are read.  Build-defined (the absent
+ * MPI_Classification's weighting is not visible). */
+int ppm_sva_insert(ppm_accum_t *acc, const ppm_sva_cfg *cfg, const void *volumes, int volumes_on_device, int n_vol, const float *wedges,
+                   const double *poses, const long *index);
 
 /* half1/half2/filtered: box^3 floats each (host).  stats: (box/2) * PPM_STATS_COLS doubles. */
 int ppm_finalize(ppm_accum_t *acc, const ppm_final_cfg *cfg, float *half1, float *half2,

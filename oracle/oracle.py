@@ -47,6 +47,7 @@ def lib():
         L.orc_insert_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_void_p]
         L.orc_finalize.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_sva_align.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_sva_insert.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_csp_pose.argtypes = [C.c_double, C.c_double, C.c_void_p, C.c_void_p]
         L.orc_csp_pose.restype = None
         L.orc_csp_refine.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
@@ -206,3 +207,14 @@ def sva_align(ref, cfg, volumes, wedges, poses):
     if rc:
         raise RuntimeError(f"oracle: sva_align failed ({rc})")
     return poses, scores, nev.value
+
+
+def sva_insert(acc, counts, cfg, volumes, wedges, poses, index=None):
+    """Sub-tomogram average (orc_sva_insert): adds the aligned sub-volumes to `acc` (accum_floats(box) float32) and `counts` (2 int64) in place."""
+    volumes = np.ascontiguousarray(volumes, dtype=np.float32)
+    wedges = np.ascontiguousarray(wedges, dtype=np.float32)
+    poses = np.ascontiguousarray(poses, dtype=np.float64)
+    idx = None if index is None else np.ascontiguousarray(index, dtype=np.int64)
+    rc = lib().orc_sva_insert(_p(acc), _p(counts), C.byref(cfg), _p(volumes), len(poses), _p(wedges), _p(poses), None if idx is None else _p(idx))
+    if rc:
+        raise RuntimeError(f"oracle: sva_insert failed ({rc})")

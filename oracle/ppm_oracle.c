@@ -1645,3 +1645,64 @@ int orc_sva_align(void *refp, const ppm_sva_cfg *cfg, const float *volumes, int 
     if (eval_count) *eval_count = nev;
     return err;
 }
+
+/* ------------------------------------------------------------------ sub-tomogram average */
+/* The averaging step of a 3DAVG iteration (the absent MPI_Classification writes `<dataset>_iteration_%03d_refined_selected_average_0.mrc`,
+ * src/pyp/refine/tomo_avg/sub_tomo_avg.py:79-94, src/pyp_main.py:3076-3100): restated as the 3-D analogue of K7 - every sub-volume's
+ * normalised transform, taken into the reference frame by its aligned pose (F_v(k) = Ref(N k) e^{+2 pi i k.p / N}, the convention of
+ * orc_sva_align), is added with its missing-wedge mask as the weight (include/ppm.h, ppm_sva_insert).  Gathered per voxel q of the
+ * accumulator's half space: k = N^T q, trilinear interpolation of F_v.  Build-defined, PARITY UNPINNED.
+ * acc / counts: the layout of orc_insert_batch; index (may be NULL): parity -> half map. */
+int orc_sva_insert(float *acc, long *counts, const ppm_sva_cfg *cfg, const float *volumes, int n_vol, const float *wedges,
+                   const double *poses, const long *index) {
+    fft_tables();
+    const int N = cfg->box;
+    if (!box_ok(N)) return -22;
+    const size_t n3 = (size_t)N * N * N, NX = N / 2 + 1, half_sz = (size_t)N * N * NX * 3;
+    const double rmax = N / 2 - 1;
+    cpx *f = (cpx *)malloc(n3 * sizeof(cpx));
+    if (!f) return -12;
+    for (int v = 0; v < n_vol; v++) {
+        const float *vol = volumes + (size_t)v * n3;
+        double s1 = 0, s2 = 0;
+        for (size_t i = 0; i < n3; i++) { s1 += vol[i]; s2 += (double)vol[i] * vol[i]; }
+        const double mu = s1 / n3, var = s2 / n3 - mu * mu, sd = var > 0 ? sqrt(var) : 1.0;
+        for (size_t i = 0; i < n3; i++) { f[i].re = (float)((vol[i] - mu) / sd); f[i].im = 0; }
+        fft3_inplace(f, N, 0);
+        const long key = index ? index[v] : (long)v;
+        const int h = (int)(((key % 2) + 2) % 2);
+        counts[h]++;
+        float *A = acc + (size_t)h * half_sz;
+        const double *Nm = poses + (size_t)v * 12, *p = Nm + 9;
+        const double lw = wedges ? wedges[2 * v] : -90.0, uw = wedges ? wedges[2 * v + 1] : 90.0;
+#pragma omp parallel for schedule(static)
+        for (int qz = -N / 2; qz < N / 2; qz++) for (int qy = -N / 2; qy < N / 2; qy++) for (int qx = 0; qx <= N / 2; qx++) {
+            const double q2 = (double)qx * qx + (double)qy * qy + (double)qz * qz;
+            if (q2 == 0 || q2 >= rmax * rmax) continue;
+            if (qx == 0 && (qy < 0 || (qy == 0 && qz < 0))) continue;          /* the fold of orc_finalize supplies the mates */
+            /* k = N^T q */
+            const double kx = Nm[0] * qx + Nm[3] * qy + Nm[6] * qz, ky = Nm[1] * qx + Nm[4] * qy + Nm[7] * qz, kz = Nm[2] * qx + Nm[5] * qy + Nm[8] * qz;
+            if (cfg->use_missing_wedge) {
+                double a = atan2(kz, kx) * 180.0 / ORC_PI;
+                if (a > 90.0) a -= 180.0;
+                if (a <= -90.0) a += 180.0;
+                if (!(a >= lw && a <= uw)) continue;
+            }
+            const int x0 = (int)floor(kx), y0 = (int)floor(ky), z0 = (int)floor(kz);
+            const double fx = kx - x0, fy = ky - y0, fz = kz - z0;
+            double sr = 0, si = 0;
+            for (int dz = 0; dz < 2; dz++) for (int dy = 0; dy < 2; dy++) for (int dx = 0; dx < 2; dx++) {
+                int x = x0 + dx, y = y0 + dy, z = z0 + dz, mate = 0;
+                if (x < 0) { x = -x; y = -y; z = -z; mate = 1; }
+                const cpx *t = &f[((size_t)((z + N) % N) * N + ((y + N) % N)) * N + x];
+                const double sg = ((x + y + z) & 1) ? -1.0 : 1.0, wt = (dx ? fx : 1 - fx) * (dy ? fy : 1 - fy) * (dz ? fz : 1 - fz);
+                sr += wt * sg * t->re; si += wt * sg * (mate ? -t->im : t->im);
+            }
+            const double ph = -2.0 * ORC_PI * (kx * p[0] + ky * p[1] + kz * p[2]) / N, cr = cos(ph), ci = sin(ph);
+            float *o = A + (((size_t)(qz + N / 2) * N + (qy + N / 2)) * NX + qx) * 3;
+            o[0] += (float)((sr * cr - si * ci) / N); o[1] += (float)((sr * ci + si * cr) / N); o[2] += 1.0f;
+        }
+    }
+    free(f);
+    return 0;
+}

@@ -234,6 +234,7 @@ struct ppm_accum {
     unsigned *d_max = nullptr;       // chunk maxima for the fixed-point scales of k_insert_bricks
     long counts[2] = { 0, 0 };
     DevBuf<double> rows; DevBuf<float> images, dose; DevBuf<float2> band, spill; DevBuf<PartIns> pp; DevBuf<CullEnt> cull; DevBuf<BrickItem> items;
+    DevBuf<float2> s_f, s_g; DevBuf<float> s_vols;      // ppm_sva_insert: the transforms' work arrays and staged host volumes
     std::vector<float> brick_load; float load_r = -1.f; int n_items = 0, items_cap = -1;
 };
 
@@ -1023,7 +1024,7 @@ void ppm_accum_destroy(ppm_accum_t *a) {
     if (a->d_sym) (void)hipFree(a->d_sym);
     if (a->d_counts) (void)hipFree(a->d_counts);
     if (a->d_max) (void)hipFree(a->d_max);
-    a->rows.release(); a->images.release(); a->dose.release(); a->band.release(); a->spill.release(); a->pp.release(); a->cull.release(); a->items.release();
+    a->rows.release(); a->images.release(); a->dose.release(); a->band.release(); a->spill.release(); a->s_f.release(); a->s_g.release(); a->s_vols.release(); a->pp.release(); a->cull.release(); a->items.release();
     if (a->stream) (void)hipStreamDestroy(a->stream);
     if (a->copy) (void)hipStreamDestroy(a->copy);
     delete a;
@@ -2072,5 +2073,88 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
             if (scores) scores[c0 + v] = hout[v];
         }
     }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ sub-tomogram average
+// include/ppm.h: ppm_sva_insert.  Per batch of <= 32 sub-volumes: the FULL 3-D transforms (the pruned passes of the alignment with
+// the band at Nyquist; normalisation (v - mean) / sigma applied through the statistics the x pass gathers), then one k_sva_insert
+// launch that gathers them into the accumulator.
+extern "C" int ppm_sva_insert(ppm_accum_t *a, const ppm_sva_cfg *cfg, const void *volumes, int volumes_on_device, int n_vol, const float *wedges,
+                              const double *poses, const long *index) {
+    if (!g.inited) return fail(-1, "ppm_init has not been called");
+    if (!a || !cfg || !volumes || !poses) return fail(-22, "null argument");
+    StreamScope ss_(a->stream, a->copy);
+    if (n_vol <= 0) return 0;
+    const int N = cfg->box;
+    if (!box_ok(N) || N != a->N) return fail(-22, "sub-volume box differs from the accumulator's box (even, 32..512, prime factors 2, 3, 5)");
+    if (a->nsym != 1) return fail(-22, "sub-tomogram averaging needs a C1 accumulator");
+    const size_t n3 = (size_t)N * N * N;
+    const int KX = N / 2 + 1, KY = N, NB = std::min(n_vol, kSvaInsBatch);
+    const bool fast16 = N % 16 == 0 && getenv("PPM_SVA_GENERIC_FFT") == nullptr;
+    if (int rc = ensure_plan(N)) return rc;
+    if (int rc = a->s_f.ensure((size_t)NB * N * N * KX)) return rc;
+    if (fast16) if (int rc = a->s_g.ensure((size_t)NB * KX * KY * N)) return rc;
+    if (!volumes_on_device) if (int rc = a->s_vols.ensure((size_t)NB * n3)) return rc;
+    DevTmp<double> d_spart, d_stats, d_poses; DevTmp<float> d_wedges; DevTmp<int> d_half;
+    const int L16 = N <= 256 ? 16 : 8;
+    HIPCHK(d_spart.alloc((size_t)2 * NB * ((size_t)N * N / L16 + 1))); HIPCHK(d_stats.alloc((size_t)2 * NB)); HIPCHK(d_poses.alloc((size_t)12 * NB));
+    HIPCHK(d_wedges.alloc((size_t)2 * NB)); HIPCHK(d_half.alloc(NB));
+    SvaWin W; for (int k = 0; k < 3; k++) W.w[k] = 0.f;       // the average is made of the whole sub-volumes: no window, no band-pass
+    W.sigma = 0.f;
+    std::vector<float> hw((size_t)2 * NB); std::vector<int> hh(NB);
+    long added[2] = { 0, 0 };
+    for (int v0 = 0; v0 < n_vol; v0 += NB) {
+        const int m = std::min(NB, n_vol - v0);
+        const float *dv = (const float *)volumes + (size_t)v0 * n3;
+        if (!volumes_on_device) {
+            HIPCHK(hipMemcpyAsync(a->s_vols.p, dv, (size_t)m * n3 * sizeof(float), hipMemcpyHostToDevice, cur_stream()));
+            dv = a->s_vols.p;
+        }
+        for (int v = 0; v < m; v++) {
+            hw[2 * v] = wedges ? wedges[2 * (size_t)(v0 + v)] : -90.f; hw[2 * v + 1] = wedges ? wedges[2 * (size_t)(v0 + v) + 1] : 90.f;
+            const long key = index ? index[v0 + v] : (long)(v0 + v);
+            hh[v] = (int)(((key % 2) + 2) % 2);
+            added[hh[v]]++;
+        }
+        HIPCHK(hipMemcpyAsync(d_wedges.p, hw.data(), (size_t)2 * m * sizeof(float), hipMemcpyHostToDevice, cur_stream()));
+        HIPCHK(hipMemcpyAsync(d_half.p, hh.data(), (size_t)m * sizeof(int), hipMemcpyHostToDevice, cur_stream()));
+        HIPCHK(hipMemcpyAsync(d_poses.p, poses + (size_t)v0 * 12, (size_t)12 * m * sizeof(double), hipMemcpyHostToDevice, cur_stream()));
+        const long NN2 = (long)N * N;
+        SvaInsP IP;
+        {
+            ProfScope ps(PPM_K_PREP);
+            if (fast16) {
+                const size_t lds = (size_t)L16 * (N + 1) * sizeof(float2);
+                SvaX16P X; X.vol = dv; X.stats = d_spart.p; X.A = a->s_f.p; X.tw = g.plans[N].plan.tw; X.n = N; X.L = L16; X.KX = KX; X.mode = 1; X.nlines = (long)m * NN2; X.W = W;
+                hipLaunchKernelGGL(k_sva_x16, dim3((unsigned)(X.nlines / L16)), dim3(256), lds, cur_stream(), X);
+                hipLaunchKernelGGL(k_sva_stats_sum, dim3(m), dim3(64), 0, cur_stream(), d_spart.p, (int)(NN2 / L16), d_stats.p);
+                SvaYZ16P Y; Y.A = a->s_f.p; Y.B = a->s_g.p; Y.tw = X.tw; Y.n = N; Y.L = L16; Y.KX = KX; Y.KY = KY; Y.R = N / 2; Y.in_place = 0; Y.nlines = 0;
+                hipLaunchKernelGGL(k_sva_yz16, dim3((unsigned)((long)m * KX * (N / L16))), dim3(256), lds, cur_stream(), Y);
+                Y.in_place = 1; Y.nlines = (long)m * KX * KY;
+                hipLaunchKernelGGL(k_sva_yz16, dim3((unsigned)((Y.nlines + L16 - 1) / L16)), dim3(256), lds, cur_stream(), Y);
+                IP.T = a->s_g.p; IP.layout = 1; IP.stats = d_stats.p;
+            } else {
+                HIPCHK(hipMemsetAsync(d_stats.p, 0, (size_t)2 * m * sizeof(double), cur_stream()));
+                hipLaunchKernelGGL(k_sva_stats, dim3(64, m), dim3(256), 0, cur_stream(), dv, n3, d_stats.p);
+                SvaXP XP; XP.vol = dv; XP.stats = d_stats.p; XP.out = a->s_f.p; XP.plan = g.plans[N].plan; XP.n = N; XP.KX = KX; XP.nlines = (long)m * NN2; XP.W = W;
+                XP.L = std::max(1, std::min(16, 7000 / N));
+                while (NN2 % XP.L) XP.L--;
+                hipLaunchKernelGGL(k_sva_xpass, dim3((unsigned)((XP.nlines + XP.L - 1) / XP.L)), dim3(256), (size_t)XP.L * N * sizeof(float2), cur_stream(), XP);
+                if (int rc = fft_lines_pass(a->s_f.p, N, (long)m * N * KX, KX, 1, (long)N * KX, KX, 1, false)) return rc;
+                if (int rc = fft_lines_pass(a->s_f.p, N, (long)m * N * KX, (long)N * KX, 1, NN2 * KX, (long)N * KX, 1, false)) return rc;
+                IP.T = a->s_f.p; IP.layout = 0; IP.stats = nullptr;
+            }
+        }
+        IP.N = N; IP.KX = KX; IP.KY = KY; IP.nv = m; IP.poses = d_poses.p; IP.wedges = d_wedges.p; IP.half = d_half.p;
+        IP.use_wedge = cfg->use_missing_wedge != 0; IP.scale = 1.0f / (float)N; IP.acc = a->acc;
+        {
+            ProfScope ps(PPM_K_INSERT);
+            hipLaunchKernelGGL(k_sva_insert, dim3((unsigned)((NN2 * (N / 2 + 1) + 255) / 256)), dim3(256), 0, cur_stream(), IP);
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(cur_stream()));          // the host tables of the batch are reused
+    }
+    for (int h = 0; h < 2; h++) ppm_accum_set_count(a, h, a->counts[h] + added[h]);      // host and device copies of the counters
     return 0;
 }

@@ -468,4 +468,96 @@ __global__ void __launch_bounds__(256) k_sva_global(SvaGlobalP P) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------- sub-tomogram average (ppm_sva_insert)
+// The 3-D analogue of K7 as a GATHER: one thread per voxel q of the accumulator's half space (|q| < N/2 - 1; on the kx = 0 plane
+// only the canonical half: its Friedel mates are filled in by the fold of ppm_finalize) walks the sub-volumes of the batch, samples
+// each one's transform at k = N^T q by trilinear interpolation (Hermitian mates for kx < 0), removes the shift's phase and adds
+// value and weight (the sub-volume's missing-wedge mask at k) to its own sums - no atomics, the same sums in the same order whatever
+// the launch shape.  The voxel's cell of the half-map the sub-volume belongs to (parity of its index) is read and written once.
+// T: the batch's full transforms, layout 1 = B[v][kx][kyi][kz] of the two-step passes (KX = N/2 + 1, KY = N), layout 0 = f[v][z][y][KX].
+struct SvaInsP {
+    const float2 *T; int layout, N, KX, KY, nv;
+    const double *poses;      // [nv][12] N row-major + shift (pixels)
+    const float *wedges;      // [nv][2]
+    const double *stats;      // null (the transform is that of the normalised volume), or [nv][2] sum and sum of squares of the raw volume
+    const int *half;          // [nv] 0 / 1
+    int use_wedge; float scale;
+    float *acc;
+};
+constexpr int kSvaInsBatch = 32;
+
+__global__ void __launch_bounds__(256) k_sva_insert(SvaInsP P) {
+    __shared__ float sNt[kSvaInsBatch][9], ssh[kSvaInsBatch][3], swd[kSvaInsBatch][2], sinv[kSvaInsBatch];
+    __shared__ int shalf[kSvaInsBatch];
+    const int tid = threadIdx.x, N = P.N, NX = N / 2 + 1;
+    if (tid < P.nv) {
+        const double *pose = P.poses + (size_t)tid * 12;
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) sNt[tid][i * 3 + j] = (float)pose[j * 3 + i];          // N^T
+        for (int k = 0; k < 3; k++) ssh[tid][k] = (float)pose[9 + k];
+        swd[tid][0] = P.wedges[2 * tid]; swd[tid][1] = P.wedges[2 * tid + 1];
+        float inv = P.scale;
+        if (P.stats) {
+            const double n3 = (double)N * N * N, mu = P.stats[2 * tid] / n3, var = P.stats[2 * tid + 1] / n3 - mu * mu;
+            inv *= (float)(1.0 / (var > 0 ? sqrt(var) : 1.0));
+        }
+        sinv[tid] = inv; shalf[tid] = P.half[tid];
+    }
+    __syncthreads();
+    const size_t i = (size_t)blockIdx.x * 256 + tid, tot = (size_t)N * N * NX;
+    if (i >= tot) return;
+    const int qx = (int)(i % NX), qy = (int)((i / NX) % N) - N / 2, qz = (int)(i / ((size_t)NX * N)) - N / 2;
+    const float rmax = (float)(N / 2 - 1);
+    const float q2 = (float)(qx * qx + qy * qy + qz * qz);
+    if (!(q2 < rmax * rmax) || q2 == 0.f) return;
+    if (qx == 0 && (qy < 0 || (qy == 0 && qz < 0))) return;
+    const float fqx = (float)qx, fqy = (float)qy, fqz = (float)qz, invN = 1.0f / (float)N;
+    float ar0 = 0.f, ai0 = 0.f, aw0 = 0.f, ar1 = 0.f, ai1 = 0.f, aw1 = 0.f;      // the two half-maps' sums (scalars: run-time indexed arrays would live in scratch)
+    auto fetch = [&](const float2 *Tv, int x, int y, int z) {            // F(x, y, z), origin at the box centre
+        const bool mate = x < 0;
+        if (mate) { x = -x; y = -y; z = -z; }
+        const int yi = y < 0 ? y + N : y, zi = z < 0 ? z + N : z;
+        const float2 v = P.layout ? Tv[((size_t)x * P.KY + yi) * N + zi] : Tv[((size_t)zi * N + yi) * P.KX + x];
+        const float sg = ((x + y + z) & 1) ? -1.f : 1.f;
+        return make_float2(v.x * sg, mate ? -v.y * sg : v.y * sg);
+    };
+    const size_t per = P.layout ? (size_t)P.KX * P.KY * N : (size_t)N * N * P.KX;
+    for (int v = 0; v < P.nv; v++) {
+        const float *m = sNt[v];
+        const float kx = m[0] * fqx + m[1] * fqy + m[2] * fqz, ky = m[3] * fqx + m[4] * fqy + m[5] * fqz, kz = m[6] * fqx + m[7] * fqy + m[8] * fqz;
+        if (P.use_wedge) {
+            float a = atan2f(kz, kx) * 57.29577951308232f;
+            if (a > 90.f) a -= 180.f;
+            if (a <= -90.f) a += 180.f;
+            if (!(a >= swd[v][0] && a <= swd[v][1])) continue;
+        }
+        const float xf = floorf(kx), yf = floorf(ky), zf = floorf(kz);
+        const int x0 = (int)xf, y0 = (int)yf, z0 = (int)zf;
+        const float fx = kx - xf, fy = ky - yf, fz = kz - zf;
+        const float2 *Tv = P.T + (size_t)v * per;
+        float sr = 0.f, si = 0.f;
+#pragma unroll
+        for (int dz = 0; dz < 2; dz++)
+#pragma unroll
+            for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+                for (int dx = 0; dx < 2; dx++) {
+                    const float wt = (dx ? fx : 1.f - fx) * (dy ? fy : 1.f - fy) * (dz ? fz : 1.f - fz);
+                    const float2 t = fetch(Tv, x0 + dx, y0 + dy, z0 + dz);
+                    sr += wt * t.x; si += wt * t.y;
+                }
+        float rev = -(kx * ssh[v][0] + ky * ssh[v][1] + kz * ssh[v][2]) * invN;       // F(k) = Ref(N k) e^{+2 pi i k.p / N}: take the shift out
+        rev -= floorf(rev);
+        const float sn = __sinf(6.283185307179586f * rev), cs = __cosf(6.283185307179586f * rev);
+        const float s = sinv[v], vr = s * (sr * cs - si * sn), vi = s * (sr * sn + si * cs);
+        if (shalf[v]) { ar1 += vr; ai1 += vi; aw1 += 1.f; } else { ar0 += vr; ai0 += vi; aw0 += 1.f; }      // block-uniform branch
+    }
+    const size_t half_sz = tot * 3;
+    if (aw0 > 0.f) { float *o = P.acc + i * 3; o[0] += ar0; o[1] += ai0; o[2] += aw0; }
+    if (aw1 > 0.f) { float *o = P.acc + half_sz + i * 3; o[0] += ar1; o[1] += ai1; o[2] += aw1; }
+}
+
 }  // namespace ppm

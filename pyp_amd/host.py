@@ -151,6 +151,31 @@ class Accumulator:
         lib.check(lib.load().ppm_insert_batch(self.h, C.byref(cfg), p, on_dev, len(rows), lib.ptr(rows)))
         del keep
 
+    def sva_insert(self, cfg, volumes, wedges, poses, index=None):
+        """Sub-tomogram average (ppm_sva_insert): add aligned sub-volumes (V, N, N, N) float32 (numpy or CUDA tensor) with their wedges
+        (V, 2) and poses (V, 12) to the half-map accumulators; index (V,) decides the half (parity), default 0 .. V-1."""
+        poses = np.ascontiguousarray(poses, dtype=np.float64)
+        if poses.ndim != 2 or poses.shape[1] != 12:
+            raise ValueError("ERROR: poses must be (V, 12)")
+        w = np.ascontiguousarray(wedges, dtype=np.float32).reshape(len(poses), 2)
+        idx = None if index is None else np.ascontiguousarray(index, dtype=np.int64)
+        if idx is not None and idx.shape != (len(poses),):
+            raise ValueError("ERROR: index must be (V,)")
+        if hasattr(volumes, "is_cuda") and volumes.is_cuda:
+            if str(volumes.dtype) != "torch.float32" or not volumes.is_contiguous() or volumes.numel() != len(poses) * self.box ** 3:
+                raise ValueError("ERROR: device volumes must be contiguous float32 of V * box^3 elements")
+            _sync_producer(volumes)
+            p, on_dev, keep = C.c_void_p(volumes.data_ptr()), 1, volumes
+        else:
+            a = np.ascontiguousarray(volumes.numpy() if hasattr(volumes, "numpy") else volumes, dtype=np.float32)
+            if a.size != len(poses) * self.box ** 3:
+                raise ValueError("ERROR: volumes do not match the poses")
+            p, on_dev, keep = lib.ptr(a), 0, a
+        if self._ext is not None:
+            _sync_producer(self._ext)
+        lib.check(lib.load().ppm_sva_insert(self.h, C.byref(cfg), p, on_dev, len(poses), lib.ptr(w), lib.ptr(poses), None if idx is None else lib.ptr(idx)))
+        del keep
+
     def counts(self):
         return [int(lib.load().ppm_accum_count(self.h, 0)), int(lib.load().ppm_accum_count(self.h, 1))]
 

@@ -12,8 +12,10 @@ tilt 0 / axis 0 and is pinned by golden vectors it produced (tests/golden/golden
     p = norm_rev^-1 R_rev^-1 tr,   tr = (-a0, a1, -a2),  a = R^-1 t,   R_rev[i][j] = (-1)^(i+j) R[j][i],  norm_rev = Rz(-nY) Rx(-nX) Rz(-nZ)
 
 (R, t = rotation and translation of the matrix).  This is NOT a drop-in of MPI_Classification: its binary side files
-(`*_averages.bin`) are not described anywhere in the reference; what is provided is the alignment step (mode 3 "align all
-volumes to the reference") on the same tables.
+(`*_averages.bin`) are not described anywhere in the reference; what is provided is the mode-3 iteration on the same tables:
+"align all volumes to the reference" (align_table -> `*_alignments_to_reference_0.txt`, src/pyp_main.py:3104) and the average of the
+aligned sub-volumes that becomes the next reference (`*_refined_selected_average_0.mrc` + `..._filtered.mrc`,
+src/pyp/refine/tomo_avg/sub_tomo_avg.py:79-94, src/pyp_main.py:3076-3100; average_from_accumulator).
 """
 import os
 import xml.etree.ElementTree as ET
@@ -125,11 +127,63 @@ def cfg_from_xml(xml_path, box, pixel_size=1.0, mode=None):
                        search_mode=search_mode, n_candidates=mval("number_of_candidate_peaks_to_search", 25))
 
 
-def align_table(reference, table, names, cfg, base_dir=".", device=0, chunk=256, max_band_px=None):
+def band_weights(cfg, n):
+    """The protocol's band-pass (Gaussian roll-offs outside highpass .. lowpass, cycles per pixel) on the n^3 FFT grid - the weights
+    the alignment metric applies (ppm_sva_cfg)."""
+    k = np.fft.fftfreq(n)
+    s = np.sqrt(k[:, None, None] ** 2 + k[None, :, None] ** 2 + k[None, None, :] ** 2)
+    w = np.ones_like(s)
+    if cfg.highpass_cutoff > 0:
+        d = np.clip(cfg.highpass_cutoff - s, 0, None)
+        w *= np.exp(-d * d / (2 * cfg.highpass_decay ** 2)) if cfg.highpass_decay > 0 else (d == 0)
+    if cfg.lowpass_cutoff > 0:
+        d = np.clip(s - cfg.lowpass_cutoff, 0, None)
+        w *= np.exp(-d * d / (2 * cfg.lowpass_decay ** 2)) if cfg.lowpass_decay > 0 else (d == 0)
+    return w
+
+
+def filtered_map(vol, cfg):
+    """A map as the alignment metric sees it: real-space window of the protocol, then its band-pass (what `Test_Metric_Filter` shows
+    the user for the mode's settings, src/pyp/refine/tomo_avg/sub_tomo_avg.py:485-497; the `_filtered.mrc` twin of an average)."""
+    n = vol.shape[0]
+    c = np.abs(np.arange(n) - n // 2).astype(np.float64)
+    win = np.ones((n, n, n))
+    for axis, half in zip((2, 1, 0), cfg.window):           # window x, y, z on array axes 2, 1, 0
+        if not half > 0:
+            continue
+        d = np.clip(c - half, 0, None)
+        w1 = np.exp(-d * d / (2 * cfg.window_sigma ** 2)) if cfg.window_sigma > 0 else (d == 0).astype(np.float64)
+        shape = [1, 1, 1]; shape[axis] = n
+        win = win * w1.reshape(shape)
+    f = np.fft.fftn((vol - vol.mean()) * win) * band_weights(cfg, n)
+    return np.fft.ifftn(f).real.astype(np.float32)
+
+
+def average_from_accumulator(acc, cfg, prefix, pixel_size=1.0, outer_radius=0.0):
+    """Finalise the sub-tomogram average held by `acc` (host.Accumulator filled by sva_insert / align_table) and write
+    `<prefix>.mrc` (FSC-weighted average of all sub-volumes: the next iteration's reference), `<prefix>_filtered.mrc` (the same through
+    the protocol's window and band-pass), `<prefix>_half1.mrc` / `_half2.mrc` (odd / even sub-volumes) and `<prefix>_statistics.txt`
+    (the 7-column table of merge3d: shell, resolution, ring radius, FSC, part-FSC, part-SSNR, rec-SSNR).  Returns (average, statistics)."""
+    from .abi import FinalCfg
+    from .surface.cli import format_statistics_rows
+    h_even, h_odd, avg, stats = acc.finalize(FinalCfg(molecular_mass_kda=0.0, inner_radius=0.0, outer_radius=float(outer_radius), mask_falloff=0.0))
+    mrc.write(avg, prefix + ".mrc", pixel_size=pixel_size)
+    mrc.write(filtered_map(avg, cfg), prefix + "_filtered.mrc", pixel_size=pixel_size)
+    mrc.write(h_odd, prefix + "_half1.mrc", pixel_size=pixel_size)
+    mrc.write(h_even, prefix + "_half2.mrc", pixel_size=pixel_size)
+    with open(prefix + "_statistics.txt", "w") as f:
+        f.write("C  NO.   RESOL  RING RAD       FSC  Part_FSC Part_SSNR  Rec_SSNR\n")
+        f.write(format_statistics_rows(stats))
+    return avg, stats
+
+
+def align_table(reference, table, names, cfg, base_dir=".", device=0, chunk=256, max_band_px=None, accumulator=None):
     """Align every sub-volume of a table to `reference` (N^3 array): returns the refined table (matrix columns replaced, the
     correlation score in cutOffset) and the scores.  Sub-volumes are read chunk by chunk (10 k x 192^3 is 283 GB) into two
     page-locked buffers, the next chunk by a reader thread while the current one is aligned; inside a call the library uploads
-    2 GB at a time while it searches the previous 2 GB."""
+    2 GB at a time while it searches the previous 2 GB.  accumulator: a host.Accumulator of the same box - every chunk is added to
+    the sub-tomogram average at its refined poses while it is still in memory (half-map = parity of the table's `number` column),
+    so the volumes are read once per iteration; finish with average_from_accumulator."""
     import threading
     from . import host
     n = int(cfg.box)
@@ -172,6 +226,8 @@ def align_table(reference, table, names, cfg, base_dir=".", device=0, chunk=256,
                 out[k, 12:28] = pose_to_matrix(got[k - lo, :9], got[k - lo, 9:], out[k, 9:12])
                 out[k, 31] = sc[k - lo]
             scores[lo:hi] = sc
+            if accumulator is not None:
+                accumulator.sva_insert(cfg, cur, out[lo:hi, 1:3].astype(np.float32), got, index=out[lo:hi, 0].astype(np.int64))
             if t is not None:
                 t.join()
                 t = None
