@@ -56,6 +56,8 @@ def parse(argv=None):
     ap.add_argument("--csp-particles", type=int, default=500, help="particles of the tilt series of the csp block (41 tilts, 128^2 boxes)")
     ap.add_argument("--sva-volumes", type=int, default=512, help="resident 192^3 sub-volumes of the sva block")
     ap.add_argument("--no-next-rows", action="store_true", help="leave the csp / sva blocks out of the default line")
+    ap.add_argument("--no-side", action="store_true", help="csp / sva blocks: only the timed figure (no second series in flight, no global search, no average) - what the "
+                                                           "counter passes of scripts/pmc_r04.sh profile, so that a kernel's dispatches are those of the timed calls")
     ap.add_argument("--no-dropin", action="store_true", help="leave the 'dropin' block (bin/refine3d + bin/reconstruct3d as child processes on a stack file) out")
     return ap.parse_args(argv)
 
@@ -606,6 +608,47 @@ def reconstruct_bench(ctx):
             "map_cc_vs_truth": round(cc, 4), "fsc_at_half_nyquist": round(float(stats[N // 4 - 1, 3]), 4)}
 
 
+def gather_roofline(kernel, summary_workload, ms_total, launches, gathers_total, units_total, unit_name, note):
+    """Roofline entry of a gather-and-score kernel (k_sva_eval, k_csp_eval: the sweep of k_local over other pose tables): every
+    gathered sample is one trilinear fetch of the reference (4 x 16-byte loads served by L1 / L2) and ~70 fp32 operations on it
+    (position, seven complex interpolations, weights, phase, dot products - the k_local model of DESIGN.md 4a).  `achieved` = those
+    operations per launch / the average launch duration from the library's HIP events; `traffic` = HBM-side bytes per launch from the
+    committed --pmc summary of the same workload (2 x FETCH_SIZE + WRITE_SIZE, separate passes, scaled by units)."""
+    launches = max(int(launches), 1)
+    ms = ms_total / launches
+    gpl, upl = gathers_total / launches, units_total / launches
+    tf = 70.0 * gpl / (ms * 1e-3) / 1e12
+    # HBM-side bytes of ONE launch: the summary's average per dispatch (every sweep is a dispatch over all profiled units), scaled by units
+    e, meta = pmc_entry(pmc_latest(summary_workload), kernel)
+    traffic, src = None, "no FETCH_SIZE / WRITE_SIZE summary for %s under profiles/%s" % (kernel, pmc_latest(summary_workload))
+    if e and "FETCH_SIZE" in e and "WRITE_SIZE" in e and meta.get("particles"):
+        traffic = (2.0 * e["FETCH_SIZE"]["per_dispatch"] + e["WRITE_SIZE"]["per_dispatch"]) * 1024.0 * upl / meta["particles"]
+        had, now = meta.get("kernels_sha16", "?"), kernels_sha16()
+        src = "profiles/%s (%d units per dispatch, 2 x FETCH_SIZE + WRITE_SIZE, KB, per dispatch; kernel sources %s%s)" % (
+            pmc_latest(summary_workload), meta["particles"], had, " = the timed ones" if had == now else ", the timed ones are " + now)
+    pv = None
+    if e and "SQ_INSTS_VALU" in e and meta.get("particles") and meta.get("gathers_per_unit"):
+        pv = {"source": "profiles/" + pmc_latest(summary_workload),
+              "SQ_INSTS_VALU_lane_instructions_per_gathered_sample": round(e["SQ_INSTS_VALU"]["sum"] * 64.0 / (meta["particles"] * meta["gathers_per_unit"]), 1)}
+        for c in ("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "TCC_HIT_sum", "TCC_MISS_sum"):
+            if c in e:
+                pv[c] = e[c]["sum"]
+    return {"bound": "valu_fp32", "kernel": kernel, "achieved": round(tf, 2), "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_VALU_TFLOPS, 4),
+            "traffic": traffic, "traffic_source": src, "avg_launch_ms": round(ms, 4), "launches": launches, unit_name + "_per_launch": round(upl, 1),
+            "gathered_samples_per_launch": round(gpl), "gather_GBps_from_cache": round(64.0 * gpl / (ms * 1e-3) / 1e9, 1),
+            "flop_model": "70 fp32 operations per gathered sample (useful arithmetic)", "pmc": pv, "note": note}
+
+
+def sva_eval_roofline(prof, lc, nv, steps, wedges):
+    """k_sva_eval (+ k_sva_finish), ~70 % of an alignment step.  Gathered samples: band samples x gathered rotations per sub-volume summed
+    over the sweeps (ppm_refine_last_counts), times the share of the band inside the missing wedge's complement (masked samples are skipped)."""
+    fw = float(np.clip((np.asarray(wedges)[:, 1] - np.asarray(wedges)[:, 0]) / 180.0, 0, 1).mean())
+    g = lc["samples_local"] * fw * nv * steps
+    return gather_roofline("k_sva_eval", "sva", prof["local"]["ms"], prof["local"]["launches"], g, nv * steps * lc["n_local"], "states",
+                           "host-driven compass: %d sweeps per call, every sweep one launch over all sub-volumes (x %d parts); %.0f %% of the band lies inside the "
+                           "tilt range; bound by the gathers' path through the vector L1 (DESIGN.md 9)" % (lc["n_local"], 4, 100 * fw))
+
+
 def recon_parity(stack, rows, rc, N, px, local, want=2000, budget_s=30.0):
     """The first `want` particles of the timed stack inserted by the oracle (oracle.insert_batch, OpenMP) and by the HIP path into
     fresh accumulators: relative L2 distance of the two accumulators (value channels and weight channel), particle counts.
@@ -671,7 +714,7 @@ def csp_bench(ctx):
     cc = CspCfg.make(CSP_PARTICLES, tol_angle=(8, 8, 8), tol_shift=4.0)
     barrier = make_barrier(world)
     out = None
-    for _ in range(max(a.warmup, 1)):
+    for _ in range(a.warmup if a.no_side else max(a.warmup, 1)):
         out = ref.csp_refine(cfg, cc, stack, rows2, p2, tilts)
     host.profile(True, True)
     barrier()
@@ -682,10 +725,11 @@ def csp_bench(ctx):
     dt = max_over_ranks(time.perf_counter() - t0, world, dev)
     prof = host.profile_report()
     host.profile(False, False)
+    lc_csp = ref.last_counts()
     # config 4 puts four tilt series on every GPU: two of them in flight on two reference handles (calls on different handles may
     # run concurrently from different threads, include/ppm.h) fill the device while the other call's host side decides its next sweep
     two = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not a.no_side:
         import threading
         ref2 = host.Reference(vol, n / 2, device=local)
         ref2.csp_refine(cfg, cc, stack, rows2.copy(), p2.copy(), tilts.copy())
@@ -730,6 +774,9 @@ def csp_bench(ctx):
                       "projections_per_gpu": nproj, "parallelism": "unit-sharded x%d, no collective" % world},
            "device_ms_per_step": {k2: round(v["ms"] / a.steps, 2) for k2, v in prof.items() if v["launches"]},
            "device_busy_frac": round(sum(v["ms"] for v in prof.values()) * 1e-3 / dt, 3),
+           "roofline": gather_roofline("k_csp_eval", "csp", prof["local"]["ms"], prof["local"]["launches"], lc_csp["samples_local"] * nproj * a.steps,
+                                       nproj * a.steps * lc_csp["n_local"], "projections",
+                                       "host-driven compass: %d sweeps per call, every sweep one launch over the usable projections of the refined units" % lc_csp["n_local"]),
            "note": "host-driven compass search: the device scores <= 13 candidate poses per projection and sweep (k_csp_eval, the sweep of k_local: "
                    "vector-issue-bound like it); the rest of a step is the host's fixed-order reductions and candidate tables",
            "accuracy_vs_truth": {"median_deg_before": round(float(np.median(perr(p2, parts))), 3), "median_deg_after": round(float(np.median(perr(out[1], parts))), 3),
@@ -779,7 +826,8 @@ def sva_bench(ctx):
     host.lib.init(local)
     ref = host.Reference(vol, n / 2, device=local)
     barrier = make_barrier(world)
-    ref.sva_align(cfg, vols[:4], wedges[:4], start[:4])
+    if not a.no_side:
+        ref.sva_align(cfg, vols[:4], wedges[:4], start[:4])
     host.profile(True, True)
     barrier()
     t0 = time.perf_counter()
@@ -789,9 +837,10 @@ def sva_bench(ctx):
     dt = max_over_ranks(time.perf_counter() - t0, world, dev)
     prof = host.profile_report()
     host.profile(False, False)
+    lc_sva = ref.last_counts()          # of the last timed alignment call
     # the protocol's global search (alignment_mode 0) from rotations anywhere on SO(3), on a bounded sample (outside the timed region above)
     glob = None
-    if rank == 0:
+    if rank == 0 and not a.no_side:
         ng = min(nv, 64)
         rng = np.random.default_rng(12)
         gstart = poses[:ng].copy()
@@ -816,6 +865,8 @@ def sva_bench(ctx):
     # ---- the averaging step of the iteration (ppm_sva_insert): the aligned sub-volumes into the half-map accumulators, then finalise
     avg_blk = None
     try:
+        if a.no_side:
+            raise RuntimeError("left out (--no-side)")
         from pyp_amd.abi import FinalCfg
         warm = host.Accumulator(n, 1.0, "C1", device=local)
         warm.sva_insert(cfg, vols[:8], wedges[:8], out[:8])
@@ -860,7 +911,8 @@ def sva_bench(ctx):
            "config": {"workload": "%d resident 192^3 sub-volumes per GPU (%.1f GB), +-10 deg / +-10 px, missing wedge +-60 deg, band 0.125 cycles/pixel" % (nv, nv * n3 * 4 / 1e9),
                       "sub_volumes_per_gpu": nv, "parallelism": "row-sharded x%d, no collective" % world},
            "device_ms_per_sub_volume": {"pre_processing": round(ms_prep, 3), "search": round(prof["local"]["ms"] / (nv * a.steps), 3)},
-           "roofline": {"bound": "hbm", "kernel": "sub-volume pre-processing (k_sva_x16 + k_sva_stats_sum + two k_sva_yz16 passes + k_sva_gather16)",
+           "roofline": sva_eval_roofline(prof, lc_sva, nv, a.steps, wedges),
+           "roofline_pre_processing": {"bound": "hbm", "kernel": "sub-volume pre-processing (k_sva_x16 + k_sva_stats_sum + two k_sva_yz16 passes + k_sva_gather16)",
                         "achieved": round(4.0 * n3 / (ms_prep * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                         "frac": round(4.0 * n3 / (ms_prep * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4), "traffic": None,
                         "algorithmic_bytes": "4 n^3: the sub-volume read once",

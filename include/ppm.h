@@ -222,6 +222,9 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
  * over all local evaluations (frequency marching makes early ones cheaper) */
 int ppm_refine_last_counts(ppm_ref_t *ref, long *n_global, long *n_local, long *samples_global,
                            long *samples_local);
+/* After ppm_csp_refine: 0, sweeps (k_csp_eval launches), in-band samples of the full band, gathered samples per projection summed over
+ * the sweeps.  After ppm_sva_align: grid rotations of a global search, sweeps (k_sva_eval launches), samples of the band (half space,
+ * before the missing wedge), band samples x gathered rotations per sub-volume summed over the sweeps. */
 /* remarks of the last ppm_refine_batch on this reference that the caller should log (e.g. the search band was capped);
  * "" if none */
 const char *ppm_refine_note(ppm_ref_t *ref);

@@ -124,7 +124,8 @@ __global__ void __launch_bounds__(PT, MINW) k_prep(PrepP P) {
     const int p = blockIdx.x;
     const int TS = P.TS, WS = P.WS;                   // padded line strides (bank spread)
     float2 *T = (float2 *)smem;                       // [nc][TS] column chunk, followed by
-    constexpr bool kInreg = PT == 512 && MINW == 2;   // the instantiation that carries the scratch-free path
+    constexpr bool kInreg = (PT == 512 && MINW == 2) || (PT == 1024 && MINW == 1);   // the instantiations that carry the scratch-free path
+    constexpr int HR = PT / 128, NIT = 64 / (HR > 0 ? HR : 1);   // scratch-free path: thread t holds column t & 127 of the rows (t >> 7) + HR it, it < NIT, of every row pass
     const bool inreg = kInreg && P.inreg;
     float2 *Wk = inreg ? T : T + (size_t)P.nc * TS;   // [L][WS]  the row work buffer (shares T's storage on the scratch-free path)
     // ring power sums in 64-bit fixed point and integer counts: a ds_add_f32 costs ~190 LDS cycles per wave-instruction on
@@ -284,13 +285,13 @@ __global__ void __launch_bounds__(PT, MINW) k_prep(PrepP P) {
             // t & 127 of the half spectrum for the rows 128 pass + 2 ((t >> 7) + 4 it) + {0, 1}: 64 complex values in registers.
             // The column pass assembles 64 columns at a time in LDS from those registers.  kx = 128 (and everything beyond the
             // band) is zero in the output, so 128 columns are all that is ever held.
-            float2 holdA[16][2], holdB[16][2];       // pass 0 / pass 1 (two arrays: each small enough to be promoted to registers)
+            float2 holdA[NIT][2], holdB[NIT][2];     // pass 0 / pass 1 (two arrays: each small enough to be promoted to registers)
 #pragma unroll
             for (int pass = 0; pass < 2; pass++) {
                 const int y0 = 128 * pass;
                 lds_barrier();                                   // the previous pass has been read out
 #pragma unroll 2
-                for (int k = 0; k < 8; k++) {                    // 64 row pairs x 64 float4 = 4096 pairs of loads over 512 threads
+                for (int k = 0; k < 4096 / PT; k++) {            // 64 row pairs x 64 float4 = 4096 pairs of loads over the block's threads
                     const int i4 = tid + k * PT, l = i4 >> 6, x = 4 * (i4 & 63), ya = y0 + 2 * l, yb = ya + 1;
                     const float4 qa = *(const float4 *)(img + ya * N + x), qb = *(const float4 *)(img + yb * N + x);
                     const float ra[4] = { qa.x, qa.y, qa.z, qa.w }, rb[4] = { qb.x, qb.y, qb.z, qb.w };
@@ -311,8 +312,8 @@ __global__ void __launch_bounds__(PT, MINW) k_prep(PrepP P) {
                 }
                 lds_fft256(Wk, 64, WS, tid, PT, tw_s);
 #pragma unroll
-                for (int it = 0; it < 16; it++) {
-                    const int l = (tid >> 7) + 4 * it, kx = tid & 127;
+                for (int it = 0; it < NIT; it++) {
+                    const int l = (tid >> 7) + HR * it, kx = tid & 127;
                     const float2 z = Wk[l * WS + kx], zc = Wk[l * WS + (kx ? N - kx : 0)];
                     const float2 d = make_float2(z.x - zc.x, z.y + zc.y);
                     const float2 xa = make_float2(0.5f * (z.x + zc.x), 0.5f * (z.y - zc.y)), xb = make_float2(0.5f * d.y, -0.5f * d.x);
@@ -334,8 +335,8 @@ __global__ void __launch_bounds__(PT, MINW) k_prep(PrepP P) {
 #pragma unroll
                     for (int pass = 0; pass < 2; pass++)
 #pragma unroll
-                        for (int it = 0; it < 16; it++) {
-                            const int y = 128 * pass + 2 * ((tid >> 7) + 4 * it);
+                        for (int it = 0; it < NIT; it++) {
+                            const int y = 128 * pass + 2 * ((tid >> 7) + HR * it);
                             T[(kx - c0) * TS + y] = pass == 0 ? holdA[it][0] : holdB[it][0];
                             T[(kx - c0) * TS + y + 1] = pass == 0 ? holdA[it][1] : holdB[it][1];
                         }

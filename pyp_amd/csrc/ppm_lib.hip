@@ -318,6 +318,8 @@ static int launch_prep(DevBuf<float2> &spill /* the calling handle's scratch */,
     // (A/B on one box, 100 k x 256^2: reconstruction 0.38 -> 0.29 us per particle, refinement 0.44 -> 0.37; PPM_PREP_INREG=0 selects the scratch path)
     const bool inreg = gm.N == 256 && !getenv("PPM_PREP_GENERIC") && !getenv("PPM_PREP_PT") && !(getenv("PPM_PREP_INREG") && atoi(getenv("PPM_PREP_INREG")) == 0);
     if (inreg) PT = 512;
+    // the same path with 1024 threads (16 waves per CU, 32 held values per thread) instead of 512 (8 waves, 64 values): PPM_PREP_INREG_PT=1024
+    if (inreg && getenv("PPM_PREP_INREG_PT") && atoi(getenv("PPM_PREP_INREG_PT")) == 1024) PT = 1024;
     const int occ3 = !(getenv("PPM_PREP_OCC") && atoi(getenv("PPM_PREP_OCC")) == 2);
     const size_t budget = (PT == 1024 ? 160 : (PT == 256 ? (getenv("PPM_PREP_LDS") ? atoi(getenv("PPM_PREP_LDS")) : (occ3 ? 40 : 52)) : 80)) * 1024;
     const size_t lds_fixed = (size_t)(gm.B + 2) * 16 + 16 + 5 * (PT / 64) * sizeof(double) + (12 + PT / 64) * sizeof(float) + (size_t)gm.N * 12 + 16;
@@ -1555,6 +1557,7 @@ extern "C" int ppm_csp_refine(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const p
     if (int rc = ref->c_mean.ensure(std::max<size_t>(active.size() * ncand_max, 1))) return rc;
     HIPCHK(hipMemcpyAsync(ref->c_uoff.p, uoff.data(), uoff.size() * sizeof(int), hipMemcpyHostToDevice, cur_stream()));
     const std::vector<int> *uploaded_list = nullptr;
+    double acct_gathers = 0; long acct_sweeps = 0;
     // one sweep: `ncand` candidates per unit (hdelta laid out [slot][ncand][6]) over `rows_list`.  unit_means: the per-unit means of
     // the scores -> `means` [active unit][ncand] (reduced on the device); otherwise the per-row scores -> hout [row][ncand]
     auto sweep = [&](const std::vector<int> &rows_list, int ncand, double rband, std::vector<double> *means) -> int {
@@ -1564,6 +1567,11 @@ extern "C" int ppm_csp_refine(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const p
             uploaded_list = &rows_list;
         }
         EP.ncand = ncand; EP.S_used = prefix_of(rband); EP.rmax2 = (float)(rband * rband);
+        {   // accounting for the roofline (ppm_refine_last_counts): gathers = samples x rotations that differ (shift candidates share the centre's)
+            int nrot_c = 0;
+            if (ncand > 1) for (int i = 0; i < 3; i++) nrot_c += en[i] ? 2 : 0;
+            acct_gathers += (double)rows_list.size() * EP.S_used * (1 + nrot_c); acct_sweeps++;
+        }
         {
             ProfScope ps(PPM_K_LOCAL);
             hipLaunchKernelGGL(k_csp_eval, dim3((unsigned)rows_list.size()), dim3(256), ring_lds_bytes(4, kMaxCand, nrings), cur_stream(), EP);
@@ -1671,6 +1679,10 @@ extern "C" int ppm_csp_refine(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const p
         }
         if (kind == PPM_CSP_PARTICLES) particles[(size_t)u * PPM_NPCOL + 10] = sn ? ssum / sn : -1.0;
     }
+    // ppm_refine_last_counts after a constrained refinement: 0, sweeps (k_csp_eval launches), in-band samples of the full band, gathered
+    // samples per projection summed over the sweeps
+    ref->last_counts[0] = 0; ref->last_counts[1] = acct_sweeps; ref->last_counts[2] = (long)std::floor(kPi * gm.r_hi * gm.r_hi / 2);
+    ref->last_counts[3] = (long)(acct_gathers / std::max(n_proj, 1));
     return 0;
 }
 
@@ -1838,6 +1850,7 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
     EP.wedges = d_wedges.p; EP.poses = d_poses.p; EP.delta = d_delta.p; EP.out = d_out.p; EP.vmap = nullptr; EP.partial = d_partial.p;
     std::vector<float> hw((size_t)2 * CH);
     std::vector<double> hdelta, hout;
+    double acct_gathers = 0; long acct_sweeps = 0;      // for the roofline: band samples x rotations gathered, summed over the sweeps (wedge-masked samples included)
     mark("set up");
     if (!volumes_on_device) {       // first chunk
         HIPCHK(hipMemcpyAsync(d_vols.p, volumes, (size_t)std::min(CH, n_vol) * n3 * sizeof(float), hipMemcpyHostToDevice, cur_copy()));
@@ -1939,6 +1952,7 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
         auto sweep = [&](int ns_, int nc, int nr_, double rb) -> int {
             HIPCHK(hipMemcpyAsync(d_delta.p, hdelta.data(), (size_t)ns_ * nc * 6 * sizeof(double), hipMemcpyHostToDevice, cur_stream()));
             EP.ncand = nc; EP.nrot = nr_; EP.S_used = prefix_of(rb); EP.rmax2 = (float)(rb * rb);
+            acct_gathers += (double)ns_ * EP.S_used * (1 + nr_); acct_sweeps++;
             {
                 ProfScope ps(PPM_K_LOCAL);
                 hipLaunchKernelGGL(k_sva_eval, dim3(ns_, kSvaParts), dim3(256), 0, cur_stream(), EP);
@@ -2073,6 +2087,9 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
             if (scores) scores[c0 + v] = hout[v];
         }
     }
+    // ppm_refine_last_counts after an alignment: grid rotations of the global search, sweeps (k_sva_eval launches), samples of the band
+    // (half space, before the wedge), band samples x gathered rotations per sub-volume summed over the sweeps
+    ref->last_counts[0] = n_grid; ref->last_counts[1] = acct_sweeps; ref->last_counts[2] = S; ref->last_counts[3] = (long)(acct_gathers / n_vol);
     return 0;
 }
 

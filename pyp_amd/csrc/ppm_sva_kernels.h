@@ -519,6 +519,8 @@ __global__ void __launch_bounds__(256) k_sva_insert(SvaInsP P) {
     auto fetch = [&](const float2 *Tv, int x, int y, int z) {            // F(x, y, z), origin at the box centre
         const bool mate = x < 0;
         if (mate) { x = -x; y = -y; z = -z; }
+        if ((x | y | z) == 0) return make_float2(0.f, 0.f);      // the transform is that of the RAW volume when P.stats is set: its DC term
+                                                                 // (mean x N^3) is the one coefficient the normalisation (v - mean) / sigma changes - to zero
         const int yi = y < 0 ? y + N : y, zi = z < 0 ? z + N : z;
         const float2 v = P.layout ? Tv[((size_t)x * P.KY + yi) * N + zi] : Tv[((size_t)zi * N + yi) * P.KX + x];
         const float sg = ((x + y + z) & 1) ? -1.f : 1.f;
