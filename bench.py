@@ -686,6 +686,94 @@ def _omp_threads(n):
     ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(n))
 
 
+def csp_pipeline(ctx, vol, stack, rows2, p2, parts_truth, tilts, cfg, cc, n, px, n_series=4):
+    """BASELINE config 4 as the caller runs it per tilt series (src/pyp/align/core.py:958-1005, docs/cli/constrained.rst:12-15): `csp` mode -2
+    crops the projections of every particle out of the 41 tilt images of 4096^2 (ppm_extract_boxes, one call per image, straight into a
+    resident stack), the particle units are refined against the reference (ppm_csp_refine), and the series' projections are inserted
+    into the rank's half-map accumulators at their refined poses (ppm_insert_batch); after the last series ONE reduce over the ranks.
+    `n_series` series are in flight per GPU, each on its own reference handle and thread (config 4: 32 series on 8 GPUs); the insertions
+    share the accumulator and are serialised by a lock.  The same synthetic series serves all of them (its images are resident)."""
+    import threading
+    import torch
+    from pyp_amd import dist as pdist
+    from pyp_amd import host, synth
+    from pyp_amd.abi import FinalCfg, ReconCfg
+    from pyp_amd.formats import cistem
+    a, rank, world, local, dev = (ctx[k] for k in ("a", "rank", "world", "local", "dev"))
+    C = cistem.COL
+    nt, size = len(tilts), 4096
+    order = np.lexsort((rows2[:, C["PIND"]], rows2[:, C["TIND"]]))          # tilt-major: the boxes of one image are consecutive in the stack
+    rows_t = rows2[order]
+    series, rows_p = synth.paste_tilt_series(stack[torch.as_tensor(order, device=dev)], rows_t, nt, shape=(size, size), seed=5 + rank)
+    torch.cuda.synchronize()
+    m = len(rows_p)
+    tind = rows_p[:, C["IMIND"]].astype(int)
+    off = np.searchsorted(tind, np.arange(nt + 1))
+    coords = np.ascontiguousarray(rows_p[:, [C["ORIGINAL_X_POSITION"], C["ORIGINAL_Y_POSITION"]]])
+    nfl = int(host.lib.load().ppm_accum_floats(n))
+    acc_t = torch.zeros(nfl, dtype=torch.float32, device=dev)
+    acc = host.Accumulator(n, px, "C1", device=local, ext_tensor=acc_t)
+    rc = ReconCfg(box=n, pixel_size=px, res_limit=2 * px, score_weight_bfactor=0.0, score_average=0.0, score_threshold=0.0, normalize=1, invert=0,
+                  split_by_pind=1, mask_radius=0.32 * n * px)
+    refs = [host.Reference(vol, n / 2, device=local) for _ in range(n_series)]
+    stacks = [torch.empty((m, n, n), dtype=torch.float32, device=dev) for _ in range(n_series)]
+    lock, errs, results, stage = threading.Lock(), [], [None] * n_series, [[0.0, 0.0, 0.0] for _ in range(n_series)]
+    torch.cuda.synchronize()
+
+    def one_series(k):
+        try:
+            t0 = time.perf_counter()
+            for t in range(nt):
+                host.extract_boxes(series[t], coords[off[t]:off[t + 1]], n, 0.32 * n * px, px, out=stacks[k][off[t]:off[t + 1]], device=local)
+            t1 = time.perf_counter()
+            rr, pp, _ = refs[k].csp_refine(cfg, cc, stacks[k], rows_p, p2, tilts)
+            t2 = time.perf_counter()
+            with lock:
+                acc.insert(rc, stacks[k], rr)
+            t3 = time.perf_counter()
+            results[k] = pp
+            stage[k] = [t1 - t0, t2 - t1, t3 - t2]
+        except Exception as e:          # noqa: BLE001 - reported in the line
+            errs.append(str(e)[:300])
+    one_series(0)                        # warm-up: code objects, work arrays of handle 0
+    barrier = make_barrier(world)
+    acc_t.zero_(); acc.set_counts(0, 0)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        th = [threading.Thread(target=one_series, args=(k,)) for k in range(n_series)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        counts = pdist.reduce_accumulators(acc_t, acc.counts())[1] if world > 1 else acc.counts()
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0, world, dev)
+    for r in refs:
+        r.close()
+    if rank != 0:
+        acc.close()
+        return None
+    if errs or any(r is None for r in results):
+        acc.close()
+        return {"error": errs[0] if errs else "a series returned nothing"}
+    acc.set_counts(counts[0], counts[1])
+    _, _, fl, _ = acc.finalize(FinalCfg(molecular_mass_kda=0.0, inner_radius=0.0, outer_radius=0.45 * n * px, mask_falloff=0.0))
+    acc.close()
+
+    def perr(x, y):
+        return np.array([np.degrees(np.arccos(np.clip((np.trace(synth.euler_matrix(-u[4], -u[5], -u[6]).T @ synth.euler_matrix(-v[4], -v[5], -v[6])) - 1) / 2, -1, 1)))
+                         for u, v in zip(x, y)])
+    return {"value": round(world * n_series * m * a.steps / dt, 1), "unit": "projections/s", "series_per_s": round(world * n_series * a.steps / dt, 2),
+            "ms_per_series": round(dt / (a.steps * n_series) * 1e3, 2), "series_in_flight_per_gpu": n_series,
+            "stage_ms_one_series_in_flight": {"extract_41_images": round(np.mean([x[0] for x in stage]) * 1e3, 2), "refine": round(np.mean([x[1] for x in stage]) * 1e3, 2),
+                                               "insert": round(np.mean([x[2] for x in stage]) * 1e3, 2),
+                                               "note": "wall time per stage inside a worker while the other series run (they overlap)"},
+            "tilt_series": "%d tilt images of %d^2 (%.1f GB resident), %d particles, %d projections of %d^2" % (nt, size, nt * size * size * 4 / 1e9, len(p2), m, n),
+            "collective": "none (one rank)" if world == 1 else "one all-reduce of the accumulators after the last series",
+            "median_deg_after": round(float(np.median(perr(results[0], parts_truth))), 3), "map_cc_vs_truth": round(float(np.corrcoef(fl.ravel(), vol.ravel())[0, 1]), 4)}
+
+
 def csp_bench(ctx):
     """configs[3] at one tilt series per rank: P particles x 41 tilts of 128^2 boxes (resident), constrained refinement of the
     particle units (csp modes 2 / 5: three rotations + 3-D shift per particle, scored over its 41 projections).  Units shard
@@ -759,6 +847,12 @@ def csp_bench(ctx):
                    "results_equal_single_series_run": same}
         ref2.close()
     ref.close()
+    pipe = None
+    if not a.no_side:
+        try:                    # the whole of config 4 per series: extraction -> refinement -> insertion, four series in flight
+            pipe = csp_pipeline(ctx, vol, stack, rows2, p2, parts, tilts, cfg, cc, n, px)
+        except Exception as e:          # noqa: BLE001
+            pipe = {"error": str(e)[:300]}
     if rank != 0:
         return None
 
@@ -783,6 +877,8 @@ def csp_bench(ctx):
                                  "median_shift_px_after": round(float(np.median(np.linalg.norm(out[1][:, 1:4] - parts[:, 1:4], axis=1))), 3)}}
     if two:
         blk["two_series_in_flight"] = two
+    if pipe:
+        blk["pipeline"] = pipe
     if world == 1 and not a.no_cpu and a.cpu_seconds > 0:
         from oracle import oracle
         cores = host_cores()
@@ -861,6 +957,31 @@ def sva_bench(ctx):
                     "frac_within_1deg": round(float((gerr < 1.0).mean()), 3)}
         except Exception as e:          # noqa: BLE001
             glob = {"error": str(e)[:200]}
+    # ---- config 5's real regime: the sub-volumes live on the HOST (10 k x 192^3 = 283 GB) and stream through PCIe once per iteration -
+    # alignment and averaging in one pass over page-locked host memory (ppm_sva_align_average: what sva.align_table / bin/sva_align call)
+    streamed = None
+    if rank == 0 and not a.no_side:
+        pb = None
+        try:
+            pb = host.PinnedBuffer(vols.numel(), local)
+            hv = pb.array.reshape(tuple(vols.shape))
+            torch.from_numpy(hv).copy_(vols)
+            torch.cuda.synchronize()
+            acc_s = host.Accumulator(n, 1.0, "C1", device=local)
+            ts = time.perf_counter()
+            out_s, sc_s = ref.sva_align(cfg, hv, wedges, start, accumulator=acc_s)
+            ts = time.perf_counter() - ts
+            cnt_s = acc_s.counts()
+            acc_s.close()
+            streamed = {"value": round(nv / ts, 1), "unit": "sub-volumes/s", "host_to_device_GBps": round(nv * float(n) ** 3 * 4 / ts / 1e9, 1),
+                        "poses_equal_resident_run": bool(np.array_equal(out_s, out)), "averaged": cnt_s,
+                        "note": "%d sub-volumes in page-locked host memory: aligned AND averaged in one pass, every chunk uploaded once while the previous one is searched "
+                                "(PCIe Gen5 x16 bounds this regime at ~1.9 k sub-volumes/s)" % nv}
+        except Exception as e:          # noqa: BLE001
+            streamed = {"error": str(e)[:300]}
+        finally:
+            if pb is not None:
+                pb.close()
     ref.close()
     # ---- the averaging step of the iteration (ppm_sva_insert): the aligned sub-volumes into the half-map accumulators, then finalise
     avg_blk = None
@@ -925,7 +1046,7 @@ def sva_bench(ctx):
                                  "median_deg_after": round(float(np.median(synth.pose_angle_error(out, poses))), 3),
                                  "median_shift_px_after": round(float(np.median(np.linalg.norm(out[:, 9:] - poses[:, 9:], axis=1))), 3),
                                  "mean_score": round(float(sc.mean()), 4)},
-           "global_search": glob, "average": avg_blk}
+           "global_search": glob, "average": avg_blk, "streamed": streamed}
     if world == 1 and not a.no_cpu and a.cpu_seconds > 0 and acc_keep is not None:
         try:                    # the average of the first sub-volumes by the oracle and by the HIP path, into fresh accumulators
             from oracle import oracle

@@ -325,6 +325,13 @@ int ppm_accum_reduce(ppm_accum_t *acc, void *comm, int root);
 int ppm_sva_insert(ppm_accum_t *acc, const ppm_sva_cfg *cfg, const void *volumes, int volumes_on_device, int n_vol, const float *wedges,
                    const double *poses, const long *index);
 
+/* One pass of a 3DAVG iteration: ppm_sva_align, and every chunk of sub-volumes is added to the average (ppm_sva_insert into `acc`) at
+ * its refined pose while it is still in device memory - sub-volumes that live on the host (config 5: 10 k x 192^3 = 283 GB) cross PCIe
+ * once per iteration instead of twice.  The calls on `acc` made inside run on the reference's stream: do not use `acc` from another
+ * thread meanwhile. */
+int ppm_sva_align_average(ppm_ref_t *ref, ppm_accum_t *acc, const ppm_sva_cfg *cfg, const void *volumes, int volumes_on_device, int n_vol,
+                          const float *wedges, double *poses, double *scores, const long *index);
+
 /* half1/half2/filtered: box^3 floats each (host).  stats: (box/2) * PPM_STATS_COLS doubles. */
 int ppm_finalize(ppm_accum_t *acc, const ppm_final_cfg *cfg, float *half1, float *half2,
                  float *filtered, double *stats);

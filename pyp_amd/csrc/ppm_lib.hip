@@ -1703,8 +1703,13 @@ double sva_band_radius(const ppm_sva_cfg &c) {
 }
 }  // namespace
 
-extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void *volumes, int volumes_on_device, int n_vol, const float *wedges,
-                             double *poses, double *scores) {
+static int sva_insert_device(ppm_accum_t *a, const ppm_sva_cfg *cfg, const float *d_vols, int n_vol, const float *wedges, const double *poses,
+                             const long *index, long index_base);
+
+// ppm_sva_align and ppm_sva_align_average: with an accumulator every chunk is added to the average at its refined poses while it is
+// still in device memory (host volumes cross PCIe once per iteration)
+static int sva_align_impl(ppm_ref_t *ref, ppm_accum_t *avg, const ppm_sva_cfg *cfg, const void *volumes, int volumes_on_device, int n_vol, const float *wedges,
+                          double *poses, double *scores, const long *index) {
     if (!g.inited) return fail(-1, "ppm_init has not been called");
     if (!ref || !cfg || !volumes || !poses) return fail(-22, "null argument");
     StreamScope ss_(ref->stream, ref->copy);
@@ -2086,6 +2091,10 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
             std::memcpy(poses + (size_t)(c0 + v) * 12, st[v].N, 9 * sizeof(double)); std::memcpy(poses + (size_t)(c0 + v) * 12 + 9, st[v].p, 3 * sizeof(double));
             if (scores) scores[c0 + v] = hout[v];
         }
+        if (avg) {
+            if (int rc = sva_insert_device(avg, cfg, dv, nb, wedges ? wedges + 2 * (size_t)c0 : nullptr, poses + (size_t)c0 * 12, index ? index + c0 : nullptr, c0)) return rc;
+            mark("chunk averaged");
+        }
     }
     // ppm_refine_last_counts after an alignment: grid rotations of the global search, sweeps (k_sva_eval launches), samples of the band
     // (half space, before the wedge), band samples x gathered rotations per sub-volume summed over the sweeps
@@ -2093,16 +2102,25 @@ extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void 
     return 0;
 }
 
+extern "C" int ppm_sva_align(ppm_ref_t *ref, const ppm_sva_cfg *cfg, const void *volumes, int volumes_on_device, int n_vol, const float *wedges,
+                             double *poses, double *scores) {
+    return sva_align_impl(ref, nullptr, cfg, volumes, volumes_on_device, n_vol, wedges, poses, scores, nullptr);
+}
+
+extern "C" int ppm_sva_align_average(ppm_ref_t *ref, ppm_accum_t *acc, const ppm_sva_cfg *cfg, const void *volumes, int volumes_on_device, int n_vol,
+                                     const float *wedges, double *poses, double *scores, const long *index) {
+    if (!acc) return fail(-22, "null accumulator");
+    if (cfg && acc->N != cfg->box) return fail(-22, "sub-volume box differs from the accumulator's box");
+    return sva_align_impl(ref, acc, cfg, volumes, volumes_on_device, n_vol, wedges, poses, scores, index);
+}
+
 // ------------------------------------------------------------------------------ sub-tomogram average
 // include/ppm.h: ppm_sva_insert.  Per batch of <= 32 sub-volumes: the FULL 3-D transforms (the pruned passes of the alignment with
 // the band at Nyquist; normalisation (v - mean) / sigma applied through the statistics the x pass gathers), then one k_sva_insert
 // launch that gathers them into the accumulator.
-extern "C" int ppm_sva_insert(ppm_accum_t *a, const ppm_sva_cfg *cfg, const void *volumes, int volumes_on_device, int n_vol, const float *wedges,
-                              const double *poses, const long *index) {
-    if (!g.inited) return fail(-1, "ppm_init has not been called");
-    if (!a || !cfg || !volumes || !poses) return fail(-22, "null argument");
-    StreamScope ss_(a->stream, a->copy);
-    if (n_vol <= 0) return 0;
+// one batch-wise pass over DEVICE-resident sub-volumes (d_vols: n_vol x N^3 floats); runs on the caller's current stream scope
+static int sva_insert_device(ppm_accum_t *a, const ppm_sva_cfg *cfg, const float *d_vols, int n_vol, const float *wedges, const double *poses,
+                             const long *index, long index_base) {
     const int N = cfg->box;
     if (!box_ok(N) || N != a->N) return fail(-22, "sub-volume box differs from the accumulator's box (even, 32..512, prime factors 2, 3, 5)");
     if (a->nsym != 1) return fail(-22, "sub-tomogram averaging needs a C1 accumulator");
@@ -2112,7 +2130,6 @@ extern "C" int ppm_sva_insert(ppm_accum_t *a, const ppm_sva_cfg *cfg, const void
     if (int rc = ensure_plan(N)) return rc;
     if (int rc = a->s_f.ensure((size_t)NB * N * N * KX)) return rc;
     if (fast16) if (int rc = a->s_g.ensure((size_t)NB * KX * KY * N)) return rc;
-    if (!volumes_on_device) if (int rc = a->s_vols.ensure((size_t)NB * n3)) return rc;
     DevTmp<double> d_spart, d_stats, d_poses; DevTmp<float> d_wedges; DevTmp<int> d_half;
     const int L16 = N <= 256 ? 16 : 8;
     HIPCHK(d_spart.alloc((size_t)2 * NB * ((size_t)N * N / L16 + 1))); HIPCHK(d_stats.alloc((size_t)2 * NB)); HIPCHK(d_poses.alloc((size_t)12 * NB));
@@ -2123,14 +2140,10 @@ extern "C" int ppm_sva_insert(ppm_accum_t *a, const ppm_sva_cfg *cfg, const void
     long added[2] = { 0, 0 };
     for (int v0 = 0; v0 < n_vol; v0 += NB) {
         const int m = std::min(NB, n_vol - v0);
-        const float *dv = (const float *)volumes + (size_t)v0 * n3;
-        if (!volumes_on_device) {
-            HIPCHK(hipMemcpyAsync(a->s_vols.p, dv, (size_t)m * n3 * sizeof(float), hipMemcpyHostToDevice, cur_stream()));
-            dv = a->s_vols.p;
-        }
+        const float *dv = d_vols + (size_t)v0 * n3;
         for (int v = 0; v < m; v++) {
             hw[2 * v] = wedges ? wedges[2 * (size_t)(v0 + v)] : -90.f; hw[2 * v + 1] = wedges ? wedges[2 * (size_t)(v0 + v) + 1] : 90.f;
-            const long key = index ? index[v0 + v] : (long)(v0 + v);
+            const long key = index ? index[v0 + v] : index_base + (long)(v0 + v);
             hh[v] = (int)(((key % 2) + 2) % 2);
             added[hh[v]]++;
         }
@@ -2173,5 +2186,25 @@ extern "C" int ppm_sva_insert(ppm_accum_t *a, const ppm_sva_cfg *cfg, const void
         HIPCHK(hipStreamSynchronize(cur_stream()));          // the host tables of the batch are reused
     }
     for (int h = 0; h < 2; h++) ppm_accum_set_count(a, h, a->counts[h] + added[h]);      // host and device copies of the counters
+    return 0;
+}
+
+extern "C" int ppm_sva_insert(ppm_accum_t *a, const ppm_sva_cfg *cfg, const void *volumes, int volumes_on_device, int n_vol, const float *wedges,
+                              const double *poses, const long *index) {
+    if (!g.inited) return fail(-1, "ppm_init has not been called");
+    if (!a || !cfg || !volumes || !poses) return fail(-22, "null argument");
+    StreamScope ss_(a->stream, a->copy);
+    if (n_vol <= 0) return 0;
+    if (volumes_on_device) return sva_insert_device(a, cfg, (const float *)volumes, n_vol, wedges, poses, index, 0);
+    const int N = cfg->box;
+    if (!box_ok(N) || N != a->N) return fail(-22, "sub-volume box differs from the accumulator's box (even, 32..512, prime factors 2, 3, 5)");
+    const size_t n3 = (size_t)N * N * N;
+    const int NB = std::min(n_vol, kSvaInsBatch);
+    if (int rc = a->s_vols.ensure((size_t)NB * n3)) return rc;
+    for (int v0 = 0; v0 < n_vol; v0 += NB) {            // host volumes: staged batch by batch
+        const int m = std::min(NB, n_vol - v0);
+        HIPCHK(hipMemcpyAsync(a->s_vols.p, (const float *)volumes + (size_t)v0 * n3, (size_t)m * n3 * sizeof(float), hipMemcpyHostToDevice, cur_stream()));
+        if (int rc = sva_insert_device(a, cfg, a->s_vols.p, m, wedges ? wedges + 2 * (size_t)v0 : nullptr, poses + (size_t)v0 * 12, index ? index + v0 : nullptr, v0)) return rc;
+    }
     return 0;
 }

@@ -35,6 +35,20 @@ def _images_arg(images, n_img, box):
     return lib.ptr(a), 0, a
 
 
+def _volumes_arg(volumes, n_vol, box):
+    """numpy array (host) or a device array (torch tensor / anything with data_ptr(), is_cuda) -> (pointer, on_device, keepalive)."""
+    if hasattr(volumes, "is_cuda") and volumes.is_cuda:
+        if str(volumes.dtype) != "torch.float32" or not volumes.is_contiguous() or volumes.numel() != n_vol * box ** 3:
+            raise ValueError("ERROR: device volumes must be contiguous float32 of V * box^3 elements")
+        if not getattr(volumes, "ready", False):
+            _sync_producer(volumes)
+        return C.c_void_p(volumes.data_ptr()), 1, volumes
+    a = np.ascontiguousarray(volumes.numpy() if hasattr(volumes, "numpy") else volumes, dtype=np.float32)
+    if a.size != n_vol * box ** 3:
+        raise ValueError("ERROR: volumes do not match the poses")
+    return lib.ptr(a), 0, a
+
+
 class Reference:
     """3-D reference prepared for projection matching up to `max_band_px` Fourier pixels."""
 
@@ -83,25 +97,27 @@ class Reference:
         del keep
         return rows, particles, tilts
 
-    def sva_align(self, cfg, volumes, wedges, poses):
+    def sva_align(self, cfg, volumes, wedges, poses, accumulator=None, index=None):
         """Sub-tomogram alignment (ppm_sva_align): volumes (V, N, N, N) float32 (numpy or CUDA tensor), wedges (V, 2) tilt limits in
-        degrees, poses (V, 12) = N row-major + shift.  Returns (refined poses, scores)."""
+        degrees, poses (V, 12) = N row-major + shift.  Returns (refined poses, scores).  accumulator: an Accumulator of the same box -
+        every chunk is added to the sub-tomogram average at its refined poses while it is in device memory (ppm_sva_align_average;
+        half-map = parity of index, default 0 .. V-1)."""
         poses = np.array(poses, dtype=np.float64, order="C")
         if poses.ndim != 2 or poses.shape[1] != 12:
             raise ValueError("ERROR: poses must be (V, 12)")
         w = np.ascontiguousarray(wedges, dtype=np.float32).reshape(len(poses), 2)
         scores = np.zeros(len(poses), dtype=np.float64)
-        if hasattr(volumes, "is_cuda") and volumes.is_cuda:
-            if str(volumes.dtype) != "torch.float32" or not volumes.is_contiguous() or volumes.numel() != len(poses) * cfg.box ** 3:
-                raise ValueError("ERROR: device volumes must be contiguous float32 of V * box^3 elements")
-            _sync_producer(volumes)
-            p, on_dev, keep = C.c_void_p(volumes.data_ptr()), 1, volumes
+        p, on_dev, keep = _volumes_arg(volumes, len(poses), cfg.box)
+        if accumulator is None:
+            lib.check(lib.load().ppm_sva_align(self.h, C.byref(cfg), p, on_dev, len(poses), lib.ptr(w), lib.ptr(poses), lib.ptr(scores)))
         else:
-            a = np.ascontiguousarray(volumes.numpy() if hasattr(volumes, "numpy") else volumes, dtype=np.float32)
-            if a.size != len(poses) * cfg.box ** 3:
-                raise ValueError("ERROR: volumes do not match the poses")
-            p, on_dev, keep = lib.ptr(a), 0, a
-        lib.check(lib.load().ppm_sva_align(self.h, C.byref(cfg), p, on_dev, len(poses), lib.ptr(w), lib.ptr(poses), lib.ptr(scores)))
+            idx = None if index is None else np.ascontiguousarray(index, dtype=np.int64)
+            if idx is not None and idx.shape != (len(poses),):
+                raise ValueError("ERROR: index must be (V,)")
+            if accumulator._ext is not None:
+                _sync_producer(accumulator._ext)
+            lib.check(lib.load().ppm_sva_align_average(self.h, accumulator.h, C.byref(cfg), p, on_dev, len(poses), lib.ptr(w), lib.ptr(poses), lib.ptr(scores),
+                                                       None if idx is None else lib.ptr(idx)))
         del keep
         return poses, scores
 
@@ -161,16 +177,7 @@ class Accumulator:
         idx = None if index is None else np.ascontiguousarray(index, dtype=np.int64)
         if idx is not None and idx.shape != (len(poses),):
             raise ValueError("ERROR: index must be (V,)")
-        if hasattr(volumes, "is_cuda") and volumes.is_cuda:
-            if str(volumes.dtype) != "torch.float32" or not volumes.is_contiguous() or volumes.numel() != len(poses) * self.box ** 3:
-                raise ValueError("ERROR: device volumes must be contiguous float32 of V * box^3 elements")
-            _sync_producer(volumes)
-            p, on_dev, keep = C.c_void_p(volumes.data_ptr()), 1, volumes
-        else:
-            a = np.ascontiguousarray(volumes.numpy() if hasattr(volumes, "numpy") else volumes, dtype=np.float32)
-            if a.size != len(poses) * self.box ** 3:
-                raise ValueError("ERROR: volumes do not match the poses")
-            p, on_dev, keep = lib.ptr(a), 0, a
+        p, on_dev, keep = _volumes_arg(volumes, len(poses), self.box)
         if self._ext is not None:
             _sync_producer(self._ext)
         lib.check(lib.load().ppm_sva_insert(self.h, C.byref(cfg), p, on_dev, len(poses), lib.ptr(w), lib.ptr(poses), None if idx is None else lib.ptr(idx)))

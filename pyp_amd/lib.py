@@ -16,7 +16,7 @@ EXPORTS = [
     "ppm_insert_batch", "ppm_accum_download", "ppm_accum_download_range", "ppm_accum_add", "ppm_accum_count", "ppm_accum_set_count",
     "ppm_finalize", "ppm_profile_enable", "ppm_profile_reset", "ppm_profile_get", "ppm_device_alloc",
     "ppm_device_free", "ppm_device_upload", "ppm_device_sync", "ppm_extract_boxes", "ppm_host_alloc", "ppm_host_free", "ppm_host_read",
-    "ppm_comm_unique_id", "ppm_comm_create", "ppm_comm_destroy", "ppm_accum_reduce", "ppm_sva_insert",
+    "ppm_comm_unique_id", "ppm_comm_create", "ppm_comm_destroy", "ppm_accum_reduce", "ppm_sva_insert", "ppm_sva_align_average",
 ]
 
 
@@ -51,6 +51,7 @@ def load():
     L.ppm_csp_refine.argtypes = [vp, vp, vp, vp, ci, ci, vp, vp, ci, vp, ci]; L.ppm_csp_refine.restype = ci
     L.ppm_sva_align.argtypes = [vp, vp, vp, ci, ci, vp, vp, vp]; L.ppm_sva_align.restype = ci
     L.ppm_sva_insert.argtypes = [vp, vp, vp, ci, ci, vp, vp, vp]; L.ppm_sva_insert.restype = ci
+    L.ppm_sva_align_average.argtypes = [vp, vp, vp, vp, ci, ci, vp, vp, vp, vp]; L.ppm_sva_align_average.restype = ci
     L.ppm_accum_floats.argtypes = [ci]; L.ppm_accum_floats.restype = C.c_size_t
     L.ppm_accum_create.argtypes = [ci, cf, C.c_char_p, vp]; L.ppm_accum_create.restype = vp
     L.ppm_accum_destroy.argtypes = [vp]; L.ppm_accum_destroy.restype = None

@@ -182,8 +182,8 @@ def align_table(reference, table, names, cfg, base_dir=".", device=0, chunk=256,
     correlation score in cutOffset) and the scores.  Sub-volumes are read chunk by chunk (10 k x 192^3 is 283 GB) into two
     page-locked buffers, the next chunk by a reader thread while the current one is aligned; inside a call the library uploads
     2 GB at a time while it searches the previous 2 GB.  accumulator: a host.Accumulator of the same box - every chunk is added to
-    the sub-tomogram average at its refined poses while it is still in memory (half-map = parity of the table's `number` column),
-    so the volumes are read once per iteration; finish with average_from_accumulator."""
+    the sub-tomogram average at its refined poses while it is still in DEVICE memory (ppm_sva_align_average; half-map = parity of the
+    table's `number` column), so the volumes are read and uploaded once per iteration; finish with average_from_accumulator."""
     import threading
     from . import host
     n = int(cfg.box)
@@ -193,14 +193,26 @@ def align_table(reference, table, names, cfg, base_dir=".", device=0, chunk=256,
     chunk = max(1, min(int(chunk), len(out)))
     bufs = [host.PinnedBuffer(chunk * n ** 3, device) for _ in range(2 if len(out) > chunk else 1)]
 
+    L = host.lib.load()
+    nthreads = max(1, min(16, int(os.environ.get("PPM_IO_THREADS", "8"))))
+
     def fill(b, lo, hi):
         vols = bufs[b].array[:(hi - lo) * n ** 3].reshape(hi - lo, n, n, n)
         for k in range(lo, hi):
             fn = names[k] if os.path.isabs(names[k]) else os.path.join(base_dir, names[k])
-            v = mrc.read(fn)
-            if v.shape != (n, n, n):
-                raise ValueError(f"ERROR: {fn} is {v.shape}, expected {n}^3")
-            vols[k - lo] = v
+            h = mrc.read_header(fn)
+            if h["shape"] != (n, n, n):
+                raise ValueError(f"ERROR: {fn} is {h['shape']}, expected {n}^3")
+            if h["dtype"] == np.dtype("<f4") and os.path.getsize(fn) >= h["data_offset"] + 4 * n ** 3:
+                # little-endian float32 (what PYP's extraction writes): the library's reader pool fills the page-locked buffer directly
+                fd = os.open(fn, os.O_RDONLY)
+                try:
+                    if L.ppm_host_read(fd, h["data_offset"], bufs[b].ptr + (k - lo) * 4 * n ** 3, 4 * n ** 3, nthreads) != 0:
+                        raise IOError(f"ERROR: reading {fn} failed: " + host.lib.last_error())
+                finally:
+                    os.close(fd)
+            else:
+                vols[k - lo] = mrc.read(fn)
         return vols
 
     t = None
@@ -221,13 +233,12 @@ def align_table(reference, table, names, cfg, base_dir=".", device=0, chunk=256,
             for k in range(lo, hi):
                 N, p = line_to_pose(out[k, 9:12], out[k, 12:28])
                 poses[k - lo, :9], poses[k - lo, 9:] = N.ravel(), p
-            got, sc = ref.sva_align(cfg, cur, out[lo:hi, 1:3].astype(np.float32), poses)
+            got, sc = ref.sva_align(cfg, cur, out[lo:hi, 1:3].astype(np.float32), poses, accumulator=accumulator,
+                                    index=out[lo:hi, 0].astype(np.int64) if accumulator is not None else None)
             for k in range(lo, hi):
                 out[k, 12:28] = pose_to_matrix(got[k - lo, :9], got[k - lo, 9:], out[k, 9:12])
                 out[k, 31] = sc[k - lo]
             scores[lo:hi] = sc
-            if accumulator is not None:
-                accumulator.sva_insert(cfg, cur, out[lo:hi, 1:3].astype(np.float32), got, index=out[lo:hi, 0].astype(np.int64))
             if t is not None:
                 t.join()
                 t = None

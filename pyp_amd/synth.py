@@ -409,10 +409,15 @@ def paste_tilt_series(stack, rows, n_tilt, shape=(512, 512), seed=5):
     tilt image (IMIND) on a unit-noise background; sets ORIGINAL_X_POSITION (column) / ORIGINAL_Y_POSITION (row) in `rows`
     (returned copy) so that extracting a box of the same size around them gives the projection back."""
     C = cistem.COL
-    st = stack.numpy() if hasattr(stack, "numpy") else np.asarray(stack)
+    on_gpu = hasattr(stack, "is_cuda") and stack.is_cuda          # a resident stack: the series is built on its device (41 x 4096^2 is 2.7 GB)
+    st = stack if on_gpu else (stack.numpy() if hasattr(stack, "numpy") else np.asarray(stack))
     m, n = st.shape[0], st.shape[1]
     rng = np.random.default_rng(seed)
-    series = rng.normal(0, 1, (n_tilt,) + tuple(shape)).astype(np.float32)
+    if on_gpu:
+        gen = torch.Generator(device=stack.device); gen.manual_seed(seed)
+        series = torch.randn((n_tilt,) + tuple(shape), generator=gen, device=stack.device, dtype=torch.float32)
+    else:
+        series = rng.normal(0, 1, (n_tilt,) + tuple(shape)).astype(np.float32)
     rows = rows.copy()
     pind = np.unique(rows[:, C["PIND"]].astype(int))
     per_row = max(1, (shape[1] - n) // (n + 16))

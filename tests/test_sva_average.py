@@ -225,3 +225,30 @@ def test_sva_align_executable_writes_the_average(tmp_path):
     assert np.abs(flt[0, 0, :]).max() < 0.05 * np.abs(flt).max()                          # the window has removed the box corners
     r = subprocess.run([sys.executable, exe, "p.xml", "missing.txt", "ref.mrc", "o.txt", "o_avg"], cwd=tmp_path, capture_output=True, text=True)
     assert r.returncode != 0 and "ERROR" in r.stdout and not (tmp_path / "o.txt").exists() and not (tmp_path / "o_avg.mrc").exists()
+
+
+@pytest.mark.gpu
+def test_fused_align_and_average_equals_the_two_calls(monkeypatch):
+    """ppm_sva_align_average (one pass: every chunk aligned, then added to the average while it is in device memory) gives the poses of
+    ppm_sva_align and the accumulator of ppm_sva_insert at those poses - from host volumes in several chunks and from resident ones."""
+    from pyp_amd import host as H
+    n, nv = 32, 10
+    vol, vols, poses, wedges = synth.make_subtomograms(n, nv, snr=0.5, seed=4)
+    start = synth.perturb_poses(poses, 3.0, 1.0)
+    cfg = SvaCfg.make(n, window=(12, 12, 12), window_sigma=2.0, highpass=(0.03, 0.01), lowpass=(0.3, 0.04), tol_angle=10.0, tol_shift=4.0)
+    index = np.arange(nv) + 7
+    ref = H.Reference(vol, n / 2)
+    p0, s0 = ref.sva_align(cfg, vols.numpy(), wedges, start)
+    a0 = H.Accumulator(n, 1.0, "C1")
+    a0.sva_insert(cfg, vols.numpy(), wedges, p0, index)
+    want, wc = a0.download(), a0.counts()
+    a0.close()
+    monkeypatch.setenv("PPM_SVA_CHUNK", "4")                     # host volumes: chunks of 4, the next one uploaded while this one is searched
+    for src in (vols.numpy(), vols.cuda()):
+        a1 = H.Accumulator(n, 1.0, "C1")
+        p1, s1 = ref.sva_align(cfg, src, wedges, start, accumulator=a1, index=index)
+        got, gc = a1.download(), a1.counts()
+        a1.close()
+        assert np.array_equal(p1, p0) and np.array_equal(s1, s0) and gc == wc
+        assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max()            # batches of the gather differ between the two call shapes: float32 sums in another order
+    ref.close()
