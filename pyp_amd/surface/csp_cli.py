@@ -10,6 +10,8 @@ config/pyp_config.toml:6241-6641) and the current map from $PYP_SCRATCH/<data_se
 Modes (src/pyp/align/core.py:1015-1023 and the 2 -> 5, 3 -> 6 remaps of local_run.py:332-335, :413, :428):
    -2  extract the projections of particles first..last from the tilt series (<images> = .mrc) or from the movies of a
        frame list (<images> = frames_csp.txt, one movie per tilt: section FIND of movie IMIND) into <stack>
+   -2.1  the same with every box replaced by the running average over the neighbouring frames of its particle
+       (csp_produce_running_average, align/core.py:1000-1001; merged by the caller into <name>_stack_weighted_average.mrc)
     1 / 2 / 5  particle rotations / 3-D shifts / both, particles first..last (PIND); 8 / 7 = 1 / 2 (the caller's region codes)
     0 / 3 / 6  tilt angle + axis / image shifts / both, tilts first..last (TIND; last = -1: up to the end)
     4  one defocus offset per tilt (csp_ToleranceMicrographDefocus1 either side, 50 A steps), tilts first..last
@@ -82,7 +84,7 @@ def _settings(p):
         tol_m_rot=(float(p.get("csp_ToleranceMicrographTiltAngles", 1.5)), float(p.get("csp_ToleranceMicrographTiltAxisAngles", 1.0)), 0.0),
         tol_m_shift=float(p.get("csp_ToleranceMicrographShifts", 100.0)), tol_defocus=float(p.get("csp_ToleranceMicrographDefocus1", 750.0)),
         normalize=int(bool(p.get("reconstruct_norm", True))), invert=int(bool(p.get("refine_invert", False))),
-        data_set=str(p.get("data_set", "")))
+        data_set=str(p.get("data_set", "")), running_frames=int(p.get("csp_running_average_frames", 2)))
 
 
 def _out_names(param_file, first, last):
@@ -148,10 +150,8 @@ def csp_main(argv=None):
     rows = cistem.read_parameters(param_file)
     ext = cistem.read_extended(ext_file)
     particles, tilts = ext["particles"], ext["tilts"]
-    if mode == -2:
-        return _extract(s, rows, first, last, images, stack, t0)
-    if mode == -2.1:
-        _die("ERROR: csp: mode -2.1 (running frame averages, frealign/<name>_stack_weighted_average.mrc, align/core.py:1000-1001, :1170) is not built")
+    if mode in (-2, -2.1):
+        return _extract(s, rows, first, last, images, stack, t0, running=(mode == -2.1))
     # the caller's own codes for region-based refinement (align/core.py:1121-1133: 7 = particle shifts, 8 = particle rotations)
     # normally arrive already mapped to 2 / 1 (and then 2 -> 5 by local_run.py:334-335); accepted as given as well
     mode = {7: 2, 8: 1}.get(mode, mode)
@@ -214,9 +214,48 @@ def csp_main(argv=None):
     return 0
 
 
-def _extract(s, rows, first, last, images, stack, t0):
+def running_average(stack, rows, half_width, radius_px):
+    """Mode -2.1 (csp_produce_running_average, src/pyp/align/core.py:1000-1001; the caller merges the outputs into
+    frealign/<name>_stack_weighted_average.mrc, :1170): every row's box becomes the weighted average of the boxes of the SAME particle
+    (PIND) in the SAME movie / tilt (IMIND) whose frame index FIND lies within `half_width` of the row's own, with weights
+    exp(-d^2 / (2 (half_width / 2)^2)) of the frame distance d - one image per row, so the stack still matches the parameter file.
+    The averaged boxes are normalised again on their background ring (mean 0, sigma 1 outside `radius_px`, like
+    src/pyp/analysis/image.py:406-417).  Build-defined: the absent program's weights are not visible (the option is hidden in
+    config/pyp_config.toml:6528-6534, "currently only for testing classification").  half_width = 0 returns the stack unchanged."""
+    if half_width <= 0:
+        return stack
+    n, box = len(rows), stack.shape[1]
+    key = np.stack([rows[:, C["PIND"]], rows[:, C["IMIND"]]], axis=1).astype(np.int64)
+    fidx = rows[:, C["FIND"]].astype(np.int64)
+    order = np.lexsort((fidx, key[:, 1], key[:, 0]))
+    out = np.empty_like(stack)
+    yy, xx = np.mgrid[:box, :box]
+    bg = ((yy - box // 2) ** 2 + (xx - box // 2) ** 2) > radius_px * radius_px
+    sig = max(half_width / 2.0, 1e-6)
+    lo = 0
+    while lo < n:
+        hi = lo + 1
+        while hi < n and np.array_equal(key[order[hi]], key[order[lo]]):
+            hi += 1
+        grp = order[lo:hi]
+        f = fidx[grp]
+        for j, fj in zip(grp, f):
+            d = f - fj
+            use = np.abs(d) <= half_width
+            w = np.exp(-(d[use].astype(np.float64) ** 2) / (2 * sig * sig))
+            avg = np.tensordot(w / w.sum(), stack[grp[use]].astype(np.float64), axes=1)
+            b = avg[bg] if bg.any() else avg.ravel()
+            sd = b.std()
+            out[j] = ((avg - b.mean()) / (sd if sd > 0 else 1.0)).astype(np.float32)
+        lo = hi
+    return out
+
+
+def _extract(s, rows, first, last, images, stack, t0, running=False):
     """Mode -2: boxes of `extract_box` pixels around (ORIGINAL_X_POSITION, ORIGINAL_Y_POSITION) of section IMIND of the tilt
-    series, normalised like every PYP particle stack (src/pyp/analysis/image.py:406-417), written in row order."""
+    series, normalised like every PYP particle stack (src/pyp/analysis/image.py:406-417), written in row order.  Mode -2.1
+    (`running`): the same boxes replaced by running frame averages (running_average; half-width csp_running_average_frames of
+    .pyp_config.toml, default 2 = five frames)."""
     if not os.path.exists(images):
         _die(f"ERROR: csp: {'frame list' if str(images).endswith('.txt') else 'tilt series'} {images} does not exist")
     if s["extract_bin"] != 1:
@@ -227,7 +266,7 @@ def _extract(s, rows, first, last, images, stack, t0):
         _die(f"ERROR: csp: no rows with PIND in {first}..{last}")
     r = rows[sel]
     if str(images).endswith(".txt"):
-        return _extract_frames(s, r, first, last, images, stack, t0)
+        return _extract_frames(s, r, first, last, images, stack, t0, running)
     series = mrc.mmap(images)
     if series.ndim == 2:
         series = series[None]
@@ -246,13 +285,16 @@ def _extract(s, rows, first, last, images, stack, t0):
                 out[idx] = host.extract_boxes(np.ascontiguousarray(series[im], dtype=np.float32), coords, box, s["radius"], px, device=dev)
     except (lib.PpmError, ValueError) as e:
         _die(str(e))
+    if running:
+        out = running_average(out, r, s["running_frames"], s["radius"] / px)
     mrc.write(out, stack, pixel_size=px)
-    print(f"\nExtracted {len(r)} projections of particles {first}..{last} into {stack} in {time.time() - t0:.1f} s")
+    print(f"\nExtracted {len(r)} projections of particles {first}..{last} into {stack} in {time.time() - t0:.1f} s"
+          + (f" (running averages over +-{s['running_frames']} frames)" if running else ""))
     print("\nCSP: Normal termination\n", flush=True)
     return 0
 
 
-def _extract_frames(s, r, first, last, images, stack, t0):
+def _extract_frames(s, r, first, last, images, stack, t0, running=False):
     """Mode -2 from a frame list (`frames_csp.txt`, written by src/pyp/extract/core.py:620-625: one movie file per line, in
     tilt-series order): a row is cut out of section FIND of movie IMIND, at (ORIGINAL_X_POSITION + FSHIFT_X, ORIGINAL_Y_POSITION
     + FSHIFT_Y) rounded down like the box corner itself.  The reference's own use of the list lives in the absent binary; this
@@ -286,7 +328,10 @@ def _extract_frames(s, r, first, last, images, stack, t0):
                     out[idx] = host.extract_boxes(np.ascontiguousarray(mv[fr], dtype=np.float32), coords, box, s["radius"], px, device=dev)
     except (lib.PpmError, ValueError) as e:
         _die(str(e))
+    if running:
+        out = running_average(out, r, s["running_frames"], s["radius"] / px)
     mrc.write(out, stack, pixel_size=px)
-    print(f"\nExtracted {len(r)} frame projections of particles {first}..{last} from {len(movies)} movies into {stack} in {time.time() - t0:.1f} s")
+    print(f"\nExtracted {len(r)} frame projections of particles {first}..{last} from {len(movies)} movies into {stack} in {time.time() - t0:.1f} s"
+          + (f" (running averages over +-{s['running_frames']} frames)" if running else ""))
     print("\nCSP: Normal termination\n", flush=True)
     return 0

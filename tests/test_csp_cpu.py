@@ -160,3 +160,44 @@ def test_csp_executable_fails_loudly(tmp_path):
     assert r.returncode != 0 and "ERROR" in r.stdout and not list(tmp_path.glob("*.cistem"))
     r = subprocess.run([sys.executable, exe, "a.cistem"], capture_output=True, text=True, cwd=tmp_path)
     assert r.returncode != 0 and "ERROR" in r.stdout and "usage" in r.stdout
+
+
+def test_running_frame_averages_of_mode_minus_2_1():
+    """csp mode -2.1 (csp_produce_running_average, align/core.py:1000-1001): one image per row, the weighted average over the frames of
+    the same particle and movie within the half-width, normalised on the background ring; rows of other particles / movies never mix."""
+    from pyp_amd.formats import cistem
+    from pyp_amd.surface import csp_cli
+    C = cistem.COL
+    rng = np.random.default_rng(2)
+    box, nf = 24, 7
+    sig = np.zeros((box, box)); sig[8:16, 8:16] = 4.0
+    rows, imgs = [], []
+    for p in range(2):
+        for m in range(2):
+            for f in range(nf):
+                r = np.zeros(32); r[C["PIND"]], r[C["IMIND"]], r[C["FIND"]] = p, m, f
+                rows.append(r)
+                imgs.append((sig if p == 0 else -sig) + rng.normal(0, 1.0, (box, box)))
+    rows, imgs = np.array(rows), np.array(imgs, dtype=np.float32)
+    perm = rng.permutation(len(rows))                       # row order must not matter
+    out = csp_cli.running_average(imgs[perm], rows[perm], 2, 10.0)
+    assert out.shape == imgs.shape and out.dtype == np.float32
+    inv = np.argsort(perm)
+    out = out[inv]
+    yy, xx = np.mgrid[:box, :box]
+    bg = ((yy - box // 2) ** 2 + (xx - box // 2) ** 2) > 100.0
+    for j in (0, 3, 6, 10, 27):
+        assert abs(out[j][bg].mean()) < 1e-5 and abs(out[j][bg].std() - 1.0) < 1e-4          # normalised again
+    # the signal-to-noise of the averaged boxes rises: the centre square stands out more than in a single frame
+    snr_in = np.array([abs(im[8:16, 8:16].mean()) / im[bg].std() for im in imgs])
+    snr_out = np.array([abs(im[8:16, 8:16].mean()) for im in out])
+    assert snr_out.mean() > 1.5 * snr_in.mean()
+    # a middle frame with weights exp(-d^2 / 2) over d = -2 .. 2, by hand
+    j = 3
+    w = np.exp(-np.arange(-2, 3) ** 2 / 2.0)
+    avg = np.tensordot(w / w.sum(), imgs[1:6].astype(np.float64), axes=1)
+    want = (avg - avg[bg].mean()) / avg[bg].std()
+    assert np.abs(out[j] - want).max() < 1e-5
+    # particles 0 and 1 carry opposite signals: no mixing across particles
+    assert out[:14, 8:16, 8:16].mean() > 0 and out[14:, 8:16, 8:16].mean() < 0
+    assert np.array_equal(csp_cli.running_average(imgs, rows, 0, 10.0), imgs)

@@ -296,6 +296,11 @@ def test_region_split_2x2x1_end_to_end_like_the_caller(tmp_path):
     run_all([f"{BIN}/csp frealign/maps/fr_r01_02.cistem frealign/maps/fr_r01_02_extended.cistem -2 0 5 1 frames_csp.txt frealign/fr_stack.mrc",
              f"{BIN}/csp frealign/maps/ser_r01_02.cistem frealign/maps/ser_r01_02_extended.cistem -2 0 5 1 frealign/ts.mrc frealign/ser_stack.mrc"], "csp_frames.log")
     assert np.array_equal(mrc.read(str(tmp_path / "frealign/fr_stack.mrc")), mrc.read(str(tmp_path / "frealign/ser_stack.mrc")))
+    # ---- mode -2.1: the same extraction with running frame averages (one frame per movie here: the average of a single frame is the
+    # frame itself, normalised again - the stack equals mode -2's up to that second normalisation)
+    run_all([f"{BIN}/csp frealign/maps/fr_r01_02.cistem frealign/maps/fr_r01_02_extended.cistem -2.1 0 5 1 frames_csp.txt frealign/fr_avg_stack.mrc"], "csp_avg.log")
+    a21, a2 = mrc.read(str(tmp_path / "frealign/fr_avg_stack.mrc")), mrc.read(str(tmp_path / "frealign/fr_stack.mrc"))
+    assert a21.shape == a2.shape and np.abs(a21 - a2).max() < 1e-3 and "running averages over +-2 frames" in (tmp_path / "csp_avg.log").read_text()
     r = subprocess.run(f"{BIN}/csp frealign/maps/fr_r01_02.cistem frealign/maps/fr_r01_02_extended.cistem -2 0 5 1 missing_frames.txt x.mrc", shell=True,
                        cwd=tmp_path, env=env, capture_output=True, text=True)
     assert r.returncode != 0 and "ERROR" in r.stdout and "missing_frames.txt" in r.stdout

@@ -559,3 +559,65 @@ def test_native_executables_end_with_error_when_an_upload_fails(project, monkeyp
     log = open(d / f"fail_{prog}.log").read()
     assert r.returncode != 0 and "ERROR" in log and "PPM_TEST_FAIL_UPLOAD" in log and "native" in log
     assert not any((d / o).exists() for o in outs)
+
+
+def test_resident_server_keeps_the_stack_and_the_reference_between_calls(project, monkeypatch, tmp_path):
+    """PPM_STACK_CACHE=1 (pyp_amd/csrc/dropin_server.h): the executables are clients of bin/ppm_server.  An iteration as PYP runs it -
+    reconstruct3d, then refine3d, then reconstruct3d again over the same stack - uploads the range once: the later calls find it
+    resident (and refine3d's second call finds its reference prepared).  Files equal those of the one-shot executables; a stack
+    that changes on disk is uploaded again; --stop frees the device."""
+    d, vol, imgs, truth, start = project
+    server = os.path.join(BIN, "ppm_server")
+    monkeypatch.setenv("PPM_LOCK_DIR", str(tmp_path))
+    used = truth.copy()
+    used[:, cistem.COL["SCORE"]] = 20.0
+    cistem.write_parameters(str(d / "s_used.cistem"), used)
+
+    def rec(tag):
+        lines = ["p_stack.mrc", "s_used.cistem", "null", "p_r01.mrc", "s_map1.mrc", "s_map2.mrc", "output.mrc", f"s_{tag}.res", "C1", 5, 50, PX, 300, 0,
+                 PX * N / 2, 2 * PX, 0, 2.0, "no", 0, -1, "no", 0, 1, 1, "yes", "no", "no", "no", "no", "yes", "no", "no", "no", "no", "yes",
+                 f"{d}/s_{tag}_map1_n1.mrc", f"{d}/s_{tag}_map2_n1.mrc", 1]
+        return "\n".join(str(x) for x in lines) + "\n"
+    # one-shot references
+    assert run("reconstruct3d", rec("one"), d, "s_one.log") == 0
+    assert run("refine3d", refine_script(5, 50, True, out="s_one.cistem"), d, "s_one_ref.log") == 0
+    monkeypatch.setenv("PPM_STACK_CACHE", "1")
+    monkeypatch.setenv("PPM_STACK_CACHE_IDLE_S", "120")
+    try:
+        assert run("reconstruct3d", rec("a"), d, "s_a.log") == 0                       # starts the server, uploads, keeps
+        assert run("refine3d", refine_script(5, 50, True, out="s_a.cistem"), d, "s_a_ref.log") == 0
+        assert run("reconstruct3d", rec("b"), d, "s_b.log") == 0
+        assert run("refine3d", refine_script(8, 40, True, out="s_b.cistem"), d, "s_b_ref.log") == 0       # a sub-range of what is resident
+        la, lar, lb, lbr = (open(d / f).read() for f in ("s_a.log", "s_a_ref.log", "s_b.log", "s_b_ref.log"))
+        assert "resident server" in la and "uploaded and kept resident" in la and "Reconstruct3D: Normal termination" in la
+        assert "are resident in device memory" in lar and "Refine3D: Normal termination" in lar and "is prepared already" not in lar
+        assert "are resident in device memory" in lb and "are resident in device memory" in lbr and "is prepared already" in lbr
+        for k in (1, 2):
+            for tag in ("a", "b"):
+                x, y = open(d / f"s_{tag}_map{k}_n1.mrc", "rb").read(), open(d / f"s_one_map{k}_n1.mrc", "rb").read()
+                assert x[:24] == y[:24] and len(x) == len(y)
+                fx, fy = np.frombuffer(x, "<f4", offset=24), np.frombuffer(y, "<f4", offset=24)
+                assert np.abs(fx - fy).max() <= 2e-6 * np.abs(fy).max()                # one call over the range instead of several: float32 sums in another order
+        assert open(d / "s_a.res").read() == open(d / "s_one.res").read()
+        a, b = cistem.read_parameters(str(d / "s_a.cistem")), cistem.read_parameters(str(d / "s_one.cistem"))
+        assert np.array_equal(a, b)
+        sub = cistem.read_parameters(str(d / "s_b.cistem"))
+        assert np.array_equal(sub, b[3:36])
+        st = subprocess.run([server, "--stats"], capture_output=True, text=True).stdout
+        assert "served 4 calls" in st and "3 resident hits" in st and "1 uploads" in st and "particles 5..50" in st
+        # the stack changes on disk (same path, new contents): its identity differs, the range is uploaded again
+        stack2 = imgs.copy(); stack2[10] *= -1.0
+        os.remove(d / "p_stack.mrc")
+        mrc.write(stack2, str(d / "p_stack.mrc"), pixel_size=PX)
+        assert run("reconstruct3d", rec("c"), d, "s_c.log") == 0
+        assert "uploaded and kept resident" in open(d / "s_c.log").read()
+        fc, fo = (np.frombuffer(open(d / f"s_{t}_map1_n1.mrc", "rb").read(), "<f4", offset=24) for t in ("c", "one"))
+        fc2, fo2 = (np.frombuffer(open(d / f"s_{t}_map2_n1.mrc", "rb").read(), "<f4", offset=24) for t in ("c", "one"))
+        assert not (np.allclose(fc, fo) and np.allclose(fc2, fo2))
+        # errors come back through the server with the contract of the executables
+        bad = rec("bad").replace("s_used.cistem", "s_missing.cistem")
+        assert run("reconstruct3d", bad, d, "s_bad.log") != 0 and "ERROR" in open(d / "s_bad.log").read() and not (d / "s_bad_map1_n1.mrc").exists()
+    finally:
+        r = subprocess.run([server, "--stop"], capture_output=True, text=True, timeout=60)
+        mrc.write(imgs, str(d / "p_stack.mrc"), pixel_size=PX)                          # the module's fixture as it was
+    assert "stopping" in r.stdout
