@@ -252,3 +252,120 @@ def align_table(reference, table, names, cfg, base_dir=".", device=0, chunk=256,
         for pb in bufs:
             pb.close()
     return out, scores
+
+
+# ------------------------------------------------------------------------------------------------ classification (3DAVG mode 1)
+class GpuBackend:
+    """The two operations classification needs, on the GPU through the C ABI: the constrained correlation of aligned sub-volumes with a
+    class average at their fixed poses (ppm_sva_align with zero search ranges = one score sweep) and class averages (ppm_sva_insert +
+    ppm_finalize).  tests/ drive the same driver with the CPU oracle behind this interface."""
+
+    def __init__(self, device=0):
+        self.device = device
+
+    def scores(self, reference, cfg, volumes, wedges, poses):
+        from . import host
+        ref = host.Reference(reference, cfg.box / 2, device=self.device)
+        try:
+            return ref.sva_align(cfg, volumes, wedges, poses)[1]
+        finally:
+            ref.close()
+
+    def average(self, cfg, chunks, members):
+        """chunks: iterable of (lo, hi, volumes, wedges, poses, index); members: boolean (V,) - the sub-volumes that enter.
+        -> (average, average of the even-index members, of the odd-index members, counts [even, odd]); None where nothing entered."""
+        from . import host
+        from .abi import FinalCfg
+        acc = host.Accumulator(cfg.box, 1.0, "C1", device=self.device)
+        try:
+            for lo, hi, vols, wedges, poses, index in chunks:
+                sel = np.where(members[lo:hi])[0]
+                if len(sel):
+                    acc.sva_insert(cfg, np.ascontiguousarray(vols[sel]), wedges[sel], poses[sel], index[sel])
+            counts = acc.counts()
+            if counts[0] + counts[1] == 0:
+                return None, None, None, counts
+            h_even, h_odd, avg, _ = acc.finalize(FinalCfg(molecular_mass_kda=0.0, inner_radius=0.0, outer_radius=0.0, mask_falloff=0.0))
+            return avg, (h_even if counts[0] else None), (h_odd if counts[1] else None), counts
+        finally:
+            acc.close()
+
+
+def score_cfg(cfg):
+    """The alignment settings with the search switched off: ppm_sva_align then only scores the given poses."""
+    c = SvaCfg.from_buffer_copy(bytes(cfg))
+    c.tol_angle, c.tol_shift, c.search_mode, c.max_iterations = 0.0, 0.0, 0, 0
+    return c
+
+
+def classify(chunks, n_vol, cfg, references, backend, iterations=4):
+    """Multi-reference classification of ALIGNED sub-volumes - the `class` / `refine` steps of a 3DAVG iteration (protocol modes 1 and 2,
+    src/pyp/refine/tomo_avg/sub_tomo_avg.py:435-449: the class averages `<dataset>_iteration_%03d_level_%d_average_%03d.mrc` of one round
+    are the references of the next, :79-94) - in the metric the alignment uses.  From K class references: every sub-volume is scored
+    against every class at its own pose over the protocol's band-pass and its measured wedge (the score sweep of ppm_sva_align), each
+    class's scores are standardised over the data set (the class with more members has the cleaner average and would attract
+    everybody otherwise) and the sub-volume joins the class it fits relatively best; the classes are averaged (ppm_sva_insert +
+    ppm_finalize) and the averages become the references of the next pass, until nothing moves or `iterations` passes are done.  A
+    sub-volume is never compared with an average it is part of: the accumulators keep even- and odd-index members apart (the half-maps
+    of ppm_finalize) and it is scored against the half of the OTHER parity; a class too small to have both halves keeps the reference
+    it came with.  `chunks()` yields (lo, hi, volumes, wedges, poses, index) over the data set - the volumes stream from wherever they
+    live on every pass.  NOT built: the unsupervised start of MPI_Classification (hierarchical clustering from pairwise comparisons) - at
+    the signal-to-noise ratio of single sub-tomograms pairwise correlations over the common wedge support did not separate classes in
+    this build's tests; the caller provides the first references (e.g. the previous level's averages).
+    -> (classes (V,), scores (V, K) of the last pass, class averages [K] (None for an empty class), passes run)."""
+    K = len(references)
+    if K < 1:
+        raise ValueError("ERROR: classification needs at least one class reference")
+    sc_cfg = score_cfg(cfg)
+    refs = [(np.asarray(r, dtype=np.float32),) * 2 for r in references]          # (scored by odd-index members, by even-index members)
+    classes = np.full(n_vol, -1, dtype=np.int64)
+    scores = np.zeros((n_vol, K))
+    averages = [None] * K
+    done = 0
+    parity = np.zeros(n_vol, dtype=bool)
+    for it in range(max(1, int(iterations))):
+        for lo, hi, vols, wedges, poses, index in chunks():
+            odd = (np.asarray(index) % 2) != 0
+            parity[lo:hi] = odd
+            for k in range(K):
+                if refs[k][0] is refs[k][1]:
+                    scores[lo:hi, k] = backend.scores(refs[k][0], sc_cfg, vols, wedges, poses)
+                else:
+                    s_odd, s_even = (backend.scores(h, sc_cfg, vols, wedges, poses) for h in refs[k])
+                    scores[lo:hi, k] = np.where(odd, s_odd, s_even)
+        z = np.zeros_like(scores)
+        for grp in (parity, ~parity):                  # the two parities are scored against different half-averages: standardised apart
+            if grp.any():
+                sd = scores[grp].std(axis=0)
+                z[grp] = (scores[grp] - scores[grp].mean(axis=0)) / np.where(sd > 0, sd, 1.0)
+        new = np.argmax(z, axis=1) if K > 1 else np.zeros(n_vol, dtype=np.int64)
+        done = it + 1
+        moved = int((new != classes).sum())
+        classes = new
+        for k in range(K):
+            avg, h_even, h_odd, counts = backend.average(cfg, chunks(), classes == k)
+            averages[k] = avg
+            if avg is not None and min(counts) >= 2:
+                refs[k] = (h_even, h_odd)                # odd-index members are scored against the even half and vice versa
+        if moved == 0:
+            break
+    return classes, scores, averages, done
+
+
+def table_chunks(table, names, n, base_dir=".", chunk=64):
+    """A chunks() provider over a volumes table: sub-volume files read `chunk` at a time, poses from the table's matrices."""
+    def gen():
+        for lo in range(0, len(table), chunk):
+            hi = min(lo + chunk, len(table))
+            vols = np.empty((hi - lo, n, n, n), dtype=np.float32)
+            poses = np.zeros((hi - lo, 12))
+            for k in range(lo, hi):
+                fn = names[k] if os.path.isabs(names[k]) else os.path.join(base_dir, names[k])
+                v = mrc.read(fn)
+                if v.shape != (n, n, n):
+                    raise ValueError(f"ERROR: {fn} is {v.shape}, expected {n}^3")
+                vols[k - lo] = v
+                N, p = line_to_pose(table[k, 9:12], table[k, 12:28])
+                poses[k - lo, :9], poses[k - lo, 9:] = N.ravel(), p
+            yield lo, hi, vols, table[lo:hi, 1:3].astype(np.float32), poses, table[lo:hi, 0].astype(np.int64)
+    return gen
