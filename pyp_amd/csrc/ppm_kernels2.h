@@ -809,235 +809,6 @@ __global__ void __launch_bounds__(NW * 64) k_insert_bricks(InsertBrickP P) {
     }
 }
 
-// ---------------------------------------------------------------------------------- record-binned insertion
-// The same bricks, fed from LISTS instead of a geometric search.  k_insert_bricks finds the samples of every (particle, brick) pair by
-// intersecting the slice plane with the brick (cull, per-row intervals, prefix sums, exact tests, hit queue): ~370 of its 568 vector
-// lane-instructions per sample are that search (profiles/r03_pmc_reconstruct.json, CHANGELOG.md round 3).  Here every sample is visited
-// ONCE by the block that owns its particle, which knows all per-particle constants as wave-uniform values: it evaluates the sample
-// completely (CTF, weights, phase: the three numbers that get scattered) and appends a 16-byte record {key, re, im, weight} to the
-// list of the brick that owns the sample's base voxel.  The brick kernel then reads its list with coalesced 16-byte loads and does
-// nothing but the trilinear scatter into LDS.
-//   k_rec_count   block = particle: LDS histogram of its samples over the bricks -> global list sizes (one atomic per touched brick)
-//   k_rec_scan    one block: exclusive scan of the list sizes, the work items (list segments of <= SEG records) of the brick kernel
-//   k_rec_fill    block = particle: reserves its run in every list it touches (one atomic per brick), writes the records
-//   k_rec_insert  block = list segment: brick in LDS (64-bit fixed point as in k_insert_bricks), records -> 24 LDS atomics each
-// key = kx (7 bits) | ky + 128 (8 bits) << 7 | symmetry operator (3 bits) << 15 | particle of the chunk (14 bits) << 18: boxes up to
-// 256, at most 8 operators and 16 384 particles per chunk; anything else takes k_insert_bricks.
-// Ownership is decided by ONE expression (rec_position + floor) in all four kernels, so a record always lands inside its brick.
-struct RecP {
-    const float2 *band; const PartIns *pp; const float *symops; int nsym;
-    int N, B, W, H, n_img; float r2;
-    int nbx, nby, nlists;          // bricks along x, along y / z; lists = 2 halves x bricks
-    unsigned *count;               // [nlists] list sizes (k_rec_count)
-    unsigned *base;                // [nlists + 1] exclusive scan (k_rec_scan)
-    unsigned *cursor;              // [nlists] next free record of every list (k_rec_fill)
-    unsigned *item_base;           // [nlists + 1] first work item of every list; item_base[nlists] = number of items
-    float4 *rec;                   // the records, list after list
-    float *mat6;                   // [n_img][kRecOps][6] first two columns of S M per (particle, operator)
-    unsigned *maxima;              // [0] bits of max |re|, |im| over the records, [1] bits of max weight (floats >= 0)
-    float *acc;
-    unsigned seg;                  // records per work item
-};
-
-constexpr int kRecOps = 8;       // operators the key's 3-bit field can name
-__device__ __forceinline__ float rec_pos(float u, float v, int kx, int ky) { return __fmaf_rn(u, (float)kx, __fmul_rn(v, (float)ky)); }
-
-// the list a sample of operator (a0 .. c1) falls into: half * nbricks + brick of its base voxel; also the reflected position
-template <int BE>
-__device__ __forceinline__ int rec_brick(const float *m6, int kx, int ky, int N, int nbx, int nby, float &X, float &Y, float &Z, bool &refl) {
-    X = rec_pos(m6[0], m6[1], kx, ky); Y = rec_pos(m6[2], m6[3], kx, ky); Z = rec_pos(m6[4], m6[5], kx, ky);
-    refl = X < 0.f;
-    if (refl) { X = -X; Y = -Y; Z = -Z; }
-    const int x0 = (int)floorf(X), y0 = (int)floorf(Y) + N / 2, z0 = (int)floorf(Z) + N / 2;
-    return ((z0 / BE) * nby + (y0 / BE)) * nbx + (x0 / BE);
-}
-
-template <int BE>
-__global__ void __launch_bounds__(256) k_rec_count(RecP P) {
-    extern __shared__ unsigned hist[];             // [nbricks]
-    __shared__ float m6[8][6];
-    const int p = blockIdx.x, tid = threadIdx.x, nbricks = P.nbx * P.nby * P.nby;
-    const PartIns &q = P.pp[p];
-    if (tid < P.nsym) {
-        const float *S = P.symops + tid * 9;
-        float *m = m6[tid];
-        m[0] = S[0] * q.m[0] + S[1] * q.m[2] + S[2] * q.m[4]; m[1] = S[0] * q.m[1] + S[1] * q.m[3] + S[2] * q.m[5];
-        m[2] = S[3] * q.m[0] + S[4] * q.m[2] + S[5] * q.m[4]; m[3] = S[3] * q.m[1] + S[4] * q.m[3] + S[5] * q.m[5];
-        m[4] = S[6] * q.m[0] + S[7] * q.m[2] + S[8] * q.m[4]; m[5] = S[6] * q.m[1] + S[7] * q.m[3] + S[8] * q.m[5];
-        for (int k = 0; k < 6; k++) P.mat6[((size_t)p * kRecOps + tid) * 6 + k] = m[k];
-    }
-    if (!q.valid) return;                          // block-uniform
-    for (int i = tid; i < nbricks; i += 256) hist[i] = 0u;
-    __syncthreads();
-    const int HW = P.H * P.W;
-    for (int i = tid; i < HW; i += 256) {
-        const int row = i / P.W, kx = i - row * P.W, ky = row - P.B;
-        const float k2 = (float)(kx * kx + ky * ky);
-        if (!(k2 < P.r2) || k2 == 0.f) continue;
-        for (int so = 0; so < P.nsym; so++) {
-            float X, Y, Z; bool refl;
-            atomicAdd(&hist[rec_brick<BE>(m6[so], kx, ky, P.N, P.nbx, P.nby, X, Y, Z, refl)], 1u);
-        }
-    }
-    __syncthreads();
-    unsigned *cnt = P.count + (size_t)q.half * nbricks;
-    for (int i = tid; i < nbricks; i += 256) if (hist[i]) atomicAdd(&cnt[i], hist[i]);
-}
-
-// one block of 1024 threads: base = exclusive scan of count; item_base = exclusive scan of ceil(count / seg); cursors zeroed
-__global__ void __launch_bounds__(1024) k_rec_scan(RecP P) {
-    __shared__ unsigned part[1024], part2[1024];
-    const int tid = threadIdx.x, n = P.nlists, per = (n + 1023) / 1024;
-    unsigned s = 0, s2 = 0;
-    for (int k = 0; k < per; k++) { const int i = tid * per + k; if (i < n) { const unsigned c = P.count[i]; s += c; s2 += (c + P.seg - 1) / P.seg; } }
-    part[tid] = s; part2[tid] = s2;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        const unsigned a = tid >= d ? part[tid - d] : 0u, b = tid >= d ? part2[tid - d] : 0u;
-        __syncthreads();
-        part[tid] += a; part2[tid] += b;
-        __syncthreads();
-    }
-    unsigned run = tid ? part[tid - 1] : 0u, run2 = tid ? part2[tid - 1] : 0u;
-    for (int k = 0; k < per; k++) {
-        const int i = tid * per + k;
-        if (i < n) { const unsigned c = P.count[i]; P.base[i] = run; P.item_base[i] = run2; P.cursor[i] = 0u; run += c; run2 += (c + P.seg - 1) / P.seg; }
-    }
-    if (tid == 1023) { P.base[n] = part[1023]; P.item_base[n] = part2[1023]; }
-}
-
-template <int BE>
-__global__ void __launch_bounds__(256) k_rec_fill(RecP P) {
-    extern __shared__ unsigned hist[];             // hist[nbricks], then lbase[nbricks]
-    __shared__ float m6[8][6];
-    const int p = blockIdx.x, tid = threadIdx.x, nbricks = P.nbx * P.nby * P.nby;
-    const PartIns &q = P.pp[p];
-    if (!q.valid) return;
-    unsigned *lbase = hist + nbricks;
-    if (tid < P.nsym * 6) m6[tid / 6][tid % 6] = P.mat6[((size_t)p * kRecOps + tid / 6) * 6 + tid % 6];
-    for (int i = tid; i < nbricks; i += 256) hist[i] = 0u;
-    __syncthreads();
-    const int HW = P.H * P.W;
-    for (int i = tid; i < HW; i += 256) {
-        const int row = i / P.W, kx = i - row * P.W, ky = row - P.B;
-        const float k2 = (float)(kx * kx + ky * ky);
-        if (!(k2 < P.r2) || k2 == 0.f) continue;
-        for (int so = 0; so < P.nsym; so++) {
-            float X, Y, Z; bool refl;
-            atomicAdd(&hist[rec_brick<BE>(m6[so], kx, ky, P.N, P.nbx, P.nby, X, Y, Z, refl)], 1u);
-        }
-    }
-    __syncthreads();
-    const size_t l0 = (size_t)q.half * nbricks;
-    for (int i = tid; i < nbricks; i += 256) {         // this particle's run in every list it touches
-        const unsigned c = hist[i];
-        lbase[i] = c ? P.base[l0 + i] + atomicAdd(&P.cursor[l0 + i], c) : 0u;
-    }
-    __syncthreads();
-    for (int i = tid; i < nbricks; i += 256) hist[i] = 0u;         // now the rank inside the run
-    __syncthreads();
-    const float2 *bandp = P.band + (size_t)p * HW;
-    float vmax = 0.f, wmax = 0.f;
-    const float invN = 1.0f / (float)P.N;
-    for (int i = tid; i < HW; i += 256) {
-        const int row = i / P.W, kx = i - row * P.W, ky = row - P.B;
-        const float k2 = (float)(kx * kx + ky * ky);
-        if (!(k2 < P.r2) || k2 == 0.f) continue;
-        const float2 iv = bandp[i];
-        const float cv = ctf_eval_fast(q.ctf, kx, ky);
-        float w = q.w0 * (q.wexp != 0.f ? expf(q.wexp * k2) : 1.f);
-        if (q.dexp != 0.f) w *= expf(q.dexp * fminf(k2, q.dcap2));
-        float rev = (kx * q.sx + ky * q.sy) * invN; rev -= floorf(rev);
-        const float sn = __sinf(6.283185307179586f * rev), cs = __cosf(6.283185307179586f * rev);
-        const float vr = w * cv * (iv.x * cs - iv.y * sn), vi = w * cv * (iv.x * sn + iv.y * cs), vw = w * cv * cv;
-        vmax = fmaxf(vmax, fmaxf(fabsf(vr), fabsf(vi))); wmax = fmaxf(wmax, vw);
-        for (int so = 0; so < P.nsym; so++) {
-            float X, Y, Z; bool refl;
-            const int b = rec_brick<BE>(m6[so], kx, ky, P.N, P.nbx, P.nby, X, Y, Z, refl);
-            const unsigned slot = lbase[b] + atomicAdd(&hist[b], 1u);
-            const unsigned key = (unsigned)kx | ((unsigned)(ky + 128) << 7) | ((unsigned)so << 15) | ((unsigned)p << 18);
-            P.rec[slot] = make_float4(__uint_as_float(key), vr, refl ? -vi : vi, vw);
-        }
-    }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) { vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64)); wmax = fmaxf(wmax, __shfl_xor(wmax, o, 64)); }
-    if ((tid & 63) == 0) {
-        if (vmax > 0.f && vmax < 3.0e38f) atomicMax(P.maxima, __float_as_uint(vmax));
-        if (wmax > 0.f && wmax < 3.0e38f) atomicMax(P.maxima + 1, __float_as_uint(wmax));
-    }
-}
-
-// grid: upper bound of the number of items (blocks beyond item_base[nlists] leave at once); NW waves
-template <int BE, int NW>
-__global__ void __launch_bounds__(NW * 64) k_rec_insert(RecP P) {
-    extern __shared__ long long brick[];           // [BE+1][BE+1][BE+1][3], strides as in k_insert_bricks
-    constexpr int BH = BE + 1, SY = BH * 3 + 1, SZ = BH * SY + 3;
-    __shared__ int s_list; __shared__ unsigned s_lo, s_hi;
-    const int tid = threadIdx.x, N = P.N;
-    const unsigned item = blockIdx.x;
-    if (item >= P.item_base[P.nlists]) return;
-    if (tid == 0) {                                // the list this item belongs to: last list with item_base <= item
-        int lo = 0, hi = P.nlists;
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (P.item_base[mid] <= item) lo = mid; else hi = mid; }
-        // lists without records share their item_base with the next one: walk on to the one that really starts here
-        while (lo + 1 < P.nlists && P.item_base[lo + 1] <= item) lo++;
-        s_list = lo;
-        const unsigned k = item - P.item_base[lo];
-        s_lo = P.base[lo] + k * P.seg;
-        s_hi = min(P.base[lo + 1], s_lo + P.seg);
-    }
-    for (int i = tid; i < BH * SZ; i += NW * 64) brick[i] = 0ll;
-    __syncthreads();
-    const int list = s_list, nbricks = P.nbx * P.nby * P.nby, h = list / nbricks, b = list - h * nbricks;
-    const int bx = b % P.nbx, by = (b / P.nbx) % P.nby, bz = b / (P.nbx * P.nby);
-    const int x_lo = bx * BE, y_lo = by * BE - N / 2, z_lo = bz * BE - N / 2;
-    float sv, sw;
-    {
-        int ev, ew;
-        const float bv = __uint_as_float(P.maxima[0]), bw = __uint_as_float(P.maxima[1]);
-        (void)frexpf(bv > 0.f ? bv : 1.f, &ev); (void)frexpf(bw > 0.f ? bw : 1.f, &ew);
-        sv = ldexpf(1.f, min(30 - ev, 120)); sw = ldexpf(1.f, min(30 - ew, 120));
-    }
-    for (unsigned r = s_lo + tid; r < s_hi; r += NW * 64) {
-        const float4 rc = P.rec[r];
-        const unsigned key = __float_as_uint(rc.x);
-        const int kx = (int)(key & 127u), ky = (int)((key >> 7) & 255u) - 128;
-        const float *m6 = P.mat6 + (size_t)(key >> 15) * 6;          // key >> 15 = particle * kRecOps + operator: the table's row
-        float X = rec_pos(m6[0], m6[1], kx, ky), Y = rec_pos(m6[2], m6[3], kx, ky), Z = rec_pos(m6[4], m6[5], kx, ky);
-        if (X < 0.f) { X = -X; Y = -Y; Z = -Z; }
-        const float xf = floorf(X), yf = floorf(Y), zf = floorf(Z);
-        const int x0 = (int)xf - x_lo, y0 = (int)yf - y_lo, z0 = (int)zf - z_lo;
-        if ((unsigned)x0 >= (unsigned)BE || (unsigned)y0 >= (unsigned)BE || (unsigned)z0 >= (unsigned)BE) continue;     // cannot happen (same arithmetic as the binning)
-        const float fx = X - xf, fy = Y - yf, fz = Z - zf;
-        const float vr = sv * rc.y, vi = sv * rc.z, vw = sw * rc.w;
-        unsigned long long *const v0 = (unsigned long long *)brick + z0 * SZ + y0 * SY + x0 * 3;
-#pragma unroll
-        for (int dz = 0; dz < 2; dz++)
-#pragma unroll
-            for (int dy = 0; dy < 2; dy++)
-#pragma unroll
-                for (int dx = 0; dx < 2; dx++) {
-                    const float wt = (dx ? fx : 1.f - fx) * (dy ? fy : 1.f - fy) * (dz ? fz : 1.f - fz);
-                    unsigned long long *v = v0 + dz * SZ + dy * SY + dx * 3;
-                    atomicAdd(v, (unsigned long long)(long long)__float2int_rn(wt * vr));
-                    atomicAdd(v + 1, (unsigned long long)(long long)__float2int_rn(wt * vi));
-                    atomicAdd(v + 2, (unsigned long long)(long long)__float2int_rn(wt * vw));
-                }
-    }
-    __syncthreads();
-    const size_t NX = N / 2 + 1;
-    float *A = P.acc + (size_t)h * N * N * NX * 3;
-    for (int i = tid; i < BH * BH * BH * 3; i += NW * 64) {
-        const int x3 = i % (BH * 3), yi = (i / (BH * 3)) % BH, zi = i / (BH * BH * 3);
-        const long long vq = brick[zi * SZ + yi * SY + x3];
-        if (vq == 0ll) continue;
-        const int gy = y_lo + yi + N / 2, gz = z_lo + zi + N / 2;
-        if (x_lo * 3 + x3 >= (int)NX * 3 || gy >= N || gz >= N) continue;
-        float *o = A + (((size_t)gz * N + gy) * NX + x_lo) * 3 + x3;
-        atomicAdd(o, (float)((double)vq / (double)(i % 3 == 2 ? sw : sv)));
-    }
-}
-
 // ---------------------------------------------------------------------------------- matching projections
 // refine3d answers 8 / 43 (frealign.py:3929-3931, refine_fmatch): the reference projected at a row's pose, times the row's CTF,
 // moved to the particle's position — the noise-free model of the stored particle image.  One thread per entry of the full

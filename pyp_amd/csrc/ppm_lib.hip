@@ -168,8 +168,6 @@ static int fft_lines_pass(float2 *d, int n, long nlines, long inner, long inner_
     return 0;
 }
 
-constexpr bool kInsertRecordsDefault = false;      // PPM_INSERT_PATH=records selects the record-binned insertion where it applies
-
 template <typename T>
 struct DevBuf {
     T *p = nullptr; size_t cap = 0;
@@ -237,7 +235,6 @@ struct ppm_accum {
     long counts[2] = { 0, 0 };
     DevBuf<double> rows; DevBuf<float> images, dose; DevBuf<float2> band, spill; DevBuf<PartIns> pp; DevBuf<CullEnt> cull; DevBuf<BrickItem> items;
     DevBuf<float2> s_f, s_g; DevBuf<float> s_vols;      // ppm_sva_insert: the transforms' work arrays and staged host volumes
-    DevBuf<float4> rec; DevBuf<float> mat6; DevBuf<unsigned> rlists;      // record-binned insertion (k_rec_*): records, operator table, list tables
     std::vector<float> brick_load; float load_r = -1.f; int n_items = 0, items_cap = -1;
 };
 
@@ -1019,11 +1016,7 @@ ppm_accum_t *ppm_accum_create(int box, float pixel_size, const char *symmetry, v
     HIPCHKP(hipMalloc(&a->d_max, 2 * sizeof(unsigned)));
     static bool attr_set = false;
     std::lock_guard<std::mutex> lk_attr(g_mu);
-    if (!attr_set) {
-        HIPCHKP(hipFuncSetAttribute((const void *)k_insert_bricks<16, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 17 * (17 * 52 + 3) * 8));
-        HIPCHKP(hipFuncSetAttribute((const void *)k_rec_insert<16, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 17 * (17 * 52 + 3) * 8));
-        attr_set = true;
-    }
+    if (!attr_set) { HIPCHKP(hipFuncSetAttribute((const void *)k_insert_bricks<16, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 17 * (17 * 52 + 3) * 8)); attr_set = true; }
     return guard.release();
 }
 
@@ -1033,7 +1026,7 @@ void ppm_accum_destroy(ppm_accum_t *a) {
     if (a->d_sym) (void)hipFree(a->d_sym);
     if (a->d_counts) (void)hipFree(a->d_counts);
     if (a->d_max) (void)hipFree(a->d_max);
-    a->rows.release(); a->images.release(); a->dose.release(); a->band.release(); a->spill.release(); a->s_f.release(); a->s_g.release(); a->s_vols.release(); a->rec.release(); a->mat6.release(); a->rlists.release(); a->pp.release(); a->cull.release(); a->items.release();
+    a->rows.release(); a->images.release(); a->dose.release(); a->band.release(); a->spill.release(); a->s_f.release(); a->s_g.release(); a->s_vols.release(); a->pp.release(); a->cull.release(); a->items.release();
     if (a->stream) (void)hipStreamDestroy(a->stream);
     if (a->copy) (void)hipStreamDestroy(a->copy);
     delete a;
@@ -1053,18 +1046,6 @@ int ppm_insert_batch(ppm_accum_t *a, const ppm_recon_cfg *cfg, const void *image
     const size_t chunk_gb = getenv("PPM_INSERT_GB") ? (size_t)std::max(1, atoi(getenv("PPM_INSERT_GB"))) : 8;
     int CH = (int)std::min<size_t>((size_t)n_img, std::max<size_t>(32, (chunk_gb << 30) / (NN * 4 + HW * 8)));
     CH = std::min(CH, 32768);
-    // record-binned insertion (k_rec_*, ppm_kernels2.h): boxes up to 256, at most 8 operators, 16 384 particles per chunk, and the
-    // records of a chunk (16 bytes per sample and operator) within PPM_INSERT_REC_GB (default 24); PPM_INSERT_PATH=bricks | records
-    long S_band = 0;
-    for (int ky = -gm.B; ky <= gm.B; ky++) for (int kx = 0; kx <= gm.B; kx++) { const double k2 = (double)kx * kx + (double)ky * ky; if (k2 > 0 && k2 < gm.r_hi * gm.r_hi) S_band++; }
-    const char *path_env = getenv("PPM_INSERT_PATH");
-    bool records = gm.N <= 256 && gm.B <= 127 && a->nsym <= kRecOps && !(path_env && !strcmp(path_env, "bricks"));
-    if (!(path_env && !strcmp(path_env, "records"))) records = records && kInsertRecordsDefault;
-    if (records) {
-        const size_t rec_gb = getenv("PPM_INSERT_REC_GB") ? (size_t)std::max(1, atoi(getenv("PPM_INSERT_REC_GB"))) : 24;
-        CH = std::min(CH, 16384);
-        CH = (int)std::min<size_t>((size_t)CH, std::max<size_t>(32, (rec_gb << 30) / ((size_t)S_band * a->nsym * 16)));
-    }
     if (const char *e = std::getenv("PPM_CHUNK")) { int v = std::atoi(e); if (v > 0) CH = std::min(CH, v); }   // tests: force several chunks
     if (int r = a->rows.ensure((size_t)CH * PPM_NCOL)) return r;
     if (!images_on_device) if (int r = a->images.ensure((size_t)2 * CH * NN)) return r;       // double-buffered staging
@@ -1097,33 +1078,6 @@ int ppm_insert_batch(ppm_accum_t *a, const ppm_recon_cfg *cfg, const void *image
                            (double)cfg->score_weight_bfactor, (double)cfg->score_average, (double)cfg->score_threshold, cfg->split_by_pind,
                            gm.r_hi * gm.r_hi, a->d_counts, a->d_max, d_dose, cfg->n_dose_weights, cfg->dose_exponent, dose_cap2);
         const int BE = gm.N >= 128 ? 16 : 8;
-        if (records) {
-            const int nbx = (gm.N / 2 + 1 + BE - 1) / BE, nby = (gm.N + BE - 1) / BE, nbricks = nbx * nby * nby, nlists = 2 * nbricks;
-            const size_t nrec = (size_t)nb * a->nsym * (size_t)S_band;
-            if (int r = a->rec.ensure(nrec)) return r;
-            if (int r = a->mat6.ensure((size_t)nb * kRecOps * 6)) return r;
-            if (int r = a->rlists.ensure((size_t)4 * (nlists + 1))) return r;
-            RecP RP;
-            RP.band = a->band.p; RP.pp = a->pp.p; RP.symops = a->d_sym; RP.nsym = a->nsym; RP.N = gm.N; RP.B = gm.B; RP.W = gm.W; RP.H = gm.H; RP.n_img = nb;
-            RP.r2 = (float)(gm.r_hi * gm.r_hi); RP.nbx = nbx; RP.nby = nby; RP.nlists = nlists;
-            RP.count = a->rlists.p; RP.base = RP.count + (nlists + 1); RP.cursor = RP.base + (nlists + 1); RP.item_base = RP.cursor + (nlists + 1);
-            RP.rec = a->rec.p; RP.mat6 = a->mat6.p; RP.maxima = a->d_max; RP.acc = a->acc;
-            RP.seg = getenv("PPM_INSERT_SEG") ? (unsigned)std::max(1024, atoi(getenv("PPM_INSERT_SEG"))) : 32768u;
-            HIPCHK(hipMemsetAsync(RP.count, 0, (size_t)(nlists + 1) * sizeof(unsigned), cur_stream()));
-            const unsigned grid_ub = (unsigned)((nrec + RP.seg - 1) / RP.seg) + (unsigned)nlists;
-            ProfScope ps(PPM_K_INSERT);
-            if (BE == 16) {
-                hipLaunchKernelGGL((k_rec_count<16>), dim3(nb), dim3(256), (size_t)nbricks * sizeof(unsigned), cur_stream(), RP);
-                hipLaunchKernelGGL(k_rec_scan, dim3(1), dim3(1024), 0, cur_stream(), RP);
-                hipLaunchKernelGGL((k_rec_fill<16>), dim3(nb), dim3(256), (size_t)2 * nbricks * sizeof(unsigned), cur_stream(), RP);
-                hipLaunchKernelGGL((k_rec_insert<16, 16>), dim3(grid_ub), dim3(1024), 17 * (17 * 52 + 3) * sizeof(long long), cur_stream(), RP);
-            } else {
-                hipLaunchKernelGGL((k_rec_count<8>), dim3(nb), dim3(256), (size_t)nbricks * sizeof(unsigned), cur_stream(), RP);
-                hipLaunchKernelGGL(k_rec_scan, dim3(1), dim3(1024), 0, cur_stream(), RP);
-                hipLaunchKernelGGL((k_rec_fill<8>), dim3(nb), dim3(256), (size_t)2 * nbricks * sizeof(unsigned), cur_stream(), RP);
-                hipLaunchKernelGGL((k_rec_insert<8, 4>), dim3(grid_ub), dim3(256), 9 * (9 * 28 + 3) * sizeof(long long), cur_stream(), RP);
-            }
-        } else {
         if (int r = build_brick_items(a, gm, BE, nb)) return r;
         InsertBrickP IP;
         IP.band = a->band.p; IP.pp = a->pp.p; IP.cull = a->cull.p; IP.symops = a->d_sym; IP.nsym = a->nsym; IP.acc = a->acc;
@@ -1134,7 +1088,6 @@ int ppm_insert_batch(ppm_accum_t *a, const ppm_recon_cfg *cfg, const void *image
             dim3 grid((unsigned)a->n_items, 2);
             if (BE == 16) hipLaunchKernelGGL((k_insert_bricks<16, 16>), grid, dim3(1024), 17 * (17 * 52 + 3) * sizeof(long long), cur_stream(), IP);
             else hipLaunchKernelGGL((k_insert_bricks<8, 4>), grid, dim3(256), 9 * (9 * 28 + 3) * sizeof(long long), cur_stream(), IP);
-        }
         }
         HIPCHK(hipGetLastError());
         if (!images_on_device && c0 + CH < n_img) {

@@ -843,42 +843,3 @@ def test_classification_limit_moves_logp_and_sigma_like_the_oracle(H, O, kw):
     # a limit at or beyond res_high is the full band
     g2 = g.refine(cfg_for(n, px, res_classification=1.0, **kw), imgs, rows)
     assert np.array_equal(g2, g0)
-
-
-@pytest.mark.parametrize("n,px,m,sym,extra", [(64, 2.0, 40, "C1", {}), (64, 2.0, 40, "D2", {}), (256, 1.0, 24, "C1", {}), (96, 1.5, 16, "C2", {}),
-                                              (128, 2.0, 600, "C4", {"PPM_CHUNK": "160", "PPM_INSERT_SEG": "4096"}), (50, 2.5, 10, "C1", {}),
-                                              (64, 2.0, 30, "O", {})])
-def test_record_binned_insertion_matches_oracle(H, O, monkeypatch, n, px, m, sym, extra):
-    """PPM_INSERT_PATH=records (k_rec_count / k_rec_scan / k_rec_fill / k_rec_insert): every sample visited once, appended as a 16-byte
-    record to the list of the brick that owns it, the bricks fed from the lists - same accumulators as the oracle (and as the brick
-    search of k_insert_bricks): score weighting, occupancy, PIND halves, a rejected particle, dose weighting, several chunks and list
-    segments, boxes of both brick sizes.  Point groups with more than 8 operators (O) take k_insert_bricks as before."""
-    monkeypatch.setenv("PPM_INSERT_PATH", "records")
-    for k, v in extra.items():
-        monkeypatch.setenv(k, v)
-    vol, imgs, rows = dataset(n, min(m, 40), px, 0.2)
-    if m > imgs.shape[0]:
-        rep = (m + imgs.shape[0] - 1) // imgs.shape[0]
-        imgs = np.concatenate([imgs] * rep)[:m]; rows = np.concatenate([rows] * rep)[:m].copy()
-        rows[:, 0] = np.arange(1, m + 1)
-    rows[:, 26] = np.arange(m) // 2
-    rows[:, 14] = np.linspace(5, 35, m)
-    rows[3, 11] = 0.0
-    rows[:, 27] = np.arange(m) % 5
-    from pyp_amd import dose
-    rc = ReconCfg(box=n, pixel_size=px, res_limit=2 * px, score_weight_bfactor=2.0, score_average=20.0, score_threshold=0.0,
-                  normalize=1, invert=0, split_by_pind=1, mask_radius=0.4 * n * px)
-    rc.set_dose_weights(dose.normalised(dose.compute_global_weights(rows)), 3.0, 0.8)
-    acc = np.zeros(O.accum_floats(n), dtype=np.float32)
-    counts = np.zeros(2, dtype=np.int64)
-    O.insert_batch(acc, counts, rc, sym, imgs, rows)
-    ga = H.Accumulator(n, px, sym)
-    ga.insert(rc, imgs[: m // 2], rows[: m // 2])
-    ga.insert(rc, imgs[m // 2:], rows[m // 2:])
-    assert ga.counts() == list(counts)
-    got = ga.download()
-    assert np.linalg.norm(got - acc) / np.linalg.norm(acc) < 1e-4
-    monkeypatch.setenv("PPM_INSERT_PATH", "bricks")
-    gb = H.Accumulator(n, px, sym)
-    gb.insert(rc, imgs, rows)
-    assert np.linalg.norm(gb.download() - got) / np.linalg.norm(got) < 2e-5          # the two device paths agree more closely than either with the oracle's doubles
