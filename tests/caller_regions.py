@@ -1,4 +1,5 @@
-"""Region-based ("patch") constrained refinement, the caller's side: a tilt series is cut into a
+"""(Test infrastructure: the CALLER's side of region-based refinement, restated so that tests can drive bin/csp the way PYP does; nothing in pyp_amd imports it.)
+Region-based ("patch") constrained refinement, the caller's side: a tilt series is cut into a
 grid of regions, every region gets its own parameter file whose tilts are refined on the region's particles only, and `csp`
 is started once per (region, particle) or (region, tilt).  numpy restatement of
 
@@ -13,12 +14,13 @@ region files byte for byte and every command line are the reference's own output
 Particle blocks are [P, 12] arrays in `cistem.PARTICLE_COLUMNS` order (3-D position in columns 7-9), tilt blocks [T, 6] in
 `cistem.TILT_COLUMNS` order (TIND, RIND, shift x, shift y, angle, axis).
 """
+
 import math
 import os
 
 import numpy as np
 
-from .formats import cistem
+from pyp_amd.formats import cistem
 
 C = cistem.COL
 

@@ -185,7 +185,7 @@ def test_region_split_2x2x1_end_to_end_like_the_caller(tmp_path):
     region's rows.  A frame list (`frames_csp.txt`) feeds the same extraction as the tilt-series file."""
     import fnmatch
     from oracle import oracle as O
-    from pyp_amd import regions
+    import caller_regions as regions
     from pyp_amd.surface import csp_cli
     n, px = 64, 2.0
     vol, stack, rows, parts, tilts = synth.make_tilt_series(n, 6, np.arange(-40, 41, 20.0), pixel=px, snr=0.3, seed=11)

@@ -1,4 +1,4 @@
-"""Region-based constrained refinement, caller side (pyp_amd/regions.py) against the reference's own output on a toy tilt series
+"""Region-based constrained refinement, caller side (tests/caller_regions.py) against the reference's own output on a toy tilt series
 (tests/golden/gen_golden_r03.py: findSpecimenBounds, divide2regions, sort_particles_regions, split_parameter_file,
 create_csp_split_commands run in the build container)."""
 import json
@@ -6,7 +6,7 @@ import os
 
 import numpy as np
 
-from pyp_amd import regions
+import caller_regions as regions
 from pyp_amd.formats import cistem
 
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
