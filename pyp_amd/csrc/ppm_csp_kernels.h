@@ -12,6 +12,7 @@ namespace ppm {
 struct CspEvalP {
     CubeView cv; const uint32_t *samples; const float2 *Il; const float *cw;
     int S_pad, N, nr; float rlo2, ring_signed;
+    int tabR;                             // radius of the LDS address tables (k_csp_eval<true>)
     int S_used; float rmax2;              // band of this sweep (frequency marching)
     int kind, ncand;                      // PPM_CSP_PARTICLES / PPM_CSP_MICROGRAPHS; candidates per unit (<= kMaxCand)
     const int *eval_rows;                 // [grid] row evaluated by each block
@@ -51,6 +52,7 @@ __device__ inline void d_csp_row_pose(const double *N, const double *p, double t
 // Block = one projection row, 256 threads: thread q < ncand derives candidate q's row pose in double precision; the
 // candidates that keep the unit's rotation share one gather group (shift variants), every rotated candidate is a group
 // of its own; one sweep (sweep_plan) scores them all.
+template <bool TAB>
 __global__ void __launch_bounds__(256, 4) k_csp_eval(CspEvalP P) {
     __shared__ SweepPlan plan;
     extern __shared__ float lsm[];
@@ -107,7 +109,8 @@ __global__ void __launch_bounds__(256, 4) k_csp_eval(CspEvalP P) {
     SC.cv = P.cv; SC.samples = P.samples; SC.Il = P.Il + (size_t)j * P.S_pad; SC.cw = P.cw + (size_t)j * P.S_pad;
     SC.invN = 1.0f / (float)P.N; SC.rlo2 = P.rlo2; SC.ring_signed = P.ring_signed; SC.nr = nr; SC.nw = nw;
     SC.ringA = lsm; SC.sumB = lsm + kMaxCand * nw * nr; SC.sumC = SC.sumB + kMaxCand * nw; SC.score = score;
-    sweep_plan(plan, SC, tid, nthr);
+    if constexpr (TAB) SC.tab = cube_tab_fill(P.cv, (char *)lsm + ring_lds_bytes8(nw, kMaxCand, nr), P.tabR, tid, nthr);
+    sweep_plan<TAB>(plan, SC, tid, nthr);
     if (tid < ncand) P.out[(size_t)blockIdx.x * ncand + tid] = score[cslot[tid]];
 }
 

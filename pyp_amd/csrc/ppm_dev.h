@@ -242,6 +242,11 @@ __host__ __device__ __forceinline__ size_t cube_element(int NBX, int NBY, unsign
 // gathers of the NEXT evaluation can be in flight while the current one is interpolated and scored (k_local).
 struct CubeTaps { float4 a, b, c, d; float fx, fy, fz; bool cj; };
 
+typedef float cube_v4f __attribute__((ext_vector_type(4)));
+
+// The four 16-byte x-pairs come through BUFFER loads: one 32-bit byte offset per load against a wave-uniform resource descriptor
+// (the cube's base and size in SGPRs) instead of a 64-bit address per lane and load - the address arithmetic of a gather drops from
+// ~20 vector instructions to ~8, and an offset beyond the cube reads zeros instead of faulting.
 __device__ __forceinline__ CubeTaps cube_fetch(const CubeView &cv, float X, float Y, float Z) {
     CubeTaps t;
     X *= cv.scale; Y *= cv.scale; Z *= cv.scale;
@@ -252,15 +257,65 @@ __device__ __forceinline__ CubeTaps cube_fetch(const CubeView &cv, float X, floa
     const int x0 = (int)xf, y0 = (int)yf + cv.off, z0 = (int)zf + cv.off;
     const bool second = (x0 & 3) == 3;
     const int xs = second ? x0 - 2 : x0;
-    // brick counts and element offsets stay below 2^24: 24-bit multiplies (full rate; v_mul_lo_u32 issues at a quarter of it)
-    const unsigned rowb = (unsigned)cv.NBX * 16u, planeb = __umul24(rowb, (unsigned)cv.NBY);
-    const unsigned xl = (unsigned)(xs >> 2) * 16u + (unsigned)(xs & 3) + (second ? cv.LB : 0u);
-    const unsigned yl0 = __umul24((unsigned)(y0 >> 1), rowb) + (unsigned)(y0 & 1) * 4u, yl1 = (y0 & 1) ? yl0 + rowb - 4u : yl0 + 4u;
-    const unsigned zl0 = __umul24((unsigned)(z0 >> 1), planeb) + (unsigned)(z0 & 1) * 8u, zl1 = (z0 & 1) ? zl0 + planeb - 8u : zl0 + 8u;
-    const float2 *pa = cv.cube + (xl + yl0 + zl0), *pb = cv.cube + (xl + yl1 + zl0), *pc = cv.cube + (xl + yl0 + zl1), *pd = cv.cube + (xl + yl1 + zl1);
-    const float2 a0 = pa[0], a1 = pa[1], b0 = pb[0], b1 = pb[1], c0 = pc[0], c1 = pc[1], d0 = pd[0], d1 = pd[1];
-    t.a = make_float4(a0.x, a0.y, a1.x, a1.y); t.b = make_float4(b0.x, b0.y, b1.x, b1.y);
-    t.c = make_float4(c0.x, c0.y, c1.x, c1.y); t.d = make_float4(d0.x, d0.y, d1.x, d1.y);
+    // byte offsets; brick counts and offsets stay below 2^24 elements: 24-bit multiplies (full rate; v_mul_lo_u32 issues at a quarter of it)
+    const unsigned rowb = (unsigned)cv.NBX * 128u, planeb = __umul24(rowb, (unsigned)cv.NBY);
+    const unsigned xl = (unsigned)(xs >> 2) * 128u + (unsigned)(xs & 3) * 8u + (second ? cv.LB * 8u : 0u);
+    const unsigned yl0 = __umul24((unsigned)(y0 >> 1), rowb) + (unsigned)(y0 & 1) * 32u, dy = (y0 & 1) ? rowb - 32u : 32u;
+    const unsigned zl0 = __umul24((unsigned)(z0 >> 1), planeb) + (unsigned)(z0 & 1) * 64u, dz = (z0 & 1) ? planeb - 64u : 64u;
+    const unsigned oa = xl + yl0 + zl0, ob = oa + dy, oc = oa + dz, od = ob + dz;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)cv.cube, 0, (int)(2u * cv.LB * 8u), 0x00020000);
+    const cube_v4f a = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)oa, 0, 0), b = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)ob, 0, 0);
+    const cube_v4f c = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)oc, 0, 0), d = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)od, 0, 0);
+    t.a = make_float4(a.x, a.y, a.z, a.w); t.b = make_float4(b.x, b.y, b.z, b.w);
+    t.c = make_float4(c.x, c.y, c.z, c.w); t.d = make_float4(d.x, d.y, d.z, d.w);
+    return t;
+}
+
+// ---- address tables (k_local / k_csp_eval): the byte offset of a tap is separable, o = ox(x0) + oy(y0) + oz(z0), and the steps to the
+// y + 1 / z + 1 taps depend on y0 / z0 alone.  Three small LDS tables (filled once per block) replace ~25 vector instructions of
+// shifts, masks, multiplies and selects per gather by three LDS reads and four adds.  Tables cover |coordinate| <= R (in cube
+// voxels, from the band and the padding factor); entry layout: ty0[yi] = (offset of row y0 = yi + off, step to y0 + 1).
+struct CubeTab { const uint2 *ty0, *tz0; const unsigned *tx0; };
+__host__ __device__ inline int cube_tab_radius(int band_px, float scale) { return (int)ceilf((float)(band_px + 2) * scale) + 2; }
+__host__ __device__ inline size_t cube_tab_bytes(int R) { return R > 0 ? (size_t)2 * (2 * R + 2) * 8 + (size_t)(R + 2) * 4 : 0; }
+__device__ inline CubeTab cube_tab_fill(const CubeView &cv, void *mem, int R, int tid, int nthr) {
+    uint2 *ty = (uint2 *)mem, *tz = ty + (2 * R + 2);
+    unsigned *tx = (unsigned *)(tz + (2 * R + 2));
+    const unsigned rowb = (unsigned)cv.NBX * 128u, planeb = rowb * (unsigned)cv.NBY;
+    for (int i = tid; i < 2 * R + 2; i += nthr) {
+        const int y0 = i - (R + 1) + cv.off;           // below 0 only where no sample of the band lands: the offset wraps and the load returns zeros
+        ty[i] = make_uint2((unsigned)(y0 >> 1) * rowb + (unsigned)(y0 & 1) * 32u, (y0 & 1) ? rowb - 32u : 32u);
+        tz[i] = make_uint2((unsigned)(y0 >> 1) * planeb + (unsigned)(y0 & 1) * 64u, (y0 & 1) ? planeb - 64u : 64u);
+    }
+    for (int x0 = tid; x0 < R + 2; x0 += nthr) {
+        const bool second = (x0 & 3) == 3;
+        const int xs = second ? x0 - 2 : x0;
+        tx[x0] = (unsigned)(xs >> 2) * 128u + (unsigned)(xs & 3) * 8u + (second ? cv.LB * 8u : 0u);
+    }
+    CubeTab t; t.ty0 = ty + (R + 1); t.tz0 = tz + (R + 1); t.tx0 = tx;
+    return t;
+}
+
+__device__ __forceinline__ int floor_to_int(float x) { int i; asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(i) : "v"(x)); return i; }
+
+// cube_fetch for coordinates that already carry the padding factor, through the address tables
+__device__ __forceinline__ CubeTaps cube_fetch_tab(const CubeView &cv, const CubeTab &tb, float X, float Y, float Z) {
+    CubeTaps t;
+    t.cj = X < 0.f;
+    if (t.cj) { X = -X; Y = -Y; Z = -Z; }
+    t.fx = __builtin_amdgcn_fractf(X); t.fy = __builtin_amdgcn_fractf(Y); t.fz = __builtin_amdgcn_fractf(Z);
+    const unsigned xl = tb.tx0[floor_to_int(X)];
+    const uint2 ey = tb.ty0[floor_to_int(Y)], ez = tb.tz0[floor_to_int(Z)];
+#ifdef PPM_DBG_SMALLCUBE
+    const unsigned oa = (xl + ey.x + ez.x) & 0x3ff0u, ob = (oa + ey.y) & 0x3ff0u, oc = (oa + ez.y) & 0x3ff0u, od = (ob + ez.y) & 0x3ff0u;
+#else
+    const unsigned oa = xl + ey.x + ez.x, ob = oa + ey.y, oc = oa + ez.y, od = ob + ez.y;
+#endif
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)cv.cube, 0, (int)(2u * cv.LB * 8u), 0x00020000);
+    const cube_v4f a = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)oa, 0, 0), b = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)ob, 0, 0);
+    const cube_v4f c = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)oc, 0, 0), d = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)od, 0, 0);
+    t.a = make_float4(a.x, a.y, a.z, a.w); t.b = make_float4(b.x, b.y, b.z, b.w);
+    t.c = make_float4(c.x, c.y, c.z, c.w); t.d = make_float4(d.x, d.y, d.z, d.w);
     return t;
 }
 

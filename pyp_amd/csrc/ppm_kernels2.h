@@ -81,6 +81,7 @@ struct LocalP {
     CubeView cv; const uint32_t *samples; const float2 *Il; const float *cw;
     int S_pad, nrings, N;
     int nr;                // rings this launch can touch (<= nrings): sizes the per-wave ring sums in dynamic LDS
+    int tabR;              // radius of the LDS address tables (k_local<true>; ppm_dev.h)
     float rlo2, ring_signed;
     LState *states; int T, final_rescore; int en[5];
     // frequency marching: band (squared) and sample-list prefix of every iteration, and of the final score
@@ -119,8 +120,12 @@ __device__ __forceinline__ float group16_sum_dpp(float v) {
 }
 
 // A sweep evaluates `ng` gather groups; group g = one rotation (6 floats) with nv[g] shift variants, the
-// scores of which go to consecutive slots starting at slot0[g].
-struct SweepPlan { float m[kMaxGroup][6]; float sh[kMaxCand][2]; int nv[kMaxGroup]; int slot0[kMaxGroup]; int ng, nslots, S_used, q_same; float rmax2; };   // slots 0 .. q_same use the shift sh[0]
+// scores of which go to consecutive slots starting at slot0[g].  ms / bsl are filled by sweep_plan itself.
+struct SweepPlan {
+    float m[kMaxGroup][6]; float sh[kMaxCand][2]; int nv[kMaxGroup]; int slot0[kMaxGroup]; int ng, nslots, S_used, q_same; float rmax2;   // slots 0 .. q_same use the shift sh[0]
+    float ms[kMaxGroup][6];      // m times the cube's padding factor
+    int bsl[kMaxCand];           // slot whose model-power sum serves slot q (the first slot of q's group: |model|^2 does not depend on the shift)
+};
 
 // sum over aligned groups of 8 lanes (double), every lane of the group gets the total; fixed combination order
 __device__ __forceinline__ double group8_sum_d(double v) {
@@ -130,26 +135,46 @@ __device__ __forceinline__ double group8_sum_d(double v) {
 
 // dynamic LDS of k_local / k_defocus for `nw` waves, `nq` score slots and `nr` rings
 __host__ __device__ inline size_t ring_lds_bytes(int nw, int nq, int nr) { return ((size_t)nq * nw * nr + (size_t)nq * nw + nw) * sizeof(float); }
+__host__ __device__ inline size_t ring_lds_bytes8(int nw, int nq, int nr) { return (ring_lds_bytes(nw, nq, nr) + 7) & ~(size_t)7; }     // where the address tables start
 
 // Context of a sweep that does not change between sweeps of one block
 struct SweepCtx {
     CubeView cv; const uint32_t *samples; const float2 *Il; const float *cw;
     float invN, rlo2, ring_signed; int nr, nw;
     float *ringA, *sumB, *sumC; double *score;     // LDS: per-wave ring tables (ring_lds_bytes) and the slot scores
+    CubeTab tab;                                   // LDS address tables (TAB = true)
 };
 
 // One sweep over the ring-ordered sample list for the poses of `plan` (in LDS): scores of all slots -> C.score[].
 // All threads of the block call.  Shared by k_local (single-image compass search) and k_csp_eval (constrained search).
-__device__ __forceinline__ void sweep_plan(const SweepPlan &plan, const SweepCtx &C, const int tid, const int nthr) {
+//
+// Per sample and rotation the kernel issues ~75 vector instructions (round 3: ~150; the ISA was counted, CHANGELOG.md round 4):
+//  * the image value is turned by the conjugate phase of the shift ONCE per sample (and slot, for shifted slots) and carries the
+//    CTF weight, so a score term is Re(conj(b) v) = two instructions on the RAW interpolated value v instead of a complex rotation;
+//  * the gathers of the next rotation are issued into a second register set (A / B ping-pong, the loop is unrolled by two): no
+//    register copies between "next" and "current";
+//  * slot numbers and the LDS cells of a group are wave-uniform and kept in scalar registers;
+//  * tap addresses come from the LDS tables of ppm_dev.h (TAB), coordinates are pre-multiplied by the padding factor;
+//  * the model power |c v|^2 goes to ONE LDS cell per group (bsl), not to one per slot.
+template <bool TAB>
+__device__ __forceinline__ void sweep_plan(SweepPlan &plan, const SweepCtx &C, const int tid, const int nthr) {
     const int lane = tid & 63, wave = tid >> 6, nw = C.nw, nr = C.nr;
     float *const ringA = C.ringA, *const sumB = C.sumB, *const sumC = C.sumC; double *const score = C.score;
     const float2 *const Il = C.Il; const float *const cw = C.cw; const float invN = C.invN;
+#ifdef PPM_DBG_NOSWEEP
+    const int nslots = plan.nslots, ng = plan.ng, S_used = 0;
+#else
     const int nslots = plan.nslots, ng = plan.ng, S_used = plan.S_used;
+#endif
     const float rmax2 = plan.rmax2;
     for (int i = tid; i < nslots * nw * nr; i += nthr) ringA[i] = 0.f;
     if (tid < kMaxCand * nw) sumB[tid] = 0.f;
+    if (tid < ng * 6) (&plan.ms[0][0])[tid] = (&plan.m[0][0])[tid] * C.cv.scale;
+    if (tid >= 64 && tid < 64 + ng) { const int g = tid - 64, q0 = plan.slot0[g]; for (int v = 0; v < plan.nv[g]; v++) plan.bsl[q0 + v] = q0; }
     __syncthreads();
     float *const myA = ringA + wave * nr, *const myB = sumB + wave;
+    const int q_same = plan.q_same, strideA = nw * nr;
+    const bool head = (lane & 15) == 0;
     float accC = 0.f;
     for (int s0 = 0; s0 < S_used; s0 += nthr) {
         const int s = s0 + tid;
@@ -163,41 +188,67 @@ __device__ __forceinline__ void sweep_plan(const SweepPlan &plan, const SweepCtx
         }
         const float fal = (float)al, fkx = (float)kx, fky = (float)ky;
         accC += fal * (iv.x * iv.x + iv.y * iv.y);
-        const float ax = fal * iv.x, ay = fal * iv.y;
-        auto fetch = [&](int g) {
-            const float *m = plan.m[g];
-            return cube_fetch(C.cv, m[0] * fkx + m[1] * fky, m[2] * fkx + m[3] * fky, m[4] * fkx + m[5] * fky);
-        };
-        CubeTaps cur = fetch(0);
-        // the angular neighbours and the centre share one shift (slots 0 .. q_same): one phase factor per sample for all
-        float cs0, sn0;
-        {
-            float rev = -(fkx * plan.sh[0][0] + fky * plan.sh[0][1]) * invN;
+        const float ac = fal * c, ax = ac * iv.x, ay = ac * iv.y, w = ac * c;      // weighted image value (with the CTF weight) and the weight of |v|^2
+        auto turned = [&](int q, float &bx, float &by) {              // conj(image value x e^{-i phase of slot q's shift}): score term = bx v.x + by v.y
+            float rev = -(fkx * plan.sh[q][0] + fky * plan.sh[q][1]) * invN;       // phase in revolutions
             rev -= floorf(rev);
-            sn0 = __sinf(6.283185307179586f * rev); cs0 = __cosf(6.283185307179586f * rev);
-        }
-        const int q_same = plan.q_same;
-        for (int g = 0; g < ng; g++) {
-            CubeTaps nxt = cur;
-            if (g + 1 < ng) nxt = fetch(g + 1);          // the next group's gathers fly while this group is scored
-            float2 pv = cube_interp(cur);
-            cur = nxt;
-            pv.x *= c; pv.y *= c;
-            float bv = group16_sum_dpp(fal * (pv.x * pv.x + pv.y * pv.y));     // |m|^2 does not depend on the shift
-            const int nv = plan.nv[g], q0 = plan.slot0[g];
-            for (int v = 0; v < nv; v++) {
-                const int q = q0 + v;
-                float sn = sn0, cs = cs0;
-                if (q > q_same) {                                    // a shifted probe (wave-uniform branch)
-                    float rev = -(fkx * plan.sh[q][0] + fky * plan.sh[q][1]) * invN;     // phase in revolutions
-                    rev -= floorf(rev);
-                    sn = __sinf(6.283185307179586f * rev); cs = __cosf(6.283185307179586f * rev);
-                }
-                float mr = pv.x * cs - pv.y * sn, mi = pv.x * sn + pv.y * cs;
-                float av = group16_sum_dpp(ax * mr + ay * mi);
-                if ((lane & 15) == 0 && ring < nr) { atomicAdd(&myA[q * nw * nr + ring], av); atomicAdd(&myB[q * nw], bv); }
+            const float sn = __sinf(6.283185307179586f * rev), cs = __cosf(6.283185307179586f * rev);
+            bx = ax * cs + ay * sn; by = ay * cs - ax * sn;
+        };
+        float b0x, b0y;
+        turned(0, b0x, b0y);           // the angular neighbours and the centre share one shift (slots 0 .. q_same)
+        auto fetch = [&](int g) {
+            const float *m = plan.ms[g];
+            const float X = m[0] * fkx + m[1] * fky, Y = m[2] * fkx + m[3] * fky, Z = m[4] * fkx + m[5] * fky;
+            if constexpr (TAB) return cube_fetch_tab(C.cv, C.tab, X, Y, Z);
+            else { CubeView one = C.cv; one.scale = 1.f; return cube_fetch(one, X, Y, Z); }
+        };
+        const bool mine = head && ring < nr;
+        // timing probe (results are wrong; scripts/ab_local.sh): PPM_DBG_NOATOM keeps the sums alive without LDS traffic
+#if defined(PPM_DBG_NOATOM)
+        auto ring_add = [&](float *cell, float v) { accC += 1e-30f * v; };
+#else
+        auto ring_add = [&](float *cell, float v) { atomicAdd(cell, v); };
+#endif
+        float *const cellA = myA + ring;
+        auto score_group = [&](int g, const CubeTaps &t) {
+            const float2 v = cube_interp(t);
+            const int nv = __builtin_amdgcn_readfirstlane(plan.nv[g]), q0 = __builtin_amdgcn_readfirstlane(plan.slot0[g]);
+            const float n2 = w * (v.x * v.x + v.y * v.y);
+            if (nv == 1 && q0 <= q_same) {                           // an angular neighbour (or a single pose): two sums side by side
+                float av = b0x * v.x + b0y * v.y, bv = n2;
+                av += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(av), 0xB1, 0xF, 0xF, true));
+                bv += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(bv), 0xB1, 0xF, 0xF, true));
+                av += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(av), 0x4E, 0xF, 0xF, true));
+                bv += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(bv), 0x4E, 0xF, 0xF, true));
+                av += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(av), 0x141, 0xF, 0xF, true));
+                bv += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(bv), 0x141, 0xF, 0xF, true));
+                av += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(av), 0x140, 0xF, 0xF, true));
+                bv += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(bv), 0x140, 0xF, 0xF, true));
+                if (mine) { ring_add(cellA + q0 * strideA, av); ring_add(myB + q0 * nw, bv); }
+                return;
             }
+            const float bv = group16_sum_dpp(n2);
+            if (mine) ring_add(myB + q0 * nw, bv);
+            for (int k = 0; k < nv; k++) {
+                const int q = q0 + k;
+                float bx = b0x, by = b0y;
+                if (q > q_same) turned(q, bx, by);                   // a shifted probe (wave-uniform branch)
+                const float av = group16_sum_dpp(bx * v.x + by * v.y);
+                if (mine) ring_add(cellA + q * strideA, av);
+            }
+        };
+        // the next group's gathers fly while this group is scored; A and B alternate.  Inside the loop both fetches are unconditional,
+        // so the wait before a group's interpolation is for ITS four loads only (a fetch under a condition forces the wait for the
+        // oldest loads of either path, i.e. for the prefetch as well)
+        CubeTaps A = fetch(0), B;
+        int g = 0;
+        for (; g + 2 < ng; g += 2) {          // sched_barrier: the loads are issued BEFORE the scheduler may start on the other set's interpolation
+            B = fetch(g + 1); __builtin_amdgcn_sched_barrier(0); score_group(g, A);
+            A = fetch(g + 2); __builtin_amdgcn_sched_barrier(0); score_group(g + 1, B);
         }
+        if (g + 1 < ng) { B = fetch(g + 1); __builtin_amdgcn_sched_barrier(0); score_group(g, A); score_group(g + 1, B); }
+        else score_group(g, A);
     }
     accC = wave_sum(accC);
     if (lane == 0) sumC[wave] = accC;
@@ -214,8 +265,9 @@ __device__ __forceinline__ void sweep_plan(const SweepPlan &plan, const SweepCtx
             }
         sa = group8_sum_d(sa);
         if (slot < nslots && j == 0) {
-            float fb = sumB[slot * nw], fc = sumC[0];
-            for (int w = 1; w < nw; w++) { fb += sumB[slot * nw + w]; fc += sumC[w]; }
+            const int bs = plan.bsl[slot];
+            float fb = sumB[bs * nw], fc = sumC[0];
+            for (int w = 1; w < nw; w++) { fb += sumB[bs * nw + w]; fc += sumC[w]; }
             const double sb = fb, sc = fc;
             score[slot] = (sb > 0 && sc > 0) ? sa / sqrt(sb * sc) : 0.0;
         }
@@ -231,9 +283,13 @@ __device__ __forceinline__ void sweep_plan(const SweepPlan &plan, const SweepCtx
 // a wave's adds happen in program order (and the lanes of one ds_add in lane order), the tables of the waves are
 // combined in a fixed order afterwards, so a score does not depend on how the waves of the block interleave
 // (bit-identical results from run to run; with one table shared by the waves a late compass decision could flip).
-__global__ void __launch_bounds__(256, 5) k_local(LocalP P) {
+#ifndef PPM_LOCAL_MINW
+#define PPM_LOCAL_MINW 4
+#endif
+template <bool TAB>
+__global__ void __launch_bounds__(256, PPM_LOCAL_MINW) k_local(LocalP P) {
     __shared__ SweepPlan plan;
-    extern __shared__ float lsm[];                    // ringA[slot][wave][nr], sumB[slot][wave], sumC[wave]
+    extern __shared__ float lsm[];                    // ringA[slot][wave][nr], sumB[slot][wave], sumC[wave]; then the address tables (TAB)
     __shared__ double score[kMaxCand];
     __shared__ LState st;
     __shared__ double sfp[5], sfm[5], sd[5], sMt[9], sshq[2], sf0;
@@ -252,7 +308,7 @@ __global__ void __launch_bounds__(256, 5) k_local(LocalP P) {
     SweepCtx SC;
     SC.cv = P.cv; SC.samples = P.samples; SC.Il = Il; SC.cw = cw; SC.invN = invN; SC.rlo2 = P.rlo2; SC.ring_signed = P.ring_signed;
     SC.nr = nr; SC.nw = nw; SC.ringA = ringA; SC.sumB = sumB; SC.sumC = sumC; SC.score = score;
-    auto sweep = [&]() { sweep_plan(plan, SC, tid, nthr); };
+    if constexpr (TAB) SC.tab = cube_tab_fill(P.cv, (char *)lsm + ring_lds_bytes8(nw, kMaxCand, nr), P.tabR, tid, nthr);    // the first sweep's barrier publishes them
     auto set_rot = [&](int g, const double *M) {
         plan.m[g][0] = (float)M[0]; plan.m[g][1] = (float)M[1]; plan.m[g][2] = (float)M[3];
         plan.m[g][3] = (float)M[4]; plan.m[g][4] = (float)M[6]; plan.m[g][5] = (float)M[7];
@@ -264,10 +320,19 @@ __global__ void __launch_bounds__(256, 5) k_local(LocalP P) {
 
     int nfree = 0;
     for (int i = 0; i < 5; i++) nfree += P.en[i] ? 1 : 0;
-    for (int it = 0; it < P.T; it++) {
-        // ---- slots: 2 per free angle (+h, -h), then the centre, then 2 per free shift.  Lanes 0..5 build one angular
-        // neighbour each (the double-precision trig is the serial part of an iteration), lane 6 the centre group.
-        {
+    // One sweep call site: the kernel is a sequence of (build a plan, sweep, use the scores) steps -
+    // per iteration the compass (centre + neighbours) and the trial pose, then the final score and the classification band.
+    enum { PH_COMPASS, PH_TRIAL, PH_FINAL, PH_CLASS, PH_DONE };
+    int it = 0, phase = PH_COMPASS;
+    if (nfree == 0 || P.T <= 0) {
+        if (tid == 0) for (int t = 0; t < P.T; t++) { st.ha *= 0.5; st.hs *= 0.5; }
+        phase = P.final_rescore ? PH_FINAL : PH_DONE;
+        __syncthreads();
+    }
+    while (phase != PH_DONE) {
+        if (phase == PH_COMPASS) {
+            // ---- slots: 2 per free angle (+h, -h), then the centre, then 2 per free shift.  Lanes 0..5 build one angular
+            // neighbour each (the double-precision trig is the serial part of an iteration), lane 6 the centre group.
             int nang = 0;
             for (int i = 0; i < 3; i++) nang += P.en[i] ? 2 : 0;
             if (tid < 6) {
@@ -302,11 +367,15 @@ __global__ void __launch_bounds__(256, 5) k_local(LocalP P) {
                 plan.nv[g] = nv;
                 plan.ng = g + 1; plan.nslots = q; plan.q_same = nang; plan.S_used = P.S_it[it]; plan.rmax2 = P.rmax2_it[it];
             }
-        }
+        } else if (phase == PH_FINAL) {
+            if (tid == 0) { single(st.M, st.sh); plan.S_used = P.S_final; plan.rmax2 = P.rmax2_final; }
+        } else if (phase == PH_CLASS) {                  // the same pose over the classification band: LOGP / SIGMA of the row
+            if (tid == 0) { plan.S_used = P.S_class; plan.rmax2 = P.rmax2_class; }
+        }                                                // PH_TRIAL: the plan was written when the compass scores were read
         __syncthreads();
-        if (nfree > 0) {
-            sweep();
-            if (tid == 0) {
+        sweep_plan<TAB>(plan, SC, tid, nthr);
+        if (tid == 0) {
+            if (phase == PH_COMPASS) {
                 int q = 0, qc = 0;
                 for (int i = 0; i < 3; i++) qc += P.en[i] ? 2 : 0;
                 if (P.use_priors) for (int k = 0; k < plan.nslots; k++) score[k] -= spen[k];
@@ -331,11 +400,8 @@ __global__ void __launch_bounds__(256, 5) k_local(LocalP P) {
                 for (int k = 0; k < 9; k++) sMt[k] = st.M[k];
                 for (int i = 0; i < 3; i++) if (P.en[i] && sd[i] != 0) { d_rot_step(sMt, i, tilt, sd[i], T9); for (int k = 0; k < 9; k++) sMt[k] = T9[k]; }
                 sshq[0] = st.sh[0] + sd[3]; sshq[1] = st.sh[1] + sd[4];
-                single(sMt, sshq);
-            }
-            __syncthreads();
-            sweep();
-            if (tid == 0) {
+                single(sMt, sshq);                       // band fields stay those of the iteration
+            } else if (phase == PH_TRIAL) {
                 const double ft = score[0] - (P.use_priors ? d_prior_pen(P, sMt, sshq[0], sshq[1]) : 0.0), f0 = sf0;
                 int bi = -1, bs = 0; double fb = f0;
                 for (int i = 0; i < 5; i++) {
@@ -352,24 +418,15 @@ __global__ void __launch_bounds__(256, 5) k_local(LocalP P) {
                     else st.sh[bi - 3] += bs * st.hs;
                     st.f = fb;
                 }
-            }
+                st.ha *= 0.5; st.hs *= 0.5;
+            } else if (phase == PH_FINAL) st.f = st.fc = score[0];
+            else st.fc = score[0];
         }
-        if (tid == 0) { st.ha *= 0.5; st.hs *= 0.5; }
+        if (phase == PH_COMPASS) phase = PH_TRIAL;
+        else if (phase == PH_TRIAL) { it++; phase = it < P.T ? PH_COMPASS : (P.final_rescore ? PH_FINAL : PH_DONE); }
+        else if (phase == PH_FINAL) phase = P.S_class > 0 ? PH_CLASS : PH_DONE;
+        else phase = PH_DONE;
         __syncthreads();
-    }
-    if (P.final_rescore) {
-        if (tid == 0) { single(st.M, st.sh); plan.S_used = P.S_final; plan.rmax2 = P.rmax2_final; }
-        __syncthreads();
-        sweep();
-        if (tid == 0) st.f = st.fc = score[0];
-        __syncthreads();
-        if (P.S_class > 0) {                          // the same pose over the classification band: LOGP / SIGMA of the row
-            if (tid == 0) { plan.S_used = P.S_class; plan.rmax2 = P.rmax2_class; }
-            __syncthreads();
-            sweep();
-            if (tid == 0) st.fc = score[0];
-            __syncthreads();
-        }
     }
     if (tid == 0) P.states[blockIdx.x] = st;
 }

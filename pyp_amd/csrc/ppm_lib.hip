@@ -570,7 +570,8 @@ ppm_ref_t *ppm_reference_create_weighted(const float *vol, int n, float max_band
     size_t cube_n = (size_t)r->CX * r->CY * r->CY;
     r->NBX = (r->CX + 3) / 4; r->NBY = (r->CY + 1) / 2;
     const size_t copy_n = (size_t)r->NBX * r->NBY * r->NBY * 16;         // blocked layout, two copies (ppm_dev.h)
-    if (2 * copy_n >= ((size_t)1 << 32)) { fail(-22, "reference cube too large"); return nullptr; }
+    if (2 * copy_n * sizeof(float2) >= ((size_t)1 << 32)) {        // byte offsets of the buffer loads are 32-bit
+    fail(-22, "reference cube too large"); return nullptr; }
     r->LB = (unsigned)copy_n;
     if (hipMalloc(&r->cube, 2 * copy_n * sizeof(float2)) != hipSuccess) { r->cube = nullptr; fail(-12, "out of device memory for the reference cube"); return nullptr; }
     HIPCHKP(hipMemsetAsync(r->cube, 0, 2 * copy_n * sizeof(float2), cur_stream()));
@@ -825,6 +826,14 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
         ndef = std::min((int)std::floor(cfg->defocus_range / cfg->defocus_step + 1e-6), PPM_MAX_DEFOCUS_STEPS);
     LocalP LP;
     LP.cv = cv; LP.samples = ref->samples.p; LP.Il = ref->Il.p; LP.cw = ref->cw.p; LP.S_pad = S_pad; LP.nrings = nrings; LP.N = gm.N;
+    LP.tabR = cube_tab_radius(gm.B, cv.scale);
+    // tap addresses from LDS tables (ppm_dev.h) unless the tables would crowd the ring sums out of a CU (PPM_LOCAL_TABLES=0: arithmetic)
+    const bool local_tab = !(getenv("PPM_LOCAL_TABLES") && atoi(getenv("PPM_LOCAL_TABLES")) == 0) && cube_tab_bytes(LP.tabR) <= 16 * 1024;
+    auto launch_local = [&](unsigned grid, int threads) {
+        const size_t lds = ring_lds_bytes8(threads / 64, kMaxCand, LP.nr) + (local_tab ? cube_tab_bytes(LP.tabR) : 0);
+        if (local_tab) hipLaunchKernelGGL(k_local<true>, dim3(grid), dim3(threads), lds, cur_stream(), LP);
+        else hipLaunchKernelGGL(k_local<false>, dim3(grid), dim3(threads), lds, cur_stream(), LP);
+    };
     LP.rlo2 = (float)(gm.r_lo * gm.r_lo); LP.ring_signed = (float)std::min(gm.ring_signed, 1e30);
     LP.en[0] = cfg->refine_psi; LP.en[1] = cfg->refine_theta; LP.en[2] = cfg->refine_phi; LP.en[3] = cfg->refine_x; LP.en[4] = cfg->refine_y;
     LP.use_priors = 0;
@@ -916,7 +925,7 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
                 fill_schedule(0.5 * gm.dstep, gm.step, 0, Tb, gm.r_s, (double)K);
                 ProfScope ps(PPM_K_LOCAL);
                 // 128-thread blocks for the hit stage (<= ~800 samples per sweep: two waves waste less on the serial steps), 256 below
-                hipLaunchKernelGGL(k_local, dim3(nb * K), dim3(128), ring_lds_bytes(2, kMaxCand, LP.nr), cur_stream(), LP);
+                launch_local((unsigned)(nb * K), 128);
             }
             {
                 ProfScope ps(PPM_K_TOPK);
@@ -927,7 +936,7 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
                 fill_schedule(0.5 * gm.dstep / (double)(1 << Tb), gm.step / (double)(1 << Tb), Tb, LP.T, gm.r_hi, 1.0);
                 sample_evals += std::floor(kPi * gm.r_hi * gm.r_hi / 2);
                 ProfScope ps(PPM_K_LOCAL);
-                hipLaunchKernelGGL(k_local, dim3(nb), dim3(256), ring_lds_bytes(4, kMaxCand, LP.nr), cur_stream(), LP);
+                launch_local((unsigned)nb, 256);
             }
         } else {
             double ha0 = cfg->local_angle_step > 0 ? cfg->local_angle_step : 2.5, hs0 = cfg->local_shift_step > 0 ? cfg->local_shift_step : 2.0;
@@ -937,7 +946,7 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
             fill_schedule(ha0, hs0, 0, LP.T, gm.r_hi, 1.0);
             sample_evals += std::floor(kPi * gm.r_hi * gm.r_hi / 2);
             ProfScope ps(PPM_K_LOCAL);
-            hipLaunchKernelGGL(k_local, dim3(nb), dim3(256), ring_lds_bytes(4, kMaxCand, LP.nr), cur_stream(), LP);
+            launch_local((unsigned)nb, 256);
         }
         const float *d_ddef = nullptr;
         if (ndef > 0) {                                 // defocus offsets at the final pose
@@ -1546,6 +1555,8 @@ extern "C" int ppm_csp_refine(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const p
     CspEvalP EP;
     EP.cv.cube = ref->cube; EP.cv.NBX = ref->NBX; EP.cv.NBY = ref->NBY; EP.cv.LB = ref->LB; EP.cv.off = ref->B + 1; EP.cv.scale = (float)ref->pad;
     EP.samples = ref->samples.p; EP.Il = Il.p; EP.cw = cw.p; EP.S_pad = S_pad; EP.N = gm.N; EP.nr = nrings;
+    EP.tabR = cube_tab_radius(gm.B, EP.cv.scale);
+    const bool csp_tab = !(getenv("PPM_LOCAL_TABLES") && atoi(getenv("PPM_LOCAL_TABLES")) == 0) && cube_tab_bytes(EP.tabR) <= 16 * 1024;
     EP.rlo2 = (float)(gm.r_lo * gm.r_lo); EP.ring_signed = (float)std::min(gm.ring_signed, 1e30);
     EP.kind = kind; EP.eval_rows = d_eval.p; EP.row_part = d_rp.p; EP.row_tilt = d_rt.p; EP.unit_slot = d_slot.p;
     EP.Nmat = d_N.p; EP.pshift = d_p.p; EP.tl = d_tl.p; EP.delta = d_delta.p; EP.s0 = d_s0.p; EP.g0 = d_g0.p; EP.out = d_out.p;
@@ -1574,7 +1585,11 @@ extern "C" int ppm_csp_refine(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const p
         }
         {
             ProfScope ps(PPM_K_LOCAL);
-            hipLaunchKernelGGL(k_csp_eval, dim3((unsigned)rows_list.size()), dim3(256), ring_lds_bytes(4, kMaxCand, nrings), cur_stream(), EP);
+            {
+                const size_t lds = ring_lds_bytes8(4, kMaxCand, nrings) + (csp_tab ? cube_tab_bytes(EP.tabR) : 0);
+                if (csp_tab) hipLaunchKernelGGL(k_csp_eval<true>, dim3((unsigned)rows_list.size()), dim3(256), lds, cur_stream(), EP);
+                else hipLaunchKernelGGL(k_csp_eval<false>, dim3((unsigned)rows_list.size()), dim3(256), lds, cur_stream(), EP);
+            }
         }
         if (means) {
             const int nm = (int)active.size() * ncand;

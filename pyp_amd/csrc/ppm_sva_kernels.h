@@ -335,7 +335,10 @@ constexpr int kSvaParts = 4;
 // trial pose), 1 .. nrot = rotated candidates (one gather each), the rest keep candidate 0's rotation (shift variants: they
 // share its gather).  Every thread accumulates its samples' sums in registers (static indices); the block combines them
 // through LDS in a fixed order.
-__global__ void __launch_bounds__(256) k_sva_eval(SvaEvalP P) {
+#ifndef PPM_SVA_EVAL_MINW
+#define PPM_SVA_EVAL_MINW 1      // blocks of 256 threads per CU the register allocation leaves room for (A/B knob, scripts/ab_r04.sh)
+#endif
+__global__ void __launch_bounds__(256, PPM_SVA_EVAL_MINW) k_sva_eval(SvaEvalP P) {
     __shared__ float cm[kMaxCand][9], csh[kMaxCand][3];
     __shared__ float red[4][2 * kMaxCand + 1];
     const int st = blockIdx.x, part = blockIdx.y, v = P.vmap ? P.vmap[st] : st, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ncand = P.ncand, nrot = P.nrot;

@@ -492,6 +492,19 @@ def test_device_resident_stack_equals_host_stack(d64, H):
     assert np.array_equal(a, g.refine(c, imgs[:8], rows[:8]))
 
 
+def test_tap_addresses_from_lds_tables_equal_the_arithmetic_path(d64, H, monkeypatch):
+    """k_local reads its tap addresses from LDS tables (ppm_dev.h, cube_tab_fill); PPM_LOCAL_TABLES=0 computes them per gather.
+    Same taps, same weights up to the last bit of a fraction: the refined rows agree far inside the parity tolerance."""
+    vol, imgs, rows, g, o = d64
+    c = cfg_for(64, 2.0)
+    tab = g.refine(c, imgs[:8], rows[:8])
+    monkeypatch.setenv("PPM_LOCAL_TABLES", "0")
+    ari = g.refine(c, imgs[:8], rows[:8])
+    monkeypatch.delenv("PPM_LOCAL_TABLES")
+    assert np.allclose(tab[:, 1:6], ari[:, 1:6], atol=2e-3)             # angles (deg) and shifts (A)
+    assert np.allclose(tab, ari, rtol=1e-4, atol=2e-3)
+
+
 def test_chunked_batches_and_empty_input(d64, H, monkeypatch):
     """Ragged chunking (n not a multiple of the chunk) gives the same rows as one chunk; zero particles is a no-op."""
     vol, imgs, rows, g, o = d64
