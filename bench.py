@@ -33,6 +33,8 @@ sys.path.insert(0, ROOT)
 
 PEAK_VALU_TFLOPS = 157.3      # MI355X_MICROARCH.md: peak fp32 vector
 PEAK_HBM_GBPS = 8000.0        # HBM3E spec
+PEAK_L1_GBPS = 64.0 * 256 * 2.4   # vector L1 delivery, 64 B per clock and CU at the 2.4 GHz peak clock = 39.3 TB/s (the gather kernels measure
+                                  # 56 B per clock with every load an L1 hit, and the chip sustains ~1.95 GHz under them)
 
 
 def parse(argv=None):
@@ -369,12 +371,14 @@ def refine_bench(ctx):
         ms_l = prof["local"]["ms"] / (M * a.steps) * 1e-3                                  # seconds per particle
         gathers = counts["samples_local"]                                                   # gathered samples per particle (every evaluation at its marching band)
         fl_l = 70.0 * gathers
-        roof["local"] = {"kernel": "k_local", "bound": "valu_fp32", "us_per_particle": round(ms_l * 1e6, 3), "gathered_samples_per_particle": gathers,
-                         "achieved": round(fl_l / ms_l / 1e12, 2), "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s", "frac": round(fl_l / ms_l / 1e12 / PEAK_VALU_TFLOPS, 4),
-                         "flop_model": "70 fp32 operations per gathered sample (useful arithmetic; the kernel issues ~130 vector instructions per gathered "
-                                       "sample, most of them gather addressing and 16-lane ring reductions)",
-                         "gather_GBps_from_cache": round(64.0 * gathers / ms_l / 1e9, 1),
-                         "note": "vector-issue-bound (VALU ~90 % busy) with the texture-address path ~60 % busy: 4 x 16 B per lane and gather"}
+        gbps_l = 64.0 * gathers / ms_l / 1e9
+        roof["local"] = {"kernel": "k_local", "bound": "l1_gather", "us_per_particle": round(ms_l * 1e6, 3), "gathered_samples_per_particle": gathers,
+                         "achieved": round(gbps_l, 1), "peak": PEAK_L1_GBPS, "unit": "GB/s", "frac": round(gbps_l / PEAK_L1_GBPS, 4),
+                         "bytes_model": "64 B per gathered sample: the 2 x 2 x 2 neighbourhood of the reference as four 16-byte loads through the CU's vector L1",
+                         "useful_TFLOPs": round(fl_l / ms_l / 1e12, 2),
+                         "flop_model": "70 fp32 operations per gathered sample (useful arithmetic; the kernel issues ~75 vector instructions per gathered sample)",
+                         "note": "bound by the vector memory path (DESIGN.md 4b): 64 cycles per 64-lane gather at 64 B/clock/CU plus ~6 line fills from L2; "
+                                 "probes with all L1 hits / without LDS atomics / with half the instructions are in CHANGELOG.md round 4"}
     pv = pmc_valu(pmc_latest("refine"), "k_global", n_slices)
     if pv:
         pv["model_flops_per_lane_instruction"] = round(fl_slice / (pv["SQ_INSTS_VALU_per_slice"] * 64.0), 3)
@@ -658,9 +662,11 @@ def gather_roofline(kernel, summary_workload, ms_total, launches, gathers_total,
         for c in ("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "TCC_HIT_sum", "TCC_MISS_sum"):
             if c in e:
                 pv[c] = e[c]["sum"]
-    return {"bound": "valu_fp32", "kernel": kernel, "achieved": round(tf, 2), "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_VALU_TFLOPS, 4),
+    gbps = 64.0 * gpl / (ms * 1e-3) / 1e9
+    return {"bound": "l1_gather", "kernel": kernel, "achieved": round(gbps, 1), "peak": PEAK_L1_GBPS, "unit": "GB/s", "frac": round(gbps / PEAK_L1_GBPS, 4),
+            "bytes_model": "64 B per gathered sample (four 16-byte loads through the CU's vector L1; DESIGN.md 4b)",
             "traffic": traffic, "traffic_source": src, "avg_launch_ms": round(ms, 4), "launches": launches, unit_name + "_per_launch": round(upl, 1),
-            "gathered_samples_per_launch": round(gpl), "gather_GBps_from_cache": round(64.0 * gpl / (ms * 1e-3) / 1e9, 1),
+            "gathered_samples_per_launch": round(gpl), "useful_TFLOPs": round(tf, 2),
             "flop_model": "70 fp32 operations per gathered sample (useful arithmetic)", "pmc": pv, "note": note}
 
 

@@ -21,6 +21,7 @@
 #pragma once
 #include <poll.h>
 #include <sys/socket.h>
+#include <sys/time.h>
 #include <sys/un.h>
 
 #include "dropin_common.h"

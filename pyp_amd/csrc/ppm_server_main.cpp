@@ -42,8 +42,11 @@ int main(int argc, char **argv) {
         if (lfd >= 0) { dup2(lfd, 1); dup2(lfd, 2); close(lfd); }
     }
     setenv("PPM_SYNC", "block", 0);
-    // ---- one server per device: a live socket means another one is serving
+    // ---- one server per device: the server holds an exclusive lock on <socket>.lock for its lifetime (two clients may start servers at the
+    // same moment: without it the second would unlink the first one's socket and leave it serving nobody); a live socket means the same
     const std::string path = server_socket_path(dev);
+    const int guard_fd = open((path + ".lock").c_str(), O_RDWR | O_CREAT, 0600);
+    if (guard_fd < 0 || flock(guard_fd, LOCK_EX | LOCK_NB) != 0) { printf("a server is already running (or starting) for device %d\n", dev); return 0; }
     { int fd = connect_server(dev); if (fd >= 0) { close(fd); printf("a server is already running for device %d\n", dev); return 0; } }
     unlink(path.c_str());
     int ls = socket(AF_UNIX, SOCK_STREAM, 0);
@@ -68,6 +71,7 @@ int main(int argc, char **argv) {
         if (pr <= 0) { printf("ppm_server: idle for %.0f s, leaving\n", idle_s); break; }
         const int fd = accept(ls, nullptr, nullptr);
         if (fd < 0) continue;
+        { timeval tv; tv.tv_sec = 10; tv.tv_usec = 0; setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv); }      // a client that connects and stays silent does not block the others
         char magic[4]; uint32_t prog = 0; std::string cwd, input;
         if (!read_all(fd, magic, 4) || memcmp(magic, "PPMS", 4) != 0 || !read_all(fd, &prog, 4) || !recv_blob(fd, cwd) || !recv_blob(fd, input)) { close(fd); continue; }
         std::string text; Out out; out.sink = &text;
@@ -89,6 +93,9 @@ int main(int argc, char **argv) {
                 } catch (const Fail &f) {
                     status = 1;
                     out.print("%s\n", f.msg.find("ERROR") != std::string::npos ? f.msg.c_str() : ("ERROR: " + f.msg).c_str());
+                } catch (const std::exception &e) {             // out of host memory, a bad table ...: the call fails, the server stays
+                    status = 1;
+                    out.print("ERROR: ppm_server: %s\n", e.what());
                 }
                 gpu_unlock(lockfd);
             }

@@ -51,6 +51,36 @@ def test_server_starts_reports_and_stops(lockdir):
     assert not (lockdir / "pyp_amd_gpu0.sock").exists()
 
 
+def test_servers_started_at_the_same_moment_leave_one(lockdir):
+    """Two clients may both find no server and start one: the lifetime lock next to the socket lets exactly one serve; the others step
+    back without touching its socket, and after --stop nobody holds the lock any more."""
+    import fcntl
+    _built("ppm_server")
+    procs = [subprocess.Popen([SERVER, "--daemon"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for _ in range(4)]
+    assert all(p.wait(timeout=30) == 0 for p in procs)
+    for _ in range(100):
+        r = subprocess.run([SERVER, "--stats"], capture_output=True, text=True)
+        if r.returncode == 0:
+            break
+        time.sleep(0.05)
+    assert r.returncode == 0 and "served 0 calls" in r.stdout
+    time.sleep(0.3)                                       # the losers are gone by now; the socket must still answer
+    assert subprocess.run([SERVER, "--stats"], capture_output=True, text=True).returncode == 0
+    with open(lockdir / "pyp_amd_gpu0.sock.lock", "r+") as f:
+        with pytest.raises(OSError):
+            fcntl.flock(f, fcntl.LOCK_EX | fcntl.LOCK_NB)            # held by the one server
+    assert subprocess.run([SERVER, "--stop"], capture_output=True, text=True, timeout=30).returncode == 0
+    with open(lockdir / "pyp_amd_gpu0.sock.lock", "r+") as f:
+        for _ in range(100):
+            try:
+                fcntl.flock(f, fcntl.LOCK_EX | fcntl.LOCK_NB)
+                break
+            except OSError:
+                time.sleep(0.05)
+        else:
+            pytest.fail("a server survived --stop")
+
+
 def _gpu_present():
     try:
         import torch
