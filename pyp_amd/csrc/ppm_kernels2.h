@@ -294,8 +294,8 @@ __global__ void __launch_bounds__(256, PPM_LOCAL_MINW) k_local(LocalP P) {
     __shared__ LState st;
     __shared__ double sfp[5], sfm[5], sd[5], sMt[9], sshq[2], sf0;
     __shared__ double spen[kMaxCand];                 // restraint of every slot's pose (use_priors)
-    const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;      // 128 or 256 threads (few samples per sweep: smaller blocks)
-    const int nw = nthr >> 6, wave = tid >> 6, nr = P.nr;
+    const int tid = threadIdx.x, nthr = blockDim.x;      // 128 or 256 threads (few samples per sweep: smaller blocks)
+    const int nw = nthr >> 6, nr = P.nr;
     float *const ringA = lsm, *const sumB = lsm + kMaxCand * nw * nr, *const sumC = sumB + kMaxCand * nw;
     if (tid == 0) st = P.states[blockIdx.x];
     __syncthreads();
