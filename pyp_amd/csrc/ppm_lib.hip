@@ -474,6 +474,7 @@ int ppm_device_upload(void *dst, const void *src, size_t bytes) {
 void *ppm_host_alloc(size_t bytes) { if (g.inited) (void)hipSetDevice(g.device); void *p = nullptr; if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { g_err = "ERROR: pinned host allocation failed"; return nullptr; } return p; }
 void ppm_host_free(void *p) { if (p) (void)hipHostFree(p); }
 // ---- file reads for the executables' reader stage: a persistent pool, one pread loop per part
+extern "C++" {
 namespace {
 struct ReadPool {
     std::mutex mu;                      // one ppm_host_read at a time
@@ -528,6 +529,7 @@ struct ReadPool {
     }
 };
 ReadPool &read_pool() { static ReadPool *p = new ReadPool(); return *p; }      // leaked on purpose: no joins at process exit
+}
 }
 int ppm_host_read(int fd, long long offset, void *dst, size_t bytes, int n_threads) {
     if (fd < 0 || offset < 0 || (!dst && bytes)) return fail(-22, "ppm_host_read: bad argument");
