@@ -47,6 +47,21 @@ def test_particle_mode_matches_oracle(series):
     assert np.array_equal(gr, g.csp_refine(cfg, cc, imgs, rows2, p2, tilts)[0])            # deterministic
 
 
+def test_tap_address_tables_and_arithmetic_agree_in_the_constrained_search(series, monkeypatch):
+    """k_csp_eval takes its tap addresses from LDS tables like k_local (ppm_dev.h); PPM_LOCAL_TABLES=0 selects the instantiation that
+    computes them per gather.  Same taps, fractions equal to the last bit but one: units and rows agree far inside the tolerance."""
+    n, px, vol, imgs, rows, parts, tilts, cfg, g, o, O = series
+    p2 = _perturb_particles(parts)
+    rows2 = synth.csp_rows_from_params(rows, parts, tilts, p2, tilts)
+    cc = CspCfg.make(CSP_PARTICLES, tol_angle=(8, 8, 8), tol_shift=4.0)
+    tr, tp, _ = g.csp_refine(cfg, cc, imgs, rows2, p2, tilts)
+    monkeypatch.setenv("PPM_LOCAL_TABLES", "0")
+    ar, ap, _ = g.csp_refine(cfg, cc, imgs, rows2, p2, tilts)
+    monkeypatch.delenv("PPM_LOCAL_TABLES")
+    assert _particle_angle_err(tp, ap).max() < 0.01 and np.abs(tp[:, 1:4] - ap[:, 1:4]).max() < 0.01
+    assert synth.angular_error_deg(tr, ar).max() < 0.01 and synth.shift_error_px(tr, ar, px).max() < 0.01
+
+
 def test_micrograph_mode_matches_oracle(series):
     n, px, vol, imgs, rows, parts, tilts, cfg, g, o, O = series
     rng = np.random.default_rng(5)
