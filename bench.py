@@ -903,7 +903,7 @@ def csp_bench(ctx):
                                        nproj * a.steps * lc_csp["n_local"], "projections",
                                        "host-driven compass: %d sweeps per call, every sweep one launch over the usable projections of the refined units" % lc_csp["n_local"]),
            "note": "host-driven compass search: the device scores <= 13 candidate poses per projection and sweep (k_csp_eval, the sweep of k_local: "
-                   "vector-issue-bound like it); the rest of a step is the host's fixed-order reductions and candidate tables",
+                   "bound by the vector memory path like it, DESIGN.md 4b); the rest of a step is the host's fixed-order reductions and candidate tables",
            "accuracy_vs_truth": {"median_deg_before": round(float(np.median(perr(p2, parts))), 3), "median_deg_after": round(float(np.median(perr(out[1], parts))), 3),
                                  "median_shift_px_after": round(float(np.median(np.linalg.norm(out[1][:, 1:4] - parts[:, 1:4], axis=1))), 3)}}
     if two:
