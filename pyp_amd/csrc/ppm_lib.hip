@@ -832,8 +832,10 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
     // tap addresses from LDS tables (ppm_dev.h) unless the tables would crowd the ring sums out of a CU (PPM_LOCAL_TABLES=0: arithmetic)
     const bool local_tab = !(getenv("PPM_LOCAL_TABLES") && atoi(getenv("PPM_LOCAL_TABLES")) == 0) && cube_tab_bytes(LP.tabR) <= 16 * 1024;
     auto launch_local = [&](unsigned grid, int threads) {
-        const size_t lds = ring_lds_bytes8(threads / 64, kMaxCand, LP.nr) + (local_tab ? cube_tab_bytes(LP.tabR) : 0);
-        if (local_tab) hipLaunchKernelGGL(k_local<true>, dim3(grid), dim3(threads), lds, cur_stream(), LP);
+        const size_t ring = ring_lds_bytes8(threads / 64, kMaxCand, LP.nr);
+        const bool tab = local_tab && ring + cube_tab_bytes(LP.tabR) + 2048 <= (size_t)64 * 1024;      // with the kernel's static LDS inside the 64 KB a launch may ask for (box 512 at the full band: arithmetic)
+        const size_t lds = ring + (tab ? cube_tab_bytes(LP.tabR) : 0);
+        if (tab) hipLaunchKernelGGL(k_local<true>, dim3(grid), dim3(threads), lds, cur_stream(), LP);
         else hipLaunchKernelGGL(k_local<false>, dim3(grid), dim3(threads), lds, cur_stream(), LP);
     };
     LP.rlo2 = (float)(gm.r_lo * gm.r_lo); LP.ring_signed = (float)std::min(gm.ring_signed, 1e30);
@@ -1558,7 +1560,8 @@ extern "C" int ppm_csp_refine(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const p
     EP.cv.cube = ref->cube; EP.cv.NBX = ref->NBX; EP.cv.NBY = ref->NBY; EP.cv.LB = ref->LB; EP.cv.off = ref->B + 1; EP.cv.scale = (float)ref->pad;
     EP.samples = ref->samples.p; EP.Il = Il.p; EP.cw = cw.p; EP.S_pad = S_pad; EP.N = gm.N; EP.nr = nrings;
     EP.tabR = cube_tab_radius(gm.B, EP.cv.scale);
-    const bool csp_tab = !(getenv("PPM_LOCAL_TABLES") && atoi(getenv("PPM_LOCAL_TABLES")) == 0) && cube_tab_bytes(EP.tabR) <= 16 * 1024;
+    const bool csp_tab = !(getenv("PPM_LOCAL_TABLES") && atoi(getenv("PPM_LOCAL_TABLES")) == 0) && cube_tab_bytes(EP.tabR) <= 16 * 1024 &&
+                         ring_lds_bytes8(4, kMaxCand, nrings) + cube_tab_bytes(EP.tabR) + 2048 <= (size_t)64 * 1024;
     EP.rlo2 = (float)(gm.r_lo * gm.r_lo); EP.ring_signed = (float)std::min(gm.ring_signed, 1e30);
     EP.kind = kind; EP.eval_rows = d_eval.p; EP.row_part = d_rp.p; EP.row_tilt = d_rt.p; EP.unit_slot = d_slot.p;
     EP.Nmat = d_N.p; EP.pshift = d_p.p; EP.tl = d_tl.p; EP.delta = d_delta.p; EP.s0 = d_s0.p; EP.g0 = d_g0.p; EP.out = d_out.p;

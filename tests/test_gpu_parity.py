@@ -705,6 +705,11 @@ def test_largest_box_512_properties(H):
     out = g.refine(c, stack, pert)
     assert np.median(synth.angular_error_deg(out, rows)) < np.median(synth.angular_error_deg(pert, rows))
     assert (out[:, 14] >= s_pert - 1e-3).all()
+    # the full band of the largest box: the per-wave ring tables alone take 54 KB of LDS, so k_local must fall back from its LDS address
+    # tables to arithmetic (a launch may ask for 64 KB) - and still rank the true pose first
+    gf = H.Reference(vol, 256)
+    cf = RefineCfg.make(box=n, pixel_size=px, mask_radius=0.32 * n * px, res_high=px * n / 255.0, global_search=0, local_refine=0, res_signed_cc=30.0)
+    assert (gf.refine(cf, stack, rows)[:, 14] > gf.refine(cf, stack, pert)[:, 14]).all()
 
 
 def test_accumulator_sum_is_linear(H, O):
