@@ -834,7 +834,11 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
     auto launch_local = [&](unsigned grid, int threads) {
         const size_t ring = ring_lds_bytes8(threads / 64, kMaxCand, LP.nr);
         const bool tab = local_tab && ring + cube_tab_bytes(LP.tabR) + 2048 <= (size_t)64 * 1024;      // with the kernel's static LDS inside the 64 KB a launch may ask for (box 512 at the full band: arithmetic)
-        const size_t lds = ring + (tab ? cube_tab_bytes(LP.tabR) : 0);
+        size_t lds = ring + (tab ? cube_tab_bytes(LP.tabR) : 0);
+        if (const char *e = getenv("PPM_LOCAL_BLOCKS_PER_CU")) {      // A/B knob: fewer blocks per CU through a larger LDS request (scripts/ab_local.sh)
+            const int bpc = atoi(e);
+            if (bpc > 0 && bpc < 8) lds = std::min((size_t)63 * 1024, std::max(lds, (size_t)(160 * 1024 / (bpc + 1) + 1024) & ~(size_t)1023));
+        }
         if (tab) hipLaunchKernelGGL(k_local<true>, dim3(grid), dim3(threads), lds, cur_stream(), LP);
         else hipLaunchKernelGGL(k_local<false>, dim3(grid), dim3(threads), lds, cur_stream(), LP);
     };
@@ -1872,6 +1876,7 @@ static int sva_align_impl(ppm_ref_t *ref, ppm_accum_t *avg, const ppm_sva_cfg *c
     SvaEvalP EP;
     EP.cv.cube = ref->cube; EP.cv.NBX = ref->NBX; EP.cv.NBY = ref->NBY; EP.cv.LB = ref->LB; EP.cv.off = ref->B + 1; EP.cv.scale = 1.f;
     EP.samples = d_samples.p; EP.bandw = d_bandw.p; EP.F = d_F.p; EP.S = S; EP.N = N; EP.use_wedge = cfg->use_missing_wedge != 0;
+    EP.tabR = ref->B + 4;           // every sample of the band (|k| <= B + 1) and its upper taps
     EP.wedges = d_wedges.p; EP.poses = d_poses.p; EP.delta = d_delta.p; EP.out = d_out.p; EP.vmap = nullptr; EP.partial = d_partial.p;
     std::vector<float> hw((size_t)2 * CH);
     std::vector<double> hdelta, hout;
@@ -1980,7 +1985,18 @@ static int sva_align_impl(ppm_ref_t *ref, ppm_accum_t *avg, const ppm_sva_cfg *c
             acct_gathers += (double)ns_ * EP.S_used * (1 + nr_); acct_sweeps++;
             {
                 ProfScope ps(PPM_K_LOCAL);
-                hipLaunchKernelGGL(k_sva_eval, dim3(ns_, kSvaParts), dim3(256), 0, cur_stream(), EP);
+                // A compass sweep runs best at TWO blocks per CU (8 waves): the seven rotations of a sample patch touch almost the same lines of the
+                // reference, and with 16-20 patches in flight per CU the 32 KB L1 keeps none of them (9.6 L2 requests per load instruction;
+                // search 0.084 ms per sub-volume at 4-5 blocks, 0.080 at 3, 0.075 at 2, 0.113 at 1: scripts/ab_sva.sh).  The blocks per CU are
+                // set through the size of the dynamic LDS request (PPM_SVA_BLOCKS_PER_CU overrides; 0 = whatever the registers allow).
+                int bpc = nr_ == 6 ? 2 : 0;
+                if (const char *e = getenv("PPM_SVA_BLOCKS_PER_CU")) bpc = atoi(e);
+                size_t tab_lds = cube_tab_bytes(EP.tabR);
+                if (bpc > 0 && bpc < 8) tab_lds = std::max(tab_lds, (size_t)(160 * 1024 / (bpc + 1) + 1024) & ~(size_t)1023);      // more than a (bpc + 1)-th of the CU's LDS
+                if (tab_lds > (size_t)64 * 1024) tab_lds = (size_t)64 * 1024;
+                if (nr_ == 0) hipLaunchKernelGGL(k_sva_eval<0>, dim3(ns_, kSvaParts), dim3(256), tab_lds, cur_stream(), EP);
+                else if (nr_ == 6) hipLaunchKernelGGL(k_sva_eval<6>, dim3(ns_, kSvaParts), dim3(256), tab_lds, cur_stream(), EP);
+                else return fail(-22, "ppm_sva_align: a sweep has 0 or 6 rotated candidates");
                 hipLaunchKernelGGL(k_sva_finish, dim3((unsigned)((ns_ * nc + 255) / 256)), dim3(256), 0, cur_stream(), EP.partial, ns_, nc, nr_, d_out.p);
             }
             HIPCHK(hipGetLastError());

@@ -2,6 +2,7 @@
 // band-limited half-space transform, and the wedge-weighted correlation of that transform with the rotated reference for a
 // set of candidate poses (include/ppm.h, ppm_sva_cfg).
 #pragma once
+#include <type_traits>
 #include "ppm_csp_kernels.h"
 
 namespace ppm {
@@ -318,7 +319,8 @@ __global__ void k_sva_gather(const float2 *__restrict__ f, const uint32_t *__res
 struct SvaEvalP {
     CubeView cv; const uint32_t *samples; const float *bandw; const float2 *F; int S, N;
     int S_used; float rmax2;
-    int ncand, nrot, use_wedge;   // candidates per volume; 1 .. nrot are the rotated ones
+    int ncand, nrot, use_wedge;   // candidates per volume; 1 .. nrot are the rotated ones (nrot = the kernel's NROT)
+    int tabR;                     // radius of the LDS address tables (ppm_dev.h)
     const float *wedges;          // [n_vol][2]
     const double *poses;          // [n_vol][12] N row-major + shift
     const double *delta;          // [n_vol][ncand][6]
@@ -332,16 +334,30 @@ constexpr int kSvaParts = 4;
 
 // Block = one sub-volume: thread q < ncand derives candidate q's pose in double precision (rotations about the specimen
 // axes, then the shift, exactly like a particle unit of k_csp_eval).  Candidate layout (host): 0 = the unit's own pose (or the
-// trial pose), 1 .. nrot = rotated candidates (one gather each), the rest keep candidate 0's rotation (shift variants: they
+// trial pose), 1 .. NROT = rotated candidates (one gather each), the rest keep candidate 0's rotation (shift variants: they
 // share its gather).  Every thread accumulates its samples' sums in registers (static indices); the block combines them
 // through LDS in a fixed order.
-#ifndef PPM_SVA_EVAL_MINW
-#define PPM_SVA_EVAL_MINW 1      // blocks of 256 threads per CU the register allocation leaves room for (A/B knob, scripts/ab_r04.sh)
+// Round 4, after the sweep of k_local (ppm_kernels2.h): NROT is a template parameter (0: translation-only and trial sweeps, 6: a
+// compass sweep), so the gathers of rotation c + 1 are issued into a second register set before rotation c is interpolated, with no
+// condition around a fetch; tap addresses come from the LDS tables of ppm_dev.h; the sub-volume's sample is turned by the conjugate
+// phase of the shift once (the rotated candidates keep the unit's shift: checked per block) so that a score term is two instructions
+// on the raw interpolated value.  128 registers instead of 208: four waves per SIMD instead of two.
+#ifdef PPM_SVA_SERIAL        // A/B probe: one rotation's taps at a time (the next rotation finds the lines of this one in L1 if few waves share the CU)
+constexpr bool kSvaSerial = true;
+#else
+constexpr bool kSvaSerial = false;
 #endif
+#ifndef PPM_SVA_EVAL_MINW
+#define PPM_SVA_EVAL_MINW 4      // blocks of 256 threads per CU the register allocation leaves room for
+#endif
+template <int NROT>
 __global__ void __launch_bounds__(256, PPM_SVA_EVAL_MINW) k_sva_eval(SvaEvalP P) {
+    static_assert(NROT >= 0 && NROT < kMaxGroup, "rotated candidates");
     __shared__ float cm[kMaxCand][9], csh[kMaxCand][3];
     __shared__ float red[4][2 * kMaxCand + 1];
-    const int st = blockIdx.x, part = blockIdx.y, v = P.vmap ? P.vmap[st] : st, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ncand = P.ncand, nrot = P.nrot;
+    __shared__ int same_shift;
+    extern __shared__ __attribute__((aligned(8))) char tabmem[];
+    const int st = blockIdx.x, part = blockIdx.y, v = P.vmap ? P.vmap[st] : st, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ncand = P.ncand;
     if (tid < ncand) {
         const double *d = P.delta + ((size_t)st * ncand + tid) * 6, *pose = P.poses + (size_t)st * 12;
         double Nm[9];
@@ -353,7 +369,15 @@ __global__ void __launch_bounds__(256, PPM_SVA_EVAL_MINW) k_sva_eval(SvaEvalP P)
         for (int k = 0; k < 9; k++) cm[tid][k] = (float)Nm[k];
         for (int k = 0; k < 3; k++) csh[tid][k] = (float)(pose[9 + k] + d[3 + k]);
     }
+    const CubeTab tab = cube_tab_fill(P.cv, tabmem, P.tabR, tid, 256);
     __syncthreads();
+    if (tid == 0) {
+        int same = 1;
+        for (int c = 1; c <= NROT; c++) same &= (csh[c][0] == csh[0][0] && csh[c][1] == csh[0][1] && csh[c][2] == csh[0][2]) ? 1 : 0;
+        same_shift = same;
+    }
+    __syncthreads();
+    const bool same = same_shift != 0;
     const float lw = P.wedges[2 * v], uw = P.wedges[2 * v + 1], invN = 1.0f / (float)P.N;
     const float2 *F = P.F + (size_t)v * P.S;
     float A[kMaxCand], B[kMaxGroup], Csum = 0.f;
@@ -361,7 +385,15 @@ __global__ void __launch_bounds__(256, PPM_SVA_EVAL_MINW) k_sva_eval(SvaEvalP P)
     for (int c = 0; c < kMaxCand; c++) A[c] = 0.f;
 #pragma unroll
     for (int g = 0; g < kMaxGroup; g++) B[g] = 0.f;
-    for (int s = part * 256 + tid; s < P.S_used; s += 256 * kSvaParts) {
+    // The sample loop, once for the usual case (the rotated candidates keep candidate 0's shift: SAME) and once for the general one: a
+    // branch INSIDE the sequence of groups splits it into basic blocks, and the compiler then sinks every interpolation below all
+    // fetches (seven tap sets live, spills) - the sequence has to be straight-line code.
+    auto sample_loop = [&](auto same_tag) {
+    constexpr bool SAME = decltype(same_tag)::value;
+    constexpr int C0 = 0, NC = NROT + 1;
+    constexpr bool LEAD = true;
+    const int s_first = part * 256 + tid, s_step = 256 * kSvaParts;
+    for (int s = s_first; s < P.S_used; s += s_step) {
         int kx, ky, kz; sva_unpack(P.samples[s], kx, ky, kz);
         float w = P.bandw[s];
         if (!((float)(kx * kx + ky * ky + kz * kz) < P.rmax2)) w = 0.f;
@@ -375,27 +407,55 @@ __global__ void __launch_bounds__(256, PPM_SVA_EVAL_MINW) k_sva_eval(SvaEvalP P)
         const float2 iv = F[s];
         const float fkx = (float)kx, fky = (float)ky, fkz = (float)kz;
         const float wx = w * iv.x, wy = w * iv.y;
-        Csum += wx * iv.x + wy * iv.y;
-        auto gather = [&](int c) {
-            const float *m = cm[c];
-            return sample_cube(P.cv, m[0] * fkx + m[1] * fky + m[2] * fkz, m[3] * fkx + m[4] * fky + m[5] * fkz, m[6] * fkx + m[7] * fky + m[8] * fkz);
-        };
-        auto corr = [&](const float2 p, int c) {
-            float rev = (fkx * csh[c][0] + fky * csh[c][1] + fkz * csh[c][2]) * invN;
+        if constexpr (LEAD) Csum += wx * iv.x + wy * iv.y;
+        int opq = 0;
+        asm volatile("" : "+v"(opq));           // (see `opaque` below: LDS reads that must not be hoisted out of the sample loop)
+        auto turned = [&](int c, float &bx, float &by) {        // conj of (weighted sample x e^{-i phase of candidate c's shift}): score term = bx p.x + by p.y
+            const float *sh = csh[c] + opq;
+            float rev = (fkx * sh[0] + fky * sh[1] + fkz * sh[2]) * invN;
             rev -= floorf(rev);
             const float sn = __sinf(6.283185307179586f * rev), cs = __cosf(6.283185307179586f * rev);
-            return wx * (p.x * cs - p.y * sn) + wy * (p.x * sn + p.y * cs);
+            bx = wx * cs + wy * sn; by = wy * cs - wx * sn;
         };
-        const float2 p0 = gather(0);
-        B[0] += w * (p0.x * p0.x + p0.y * p0.y);
-        A[0] += corr(p0, 0);
+        float b0x, b0y;
+        turned(0, b0x, b0y);
+        // the candidates' matrices stay in LDS: read through an offset the compiler cannot see through, or it keeps all 7 x 9 (+ 13 x 3 shifts)
+        // loop-invariant values in registers for the whole sample loop (that, not the taps, made the round-3 kernel a 208-register one)
+        int opaque = 0;
+        asm volatile("" : "+v"(opaque));
+        auto fetch = [&](int c) {
+            const float *m = cm[c] + opaque;
+            return cube_fetch_tab(P.cv, tab, m[0] * fkx + m[1] * fky + m[2] * fkz, m[3] * fkx + m[4] * fky + m[5] * fkz, m[6] * fkx + m[7] * fky + m[8] * fkz);
+        };
+        float2 p0 = make_float2(0.f, 0.f);
+        CubeTaps T0 = fetch(C0), T1;
+        // rotation C0 + K is scored while the taps of rotation C0 + K + 1 are in flight (T0 / T1 alternate; all indices are compile-time constants)
+#define PPM_SVA_GROUP(K, CUR, NXT)                                                                                          \
+        if constexpr ((K) < NC) {                                                                                           \
+            constexpr int C = C0 + (K);                                                                                     \
+            if constexpr (!kSvaSerial && (K) + 1 < NC) { NXT = fetch(C + 1); __builtin_amdgcn_sched_barrier(0); }           \
+            if constexpr (kSvaSerial && (K) > 0) { CUR = fetch(C); __builtin_amdgcn_sched_barrier(0); }                     \
+            float bx = b0x, by = b0y;                                                                                       \
+            if constexpr (C > 0 && !SAME) turned(C, bx, by);                                                                \
+            const float2 p = cube_interp(CUR);                                                                              \
+            if constexpr (C == 0) p0 = p;                                                                                   \
+            B[C] += w * (p.x * p.x + p.y * p.y);                                                                            \
+            A[C] += bx * p.x + by * p.y;                                                                                    \
+            asm volatile("" : "+v"(A[C]), "+v"(B[C]));      /* the sums exist HERE: the compiler otherwise sinks every interpolation below the */ \
+                                                            /* branches at the end of the body, i.e. below all fetches (all tap sets live) */ \
+            __builtin_amdgcn_sched_barrier(0);      /* the fetch after next stays behind this group: two tap sets live, not three */ \
+        }
+        PPM_SVA_GROUP(0, T0, T1) PPM_SVA_GROUP(1, T1, T0) PPM_SVA_GROUP(2, T0, T1) PPM_SVA_GROUP(3, T1, T0)
+        PPM_SVA_GROUP(4, T0, T1) PPM_SVA_GROUP(5, T1, T0) PPM_SVA_GROUP(6, T0, T1)
+#undef PPM_SVA_GROUP
+        if constexpr (LEAD) {
 #pragma unroll
-        for (int c = 1; c < kMaxGroup; c++)
-            if (c <= nrot) { const float2 p = gather(c); B[c] += w * (p.x * p.x + p.y * p.y); A[c] += corr(p, c); }
-#pragma unroll
-        for (int c = 1; c < kMaxCand; c++)
-            if (c > nrot && c < ncand) A[c] += corr(p0, c);
+            for (int c = NROT + 1; c < kMaxCand; c++)
+                if (c < ncand) { float bx, by; turned(c, bx, by); A[c] += bx * p0.x + by * p0.y; }
+        }
     }
+    };
+    if (same) sample_loop(std::true_type{}); else sample_loop(std::false_type{});
 #pragma unroll
     for (int c = 0; c < kMaxCand; c++) { const float t = wave_sum(A[c]); if (lane == 0) red[wave][c] = t; }
 #pragma unroll
