@@ -1564,6 +1564,7 @@ extern "C" int ppm_csp_refine(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const p
     EP.cv.cube = ref->cube; EP.cv.NBX = ref->NBX; EP.cv.NBY = ref->NBY; EP.cv.LB = ref->LB; EP.cv.off = ref->B + 1; EP.cv.scale = (float)ref->pad;
     EP.samples = ref->samples.p; EP.Il = Il.p; EP.cw = cw.p; EP.S_pad = S_pad; EP.N = gm.N; EP.nr = nrings;
     EP.tabR = cube_tab_radius(gm.B, EP.cv.scale);
+    const int csp_bpc = getenv("PPM_CSP_BLOCKS_PER_CU") ? atoi(getenv("PPM_CSP_BLOCKS_PER_CU")) : 0;      // blocks of k_csp_eval per CU through the LDS request (0: what registers and LDS allow)
     const bool csp_tab = !(getenv("PPM_LOCAL_TABLES") && atoi(getenv("PPM_LOCAL_TABLES")) == 0) && cube_tab_bytes(EP.tabR) <= 16 * 1024 &&
                          ring_lds_bytes8(4, kMaxCand, nrings) + cube_tab_bytes(EP.tabR) + 2048 <= (size_t)64 * 1024;
     EP.rlo2 = (float)(gm.r_lo * gm.r_lo); EP.ring_signed = (float)std::min(gm.ring_signed, 1e30);
@@ -1595,7 +1596,8 @@ extern "C" int ppm_csp_refine(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const p
         {
             ProfScope ps(PPM_K_LOCAL);
             {
-                const size_t lds = ring_lds_bytes8(4, kMaxCand, nrings) + (csp_tab ? cube_tab_bytes(EP.tabR) : 0);
+                size_t lds = ring_lds_bytes8(4, kMaxCand, nrings) + (csp_tab ? cube_tab_bytes(EP.tabR) : 0);
+                if (csp_bpc > 0 && csp_bpc < 8) lds = std::min((size_t)63 * 1024, std::max(lds, (size_t)(160 * 1024 / (csp_bpc + 1) + 1024) & ~(size_t)1023));
                 if (csp_tab) hipLaunchKernelGGL(k_csp_eval<true>, dim3((unsigned)rows_list.size()), dim3(256), lds, cur_stream(), EP);
                 else hipLaunchKernelGGL(k_csp_eval<false>, dim3((unsigned)rows_list.size()), dim3(256), lds, cur_stream(), EP);
             }
