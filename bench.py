@@ -138,7 +138,7 @@ def pmc_latest(workload):
     return os.path.basename(c[-1]) if c else "r02_pmc_%s.json" % workload
 
 
-def pmc_entry(summary, kernel):
+def pmc_entry(summary, kernel, merge=False):
     """One kernel's counters from a committed rocprofv3 --pmc summary (scripts/pmc_r02.sh -> scripts/pmc_summary.py).
     Returns (entry, meta) or (None, None)."""
     path = os.path.join(ROOT, "profiles", summary)
@@ -147,6 +147,15 @@ def pmc_entry(summary, kernel):
     d = json.load(open(path))
     meta = d.get("_meta", {})
     key = [k for k in d if kernel in k]
+    if len(key) > 1 and merge:            # template instances of one kernel (k_sva_eval<0>, k_sva_eval<6>): counters added up
+        out = {}
+        for k in key:
+            for c, v in d[k].items():
+                o = out.setdefault(c, {"sum": 0.0, "dispatches": 0})
+                o["sum"] += v["sum"]; o["dispatches"] += v["dispatches"]
+        for v in out.values():
+            v["per_dispatch"] = v["sum"] / max(v["dispatches"], 1)
+        return out, meta
     return (d[key[0]], meta) if key else (None, meta)
 
 
@@ -648,7 +657,7 @@ def gather_roofline(kernel, summary_workload, ms_total, launches, gathers_total,
     gpl, upl = gathers_total / launches, units_total / launches
     tf = 70.0 * gpl / (ms * 1e-3) / 1e12
     # HBM-side bytes of ONE launch: the summary's average per dispatch (every sweep is a dispatch over all profiled units), scaled by units
-    e, meta = pmc_entry(pmc_latest(summary_workload), kernel)
+    e, meta = pmc_entry(pmc_latest(summary_workload), kernel, merge=True)
     traffic, src = None, "no FETCH_SIZE / WRITE_SIZE summary for %s under profiles/%s" % (kernel, pmc_latest(summary_workload))
     if e and "FETCH_SIZE" in e and "WRITE_SIZE" in e and meta.get("particles"):
         traffic = (2.0 * e["FETCH_SIZE"]["per_dispatch"] + e["WRITE_SIZE"]["per_dispatch"]) * 1024.0 * upl / meta["particles"]
