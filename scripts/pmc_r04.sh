@@ -18,7 +18,9 @@ case "$W" in
   csp)         ARGS="--workload csp --csp-particles $N --steps 1 --warmup 0 --no-cpu --no-side"; TCC="TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum"; UNITS=$((N * 41));;
   *)           ARGS="--workload refine --particles $N --steps 1 --warmup 0 --no-cpu --no-dropin"; TCC="TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum";;
 esac
-GROUPS_=("${COMMON[@]}" "$TCC" "FETCH_SIZE" "WRITE_SIZE")
+# vector L1 of the gather kernels (k_local, k_csp_eval, k_sva_eval): lines looked up, requests sent on to L2, texture-addresser busy
+TCP="TA_BUSY_avr TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum"
+GROUPS_=("${COMMON[@]}" "$TCC" "$TCP" "FETCH_SIZE" "WRITE_SIZE")
 i=0
 for grp in "${GROUPS_[@]}"; do
   i=$((i+1))
