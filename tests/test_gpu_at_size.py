@@ -38,6 +38,30 @@ def test_sva_align_at_192_matches_oracle_on_four_sub_volumes():
     assert np.array_equal(got, got_h) and np.array_equal(gsc, gsc_h)
 
 
+def test_sva_average_at_192_matches_oracle_on_four_sub_volumes():
+    """ppm_sva_insert at config 5's box (full 192^3 transforms through the two-step passes, wedge-weighted gather into the half maps)
+    against orc_sva_insert on the same four sub-volumes: weights equal except where a wedge edge flips a voxel between float and
+    double, values to float32 round-off; the counts follow the index parity."""
+    from oracle import oracle as O
+    from pyp_amd import host
+    n = 192
+    vol, vols, poses, wedges = synth.make_subtomograms(n, 4, snr=0.3, device="cuda", seed=11)
+    poses = synth.perturb_poses(poses, 1.0, 0.5)
+    cfg = SvaCfg.make(n, use_missing_wedge=1)
+    index = np.array([3, 4, 8, 11])
+    want, cnt = np.zeros(O.accum_floats(n), np.float32), np.zeros(2, np.int64)
+    O.sva_insert(want, cnt, cfg, vols.cpu().numpy(), wedges, poses, index)
+    acc = host.Accumulator(n, 1.0, "C1")
+    acc.sva_insert(cfg, vols, wedges, poses, index)
+    got = acc.download()
+    assert acc.counts() == [int(cnt[0]), int(cnt[1])] == [2, 2]
+    acc.close()
+    w, g = want.reshape(-1, 3), got.reshape(-1, 3)
+    assert np.abs(g[:, 2] - w[:, 2]).sum() <= 1e-4 * w[:, 2].sum()
+    ok = g[:, 2] == w[:, 2]
+    assert ok.mean() > 0.9999 and np.linalg.norm((g - w)[ok, :2]) < 2e-5 * np.linalg.norm(w[:, :2])
+
+
 def test_sva_align_at_192_properties_on_64_sub_volumes():
     """Two launches of 32 sub-volumes: every alignment improves, the batch result does not depend on the batch it ran in, repeat
     runs are bit-identical, and the bounds of the protocol hold."""
