@@ -422,6 +422,7 @@ const char *ppm_version(void) { return "pypmatch 0.1 (gfx950)"; }
 int ppm_init(int device) {
     static std::mutex init_mu;                       // a caller may start the device from a helper thread and call again from its main thread
     std::lock_guard<std::mutex> lk(init_mu);
+    const auto t_init0 = std::chrono::steady_clock::now();
     if (g.inited && g.device == device) { (void)hipSetDevice(device); return 0; }      // the current device is a per-thread setting
     if (g.inited) return fail(-16, "libpypmatch is bound to device " + std::to_string(g.device) + " in this process (one process per GPU); start another process for device " + std::to_string(device));
     int count = 0;
@@ -441,11 +442,15 @@ int ppm_init(int device) {
     if (!g.stream) HIPCHK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     if (!g.copy) HIPCHK(hipStreamCreateWithFlags(&g.copy, hipStreamNonBlocking));
     if (!g.upload) HIPCHK(hipStreamCreateWithFlags(&g.upload, hipStreamNonBlocking));
+    const auto t_ctx = std::chrono::steady_clock::now();
     // the code object is loaded at the first launch (tens of ms): here, where a caller can overlap it with its own start-up
     hipLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, g.stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(g.stream));
     g.device = device; g.inited = true;
+    if (getenv("PPM_TRACE"))
+        fprintf(stderr, "ppm_init: context + streams %.1f ms, code object + first launch %.1f ms\n",
+                std::chrono::duration<double, std::milli>(t_ctx - t_init0).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_ctx).count());
     return 0;
 }
 
