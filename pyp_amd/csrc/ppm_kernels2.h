@@ -177,11 +177,7 @@ __device__ __forceinline__ void sweep_plan(SweepPlan &plan, const SweepCtx &C, c
     const bool head = (lane & 15) == 0;
     float accC = 0.f;
     for (int s0 = 0; s0 < S_used; s0 += nthr) {
-#ifdef PPM_DBG_HALFDUP      // timing probe (results wrong): lanes 32-63 repeat the samples of lanes 0-31 - half the distinct lines per load instruction
-        const int s = s0 + (tid & ~32);
-#else
         const int s = s0 + tid;
-#endif
         int kx = 0, ky = 0, al = 0, ring = 0;
         float2 iv = make_float2(0.f, 0.f); float c = 0.f;
         if (s < S_used) {
