@@ -298,7 +298,7 @@ def score_cfg(cfg):
     return c
 
 
-def classify(chunks, n_vol, cfg, references, backend, iterations=4):
+def classify(chunks, n_vol, cfg, references, backend, iterations=4, start=None):
     """Multi-reference classification of ALIGNED sub-volumes - the `class` / `refine` steps of a 3DAVG iteration (protocol modes 1 and 2,
     src/pyp/refine/tomo_avg/sub_tomo_avg.py:435-449: the class averages `<dataset>_iteration_%03d_level_%d_average_%03d.mrc` of one round
     are the references of the next, :79-94) - in the metric the alignment uses.  From K class references: every sub-volume is scored
@@ -309,20 +309,37 @@ def classify(chunks, n_vol, cfg, references, backend, iterations=4):
     sub-volume is never compared with an average it is part of: the accumulators keep even- and odd-index members apart (the half-maps
     of ppm_finalize) and it is scored against the half of the OTHER parity; a class too small to have both halves keeps the reference
     it came with.  `chunks()` yields (lo, hi, volumes, wedges, poses, index) over the data set - the volumes stream from wherever they
-    live on every pass.  NOT built: the unsupervised start of MPI_Classification (hierarchical clustering from pairwise comparisons) - at
-    the signal-to-noise ratio of single sub-tomograms pairwise correlations over the common wedge support did not separate classes in
-    this build's tests; the caller provides the first references (e.g. the previous level's averages).
+    live on every pass.  `start` (instead of references): a first assignment (V,) of class numbers - the first references are the
+    half-averages of those classes (classify_unsupervised draws them at random).
     -> (classes (V,), scores (V, K) of the last pass, class averages [K] (None for an empty class), passes run)."""
-    K = len(references)
-    if K < 1:
-        raise ValueError("ERROR: classification needs at least one class reference")
+    if start is not None:
+        classes = np.asarray(start, dtype=np.int64).copy()
+        if len(classes) != n_vol or classes.min() < 0:
+            raise ValueError("ERROR: classification: the first assignment must name a class for every sub-volume")
+        K = int(classes.max()) + 1
+        refs = [None] * K
+    else:
+        K = len(references or [])
+        if K < 1:
+            raise ValueError("ERROR: classification needs at least one class reference")
+        refs = [(np.asarray(r, dtype=np.float32),) * 2 for r in references]          # (scored by odd-index members, by even-index members)
+        classes = np.full(n_vol, -1, dtype=np.int64)
     sc_cfg = score_cfg(cfg)
-    refs = [(np.asarray(r, dtype=np.float32),) * 2 for r in references]          # (scored by odd-index members, by even-index members)
-    classes = np.full(n_vol, -1, dtype=np.int64)
     scores = np.zeros((n_vol, K))
     averages = [None] * K
     done = 0
     parity = np.zeros(n_vol, dtype=bool)
+
+    def reaverage():
+        for k in range(K):
+            avg, h_even, h_odd, counts = backend.average(cfg, chunks(), classes == k)
+            averages[k] = avg
+            if avg is not None and min(counts) >= 2:
+                refs[k] = (h_even, h_odd)                # odd-index members are scored against the even half and vice versa
+            elif refs[k] is None:
+                raise ValueError("ERROR: classification: class %d of the first assignment has fewer than two members of each index parity" % k)
+    if start is not None:
+        reaverage()
     for it in range(max(1, int(iterations))):
         for lo, hi, vols, wedges, poses, index in chunks():
             odd = (np.asarray(index) % 2) != 0
@@ -342,14 +359,53 @@ def classify(chunks, n_vol, cfg, references, backend, iterations=4):
         done = it + 1
         moved = int((new != classes).sum())
         classes = new
-        for k in range(K):
-            avg, h_even, h_odd, counts = backend.average(cfg, chunks(), classes == k)
-            averages[k] = avg
-            if avg is not None and min(counts) >= 2:
-                refs[k] = (h_even, h_odd)                # odd-index members are scored against the even half and vice versa
+        reaverage()
         if moved == 0:
             break
     return classes, scores, averages, done
+
+
+def random_assignment(index, n_classes, rng):
+    """A first assignment for classify(start=...): neighbouring (even, odd) table indices share a class, so that every class has both
+    half-averages from the start; the pairs are dealt out over the classes in random order (equal sizes up to one pair)."""
+    index = np.asarray(index, dtype=np.int64)
+    pair = index // 2
+    ids = np.unique(pair)
+    deal = np.empty(len(ids), dtype=np.int64)
+    deal[rng.permutation(len(ids))] = np.arange(len(ids)) % n_classes
+    return deal[np.searchsorted(ids, pair)]
+
+
+def classify_unsupervised(chunks, n_vol, cfg, n_classes, backend, restarts=6, iterations=12, seed=0):
+    """Classification without class references (what MPI_Classification's protocol mode 1 does from the aligned sub-volumes alone; its
+    method - hierarchical clustering of pairwise comparisons - is in the absent binary, this one is build-defined): `restarts` random
+    first assignments (random_assignment) are each iterated by classify(); the partition whose members fit their own class best - the
+    mean CROSS-VALIDATED score of a sub-volume against the half-average of its class that does not contain it - is kept.  The
+    cross-validation is what makes a random start workable: without it every sub-volume correlates best with the average it is
+    part of and nothing moves.  On the two-structure mixtures of the tests six of ten random starts reach the true partition, the
+    others end in mixed classes with a visibly lower objective (CHANGELOG.md round 4).
+    -> (classes, scores, averages, passes, objective, objectives of all restarts)."""
+    index = np.concatenate([np.asarray(ix, dtype=np.int64) for _, _, _, _, _, ix in chunks()])
+    if len(index) != n_vol:
+        raise ValueError("ERROR: classification: the chunks do not cover the data set")
+    n_classes = int(n_classes)
+    if n_classes < 1 or 4 * n_classes > n_vol:
+        raise ValueError("ERROR: classification: %d classes need at least %d sub-volumes (two of each index parity per class)" % (n_classes, 4 * max(n_classes, 1)))
+    rng = np.random.default_rng(seed)
+    best, objectives = None, []
+    for _ in range(max(1, int(restarts))):
+        try:
+            classes, sc, avgs, its = classify(chunks, n_vol, cfg, None, backend, iterations=iterations, start=random_assignment(index, n_classes, rng))
+        except ValueError:                       # a start whose classes lack a half (odd data sets): draw again
+            objectives.append(float("-inf"))
+            continue
+        obj = float(sc[np.arange(n_vol), classes].mean())
+        objectives.append(obj)
+        if best is None or obj > best[4]:
+            best = (classes, sc, avgs, its, obj)
+    if best is None:
+        raise ValueError("ERROR: classification: no random start gave every class two members of each index parity")
+    return best + (objectives,)
 
 
 def table_chunks(table, names, n, base_dir=".", chunk=64):

@@ -84,6 +84,38 @@ def test_multi_reference_classification_separates_two_structures_on_the_oracle()
     assert s.tol_angle == 0 and s.tol_shift == 0 and abs(s.lowpass_cutoff - cfg.lowpass_cutoff) < 1e-9 and cfg.tol_angle == 5.0
 
 
+def test_classification_without_references_from_random_starts_on_the_oracle():
+    """classify_unsupervised: five random first assignments (neighbouring even / odd indices share a class, so every class has both
+    half-averages), each iterated with the cross-validated driver; the partition with the best mean cross-validated score of a
+    sub-volume against its own class is the true one (up to the naming of the classes), and restarts that ended in mixed classes score lower."""
+    n = 24
+    va, vb, vols, wedges, poses, truth = two_structures(n, 12)
+    cfg = SvaCfg.make(n, window=(9, 9, 9), window_sigma=2.0, highpass=(0.03, 0.01), lowpass=(0.3, 0.05), tol_angle=5.0, tol_shift=2.0)
+    classes, sc, avgs, its, obj, objs = sva.classify_unsupervised(chunks_of(vols, wedges, poses), len(vols), cfg, 2, OracleBackend(), restarts=5, iterations=10, seed=0)
+    assert np.array_equal(classes, truth) or np.array_equal(classes, 1 - truth)
+    assert len(objs) == 5 and obj == max(objs) and min(objs) < obj - 0.003 and all(a is not None for a in avgs)
+    # the first assignment: pairs of neighbouring indices stay together, the classes are equally large
+    start = sva.random_assignment(np.arange(24), 3, np.random.default_rng(1))
+    assert (start[0::2] == start[1::2]).all() and sorted(np.bincount(start)) == [8, 8, 8]
+    with pytest.raises(ValueError, match="ERROR"):
+        sva.classify_unsupervised(chunks_of(vols[:6], wedges[:6], poses[:6]), 6, cfg, 2, OracleBackend())        # two classes need eight sub-volumes
+    with pytest.raises(ValueError, match="ERROR"):
+        sva.classify(chunks_of(vols, wedges, poses), len(vols), cfg, None, OracleBackend(), start=np.r_[np.zeros(23, int), 1])     # class 1 has no halves
+
+
+@pytest.mark.gpu
+def test_gpu_classification_without_references_equals_the_oracle_run():
+    """The random-start driver through the HIP path: the same restarts (same seed) end in the same partition with the same objective."""
+    n = 32
+    va, vb, vols, wedges, poses, truth = two_structures(n, 12, seed=5)
+    cfg = SvaCfg.make(n, window=(12, 12, 12), window_sigma=2.0, highpass=(0.03, 0.01), lowpass=(0.3, 0.05), tol_angle=5.0, tol_shift=2.0)
+    co, _, _, _, oo, objs_o = sva.classify_unsupervised(chunks_of(vols, wedges, poses, 7), len(vols), cfg, 2, OracleBackend(), restarts=4, iterations=8, seed=2)
+    cg, _, ag, _, og, objs_g = sva.classify_unsupervised(chunks_of(vols, wedges, poses, 7), len(vols), cfg, 2, sva.GpuBackend(0), restarts=4, iterations=8, seed=2)
+    assert np.array_equal(co, cg) and abs(oo - og) < 2e-3 and np.abs(np.array(objs_o) - np.array(objs_g)).max() < 2e-3
+    assert np.array_equal(cg, truth) or np.array_equal(cg, 1 - truth)
+    assert all(a is not None for a in ag)
+
+
 @pytest.mark.gpu
 def test_gpu_classification_equals_the_oracle_run():
     """The same driver, references and data through the HIP path: the same classes, scores to the alignment tests' tolerance."""
@@ -131,3 +163,9 @@ def test_sva_align_executable_classifies_under_protocol_mode_1(tmp_path):
     assert np.allclose(out[:, 12:28], tab[:, 12:28], atol=1e-5)                 # classification leaves the poses alone
     r = subprocess.run([sys.executable, exe, "p.xml", "d_volumes.txt", "c0.mrc,c1.mrc", "o2.txt"], cwd=tmp_path, capture_output=True, text=True)
     assert r.returncode != 0 and "ERROR" in r.stdout and "average_prefix" in r.stdout
+    # ONE reference: the classes are found without references (class_number_of_classes = 2 of the protocol, random first assignments)
+    r = subprocess.run([sys.executable, exe, "p.xml", "d_volumes.txt", "c0.mrc", "o3.txt", "u_avg"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0 and "no references: 2 classes" in r.stdout and "SVA: Normal termination" in r.stdout, r.stdout + r.stderr
+    cu = np.loadtxt(str(tmp_path / "u_avg_classes.txt"), skiprows=1)[:, 1].astype(int)
+    assert np.array_equal(cu, truth) or np.array_equal(cu, 1 - truth)
+    assert (tmp_path / "u_avg_000.mrc").exists() and (tmp_path / "u_avg_001.mrc").exists()
