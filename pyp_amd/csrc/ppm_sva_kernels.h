@@ -113,7 +113,7 @@ __device__ __forceinline__ void fft16m(float2 *buf, int nl, int N, int LS, const
         __syncthreads();
     }
     for (int task = tid; task < nl * 16; task += 256) {
-        const int k2 = task / nl, line = task - k2 * nl;          // line fastest: a wave's stores are runs of nl values
+        const int k2 = task / nl, line = task - k2 * nl;          // line fastest: a wave's stores are runs of nl values (k2 fastest for the in-place z pass: no gain)
         const float2 *row = buf + line * LS + k2 * M;
         if constexpr (MT > 0) {
             float2 v[MT];
@@ -207,16 +207,23 @@ __global__ void __launch_bounds__(256) k_sva_x16(SvaX16P P) {
     if (tid < nl) wyz[tid] = win1(y0 + tid - n / 2, 1) * win1(z - n / 2, 2);
     __syncthreads();
     {
-        const int dl = 256 / n, de = 256 % n;
-        int line = tid / n, e = tid % n;
-        const float *src = P.vol + l0 * n;
+        const float *src1 = P.vol + l0 * n;
+        const bool vec = P.mode == 2 || (((size_t)src1) & 15) == 0;    // n is a multiple of 16: four voxels per load unless the caller's pointer is oddly aligned
+        const float4 *src = (const float4 *)src1;
         double s1 = 0, s2 = 0;
-        for (int i = tid; i < nl * n; i += 256) {
-            const float x = P.mode == 2 ? 1.f : src[i];
-            if (P.mode == 1) { s1 += (double)x; s2 += (double)x * (double)x; }
-            buf[line * LS + e] = make_float2((x - fmu) * finv * (wx[e] * wyz[line]), 0.f);
-            line += dl; e += de;
-            if (e >= n) { e -= n; line++; }
+        const int n4 = n >> 2;
+        for (int i4 = tid; i4 < nl * n4; i4 += 256) {
+            const int line = i4 / n4, e = (i4 - line * n4) << 2;
+            float4 x4 = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (P.mode != 2) x4 = vec ? src[i4] : make_float4(src1[4 * i4], src1[4 * i4 + 1], src1[4 * i4 + 2], src1[4 * i4 + 3]);
+            const float xs[4] = { x4.x, x4.y, x4.z, x4.w };
+            const float wl = wyz[line];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const float x = xs[c];
+                if (P.mode == 1) { s1 += (double)x; s2 += (double)x * (double)x; }
+                buf[line * LS + e + c] = make_float2((x - fmu) * finv * (wx[e + c] * wl), 0.f);
+            }
         }
         if (P.mode == 1) {
             __shared__ double r1[4], r2[4];
@@ -261,7 +268,15 @@ __global__ void __launch_bounds__(256) k_sva_yz16(SvaYZ16P P) {
         const int nl = (int)((P.nlines - l0) < P.L ? (P.nlines - l0) : P.L);
         if (nl <= 0) return;
         float2 *base = P.B + l0 * n;
-        for (int i = tid; i < nl * n; i += 256) { const int line = i / n, e = i - line * n; buf[line * LS + e] = base[i]; }
+        {   // two complex values per load (n is even; B is 16-byte aligned and so is every line of it)
+            const float4 *b4 = (const float4 *)base;
+            const int n2 = n >> 1;
+            for (int i2 = tid; i2 < nl * n2; i2 += 256) {
+                const int line = i2 / n2, e = (i2 - line * n2) << 1;
+                const float4 v = b4[i2];
+                buf[line * LS + e] = make_float2(v.x, v.y); buf[line * LS + e + 1] = make_float2(v.z, v.w);
+            }
+        }
         __syncthreads();
         fft16m_any<false>(buf, nl, n, LS, tw_s, tid, need, [&](int line, int k, float2 val) { base[(long)line * n + k] = val; });
     } else {
@@ -269,9 +284,13 @@ __global__ void __launch_bounds__(256) k_sva_yz16(SvaYZ16P P) {
         const int zb = blockIdx.x % zblocks, kx = (blockIdx.x / zblocks) % KX;
         const long v = blockIdx.x / ((long)zblocks * KX);
         const int z0 = zb * P.L, nl = P.L;
-        for (int i = tid; i < nl * n; i += 256) {
-            const int line = i / n, e = i - line * n;
-            buf[line * LS + e] = P.A[((v * n + z0 + line) * KX + kx) * (long)n + e];
+        {
+            const int n2 = n >> 1;
+            for (int i2 = tid; i2 < nl * n2; i2 += 256) {
+                const int line = i2 / n2, e = (i2 - line * n2) << 1;
+                const float4 v4 = *(const float4 *)(P.A + ((v * n + z0 + line) * KX + kx) * (long)n + e);
+                buf[line * LS + e] = make_float2(v4.x, v4.y); buf[line * LS + e + 1] = make_float2(v4.z, v4.w);
+            }
         }
         __syncthreads();
         float2 *dst = P.B + ((v * KX + kx) * KY) * (long)n + z0;
