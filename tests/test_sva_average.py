@@ -163,6 +163,24 @@ def test_two_iterations_align_average_align_improve_the_score():
     assert np.median(e2) <= np.median(e1) + 0.05 and np.median(e2) < np.median(synth.pose_angle_error(start, poses))
 
 
+@pytest.mark.gpu
+def test_empty_and_single_inputs_are_no_ops_not_faults():
+    """Zero sub-volumes: alignment returns empty arrays, insertion leaves the accumulator untouched; one sub-volume lands in the half its
+    index parity names (the reference's tests feed ragged tables: the edge of the range must not reach a kernel with a zero grid)."""
+    from pyp_amd import host as H
+    n = 32
+    vol, vols, poses, wedges = synth.make_subtomograms(n, 2, snr=0.5)
+    cfg = SvaCfg.make(n, use_missing_wedge=1, tol_angle=5.0, tol_shift=2.0)
+    out, sc = H.Reference(vol, n / 2).sva_align(cfg, vols.numpy()[:0], wedges[:0], poses[:0])
+    assert out.shape == (0, 12) and sc.shape == (0,)
+    acc = H.Accumulator(n, 1.0, "C1")
+    acc.sva_insert(cfg, vols.numpy()[:0], wedges[:0], poses[:0], np.zeros(0, np.int64))
+    assert acc.counts() == [0, 0] and not acc.download().any()
+    acc.sva_insert(cfg, vols.numpy()[:1], wedges[:1], poses[:1], np.array([5]))
+    assert acc.counts() == [0, 1]
+    acc.close()
+
+
 def test_filtered_map_applies_the_protocol_window_and_band_pass():
     """`<average>_filtered.mrc`: the map as the metric sees it - zero outside the (hard) window, and a plane wave inside the pass band
     survives while one beyond the low-pass is removed."""
