@@ -1,0 +1,321 @@
+// ppm_gfft.h — global search over WIDE shift windows: the whole correlation image of every (particle, orientation) by a pruned
+// two-dimensional transform in registers and LDS (gfx950 only).
+//
+// PYP's default call sends "search range X / Y" = 0 = the mask radius (frealign.py:3954-3957, config/pyp_config.toml:5338-5350):
+// at a 256 box and a 4 A search band that is +-41 steps of the 128-point search grid — 83 x 83 shifts per orientation, where
+// k_global's register-held window of <= 17 x 17 needs 25 passes over the slice bank.  Here a block owns one particle and, per
+// stored slice (which serves psi and psi + 180 deg), computes
+//
+//     c(sx, sy) = Re sum_{kx >= 0, ky} W(k) conj(P(k)) e^{+2 pi i (kx sx + ky sy) / Ns},    Ns = 2 L,
+//
+// for all shifts of the window as the oracle's zero-filled inverse transform does (oracle/ppm_oracle.c ccf_peak mode 0), in two
+// passes that each keep a whole line in the registers of one thread (ppm_fft_reg.h):
+//
+//  * COLUMN pass, lane = kx: the transform over ky.  A thread forms x[n] = W conj(P) (or W P for psi + 180) for ky = n and
+//    ky = n - L straight from the bank row (one 16-byte load: the bank stores the two rows side by side) and the particle's
+//    W table in LDS (one 16-byte read), takes the first decimation-in-frequency step on the way — y[n] = x[n] + x[n + L] gives
+//    the even output rows, (x[n] - x[n + L]) w^n the odd ones — and runs an L-point transform on its 64 registers.  The four
+//    waves of a block are the four (orientation, row parity) combinations, so the sign pattern is wave-uniform code, not data.
+//    The rows inside the window go to the LDS image T[orientation][sy][kx].
+//  * ROW pass, thread = one row (orientation, sy): the real 2 L-point transform over kx through one L-point complex transform
+//    (Z[k] = (X[k] + conj X[L-k]) + i w^k (X[k] - conj X[L-k]); its output is c(2n) + i c(2n+1)), then the maximum over the
+//    window's columns.  Only the MAXIMUM is formed per orientation — the shift of an orientation matters only for the K best
+//    of them, so after the top-K selection the K winning slices are transformed once more with the arg-max switched on
+//    (K / n_orient = 0.5 % more work instead of two compare-selects per correlation value everywhere).
+//
+// LDS at L = 64: W 64 KB + T 2 x (2 RSy + 1) x 66 x 8 B (86 KB at RSy = 41) — one block per CU, one wave per SIMD; a single wave
+// issues one instruction per four cycles, which a packed instruction fills (scripts/micro/fft_reg_bench: a 64-point transform
+// costs 2 840 cycles at one wave per SIMD against 2 500 at two).  Smaller search grids put 64 / L slices into one pass.
+#pragma once
+#include "ppm_fft_reg.h"
+
+namespace ppm {
+
+struct GfftP {
+    const float4 *bank4;     // [nslices][L][L]: (P(ky = n, kx), P(ky = n - L, kx)), zero outside the search band (k_bank4)
+    const float2 *Wp;        // [n][Hs][64] search tables of the chunk (k_prep), rows ky + Bs
+    const float *nP, *nI;    // slice norms [n][nslices] (k_slice_norms), image norms [n]
+    const float2 *twN;       // e^{2 pi i t / Ns}, t = 0 .. Ns - 1
+    const float2 *penpos;    // [L] pairs: 0 or -3e38 for the columns sx(2 f), sx(2 f + 1) with f = freq_at(L, position)
+    float *part;             // [n][n_orient][NPART] raw window maxima
+    float *cc;               // [n][n_orient] scores for the top-K pass when they do not fit the LDS
+    Hit *hits;               // [n][K]
+    int n, Bs, Hs, RSx, RSy, n_dir, n_psi, npsi_store, n_orient, K, topk_lds;
+    int RC, nchunk;          // rows of T held at a time, and how many such chunks cover the 2 RSy + 1 rows (1 unless LDS is short)
+    int t_bytes;             // bytes of the T image (the small arrays follow it)
+};
+
+constexpr int gfft_row_stride(int L) { return L + 2; }       // float2 per T row: 16-byte row reads of 64 lanes hit distinct banks
+constexpr int gfft_slices_per_pass(int L) { return 64 / L; }
+constexpr size_t gfft_small_bytes() { return 256 * 8 + PPM_MAX_TOP_HITS * 8 + 256; }
+
+// a * conj(w), both in VGPR pairs
+__device__ __forceinline__ fr::v2f cmulc_v(fr::v2f a, fr::v2f w) {
+    fr::v2f t, d;
+    asm("v_pk_mul_f32 %1, %2, %3 op_sel_hi:[1,0]\n\tv_pk_fma_f32 %0, %2, %3, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(d), "=&v"(t) : "v"(a), "v"(w));
+    return d;
+}
+
+// ---------------------------------------------------------------------------------- slice bank in the layout of the column pass
+struct Bank4P { CubeView cv; const float *mats; float4 *bank4; int nslices, Bs, L; float r_s2; };
+
+__global__ void __launch_bounds__(256) k_bank4(Bank4P P) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, per = (size_t)P.L * P.L;
+    if (i >= per * P.nslices) return;
+    const int sl = (int)(i / per), r = (int)(i - (size_t)sl * per), n = r / P.L, kx = r - n * P.L;
+    const float *m = P.mats + (size_t)sl * 6;
+    float2 v[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int ky = h ? n - P.L : n;
+        const float k2 = (float)(kx * kx + ky * ky);
+        v[h] = make_float2(0.f, 0.f);
+        if (kx <= P.Bs && ky >= -P.Bs && ky <= P.Bs && k2 < P.r_s2) {
+            const float fx = (float)kx, fy = (float)ky;
+            v[h] = sample_cube(P.cv, m[0] * fx + m[1] * fy, m[2] * fx + m[3] * fy, m[4] * fx + m[5] * fy);
+        }
+    }
+    P.bank4[i] = make_float4(v[0].x, v[0].y, v[1].x, v[1].y);
+}
+
+// ---------------------------------------------------------------------------------- the column pass of one thread
+// y[n] = x[n] + x[n + L] (H = 0) or (x[n] - x[n + L]) w^n (H = 1), x = W conj(P) (E = 0) or W P (E = 1); bp / wl point at this
+// lane's column of the bank slice / of the W table.  Bank rows travel D rows ahead of their use (one wave per SIMD: nothing
+// else hides the L2 / Infinity-Cache latency), LDS rows DW ahead.
+template <int L, int E, int H>
+__device__ __forceinline__ void gfft_col_products(fr::v2f (&y)[L], const float4 *__restrict__ bp, const float4 *wl, fr::TwPtr tw) {
+    using namespace fr;
+    constexpr int D = L < 16 ? L : 16, DW = L < 4 ? L : 4;
+    float4 pb[D], wb[DW];
+    static_for<0, D>([&](auto ic) { constexpr int i = decltype(ic)::value; pb[i] = bp[i * L]; });
+    static_for<0, DW>([&](auto ic) { constexpr int i = decltype(ic)::value; wb[i] = wl[i * L]; });
+    static_for<0, L>([&](auto nc) {
+        constexpr int n = decltype(nc)::value;
+        const float4 p4 = pb[n % D], w4 = wb[n % DW];
+        if constexpr (n + D < L) pb[n % D] = bp[(n + D) * L];
+        if constexpr (n + DW < L) wb[n % DW] = wl[(n + DW) * L];
+        const v2f pa = { p4.x, p4.y }, pbv = { p4.z, p4.w }, wa = { w4.x, w4.y }, wbv = { w4.z, w4.w };
+        v2f t = E ? cmul_v(wa, pa) : cmulc_v(wa, pa);
+        if constexpr (H) t = E ? cmsub_v(t, wbv, pbv) : cmsub_conj_v(t, wbv, pbv);
+        else t = E ? cmac_v(t, wbv, pbv) : cmac_conj_v(t, wbv, pbv);
+        if constexpr (H && n > 0) t = cmul_s(t, tw[n]);
+        y[n] = t;
+    });
+}
+
+// maximum over groups of W consecutive lanes (W = 16, 32, 64), every lane gets its group's result; full EXEC required
+template <int W> __device__ __forceinline__ float group_max(float v) {
+    v = max_raw(v, dpp_mov<kDppXor1>(v)); v = max_raw(v, dpp_mov<kDppXor2>(v)); v = max_raw(v, dpp_mov<kDppHalfMirror>(v)); v = max_raw(v, dpp_mov<kDppMirror>(v));
+    if constexpr (W >= 32) { float w = v; lane_swap<16>(v, w); v = max_raw(v, w); }
+    if constexpr (W >= 64) { float w = v; lane_swap<32>(v, w); v = max_raw(v, w); }
+    return v;
+}
+
+template <int LN>
+__global__ void __launch_bounds__(256) k_gfft(GfftP P) {
+    using namespace fr;
+    constexpr int Ns = 1 << LN, L = Ns / 2, G = gfft_slices_per_pass(L), TS = gfft_row_stride(L), NPART = L == 64 ? 2 : 1;
+    constexpr int GW = 2 * L < 64 ? 2 * L : 64;                    // lanes of a wave that share one (slice, orientation) in the row pass
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4 *W4 = (float4 *)smem;                                    // [L][L]
+    float2 *T = (float2 *)(smem + (size_t)L * L * sizeof(float4));  // [G][2][RC][TS]
+    char *small = smem + (size_t)L * L * sizeof(float4) + P.t_bytes;
+    float *red_v = (float *)small; int *red_k = (int *)(red_v + 256);      // per-thread (maximum, key) of an arg-max pass
+    int *win_o = red_k + 256; float *win_c = (float *)(win_o + PPM_MAX_TOP_HITS);   // the K winning orientations and their scores
+    float *rv = win_c + PPM_MAX_TOP_HITS; int *ri = (int *)(rv + 16);               // top-K scratch (4 waves)
+
+    const int tid = threadIdx.x, lane = tid & 63, p = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Bs = P.Bs, RSy = P.RSy, RC = P.RC, NR = 2 * RSy + 1;
+    const int nslices = P.n_dir * P.npsi_store;
+    const bool half = P.npsi_store != P.n_psi;
+    const TwPtr tw = (TwPtr)P.twN, pen = (TwPtr)P.penpos;
+
+    // ---- the particle's W table, two ky rows side by side like the bank
+    {
+        const float2 *src = P.Wp + (size_t)p * P.Hs * 64;
+        for (int i = tid; i < L * L; i += 256) {
+            const int n = i / L, kx = i - n * L;
+            float2 a = make_float2(0.f, 0.f), b = a;
+            if (kx <= Bs) {
+                if (n <= Bs) a = src[(n + Bs) * 64 + kx];
+                if (L - n <= Bs) b = src[(n - L + Bs) * 64 + kx];
+            }
+            W4[i] = make_float4(a.x, a.y, b.x, b.y);
+        }
+    }
+    __syncthreads();
+
+    // column-pass role of this thread: wave = (orientation half e, output parity h), lane = (slice of the pass, kx)
+    const int ce = wave >> 1, ch = wave & 1, cg = lane / L, ckx = lane - cg * L;
+    const float4 *wl = W4 + ckx;
+    float2 *Tc = T + (size_t)((cg * 2 + ce) * RC) * TS + ckx;
+    // row-pass role: 4 L consecutive threads per slice, 2 L per orientation
+    const int rg = tid / (4 * L), re = (tid / (2 * L)) & 1, rr = tid & (2 * L - 1);
+    const float2 *Tr = T + (size_t)((rg * 2 + re) * RC + rr) * TS;
+
+    const int npass0 = (nslices + G - 1) / G;
+    int npass1 = 0;                                                  // arg-max passes over the winners, known after the top-K step
+    float *partp = P.part + (size_t)p * P.n_orient * NPART;
+    const float nIp = P.nI[p];
+    const float *nPp = P.nP + (size_t)p * nslices;
+    Hit *hitp = P.hits + (size_t)p * P.K;
+
+    for (int it = 0;; it++) {
+        if (it == npass0) {
+            // ---- scores of all orientations, top-K (ties -> lower orientation index, like the oracle)
+            __threadfence_block();
+            __syncthreads();
+            float *sc = P.topk_lds ? (float *)T : P.cc + (size_t)p * P.n_orient;
+            for (int o = tid; o < P.n_orient; o += 256) {
+                const int dir = o / P.n_psi, k = o - dir * P.n_psi;
+                const int e = (half && k >= P.npsi_store) ? 1 : 0, sl = dir * P.npsi_store + k - e * P.npsi_store;
+                float v = partp[(size_t)o * NPART];
+                if constexpr (NPART == 2) v = fmaxf(v, partp[(size_t)o * NPART + 1]);
+                const float nP = nPp[sl];
+                const float inv = (nP > 0.f && nIp > 0.f) ? rsqrtf(nP * nIp) : 0.f;
+                sc[o] = 0.5f * v * inv;                              // the row transform yields twice the correlation
+            }
+            __threadfence_block();
+            __syncthreads();
+            for (int k = 0; k < P.K; k++) {
+                float bv = -3.0e38f; int bi = 0x7fffffff;
+                for (int o = tid; o < P.n_orient; o += 256) {
+                    const float v = sc[o];
+                    if (v > bv || (v == bv && o < bi)) { bv = v; bi = o; }
+                }
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) {
+                    const float ov = __shfl_xor(bv, m, 64); const int oi = __shfl_xor(bi, m, 64);
+                    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                }
+                if (lane == 0) { rv[wave] = bv; ri[wave] = bi; }
+                __syncthreads();
+                if (tid == 0) {
+                    for (int w = 1; w < 4; w++) if (rv[w] > bv || (rv[w] == bv && ri[w] < bi)) { bv = rv[w]; bi = ri[w]; }
+                    if (bi >= P.n_orient) { bi = 0; bv = 0.f; }      // nothing comparable left (NaN scores): stay inside the tables
+                    win_o[k] = bi; win_c[k] = bv;
+                    sc[bi] = -__builtin_inff();
+                }
+                __threadfence_block();
+                __syncthreads();
+            }
+            npass1 = (P.K + G - 1) / G;
+        }
+        if (it >= npass0 && it - npass0 >= npass1) break;
+        const bool argpass = it >= npass0;
+
+        // ---- which slice each role works on in this pass
+        auto slice_of = [&](int g, int &e_hit, int &hit) {
+            if (!argpass) { e_hit = -1; hit = -1; const int s = it * G + g; return s < nslices ? s : -1; }
+            hit = (it - npass0) * G + g;
+            if (hit >= P.K) { e_hit = -1; hit = -1; return -1; }
+            const int o = win_o[hit], dir = o / P.n_psi, k = o - dir * P.n_psi;
+            e_hit = (half && k >= P.npsi_store) ? 1 : 0;
+            return dir * P.npsi_store + k - e_hit * P.npsi_store;
+        };
+        int c_eh, c_hit, r_eh, r_hit;
+        const int c_sl = slice_of(cg, c_eh, c_hit), r_sl = slice_of(rg, r_eh, r_hit);
+
+        for (int c = 0; c < P.nchunk; c++) {
+            const int c0 = c * RC;                                   // first T row (slot) of this chunk
+            // ================= column pass
+            if (half || ce == 0) {
+                v2f y[L];
+                const float4 *bp = P.bank4 + (size_t)(c_sl < 0 ? 0 : c_sl) * L * L + ckx;
+                if (ch == 0) { if (ce == 0) gfft_col_products<L, 0, 0>(y, bp, wl, tw); else gfft_col_products<L, 1, 0>(y, bp, wl, tw); }
+                else { if (ce == 0) gfft_col_products<L, 0, 1>(y, bp, wl, tw); else gfft_col_products<L, 1, 1>(y, bp, wl, tw); }
+                fft_inreg<L, Ns>(y, tw);
+                // output f of the L-point transform is row sy = 2 f + h (mod Ns) of the image: rows 0 .. RSy sit in slots 0 .. RSy,
+                // rows -1 .. -RSy in slots RSy + 1 .. 2 RSy
+                const int spos = ch - c0, sneg = RSy - ch - c0;
+                static_for<0, L>([&](auto pc) {
+                    constexpr int pp = decltype(pc)::value, f = freq_at(L, pp);
+                    if constexpr (2 * f < L) {
+                        const int slot = 2 * f + spos;
+                        if (2 * f + ch <= RSy && slot >= 0 && slot < RC) Tc[slot * TS] = make_float2(y[pp].x, y[pp].y);
+                    } else {
+                        const int slot = 2 * (L - f) + sneg;
+                        if (2 * (L - f) - ch <= RSy && slot >= 0 && slot < RC) Tc[slot * TS] = make_float2(y[pp].x, y[pp].y);
+                    }
+                });
+            }
+            lds_barrier();
+            // ================= row pass
+            const int slot = rr + c0;
+            const bool active = rr < RC && slot < NR && r_sl >= 0 && (half || re == 0) && (!argpass || re == r_eh);
+            float best = -3.0e38f; int bkey = 0x7fffffff;
+            if (active) {
+                v2f z[L];
+                {
+                    v2f x[L];
+                    static_for<0, L / 2>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        const float4 v = *(const float4 *)(Tr + 2 * i);
+                        x[2 * i] = (v2f){ v.x, v.y }; x[2 * i + 1] = (v2f){ v.z, v.w };
+                    });
+                    // Z[k] = (X[k] + conj X[L-k]) + i w^k (X[k] - conj X[L-k]);  Z[L-k] = conj(s) + i conj(t)
+                    z[0] = (v2f){ 2.f * x[0].x, 2.f * x[0].x };
+                    z[L / 2] = (v2f){ 2.f * x[L / 2].x, -2.f * x[L / 2].y };
+                    static_for<1, L / 2>([&](auto kc) {
+                        constexpr int k = decltype(kc)::value;
+                        const v2f s = add_conj(x[k], x[L - k]), d = sub_conj(x[k], x[L - k]);
+                        const v2f t = cmul_s(d, tw[k]);
+                        z[k] = add_i(s, t);
+                        z[L - k] = conj_add_i_conj(s, t);
+                    });
+                }
+                fft_inreg<L, Ns>(z, tw);
+                // z[position of f] = 2 (c(2 f), c(2 f + 1)); columns outside the window get -3e38
+                static_for<0, L>([&](auto pc) {
+                    constexpr int pp = decltype(pc)::value;
+                    z[pp] += pen[pp];
+                    best = fmaxf(best, fmaxf(z[pp].x, z[pp].y));
+                });
+                if (argpass) {
+                    // lowest column (scan order of the oracle: sx ascending) that holds the row's maximum
+                    int bsx = 0x7fff;
+                    static_for<0, Ns>([&](auto jc) {
+                        constexpr int jj = Ns - 1 - decltype(jc)::value;      // descending sx: the last match that sticks is the lowest
+                        constexpr int sxm = (jj + L) % Ns;                     // sx = jj - L + ... : walk sx = L-1 .. -L
+                        constexpr int pp = pos_of(L, sxm / 2);
+                        const float v = (sxm & 1) ? z[pp].y : z[pp].x;
+                        if (v == best) bsx = sxm < L ? sxm : sxm - Ns;
+                    });
+                    const int sy = slot <= RSy ? slot : RSy - slot;
+                    bkey = (sy + RSy) * Ns + (bsx + L);
+                }
+            }
+            if (!argpass) {
+                if (c > 0) best = fmaxf(best, red_v[tid]);           // rows of the earlier chunks (same thread, same role)
+                if (c + 1 < P.nchunk) red_v[tid] = best;
+                else {
+                    const float m = group_max<GW>(best);
+                    if ((lane & (GW - 1)) == 0 && r_sl >= 0 && (half || re == 0)) {
+                        const int dir = r_sl / P.npsi_store, ks = r_sl - dir * P.npsi_store;
+                        const int o = dir * P.n_psi + ks + re * P.npsi_store;
+                        partp[(size_t)o * NPART + (NPART == 2 ? (wave & 1) : 0)] = m;
+                    }
+                }
+            } else {
+                if (c > 0 && (red_v[tid] > best || (red_v[tid] == best && red_k[tid] < bkey))) { best = red_v[tid]; bkey = red_k[tid]; }
+                red_v[tid] = best; red_k[tid] = bkey;
+            }
+            lds_barrier();                                           // T may be overwritten, red_* are visible
+        }
+        if (argpass && rr == 0 && r_hit >= 0 && re == r_eh) {
+            // one thread per hit: best (value, key) over the rows of its orientation
+            float bv = -3.0e38f; int bk = 0x7fffffff;
+            for (int j = 0; j < 2 * L; j++) {
+                const float v = red_v[tid + j]; const int k = red_k[tid + j];
+                if (v > bv || (v == bv && k < bk)) { bv = v; bk = k; }
+            }
+            Hit h; h.cc = win_c[r_hit]; h.orient = win_o[r_hit]; h.sx = 0; h.sy = 0;
+            if (bk != 0x7fffffff) { h.sy = bk / Ns - RSy; h.sx = bk % Ns - L; }
+            hitp[r_hit] = h;
+        }
+        if (argpass) lds_barrier();                                  // red_* are reused by the next pass
+    }
+}
+
+}  // namespace ppm

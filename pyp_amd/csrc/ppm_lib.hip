@@ -26,6 +26,7 @@
 #include "ppm_kernels2.h"
 #include "ppm_csp_kernels.h"
 #include "ppm_sva_kernels.h"
+#include "ppm_gfft.h"
 
 using namespace ppm;
 
@@ -219,7 +220,9 @@ struct ppm_ref {
     DevBuf<Hit> hits, hits_t;        // hits_t: per-tile top-K lists of a shift window wider than the kernel's
     DevBuf<int> tile_c;
     DevBuf<LState> states, states2;
-    std::string bank_key;
+    // full-window correlation (k_gfft): the bank in the column pass's layout, window maxima per (particle, orientation), column penalties
+    DevBuf<float4> bank4; DevBuf<float> part; DevBuf<float2> penpos;
+    std::string bank_key, bank4_key, pen_key;
     long last_counts[4] = { 0, 0, 0, 0 };
     std::string note;
 };
@@ -406,9 +409,50 @@ static int launch_global(GlobP &P, int n_img, bool half, int R) {
         case 3: return launch_global_r<3>(P, n_img, half, lds);
         case 4: return launch_global_r<4>(P, n_img, half, lds);
         case 5: return launch_global_r<5>(P, n_img, half, lds);
-        case 6: return launch_global_r<6>(P, n_img, half, lds);
-        case 7: return launch_global_r<7>(P, n_img, half, lds);
-        default: return launch_global_r<8>(P, n_img, half, lds);
+        default: return launch_global_r<6>(P, n_img, half, lds);      // wider windows: k_gfft, or tiles of this one (ppm_refine_batch)
+    }
+}
+
+// Full-window correlation (ppm_gfft.h): LDS plan and launch.  Returns -1 when the search grid is outside what the kernel is built
+// for (Ns = 16 .. 128), in which case the caller keeps the tiled k_global.
+struct GfftPlan { int LN = 0, L = 0, RC = 0, nchunk = 1; size_t t_bytes = 0, lds = 0; int topk_lds = 0; };
+static bool gfft_plan(const Geom &gm, GfftPlan &pl) {
+    int LN = 0; while ((1 << LN) < gm.Ns) LN++;
+    if ((1 << LN) != gm.Ns || LN < 4 || LN > 7) return false;
+    pl.LN = LN; pl.L = gm.Ns / 2;
+    const int L = pl.L, G = gfft_slices_per_pass(L), NR = 2 * gm.RSy + 1;
+    const size_t row = (size_t)G * 2 * gfft_row_stride(L) * sizeof(float2), fixed = (size_t)L * L * sizeof(float4) + gfft_small_bytes();
+    const size_t room = (size_t)160 * 1024 - fixed;
+    int RC = NR;
+    if (const char *e = getenv("PPM_GFFT_ROWS")) { const int v = atoi(e); if (v > 0 && v < RC) RC = v; }       // tests: force several row chunks
+    if ((size_t)RC * row > room) RC = (int)(room / row);
+    if (RC > 2 * L) RC = 2 * L;
+    pl.RC = RC; pl.nchunk = (NR + RC - 1) / RC;
+    pl.RC = (NR + pl.nchunk - 1) / pl.nchunk;        // even chunks
+    pl.t_bytes = (size_t)pl.RC * row;
+    const size_t topk = (size_t)gm.n_orient * sizeof(float);
+    pl.topk_lds = 0;
+    if (topk <= pl.t_bytes) pl.topk_lds = 1;
+    else if (fixed + topk <= (size_t)160 * 1024) { pl.topk_lds = 1; pl.t_bytes = (topk + 15) & ~(size_t)15; }
+    pl.lds = fixed + pl.t_bytes;
+    return true;
+}
+template <int LN>
+static int launch_gfft_k(const GfftP &P, int n_img, size_t lds) {
+    static bool set = false;
+    { std::lock_guard<std::mutex> lk_attr(g_mu); if (!set) { HIPCHK(hipFuncSetAttribute((const void *)k_gfft<LN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } }
+    hipLaunchKernelGGL((k_gfft<LN>), dim3(n_img), dim3(256), lds, cur_stream(), P);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+static int launch_gfft(GfftP &P, int n_img, const GfftPlan &pl) {
+    P.n = n_img; P.RC = pl.RC; P.nchunk = pl.nchunk; P.t_bytes = (int)pl.t_bytes; P.topk_lds = pl.topk_lds;
+    ProfScope ps(PPM_K_GLOBAL);
+    switch (pl.LN) {
+        case 4: return launch_gfft_k<4>(P, n_img, pl.lds);
+        case 5: return launch_gfft_k<5>(P, n_img, pl.lds);
+        case 6: return launch_gfft_k<6>(P, n_img, pl.lds);
+        default: return launch_gfft_k<7>(P, n_img, pl.lds);
     }
 }
 
@@ -605,6 +649,7 @@ void ppm_reference_destroy(ppm_ref_t *r) {
     r->c_delta.release(); r->c_s0.release(); r->c_g0.release(); r->c_out.release(); r->c_eval.release(); r->c_rp.release(); r->c_rt.release(); r->c_slot.release(); r->c_states.release(); r->c_uoff.release(); r->c_mean.release(); r->cc.release(); r->mats.release(); r->ddef.release();
     r->band.release(); r->spill.release(); r->Il.release(); r->Wp.release(); r->bank.release(); r->twN.release(); r->rowtw.release(); r->sh.release(); r->samples.release();
     r->hits.release(); r->states.release(); r->states2.release();
+    r->hits_t.release(); r->tile_c.release(); r->bank4.release(); r->part.release(); r->penpos.release();
     if (r->stream) (void)hipStreamDestroy(r->stream);
     if (r->copy) (void)hipStreamDestroy(r->copy);
     delete r;
@@ -721,7 +766,19 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
     const size_t NN = (size_t)gm.N * gm.N, HW = (size_t)gm.H * gm.W, HS = (size_t)gm.Hs * 64;
     // shift window: the kernel searches +-PPM_MAX_SHIFT_STEPS steps; a wider window is covered by overlapping tiles of that
     // half-width whose union is exactly [-RS, RS] (centres cxs / cys, in steps)
-    const int Rtx = std::min(gm.RSx, PPM_MAX_SHIFT_STEPS), Rty = std::min(gm.RSy, PPM_MAX_SHIFT_STEPS);
+    // k_global keeps its shift window in registers: up to kTileR steps either side without scratch.  Anything wider — PYP's default
+    // "search range 0 = mask radius" is +-41 steps at a 256 box and 4 A — goes to the full-window transform (k_gfft, ppm_gfft.h);
+    // PPM_GLOBAL_PATH=tiles keeps the tiled k_global (A/B runs and the tests that hold one path against the other), =fft forces
+    // the transform for narrow windows too.
+    constexpr int kTileR = 6;
+    GfftPlan gpl;
+    bool use_fft = false;
+    if (cfg->global_search && gfft_plan(gm, gpl)) {
+        const char *gp = getenv("PPM_GLOBAL_PATH");
+        const bool force_fft = gp && !strcmp(gp, "fft"), force_tiles = gp && !strcmp(gp, "tiles");
+        use_fft = force_fft || (!force_tiles && std::max(gm.RSx, gm.RSy) > kTileR);
+    }
+    const int Rtx = std::min(gm.RSx, kTileR), Rty = std::min(gm.RSy, kTileR);
     auto tile_centres = [](int RS, int Rt) {
         const int T = (2 * RS + 1 + 2 * Rt) / (2 * Rt + 1);
         std::vector<int> c(T, 0);
@@ -809,6 +866,37 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
             HIPCHK(hipGetLastError());
             HIPCHK(hipStreamSynchronize(cur_stream()));   // host vectors go out of scope
             ref->bank_key = key;
+        }
+    }
+    if (use_fft) {
+        const int L = gpl.L;
+        if (int rc = ref->part.ensure((size_t)CH * gm.n_orient * 2)) return rc;
+        char key[200];
+        std::snprintf(key, sizeof(key), "%s/L%d", ref->bank_key.c_str(), L);
+        if (ref->bank4_key != key) {
+            if (int rc = ref->bank4.ensure((size_t)nslices * L * L)) return rc;
+            Bank4P BP; BP.cv = cv; BP.mats = ref->mats.p; BP.bank4 = ref->bank4.p; BP.nslices = nslices; BP.Bs = gm.Bs; BP.L = L; BP.r_s2 = (float)(gm.r_s * gm.r_s);
+            ProfScope ps(PPM_K_BANK);
+            const size_t tot = (size_t)nslices * L * L;
+            hipLaunchKernelGGL(k_bank4, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, cur_stream(), BP);
+            HIPCHK(hipGetLastError());
+            ref->bank4_key = key;
+        }
+        std::snprintf(key, sizeof(key), "%d/%d", gm.Ns, gm.RSx);
+        if (ref->pen_key != key) {
+            // column penalties of the row pass, in the order the L-point transform leaves its outputs: position p holds the columns
+            // j = 2 f, 2 f + 1 (f = freq_at(L, p)), column j is the shift sx = j (j < L) or j - Ns
+            std::vector<float2> pen(L);
+            for (int pp = 0; pp < L; pp++) {
+                const int f = fr::freq_at(L, pp);
+                float v[2];
+                for (int h = 0; h < 2; h++) { const int j = 2 * f + h, sx = j < L ? j : j - gm.Ns; v[h] = std::abs(sx) <= gm.RSx ? 0.f : -3.0e38f; }
+                pen[pp] = make_float2(v[0], v[1]);
+            }
+            if (int rc = ref->penpos.ensure(L)) return rc;
+            HIPCHK(hipMemcpyAsync(ref->penpos.p, pen.data(), pen.size() * sizeof(float2), hipMemcpyHostToDevice, cur_stream()));
+            HIPCHK(hipStreamSynchronize(cur_stream()));       // the host vector goes out of scope
+            ref->pen_key = key;
         }
     }
     HIPCHK(hipStreamSynchronize(cur_stream()));
@@ -904,7 +992,14 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
                 NormP NP; NP.C2 = ref->C2.p; NP.bank = ref->bank.p; NP.nP = ref->nP.p; NP.n = nb; NP.nslices = nslices; NP.Bs = gm.Bs; NP.Hs = gm.Hs; NP.HsP = HsP;
                 hipLaunchKernelGGL(k_slice_norms, dim3((nb + 127) / 128, (nslices + 127) / 128), dim3(256), 0, cur_stream(), NP);
             }
-            if (ntiles == 1) {
+            if (use_fft) {
+                GfftP FP;
+                FP.bank4 = ref->bank4.p; FP.Wp = ref->Wp.p; FP.nP = ref->nP.p; FP.nI = ref->nI.p; FP.twN = ref->twN.p; FP.penpos = ref->penpos.p;
+                FP.part = ref->part.p; FP.cc = ref->cc.p; FP.hits = ref->hits.p;
+                FP.Bs = gm.Bs; FP.Hs = gm.Hs; FP.RSx = gm.RSx; FP.RSy = gm.RSy;
+                FP.n_dir = gm.n_dir; FP.n_psi = gm.n_psi; FP.npsi_store = gm.npsi_store; FP.n_orient = gm.n_orient; FP.K = K;
+                if (int rc = launch_gfft(FP, nb, gpl)) return rc;
+            } else if (ntiles == 1) {
                 if (int rc = launch_global(GP, nb, gm.half != 0, Rwin)) return rc;
             } else {
                 // tiles of the shift window: ramp the search tables to the tile's centre, search, keep the tile's top-K; then merge
