@@ -1,12 +1,20 @@
 // In-register complex transforms for the full-window correlation kernel (ppm_gfft.h).
 //
 // A thread holds a whole line of N <= 64 complex values in VGPR pairs (re, im) and transforms it without touching LDS: every
-// butterfly is a packed two-lane instruction (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32), so one instruction does the real and
-// the imaginary part.  What the compiler does not find by itself is that a multiplication by +-i and the cross terms of a
-// complex product are SOURCE MODIFIERS of those instructions (op_sel swaps the halves of a 64-bit operand, neg_lo / neg_hi negate
-// one of them): written in C it emits a v_xor + v_mov pair per rotation.  The four helpers below pin the modifier forms.
-// Twiddles are wave-uniform: they come out of a table e^{2 pi i t / TWN} in device memory through the constant address space
-// (scalar loads into SGPR pairs) and enter the packed instructions as their one scalar operand.
+// butterfly step is a packed two-lane instruction (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32), so one instruction does the real
+// and the imaginary part.  A multiplication by +-i and the cross terms of a complex product are SOURCE MODIFIERS of those
+// instructions (op_sel swaps the halves of a 64-bit operand, neg_lo / neg_hi negate one of them).
+//
+// Why whole butterflies are single asm statements: (1) hipcc reaches op_sel from a two-element shuffle but not a negated lane;
+// (2) ROCm 7.2's hazard recogniser takes op_sel_hi[0] of a packed instruction — set in the DEFAULT encoding of every v_pk_* — for
+// "writes the high half of its destination" and puts an s_nop in front of any instruction that reads the result directly
+// afterwards (scripts/micro/pk_dep_bench: a dependent v_pk_fma_f32 issues exactly as fast as an independent one, so the nop
+// buys nothing), and it assumes the same of every value an asm statement defines.  At one wave per SIMD every instruction,
+// s_nop included, costs a 4-cycle issue slot (2.35 ns per v_pk_fma_f32, dependent or not), so the kernel wants straight runs of
+// packed instructions: a statement holds a complete radix-4 butterfly with its three twiddle products (14 instructions), two rows
+// of the correlation's products (8), or four twiddle products (8); statements of one pass are independent of their neighbours.
+// Twiddles are wave-uniform: (c, s, -s, s) entries of tables in device memory, fetched 16 dwords at a time by scalar loads through
+// the constant address space, and enter the packed instructions as their one scalar operand.
 //
 // Sign convention: all transforms here are X[m] = sum_n x[n] e^{+2 pi i n m / N} (the correlation's inverse transforms).
 #pragma once
@@ -17,71 +25,10 @@ namespace ppm {
 namespace fr {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
-typedef const __attribute__((address_space(4))) v2f *TwPtr;
-
-// a + i b  = (a.x - b.y, a.y + b.x)
-__device__ __forceinline__ v2f add_i(v2f a, v2f b) {
-    v2f d;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-// a - i b  = (a.x + b.y, a.y - b.x)
-__device__ __forceinline__ v2f sub_i(v2f a, v2f b) {
-    v2f d;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-// a + conj(b), a - conj(b)
-__device__ __forceinline__ v2f add_conj(v2f a, v2f b) {
-    v2f d;
-    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-__device__ __forceinline__ v2f sub_conj(v2f a, v2f b) {
-    v2f d;
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-// conj(a) + i conj(b) = (a.x + b.y, b.x - a.y)
-__device__ __forceinline__ v2f conj_add_i_conj(v2f a, v2f b) {
-    v2f d;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[1,0]" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-// a * w, w = (cos, sin) in an SGPR pair
-__device__ __forceinline__ v2f cmul_s(v2f a, v2f w) {
-    v2f t, d;
-    asm("v_pk_mul_f32 %1, %2, %3 op_sel_hi:[1,0]\n\tv_pk_fma_f32 %0, %2, %3, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(d), "=&v"(t) : "v"(a), "s"(w));
-    return d;
-}
-// the same with the twiddle in a VGPR pair (per-lane twiddles)
-__device__ __forceinline__ v2f cmul_v(v2f a, v2f w) {
-    v2f t, d;
-    asm("v_pk_mul_f32 %1, %2, %3 op_sel_hi:[1,0]\n\tv_pk_fma_f32 %0, %2, %3, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(d), "=&v"(t) : "v"(a), "v"(w));
-    return d;
-}
-// acc + a * w and acc + a * conj(w), all three in VGPR pairs (the products W P and W conj(P) of the correlation)
-__device__ __forceinline__ v2f cmac_v(v2f acc, v2f a, v2f w) {
-    v2f t, d;
-    asm("v_pk_fma_f32 %1, %2, %3, %4 op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %0, %2, %3, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(d), "=&v"(t) : "v"(a), "v"(w), "v"(acc));
-    return d;
-}
-__device__ __forceinline__ v2f cmac_conj_v(v2f acc, v2f a, v2f w) {
-    v2f t, d;
-    asm("v_pk_fma_f32 %1, %2, %3, %4 op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %0, %2, %3, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(d), "=&v"(t) : "v"(a), "v"(w), "v"(acc));
-    return d;
-}
-// acc - a * w, acc - a * conj(w)
-__device__ __forceinline__ v2f cmsub_v(v2f acc, v2f a, v2f w) {
-    v2f t, d;
-    asm("v_pk_fma_f32 %1, %2, %3, %4 op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\tv_pk_fma_f32 %0, %2, %3, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(d), "=&v"(t) : "v"(a), "v"(w), "v"(acc));
-    return d;
-}
-__device__ __forceinline__ v2f cmsub_conj_v(v2f acc, v2f a, v2f w) {
-    v2f t, d;
-    asm("v_pk_fma_f32 %1, %2, %3, %4 op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\tv_pk_fma_f32 %0, %2, %3, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(d), "=&v"(t) : "v"(a), "v"(w), "v"(acc));
-    return d;
-}
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef const __attribute__((address_space(4))) v2f *TwPtr;        // wave-uniform pairs (scalar loads)
+typedef const __attribute__((address_space(4))) v16f *Tw16Ptr;     // 64-byte table entries: up to four twiddles (c, s, -s, s)
 
 constexpr int ilog2(int n) { return n <= 1 ? 0 : 1 + ilog2(n / 2); }
 
@@ -97,42 +44,165 @@ constexpr int pos_of(int M, int m) {
     for (int p = 0; p < M; p++) if (freq_at(M, p) == m) return p;
     return -1;
 }
-// compile-time loop: f(std::integral_constant<int, I>) for I = 0 .. N - 1 (register arrays need constant indices)
+// compile-time loop: f(std::integral_constant<int, I>) for I = I0 .. N - 1 (register arrays need constant indices)
 template <int I, int N, class F> __device__ __forceinline__ void static_for(F &&f) {
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
 }
 
-// In-place transform of x[BASE .. BASE + M) of an N-element register array; tw = e^{2 pi i t / TWN}, TWN a multiple of M.
-template <int N, int M, int BASE, int TWN>
-__device__ __forceinline__ void fft_dif(v2f (&x)[N], TwPtr tw) {
-    if constexpr (M == 2) {
-        const v2f a = x[BASE], b = x[BASE + 1];
-        x[BASE] = a + b; x[BASE + 1] = a - b;
-    } else if constexpr (M >= 4) {
-        constexpr int q = M / 4, ts = TWN / M;
-#pragma unroll
-        for (int k = 0; k < q; k++) {
-            const v2f a = x[BASE + k], b = x[BASE + k + q], c = x[BASE + k + 2 * q], d = x[BASE + k + 3 * q];
-            const v2f s0 = a + c, s1 = a - c, s2 = b + d, s3 = b - d;
-            const v2f y0 = s0 + s2, y2 = s0 - s2, y1 = add_i(s1, s3), y3 = sub_i(s1, s3);
-            x[BASE + k] = y0;
-            if (k == 0) { x[BASE + q] = y1; x[BASE + 2 * q] = y2; x[BASE + 3 * q] = y3; }
-            else {
-                x[BASE + k + q] = cmul_s(y1, tw[k * ts]);
-                x[BASE + k + 2 * q] = cmul_s(y2, tw[2 * k * ts]);
-                x[BASE + k + 3 * q] = cmul_s(y3, tw[3 * k * ts]);
-            }
-        }
-        fft_dif<N, q, BASE, TWN>(x, tw);
-        fft_dif<N, q, BASE + q, TWN>(x, tw);
-        fft_dif<N, q, BASE + 2 * q, TWN>(x, tw);
-        fft_dif<N, q, BASE + 3 * q, TWN>(x, tw);
+// ---- twiddle tables (built on the host, read by the kernels through scalar loads)
+// Butterfly table of an N-point transform: for every radix-4 pass with block size M = N, N/4, ... >= 8 and every k = 1 .. M/4 - 1 one
+// 16-float entry (w^k, w^2k, w^3k, padding), w = e^{2 pi i / M}, each twiddle as (c, s, -s, s).  bfly_entry(N, M, k) is its index.
+constexpr int bfly_entries(int N) { int e = 0; for (int M = N; M >= 8; M /= 4) e += M / 4 - 1; return e; }
+constexpr int bfly_entry(int N, int M, int k) { int e = 0; for (int m = N; m > M; m /= 4) e += m / 4 - 1; return e + k - 1; }
+// Line table of a 2 L-point grid: entry j holds w^(4j) .. w^(4j+3), w = e^{2 pi i / (2 L)} (the decimation twiddles of the column pass
+// and the half-length trick of the row pass); L / 4 entries cover w^0 .. w^(L-1).
+
+// ---- one radix-4 decimation-in-frequency butterfly, in place; with TW the outputs 1 .. 3 are multiplied by w^k, w^2k, w^3k
+template <bool TW>
+__device__ __forceinline__ void bfly4(v2f &x0, v2f &x1, v2f &x2, v2f &x3, v16f w) {
+    v2f a = x0, b = x1, c = x2, d = x3, t0, t1;
+    if constexpr (TW) {
+        const v2f w1c = { w[0], w[1] }, w1s = { w[2], w[3] }, w2c = { w[4], w[5] }, w2s = { w[6], w[7] }, w3c = { w[8], w[9] }, w3s = { w[10], w[11] };
+        asm("v_pk_add_f32 %4, %0, %2\n\t"
+            "v_pk_add_f32 %0, %0, %2 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "v_pk_add_f32 %2, %1, %3\n\t"
+            "v_pk_add_f32 %1, %1, %3 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "v_pk_add_f32 %3, %4, %2 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "v_pk_add_f32 %4, %4, %2\n\t"
+            "v_pk_add_f32 %2, %0, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+            "v_pk_add_f32 %0, %0, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"
+            "v_pk_mul_f32 %5, %2, %6 op_sel_hi:[1,0]\n\t"
+            "v_pk_fma_f32 %2, %2, %7, %5 op_sel:[1,0,0] op_sel_hi:[0,1,1]\n\t"
+            "v_pk_mul_f32 %5, %3, %8 op_sel_hi:[1,0]\n\t"
+            "v_pk_fma_f32 %3, %3, %9, %5 op_sel:[1,0,0] op_sel_hi:[0,1,1]\n\t"
+            "v_pk_mul_f32 %5, %0, %10 op_sel_hi:[1,0]\n\t"
+            "v_pk_fma_f32 %0, %0, %11, %5 op_sel:[1,0,0] op_sel_hi:[0,1,1]"
+            : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "=&v"(t0), "=&v"(t1)
+            : "s"(w1c), "s"(w1s), "s"(w2c), "s"(w2s), "s"(w3c), "s"(w3s));
+    } else {
+        asm("v_pk_add_f32 %4, %0, %2\n\t"
+            "v_pk_add_f32 %0, %0, %2 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "v_pk_add_f32 %2, %1, %3\n\t"
+            "v_pk_add_f32 %1, %1, %3 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "v_pk_add_f32 %3, %4, %2 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "v_pk_add_f32 %4, %4, %2\n\t"
+            "v_pk_add_f32 %2, %0, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+            "v_pk_add_f32 %0, %0, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]"
+            : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "=&v"(t0) : );
     }
+    x0 = t0; x1 = c; x2 = d; x3 = a;          // y0 = s0 + s2, y1 = s1 + i s3, y2 = s0 - s2, y3 = s1 - i s3 (renamings, no moves)
+}
+// two radix-2 butterflies in one statement (the last pass of 8- and 32-point transforms)
+__device__ __forceinline__ void bfly2x2(v2f &x0, v2f &x1, v2f &x2, v2f &x3) {
+    v2f a = x0, b = x1, c = x2, d = x3, t0, t1;
+    asm("v_pk_add_f32 %4, %0, %1\n\t"
+        "v_pk_add_f32 %5, %2, %3\n\t"
+        "v_pk_add_f32 %1, %0, %1 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %3, %2, %3 neg_lo:[0,1] neg_hi:[0,1]"
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "=&v"(t0), "=&v"(t1) : );
+    x0 = t0; x1 = b; x2 = t1; x3 = d;
 }
 
+// In-place transform of x[BASE .. BASE + M) of an N-element register array (N a power of two, 8 .. 64); tb = bfly table of N
+template <int N, int M, int BASE>
+__device__ __forceinline__ void fft_dif(v2f (&x)[N], Tw16Ptr tb) {
+    if constexpr (M == 2) {
+        static_assert(BASE % 4 == 0, "radix-2 blocks are taken in pairs");
+        bfly2x2(x[BASE], x[BASE + 1], x[BASE + 2], x[BASE + 3]);
+    } else if constexpr (M >= 4) {
+        constexpr int q = M / 4;
+        static_for<0, q>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            if constexpr (k == 0) bfly4<false>(x[BASE], x[BASE + q], x[BASE + 2 * q], x[BASE + 3 * q], v16f{});
+            else bfly4<true>(x[BASE + k], x[BASE + k + q], x[BASE + k + 2 * q], x[BASE + k + 3 * q], tb[bfly_entry(N, M, k)]);
+        });
+        if constexpr (q == 2) {            // two radix-2 blocks per statement
+            fft_dif<N, 2, BASE>(x, tb);
+            fft_dif<N, 2, BASE + 4>(x, tb);
+        } else if constexpr (q >= 4) {
+            fft_dif<N, q, BASE>(x, tb);
+            fft_dif<N, q, BASE + q>(x, tb);
+            fft_dif<N, q, BASE + 2 * q>(x, tb);
+            fft_dif<N, q, BASE + 3 * q>(x, tb);
+        }
+    }
+}
 // X[m] = sum_n x[n] e^{+2 pi i n m / N}; afterwards x[pos_of(N, m)] holds X[m].
-template <int N, int TWN>
-__device__ __forceinline__ void fft_inreg(v2f (&x)[N], TwPtr tw) { fft_dif<N, N, 0, TWN>(x, tw); }
+template <int N>
+__device__ __forceinline__ void fft_inreg(v2f (&x)[N], Tw16Ptr tb) { fft_dif<N, N, 0>(x, tb); }
+
+// ---- four products with the twiddles of one line-table entry: x_i *= w_i
+__device__ __forceinline__ void cmul4(v2f &x0, v2f &x1, v2f &x2, v2f &x3, v16f w) {
+    v2f a = x0, b = x1, c = x2, d = x3, t0, t1;
+    const v2f w0c = { w[0], w[1] }, w0s = { w[2], w[3] }, w1c = { w[4], w[5] }, w1s = { w[6], w[7] }, w2c = { w[8], w[9] }, w2s = { w[10], w[11] }, w3c = { w[12], w[13] }, w3s = { w[14], w[15] };
+    asm("v_pk_mul_f32 %4, %0, %6 op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %5, %1, %8 op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %0, %7, %4 op_sel:[1,0,0] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %1, %1, %9, %5 op_sel:[1,0,0] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_mul_f32 %4, %2, %10 op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %5, %3, %12 op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %2, %2, %11, %4 op_sel:[1,0,0] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %3, %3, %13, %5 op_sel:[1,0,0] op_sel_hi:[0,1,1]"
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "=&v"(t0), "=&v"(t1)
+        : "s"(w0c), "s"(w0s), "s"(w1c), "s"(w1s), "s"(w2c), "s"(w2s), "s"(w3c), "s"(w3s));
+    x0 = a; x1 = b; x2 = c; x3 = d;
+}
+
+// ---- the product chains of the correlation's column pass, two rows per statement:
+// d_r = wa_r p~a_r +- wb_r p~b_r with p~ = p (E = 1) or conj(p) (E = 0) and the sign - for H = 1; all operands per-lane VGPR pairs.
+#define PPM_PROD2X2(N1, N2, N3) \
+    asm("v_pk_mul_f32 %0, %2, %3 op_sel_hi:[1,0]\n\t" \
+        "v_pk_mul_f32 %1, %6, %7 op_sel_hi:[1,0]\n\t" \
+        "v_pk_fma_f32 %0, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] " N1 "\n\t" \
+        "v_pk_fma_f32 %1, %6, %7, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] " N1 "\n\t" \
+        "v_pk_fma_f32 %0, %4, %5, %0 op_sel_hi:[1,0,1] " N2 "\n\t" \
+        "v_pk_fma_f32 %1, %8, %9, %1 op_sel_hi:[1,0,1] " N2 "\n\t" \
+        "v_pk_fma_f32 %0, %4, %5, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] " N3 "\n\t" \
+        "v_pk_fma_f32 %1, %8, %9, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] " N3 \
+        : "=&v"(d0), "=&v"(d1) : "v"(wa0), "v"(pa0), "v"(wb0), "v"(pb0), "v"(wa1), "v"(pa1), "v"(wb1), "v"(pb1))
+template <int E, int H>
+__device__ __forceinline__ void prod2x2(v2f &d0, v2f &d1, v2f wa0, v2f pa0, v2f wb0, v2f pb0, v2f wa1, v2f pa1, v2f wb1, v2f pb1) {
+    // cross term of w p: (-w.y p.y, w.x p.y) -> neg_lo on the swapped w; of w conj(p): (w.y p.y, -w.x p.y) -> neg_hi
+    if constexpr (E == 1 && H == 0) PPM_PROD2X2("neg_lo:[1,0,0]", "", "neg_lo:[1,0,0]");
+    else if constexpr (E == 0 && H == 0) PPM_PROD2X2("neg_hi:[1,0,0]", "", "neg_hi:[1,0,0]");
+    else if constexpr (E == 1 && H == 1) PPM_PROD2X2("neg_lo:[1,0,0]", "neg_lo:[1,0,0] neg_hi:[1,0,0]", "neg_hi:[1,0,0]");
+    else PPM_PROD2X2("neg_hi:[1,0,0]", "neg_lo:[1,0,0] neg_hi:[1,0,0]", "neg_lo:[1,0,0]");
+}
+#undef PPM_PROD2X2
+
+// ---- the half-length trick of a real 2 L-point transform (row pass): with s = X[k] + conj X[L-k], t = w^k (X[k] - conj X[L-k]),
+// Z[k] = s + i t and Z[L-k] = conj(s) + i conj(t).  Two pairs per statement; wc / ws = (c, s) / (-s, s) of w^k.
+__device__ __forceinline__ void halfpair2(v2f &xk0, v2f &xl0, v2f &xk1, v2f &xl1, v2f w0c, v2f w0s, v2f w1c, v2f w1s) {
+    v2f a = xk0, b = xl0, c = xk1, d = xl1, t0, t1;
+    asm("v_pk_add_f32 %4, %0, %1 neg_lo:[0,1]\n\t"                               // d = a - conj(b)
+        "v_pk_add_f32 %5, %2, %3 neg_lo:[0,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1 neg_hi:[0,1]\n\t"                               // s = a + conj(b)
+        "v_pk_add_f32 %2, %2, %3 neg_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %1, %4, %6 op_sel_hi:[1,0]\n\t"                            // t = d w
+        "v_pk_mul_f32 %3, %5, %8 op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %1, %4, %7, %1 op_sel:[1,0,0] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %3, %5, %9, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_add_f32 %4, %0, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"  // Z[k] = s + i t
+        "v_pk_add_f32 %5, %2, %3 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+        "v_pk_add_f32 %1, %0, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[1,0]\n\t"  // Z[L-k] = (s.x + t.y, t.x - s.y)
+        "v_pk_add_f32 %3, %2, %3 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[1,0]"
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "=&v"(t0), "=&v"(t1)
+        : "s"(w0c), "s"(w0s), "s"(w1c), "s"(w1s));
+    xk0 = t0; xl0 = b; xk1 = t1; xl1 = d;
+}
+
+// one pair (the odd one out: k = 1)
+__device__ __forceinline__ void halfpair1(v2f &xk, v2f &xl, v2f wc, v2f ws) {
+    v2f a = xk, b = xl, t0;
+    asm("v_pk_add_f32 %2, %0, %1 neg_lo:[0,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1 neg_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %1, %2, %3 op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %1, %2, %4, %1 op_sel:[1,0,0] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_add_f32 %2, %0, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+        "v_pk_add_f32 %1, %0, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[1,0]"
+        : "+v"(a), "+v"(b), "=&v"(t0) : "s"(wc), "s"(ws));
+    xk = t0; xl = b;
+}
 
 }  // namespace fr
 }  // namespace ppm

@@ -23,7 +23,7 @@
 //    of them, so after the top-K selection the K winning slices are transformed once more with the arg-max switched on
 //    (K / n_orient = 0.5 % more work instead of two compare-selects per correlation value everywhere).
 //
-// LDS at L = 64: W 64 KB + T 2 x (2 RSy + 1) x 66 x 8 B (86 KB at RSy = 41) — one block per CU, one wave per SIMD; a single wave
+// LDS at L = 64: T 2 x (2 RSy + 1) x 66 x 8 B (86 KB at RSy = 41) + W 64 KB — one block per CU, one wave per SIMD; a single wave
 // issues one instruction per four cycles, which a packed instruction fills (scripts/micro/fft_reg_bench: a 64-point transform
 // costs 2 840 cycles at one wave per SIMD against 2 500 at two).  Smaller search grids put 64 / L slices into one pass.
 #pragma once
@@ -33,10 +33,11 @@ namespace ppm {
 
 struct GfftP {
     const float4 *bank4;     // [nslices][L][L]: (P(ky = n, kx), P(ky = n - L, kx)), zero outside the search band (k_bank4)
+    unsigned bank4_bytes;    // its size (below 4 GB: the column pass reads it through a buffer descriptor)
     const float2 *Wp;        // [n][Hs][64] search tables of the chunk (k_prep), rows ky + Bs
     const float *nP, *nI;    // slice norms [n][nslices] (k_slice_norms), image norms [n]
-    const float2 *twN;       // e^{2 pi i t / Ns}, t = 0 .. Ns - 1
-    const float2 *penpos;    // [L] pairs: 0 or -3e38 for the columns sx(2 f), sx(2 f + 1) with f = freq_at(L, position)
+    const float *twb;        // butterfly table of the L-point transform (ppm_fft_reg.h: bfly_entries(L) entries of 16 floats)
+    const float *twl;        // line table of the Ns-point grid: entry j = w^(4j) .. w^(4j+3), each (c, s, -s, s); L / 4 entries
     float *part;             // [n][n_orient][NPART] raw window maxima
     float *cc;               // [n][n_orient] scores for the top-K pass when they do not fit the LDS
     Hit *hits;               // [n][K]
@@ -48,13 +49,6 @@ struct GfftP {
 constexpr int gfft_row_stride(int L) { return L + 2; }       // float2 per T row: 16-byte row reads of 64 lanes hit distinct banks
 constexpr int gfft_slices_per_pass(int L) { return 64 / L; }
 constexpr size_t gfft_small_bytes() { return 256 * 8 + PPM_MAX_TOP_HITS * 8 + 256; }
-
-// a * conj(w), both in VGPR pairs
-__device__ __forceinline__ fr::v2f cmulc_v(fr::v2f a, fr::v2f w) {
-    fr::v2f t, d;
-    asm("v_pk_mul_f32 %1, %2, %3 op_sel_hi:[1,0]\n\tv_pk_fma_f32 %0, %2, %3, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(d), "=&v"(t) : "v"(a), "v"(w));
-    return d;
-}
 
 // ---------------------------------------------------------------------------------- slice bank in the layout of the column pass
 struct Bank4P { CubeView cv; const float *mats; float4 *bank4; int nslices, Bs, L; float r_s2; };
@@ -78,28 +72,41 @@ __global__ void __launch_bounds__(256) k_bank4(Bank4P P) {
     P.bank4[i] = make_float4(v[0].x, v[0].y, v[1].x, v[1].y);
 }
 
+// A wave-uniform table pointer the compiler may not look through: without it the twiddle loads of both passes are hoisted out of
+// the slice loop as loop invariants, outgrow the scalar registers, get parked in VGPR lanes and come back one v_readlane per dword.
+__device__ __forceinline__ fr::Tw16Ptr opaque(fr::Tw16Ptr p) { asm volatile("" : "+s"(p)); return p; }
+// ... and a wave-uniform integer: the window tests of a pass compare against loop invariants, and hoisted out of the slice loop
+// every one of them becomes a 64-bit mask parked in VGPR lanes (two v_readlane per test instead of one s_cmp)
+__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+s"(v)); return v; }
+
 // ---------------------------------------------------------------------------------- the column pass of one thread
-// y[n] = x[n] + x[n + L] (H = 0) or (x[n] - x[n + L]) w^n (H = 1), x = W conj(P) (E = 0) or W P (E = 1); bp / wl point at this
-// lane's column of the bank slice / of the W table.  Bank rows travel D rows ahead of their use (one wave per SIMD: nothing
-// else hides the L2 / Infinity-Cache latency), LDS rows DW ahead.
+// y[n] = x[n] + x[n + L] (H = 0) or x[n] - x[n + L] (H = 1; the factor w^n follows in a pass of its own), x = W conj(P) (E = 0) or
+// W P (E = 1).  `bank` is the wave-uniform base of the slice bank, voff this lane's byte offset of (slice, row 0, kx) — scalar base +
+// 32-bit lane offset + immediate, no 64-bit address arithmetic per row; wl points at this lane's column of the W table in LDS.
+// Bank rows travel D rows ahead of their use (one wave per SIMD: nothing else hides the L2 / Infinity-Cache latency), LDS rows DW
+// ahead; the scheduling barriers keep the compiler from sinking the loads back to their uses.
 template <int L, int E, int H>
-__device__ __forceinline__ void gfft_col_products(fr::v2f (&y)[L], const float4 *__restrict__ bp, const float4 *wl, fr::TwPtr tw) {
+__device__ __forceinline__ void gfft_col_products(fr::v2f (&y)[L], __amdgpu_buffer_rsrc_t bank, unsigned voff, const float4 *wl) {
     using namespace fr;
-    constexpr int D = L < 16 ? L : 16, DW = L < 4 ? L : 4;
-    float4 pb[D], wb[DW];
-    static_for<0, D>([&](auto ic) { constexpr int i = decltype(ic)::value; pb[i] = bp[i * L]; });
+    constexpr int D = L < 12 ? L : 12, DW = L < 4 ? L : 4;
+    v4f pb[D]; float4 wb[DW];
+    // bank row n of this lane: lane offset + (n % 4) KB as the instruction's immediate + 4 (n / 4) KB in a scalar register that steps once
+    // per four rows (left to itself the compiler keeps one VGPR offset per row, parks the 64 of them in AGPRs and fetches one per load)
+    int soff[L / 4 + 1];
+    soff[0] = opaque(0);
+    static_for<1, L / 4 + 1>([&](auto ic) { constexpr int i = decltype(ic)::value; soff[i] = soff[i - 1] + 4 * L * 16; });
+    auto bank_row = [&](auto nc) { constexpr int n = decltype(nc)::value; return __builtin_amdgcn_raw_buffer_load_b128(bank, (int)(voff + (n % 4) * L * 16), soff[n / 4], 0); };
+    static_for<0, D>([&](auto ic) { pb[decltype(ic)::value] = bank_row(ic); });
     static_for<0, DW>([&](auto ic) { constexpr int i = decltype(ic)::value; wb[i] = wl[i * L]; });
-    static_for<0, L>([&](auto nc) {
-        constexpr int n = decltype(nc)::value;
-        const float4 p4 = pb[n % D], w4 = wb[n % DW];
-        if constexpr (n + D < L) pb[n % D] = bp[(n + D) * L];
-        if constexpr (n + DW < L) wb[n % DW] = wl[(n + DW) * L];
-        const v2f pa = { p4.x, p4.y }, pbv = { p4.z, p4.w }, wa = { w4.x, w4.y }, wbv = { w4.z, w4.w };
-        v2f t = E ? cmul_v(wa, pa) : cmulc_v(wa, pa);
-        if constexpr (H) t = E ? cmsub_v(t, wbv, pbv) : cmsub_conj_v(t, wbv, pbv);
-        else t = E ? cmac_v(t, wbv, pbv) : cmac_conj_v(t, wbv, pbv);
-        if constexpr (H && n > 0) t = cmul_s(t, tw[n]);
-        y[n] = t;
+    static_for<0, L / 2>([&](auto nc) {
+        constexpr int n = 2 * decltype(nc)::value;
+        const v4f p0 = pb[n % D], p1 = pb[(n + 1) % D]; const float4 w0 = wb[n % DW], w1 = wb[(n + 1) % DW];
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (n + D < L) { pb[n % D] = bank_row(std::integral_constant<int, n + D>{}); pb[(n + 1) % D] = bank_row(std::integral_constant<int, n + 1 + D>{}); }
+        if constexpr (n + DW < L) { wb[n % DW] = wl[(n + DW) * L]; wb[(n + 1) % DW] = wl[(n + 1 + DW) * L]; }
+        prod2x2<E, H>(y[n], y[n + 1], (v2f){ w0.x, w0.y }, (v2f){ p0.x, p0.y }, (v2f){ w0.z, w0.w }, (v2f){ p0.z, p0.w },
+                      (v2f){ w1.x, w1.y }, (v2f){ p1.x, p1.y }, (v2f){ w1.z, w1.w }, (v2f){ p1.z, p1.w });
+        __builtin_amdgcn_sched_barrier(0);
     });
 }
 
@@ -111,14 +118,16 @@ template <int W> __device__ __forceinline__ float group_max(float v) {
     return v;
 }
 
-template <int LN>
+// CHUNKED: the window's rows pass through T in several chunks (the column pass then runs once per chunk and tests every output
+// against the chunk); only search grids of 128 points with more than +-44 steps need it.
+template <int LN, bool CHUNKED>
 __global__ void __launch_bounds__(256) k_gfft(GfftP P) {
     using namespace fr;
     constexpr int Ns = 1 << LN, L = Ns / 2, G = gfft_slices_per_pass(L), TS = gfft_row_stride(L), NPART = L == 64 ? 2 : 1;
     constexpr int GW = 2 * L < 64 ? 2 * L : 64;                    // lanes of a wave that share one (slice, orientation) in the row pass
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4 *W4 = (float4 *)smem;                                    // [L][L]
-    float2 *T = (float2 *)(smem + (size_t)L * L * sizeof(float4));  // [G][2][RC][TS]
+    float2 *T = (float2 *)smem;                                     // [G][2][RC][TS], first: its rows are addressed base + immediate
+    float4 *W4 = (float4 *)(smem + P.t_bytes);                      // [L][L]
     char *small = smem + (size_t)L * L * sizeof(float4) + P.t_bytes;
     float *red_v = (float *)small; int *red_k = (int *)(red_v + 256);      // per-thread (maximum, key) of an arg-max pass
     int *win_o = red_k + 256; float *win_c = (float *)(win_o + PPM_MAX_TOP_HITS);   // the K winning orientations and their scores
@@ -129,7 +138,8 @@ __global__ void __launch_bounds__(256) k_gfft(GfftP P) {
     const int Bs = P.Bs, RSy = P.RSy, RC = P.RC, NR = 2 * RSy + 1;
     const int nslices = P.n_dir * P.npsi_store;
     const bool half = P.npsi_store != P.n_psi;
-    const TwPtr tw = (TwPtr)P.twN, pen = (TwPtr)P.penpos;
+    const Tw16Ptr twb0 = (Tw16Ptr)P.twb, twl0 = (Tw16Ptr)P.twl;
+    const __amdgpu_buffer_rsrc_t bank = __builtin_amdgcn_make_buffer_rsrc((void *)P.bank4, 0, (int)P.bank4_bytes, 0x00020000);
 
     // ---- the particle's W table, two ky rows side by side like the bank
     {
@@ -222,23 +232,46 @@ __global__ void __launch_bounds__(256) k_gfft(GfftP P) {
             // ================= column pass
             if (half || ce == 0) {
                 v2f y[L];
-                const float4 *bp = P.bank4 + (size_t)(c_sl < 0 ? 0 : c_sl) * L * L + ckx;
-                if (ch == 0) { if (ce == 0) gfft_col_products<L, 0, 0>(y, bp, wl, tw); else gfft_col_products<L, 1, 0>(y, bp, wl, tw); }
-                else { if (ce == 0) gfft_col_products<L, 0, 1>(y, bp, wl, tw); else gfft_col_products<L, 1, 1>(y, bp, wl, tw); }
-                fft_inreg<L, Ns>(y, tw);
+                const Tw16Ptr twb = opaque(twb0), twl = opaque(twl0);
+                const unsigned voff = ((unsigned)(c_sl < 0 ? 0 : c_sl) * (unsigned)(L * L) + (unsigned)ckx) * 16u;
+                if (ch == 0) { if (ce == 0) gfft_col_products<L, 0, 0>(y, bank, voff, wl); else gfft_col_products<L, 1, 0>(y, bank, voff, wl); }
+                else {
+                    if (ce == 0) gfft_col_products<L, 0, 1>(y, bank, voff, wl); else gfft_col_products<L, 1, 1>(y, bank, voff, wl);
+                    static_for<0, L / 4>([&](auto jc) { constexpr int j = decltype(jc)::value; cmul4(y[4 * j], y[4 * j + 1], y[4 * j + 2], y[4 * j + 3], twl[j]); });
+                }
+                fft_inreg<L>(y, twb);
                 // output f of the L-point transform is row sy = 2 f + h (mod Ns) of the image: rows 0 .. RSy sit in slots 0 .. RSy,
                 // rows -1 .. -RSy in slots RSy + 1 .. 2 RSy
-                const int spos = ch - c0, sneg = RSy - ch - c0;
-                static_for<0, L>([&](auto pc) {
-                    constexpr int pp = decltype(pc)::value, f = freq_at(L, pp);
-                    if constexpr (2 * f < L) {
-                        const int slot = 2 * f + spos;
-                        if (2 * f + ch <= RSy && slot >= 0 && slot < RC) Tc[slot * TS] = make_float2(y[pp].x, y[pp].y);
-                    } else {
-                        const int slot = 2 * (L - f) + sneg;
-                        if (2 * (L - f) - ch <= RSy && slot >= 0 && slot < RC) Tc[slot * TS] = make_float2(y[pp].x, y[pp].y);
-                    }
-                });
+                if constexpr (!CHUNKED) {
+                    // f <= fmax (rows 2 f + h <= RSy) and j = L - f <= jmax (rows -(2 j - h) >= -RSy) are inside the window: tested per
+                    // group of four outputs, per output only in the one group the window's edge cuts
+                    float2 *Tpos = Tc + ch * TS, *Tneg = Tc + (RSy - ch) * TS;
+                    const int fmax = opaque(min((RSy - ch) >> 1, L / 2 - 1)), jmax = opaque(min((RSy + ch) >> 1, L / 2));
+                    auto st_pos = [&](auto fc) { constexpr int f = decltype(fc)::value; constexpr int pp = pos_of(L, f); Tpos[2 * f * TS] = make_float2(y[pp].x, y[pp].y); };
+                    auto st_neg = [&](auto jc) { constexpr int j = decltype(jc)::value; constexpr int pp = pos_of(L, L - j); Tneg[2 * j * TS] = make_float2(y[pp].x, y[pp].y); };
+                    static_for<0, L / 8>([&](auto gc) {
+                        constexpr int f0 = 4 * decltype(gc)::value;
+                        if (f0 + 3 <= fmax) static_for<f0, f0 + 4>(st_pos);
+                        else if (f0 <= fmax) static_for<f0, f0 + 3>([&](auto fc) { if (decltype(fc)::value <= fmax) st_pos(fc); });
+                    });
+                    static_for<0, L / 8>([&](auto gc) {
+                        constexpr int j0 = 4 * decltype(gc)::value + 1;
+                        if (j0 + 3 <= jmax) static_for<j0, j0 + 4>(st_neg);
+                        else if (j0 <= jmax) static_for<j0, j0 + 3>([&](auto jc) { if (decltype(jc)::value <= jmax) st_neg(jc); });
+                    });
+                } else {
+                    const int spos = ch - c0, sneg = RSy - ch - c0;
+                    static_for<0, L>([&](auto pc) {
+                        constexpr int pp = decltype(pc)::value, f = freq_at(L, pp);
+                        if constexpr (2 * f < L) {
+                            const int slot = 2 * f + spos;
+                            if (2 * f + ch <= RSy && slot >= 0 && slot < RC) Tc[slot * TS] = make_float2(y[pp].x, y[pp].y);
+                        } else {
+                            const int slot = 2 * (L - f) + sneg;
+                            if (2 * (L - f) - ch <= RSy && slot >= 0 && slot < RC) Tc[slot * TS] = make_float2(y[pp].x, y[pp].y);
+                        }
+                    });
+                }
             }
             lds_barrier();
             // ================= row pass
@@ -247,40 +280,45 @@ __global__ void __launch_bounds__(256) k_gfft(GfftP P) {
             float best = -3.0e38f; int bkey = 0x7fffffff;
             if (active) {
                 v2f z[L];
-                {
-                    v2f x[L];
-                    static_for<0, L / 2>([&](auto ic) {
-                        constexpr int i = decltype(ic)::value;
-                        const float4 v = *(const float4 *)(Tr + 2 * i);
-                        x[2 * i] = (v2f){ v.x, v.y }; x[2 * i + 1] = (v2f){ v.z, v.w };
-                    });
-                    // Z[k] = (X[k] + conj X[L-k]) + i w^k (X[k] - conj X[L-k]);  Z[L-k] = conj(s) + i conj(t)
-                    z[0] = (v2f){ 2.f * x[0].x, 2.f * x[0].x };
-                    z[L / 2] = (v2f){ 2.f * x[L / 2].x, -2.f * x[L / 2].y };
-                    static_for<1, L / 2>([&](auto kc) {
-                        constexpr int k = decltype(kc)::value;
-                        const v2f s = add_conj(x[k], x[L - k]), d = sub_conj(x[k], x[L - k]);
-                        const v2f t = cmul_s(d, tw[k]);
-                        z[k] = add_i(s, t);
-                        z[L - k] = conj_add_i_conj(s, t);
-                    });
-                }
-                fft_inreg<L, Ns>(z, tw);
-                // z[position of f] = 2 (c(2 f), c(2 f + 1)); columns outside the window get -3e38
-                static_for<0, L>([&](auto pc) {
-                    constexpr int pp = decltype(pc)::value;
-                    z[pp] += pen[pp];
-                    best = fmaxf(best, fmaxf(z[pp].x, z[pp].y));
+                const Tw16Ptr twb = opaque(twb0), twl = opaque(twl0);
+                static_for<0, L / 2>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    const float4 v = *(const float4 *)(Tr + 2 * i);
+                    z[2 * i] = (v2f){ v.x, v.y }; z[2 * i + 1] = (v2f){ v.z, v.w };
+                });
+                // the real Ns-point transform of the row through one L-point complex transform, in place:
+                // Z[k] = (X[k] + conj X[L-k]) + i w^k (X[k] - conj X[L-k]), Z[L-k] = conj(s) + i conj(t); Z[0] = 2 Re X[0] (1 + i), Z[L/2] = 2 conj X[L/2]
+                z[0] = (v2f){ 2.f * z[0].x, 2.f * z[0].x };
+                z[L / 2] = (v2f){ 2.f * z[L / 2].x, -2.f * z[L / 2].y };
+                { const v16f w = twl[0]; halfpair1(z[1], z[L - 1], (v2f){ w[4], w[5] }, (v2f){ w[6], w[7] }); }
+                static_for<1, L / 4>([&](auto kc) {
+                    constexpr int k = 2 * decltype(kc)::value, e4 = (k % 4) * 4;
+                    const v16f w = twl[k / 4];
+                    halfpair2(z[k], z[L - k], z[k + 1], z[L - k - 1], (v2f){ w[e4], w[e4 + 1] }, (v2f){ w[e4 + 2], w[e4 + 3] }, (v2f){ w[e4 + 4], w[e4 + 5] }, (v2f){ w[e4 + 6], w[e4 + 7] });
+                });
+                fft_inreg<L>(z, twb);
+                // z[position of f] = 2 (c(2 f), c(2 f + 1)), column j = the shift sx = j (j < L) or j - Ns.  Columns |sx| <= RSx are inside
+                // the window: tested per group of four |sx|, per column only in the group the window's edge cuts
+                auto col = [&](auto jc) -> float { constexpr int j = decltype(jc)::value; constexpr int pp = pos_of(L, j / 2); return (j & 1) ? z[pp].y : z[pp].x; };
+                auto mx = [&](auto ac) {
+                    constexpr int a = decltype(ac)::value;
+                    if constexpr (a == 0) best = fmaxf(best, col(std::integral_constant<int, 0>{}));
+                    else best = fmaxf(best, fmaxf(col(std::integral_constant<int, a>{}), col(std::integral_constant<int, Ns - a>{})));
+                };
+                const int rsx = opaque(P.RSx);
+                static_for<0, L / 4>([&](auto gc) {
+                    constexpr int a0 = 4 * decltype(gc)::value;
+                    if (a0 + 3 <= rsx) static_for<a0, a0 + 4>(mx);
+                    else if (a0 <= rsx) static_for<a0, a0 + 3>([&](auto ac) { if (decltype(ac)::value <= rsx) mx(ac); });
                 });
                 if (argpass) {
                     // lowest column (scan order of the oracle: sx ascending) that holds the row's maximum
                     int bsx = 0x7fff;
-                    static_for<0, Ns>([&](auto jc) {
-                        constexpr int jj = Ns - 1 - decltype(jc)::value;      // descending sx: the last match that sticks is the lowest
-                        constexpr int sxm = (jj + L) % Ns;                     // sx = jj - L + ... : walk sx = L-1 .. -L
-                        constexpr int pp = pos_of(L, sxm / 2);
-                        const float v = (sxm & 1) ? z[pp].y : z[pp].x;
-                        if (v == best) bsx = sxm < L ? sxm : sxm - Ns;
+                    static_for<0, Ns - 1>([&](auto jc) {
+                        constexpr int sx = L - 1 - decltype(jc)::value;                  // L - 1 down to -(L - 1): the last match that sticks is the lowest
+                        constexpr int jj = (sx + Ns) % Ns, pp = pos_of(L, jj / 2);
+                        const float v = (jj & 1) ? z[pp].y : z[pp].x;
+                        if (v == best && sx >= -rsx && sx <= rsx) bsx = sx;
                     });
                     const int sy = slot <= RSy ? slot : RSy - slot;
                     bkey = (sy + RSy) * Ns + (bsx + L);

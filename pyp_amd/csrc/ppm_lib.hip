@@ -221,8 +221,8 @@ struct ppm_ref {
     DevBuf<int> tile_c;
     DevBuf<LState> states, states2;
     // full-window correlation (k_gfft): the bank in the column pass's layout, window maxima per (particle, orientation), column penalties
-    DevBuf<float4> bank4; DevBuf<float> part; DevBuf<float2> penpos;
-    std::string bank_key, bank4_key, pen_key;
+    DevBuf<float4> bank4; DevBuf<float> part, gtw;       // gtw: twiddle tables of the search grid (butterfly table, then line table)
+    std::string bank_key, bank4_key; int gtw_ns = 0;
     long last_counts[4] = { 0, 0, 0, 0 };
     std::string note;
 };
@@ -437,22 +437,30 @@ static bool gfft_plan(const Geom &gm, GfftPlan &pl) {
     pl.lds = fixed + pl.t_bytes;
     return true;
 }
-template <int LN>
+template <int LN, bool CHUNKED>
 static int launch_gfft_k(const GfftP &P, int n_img, size_t lds) {
     static bool set = false;
-    { std::lock_guard<std::mutex> lk_attr(g_mu); if (!set) { HIPCHK(hipFuncSetAttribute((const void *)k_gfft<LN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } }
-    hipLaunchKernelGGL((k_gfft<LN>), dim3(n_img), dim3(256), lds, cur_stream(), P);
+    { std::lock_guard<std::mutex> lk_attr(g_mu); if (!set) { HIPCHK(hipFuncSetAttribute((const void *)k_gfft<LN, CHUNKED>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } }
+    hipLaunchKernelGGL((k_gfft<LN, CHUNKED>), dim3(n_img), dim3(256), lds, cur_stream(), P);
     HIPCHK(hipGetLastError());
     return 0;
 }
 static int launch_gfft(GfftP &P, int n_img, const GfftPlan &pl) {
     P.n = n_img; P.RC = pl.RC; P.nchunk = pl.nchunk; P.t_bytes = (int)pl.t_bytes; P.topk_lds = pl.topk_lds;
     ProfScope ps(PPM_K_GLOBAL);
+    if (pl.nchunk > 1) {
+        switch (pl.LN) {
+            case 4: return launch_gfft_k<4, true>(P, n_img, pl.lds);
+            case 5: return launch_gfft_k<5, true>(P, n_img, pl.lds);
+            case 6: return launch_gfft_k<6, true>(P, n_img, pl.lds);
+            default: return launch_gfft_k<7, true>(P, n_img, pl.lds);
+        }
+    }
     switch (pl.LN) {
-        case 4: return launch_gfft_k<4>(P, n_img, pl.lds);
-        case 5: return launch_gfft_k<5>(P, n_img, pl.lds);
-        case 6: return launch_gfft_k<6>(P, n_img, pl.lds);
-        default: return launch_gfft_k<7>(P, n_img, pl.lds);
+        case 4: return launch_gfft_k<4, false>(P, n_img, pl.lds);
+        case 5: return launch_gfft_k<5, false>(P, n_img, pl.lds);
+        case 6: return launch_gfft_k<6, false>(P, n_img, pl.lds);
+        default: return launch_gfft_k<7, false>(P, n_img, pl.lds);
     }
 }
 
@@ -649,7 +657,7 @@ void ppm_reference_destroy(ppm_ref_t *r) {
     r->c_delta.release(); r->c_s0.release(); r->c_g0.release(); r->c_out.release(); r->c_eval.release(); r->c_rp.release(); r->c_rt.release(); r->c_slot.release(); r->c_states.release(); r->c_uoff.release(); r->c_mean.release(); r->cc.release(); r->mats.release(); r->ddef.release();
     r->band.release(); r->spill.release(); r->Il.release(); r->Wp.release(); r->bank.release(); r->twN.release(); r->rowtw.release(); r->sh.release(); r->samples.release();
     r->hits.release(); r->states.release(); r->states2.release();
-    r->hits_t.release(); r->tile_c.release(); r->bank4.release(); r->part.release(); r->penpos.release();
+    r->hits_t.release(); r->tile_c.release(); r->bank4.release(); r->part.release(); r->gtw.release();
     if (r->stream) (void)hipStreamDestroy(r->stream);
     if (r->copy) (void)hipStreamDestroy(r->copy);
     delete r;
@@ -874,6 +882,7 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
         char key[200];
         std::snprintf(key, sizeof(key), "%s/L%d", ref->bank_key.c_str(), L);
         if (ref->bank4_key != key) {
+            if ((size_t)nslices * L * L * sizeof(float4) >= ((size_t)1 << 32)) return fail(-22, "slice bank of the grid search exceeds 4 GB: use a coarser angular step or a narrower search band");
             if (int rc = ref->bank4.ensure((size_t)nslices * L * L)) return rc;
             Bank4P BP; BP.cv = cv; BP.mats = ref->mats.p; BP.bank4 = ref->bank4.p; BP.nslices = nslices; BP.Bs = gm.Bs; BP.L = L; BP.r_s2 = (float)(gm.r_s * gm.r_s);
             ProfScope ps(PPM_K_BANK);
@@ -882,21 +891,20 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
             HIPCHK(hipGetLastError());
             ref->bank4_key = key;
         }
-        std::snprintf(key, sizeof(key), "%d/%d", gm.Ns, gm.RSx);
-        if (ref->pen_key != key) {
-            // column penalties of the row pass, in the order the L-point transform leaves its outputs: position p holds the columns
-            // j = 2 f, 2 f + 1 (f = freq_at(L, p)), column j is the shift sx = j (j < L) or j - Ns
-            std::vector<float2> pen(L);
-            for (int pp = 0; pp < L; pp++) {
-                const int f = fr::freq_at(L, pp);
-                float v[2];
-                for (int h = 0; h < 2; h++) { const int j = 2 * f + h, sx = j < L ? j : j - gm.Ns; v[h] = std::abs(sx) <= gm.RSx ? 0.f : -3.0e38f; }
-                pen[pp] = make_float2(v[0], v[1]);
-            }
-            if (int rc = ref->penpos.ensure(L)) return rc;
-            HIPCHK(hipMemcpyAsync(ref->penpos.p, pen.data(), pen.size() * sizeof(float2), hipMemcpyHostToDevice, cur_stream()));
+        if (ref->gtw_ns != gm.Ns) {
+            // twiddle tables of the in-register transforms (ppm_fft_reg.h), 16 floats per entry, each twiddle as (c, s, -s, s):
+            // the butterfly table of the L-point transform, then the line table w^0 .. w^(L-1) of the Ns-point grid
+            const int nb = fr::bfly_entries(L);
+            std::vector<float> tw((size_t)(nb + L / 4) * 16, 0.f);
+            auto put = [&](float *d, double ang) { const float c = (float)std::cos(ang), sn = (float)std::sin(ang); d[0] = c; d[1] = sn; d[2] = -sn; d[3] = sn; };
+            for (int M = L; M >= 8; M /= 4)
+                for (int k = 1; k < M / 4; k++)
+                    for (int j = 1; j <= 3; j++) put(&tw[(size_t)fr::bfly_entry(L, M, k) * 16 + (j - 1) * 4], 2.0 * kPi * j * k / M);
+            for (int t = 0; t < L; t++) put(&tw[(size_t)nb * 16 + (size_t)t * 4], 2.0 * kPi * t / gm.Ns);
+            if (int rc = ref->gtw.ensure(tw.size())) return rc;
+            HIPCHK(hipMemcpyAsync(ref->gtw.p, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice, cur_stream()));
             HIPCHK(hipStreamSynchronize(cur_stream()));       // the host vector goes out of scope
-            ref->pen_key = key;
+            ref->gtw_ns = gm.Ns;
         }
     }
     HIPCHK(hipStreamSynchronize(cur_stream()));
@@ -994,7 +1002,7 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
             }
             if (use_fft) {
                 GfftP FP;
-                FP.bank4 = ref->bank4.p; FP.Wp = ref->Wp.p; FP.nP = ref->nP.p; FP.nI = ref->nI.p; FP.twN = ref->twN.p; FP.penpos = ref->penpos.p;
+                FP.bank4 = ref->bank4.p; FP.bank4_bytes = (unsigned)((size_t)nslices * gpl.L * gpl.L * sizeof(float4)); FP.Wp = ref->Wp.p; FP.nP = ref->nP.p; FP.nI = ref->nI.p; FP.twb = ref->gtw.p; FP.twl = ref->gtw.p + (size_t)fr::bfly_entries(gpl.L) * 16;
                 FP.part = ref->part.p; FP.cc = ref->cc.p; FP.hits = ref->hits.p;
                 FP.Bs = gm.Bs; FP.Hs = gm.Hs; FP.RSx = gm.RSx; FP.RSy = gm.RSy;
                 FP.n_dir = gm.n_dir; FP.n_psi = gm.n_psi; FP.npsi_store = gm.npsi_store; FP.n_orient = gm.n_orient; FP.K = K;
