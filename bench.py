@@ -110,7 +110,7 @@ def probe_main(a, rank, world):
 
 
 # --------------------------------------------------------------------------------------------- helpers
-KERNEL_SOURCES = ("ppm_dev.h", "ppm_kernels.h", "ppm_kernels2.h", "ppm_csp_kernels.h", "ppm_sva_kernels.h")
+KERNEL_SOURCES = ("ppm_dev.h", "ppm_kernels.h", "ppm_kernels2.h", "ppm_csp_kernels.h", "ppm_sva_kernels.h", "ppm_gfft.h", "ppm_fft_reg.h")
 
 
 def so_sha16():
@@ -119,7 +119,7 @@ def so_sha16():
     return hashlib.sha256(open(p, "rb").read()).hexdigest()[:16] if os.path.exists(p) else None
 
 
-KERNEL_SOURCES_MAIN = ("ppm_dev.h", "ppm_kernels.h", "ppm_kernels2.h")      # the refinement and insertion kernels (what the PMC summaries profile)
+KERNEL_SOURCES_MAIN = ("ppm_dev.h", "ppm_kernels.h", "ppm_kernels2.h", "ppm_gfft.h", "ppm_fft_reg.h")      # the refinement and insertion kernels (what the PMC summaries profile)
 
 
 def kernels_sha16(files=KERNEL_SOURCES):

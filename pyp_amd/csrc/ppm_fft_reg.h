@@ -13,8 +13,7 @@
 // s_nop included, costs a 4-cycle issue slot (2.35 ns per v_pk_fma_f32, dependent or not), so the kernel wants straight runs of
 // packed instructions: a statement holds a complete radix-4 butterfly with its three twiddle products (14 instructions), two rows
 // of the correlation's products (8), or four twiddle products (8); statements of one pass are independent of their neighbours.
-// Twiddles are wave-uniform: (c, s, -s, s) entries of tables in device memory, fetched 16 dwords at a time by scalar loads through
-// the constant address space, and enter the packed instructions as their one scalar operand.
+// Twiddles are wave-uniform (cos, sin) pairs read from tables in LDS (all lanes one address: a broadcast read) two statements ahead.
 //
 // Sign convention: all transforms here are X[m] = sum_n x[n] e^{+2 pi i n m / N} (the correlation's inverse transforms).
 #pragma once
@@ -27,8 +26,6 @@ namespace fr {
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v16f __attribute__((ext_vector_type(16)));
-typedef const __attribute__((address_space(4))) v2f *TwPtr;        // wave-uniform pairs (scalar loads)
-typedef const __attribute__((address_space(4))) v16f *Tw16Ptr;     // 64-byte table entries: up to four twiddles (c, s, -s, s)
 
 constexpr int ilog2(int n) { return n <= 1 ? 0 : 1 + ilog2(n / 2); }
 
@@ -49,20 +46,44 @@ template <int I, int N, class F> __device__ __forceinline__ void static_for(F &&
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
 }
 
-// ---- twiddle tables (built on the host, read by the kernels through scalar loads)
+// ---- twiddle tables (built on the host, copied into LDS by the kernel, read by broadcast ds_reads)
+// Twiddles are (cos, sin) pairs in VGPRs: the scalar path was tried first (s_load_dwordx16 into SGPR operands) and lost — scalar loads
+// return out of order, so the only wait is lgkmcnt(0), and every table entry cost a full exposed scalar-cache round trip (36 % of the
+// kernel's wave cycles sat in s_waitcnt, profiles/r05_pmc_refine0_a.json).  LDS reads return in order and can be counted, so the
+// entries travel two butterflies ahead of their use.
 // Butterfly table of an N-point transform: for every radix-4 pass with block size M = N, N/4, ... >= 8 and every k = 1 .. M/4 - 1 one
-// 16-float entry (w^k, w^2k, w^3k, padding), w = e^{2 pi i / M}, each twiddle as (c, s, -s, s).  bfly_entry(N, M, k) is its index.
+// 8-float entry (w^k, w^2k, w^3k, padding), w = e^{2 pi i / M}.  bfly_entry(N, M, k) is its index.
 constexpr int bfly_entries(int N) { int e = 0; for (int M = N; M >= 8; M /= 4) e += M / 4 - 1; return e; }
 constexpr int bfly_entry(int N, int M, int k) { int e = 0; for (int m = N; m > M; m /= 4) e += m / 4 - 1; return e + k - 1; }
-// Line table of a 2 L-point grid: entry j holds w^(4j) .. w^(4j+3), w = e^{2 pi i / (2 L)} (the decimation twiddles of the column pass
-// and the half-length trick of the row pass); L / 4 entries cover w^0 .. w^(L-1).
+// Line table of a 2 L-point grid: w^n, n = 0 .. L - 1, w = e^{2 pi i / (2 L)} (the decimation twiddles of the column pass and the
+// half-length trick of the row pass).
+constexpr int tw_table_floats(int L) { return bfly_entries(L) * 8 + L * 2; }
 
-// ---- one radix-4 decimation-in-frequency butterfly, in place; with TW the outputs 1 .. 3 are multiplied by w^k, w^2k, w^3k
+// The radix-4 passes of an N-point transform, breadth first: butterfly i works on x[pos[i][0..3]]; entry[i] is its table entry (-1: k = 0,
+// no twiddles) and tidx[i] its number among the twiddled ones, whose entries in order are seq[0 .. NT).
+template <int N> struct FftPlan {
+    static constexpr int NS4 = ilog2(N) / 2, NB = NS4 * (N / 4);
+    int pos[NB > 0 ? NB : 1][4], entry[NB > 0 ? NB : 1], tidx[NB > 0 ? NB : 1], seq[NB > 0 ? NB : 1], NT;
+    constexpr FftPlan() : pos{}, entry{}, tidx{}, seq{}, NT(0) {
+        int i = 0;
+        for (int M = N; M >= 4; M /= 4) {
+            const int q = M / 4;
+            for (int base = 0; base < N; base += M)
+                for (int k = 0; k < q; k++, i++) {
+                    for (int j = 0; j < 4; j++) pos[i][j] = base + k + j * q;
+                    entry[i] = k > 0 ? bfly_entry(N, M, k) : -1;
+                    tidx[i] = -1;
+                    if (k > 0) { tidx[i] = NT; seq[NT++] = entry[i]; }
+                }
+        }
+    }
+};
+
+// ---- one radix-4 decimation-in-frequency butterfly, in place; with TW the outputs 1 .. 3 are multiplied by w1, w2, w3 = (cos, sin)
 template <bool TW>
-__device__ __forceinline__ void bfly4(v2f &x0, v2f &x1, v2f &x2, v2f &x3, v16f w) {
+__device__ __forceinline__ void bfly4(v2f &x0, v2f &x1, v2f &x2, v2f &x3, v2f w1, v2f w2, v2f w3) {
     v2f a = x0, b = x1, c = x2, d = x3, t0, t1;
     if constexpr (TW) {
-        const v2f w1c = { w[0], w[1] }, w1s = { w[2], w[3] }, w2c = { w[4], w[5] }, w2s = { w[6], w[7] }, w3c = { w[8], w[9] }, w3s = { w[10], w[11] };
         asm("v_pk_add_f32 %4, %0, %2\n\t"
             "v_pk_add_f32 %0, %0, %2 neg_lo:[0,1] neg_hi:[0,1]\n\t"
             "v_pk_add_f32 %2, %1, %3\n\t"
@@ -72,13 +93,13 @@ __device__ __forceinline__ void bfly4(v2f &x0, v2f &x1, v2f &x2, v2f &x3, v16f w
             "v_pk_add_f32 %2, %0, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
             "v_pk_add_f32 %0, %0, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"
             "v_pk_mul_f32 %5, %2, %6 op_sel_hi:[1,0]\n\t"
-            "v_pk_fma_f32 %2, %2, %7, %5 op_sel:[1,0,0] op_sel_hi:[0,1,1]\n\t"
-            "v_pk_mul_f32 %5, %3, %8 op_sel_hi:[1,0]\n\t"
-            "v_pk_fma_f32 %3, %3, %9, %5 op_sel:[1,0,0] op_sel_hi:[0,1,1]\n\t"
-            "v_pk_mul_f32 %5, %0, %10 op_sel_hi:[1,0]\n\t"
-            "v_pk_fma_f32 %0, %0, %11, %5 op_sel:[1,0,0] op_sel_hi:[0,1,1]"
+            "v_pk_fma_f32 %2, %2, %6, %5 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]\n\t"
+            "v_pk_mul_f32 %5, %3, %7 op_sel_hi:[1,0]\n\t"
+            "v_pk_fma_f32 %3, %3, %7, %5 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]\n\t"
+            "v_pk_mul_f32 %5, %0, %8 op_sel_hi:[1,0]\n\t"
+            "v_pk_fma_f32 %0, %0, %8, %5 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
             : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "=&v"(t0), "=&v"(t1)
-            : "s"(w1c), "s"(w1s), "s"(w2c), "s"(w2s), "s"(w3c), "s"(w3s));
+            : "v"(w1), "v"(w2), "v"(w3));
     } else {
         asm("v_pk_add_f32 %4, %0, %2\n\t"
             "v_pk_add_f32 %0, %0, %2 neg_lo:[0,1] neg_hi:[0,1]\n\t"
@@ -103,48 +124,42 @@ __device__ __forceinline__ void bfly2x2(v2f &x0, v2f &x1, v2f &x2, v2f &x3) {
     x0 = t0; x1 = b; x2 = t1; x3 = d;
 }
 
-// In-place transform of x[BASE .. BASE + M) of an N-element register array (N a power of two, 8 .. 64); tb = bfly table of N
-template <int N, int M, int BASE>
-__device__ __forceinline__ void fft_dif(v2f (&x)[N], Tw16Ptr tb) {
-    if constexpr (M == 2) {
-        static_assert(BASE % 4 == 0, "radix-2 blocks are taken in pairs");
-        bfly2x2(x[BASE], x[BASE + 1], x[BASE + 2], x[BASE + 3]);
-    } else if constexpr (M >= 4) {
-        constexpr int q = M / 4;
-        static_for<0, q>([&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            if constexpr (k == 0) bfly4<false>(x[BASE], x[BASE + q], x[BASE + 2 * q], x[BASE + 3 * q], v16f{});
-            else bfly4<true>(x[BASE + k], x[BASE + k + q], x[BASE + k + 2 * q], x[BASE + k + 3 * q], tb[bfly_entry(N, M, k)]);
-        });
-        if constexpr (q == 2) {            // two radix-2 blocks per statement
-            fft_dif<N, 2, BASE>(x, tb);
-            fft_dif<N, 2, BASE + 4>(x, tb);
-        } else if constexpr (q >= 4) {
-            fft_dif<N, q, BASE>(x, tb);
-            fft_dif<N, q, BASE + q>(x, tb);
-            fft_dif<N, q, BASE + 2 * q>(x, tb);
-            fft_dif<N, q, BASE + 3 * q>(x, tb);
-        }
-    }
-}
-// X[m] = sum_n x[n] e^{+2 pi i n m / N}; afterwards x[pos_of(N, m)] holds X[m].
+// X[m] = sum_n x[n] e^{+2 pi i n m / N}, in place; afterwards x[pos_of(N, m)] holds X[m].  tb: the butterfly table of N in LDS.
 template <int N>
-__device__ __forceinline__ void fft_inreg(v2f (&x)[N], Tw16Ptr tb) { fft_dif<N, N, 0>(x, tb); }
+__device__ __forceinline__ void fft_inreg(v2f (&x)[N], const float *tb) {
+    constexpr FftPlan<N> P{};
+    constexpr int NB = FftPlan<N>::NB, NT = P.NT, DQ = 3;
+    v4f wa[DQ]; v2f wb[DQ];                         // (w1, w2) and w3 of the twiddled butterflies in flight
+    auto fetch = [&](auto tc) { constexpr int t = decltype(tc)::value; wa[t % DQ] = *(const v4f *)(tb + P.seq[t] * 8); wb[t % DQ] = *(const v2f *)(tb + P.seq[t] * 8 + 4); };
+    if constexpr (NT > 0) fetch(std::integral_constant<int, 0>{});
+    if constexpr (NT > 1) fetch(std::integral_constant<int, 1>{});
+    static_for<0, NB>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (P.entry[i] < 0) bfly4<false>(x[P.pos[i][0]], x[P.pos[i][1]], x[P.pos[i][2]], x[P.pos[i][3]], v2f{}, v2f{}, v2f{});
+        else {
+            constexpr int t = P.tidx[i];
+            const v4f w12 = wa[t % DQ]; const v2f w3 = wb[t % DQ];
+            if constexpr (t + 2 < NT) fetch(std::integral_constant<int, t + 2>{});
+            __builtin_amdgcn_sched_barrier(0);
+            bfly4<true>(x[P.pos[i][0]], x[P.pos[i][1]], x[P.pos[i][2]], x[P.pos[i][3]], (v2f){ w12.x, w12.y }, (v2f){ w12.z, w12.w }, w3);
+        }
+    });
+    if constexpr (ilog2(N) % 2 == 1) static_for<0, N / 4>([&](auto ic) { constexpr int i = 4 * decltype(ic)::value; bfly2x2(x[i], x[i + 1], x[i + 2], x[i + 3]); });
+}
 
-// ---- four products with the twiddles of one line-table entry: x_i *= w_i
-__device__ __forceinline__ void cmul4(v2f &x0, v2f &x1, v2f &x2, v2f &x3, v16f w) {
+// ---- four products with consecutive entries of the line table: x_i *= w_i
+__device__ __forceinline__ void cmul4(v2f &x0, v2f &x1, v2f &x2, v2f &x3, v2f w0, v2f w1, v2f w2, v2f w3) {
     v2f a = x0, b = x1, c = x2, d = x3, t0, t1;
-    const v2f w0c = { w[0], w[1] }, w0s = { w[2], w[3] }, w1c = { w[4], w[5] }, w1s = { w[6], w[7] }, w2c = { w[8], w[9] }, w2s = { w[10], w[11] }, w3c = { w[12], w[13] }, w3s = { w[14], w[15] };
     asm("v_pk_mul_f32 %4, %0, %6 op_sel_hi:[1,0]\n\t"
-        "v_pk_mul_f32 %5, %1, %8 op_sel_hi:[1,0]\n\t"
-        "v_pk_fma_f32 %0, %0, %7, %4 op_sel:[1,0,0] op_sel_hi:[0,1,1]\n\t"
-        "v_pk_fma_f32 %1, %1, %9, %5 op_sel:[1,0,0] op_sel_hi:[0,1,1]\n\t"
-        "v_pk_mul_f32 %4, %2, %10 op_sel_hi:[1,0]\n\t"
-        "v_pk_mul_f32 %5, %3, %12 op_sel_hi:[1,0]\n\t"
-        "v_pk_fma_f32 %2, %2, %11, %4 op_sel:[1,0,0] op_sel_hi:[0,1,1]\n\t"
-        "v_pk_fma_f32 %3, %3, %13, %5 op_sel:[1,0,0] op_sel_hi:[0,1,1]"
+        "v_pk_mul_f32 %5, %1, %7 op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %0, %6, %4 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]\n\t"
+        "v_pk_fma_f32 %1, %1, %7, %5 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]\n\t"
+        "v_pk_mul_f32 %4, %2, %8 op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %5, %3, %9 op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %2, %2, %8, %4 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]\n\t"
+        "v_pk_fma_f32 %3, %3, %9, %5 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
         : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "=&v"(t0), "=&v"(t1)
-        : "s"(w0c), "s"(w0s), "s"(w1c), "s"(w1s), "s"(w2c), "s"(w2s), "s"(w3c), "s"(w3s));
+        : "v"(w0), "v"(w1), "v"(w2), "v"(w3));
     x0 = a; x1 = b; x2 = c; x3 = d;
 }
 
@@ -171,36 +186,35 @@ __device__ __forceinline__ void prod2x2(v2f &d0, v2f &d1, v2f wa0, v2f pa0, v2f 
 #undef PPM_PROD2X2
 
 // ---- the half-length trick of a real 2 L-point transform (row pass): with s = X[k] + conj X[L-k], t = w^k (X[k] - conj X[L-k]),
-// Z[k] = s + i t and Z[L-k] = conj(s) + i conj(t).  Two pairs per statement; wc / ws = (c, s) / (-s, s) of w^k.
-__device__ __forceinline__ void halfpair2(v2f &xk0, v2f &xl0, v2f &xk1, v2f &xl1, v2f w0c, v2f w0s, v2f w1c, v2f w1s) {
+// Z[k] = s + i t and Z[L-k] = conj(s) + i conj(t).  Two pairs per statement; w = (cos, sin) of w^k.
+__device__ __forceinline__ void halfpair2(v2f &xk0, v2f &xl0, v2f &xk1, v2f &xl1, v2f w0, v2f w1) {
     v2f a = xk0, b = xl0, c = xk1, d = xl1, t0, t1;
     asm("v_pk_add_f32 %4, %0, %1 neg_lo:[0,1]\n\t"                               // d = a - conj(b)
         "v_pk_add_f32 %5, %2, %3 neg_lo:[0,1]\n\t"
         "v_pk_add_f32 %0, %0, %1 neg_hi:[0,1]\n\t"                               // s = a + conj(b)
         "v_pk_add_f32 %2, %2, %3 neg_hi:[0,1]\n\t"
         "v_pk_mul_f32 %1, %4, %6 op_sel_hi:[1,0]\n\t"                            // t = d w
-        "v_pk_mul_f32 %3, %5, %8 op_sel_hi:[1,0]\n\t"
-        "v_pk_fma_f32 %1, %4, %7, %1 op_sel:[1,0,0] op_sel_hi:[0,1,1]\n\t"
-        "v_pk_fma_f32 %3, %5, %9, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_mul_f32 %3, %5, %7 op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %1, %4, %6, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]\n\t"
+        "v_pk_fma_f32 %3, %5, %7, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]\n\t"
         "v_pk_add_f32 %4, %0, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"  // Z[k] = s + i t
         "v_pk_add_f32 %5, %2, %3 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
         "v_pk_add_f32 %1, %0, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[1,0]\n\t"  // Z[L-k] = (s.x + t.y, t.x - s.y)
         "v_pk_add_f32 %3, %2, %3 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[1,0]"
         : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "=&v"(t0), "=&v"(t1)
-        : "s"(w0c), "s"(w0s), "s"(w1c), "s"(w1s));
+        : "v"(w0), "v"(w1));
     xk0 = t0; xl0 = b; xk1 = t1; xl1 = d;
 }
-
 // one pair (the odd one out: k = 1)
-__device__ __forceinline__ void halfpair1(v2f &xk, v2f &xl, v2f wc, v2f ws) {
+__device__ __forceinline__ void halfpair1(v2f &xk, v2f &xl, v2f w) {
     v2f a = xk, b = xl, t0;
     asm("v_pk_add_f32 %2, %0, %1 neg_lo:[0,1]\n\t"
         "v_pk_add_f32 %0, %0, %1 neg_hi:[0,1]\n\t"
         "v_pk_mul_f32 %1, %2, %3 op_sel_hi:[1,0]\n\t"
-        "v_pk_fma_f32 %1, %2, %4, %1 op_sel:[1,0,0] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %1, %2, %3, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]\n\t"
         "v_pk_add_f32 %2, %0, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
         "v_pk_add_f32 %1, %0, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[1,0]"
-        : "+v"(a), "+v"(b), "=&v"(t0) : "s"(wc), "s"(ws));
+        : "+v"(a), "+v"(b), "=&v"(t0) : "v"(w));
     xk = t0; xl = b;
 }
 

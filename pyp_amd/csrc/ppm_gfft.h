@@ -36,8 +36,9 @@ struct GfftP {
     unsigned bank4_bytes;    // its size (below 4 GB: the column pass reads it through a buffer descriptor)
     const float2 *Wp;        // [n][Hs][64] search tables of the chunk (k_prep), rows ky + Bs
     const float *nP, *nI;    // slice norms [n][nslices] (k_slice_norms), image norms [n]
-    const float *twb;        // butterfly table of the L-point transform (ppm_fft_reg.h: bfly_entries(L) entries of 16 floats)
-    const float *twl;        // line table of the Ns-point grid: entry j = w^(4j) .. w^(4j+3), each (c, s, -s, s); L / 4 entries
+    const float *tw;         // twiddle tables (ppm_fft_reg.h: tw_table_floats(L) floats — the butterfly table of the L-point transform, then
+                             // the line table w^0 .. w^(L-1) of the Ns-point grid) followed by the column penalties of the row pass: pairs
+                             // (0 or -3e38) for the columns sx(2 f), sx(2 f + 1), f = freq_at(L, position); copied into LDS by every block
     float *part;             // [n][n_orient][NPART] raw window maxima
     float *cc;               // [n][n_orient] scores for the top-K pass when they do not fit the LDS
     Hit *hits;               // [n][K]
@@ -48,7 +49,7 @@ struct GfftP {
 
 constexpr int gfft_row_stride(int L) { return L + 2; }       // float2 per T row: 16-byte row reads of 64 lanes hit distinct banks
 constexpr int gfft_slices_per_pass(int L) { return 64 / L; }
-constexpr size_t gfft_small_bytes() { return 256 * 8 + PPM_MAX_TOP_HITS * 8 + 256; }
+constexpr size_t gfft_small_bytes(int L) { return 256 * 8 + PPM_MAX_TOP_HITS * 8 + 256 + (size_t)(fr::tw_table_floats(L) + 2 * L) * 4; }
 
 // ---------------------------------------------------------------------------------- slice bank in the layout of the column pass
 struct Bank4P { CubeView cv; const float *mats; float4 *bank4; int nslices, Bs, L; float r_s2; };
@@ -72,11 +73,8 @@ __global__ void __launch_bounds__(256) k_bank4(Bank4P P) {
     P.bank4[i] = make_float4(v[0].x, v[0].y, v[1].x, v[1].y);
 }
 
-// A wave-uniform table pointer the compiler may not look through: without it the twiddle loads of both passes are hoisted out of
-// the slice loop as loop invariants, outgrow the scalar registers, get parked in VGPR lanes and come back one v_readlane per dword.
-__device__ __forceinline__ fr::Tw16Ptr opaque(fr::Tw16Ptr p) { asm volatile("" : "+s"(p)); return p; }
-// ... and a wave-uniform integer: the window tests of a pass compare against loop invariants, and hoisted out of the slice loop
-// every one of them becomes a 64-bit mask parked in VGPR lanes (two v_readlane per test instead of one s_cmp)
+// A wave-uniform integer the compiler may not look through: the window tests of a pass compare against loop invariants, and hoisted
+// out of the slice loop every one of them becomes a 64-bit mask parked in VGPR lanes (two v_readlane per test instead of one s_cmp)
 __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+s"(v)); return v; }
 
 // ---------------------------------------------------------------------------------- the column pass of one thread
@@ -85,30 +83,67 @@ __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+s"(v)); retur
 // 32-bit lane offset + immediate, no 64-bit address arithmetic per row; wl points at this lane's column of the W table in LDS.
 // Bank rows travel D rows ahead of their use (one wave per SIMD: nothing else hides the L2 / Infinity-Cache latency), LDS rows DW
 // ahead; the scheduling barriers keep the compiler from sinking the loads back to their uses.
-template <int L, int E, int H>
-__device__ __forceinline__ void gfft_col_products(fr::v2f (&y)[L], __amdgpu_buffer_rsrc_t bank, unsigned voff, const float4 *wl) {
-    using namespace fr;
-    constexpr int D = L < 12 ? L : 12, DW = L < 4 ? L : 4;
-    v4f pb[D]; float4 wb[DW];
-    // bank row n of this lane: lane offset + (n % 4) KB as the instruction's immediate + 4 (n / 4) KB in a scalar register that steps once
-    // per four rows (left to itself the compiler keeps one VGPR offset per row, parks the 64 of them in AGPRs and fetches one per load)
-    int soff[L / 4 + 1];
+constexpr int gfft_depth(int L) { return L < 16 ? L : 16; }       // bank rows in flight per lane
+
+// bank row n of a lane: lane offset + (n % 4) rows as the instruction's immediate + 4 (n / 4) rows in a scalar register that steps once
+// per four rows (left to itself the compiler keeps one VGPR offset per row, parks the 64 of them in AGPRs and fetches one per load)
+template <int L, int N>
+__device__ __forceinline__ fr::v4f gfft_bank_row(__amdgpu_buffer_rsrc_t bank, unsigned voff, const int (&soff)[L / 4 + 1]) {
+    return __builtin_amdgcn_raw_buffer_load_b128(bank, (int)(voff + (N % 4) * L * 16), soff[N / 4], 0);
+}
+template <int L>
+__device__ __forceinline__ void gfft_row_offsets(int (&soff)[L / 4 + 1]) {
     soff[0] = opaque(0);
-    static_for<1, L / 4 + 1>([&](auto ic) { constexpr int i = decltype(ic)::value; soff[i] = soff[i - 1] + 4 * L * 16; });
-    auto bank_row = [&](auto nc) { constexpr int n = decltype(nc)::value; return __builtin_amdgcn_raw_buffer_load_b128(bank, (int)(voff + (n % 4) * L * 16), soff[n / 4], 0); };
-    static_for<0, D>([&](auto ic) { pb[decltype(ic)::value] = bank_row(ic); });
+    fr::static_for<1, L / 4 + 1>([&](auto ic) { constexpr int i = decltype(ic)::value; soff[i] = soff[i - 1] + 4 * L * 16; });
+}
+// the first rows of a slice, requested a whole pass ahead of their use
+template <int L>
+__device__ __forceinline__ void gfft_prefetch(fr::v4f (&pb)[gfft_depth(L)], __amdgpu_buffer_rsrc_t bank, unsigned voff) {
+    int soff[L / 4 + 1];
+    gfft_row_offsets<L>(soff);
+    fr::static_for<0, gfft_depth(L)>([&](auto ic) { constexpr int i = decltype(ic)::value; pb[i] = gfft_bank_row<L, i>(bank, voff, soff); });
+}
+
+template <int L, int E, int H>
+__device__ __forceinline__ void gfft_col_products(fr::v2f (&y)[L], fr::v4f (&pb)[gfft_depth(L)], __amdgpu_buffer_rsrc_t bank, unsigned voff, const float4 *wl) {
+    using namespace fr;
+    constexpr int D = gfft_depth(L), DW = L < 4 ? L : 4;
+    float4 wb[DW];
+    int soff[L / 4 + 1];
+    gfft_row_offsets<L>(soff);
     static_for<0, DW>([&](auto ic) { constexpr int i = decltype(ic)::value; wb[i] = wl[i * L]; });
     static_for<0, L / 2>([&](auto nc) {
         constexpr int n = 2 * decltype(nc)::value;
         const v4f p0 = pb[n % D], p1 = pb[(n + 1) % D]; const float4 w0 = wb[n % DW], w1 = wb[(n + 1) % DW];
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (n + D < L) { pb[n % D] = bank_row(std::integral_constant<int, n + D>{}); pb[(n + 1) % D] = bank_row(std::integral_constant<int, n + 1 + D>{}); }
+        if constexpr (n + D < L) { pb[n % D] = gfft_bank_row<L, n + D>(bank, voff, soff); pb[(n + 1) % D] = gfft_bank_row<L, n + 1 + D>(bank, voff, soff); }
         if constexpr (n + DW < L) { wb[n % DW] = wl[(n + DW) * L]; wb[(n + 1) % DW] = wl[(n + 1 + DW) * L]; }
         prod2x2<E, H>(y[n], y[n + 1], (v2f){ w0.x, w0.y }, (v2f){ p0.x, p0.y }, (v2f){ w0.z, w0.w }, (v2f){ p0.z, p0.w },
                       (v2f){ w1.x, w1.y }, (v2f){ p1.x, p1.y }, (v2f){ w1.z, w1.w }, (v2f){ p1.z, p1.w });
         __builtin_amdgcn_sched_barrier(0);
     });
 }
+
+// Four LDS stores of the column pass, each predicated on a bit of a wave-uniform mask by switching EXEC (a uniform test compiles to
+// a branch, and the 60 odd taken branches of a pass cost more than its butterflies: scripts/.. stamps, CHANGELOG round 5).  All
+// lanes are active on entry (wave-uniform control flow around the call); EXEC is all ones again on exit.
+template <int B0, int B1, int B2, int B3, int O0, int O1, int O2, int O3>
+__device__ __forceinline__ void lds_store4_masked(const void *addr, unsigned mask, fr::v2f v0, fr::v2f v1, fr::v2f v2, fr::v2f v3) {
+    const unsigned a = (unsigned)(size_t)addr;
+    asm volatile("s_bitcmp1_b32 %5, %6\n\ts_cselect_b64 exec, -1, 0\n\tds_write_b64 %4, %0 offset:%10\n\t"
+                 "s_bitcmp1_b32 %5, %7\n\ts_cselect_b64 exec, -1, 0\n\tds_write_b64 %4, %1 offset:%11\n\t"
+                 "s_bitcmp1_b32 %5, %8\n\ts_cselect_b64 exec, -1, 0\n\tds_write_b64 %4, %2 offset:%12\n\t"
+                 "s_bitcmp1_b32 %5, %9\n\ts_cselect_b64 exec, -1, 0\n\tds_write_b64 %4, %3 offset:%13\n\t"
+                 "s_mov_b64 exec, -1"
+                 :: "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(a), "s"(mask), "n"(B0), "n"(B1), "n"(B2), "n"(B3), "n"(O0), "n"(O1), "n"(O2), "n"(O3) : "memory", "scc");
+}
+
+// v_max3_f32 as it is (fmaxf() adds a canonicalising v_max per operand); eight values per statement
+__device__ __forceinline__ float max8_raw(float m, float a, float b, float c, float d, float e, float f, float g, float h) {
+    asm("v_max3_f32 %0, %0, %1, %2\n\tv_max3_f32 %0, %0, %3, %4\n\tv_max3_f32 %0, %0, %5, %6\n\tv_max3_f32 %0, %0, %7, %8" : "+v"(m) : "v"(a), "v"(b), "v"(c), "v"(d), "v"(e), "v"(f), "v"(g), "v"(h));
+    return m;
+}
+__device__ __forceinline__ float max3_raw(float m, float a, float b) { asm("v_max3_f32 %0, %0, %1, %2" : "+v"(m) : "v"(a), "v"(b)); return m; }
 
 // maximum over groups of W consecutive lanes (W = 16, 32, 64), every lane gets its group's result; full EXEC required
 template <int W> __device__ __forceinline__ float group_max(float v) {
@@ -120,6 +155,14 @@ template <int W> __device__ __forceinline__ float group_max(float v) {
 
 // CHUNKED: the window's rows pass through T in several chunks (the column pass then runs once per chunk and tests every output
 // against the chunk); only search grids of 128 points with more than +-44 steps need it.
+// Diagnostic build (-DPPM_GFFT_STAMPS): cycles per phase of the slice loop (s_memtime), summed per wave over the timed passes and
+// written by blocks 0 .. 3 into the `cc` scratch (which the LDS top-K path leaves unused): [block][wave][phase] as floats.
+#ifdef PPM_GFFT_STAMPS
+#define GF_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_t; st_t = t_; } while (0)
+#else
+#define GF_STAMP(i) do { } while (0)
+#endif
+
 template <int LN, bool CHUNKED>
 __global__ void __launch_bounds__(256) k_gfft(GfftP P) {
     using namespace fr;
@@ -138,10 +181,12 @@ __global__ void __launch_bounds__(256) k_gfft(GfftP P) {
     const int Bs = P.Bs, RSy = P.RSy, RC = P.RC, NR = 2 * RSy + 1;
     const int nslices = P.n_dir * P.npsi_store;
     const bool half = P.npsi_store != P.n_psi;
-    const Tw16Ptr twb0 = (Tw16Ptr)P.twb, twl0 = (Tw16Ptr)P.twl;
+    const float *twb = (const float *)(rv + 32), *twl = twb + bfly_entries(L) * 8;   // twiddle tables in LDS (16-byte aligned)
+    const float *pen = twb + tw_table_floats(L);                                      // column penalties of the row pass, [L] pairs
     const __amdgpu_buffer_rsrc_t bank = __builtin_amdgcn_make_buffer_rsrc((void *)P.bank4, 0, (int)P.bank4_bytes, 0x00020000);
 
-    // ---- the particle's W table, two ky rows side by side like the bank
+    // ---- the twiddle tables and the particle's W table, two ky rows side by side like the bank
+    for (int i = tid; i < tw_table_floats(L) + Ns; i += 256) ((float *)twb)[i] = P.tw[i];
     {
         const float2 *src = P.Wp + (size_t)p * P.Hs * 64;
         for (int i = tid; i < L * L; i += 256) {
@@ -171,8 +216,22 @@ __global__ void __launch_bounds__(256) k_gfft(GfftP P) {
     const float *nPp = P.nP + (size_t)p * nslices;
     Hit *hitp = P.hits + (size_t)p * P.K;
 
+    // window rows of this wave's outputs (column pass, not CHUNKED): bit f of mask_pos for f = 0 .. fmax, bit j - 1 of mask_neg for j = 1 .. jmax
+    const int fmax_ = min((RSy - ch) >> 1, L / 2 - 1), jmax_ = min((RSy + ch) >> 1, L / 2);
+    const unsigned mask_pos = fmax_ >= 31 ? 0xffffffffu : ((1u << (fmax_ + 1)) - 1u), mask_neg = jmax_ >= 32 ? 0xffffffffu : ((1u << jmax_) - 1u);
+    // bank rows 0 .. D-1 of the slice the next column pass works on, requested at the end of the current one
+    v4f pb[gfft_depth(L)];
+    unsigned pf_voff = 0xffffffffu;
+    auto col_voff = [&](int sl) { return ((unsigned)(sl < 0 ? 0 : sl) * (unsigned)(L * L) + (unsigned)ckx) * 16u; };
+
+#ifdef PPM_GFFT_STAMPS
+    unsigned long long st_acc[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, st_t = __builtin_amdgcn_s_memtime();
+#endif
     for (int it = 0;; it++) {
         if (it == npass0) {
+#ifdef PPM_GFFT_STAMPS
+            if (blockIdx.x < 4 && lane == 0) for (int i = 0; i < 12; i++) P.cc[(blockIdx.x * 4 + wave) * 12 + i] = (float)st_acc[i];
+#endif
             // ---- scores of all orientations, top-K (ties -> lower orientation index, like the oracle)
             __threadfence_block();
             __syncthreads();
@@ -228,36 +287,53 @@ __global__ void __launch_bounds__(256) k_gfft(GfftP P) {
         const int c_sl = slice_of(cg, c_eh, c_hit), r_sl = slice_of(rg, r_eh, r_hit);
 
         for (int c = 0; c < P.nchunk; c++) {
+            GF_STAMP(7);
             const int c0 = c * RC;                                   // first T row (slot) of this chunk
             // ================= column pass
             if (half || ce == 0) {
                 v2f y[L];
-                const Tw16Ptr twb = opaque(twb0), twl = opaque(twl0);
-                const unsigned voff = ((unsigned)(c_sl < 0 ? 0 : c_sl) * (unsigned)(L * L) + (unsigned)ckx) * 16u;
-                if (ch == 0) { if (ce == 0) gfft_col_products<L, 0, 0>(y, bank, voff, wl); else gfft_col_products<L, 1, 0>(y, bank, voff, wl); }
+                const unsigned voff = col_voff(c_sl);
+                if (pf_voff != voff) gfft_prefetch<L>(pb, bank, voff);          // first pass, after the top-K step, or a lane whose slice changed
+                if (ch == 0) { if (ce == 0) gfft_col_products<L, 0, 0>(y, pb, bank, voff, wl); else gfft_col_products<L, 1, 0>(y, pb, bank, voff, wl); }
                 else {
-                    if (ce == 0) gfft_col_products<L, 0, 1>(y, bank, voff, wl); else gfft_col_products<L, 1, 1>(y, bank, voff, wl);
-                    static_for<0, L / 4>([&](auto jc) { constexpr int j = decltype(jc)::value; cmul4(y[4 * j], y[4 * j + 1], y[4 * j + 2], y[4 * j + 3], twl[j]); });
+                    if (ce == 0) gfft_col_products<L, 0, 1>(y, pb, bank, voff, wl); else gfft_col_products<L, 1, 1>(y, pb, bank, voff, wl);
+                    GF_STAMP(0);
+                    // the decimation twiddles w^n of the odd rows; table entries two statements ahead
+                    v4f wq[3][2];
+                    auto fetch = [&](auto jc) { constexpr int j = decltype(jc)::value; wq[j % 3][0] = *(const v4f *)(twl + 8 * j); wq[j % 3][1] = *(const v4f *)(twl + 8 * j + 4); };
+                    fetch(std::integral_constant<int, 0>{});
+                    if constexpr (L / 4 > 1) fetch(std::integral_constant<int, 1>{});
+                    static_for<0, L / 4>([&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
+                        const v4f wa = wq[j % 3][0], wb = wq[j % 3][1];
+                        if constexpr (j + 2 < L / 4) fetch(std::integral_constant<int, j + 2>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                        cmul4(y[4 * j], y[4 * j + 1], y[4 * j + 2], y[4 * j + 3], (v2f){ wa.x, wa.y }, (v2f){ wa.z, wa.w }, (v2f){ wb.x, wb.y }, (v2f){ wb.z, wb.w });
+                    });
+                }
+                GF_STAMP(6);
+                {   // the next column pass: the same slice again (next row chunk) or the next slices of the grid
+                    const int nsl = (c + 1 < P.nchunk) ? c_sl : (it + 1 < npass0 ? min((it + 1) * G + cg, nslices - 1) : c_sl);
+                    pf_voff = col_voff(nsl);
+                    gfft_prefetch<L>(pb, bank, pf_voff);
                 }
                 fft_inreg<L>(y, twb);
+                GF_STAMP(1);
                 // output f of the L-point transform is row sy = 2 f + h (mod Ns) of the image: rows 0 .. RSy sit in slots 0 .. RSy,
                 // rows -1 .. -RSy in slots RSy + 1 .. 2 RSy
                 if constexpr (!CHUNKED) {
-                    // f <= fmax (rows 2 f + h <= RSy) and j = L - f <= jmax (rows -(2 j - h) >= -RSy) are inside the window: tested per
-                    // group of four outputs, per output only in the one group the window's edge cuts
-                    float2 *Tpos = Tc + ch * TS, *Tneg = Tc + (RSy - ch) * TS;
-                    const int fmax = opaque(min((RSy - ch) >> 1, L / 2 - 1)), jmax = opaque(min((RSy + ch) >> 1, L / 2));
-                    auto st_pos = [&](auto fc) { constexpr int f = decltype(fc)::value; constexpr int pp = pos_of(L, f); Tpos[2 * f * TS] = make_float2(y[pp].x, y[pp].y); };
-                    auto st_neg = [&](auto jc) { constexpr int j = decltype(jc)::value; constexpr int pp = pos_of(L, L - j); Tneg[2 * j * TS] = make_float2(y[pp].x, y[pp].y); };
+                    // output f < L / 2 is inside the window when f <= fmax (row 2 f + h <= RSy), output f = L - j >= L / 2 when j <= jmax
+                    // (row -(2 j - h) >= -RSy): bits of two wave-uniform masks that predicate the stores
+                    const float2 *Tpos = Tc + ch * TS, *Tneg = Tc + (RSy - ch) * TS;
                     static_for<0, L / 8>([&](auto gc) {
-                        constexpr int f0 = 4 * decltype(gc)::value;
-                        if (f0 + 3 <= fmax) static_for<f0, f0 + 4>(st_pos);
-                        else if (f0 <= fmax) static_for<f0, f0 + 3>([&](auto fc) { if (decltype(fc)::value <= fmax) st_pos(fc); });
+                        constexpr int f0 = 4 * decltype(gc)::value, q0 = pos_of(L, f0), q1 = pos_of(L, f0 + 1), q2 = pos_of(L, f0 + 2), q3 = pos_of(L, f0 + 3);
+                        lds_store4_masked<f0, f0 + 1, f0 + 2, f0 + 3, 2 * f0 * TS * 8, 2 * (f0 + 1) * TS * 8, 2 * (f0 + 2) * TS * 8, 2 * (f0 + 3) * TS * 8>(
+                            Tpos, mask_pos, y[q0], y[q1], y[q2], y[q3]);
                     });
                     static_for<0, L / 8>([&](auto gc) {
-                        constexpr int j0 = 4 * decltype(gc)::value + 1;
-                        if (j0 + 3 <= jmax) static_for<j0, j0 + 4>(st_neg);
-                        else if (j0 <= jmax) static_for<j0, j0 + 3>([&](auto jc) { if (decltype(jc)::value <= jmax) st_neg(jc); });
+                        constexpr int j0 = 4 * decltype(gc)::value + 1, q0 = pos_of(L, L - j0), q1 = pos_of(L, L - j0 - 1), q2 = pos_of(L, L - j0 - 2), q3 = pos_of(L, L - j0 - 3);
+                        lds_store4_masked<j0 - 1, j0, j0 + 1, j0 + 2, 2 * j0 * TS * 8, 2 * (j0 + 1) * TS * 8, 2 * (j0 + 2) * TS * 8, 2 * (j0 + 3) * TS * 8>(
+                            Tneg, mask_neg, y[q0], y[q1], y[q2], y[q3]);
                     });
                 } else {
                     const int spos = ch - c0, sneg = RSy - ch - c0;
@@ -273,46 +349,70 @@ __global__ void __launch_bounds__(256) k_gfft(GfftP P) {
                     });
                 }
             }
+            GF_STAMP(2);
             lds_barrier();
+            GF_STAMP(3);
             // ================= row pass
             const int slot = rr + c0;
             const bool active = rr < RC && slot < NR && r_sl >= 0 && (half || re == 0) && (!argpass || re == r_eh);
             float best = -3.0e38f; int bkey = 0x7fffffff;
             if (active) {
                 v2f z[L];
-                const Tw16Ptr twb = opaque(twb0), twl = opaque(twl0);
-                static_for<0, L / 2>([&](auto ic) {
-                    constexpr int i = decltype(ic)::value;
-                    const float4 v = *(const float4 *)(Tr + 2 * i);
-                    z[2 * i] = (v2f){ v.x, v.y }; z[2 * i + 1] = (v2f){ v.z, v.w };
-                });
-                // the real Ns-point transform of the row through one L-point complex transform, in place:
-                // Z[k] = (X[k] + conj X[L-k]) + i w^k (X[k] - conj X[L-k]), Z[L-k] = conj(s) + i conj(t); Z[0] = 2 Re X[0] (1 + i), Z[L/2] = 2 conj X[L/2]
-                z[0] = (v2f){ 2.f * z[0].x, 2.f * z[0].x };
-                z[L / 2] = (v2f){ 2.f * z[L / 2].x, -2.f * z[L / 2].y };
-                { const v16f w = twl[0]; halfpair1(z[1], z[L - 1], (v2f){ w[4], w[5] }, (v2f){ w[6], w[7] }); }
-                static_for<1, L / 4>([&](auto kc) {
-                    constexpr int k = 2 * decltype(kc)::value, e4 = (k % 4) * 4;
-                    const v16f w = twl[k / 4];
-                    halfpair2(z[k], z[L - k], z[k + 1], z[L - k - 1], (v2f){ w[e4], w[e4 + 1] }, (v2f){ w[e4 + 2], w[e4 + 3] }, (v2f){ w[e4 + 4], w[e4 + 5] }, (v2f){ w[e4 + 6], w[e4 + 7] });
-                });
+                // the row, 16 bytes per read.  (The empty asm statements keep the reads whole: left alone the compiler drops the unused
+                // imaginary part of X[0], re-pairs the rest into ds_read2_b64 — and those hit the row stride's 2-way bank conflict.)
+                {
+                    v4f zr[L / 2];
+                    static_for<0, L / 2>([&](auto ic) { constexpr int i = decltype(ic)::value; zr[i] = *(const v4f *)(Tr + 2 * i); });
+                    static_for<0, L / 2>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        asm volatile("" : "+v"(zr[i]));
+                        z[2 * i] = (v2f){ zr[i].x, zr[i].y }; z[2 * i + 1] = (v2f){ zr[i].z, zr[i].w };
+                    });
+                }
+                {
+                    // the real Ns-point transform of the row through one L-point complex transform, in place: pairs (k, L - k), k = 1 alone,
+                    // then (2, 3), (4, 5), ...; their twiddles w^k four statements ahead.
+                    // Z[k] = (X[k] + conj X[L-k]) + i w^k (X[k] - conj X[L-k]), Z[L-k] = conj(s) + i conj(t); Z[0] = 2 Re X[0] (1 + i), Z[L/2] = 2 conj X[L/2]
+                    constexpr int DQ = 5, NP = L / 4;
+                    v4f wq[DQ];
+                    auto fetch = [&](auto qc) { constexpr int q = decltype(qc)::value; wq[q % DQ] = *(const v4f *)(twl + 4 * q); };      // w^(2q), w^(2q+1)
+                    static_for<0, (NP < DQ - 1 ? NP : DQ - 1)>(fetch);
+                    static_for<0, NP>([&](auto qc) {
+                        constexpr int q = decltype(qc)::value, k = 2 * q;
+                        const v4f w = wq[q % DQ];
+                        if constexpr (q + DQ - 1 < NP) fetch(std::integral_constant<int, q + DQ - 1>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (k == 0) halfpair1(z[1], z[L - 1], (v2f){ w.z, w.w });
+                        else halfpair2(z[k], z[L - k], z[k + 1], z[L - k - 1], (v2f){ w.x, w.y }, (v2f){ w.z, w.w });
+                    });
+                    z[0] = (v2f){ 2.f * z[0].x, 2.f * z[0].x };
+                    z[L / 2] = (v2f){ 2.f * z[L / 2].x, -2.f * z[L / 2].y };
+                }
+                GF_STAMP(8);
                 fft_inreg<L>(z, twb);
+                GF_STAMP(9);
                 // z[position of f] = 2 (c(2 f), c(2 f + 1)), column j = the shift sx = j (j < L) or j - Ns.  Columns |sx| <= RSx are inside
                 // the window: tested per group of four |sx|, per column only in the group the window's edge cuts
-                auto col = [&](auto jc) -> float { constexpr int j = decltype(jc)::value; constexpr int pp = pos_of(L, j / 2); return (j & 1) ? z[pp].y : z[pp].x; };
-                auto mx = [&](auto ac) {
-                    constexpr int a = decltype(ac)::value;
-                    if constexpr (a == 0) best = fmaxf(best, col(std::integral_constant<int, 0>{}));
-                    else best = fmaxf(best, fmaxf(col(std::integral_constant<int, a>{}), col(std::integral_constant<int, Ns - a>{})));
-                };
-                const int rsx = opaque(P.RSx);
-                static_for<0, L / 4>([&](auto gc) {
-                    constexpr int a0 = 4 * decltype(gc)::value;
-                    if (a0 + 3 <= rsx) static_for<a0, a0 + 4>(mx);
-                    else if (a0 <= rsx) static_for<a0, a0 + 3>([&](auto ac) { if (decltype(ac)::value <= rsx) mx(ac); });
-                });
+                // the window's columns: a penalty of 0 or -3e38 per column (table in LDS, in the order the transform leaves its outputs, read
+                // four statements ahead), then the maximum over all of them — no test, no branch
+                {
+                    constexpr int DQ = 5, NG = L / 4;
+                    v4f pq[DQ][2];
+                    auto fetch = [&](auto gc) { constexpr int g = decltype(gc)::value; pq[g % DQ][0] = *(const v4f *)(pen + 8 * g); pq[g % DQ][1] = *(const v4f *)(pen + 8 * g + 4); };
+                    static_for<0, (NG < DQ - 1 ? NG : DQ - 1)>(fetch);
+                    static_for<0, NG>([&](auto gc) {
+                        constexpr int g = decltype(gc)::value, p0 = 4 * g;
+                        const v4f pa = pq[g % DQ][0], pb2 = pq[g % DQ][1];
+                        if constexpr (g + DQ - 1 < NG) fetch(std::integral_constant<int, g + DQ - 1>{});
+                        const v2f a0 = z[p0] + (v2f){ pa.x, pa.y }, a1 = z[p0 + 1] + (v2f){ pa.z, pa.w }, a2 = z[p0 + 2] + (v2f){ pb2.x, pb2.y }, a3 = z[p0 + 3] + (v2f){ pb2.z, pb2.w };
+                        __builtin_amdgcn_sched_barrier(0);
+                        best = max8_raw(best, a0.x, a0.y, a1.x, a1.y, a2.x, a2.y, a3.x, a3.y);
+                    });
+                }
+                GF_STAMP(10);
                 if (argpass) {
                     // lowest column (scan order of the oracle: sx ascending) that holds the row's maximum
+                    const int rsx = opaque(P.RSx);
                     int bsx = 0x7fff;
                     static_for<0, Ns - 1>([&](auto jc) {
                         constexpr int sx = L - 1 - decltype(jc)::value;                  // L - 1 down to -(L - 1): the last match that sticks is the lowest
@@ -339,7 +439,9 @@ __global__ void __launch_bounds__(256) k_gfft(GfftP P) {
                 if (c > 0 && (red_v[tid] > best || (red_v[tid] == best && red_k[tid] < bkey))) { best = red_v[tid]; bkey = red_k[tid]; }
                 red_v[tid] = best; red_k[tid] = bkey;
             }
+            GF_STAMP(4);
             lds_barrier();                                           // T may be overwritten, red_* are visible
+            GF_STAMP(5);
         }
         if (argpass && rr == 0 && r_hit >= 0 && re == r_eh) {
             // one thread per hit: best (value, key) over the rows of its orientation
@@ -355,5 +457,7 @@ __global__ void __launch_bounds__(256) k_gfft(GfftP P) {
         if (argpass) lds_barrier();                                  // red_* are reused by the next pass
     }
 }
+
+#undef GF_STAMP
 
 }  // namespace ppm

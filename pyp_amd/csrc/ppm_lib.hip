@@ -221,8 +221,8 @@ struct ppm_ref {
     DevBuf<int> tile_c;
     DevBuf<LState> states, states2;
     // full-window correlation (k_gfft): the bank in the column pass's layout, window maxima per (particle, orientation), column penalties
-    DevBuf<float4> bank4; DevBuf<float> part, gtw;       // gtw: twiddle tables of the search grid (butterfly table, then line table)
-    std::string bank_key, bank4_key; int gtw_ns = 0;
+    DevBuf<float4> bank4; DevBuf<float> part, gtw;       // gtw: twiddle tables of the search grid (butterfly table, line table), then the window's column penalties
+    std::string bank_key, bank4_key; int gtw_ns = 0, gtw_rsx = -1;
     long last_counts[4] = { 0, 0, 0, 0 };
     std::string note;
 };
@@ -421,7 +421,7 @@ static bool gfft_plan(const Geom &gm, GfftPlan &pl) {
     if ((1 << LN) != gm.Ns || LN < 4 || LN > 7) return false;
     pl.LN = LN; pl.L = gm.Ns / 2;
     const int L = pl.L, G = gfft_slices_per_pass(L), NR = 2 * gm.RSy + 1;
-    const size_t row = (size_t)G * 2 * gfft_row_stride(L) * sizeof(float2), fixed = (size_t)L * L * sizeof(float4) + gfft_small_bytes();
+    const size_t row = (size_t)G * 2 * gfft_row_stride(L) * sizeof(float2), fixed = (size_t)L * L * sizeof(float4) + gfft_small_bytes(L);
     const size_t room = (size_t)160 * 1024 - fixed;
     int RC = NR;
     if (const char *e = getenv("PPM_GFFT_ROWS")) { const int v = atoi(e); if (v > 0 && v < RC) RC = v; }       // tests: force several row chunks
@@ -443,6 +443,20 @@ static int launch_gfft_k(const GfftP &P, int n_img, size_t lds) {
     { std::lock_guard<std::mutex> lk_attr(g_mu); if (!set) { HIPCHK(hipFuncSetAttribute((const void *)k_gfft<LN, CHUNKED>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } }
     hipLaunchKernelGGL((k_gfft<LN, CHUNKED>), dim3(n_img), dim3(256), lds, cur_stream(), P);
     HIPCHK(hipGetLastError());
+#ifdef PPM_GFFT_STAMPS
+    {   // diagnostic build: cycles per phase and wave of blocks 0 .. 3 (ppm_gfft.h)
+        float st[4 * 4 * 12];
+        HIPCHK(hipStreamSynchronize(cur_stream()));
+        HIPCHK(hipMemcpy(st, P.cc, sizeof(st), hipMemcpyDeviceToHost));
+        const char *names[12] = { "products", "fft", "stores", "barrier A", "row tail", "barrier B", "twiddles", "loop", "row reads + pairs", "row fft", "row max", "-" };
+        const int nsl = P.n_dir * P.npsi_store;
+        for (int b = 0; b < 4 && b < n_img; b++) for (int w = 0; w < 4; w++) {
+            fprintf(stderr, "k_gfft stamps block %d wave %d (cycles per slice):", b, w);
+            for (int i = 0; i < 11; i++) fprintf(stderr, " | %s %.0f", names[i], st[(b * 4 + w) * 12 + i] / nsl);
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
     return 0;
 }
 static int launch_gfft(GfftP &P, int n_img, const GfftPlan &pl) {
@@ -891,20 +905,27 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
             HIPCHK(hipGetLastError());
             ref->bank4_key = key;
         }
-        if (ref->gtw_ns != gm.Ns) {
-            // twiddle tables of the in-register transforms (ppm_fft_reg.h), 16 floats per entry, each twiddle as (c, s, -s, s):
-            // the butterfly table of the L-point transform, then the line table w^0 .. w^(L-1) of the Ns-point grid
+        if (ref->gtw_ns != gm.Ns || ref->gtw_rsx != gm.RSx) {
+            // twiddle tables of the in-register transforms (ppm_fft_reg.h), (cos, sin) pairs: the butterfly table of the L-point transform
+            // (8 floats per entry: w^k, w^2k, w^3k, padding), then the line table w^0 .. w^(L-1) of the Ns-point grid
             const int nb = fr::bfly_entries(L);
-            std::vector<float> tw((size_t)(nb + L / 4) * 16, 0.f);
-            auto put = [&](float *d, double ang) { const float c = (float)std::cos(ang), sn = (float)std::sin(ang); d[0] = c; d[1] = sn; d[2] = -sn; d[3] = sn; };
+            std::vector<float> tw((size_t)fr::tw_table_floats(L) + gm.Ns, 0.f);
+            auto put = [&](float *d, double ang) { d[0] = (float)std::cos(ang); d[1] = (float)std::sin(ang); };
             for (int M = L; M >= 8; M /= 4)
                 for (int k = 1; k < M / 4; k++)
-                    for (int j = 1; j <= 3; j++) put(&tw[(size_t)fr::bfly_entry(L, M, k) * 16 + (j - 1) * 4], 2.0 * kPi * j * k / M);
-            for (int t = 0; t < L; t++) put(&tw[(size_t)nb * 16 + (size_t)t * 4], 2.0 * kPi * t / gm.Ns);
+                    for (int j = 1; j <= 3; j++) put(&tw[(size_t)fr::bfly_entry(L, M, k) * 8 + (j - 1) * 2], 2.0 * kPi * j * k / M);
+            for (int t = 0; t < L; t++) put(&tw[(size_t)nb * 8 + (size_t)t * 2], 2.0 * kPi * t / gm.Ns);
+            // column penalties of the row pass, in the order the L-point transform leaves its outputs: position p holds the columns
+            // j = 2 f, 2 f + 1 (f = freq_at(L, p)), column j is the shift sx = j (j < L) or j - Ns
+            for (int pp = 0; pp < L; pp++)
+                for (int h = 0; h < 2; h++) {
+                    const int j = 2 * fr::freq_at(L, pp) + h, sx = j < L ? j : j - gm.Ns;
+                    tw[(size_t)fr::tw_table_floats(L) + 2 * pp + h] = std::abs(sx) <= gm.RSx ? 0.f : -3.0e38f;
+                }
             if (int rc = ref->gtw.ensure(tw.size())) return rc;
             HIPCHK(hipMemcpyAsync(ref->gtw.p, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice, cur_stream()));
             HIPCHK(hipStreamSynchronize(cur_stream()));       // the host vector goes out of scope
-            ref->gtw_ns = gm.Ns;
+            ref->gtw_ns = gm.Ns; ref->gtw_rsx = gm.RSx;
         }
     }
     HIPCHK(hipStreamSynchronize(cur_stream()));
@@ -1002,7 +1023,7 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
             }
             if (use_fft) {
                 GfftP FP;
-                FP.bank4 = ref->bank4.p; FP.bank4_bytes = (unsigned)((size_t)nslices * gpl.L * gpl.L * sizeof(float4)); FP.Wp = ref->Wp.p; FP.nP = ref->nP.p; FP.nI = ref->nI.p; FP.twb = ref->gtw.p; FP.twl = ref->gtw.p + (size_t)fr::bfly_entries(gpl.L) * 16;
+                FP.bank4 = ref->bank4.p; FP.bank4_bytes = (unsigned)((size_t)nslices * gpl.L * gpl.L * sizeof(float4)); FP.Wp = ref->Wp.p; FP.nP = ref->nP.p; FP.nI = ref->nI.p; FP.tw = ref->gtw.p;
                 FP.part = ref->part.p; FP.cc = ref->cc.p; FP.hits = ref->hits.p;
                 FP.Bs = gm.Bs; FP.Hs = gm.Hs; FP.RSx = gm.RSx; FP.RSy = gm.RSy;
                 FP.n_dir = gm.n_dir; FP.n_psi = gm.n_psi; FP.npsi_store = gm.npsi_store; FP.n_orient = gm.n_orient; FP.K = K;
