@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_VALU_TFLOPS = 157.3      # MI355X_MICROARCH.md: peak fp32 vector
 PEAK_HBM_GBPS = 8000.0        # HBM3E spec
+PEAK_L1_NOTE = "derived, not a figure of MI355X_MICROARCH.md: 64 B per clock and CU x 256 CUs x 2.4 GHz"
 PEAK_L1_GBPS = 64.0 * 256 * 2.4   # vector L1 delivery, 64 B per clock and CU at the 2.4 GHz peak clock = 39.3 TB/s (the gather kernels measure
                                   # 56 B per clock with every load an L1 hit, and the chip sustains ~1.95 GHz under them)
 
@@ -47,7 +48,7 @@ def parse(argv=None):
     ap.add_argument("--box", type=int, default=256)
     ap.add_argument("--band", type=float, default=64.0, help="search / refinement band limit, Fourier pixels")
     ap.add_argument("--angular-step", type=float, default=15.0)
-    ap.add_argument("--search-range", type=float, default=6.0, help="shift search range of the grid search, pixels (BASELINE config 2: shifts clipped at +-6 px); 0 = the mask radius, what PYP's default refine_searchx = 0 asks for (covered by overlapping tiles of 17 x 17 search-grid steps, one k_global launch each)")
+    ap.add_argument("--search-range", type=float, default=6.0, help="shift search range of the grid search, pixels (BASELINE config 2: shifts clipped at +-6 px); 0 = the mask radius, what PYP's default refine_searchx = 0 asks for (full-window transform kernel k_gfft; the default line reports it as the `default_search` block)")
     ap.add_argument("--unique", type=int, default=0, help="distinct clean projections (0 = one per particle: every particle has its own pose)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of each CPU oracle leg (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -179,6 +180,20 @@ def pmc_traffic(summary, kernel, particles_per_launch):
     return per_particle * particles_per_launch, src
 
 
+def pmc_traffic_sum(summary, kernels):
+    """HBM-side bytes per profiled unit summed over several kernels (2 x FETCH_SIZE + WRITE_SIZE, KB; all their dispatches)."""
+    tot, meta_ = 0.0, None
+    for kname in kernels:
+        e, meta = pmc_entry(summary, kname, merge=True)
+        if not e or "FETCH_SIZE" not in e or "WRITE_SIZE" not in e or not meta.get("particles"):
+            return None, "no FETCH_SIZE / WRITE_SIZE summary for %s under profiles/%s" % (kname, summary)
+        tot += (2.0 * e["FETCH_SIZE"]["sum"] + e["WRITE_SIZE"]["sum"]) * 1024.0 / meta["particles"]
+        meta_ = meta
+    had, now = meta_.get("kernels_sha16", "?"), kernels_sha16()
+    return tot, "profiles/%s (%d units, 2 x FETCH_SIZE + WRITE_SIZE, KB, summed over %s; kernel sources %s%s)" % (
+        summary, meta_["particles"], " + ".join(kernels), had, " = the timed ones" if had == now else ", the timed ones are " + now)
+
+
 def pmc_valu(summary, kernel, slices_per_particle):
     """Vector-instruction counters of the same summary: wave-instructions per particle and per stored slice."""
     e, meta = pmc_entry(summary, kernel)
@@ -205,14 +220,110 @@ def global_flops_per_slice(band, search_range_px, box, mask_radius_px):
     while Ns < 2 * (Bs + 1):
         Ns *= 2
     # the window in search-grid steps as ppm_geom.h derives it: range 0 = the mask radius, at most Ns / 2 - 1 steps; windows wider
-    # than 8 steps either side are searched as ntiles overlapping tiles of 17 x 17 steps, one k_global launch each (ppm_refine_batch)
+    # than 6 steps either side go to the full-window transform (k_gfft); forced onto k_global (PPM_GLOBAL_PATH=tiles) they are searched as
+    # ntiles overlapping tiles of 13 x 13 steps, one k_global launch each (ppm_refine_batch)
     rng_px = search_range_px if search_range_px > 0 else mask_radius_px
     RS = max(1, min(int(np.ceil(rng_px / (box / Ns))), Ns // 2 - 1))
-    R = min(RS, 8)
+    R = min(RS, 6)            # k_global's register window (wider windows go to k_gfft unless PPM_GLOBAL_PATH=tiles)
     tiles_1d = (2 * RS + 1 + 2 * R) // (2 * R + 1)
     trip = 16 if R <= 3 else 8
     HsP = ((2 * (Bs + 1) + trip - 1) // trip) * trip
     return (64 * (HsP // 2) * (16 * R + 20 + 4) + 64 * 800) * tiles_1d * tiles_1d, R, HsP, tiles_1d * tiles_1d
+
+
+def gfft_model(band, search_range_px, box, mask_radius_px):
+    """Executed fp32 operations of k_gfft (ppm_gfft.h) per STORED slice and particle, and the bytes its column pass pulls through the
+    CU's vector L1.  Column pass, 4 L threads (two orientations x two row parities x L columns): per bank row one v_pk_mul + three
+    v_pk_fma (14 flop), the decimation twiddles on half the threads (6 per row), one L-point transform; row pass, 2 (2 RSy + 1)
+    threads: L/2 - 1 pairs of the half-length trick (18 flop), one L-point transform, a penalty add and a maximum per column (4 L).
+    L-point transform: radix-4 butterflies of 8 packed adds (16 flop), 3 complex twiddle products (18 flop) on the twiddled ones,
+    a last radix-2 pass (4 flop per butterfly) when log2 L is odd.  DESIGN.md 4c."""
+    Bs = int(np.ceil(band)) - 1
+    Ns = 2
+    while Ns < 2 * (Bs + 1):
+        Ns *= 2
+    rng_px = search_range_px if search_range_px > 0 else mask_radius_px
+    RS = max(1, min(int(np.ceil(rng_px / (box / Ns))), Ns // 2 - 1))
+    L = Ns // 2
+    lg = int(np.log2(L))
+    fft = (lg // 2) * (L // 4) * 16
+    M = L
+    while M >= 8:
+        fft += (L // M) * (M // 4 - 1) * 18
+        M //= 4
+    if lg % 2:
+        fft += (L // 2) * 4
+    col = 4 * L * (L * 14 + L * 3 + fft)
+    row = 2 * (2 * RS + 1) * ((L // 2 - 1) * 18 + fft + 4 * L)
+    return {"flops_per_slice": float(col + row), "Ns": Ns, "L": L, "RS": RS, "fft_flops": fft,
+            "l1_bytes_per_slice": 4.0 * L * L * 16.0, "lds_bytes_per_slice": 4.0 * L * L * 16.0 + 2.0 * (2 * RS + 1) * (L + 2) * 8.0 * 2}
+
+
+def default_search_bench(a, ref, stack, start_rows, truth, vol, px, cpu):
+    """PYP's own default call of the grid search: "search range X / Y" = 0 = the mask radius (frealign.py:3954-3957,
+    config/pyp_config.toml:5338-5350).  At 256^2 / 4 A that is a window of +-41 steps of the 128-point search grid, 83 x 83 shifts per
+    orientation, which goes to the full-window transform kernel k_gfft instead of k_global's register-held 7 x 7 window.  Two
+    configurations on particles of the SAME resident stack: the headline's (15 deg, band r) and PYP's defaults (20 deg, search
+    limit 10 A); wall clock around the library call with inputs resident, kernel times from the library's HIP events."""
+    import torch
+    from pyp_amd import host, synth
+    from pyp_amd.abi import RefineCfg
+    N, M = a.box, len(start_rows)
+    res = px * N / a.band
+    out = {"what": "search range X / Y = 0 = the mask radius, as PYP sends it (frealign.py:3954-3957, config/pyp_config.toml:5338-5350)"}
+    for key, step, res_search, npart in (("mask_radius_window_15deg_r%g" % a.band, a.angular_step, res, min(M, 16384)),
+                                         ("pyp_defaults_20deg_10A", 20.0, 10.0 * px, min(M, 16384))):
+        cfg = RefineCfg.make(box=N, pixel_size=px, mask_radius=0.32 * N * px, res_high=res, res_search=res_search, res_low=0.0,
+                             angular_step=step, top_hits=20, search_range_x=0.0, search_range_y=0.0, res_signed_cc=30.0, molecular_mass_kda=500.0)
+        sub, rows0 = stack[:npart], start_rows[:npart]
+        ref.refine(cfg, stack[:256], start_rows[:256])                 # bank, tables, code objects
+        host.profile(True, True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        got = ref.refine(cfg, sub, rows0)
+        host.lib.load().ppm_device_sync()
+        dt = time.perf_counter() - t0
+        prof = host.profile_report()
+        host.profile(False, False)
+        counts = ref.last_counts()
+        band_s = px * N / res_search
+        mdl = gfft_model(band_s, 0.0, N, 0.32 * N)
+        nsl = counts["n_global"] / 2.0
+        launches = max(prof["global"]["launches"], 1)
+        ms_g = prof["global"]["ms"] / launches
+        ppl = npart / launches
+        tf = ppl * nsl * mdl["flops_per_slice"] / (ms_g * 1e-3) / 1e12
+        l1 = ppl * nsl * mdl["l1_bytes_per_slice"] / (ms_g * 1e-3) / 1e9
+        k = min(npart, 2000)
+        ang = synth.angular_error_deg(got[:k], truth[:k])
+        blk = {"value": round(npart / dt, 1), "unit": "particles/s", "particles": npart, "wall_s": round(dt, 3),
+               "config": {"box": N, "angular_step": step, "res_search_A": round(res_search, 3), "search_band_px": round(band_s, 2), "orientations": counts["n_global"],
+                          "search_grid_points": mdl["Ns"], "window_steps_each_side": mdl["RS"], "shifts_per_orientation": (2 * mdl["RS"] + 1) ** 2},
+               "kernels_us_per_particle": {k2: round(v["ms"] * 1e3 / npart, 3) for k2, v in prof.items() if v["launches"]},
+               "roofline": {"bound": "valu_fp32", "kernel": "k_gfft", "achieved": round(tf, 2), "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_VALU_TFLOPS, 4),
+                            "traffic": None, "avg_launch_ms": round(ms_g, 3), "particles_per_launch": round(ppl, 1),
+                            "flops_per_stored_slice_and_particle": mdl["flops_per_slice"],
+                            "flop_model": "column pass 4 L x (17 L + T) + row pass 2 (2 RS + 1) x (9 L + T - 18 + 4 L) with T = %d flop per %d-point transform (gfft_model)" % (mdl["fft_flops"], mdl["L"]),
+                            "l1_path": {"GBps": round(l1, 1), "peak": PEAK_L1_GBPS, "frac": round(l1 / PEAK_L1_GBPS, 4),
+                                        "note": "bank rows pulled through the vector L1 by the four waves of a block (4 x the slice); peak derived: 64 B/clk/CU x 256 CUs x 2.4 GHz"}},
+               "accuracy_vs_truth": {"median_deg": round(float(np.median(ang)), 3), "frac_within_2deg": round(float((ang < 2).mean()), 3)}}
+        if cpu and key.startswith("mask_radius"):
+            # the same particles through the oracle's zero-filled inverse transform (ccf_mode 0), all host cores
+            import ctypes
+            from oracle import oracle
+            cores = host_cores()
+            ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)
+            n = min(npart, cores)
+            oref = oracle.Reference(vol, N / 2)
+            t0 = time.time()
+            want, _ = oracle.refine_batch(oref, cfg, sub[:n].cpu().numpy(), rows0[:n], ccf_mode=0)
+            tc = time.time() - t0
+            oref.close()
+            blk["parity_vs_oracle"] = pose_parity(want, got[:n], px, "the first %d particles of this run against the oracle's zero-filled inverse transform (ccf_mode 0)" % n)
+            blk["cpu_baseline"] = {"value": round(n / tc, 3), "unit": "particles/s", "cores": cores, "kind": "port",
+                                   "sample": "%d particles, %.1f s wall, OpenMP over particles, oracle ccf_mode 0 (zero-filled %d^2 inverse transform per orientation)" % (n, tc, mdl["Ns"])}
+        out[key] = blk
+    return out
 
 
 # --------------------------------------------------------------------------------------------- main
@@ -267,11 +378,50 @@ def main(argv=None):
                 else:
                     line[name] = blk
     if rank == 0:
+        line["summary"] = summary_of(line)          # LAST key: the figures a reader of the line's tail needs
         print(json.dumps(line))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     return 0
+
+
+def summary_of(line):
+    """The handful of figures that decide the reading of the line, gathered under its LAST key (a record that keeps only the tail of
+    the 15 KB line still shows them): headline value and parity, PYP's default search, reconstruction value and parity, the
+    executables, the next rows, and what the collective ran on."""
+    def pick(d, *keys):
+        for k in keys:
+            if not isinstance(d, dict) or k not in d:
+                return None
+            d = d[k]
+        return d
+
+    def par(d):
+        return None if not isinstance(d, dict) else {k: d[k] for k in ("n", "max_deg", "max_shift_px", "rel_l2_accumulator", "see", "error") if k in d}
+    main_is_refine = "particles/sec projection-matching" in str(line.get("metric", ""))
+    rec = line if not main_is_refine and "Fourier insertion" in str(line.get("metric", "")) else line.get("reconstruct")
+    s = {"metric": line.get("metric"), "value": line.get("value"), "unit": line.get("unit"), "n_gpus": line.get("n_gpus"), "ms_per_step": line.get("ms_per_step"),
+         "roofline_frac": pick(line, "roofline", "frac"), "parity_vs_oracle": par(line.get("parity_vs_oracle")), "cpu_baseline_value": pick(line, "cpu_baseline", "value")}
+    ds = line.get("default_search")
+    if isinstance(ds, dict):
+        s["default_search"] = {k: {"value": v.get("value"), "roofline_frac": pick(v, "roofline", "frac"), "parity_vs_oracle": par(v.get("parity_vs_oracle"))}
+                               for k, v in ds.items() if isinstance(v, dict)} or {"error": ds.get("error")}
+    if isinstance(rec, dict):
+        s["reconstruct"] = {"value": rec.get("value"), "unit": rec.get("unit"), "roofline_frac": pick(rec, "roofline", "frac"),
+                            "parity_vs_oracle": par(rec.get("parity_vs_oracle")), "collective": rec.get("collective")}
+    dr = line.get("dropin")
+    if isinstance(dr, dict):
+        s["dropin"] = {"refine3d": pick(dr, "refine3d", "value"), "refine3d_search_range_0": pick(dr, "refine3d_search_range_0", "value"),
+                       "reconstruct3d": pick(dr, "reconstruct3d", "value"),
+                       "resident_server": {k: pick(dr, "resident_server", k, "value") for k in ("refine3d", "reconstruct3d", "refine3d_again")} if "resident_server" in dr else None,
+                       "error": dr.get("error")}
+    for name in ("csp", "sva"):
+        b = line.get(name)
+        if isinstance(b, dict):
+            s[name] = {"value": b.get("value"), "unit": b.get("unit"), "roofline_frac": pick(b, "roofline", "frac"),
+                       "parity_vs_oracle": par(b.get("parity_vs_oracle")) or pick(b, "parity_vs_oracle", "max_deg")}
+    return s
 
 
 def make_barrier(world):
@@ -347,17 +497,22 @@ def refine_bench(ctx):
     ppl = M * a.steps / launches_g                                            # particles per k_global launch (a tiled shift window launches once per tile: see below)
     ms_g = prof["global"]["ms"] / launches_g
     fl_slice, R, HsP, ntiles = global_flops_per_slice(a.band, srange / px, N, 0.32 * N)
+    gm_ = gfft_model(a.band, srange / px, N, 0.32 * N)
+    use_gfft = gm_["RS"] > 6 and gm_["Ns"] >= 16 and os.environ.get("PPM_GLOBAL_PATH") != "tiles"       # the library's own rule (ppm_refine_batch)
+    if use_gfft:
+        fl_slice, ntiles = gm_["flops_per_slice"], 1
     n_slices = counts["n_global"] / 2.0                                        # stored slices (psi and psi + 180 share one)
     flops_g = ppl * n_slices * fl_slice
     tf = flops_g / (ms_g * 1e-3) / 1e12
     bytes_model = ppl * counts["n_global"] * 8.0 * S_g * ntiles               # SURVEY §8(d) streaming model (every tile of the shift window streams the bank again)
     gbps_model = bytes_model / (ms_g * 1e-3) / 1e9
     traffic, traffic_src = pmc_traffic(pmc_latest("refine"), "k_global", ppl)
-    roof = {"bound": "valu_fp32", "kernel": "k_global", "achieved": round(tf, 2), "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s",
+    roof = {"bound": "valu_fp32", "kernel": "k_gfft" if use_gfft else "k_global", "achieved": round(tf, 2), "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tf / PEAK_VALU_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(ms_g, 3),
             "particles_per_launch": round(ppl * ntiles, 1), "shift_window_tiles": ntiles, "flops_per_launch": flops_g,
-            "flop_model": "stored slices (%d) x [64 lanes x %d row pairs x (16 R + 24) + 64 x 800], R = %d shift rows; executed fp32 "
-                          "operations incl. masked lanes (DESIGN.md §4)%s" % (int(n_slices), HsP // 2, R, "" if ntiles == 1 else " x %d tiles of the shift window" % ntiles),
+            "flop_model": ("stored slices (%d) x gfft_model(): full-window transform, %d-point search grid, window +-%d steps (DESIGN.md 4c)" % (int(n_slices), gm_["Ns"], gm_["RS"])) if use_gfft else
+                          ("stored slices (%d) x [64 lanes x %d row pairs x (16 R + 24) + 64 x 800], R = %d shift rows; executed fp32 "
+                           "operations incl. masked lanes (DESIGN.md §4)%s" % (int(n_slices), HsP // 2, R, "" if ntiles == 1 else " x %d tiles of the shift window" % ntiles)),
             "in_band_fraction_of_lane_rows": round(S_g / (64.0 * HsP), 3),
             "hbm_streaming_model": {"bytes_per_launch": bytes_model, "GBps": round(gbps_model, 1),
                                     "frac_clamped": round(min(1.0, gbps_model / PEAK_HBM_GBPS), 4), "exceeds_peak": bool(gbps_model > PEAK_HBM_GBPS),
@@ -384,6 +539,7 @@ def refine_bench(ctx):
         roof["local"] = {"kernel": "k_local", "bound": "l1_gather", "us_per_particle": round(ms_l * 1e6, 3), "gathered_samples_per_particle": gathers,
                          "achieved": round(gbps_l, 1), "peak": PEAK_L1_GBPS, "unit": "GB/s", "frac": round(gbps_l / PEAK_L1_GBPS, 4),
                          "bytes_model": "64 B per gathered sample: the 2 x 2 x 2 neighbourhood of the reference as four 16-byte loads through the CU's vector L1",
+                         "peak_note": PEAK_L1_NOTE,
                          "useful_TFLOPs": round(fl_l / ms_l / 1e12, 2),
                          "flop_model": "70 fp32 operations per gathered sample (useful arithmetic; the kernel issues ~75 vector instructions per gathered sample)",
                          "note": "bound by the vector memory path (DESIGN.md 4b): 64 cycles per 64-lane gather at 64 B/clock/CU plus ~6 line fills from L2; "
@@ -415,6 +571,16 @@ def refine_bench(ctx):
     }
     if world == 1 and not a.no_cpu and a.cpu_seconds > 0:
         line["cpu_baseline"], line["parity_vs_oracle"] = cpu_baseline(vol, stack, start_rows, cfg, N, a.cpu_seconds, out, px)
+    elif world > 1:
+        line["cpu_baseline"] = {"see": "N=1 line (the CPU legs run on rank 0 of the one-GPU run only)"}
+        line["parity_vs_oracle"] = {"see": "N=1 line"}
+    if world == 1 and not a.no_side:
+        try:                    # side figures: a failure is reported in the line
+            ref2 = host.Reference(vol, N / 2, device=local)
+            line["default_search"] = default_search_bench(a, ref2, stack, start_rows, rows, vol, px, (not a.no_cpu) and a.cpu_seconds > 0)
+            ref2.close()
+        except Exception as e:          # noqa: BLE001
+            line["default_search"] = {"error": str(e)[:300]}
     if world == 1 and not a.no_dropin:
         try:                    # side figures: a failure is reported in the line
             line["dropin"] = dropin_bench(a, vol, stack, start_rows, rows, px, res, srange)
@@ -427,7 +593,8 @@ def refine_bench(ctx):
 
 def dropin_bench(a, vol, stack, start_rows, truth, px, res, srange):
     """The boundary PYP really calls: `bin/refine3d` and `bin/reconstruct3d` as child processes, answers on stdin in the order of
-    frealign.py:3918-3994 / :1780-1824 (PYP's default flags: global = yes, local = no, 20 hits; C1), the SAME stack as a file
+    frealign.py:3918-3994 / :1780-1824 (PYP's default flags: global = yes, local = no, 20 hits; C1; the shift search range of the
+    headline configuration, --search-range, and once more with PYP's default range 0 = the mask radius), the SAME stack as a file
     (memory-backed, so the page cache is warm like a node-local scratch copy), one process for the whole range.  Wall time of the
     child from start to exit: interpreter, GPU context, reference preparation, reading, uploads, outputs - all included."""
     import shutil
@@ -495,6 +662,21 @@ def dropin_bench(a, vol, stack, start_rows, truth, px, res, srange):
             dt, timing, pipe = sorted(runs)[1]
             out[prog] = {"value": round(M / dt, 1), "unit": "particles/s", "wall_s": round(dt, 2), "wall_s_all_runs": [round(r[0], 2) for r in runs],
                          "phases": timing, "pipeline": pipe}
+        # ---- refine3d exactly as PYP's default parameters call it: answers 27 / 28 = 0 = the mask radius (frealign.py:3954-3957)
+        if "value" in out.get("refine3d", {}):
+            refine0 = list(refine)
+            refine0[26] = refine0[27] = 0
+            cmd = f"{ROOT}/bin/refine3d << eot > refine3d_s0.log 2>&1\n" + "\n".join(str(x) for x in refine0) + "\neot\n"
+            t0 = time.time()
+            rc = subprocess.run(cmd, shell=True, cwd=d).returncode
+            dt = time.time() - t0
+            log = open(os.path.join(d, "refine3d_s0.log")).read()
+            if rc != 0 or "Refine3D: Normal termination" not in log:
+                out["refine3d_search_range_0"] = {"error": log[-400:]}
+            else:
+                timing = [ln for ln in log.splitlines() if ln.startswith("Timing:")]
+                out["refine3d_search_range_0"] = {"value": round(M / dt, 1), "unit": "particles/s", "wall_s": round(dt, 2), "phases": timing[0][8:] if timing else None,
+                                                  "note": "answers 27 / 28 = 0 = the mask radius: +-41 search-grid steps at 256^2 / 4 A (k_gfft); one run"}
         # ---- the same iteration with the resident per-GPU server (PPM_STACK_CACHE=1, pyp_amd/csrc/dropin_server.h): the first call starts
         # it and uploads the range, the calls after it find context, stack and reference in place
         if "value" in out.get("refine3d", {}) and "value" in out.get("reconstruct3d", {}):
@@ -581,6 +763,13 @@ def reconstruct_bench(ctx):
         if int(flag.item()) == 0:
             via_abi = False
             abi_note = abi_note or "ppm_comm_create failed on another rank: torch.distributed all_reduce used instead"
+    # what the collective ran on, for the record: the communicator's size as RCCL itself reports it (ppm_comm_count = ncclCommCount)
+    collective = {"library": None, "ranks": 1, "via_abi": False, "world_size": world}
+    if world > 1:
+        collective = {"library": "RCCL through ppm_accum_reduce (C ABI)" if via_abi else "torch.distributed all_reduce (%s)" % tdist.get_backend(),
+                      "ranks": host.comm_count(pdist.library_comm(local)) if via_abi else tdist.get_world_size(), "via_abi": bool(via_abi), "world_size": world}
+        if abi_note:
+            collective["note"] = abi_note
     counts = None
     for _ in range(a.warmup):
         counts = step()
@@ -633,6 +822,9 @@ def reconstruct_bench(ctx):
             extra["parity_vs_oracle"], extra["cpu_baseline"] = recon_parity(stack, rows, rc, N, px, local)
         except Exception as e:          # noqa: BLE001
             extra["parity_vs_oracle"] = {"error": str(e)[:300]}
+    elif world > 1:
+        extra["cpu_baseline"] = {"see": "N=1 line"}
+        extra["parity_vs_oracle"] = {"see": "N=1 line"}
     return {**extra, "metric": "particles/sec Fourier insertion, 256^2 box", "value": round(world * M * a.steps / dt, 1), "unit": "particles/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -643,7 +835,7 @@ def reconstruct_bench(ctx):
             "roofline": roof, "kernels_ms": {k2: round(v["ms"], 2) for k2, v in prof.items() if v["launches"]},
             "kernels_us_per_particle": per_us, "compulsory_bytes_per_particle": 4 * N * N,
             "path_hbm_frac_compulsory": round(world * M * a.steps * 4.0 * N * N / dt / 1e9 / PEAK_HBM_GBPS / world, 4),
-            "map_cc_vs_truth": round(cc, 4), "fsc_at_half_nyquist": round(float(stats[N // 4 - 1, 3]), 4)}
+            "map_cc_vs_truth": round(cc, 4), "fsc_at_half_nyquist": round(float(stats[N // 4 - 1, 3]), 4), "collective": collective}
 
 
 def gather_roofline(kernel, summary_workload, ms_total, launches, gathers_total, units_total, unit_name, note):
@@ -673,7 +865,7 @@ def gather_roofline(kernel, summary_workload, ms_total, launches, gathers_total,
                 pv[c] = e[c]["sum"]
     gbps = 64.0 * gpl / (ms * 1e-3) / 1e9
     return {"bound": "l1_gather", "kernel": kernel, "achieved": round(gbps, 1), "peak": PEAK_L1_GBPS, "unit": "GB/s", "frac": round(gbps / PEAK_L1_GBPS, 4),
-            "bytes_model": "64 B per gathered sample (four 16-byte loads through the CU's vector L1; DESIGN.md 4b)",
+            "bytes_model": "64 B per gathered sample (four 16-byte loads through the CU's vector L1; DESIGN.md 4b)", "peak_note": PEAK_L1_NOTE,
             "traffic": traffic, "traffic_source": src, "avg_launch_ms": round(ms, 4), "launches": launches, unit_name + "_per_launch": round(upl, 1),
             "gathered_samples_per_launch": round(gpl), "useful_TFLOPs": round(tf, 2),
             "flop_model": "70 fp32 operations per gathered sample (useful arithmetic)", "pmc": pv, "note": note}
@@ -1066,6 +1258,7 @@ def sva_bench(ctx):
     R_ = int(np.ceil(min(0.5, 0.125 + 3.7169 * 0.05) * n))          # band radius of the protocol's low-pass (weights >= 1e-3), Fourier pixels
     KX_, KY_ = min(n // 2 + 1, R_ + 1), min(n, 2 * R_ + 1)
     moved = 4.0 * n3 + 2 * 8.0 * n * n * KX_ + 4 * 8.0 * n * KX_ * KY_
+    pre_traffic, pre_src = pmc_traffic_sum(pmc_latest("sva"), ("k_sva_x16", "k_sva_stats_sum", "k_sva_yz16", "k_sva_gather16"))
     blk = {"metric": "sub-volumes/sec sub-tomogram alignment, 192^3 box", "value": round(world * nv * a.steps / dt, 1), "unit": "sub-volumes/s",
            "n_gpus": world, "steps": a.steps, "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
            "dtype": "f32", "data": "synthetic",
@@ -1075,7 +1268,9 @@ def sva_bench(ctx):
            "roofline": sva_eval_roofline(prof, lc_sva, nv, a.steps, wedges),
            "roofline_pre_processing": {"bound": "hbm", "kernel": "sub-volume pre-processing (k_sva_x16 + k_sva_stats_sum + two k_sva_yz16 passes + k_sva_gather16)",
                         "achieved": round(4.0 * n3 / (ms_prep * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                        "frac": round(4.0 * n3 / (ms_prep * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4), "traffic": None,
+                        "frac": round(4.0 * n3 / (ms_prep * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4), "traffic": pre_traffic, "traffic_source": pre_src,
+                        "traffic_over_algorithmic": None if pre_traffic is None else round(pre_traffic / (4.0 * n3), 2),
+                        "hbm_traffic_frac": None if pre_traffic is None else round(pre_traffic / (ms_prep * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
                         "algorithmic_bytes": "4 n^3: the sub-volume read once",
                         "moved_bytes_model": {"bytes_per_sub_volume": round(moved), "GBps": round(moved / (ms_prep * 1e-3) / 1e9, 1),
                                               "note": "the volume is read once (the x pass gathers the statistics, the normalisation is applied at the samples); the pruned transform (kx <= R, |ky|, |kz| <= R) writes and "

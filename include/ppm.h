@@ -307,6 +307,7 @@ void ppm_accum_set_count(ppm_accum_t *acc, int half, long count);
 typedef struct ppm_comm_id { char bytes[128]; } ppm_comm_id; /* = ncclUniqueId */
 int ppm_comm_unique_id(ppm_comm_id *id);
 void *ppm_comm_create(int n_ranks, int rank, const ppm_comm_id *id);
+int ppm_comm_count(void *comm); /* ranks of the communicator as RCCL reports them (ncclCommCount); < 0 on error */
 void ppm_comm_destroy(void *comm);
 int ppm_accum_reduce(ppm_accum_t *acc, void *comm, int root);
 

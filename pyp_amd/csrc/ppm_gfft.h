@@ -8,7 +8,7 @@
 //
 //     c(sx, sy) = Re sum_{kx >= 0, ky} W(k) conj(P(k)) e^{+2 pi i (kx sx + ky sy) / Ns},    Ns = 2 L,
 //
-// for all shifts of the window as the oracle's zero-filled inverse transform does (oracle/ppm_oracle.c ccf_peak mode 0), in two
+// for all shifts of the window as a zero-filled Ns x Ns inverse transform would (the form the CPU checker states it in), in two
 // passes that each keep a whole line in the registers of one thread (ppm_fft_reg.h):
 //
 //  * COLUMN pass, lane = kx: the transform over ky.  A thread forms x[n] = W conj(P) (or W P for psi + 180) for ky = n and

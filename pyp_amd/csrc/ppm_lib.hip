@@ -1297,6 +1297,7 @@ struct Rccl {
     int (*GetUniqueId)(void *) = nullptr;
     int (*CommInitRank)(void **, int, ppm_comm_id, int) = nullptr;      // ncclUniqueId is passed by value: 128 opaque bytes
     int (*CommDestroy)(void *) = nullptr;
+    int (*CommCount)(const void *, int *) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
     int (*Reduce)(const void *, void *, size_t, int, int, int, void *, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
@@ -1310,6 +1311,7 @@ static void rccl_load(Rccl &r) {
     r.GetUniqueId = (int (*)(void *))sym("ncclGetUniqueId");
     r.CommInitRank = (int (*)(void **, int, ppm_comm_id, int))sym("ncclCommInitRank");
     r.CommDestroy = (int (*)(void *))sym("ncclCommDestroy");
+    r.CommCount = (int (*)(const void *, int *))sym("ncclCommCount");
     r.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))sym("ncclAllReduce");
     r.Reduce = (int (*)(const void *, void *, size_t, int, int, int, void *, hipStream_t))sym("ncclReduce");
     r.GetErrorString = (const char *(*)(int))sym("ncclGetErrorString");
@@ -1344,6 +1346,15 @@ void *ppm_comm_create(int n_ranks, int rank, const ppm_comm_id *id) {
     (void)hipSetDevice(g.device);                    // the communicator binds to the calling thread's current device
     if (int rc = r.CommInitRank(&comm, n_ranks, *id, rank)) { rccl_fail(r, rc, "ncclCommInitRank"); return nullptr; }
     return comm;
+}
+
+int ppm_comm_count(void *comm) {
+    if (!comm) return fail(-22, "null communicator");
+    Rccl &r = rccl();
+    if (!r.err.empty()) return fail(-38, r.err);
+    int n = 0;
+    if (int rc = r.CommCount(comm, &n)) return rccl_fail(r, rc, "ncclCommCount");
+    return n;
 }
 
 void ppm_comm_destroy(void *comm) {

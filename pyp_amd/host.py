@@ -254,6 +254,14 @@ def make_comm(n_ranks, rank, unique_id, device=0):
     return h
 
 
+def comm_count(comm):
+    """Ranks of the communicator as RCCL itself reports them (ppm_comm_count = ncclCommCount)."""
+    n = lib.load().ppm_comm_count(comm)
+    if n < 0:
+        raise lib.PpmError(lib.last_error())
+    return int(n)
+
+
 def destroy_comm(comm):
     if comm:
         lib.load().ppm_comm_destroy(C.c_void_p(comm))

@@ -16,7 +16,7 @@ EXPORTS = [
     "ppm_insert_batch", "ppm_accum_download", "ppm_accum_download_range", "ppm_accum_add", "ppm_accum_count", "ppm_accum_set_count",
     "ppm_finalize", "ppm_profile_enable", "ppm_profile_reset", "ppm_profile_get", "ppm_device_alloc",
     "ppm_device_free", "ppm_device_upload", "ppm_device_sync", "ppm_extract_boxes", "ppm_host_alloc", "ppm_host_free", "ppm_host_read",
-    "ppm_comm_unique_id", "ppm_comm_create", "ppm_comm_destroy", "ppm_accum_reduce", "ppm_sva_insert", "ppm_sva_align_average",
+    "ppm_comm_unique_id", "ppm_comm_create", "ppm_comm_count", "ppm_comm_destroy", "ppm_accum_reduce", "ppm_sva_insert", "ppm_sva_align_average",
 ]
 
 
@@ -75,6 +75,7 @@ def load():
     L.ppm_extract_boxes.argtypes = [vp, ci, ci, ci, vp, ci, ci, C.c_double, C.c_double, ci, ci, vp, ci]; L.ppm_extract_boxes.restype = ci
     L.ppm_comm_unique_id.argtypes = [vp]; L.ppm_comm_unique_id.restype = ci
     L.ppm_comm_create.argtypes = [ci, ci, vp]; L.ppm_comm_create.restype = vp
+    L.ppm_comm_count.argtypes = [vp]; L.ppm_comm_count.restype = ci
     L.ppm_comm_destroy.argtypes = [vp]; L.ppm_comm_destroy.restype = None
     L.ppm_accum_reduce.argtypes = [vp, vp, ci]; L.ppm_accum_reduce.restype = ci
     _lib = L

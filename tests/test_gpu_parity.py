@@ -678,6 +678,7 @@ def test_accum_reduce_through_the_c_abi_on_one_rank(H, O):
     assert len(uid) == 128 and any(uid)
     comm = H.make_comm(1, 0, uid)
     try:
+        assert H.comm_count(comm) == 1     # what RCCL itself says about the communicator (ppm_comm_count = ncclCommCount)
         acc.reduce(comm)                   # all-reduce
         assert np.array_equal(acc.download(), before) and acc.counts() == counts and sum(counts) == 12
         acc.reduce(comm, root=0)
