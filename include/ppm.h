@@ -201,6 +201,8 @@ enum { PPM_K_PREP = 0, PPM_K_BANK = 1, PPM_K_GLOBAL = 2, PPM_K_TOPK = 3, PPM_K_L
 int ppm_init(int device);
 const char *ppm_last_error(void);
 const char *ppm_version(void);
+const char *ppm_build_id(void);       /* changes with every build of the library: a resident server and its clients compare it */
+int ppm_device_mem_info(size_t *free_bytes, size_t *total_bytes);       /* of the library's device (hipMemGetInfo) */
 
 /* vol: n*n*n floats, x fastest. max_band_px: largest Fourier radius (pixels) any later call will
  * use with this reference (<= n/2). */
@@ -322,7 +324,10 @@ int ppm_accum_reduce(ppm_accum_t *acc, void *comm, int root);
  * and everywhere otherwise.  `acc` = ppm_accum_create(box, pixel, "C1", ...); ppm_accum_count counts sub-volumes; shards on several
  * GPUs are summed with ppm_accum_reduce; ppm_finalize turns the sums into the two half-maps, the FSC-weighted average and the
  * statistics table exactly as for a reconstruction.  Of cfg only box and use_missing_wedge are read.  Build-defined (the absent
- * MPI_Classification's weighting is not visible). */
+ * MPI_Classification's weighting is not visible).  Sub-volumes enter the sums in batches of up to 32 and the counters follow every
+ * completed batch: after an error return ppm_accum_count says how many are in the sums (the caller can go on from there or start
+ * the accumulator again).  With index == NULL the half-map parity is that of the POSITION IN THIS CALL (plus the call's base in
+ * ppm_sva_align_average): callers that split a table into several calls pass the table numbers in `index`. */
 int ppm_sva_insert(ppm_accum_t *acc, const ppm_sva_cfg *cfg, const void *volumes, int volumes_on_device, int n_vol, const float *wedges,
                    const double *poses, const long *index);
 

@@ -28,11 +28,19 @@
 
 namespace dropin {
 
-enum { kProgRecon = 1, kProgRefine = 2, kProgStats = 8, kProgStop = 9, kHandOver = -100 };
+enum { kProgRecon = 1, kProgRefine = 2, kProgHello = 7, kProgStats = 8, kProgStop = 9, kHandOver = -100 };
 
-inline std::string server_socket_path(int dev) {
+// Where the server's socket, its guard lock and its log live: PPM_LOCK_DIR, else the user's runtime directory, else /tmp — the names carry
+// the user id, so two users of a node run a server each (the GPU lock file itself, pyp_amd_gpu<N>.lock, stays shared between them).
+inline std::string server_dir() {
     const char *ld = getenv("PPM_LOCK_DIR");
-    return std::string(ld && *ld ? ld : "/tmp") + "/pyp_amd_gpu" + std::to_string(dev) + ".sock";
+    if (ld && *ld) return ld;
+    const char *xr = getenv("XDG_RUNTIME_DIR");
+    if (xr && *xr && access(xr, W_OK) == 0) return xr;
+    return "/tmp";
+}
+inline std::string server_socket_path(int dev) {
+    return server_dir() + "/pyp_amd_gpu" + std::to_string(dev) + ".u" + std::to_string((long)getuid()) + ".sock";
 }
 inline bool write_all(int fd, const void *p, size_t n) {
     const char *c = (const char *)p;
@@ -85,6 +93,7 @@ inline bool start_server(int dev, double wait_s = 20.0) {
     if (posix_spawn(&pid, exe.c_str(), nullptr, nullptr, argv, environ) != 0) return false;
     int st = 0;
     while (waitpid(pid, &st, 0) < 0 && errno == EINTR) {}       // --daemon: the child forks the server and returns at once
+    if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) return false;   // the launcher itself failed: nothing will ever listen
     const auto t0 = Clock::now();
     while (since(t0) < wait_s) {
         int fd = connect_server(dev);
@@ -98,6 +107,13 @@ inline bool run_through_server(int prog, const std::string &input, int &status, 
     const char *e = getenv("PPM_STACK_CACHE");
     if (!e || !*e || !strcmp(e, "0")) return false;
     const int dev = getenv("PPM_DEVICE") ? atoi(getenv("PPM_DEVICE")) : 0;
+    // a server left over from an older build of the library (it answers with its own build id) is stopped and replaced
+    int hs = 0; std::string hello;
+    if (server_call(dev, kProgHello, "", hs, hello) && hello != ppm_build_id()) {
+        int st = 0; std::string t;
+        (void)server_call(dev, kProgStop, "", st, t);
+        for (int i = 0; i < 250; i++) { int fd = connect_server(dev); if (fd < 0) break; close(fd); usleep(20000); }
+    }
     if (server_call(dev, prog, input, status, text)) return true;
     if (!start_server(dev)) return false;
     return server_call(dev, prog, input, status, text);
@@ -108,7 +124,8 @@ struct StackEntry { FileId id; long first = 0, count = 0; int box = 0; void *dpt
 struct RefEntry { FileId id; int pad = 1, box = 0; ppm_ref_t *ref = nullptr; double used = 0; };
 struct Cache {
     int dev = 0;
-    size_t budget = (size_t)160 << 30, used = 0;
+    size_t budget = (size_t)160 << 30, used = 0;        // upper bound on resident ranges; what the device really has free decides (reserve)
+    size_t headroom = (size_t)24 << 30;                 // left free on the device for work buffers, cached references and other programs (PPM_STACK_CACHE_HEADROOM_GB)
     std::vector<StackEntry> stacks; std::vector<RefEntry> refs;
     void *pinned[3] = { nullptr, nullptr, nullptr }; size_t pin_bytes = 0;
     long hits = 0, misses = 0, served = 0;
@@ -125,11 +142,17 @@ struct Cache {
         if (bytes > budget) return nullptr;
         for (size_t i = 0; i < stacks.size();) if (stacks[i].id.dev == id.dev && stacks[i].id.ino == id.ino && !(stacks[i].id == id)) drop_stack(i); else i++;   // the file has changed
         for (int attempt = 0; attempt < 2; attempt++) {
-            while (used + bytes > budget && !stacks.empty()) {
+            // least recently used ranges go until the new one fits the budget AND the device keeps `headroom` bytes free next to it
+            // (hipMemGetInfo: references, work buffers and other processes' allocations are counted by the device, not by this table)
+            for (;;) {
+                size_t fr = 0, tot = 0;
+                const bool tight = ppm_device_mem_info(&fr, &tot) == 0 && fr < bytes + headroom;
+                if ((used + bytes <= budget && !tight) || stacks.empty()) break;
                 size_t lru = 0;
                 for (size_t i = 1; i < stacks.size(); i++) if (stacks[i].used < stacks[lru].used) lru = i;
                 drop_stack(lru);
             }
+            { size_t fr = 0, tot = 0; if (ppm_device_mem_info(&fr, &tot) == 0 && fr < bytes + headroom / 2) return nullptr; }      // does not fit next to what else lives on the device: stream it
             if (void *p = ppm_device_alloc(bytes)) return p;
             while (!stacks.empty()) drop_stack(0);                  // the device is fuller than the budget assumed: give everything back, try once more
         }
@@ -158,6 +181,12 @@ struct Cache {
         for (void *&p : pinned) { p = ppm_host_alloc(bytes); if (!p) return false; }
         pin_bytes = bytes;
         return true;
+    }
+    // everything this process holds on the device: before a call is handed over to a child process that needs the memory itself
+    void release_device() {
+        while (!stacks.empty()) drop_stack(0);
+        for (auto &e : refs) ppm_reference_destroy(e.ref);
+        refs.clear();
     }
     void clear() {
         while (!stacks.empty()) drop_stack(0);

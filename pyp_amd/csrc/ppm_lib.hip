@@ -484,6 +484,16 @@ extern "C" {
 
 const char *ppm_last_error(void) { return g_err.c_str(); }
 const char *ppm_version(void) { return "pypmatch 0.1 (gfx950)"; }
+const char *ppm_build_id(void) { return "pypmatch " __DATE__ " " __TIME__; }
+int ppm_device_mem_info(size_t *free_bytes, size_t *total_bytes) {
+    if (!g.inited) return fail(-1, "ppm_init has not been called");
+    (void)hipSetDevice(g.device);
+    size_t f = 0, t = 0;
+    HIPCHK(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return 0;
+}
 
 int ppm_init(int device) {
     static std::mutex init_mu;                       // a caller may start the device from a helper thread and call again from its main thread
@@ -2362,8 +2372,9 @@ static int sva_insert_device(ppm_accum_t *a, const ppm_sva_cfg *cfg, const float
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(cur_stream()));          // the host tables of the batch are reused
+        // the counters follow every completed batch: after an error in a later one they still say which sub-volumes are in the sums
+        for (int h = 0; h < 2; h++) { ppm_accum_set_count(a, h, a->counts[h] + added[h]); added[h] = 0; }
     }
-    for (int h = 0; h < 2; h++) ppm_accum_set_count(a, h, a->counts[h] + added[h]);      // host and device copies of the counters
     return 0;
 }
 

@@ -35,11 +35,8 @@ int main(int argc, char **argv) {
         if (pid < 0) return 1;
         if (pid > 0) return 0;
         setsid();
-        const char *ld = getenv("PPM_LOCK_DIR");
-        const std::string log = std::string(ld && *ld ? ld : "/tmp") + "/pyp_amd_gpu" + std::to_string(dev) + ".server.log";
-        int nfd = open("/dev/null", O_RDONLY), lfd = open(log.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0600);
-        if (nfd >= 0) { dup2(nfd, 0); close(nfd); }
-        if (lfd >= 0) { dup2(lfd, 1); dup2(lfd, 2); close(lfd); }
+        int nfd = open("/dev/null", O_RDWR);
+        if (nfd >= 0) { dup2(nfd, 0); dup2(nfd, 1); dup2(nfd, 2); close(nfd); }      // the log is opened once this process holds the guard lock
     }
     setenv("PPM_SYNC", "block", 0);
     // ---- one server per device: the server holds an exclusive lock on <socket>.lock for its lifetime (two clients may start servers at the
@@ -48,6 +45,11 @@ int main(int argc, char **argv) {
     const int guard_fd = open((path + ".lock").c_str(), O_RDWR | O_CREAT, 0600);
     if (guard_fd < 0 || flock(guard_fd, LOCK_EX | LOCK_NB) != 0) { printf("a server is already running (or starting) for device %d\n", dev); return 0; }
     { int fd = connect_server(dev); if (fd >= 0) { close(fd); printf("a server is already running for device %d\n", dev); return 0; } }
+    if (daemon) {                                   // this process is THE server of the device: only now may it touch the log (appended, never followed through a link)
+        const std::string log = server_dir() + "/pyp_amd_gpu" + std::to_string(dev) + ".u" + std::to_string((long)getuid()) + ".server.log";
+        const int lfd = open(log.c_str(), O_WRONLY | O_CREAT | O_APPEND | O_NOFOLLOW, 0600);
+        if (lfd >= 0) { dup2(lfd, 1); dup2(lfd, 2); close(lfd); }
+    }
     unlink(path.c_str());
     int ls = socket(AF_UNIX, SOCK_STREAM, 0);
     sockaddr_un ad; memset(&ad, 0, sizeof ad); ad.sun_family = AF_UNIX;
@@ -60,6 +62,7 @@ int main(int argc, char **argv) {
     Cache cache;
     cache.dev = dev;
     if (const char *e = getenv("PPM_STACK_CACHE_GB")) { const double gb = atof(e); if (gb > 0) cache.budget = (size_t)(gb * (double)(1ull << 30)); }
+    if (const char *e = getenv("PPM_STACK_CACHE_HEADROOM_GB")) { const double gb = atof(e); if (gb >= 0) cache.headroom = (size_t)(gb * (double)(1ull << 30)); }
     const double idle_s = getenv("PPM_STACK_CACHE_IDLE_S") ? atof(getenv("PPM_STACK_CACHE_IDLE_S")) : 600.0;
     bool inited = false;
     printf("ppm_server: device %d, socket %s, cache %.0f GB, idle limit %.0f s\n", dev, path.c_str(), cache.budget / 1e9, idle_s);
@@ -77,7 +80,8 @@ int main(int argc, char **argv) {
         std::string text; Out out; out.sink = &text;
         int32_t status = 0;
         bool leave = false;
-        if (prog == kProgStop) { out.print("ppm_server: stopping (served %ld calls, %ld resident hits, %ld uploads)\n", cache.served, cache.hits, cache.misses); leave = true; }
+        if (prog == kProgHello) out.print("%s", ppm_build_id());
+        else if (prog == kProgStop) { out.print("ppm_server: stopping (served %ld calls, %ld resident hits, %ld uploads)\n", cache.served, cache.hits, cache.misses); leave = true; }
         else if (prog == kProgStats) {
             out.print("ppm_server: device %d, served %ld calls, %ld resident hits, %ld uploads, %.2f of %.0f GB cached\n", dev, cache.served, cache.hits, cache.misses, cache.used / 1e9, cache.budget / 1e9);
             for (const auto &e : cache.stacks) out.print("  stack inode %llu: particles %ld..%ld, box %d, %.2f GB\n", e.id.ino, e.first, e.first + e.count - 1, e.box, e.bytes / 1e9);
@@ -103,7 +107,7 @@ int main(int argc, char **argv) {
             printf("ppm_server: %s in %s -> status %d, %.2f s\n", prog == kProgRecon ? "reconstruct3d" : "refine3d", cwd.c_str(), status, since(t0));
             fflush(stdout);
         } else { status = 1; out.print("ERROR: ppm_server: unknown request %u\n", prog); }
-        if (status == kHandOver) text.clear();
+        if (status == kHandOver) { text.clear(); cache.release_device(); }      // the client runs the call in a child process of its own, on this GPU: it gets the memory
         (void)(write_all(fd, &status, 4) && send_blob(fd, text));
         close(fd);
         if (leave) break;

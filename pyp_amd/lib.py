@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libpypmatch.so")
 
 EXPORTS = [
-    "ppm_init", "ppm_last_error", "ppm_version", "ppm_reference_create", "ppm_reference_create_padded", "ppm_reference_create_weighted", "ppm_reference_destroy",
+    "ppm_init", "ppm_last_error", "ppm_version", "ppm_build_id", "ppm_device_mem_info", "ppm_reference_create", "ppm_reference_create_padded", "ppm_reference_create_weighted", "ppm_reference_destroy",
     "ppm_refine_batch", "ppm_refine_last_counts", "ppm_refine_note", "ppm_match_projections", "ppm_csp_refine", "ppm_sva_align", "ppm_accum_floats", "ppm_accum_create", "ppm_accum_destroy",
     "ppm_insert_batch", "ppm_accum_download", "ppm_accum_download_range", "ppm_accum_add", "ppm_accum_count", "ppm_accum_set_count",
     "ppm_finalize", "ppm_profile_enable", "ppm_profile_reset", "ppm_profile_get", "ppm_device_alloc",
@@ -40,6 +40,8 @@ def load():
     L.ppm_init.argtypes = [ci]; L.ppm_init.restype = ci
     L.ppm_last_error.restype = C.c_char_p
     L.ppm_version.restype = C.c_char_p
+    L.ppm_build_id.restype = C.c_char_p
+    L.ppm_device_mem_info.argtypes = [vp, vp]; L.ppm_device_mem_info.restype = ci
     L.ppm_reference_create.argtypes = [vp, ci, cf]; L.ppm_reference_create.restype = vp
     L.ppm_reference_create_padded.argtypes = [vp, ci, cf, ci]; L.ppm_reference_create_padded.restype = vp
     L.ppm_reference_create_weighted.argtypes = [vp, ci, cf, ci, vp, ci]; L.ppm_reference_create_weighted.restype = vp

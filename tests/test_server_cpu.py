@@ -12,6 +12,8 @@ from pyp_amd.formats import cistem, mrc
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SERVER = os.path.join(ROOT, "bin", "ppm_server")
 
+SOCK = "pyp_amd_gpu0.u%d.sock" % os.getuid()          # the server's socket carries the user id (pyp_amd/csrc/dropin_server.h)
+
 
 def _built(prog):
     exe = os.path.join(ROOT, "bin", prog)
@@ -37,18 +39,18 @@ def test_server_starts_reports_and_stops(lockdir):
         if r.returncode == 0:
             break
         time.sleep(0.05)
-    assert r.returncode == 0 and "served 0 calls" in r.stdout and (lockdir / "pyp_amd_gpu0.sock").exists()
-    assert oct((lockdir / "pyp_amd_gpu0.sock").stat().st_mode & 0o777) == "0o700"                           # the owner's only
+    assert r.returncode == 0 and "served 0 calls" in r.stdout and (lockdir / SOCK).exists()
+    assert oct((lockdir / SOCK).stat().st_mode & 0o777) == "0o700"                           # the owner's only
     # a second server for the same device steps back
     r2 = subprocess.run([SERVER], capture_output=True, text=True, timeout=30)
     assert r2.returncode == 0 and "already running" in r2.stdout
     r = subprocess.run([SERVER, "--stop"], capture_output=True, text=True, timeout=30)
     assert r.returncode == 0 and "stopping" in r.stdout
     for _ in range(100):
-        if not (lockdir / "pyp_amd_gpu0.sock").exists():
+        if not (lockdir / SOCK).exists():
             break
         time.sleep(0.05)
-    assert not (lockdir / "pyp_amd_gpu0.sock").exists()
+    assert not (lockdir / SOCK).exists()
 
 
 def test_servers_started_at_the_same_moment_leave_one(lockdir):
@@ -66,11 +68,11 @@ def test_servers_started_at_the_same_moment_leave_one(lockdir):
     assert r.returncode == 0 and "served 0 calls" in r.stdout
     time.sleep(0.3)                                       # the losers are gone by now; the socket must still answer
     assert subprocess.run([SERVER, "--stats"], capture_output=True, text=True).returncode == 0
-    with open(lockdir / "pyp_amd_gpu0.sock.lock", "r+") as f:
+    with open(lockdir / (SOCK + ".lock"), "r+") as f:
         with pytest.raises(OSError):
             fcntl.flock(f, fcntl.LOCK_EX | fcntl.LOCK_NB)            # held by the one server
     assert subprocess.run([SERVER, "--stop"], capture_output=True, text=True, timeout=30).returncode == 0
-    with open(lockdir / "pyp_amd_gpu0.sock.lock", "r+") as f:
+    with open(lockdir / (SOCK + ".lock"), "r+") as f:
         for _ in range(100):
             try:
                 fcntl.flock(f, fcntl.LOCK_EX | fcntl.LOCK_NB)
