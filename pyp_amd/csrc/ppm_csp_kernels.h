@@ -1,9 +1,11 @@
 // ppm_csp_kernels.h — constrained (tilt-series) scoring kernel of libpypmatch (gfx950).
 //
 // A projection row's pose follows from its particle's 3-D pose and its tilt's geometry (include/ppm.h, ppm_csp_cfg; the
-// relation restates csp_euler_angles, src/pyp/analysis/geometry/core.py:1081-1213).  The optimiser lives on the host
-// (ppm_csp_refine in ppm_lib.hip): every sweep it hands the device one displacement table per unit and gets one score per
-// (row, candidate) back; the rows of a unit are averaged on the host in a fixed order.
+// relation restates csp_euler_angles, src/pyp/analysis/geometry/core.py:1081-1213).  The optimiser's state lives on the device
+// (round 5): a compass iteration is a fixed sequence of launches — score the candidates (k_csp_eval), average per unit
+// (k_csp_unit_means), parabolic trial step (k_csp_step_trial), score it, average, accept and lay out the next iteration's candidates
+// (k_csp_step_accept) — and the host (ppm_csp_refine in ppm_lib.hip) enqueues all iterations without waiting in between; the rows of a
+// unit are averaged in a fixed order, so results do not depend on the launch shape.
 #pragma once
 #include "ppm_kernels2.h"
 
@@ -124,6 +126,107 @@ __global__ void k_csp_unit_means(const double *__restrict__ out, const int *__re
     double s = 0;
     for (int r = lo; r < hi; r++) s += out[(size_t)r * ncand + c];
     mean[i] = s / (double)(hi - lo);
+}
+
+// ---- the compass search's decisions, one thread per active unit (double precision, the same rule as the CPU checker's loop and k_local's
+// compass iteration).  Candidate 0 is the unit as it stands; then +h and -h for every enabled parameter in order.
+struct CspStepP {
+    int kind, n_active, ncand;
+    const int *active;        // [n_active] index of the unit in the particle / tilt tables (null: the identity)
+    const int *unit_slot;     // [n_units] row of the unit in the displacement tables (null: the identity)
+    int en[6]; double tol[6];
+    double ha, hs;            // steps of THIS iteration (degrees, pixels)
+    double ha_next, hs_next;  // steps of the next one (k_csp_step_accept lays out its candidates)
+    const double *mean;       // [n_active][ncand] unit means of the compass sweep
+    const double *tmean;      // [n_active] unit means of the trial sweep
+    double *acc;              // [n_active][6] displacement accumulated so far (bounded by +-tol)
+    double *dtrial;           // [n_active][6] trial step
+    double *fpm;              // [n_active][12] f(+h), f(-h) per parameter (-1e300: outside the bounds)
+    double *delta_c;          // [n_slots][ncand][6] candidates of the compass sweep
+    double *delta_t;          // [n_slots][6] the trial step as k_csp_eval reads it
+    double *Nmat, *pshift, *tl;   // unit state (k_csp_eval's tables; the sub-volume search keeps N and p in one row of 12)
+    int nstride, pstride;         // doubles between two units' N / p (9 and 3 in k_csp_eval's tables, 12 and 12 in k_sva_eval's)
+};
+__device__ __forceinline__ int d_csp_unit(const CspStepP &P, int a) { return P.active ? P.active[a] : a; }
+__device__ __forceinline__ int d_csp_slot(const CspStepP &P, int u) { return P.unit_slot ? P.unit_slot[u] : u; }
+
+__device__ __forceinline__ void d_csp_layout_candidates(const CspStepP &P, int slot, double ha, double hs) {
+    double *d = P.delta_c + (size_t)slot * P.ncand * 6;
+    for (int k = 0; k < P.ncand * 6; k++) d[k] = 0.0;
+    int c = 1;
+    for (int i = 0; i < 6; i++) {
+        if (!P.en[i]) continue;
+        const double h = i < 3 ? ha : hs;
+        d[(size_t)c * 6 + i] = h; d[(size_t)(c + 1) * 6 + i] = -h;
+        c += 2;
+    }
+}
+
+// candidates of the first iteration
+__global__ void k_csp_step_init(CspStepP P) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= P.n_active) return;
+    d_csp_layout_candidates(P, d_csp_slot(P, d_csp_unit(P, a)), P.ha_next, P.hs_next);
+}
+
+// after the compass sweep: the parabolic trial step of every unit
+__global__ void k_csp_step_trial(CspStepP P) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= P.n_active) return;
+    const double *mean = P.mean + (size_t)a * P.ncand, *acc = P.acc + (size_t)a * 6;
+    double *d = P.dtrial + (size_t)a * 6, *fpm = P.fpm + (size_t)a * 12;
+    const double f0 = mean[0];
+    for (int i = 0, c = 1; i < 6; i++) {
+        d[i] = 0; fpm[2 * i] = fpm[2 * i + 1] = -1e300;
+        if (!P.en[i]) continue;
+        const double h = i < 3 ? P.ha : P.hs, tol = P.tol[i];
+        const bool okp = fabs(acc[i] + h) <= tol + 1e-9, okm = fabs(acc[i] - h) <= tol + 1e-9;
+        const double fp = okp ? mean[c] : -1e300, fm = okm ? mean[c + 1] : -1e300;
+        c += 2;
+        fpm[2 * i] = fp; fpm[2 * i + 1] = fm;
+        if (okp && okm) {
+            const double den = 2.0 * f0 - fp - fm;
+            if (den > 1e-12) { const double t = 0.5 * h * (fp - fm) / den; d[i] = t > h ? h : (t < -h ? -h : t); }
+            else { const double best = fp > fm ? fp : fm; d[i] = best > f0 ? (fp > fm ? h : -h) : 0.0; }
+        } else if (okp) d[i] = fp > f0 ? h : 0.0;
+        else if (okm) d[i] = fm > f0 ? -h : 0.0;
+        if (acc[i] + d[i] > tol) d[i] = tol - acc[i];
+        if (acc[i] + d[i] < -tol) d[i] = -tol - acc[i];
+    }
+    double *dt = P.delta_t + (size_t)d_csp_slot(P, d_csp_unit(P, a)) * 6;
+    for (int i = 0; i < 6; i++) dt[i] = d[i];
+}
+
+// after the trial sweep: keep the trial step, the best single probe, or nothing; move the unit; lay out the next candidates
+__global__ void k_csp_step_accept(CspStepP P) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= P.n_active) return;
+    const int u = d_csp_unit(P, a);
+    const double f0 = P.mean[(size_t)a * P.ncand], ft = P.tmean[a];
+    const double *fpm = P.fpm + (size_t)a * 12, *dtr = P.dtrial + (size_t)a * 6;
+    int bi = -1, bs = 0; double fb = f0;
+    for (int i = 0; i < 6; i++) {
+        if (!P.en[i]) continue;
+        if (fpm[2 * i] > fb) { fb = fpm[2 * i]; bi = i; bs = 1; }
+        if (fpm[2 * i + 1] > fb) { fb = fpm[2 * i + 1]; bi = i; bs = -1; }
+    }
+    double d[6] = { 0, 0, 0, 0, 0, 0 };
+    bool move = false;
+    if (ft > f0 && ft >= fb) { for (int i = 0; i < 6; i++) d[i] = dtr[i]; move = true; }
+    else if (bi >= 0) { d[bi] = bs * (bi < 3 ? P.ha : P.hs); move = true; }
+    if (move) {
+        if (P.kind == PPM_CSP_PARTICLES) {
+            double *N = P.Nmat + (size_t)u * P.nstride, *p = P.pshift + (size_t)u * P.pstride;
+            for (int k = 0; k < 3; k++)
+                if (d[k] != 0.0) { double R[9], T[9]; d_rot_xyz(k, d[k], R); d_mat_mul3(N, R, T); for (int q = 0; q < 9; q++) N[q] = T[q]; }
+            for (int k = 0; k < 3; k++) p[k] += d[3 + k];
+        } else {
+            double *tl = P.tl + (size_t)u * 4;
+            tl[0] += d[0]; tl[1] += d[1]; tl[2] += d[3]; tl[3] += d[4];
+        }
+        for (int k = 0; k < 6; k++) P.acc[(size_t)a * 6 + k] += d[k];
+    }
+    d_csp_layout_candidates(P, d_csp_slot(P, u), P.ha_next, P.hs_next);
 }
 
 }  // namespace ppm

@@ -206,7 +206,7 @@ struct ppm_ref {
     DevBuf<float> images, wring, cw, C2, nP, nI, cc, mats, ddef;
     // constrained search (ppm_csp_refine)
     DevBuf<float2> c_Il, c_band; DevBuf<float> c_cw, c_img, c_wring; DevBuf<double> c_rows, c_N, c_p, c_tl, c_delta, c_s0, c_g0, c_out;
-    DevBuf<int> c_eval, c_rp, c_rt, c_slot, c_uoff; DevBuf<LState> c_states; DevBuf<double> c_mean;
+    DevBuf<int> c_eval, c_rp, c_rt, c_slot, c_uoff, c_active; DevBuf<LState> c_states; DevBuf<double> c_mean, c_tmean, c_acc, c_dtrial, c_fpm, c_delta_t;
     // sub-tomogram alignment (ppm_sva_align): the transforms' work array, the band-limited transforms of a chunk, staged host volumes
     // (GBs: allocating and freeing them on every call cost ~20 ms of a 120 ms call)
     DevBuf<float2> s_f, s_g, s_F; DevBuf<float> s_vols;
@@ -678,7 +678,7 @@ void ppm_reference_destroy(ppm_ref_t *r) {
     r->images.release(); r->wring.release(); r->cw.release(); r->C2.release(); r->nP.release(); r->nI.release();
     r->s_f.release(); r->s_g.release(); r->s_F.release(); r->s_vols.release(); r->s_plan.samples.release(); r->s_plan.bandw.release(); r->s_plan.Fw.release();
     r->c_Il.release(); r->c_band.release(); r->c_cw.release(); r->c_img.release(); r->c_wring.release(); r->c_rows.release(); r->c_N.release(); r->c_p.release(); r->c_tl.release();
-    r->c_delta.release(); r->c_s0.release(); r->c_g0.release(); r->c_out.release(); r->c_eval.release(); r->c_rp.release(); r->c_rt.release(); r->c_slot.release(); r->c_states.release(); r->c_uoff.release(); r->c_mean.release(); r->cc.release(); r->mats.release(); r->ddef.release();
+    r->c_delta.release(); r->c_s0.release(); r->c_g0.release(); r->c_out.release(); r->c_eval.release(); r->c_rp.release(); r->c_rt.release(); r->c_slot.release(); r->c_states.release(); r->c_uoff.release(); r->c_mean.release(); r->c_active.release(); r->c_tmean.release(); r->c_acc.release(); r->c_dtrial.release(); r->c_fpm.release(); r->c_delta_t.release(); r->cc.release(); r->mats.release(); r->ddef.release();
     r->band.release(); r->spill.release(); r->Il.release(); r->Wp.release(); r->bank.release(); r->twN.release(); r->rowtw.release(); r->sh.release(); r->samples.release();
     r->hits.release(); r->states.release(); r->states2.release();
     r->hits_t.release(); r->tile_c.release(); r->bank4.release(); r->part.release(); r->gtw.release();
@@ -1517,6 +1517,44 @@ extern "C" int ppm_csp_refine(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const p
     if (gm.N != ref->N) return fail(-22, "particle box differs from the reference box");
     if (gm.B > (ref->B + 1) / ref->pad - 1) return fail(-22, "high-resolution limit exceeds the band the reference was prepared for");
     const int kind = cc->unit;
+    const Trace trace_("ppm_csp_refine");
+    // ---- device first: sample list and the prepared spectra of all rows are enqueued before the host builds its unit tables, which then
+    // happens while the device works (20 k rows: ~1.5 ms of hash maps and poses against ~3 ms of pre-processing)
+    const double rm_px = cfg->mask_radius / gm.a;
+    SampleList sl; build_samples(gm, sl);
+    const int S_pad = (int)sl.packed.size(), nrings = gm.B + 2;
+    auto prefix_of = [&](double rband) { int rg = (int)std::ceil(rband); if (rg > gm.B + 1) rg = gm.B + 1; return sl.ring_off[rg]; };
+    const size_t NN = (size_t)gm.N * gm.N, HW = (size_t)gm.H * gm.W;
+    if (int rc = ref->samples.ensure(S_pad)) return rc;
+    HIPCHK(hipMemcpyAsync(ref->samples.p, sl.packed.data(), S_pad * sizeof(uint32_t), hipMemcpyHostToDevice, cur_stream()));
+    // scratch of the constrained search lives in the reference handle (grown on demand, freed with it): allocating and freeing
+    // several hundred MB per call cost a third of a call on a 20 k-projection series
+    DevBuf<float2> &Il = ref->c_Il, &band = ref->c_band; DevBuf<float> &cw = ref->c_cw, &img = ref->c_img, &wring = ref->c_wring;
+    DevBuf<double> &d_rows = ref->c_rows, &d_N = ref->c_N, &d_p = ref->c_p, &d_tl = ref->c_tl, &d_delta = ref->c_delta, &d_s0 = ref->c_s0, &d_g0 = ref->c_g0, &d_out = ref->c_out;
+    DevBuf<int> &d_eval = ref->c_eval, &d_rp = ref->c_rp, &d_rt = ref->c_rt, &d_slot = ref->c_slot;
+    DevBuf<LState> &d_states = ref->c_states;
+    const bool mode4 = cc->refine_defocus != 0;
+    if (mode4 && kind != PPM_CSP_MICROGRAPHS) return fail(-22, "csp: defocus refinement works on tilts (unit = micrographs)");
+    const int CH = (int)std::min<size_t>((size_t)n_proj, std::max<size_t>(64, ((size_t)2 << 30) / (NN * 4 + HW * 8)));
+    if (int rc = Il.ensure((size_t)n_proj * S_pad)) return rc;
+    if (int rc = cw.ensure((size_t)n_proj * S_pad)) return rc;
+    if (int rc = band.ensure((size_t)CH * HW)) return rc;
+    if (int rc = d_rows.ensure((size_t)n_proj * PPM_NCOL)) return rc;
+    if (mode4) if (int rc = wring.ensure((size_t)n_proj * (gm.B + 2))) return rc;
+    if (!images_on_device) if (int rc = img.ensure((size_t)CH * NN)) return rc;
+    HIPCHK(hipMemcpyAsync(d_rows.p, rows, (size_t)n_proj * PPM_NCOL * sizeof(double), hipMemcpyHostToDevice, cur_stream()));
+    const double fall = cfg->mask_falloff > 0 ? cfg->mask_falloff : 20.0;
+    for (int c0 = 0; c0 < n_proj; c0 += CH) {
+        const int nb = std::min(CH, n_proj - c0);
+        const float *d_img = (const float *)images + (size_t)c0 * NN;
+        if (!images_on_device) {
+            HIPCHK(hipMemcpyAsync(img.p, (const float *)images + (size_t)c0 * NN, (size_t)nb * NN * sizeof(float), hipMemcpyHostToDevice, cur_stream()));
+            d_img = img.p;
+        }
+        if (int rc = launch_prep(ref->spill, d_img, d_rows.p + (size_t)c0 * PPM_NCOL, nb, gm, (float)rm_px, (float)(fall / gm.a), cfg->normalize, cfg->invert, 1, 1,
+                                 band.p, mode4 ? wring.p + (size_t)c0 * (gm.B + 2) : nullptr, ref->samples.p, S_pad, Il.p + (size_t)c0 * S_pad, cw.p + (size_t)c0 * S_pad, nullptr, nullptr, nullptr)) return rc;
+        if (!images_on_device) HIPCHK(hipStreamSynchronize(cur_stream()));     // the staging buffer is reused by the next chunk
+    }
     // ---- rows -> units
     std::unordered_map<long, int> pmap, tmap;          // tilt key: (TIND, RIND) folded into one integer
     pmap.reserve((size_t)n_part * 2); tmap.reserve((size_t)n_tilt * 2);
@@ -1588,7 +1626,7 @@ extern "C" int ppm_csp_refine(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const p
     int T = cc->max_iterations;
     if (T <= 0) { const double m = std::max(ha0, hs0); T = m > steptol ? (int)std::ceil(std::log(m / steptol) / std::log(2.0)) : 1; T = std::min(12, std::max(1, T)); }
     if (!nfree || active.empty()) T = 0;
-    const double bf = cfg->band_factor == 0 ? 3.0 : cfg->band_factor, rm_px = cfg->mask_radius / gm.a;
+    const double bf = cfg->band_factor == 0 ? 3.0 : cfg->band_factor;
     const bool any_ang = en[0] || en[1] || en[2], any_sh = en[3] || en[4] || en[5];
     auto iter_band = [&](double ha, double hs) {
         if (bf < 0) return gm.r_hi;
@@ -1601,43 +1639,7 @@ extern "C" int ppm_csp_refine(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const p
         return rit < gm.r_hi ? rit : gm.r_hi;
     };
 
-    const Trace trace_("ppm_csp_refine");
     trace_.mark("host tables");
-    // ---- device: sample list, prepared spectra of all rows
-    SampleList sl; build_samples(gm, sl);
-    const int S_pad = (int)sl.packed.size(), nrings = gm.B + 2;
-    auto prefix_of = [&](double rband) { int rg = (int)std::ceil(rband); if (rg > gm.B + 1) rg = gm.B + 1; return sl.ring_off[rg]; };
-    const size_t NN = (size_t)gm.N * gm.N, HW = (size_t)gm.H * gm.W;
-    if (int rc = ref->samples.ensure(S_pad)) return rc;
-    HIPCHK(hipMemcpyAsync(ref->samples.p, sl.packed.data(), S_pad * sizeof(uint32_t), hipMemcpyHostToDevice, cur_stream()));
-    // scratch of the constrained search lives in the reference handle (grown on demand, freed with it): allocating and freeing
-    // several hundred MB per call cost a third of a call on a 20 k-projection series
-    DevBuf<float2> &Il = ref->c_Il, &band = ref->c_band; DevBuf<float> &cw = ref->c_cw, &img = ref->c_img, &wring = ref->c_wring;
-    DevBuf<double> &d_rows = ref->c_rows, &d_N = ref->c_N, &d_p = ref->c_p, &d_tl = ref->c_tl, &d_delta = ref->c_delta, &d_s0 = ref->c_s0, &d_g0 = ref->c_g0, &d_out = ref->c_out;
-    DevBuf<int> &d_eval = ref->c_eval, &d_rp = ref->c_rp, &d_rt = ref->c_rt, &d_slot = ref->c_slot;
-    DevBuf<LState> &d_states = ref->c_states;
-    const bool mode4 = cc->refine_defocus != 0;
-    if (mode4 && kind != PPM_CSP_MICROGRAPHS) return fail(-22, "csp: defocus refinement works on tilts (unit = micrographs)");
-    const int CH = (int)std::min<size_t>((size_t)n_proj, std::max<size_t>(64, ((size_t)2 << 30) / (NN * 4 + HW * 8)));
-    if (int rc = Il.ensure((size_t)n_proj * S_pad)) return rc;
-    if (int rc = cw.ensure((size_t)n_proj * S_pad)) return rc;
-    if (int rc = band.ensure((size_t)CH * HW)) return rc;
-    if (int rc = d_rows.ensure((size_t)n_proj * PPM_NCOL)) return rc;
-    if (mode4) if (int rc = wring.ensure((size_t)n_proj * (gm.B + 2))) return rc;
-    if (!images_on_device) if (int rc = img.ensure((size_t)CH * NN)) return rc;
-    HIPCHK(hipMemcpyAsync(d_rows.p, rows, (size_t)n_proj * PPM_NCOL * sizeof(double), hipMemcpyHostToDevice, cur_stream()));
-    const double fall = cfg->mask_falloff > 0 ? cfg->mask_falloff : 20.0;
-    for (int c0 = 0; c0 < n_proj; c0 += CH) {
-        const int nb = std::min(CH, n_proj - c0);
-        const float *d_img = (const float *)images + (size_t)c0 * NN;
-        if (!images_on_device) {
-            HIPCHK(hipMemcpyAsync(img.p, (const float *)images + (size_t)c0 * NN, (size_t)nb * NN * sizeof(float), hipMemcpyHostToDevice, cur_stream()));
-            d_img = img.p;
-        }
-        if (int rc = launch_prep(ref->spill, d_img, d_rows.p + (size_t)c0 * PPM_NCOL, nb, gm, (float)rm_px, (float)(fall / gm.a), cfg->normalize, cfg->invert, 1, 1,
-                                 band.p, mode4 ? wring.p + (size_t)c0 * (gm.B + 2) : nullptr, ref->samples.p, S_pad, Il.p + (size_t)c0 * S_pad, cw.p + (size_t)c0 * S_pad, nullptr, nullptr, nullptr)) return rc;
-        HIPCHK(hipStreamSynchronize(cur_stream()));
-    }
     if (mode4) {
         // ---- csp mode 4: every row's score for every defocus offset in one sweep (k_defocus), averaged per tilt on the host
         const double step = cc->defocus_step > 0 ? cc->defocus_step : 50.0;
@@ -1768,60 +1770,69 @@ extern "C" int ppm_csp_refine(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const p
     };
     if (int rc = upload_units()) return rc;
     trace_.mark("spectra prepared, units uploaded");
-    double ha = ha0, hs = hs0;
-    std::vector<double> mean, tmean, dtrial((size_t)active.size() * 6);
-    std::vector<int> cand_param, cand_sign;      // candidate c >= 1 moves parameter cand_param[c] by cand_sign[c] h
-    cand_param.push_back(-1); cand_sign.push_back(0);
-    for (int i = 0; i < 6; i++) if (en[i]) { cand_param.push_back(i); cand_sign.push_back(1); cand_param.push_back(i); cand_sign.push_back(-1); }
-    const int ncand = (int)cand_param.size();
-    for (int it = 0; it < T; it++) {
-        const double rband = iter_band(ha, hs);
-        hdelta.assign((size_t)n_slots * ncand * 6, 0.0);
-        for (size_t a = 0; a < active.size(); a++)
-            for (int c = 1; c < ncand; c++) hdelta[((size_t)unit_slot[active[a]] * ncand + c) * 6 + cand_param[c]] = cand_sign[c] * (cand_param[c] < 3 ? ha : hs);
-        if (int rc = sweep(eval_rows, ncand, rband, &mean)) return rc;
-        // parabolic step per unit (same rule as the oracle's loop and k_local's compass iteration)
-        std::vector<double> fpv((size_t)active.size() * 6, -1e300), fmv((size_t)active.size() * 6, -1e300);
-        for (size_t a = 0; a < active.size(); a++) {
-            const CUnit &s = units[active[a]];
-            const double f0 = mean[a * ncand];
-            double *d = &dtrial[a * 6];
-            for (int i = 0, c = 1; i < 6; i++) {
-                d[i] = 0;
-                if (!en[i]) continue;
-                const double h = i < 3 ? ha : hs;
-                const bool okp = std::fabs(s.acc[i] + h) <= tol[i] + 1e-9, okm = std::fabs(s.acc[i] - h) <= tol[i] + 1e-9;
-                const double fp = okp ? mean[a * ncand + c] : -1e300, fm = okm ? mean[a * ncand + c + 1] : -1e300;
-                c += 2;
-                fpv[a * 6 + i] = fp; fmv[a * 6 + i] = fm;
-                if (okp && okm) {
-                    const double den = 2.0 * f0 - fp - fm;
-                    if (den > 1e-12) { double t = 0.5 * h * (fp - fm) / den; d[i] = t > h ? h : (t < -h ? -h : t); }
-                    else { const double best = fp > fm ? fp : fm; d[i] = best > f0 ? (fp > fm ? h : -h) : 0.0; }
-                } else if (okp) d[i] = fp > f0 ? h : 0.0;
-                else if (okm) d[i] = fm > f0 ? -h : 0.0;
-                if (s.acc[i] + d[i] > tol[i]) d[i] = tol[i] - s.acc[i];
-                if (s.acc[i] + d[i] < -tol[i]) d[i] = -tol[i] - s.acc[i];
+    // ---- the compass search: state and decisions on the device (ppm_csp_kernels.h), the iterations enqueued back to back — six launches
+    // each (candidates, unit means, trial step, its score, its means, accept) and no host wait until the units come back at the end.
+    // The bands follow from the step schedule alone, so the host knows them up front.
+    if (T > 0) {
+        const int na = (int)active.size();
+        DevBuf<double> &d_acc = ref->c_acc, &d_dtrial = ref->c_dtrial, &d_fpm = ref->c_fpm, &d_delta_t = ref->c_delta_t, &d_tmean = ref->c_tmean;
+        DevBuf<int> &d_active = ref->c_active;
+        if (int rc = d_acc.ensure((size_t)na * 6)) return rc;
+        if (int rc = d_dtrial.ensure((size_t)na * 6)) return rc;
+        if (int rc = d_fpm.ensure((size_t)na * 12)) return rc;
+        if (int rc = d_delta_t.ensure((size_t)std::max(n_slots, 1) * 6)) return rc;
+        if (int rc = d_tmean.ensure((size_t)na)) return rc;
+        if (int rc = d_active.ensure((size_t)na)) return rc;
+        HIPCHK(hipMemcpyAsync(d_active.p, active.data(), (size_t)na * sizeof(int), hipMemcpyHostToDevice, cur_stream()));
+        HIPCHK(hipMemcpyAsync(d_eval.p, eval_rows.data(), eval_rows.size() * sizeof(int), hipMemcpyHostToDevice, cur_stream()));
+        uploaded_list = &eval_rows;
+        HIPCHK(hipMemsetAsync(d_delta.p, 0, (size_t)std::max(n_slots, 1) * ncand_max * 6 * sizeof(double), cur_stream()));      // slots of units without usable rows stay zero
+        HIPCHK(hipMemsetAsync(d_delta_t.p, 0, (size_t)std::max(n_slots, 1) * 6 * sizeof(double), cur_stream()));
+        int ncand = 1;
+        for (int i = 0; i < 6; i++) ncand += en[i] ? 2 : 0;
+        CspStepP SP;
+        SP.kind = kind; SP.n_active = na; SP.ncand = ncand; SP.active = d_active.p; SP.unit_slot = d_slot.p;
+        for (int i = 0; i < 6; i++) { SP.en[i] = en[i]; SP.tol[i] = tol[i]; }
+        SP.mean = ref->c_mean.p; SP.tmean = d_tmean.p; SP.acc = d_acc.p; SP.dtrial = d_dtrial.p; SP.fpm = d_fpm.p;
+        SP.delta_c = d_delta.p; SP.delta_t = d_delta_t.p; SP.Nmat = d_N.p; SP.pshift = d_p.p; SP.tl = d_tl.p; SP.nstride = 9; SP.pstride = 3;
+        HIPCHK(hipMemsetAsync(d_acc.p, 0, (size_t)na * 6 * sizeof(double), cur_stream()));
+        const unsigned gstep = (unsigned)((na + 127) / 128);
+        int nrot_c = 0;
+        for (int i = 0; i < 3; i++) nrot_c += en[i] ? 2 : 0;
+        auto eval_async = [&](const double *delta, int nc, double rband, double *means) {
+            EP.delta = delta; EP.ncand = nc; EP.S_used = prefix_of(rband); EP.rmax2 = (float)(rband * rband);
+            acct_gathers += (double)eval_rows.size() * EP.S_used * (nc > 1 ? 1 + nrot_c : 1); acct_sweeps++;
+            {
+                ProfScope ps(PPM_K_LOCAL);
+                size_t lds = ring_lds_bytes8(4, kMaxCand, nrings) + (csp_tab ? cube_tab_bytes(EP.tabR) : 0);
+                if (csp_bpc > 0 && csp_bpc < 8) lds = std::min((size_t)63 * 1024, std::max(lds, (size_t)(160 * 1024 / (csp_bpc + 1) + 1024) & ~(size_t)1023));
+                if (csp_tab) hipLaunchKernelGGL(k_csp_eval<true>, dim3((unsigned)eval_rows.size()), dim3(256), lds, cur_stream(), EP);
+                else hipLaunchKernelGGL(k_csp_eval<false>, dim3((unsigned)eval_rows.size()), dim3(256), lds, cur_stream(), EP);
             }
+            const int nm = na * nc;
+            hipLaunchKernelGGL(k_csp_unit_means, dim3((nm + 255) / 256), dim3(256), 0, cur_stream(), d_out.p, ref->c_uoff.p, na, nc, means);
+        };
+        double ha = ha0, hs = hs0;
+        SP.ha = ha; SP.hs = hs; SP.ha_next = ha; SP.hs_next = hs;
+        hipLaunchKernelGGL(k_csp_step_init, dim3(gstep), dim3(128), 0, cur_stream(), SP);
+        for (int it = 0; it < T; it++) {
+            const double rband = iter_band(ha, hs);
+            SP.ha = ha; SP.hs = hs; SP.ha_next = 0.5 * ha; SP.hs_next = 0.5 * hs;
+            eval_async(d_delta.p, ncand, rband, ref->c_mean.p);
+            hipLaunchKernelGGL(k_csp_step_trial, dim3(gstep), dim3(128), 0, cur_stream(), SP);
+            eval_async(d_delta_t.p, 1, rband, d_tmean.p);
+            hipLaunchKernelGGL(k_csp_step_accept, dim3(gstep), dim3(128), 0, cur_stream(), SP);
+            ha *= 0.5; hs *= 0.5;
         }
-        hdelta.assign((size_t)n_slots * 6, 0.0);
-        for (size_t a = 0; a < active.size(); a++) std::memcpy(&hdelta[(size_t)unit_slot[active[a]] * 6], &dtrial[a * 6], 6 * sizeof(double));
-        if (int rc = sweep(eval_rows, 1, rband, &tmean)) return rc;
-        for (size_t a = 0; a < active.size(); a++) {
-            CUnit &s = units[active[a]];
-            const double f0 = mean[a * ncand], ft = tmean[a];
-            int bi = -1, bs = 0; double fb = f0;
-            for (int i = 0; i < 6; i++) {
-                if (!en[i]) continue;
-                if (fpv[a * 6 + i] > fb) { fb = fpv[a * 6 + i]; bi = i; bs = 1; }
-                if (fmv[a * 6 + i] > fb) { fb = fmv[a * 6 + i]; bi = i; bs = -1; }
-            }
-            CUnit q;
-            if (ft > f0 && ft >= fb) { csp_apply(kind, s, &dtrial[a * 6], q); s = q; }
-            else if (bi >= 0) { double dd[6] = { 0, 0, 0, 0, 0, 0 }; dd[bi] = bs * (bi < 3 ? ha : hs); csp_apply(kind, s, dd, q); s = q; }
-        }
-        if (int rc = upload_units()) return rc;
-        ha *= 0.5; hs *= 0.5;
+        HIPCHK(hipGetLastError());
+        // the units as the search left them
+        HIPCHK(hipMemcpyAsync(hN.data(), d_N.p, hN.size() * sizeof(double), hipMemcpyDeviceToHost, cur_stream()));
+        HIPCHK(hipMemcpyAsync(hp.data(), d_p.p, hp.size() * sizeof(double), hipMemcpyDeviceToHost, cur_stream()));
+        HIPCHK(hipMemcpyAsync(htl.data(), d_tl.p, htl.size() * sizeof(double), hipMemcpyDeviceToHost, cur_stream()));
+        HIPCHK(hipStreamSynchronize(cur_stream()));
+        for (int i = 0; i < n_part; i++) { std::memcpy(parts[i].N, &hN[(size_t)9 * i], 9 * sizeof(double)); std::memcpy(parts[i].p, &hp[(size_t)3 * i], 3 * sizeof(double)); }
+        for (int i = 0; i < n_tilt; i++) std::memcpy(tls[i].tl, &htl[(size_t)4 * i], 4 * sizeof(double));
+        EP.delta = d_delta.p;
     }
     trace_.mark("searched");
     // ---- final scores of every row of the refined units at the full band; write-back
@@ -2016,6 +2027,14 @@ static int sva_align_impl(ppm_ref_t *ref, ppm_accum_t *avg, const ppm_sva_cfg *c
     const size_t CHS = (size_t)CH * (global ? Kc : 1);       // states per chunk: the global search refines Kc candidates per sub-volume
     HIPCHK(d_stats.alloc((size_t)2 * CH)); HIPCHK(d_poses.alloc((size_t)12 * CHS)); HIPCHK(d_delta.alloc(CHS * ncand * 6)); HIPCHK(d_out.alloc(CHS * ncand));
     HIPCHK(d_vmap.alloc(CHS)); HIPCHK(d_partial.alloc(CHS * kSvaParts * (2 * kMaxCand + 1)));
+    // the compass search's state on the device (ppm_csp_kernels.h: k_csp_step_*), kept in the handle like the constrained search's
+    // (allocating and freeing five more buffers per call cost 7 ms of a 57 ms call: hipFree waits for the device)
+    DevBuf<double> &d_acc = ref->c_acc, &d_dtrial = ref->c_dtrial, &d_fpm = ref->c_fpm, &d_delta_t = ref->c_delta_t, &d_tout = ref->c_tmean;
+    if (int rc = d_acc.ensure(CHS * 6)) return rc;
+    if (int rc = d_dtrial.ensure(CHS * 6)) return rc;
+    if (int rc = d_fpm.ensure(CHS * 12)) return rc;
+    if (int rc = d_delta_t.ensure(CHS * 6)) return rc;
+    if (int rc = d_tout.ensure(CHS)) return rc;
     if (global) {
         std::vector<float> gf(grid_d.begin(), grid_d.end());
         HIPCHK(d_grid.alloc(gf.size())); HIPCHK(d_gscore.alloc((size_t)CH * n_grid));
@@ -2157,14 +2176,31 @@ static int sva_align_impl(ppm_ref_t *ref, ppm_accum_t *avg, const ppm_sva_cfg *c
             HIPCHK(hipStreamSynchronize(cur_stream()));
             return 0;
         };
-        // `Tn` compass iterations of all states at once (two launches per iteration), steps halved after each
+        // `Tn` compass iterations of all states at once, steps halved after each: state and decisions on the device (k_csp_step_*), six
+        // launches per iteration enqueued back to back, the poses come back once at the end
+        auto launch_eval = [&](int ns_, int nc, int nr_, double rb, const double *delta, double *out) -> int {
+            EP.delta = delta; EP.ncand = nc; EP.nrot = nr_; EP.S_used = prefix_of(rb); EP.rmax2 = (float)(rb * rb);
+            acct_gathers += (double)ns_ * EP.S_used * (1 + nr_); acct_sweeps++;
+            ProfScope ps(PPM_K_LOCAL);
+            int bpc = nr_ == 6 ? 2 : 0;                                    // two blocks per CU for a compass sweep (see `sweep`)
+            if (const char *e = getenv("PPM_SVA_BLOCKS_PER_CU")) bpc = atoi(e);
+            size_t tab_lds = cube_tab_bytes(EP.tabR);
+            if (bpc > 0 && bpc < 8) tab_lds = std::max(tab_lds, (size_t)(160 * 1024 / (bpc + 1) + 1024) & ~(size_t)1023);
+            if (tab_lds > (size_t)64 * 1024) tab_lds = (size_t)64 * 1024;
+            if (nr_ == 0) hipLaunchKernelGGL(k_sva_eval<0>, dim3(ns_, kSvaParts), dim3(256), tab_lds, cur_stream(), EP);
+            else if (nr_ == 6) hipLaunchKernelGGL(k_sva_eval<6>, dim3(ns_, kSvaParts), dim3(256), tab_lds, cur_stream(), EP);
+            else return fail(-22, "ppm_sva_align: a sweep has 0 or 6 rotated candidates");
+            hipLaunchKernelGGL(k_sva_finish, dim3((unsigned)((ns_ * nc + 255) / 256)), dim3(256), 0, cur_stream(), EP.partial, ns_, nc, nr_, out);
+            return 0;
+        };
         auto compass = [&](std::vector<CUnit> &S_, const std::vector<int> *vm, const int *en_, const double *tol_, double &ha, double &hs, int Tn) -> int {
             const int ns_ = (int)S_.size();
             const int nrot_ = en_[0] ? 6 : 0, nsh_ = en_[3] ? 6 : 0, nc_ = 1 + nrot_ + nsh_;
-            if (nc_ == 1 || ns_ == 0) return 0;
+            if (nc_ == 1 || ns_ == 0 || Tn <= 0) return 0;
             if (int rc = upload_states(S_, vm)) return rc;
-            std::vector<double> mean, dtrial((size_t)ns_ * 6), fpv((size_t)ns_ * 6), fmv((size_t)ns_ * 6);
-            auto cand_of = [&](int i, int sign) { return i < 3 ? 1 + 2 * i + (sign < 0) : 1 + nrot_ + 2 * (i - 3) + (sign < 0); };
+            std::vector<double> hacc((size_t)ns_ * 6);
+            for (int v = 0; v < ns_; v++) std::memcpy(&hacc[(size_t)v * 6], S_[v].acc, 6 * sizeof(double));
+            HIPCHK(hipMemcpyAsync(d_acc.p, hacc.data(), hacc.size() * sizeof(double), hipMemcpyHostToDevice, cur_stream()));
             auto band_of = [&](double ha_, double hs_) {
                 if (bf < 0) return rband;
                 double d = 0;
@@ -2175,53 +2211,32 @@ static int sva_align_impl(ppm_ref_t *ref, ppm_accum_t *avg, const ppm_sva_cfg *c
                 if (rit < 4.0) rit = 4.0;
                 return rit < rband ? rit : rband;
             };
+            CspStepP SP;
+            SP.kind = PPM_CSP_PARTICLES; SP.n_active = ns_; SP.ncand = nc_; SP.active = nullptr; SP.unit_slot = nullptr;
+            for (int i = 0; i < 6; i++) { SP.en[i] = en_[i]; SP.tol[i] = tol_[i]; }
+            SP.mean = d_out.p; SP.tmean = d_tout.p; SP.acc = d_acc.p; SP.dtrial = d_dtrial.p; SP.fpm = d_fpm.p;
+            SP.delta_c = d_delta.p; SP.delta_t = d_delta_t.p; SP.Nmat = d_poses.p; SP.pshift = d_poses.p + 9; SP.tl = nullptr; SP.nstride = 12; SP.pstride = 12;
+            const unsigned gstep = (unsigned)((ns_ + 127) / 128);
+            SP.ha = ha; SP.hs = hs; SP.ha_next = ha; SP.hs_next = hs;
+            hipLaunchKernelGGL(k_csp_step_init, dim3(gstep), dim3(128), 0, cur_stream(), SP);
             for (int it = 0; it < Tn; it++) {
                 const double rb = band_of(ha, hs);
-                hdelta.assign((size_t)ns_ * nc_ * 6, 0.0);
-                for (int v = 0; v < ns_; v++) for (int i = 0; i < 6; i++) if (en_[i]) {
-                    const double h = i < 3 ? ha : hs;
-                    hdelta[((size_t)v * nc_ + cand_of(i, 1)) * 6 + i] = h; hdelta[((size_t)v * nc_ + cand_of(i, -1)) * 6 + i] = -h;
-                }
-                if (int rc = sweep(ns_, nc_, nrot_, rb)) return rc;
-                mean = hout;
-                for (int v = 0; v < ns_; v++) {
-                    const CUnit &u = S_[v];
-                    const double f0 = mean[(size_t)v * nc_];
-                    double *d = &dtrial[(size_t)v * 6];
-                    for (int i = 0; i < 6; i++) {
-                        d[i] = 0; fpv[(size_t)v * 6 + i] = fmv[(size_t)v * 6 + i] = -1e300;
-                        if (!en_[i]) continue;
-                        const double h = i < 3 ? ha : hs;
-                        const bool okp = std::fabs(u.acc[i] + h) <= tol_[i] + 1e-9, okm = std::fabs(u.acc[i] - h) <= tol_[i] + 1e-9;
-                        const double fp = okp ? mean[(size_t)v * nc_ + cand_of(i, 1)] : -1e300, fm = okm ? mean[(size_t)v * nc_ + cand_of(i, -1)] : -1e300;
-                        fpv[(size_t)v * 6 + i] = fp; fmv[(size_t)v * 6 + i] = fm;
-                        if (okp && okm) {
-                            const double den = 2.0 * f0 - fp - fm;
-                            if (den > 1e-12) { double t = 0.5 * h * (fp - fm) / den; d[i] = t > h ? h : (t < -h ? -h : t); }
-                            else { const double best = fp > fm ? fp : fm; d[i] = best > f0 ? (fp > fm ? h : -h) : 0.0; }
-                        } else if (okp) d[i] = fp > f0 ? h : 0.0;
-                        else if (okm) d[i] = fm > f0 ? -h : 0.0;
-                        if (u.acc[i] + d[i] > tol_[i]) d[i] = tol_[i] - u.acc[i];
-                        if (u.acc[i] + d[i] < -tol_[i]) d[i] = -tol_[i] - u.acc[i];
-                    }
-                }
-                hdelta = dtrial;
-                if (int rc = sweep(ns_, 1, 0, rb)) return rc;
-                for (int v = 0; v < ns_; v++) {
-                    CUnit &u = S_[v];
-                    const double f0 = mean[(size_t)v * nc_], ft = hout[v];
-                    int bi = -1, bs = 0; double fb = f0;
-                    for (int i = 0; i < 6; i++) {
-                        if (!en_[i]) continue;
-                        if (fpv[(size_t)v * 6 + i] > fb) { fb = fpv[(size_t)v * 6 + i]; bi = i; bs = 1; }
-                        if (fmv[(size_t)v * 6 + i] > fb) { fb = fmv[(size_t)v * 6 + i]; bi = i; bs = -1; }
-                    }
-                    CUnit q;
-                    if (ft > f0 && ft >= fb) { csp_apply(PPM_CSP_PARTICLES, u, &dtrial[(size_t)v * 6], q); u = q; }
-                    else if (bi >= 0) { double dd[6] = { 0, 0, 0, 0, 0, 0 }; dd[bi] = bs * (bi < 3 ? ha : hs); csp_apply(PPM_CSP_PARTICLES, u, dd, q); u = q; }
-                }
-                if (int rc = upload_states(S_, vm)) return rc;
+                SP.ha = ha; SP.hs = hs; SP.ha_next = 0.5 * ha; SP.hs_next = 0.5 * hs;
+                if (int rc = launch_eval(ns_, nc_, nrot_, rb, d_delta.p, d_out.p)) return rc;
+                hipLaunchKernelGGL(k_csp_step_trial, dim3(gstep), dim3(128), 0, cur_stream(), SP);
+                if (int rc = launch_eval(ns_, 1, 0, rb, d_delta_t.p, d_tout.p)) return rc;
+                hipLaunchKernelGGL(k_csp_step_accept, dim3(gstep), dim3(128), 0, cur_stream(), SP);
                 ha *= 0.5; hs *= 0.5;
+            }
+            HIPCHK(hipGetLastError());
+            EP.delta = d_delta.p;
+            hp.resize((size_t)12 * ns_);
+            HIPCHK(hipMemcpyAsync(hp.data(), d_poses.p, hp.size() * sizeof(double), hipMemcpyDeviceToHost, cur_stream()));
+            HIPCHK(hipMemcpyAsync(hacc.data(), d_acc.p, hacc.size() * sizeof(double), hipMemcpyDeviceToHost, cur_stream()));
+            HIPCHK(hipStreamSynchronize(cur_stream()));
+            for (int v = 0; v < ns_; v++) {
+                std::memcpy(S_[v].N, &hp[(size_t)12 * v], 9 * sizeof(double)); std::memcpy(S_[v].p, &hp[(size_t)12 * v + 9], 3 * sizeof(double));
+                std::memcpy(S_[v].acc, &hacc[(size_t)v * 6], 6 * sizeof(double));
             }
             return 0;
         };
