@@ -877,7 +877,7 @@ def sva_eval_roofline(prof, lc, nv, steps, wedges):
     fw = float(np.clip((np.asarray(wedges)[:, 1] - np.asarray(wedges)[:, 0]) / 180.0, 0, 1).mean())
     g = lc["samples_local"] * fw * nv * steps
     return gather_roofline("k_sva_eval", "sva", prof["local"]["ms"], prof["local"]["launches"], g, nv * steps * lc["n_local"], "states",
-                           "host-driven compass: %d sweeps per call, every sweep one launch over all sub-volumes (x %d parts); %.0f %% of the band lies inside the "
+                           "device-resident compass: %d sweeps per call, every sweep one launch over all sub-volumes (x %d parts), no host wait between them; %.0f %% of the band lies inside the "
                            "tilt range; bound by the gathers' path through the vector L1 (DESIGN.md 9)" % (lc["n_local"], 4, 100 * fw))
 
 
@@ -1091,6 +1091,38 @@ def csp_bench(ctx):
     def perr(x, y):
         return np.array([np.degrees(np.arccos(np.clip((np.trace(synth.euler_matrix(-u[4], -u[5], -u[6]).T @ synth.euler_matrix(-v[4], -v[5], -v[6])) - 1) / 2, -1, 1)))
                          for u, v in zip(x, y)])
+    box384 = None
+    if world == 1 and not a.no_side:
+        try:                    # the box of the reference's tomography tutorial (docs/tutorials/tomo_empiar_10164.rst:454): 100 particles x 41 tilts of 384^2
+            n3, px3, np3 = 384, 1.35, 100
+            v3, st3, r3, pa3, ti3 = synth.make_tilt_series(n3, np3, tl, pixel=px3, snr=0.1, device=dev, seed=20240701)
+            q3 = pa3.copy()
+            for i in range(len(q3)):
+                Nm = synth.euler_matrix(-q3[i, 4], -q3[i, 5], -q3[i, 6])
+                for k in range(3):
+                    Nm = Nm @ synth.rot_xyz(k, rng.normal(0, 2.0))
+                q3[i, 4:7] = -synth.angles_from_matrix(Nm)
+                q3[i, 1:4] += rng.normal(0, 1.0, 3)
+            rr3 = synth.csp_rows_from_params(r3, pa3, ti3, q3, ti3)
+            c3 = RefineCfg.make(box=n3, pixel_size=px3, mask_radius=0.32 * n3 * px3, res_high=px3 * n3 / (0.25 * n3), res_signed_cc=30.0, global_search=0)
+            ref3 = host.Reference(v3, n3 / 2, device=local)
+            ref3.csp_refine(c3, cc, st3, rr3, q3, ti3)
+            host.profile(True, True)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            o3 = ref3.csp_refine(c3, cc, st3, rr3, q3, ti3)
+            dt3 = time.perf_counter() - t1
+            pr3 = host.profile_report()
+            host.profile(False, False)
+            ref3.close()
+            box384 = {"value": round(len(r3) / dt3, 1), "unit": "projections/s", "ms_per_step": round(dt3 * 1e3, 2),
+                      "config": "%d particles x 41 tilts of 384^2 (%.1f GB resident), band r = 96 px, particle units" % (np3, len(r3) * n3 * n3 * 4 / 1e9),
+                      "device_ms_per_step": {k2: round(v["ms"], 2) for k2, v in pr3.items() if v["launches"]},
+                      "accuracy_vs_truth": {"median_deg_before": round(float(np.median(perr(q3, pa3))), 3), "median_deg_after": round(float(np.median(perr(o3[1], pa3))), 3)}}
+            del st3
+            torch.cuda.empty_cache()
+        except Exception as e:          # noqa: BLE001
+            box384 = {"error": str(e)[:300]}
     nproj = len(rows)
     blk = {"metric": "projections/sec constrained tilt-series refinement, 128^2 box", "value": round(world * nproj * a.steps / dt, 1), "unit": "projections/s",
            "particles_per_s": round(world * npart * a.steps / dt, 1), "n_gpus": world, "steps": a.steps, "ms_per_step": round(dt / a.steps * 1e3, 2),
@@ -1102,11 +1134,13 @@ def csp_bench(ctx):
            "device_busy_frac": round(sum(v["ms"] for v in prof.values()) * 1e-3 / dt, 3),
            "roofline": gather_roofline("k_csp_eval", "csp", prof["local"]["ms"], prof["local"]["launches"], lc_csp["samples_local"] * nproj * a.steps,
                                        nproj * a.steps * lc_csp["n_local"], "projections",
-                                       "host-driven compass: %d sweeps per call, every sweep one launch over the usable projections of the refined units" % lc_csp["n_local"]),
-           "note": "host-driven compass search: the device scores <= 13 candidate poses per projection and sweep (k_csp_eval, the sweep of k_local: "
-                   "bound by the vector memory path like it, DESIGN.md 4b); the rest of a step is the host's fixed-order reductions and candidate tables",
+                                       "device-resident compass: %d sweeps per call, every sweep one launch over the usable projections of the refined units, no host wait between them" % lc_csp["n_local"]),
+           "note": "compass search with its state on the device (k_csp_step_*): the device scores <= 13 candidate poses per projection and sweep (k_csp_eval, the sweep of "
+                   "k_local: bound by the vector memory path like it, DESIGN.md 4b); the rest of a step is the host's row / unit tables before and the write-back after",
            "accuracy_vs_truth": {"median_deg_before": round(float(np.median(perr(p2, parts))), 3), "median_deg_after": round(float(np.median(perr(out[1], parts))), 3),
                                  "median_shift_px_after": round(float(np.median(np.linalg.norm(out[1][:, 1:4] - parts[:, 1:4], axis=1))), 3)}}
+    if box384:
+        blk["box384"] = box384
     if two:
         blk["two_series_in_flight"] = two
     if pipe:

@@ -163,3 +163,36 @@ def test_csp_refine_at_128_box_and_41_tilts_matches_oracle_on_eight_units():
     sub = CspCfg.make(CSP_PARTICLES, tol_angle=(8, 8, 8), tol_shift=4.0, first=10, last=19)
     r3, q3, _ = g.csp_refine(cfg, sub, stack, rows2, p2, tilts)
     assert np.array_equal(q3[10:20], q1[10:20]) and np.array_equal(q3[:10], p2[:10]) and np.array_equal(q3[20:], p2[20:])
+
+
+def test_csp_refine_at_384_box_matches_oracle():
+    """The box of the reference's own tomography tutorial (constrained refinement at box 384, docs/tutorials/tomo_empiar_10164.rst:454):
+    384 = 2^7 x 3 takes the generic pre-processing kernel (mixed-radix transforms in LDS) and tap addresses by arithmetic (the LDS address
+    tables of a 96-pixel band do not fit next to the ring sums).  Two particle units x 41 tilts against the oracle, band 0.25 N."""
+    from oracle import oracle as O
+    from pyp_amd import host
+    from test_csp_cpu import _particle_angle_err, _perturb_particles
+    n, px = 384, 1.35
+    tl = np.linspace(-60, 60, 41)
+    cfg = RefineCfg.make(box=n, pixel_size=px, mask_radius=0.32 * n * px, res_high=px * n / (0.25 * n), res_signed_cc=30.0, global_search=0)
+    vol, stack, rows, parts, tilts = synth.make_tilt_series(n, 2, tl, pixel=px, snr=0.1, device="cuda")
+    imgs = stack.cpu().numpy()
+    p2 = _perturb_particles(parts)
+    rows2 = synth.csp_rows_from_params(rows, parts, tilts, p2, tilts)
+    cc = CspCfg.make(CSP_PARTICLES, tol_angle=(8, 8, 8), tol_shift=4.0)
+    wr, wp, wt, _ = O.csp_refine(O.Reference(vol, n / 2), cfg, cc, imgs, rows2, p2, tilts)
+    g = host.Reference(vol, n / 2)
+    gr, gp, gt = g.csp_refine(cfg, cc, imgs, rows2, p2, tilts)
+    assert _particle_angle_err(wp, gp).max() < 0.1 and np.abs(wp[:, 1:4] - gp[:, 1:4]).max() < 0.5
+    assert synth.angular_error_deg(wr, gr).max() < 0.1 and synth.shift_error_px(wr, gr, px).max() < 0.5
+    assert np.abs(wr[:, 14] - gr[:, 14]).max() < 0.05 and np.array_equal(gt, tilts)
+    assert _particle_angle_err(gp, parts).mean() < 0.5 * _particle_angle_err(p2, parts).mean()
+    # tilt units at the same box
+    ct = CspCfg.make(2, tol_angle=(2, 2, 0), tol_shift=3.0)
+    t2 = tilts.copy()
+    t2[:, 2:4] += np.random.default_rng(3).normal(0, 1.0, (len(tilts), 2))
+    rows3 = synth.csp_rows_from_params(rows, parts, tilts, parts, t2)
+    wr, wp, wt, _ = O.csp_refine(O.Reference(vol, n / 2), cfg, ct, imgs, rows3, parts, t2)
+    gr, gp, gt = g.csp_refine(cfg, ct, imgs, rows3, parts, t2)
+    assert np.abs(wt[:, 4:6] - gt[:, 4:6]).max() < 0.1 and np.abs(wt[:, 2:4] - gt[:, 2:4]).max() < 0.5
+    assert synth.angular_error_deg(wr, gr).max() < 0.1 and synth.shift_error_px(wr, gr, px).max() < 0.5
