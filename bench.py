@@ -812,6 +812,17 @@ def reconstruct_bench(ctx):
                               "exceeds_peak": bool(model_gbps > PEAK_HBM_GBPS),
                               "note": "SURVEY §8(d) contract figure (what a scatter into HBM would move: S x 8 taps x 12 B x 2); the bricks are "
                                       "accumulated in LDS, so this is not HBM traffic"}}
+    if prof.get("insert", {}).get("launches"):
+        # what k_insert_bricks really runs on: LDS integer atomics.  Every in-band sample adds its 8 trilinear taps x (re, im, weight) = 24
+        # 64-bit adds into the brick in LDS; a 64-lane ds_add_u64 occupies the LDS for ~7.7 cycles (scripts/micro/lds_atomic_bench)
+        ms_i = prof["insert"]["ms"] / (M * a.steps) * 1e-3                  # seconds per particle in the kernel
+        lane_atomics = 24.0 * S
+        peak_at = 256 * 64.0 / 7.7 * 2.4e9
+        roof["lds_atomic"] = {"kernel": "k_insert_bricks", "bound": "lds_atomic", "achieved": round(lane_atomics / ms_i / 1e9, 1), "peak": round(peak_at / 1e9, 1),
+                              "unit": "G lane-atomics/s", "frac": round(lane_atomics / ms_i / peak_at, 4), "us_per_particle": round(ms_i * 1e6, 3),
+                              "model": "24 ds_add_u64 per in-band sample (8 taps x re, im, weight), S = %d samples per particle" % S,
+                              "peak_note": "derived: one 64-lane ds_add_u64 per 7.7 cycles and CU (measured, scripts/micro/lds_atomic_bench) x 256 CUs x 2.4 GHz; the "
+                                           "kernel's vector instructions (568 lane-instructions per sample) run beside them, so neither pipe is the whole bound"}
     acc.set_counts(counts[0], counts[1])
     h1, h2, fl, stats = acc.finalize(FinalCfg(molecular_mass_kda=500.0, inner_radius=0.0, outer_radius=0.45 * N * px, mask_falloff=0.0))
     acc.close()

@@ -78,46 +78,41 @@ __global__ void __launch_bounds__(256) k_bank4(Bank4P P) {
 __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+s"(v)); return v; }
 
 // ---------------------------------------------------------------------------------- the column pass of one thread
-// y[n] = x[n] + x[n + L] (H = 0) or x[n] - x[n + L] (H = 1; the factor w^n follows in a pass of its own), x = W conj(P) (E = 0) or
-// W P (E = 1).  `bank` is the wave-uniform base of the slice bank, voff this lane's byte offset of (slice, row 0, kx) — scalar base +
-// 32-bit lane offset + immediate, no 64-bit address arithmetic per row; wl points at this lane's column of the W table in LDS.
-// Bank rows travel D rows ahead of their use (one wave per SIMD: nothing else hides the L2 / Infinity-Cache latency), LDS rows DW
-// ahead; the scheduling barriers keep the compiler from sinking the loads back to their uses.
-constexpr int gfft_depth(int L) { return L < 16 ? L : 16; }       // bank rows in flight per lane
+// Every (orientation, parity) wave of a block needs the WHOLE bank slice for its columns.  Loaded by each wave for itself that is four
+// times the slice through the CU's vector L1, whose 64 B per clock then set the pace of the pass (5 800 of a slice's 22 000 cycles,
+// PPM_GFFT_STAMPS).  So the slice is STAGED: every wave fetches a quarter of its rows from the bank (a whole pass ahead, into
+// registers), writes them into LDS — the region of the image T, which is idle between the row pass of one slice and the stores of
+// the next — and after a barrier all four read their rows from there at the LDS's 256 B per clock.
+constexpr int gfft_depth(int L) { return L / 4; }       // bank rows a wave stages per slice and lane
 
-// bank row n of a lane: lane offset + (n % 4) rows as the instruction's immediate + 4 (n / 4) rows in a scalar register that steps once
-// per four rows (left to itself the compiler keeps one VGPR offset per row, parks the 64 of them in AGPRs and fetches one per load)
-template <int L, int N>
-__device__ __forceinline__ fr::v4f gfft_bank_row(__amdgpu_buffer_rsrc_t bank, unsigned voff, const int (&soff)[L / 4 + 1]) {
-    return __builtin_amdgcn_raw_buffer_load_b128(bank, (int)(voff + (N % 4) * L * 16), soff[N / 4], 0);
-}
-template <int L>
-__device__ __forceinline__ void gfft_row_offsets(int (&soff)[L / 4 + 1]) {
-    soff[0] = opaque(0);
-    fr::static_for<1, L / 4 + 1>([&](auto ic) { constexpr int i = decltype(ic)::value; soff[i] = soff[i - 1] + 4 * L * 16; });
-}
-// the first rows of a slice, requested a whole pass ahead of their use
+// bank row N of the rows a lane stages: lane offset + (N % 4) rows as the instruction's immediate + 4 (N / 4) rows in a scalar register
+// (left to itself the compiler keeps one VGPR offset per row and parks them in AGPRs)
 template <int L>
 __device__ __forceinline__ void gfft_prefetch(fr::v4f (&pb)[gfft_depth(L)], __amdgpu_buffer_rsrc_t bank, unsigned voff) {
-    int soff[L / 4 + 1];
-    gfft_row_offsets<L>(soff);
-    fr::static_for<0, gfft_depth(L)>([&](auto ic) { constexpr int i = decltype(ic)::value; pb[i] = gfft_bank_row<L, i>(bank, voff, soff); });
+    constexpr int D = gfft_depth(L);
+    int soff[D / 4 + 1];
+    soff[0] = opaque(0);
+    fr::static_for<1, D / 4 + 1>([&](auto ic) { constexpr int i = decltype(ic)::value; soff[i] = soff[i - 1] + 4 * L * 16; });
+    fr::static_for<0, D>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        pb[i] = __builtin_amdgcn_raw_buffer_load_b128(bank, (int)(voff + (i % 4) * L * 16), soff[i / 4], 0);
+    });
 }
 
+// y[n] = x[n] + x[n + L] (H = 0) or x[n] - x[n + L] (H = 1; the factor w^n follows in a pass of its own), x = W conj(P) (E = 0) or
+// W P (E = 1).  pl / wl point at this lane's column of the staged slice / of the W table, both in LDS, rows L float4 apart; the reads
+// travel DW rows ahead of their use and the scheduling barriers keep the compiler from sinking them back.
 template <int L, int E, int H>
-__device__ __forceinline__ void gfft_col_products(fr::v2f (&y)[L], fr::v4f (&pb)[gfft_depth(L)], __amdgpu_buffer_rsrc_t bank, unsigned voff, const float4 *wl) {
+__device__ __forceinline__ void gfft_col_products(fr::v2f (&y)[L], const float4 *pl, const float4 *wl) {
     using namespace fr;
-    constexpr int D = gfft_depth(L), DW = L < 4 ? L : 4;
-    float4 wb[DW];
-    int soff[L / 4 + 1];
-    gfft_row_offsets<L>(soff);
-    static_for<0, DW>([&](auto ic) { constexpr int i = decltype(ic)::value; wb[i] = wl[i * L]; });
+    constexpr int DW = L < 6 ? L : 6;
+    float4 pb[DW], wb[DW];
+    static_for<0, DW>([&](auto ic) { constexpr int i = decltype(ic)::value; pb[i] = pl[i * L]; wb[i] = wl[i * L]; });
     static_for<0, L / 2>([&](auto nc) {
         constexpr int n = 2 * decltype(nc)::value;
-        const v4f p0 = pb[n % D], p1 = pb[(n + 1) % D]; const float4 w0 = wb[n % DW], w1 = wb[(n + 1) % DW];
+        const float4 p0 = pb[n % DW], p1 = pb[(n + 1) % DW], w0 = wb[n % DW], w1 = wb[(n + 1) % DW];
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (n + D < L) { pb[n % D] = gfft_bank_row<L, n + D>(bank, voff, soff); pb[(n + 1) % D] = gfft_bank_row<L, n + 1 + D>(bank, voff, soff); }
-        if constexpr (n + DW < L) { wb[n % DW] = wl[(n + DW) * L]; wb[(n + 1) % DW] = wl[(n + 1 + DW) * L]; }
+        if constexpr (n + DW < L) { pb[n % DW] = pl[(n + DW) * L]; wb[n % DW] = wl[(n + DW) * L]; pb[(n + 1) % DW] = pl[(n + 1 + DW) * L]; wb[(n + 1) % DW] = wl[(n + 1 + DW) * L]; }
         prod2x2<E, H>(y[n], y[n + 1], (v2f){ w0.x, w0.y }, (v2f){ p0.x, p0.y }, (v2f){ w0.z, w0.w }, (v2f){ p0.z, p0.w },
                       (v2f){ w1.x, w1.y }, (v2f){ p1.x, p1.y }, (v2f){ w1.z, w1.w }, (v2f){ p1.z, p1.w });
         __builtin_amdgcn_sched_barrier(0);
@@ -219,10 +214,15 @@ __global__ void __launch_bounds__(256) k_gfft(GfftP P) {
     // window rows of this wave's outputs (column pass, not CHUNKED): bit f of mask_pos for f = 0 .. fmax, bit j - 1 of mask_neg for j = 1 .. jmax
     const int fmax_ = min((RSy - ch) >> 1, L / 2 - 1), jmax_ = min((RSy + ch) >> 1, L / 2);
     const unsigned mask_pos = fmax_ >= 31 ? 0xffffffffu : ((1u << (fmax_ + 1)) - 1u), mask_neg = jmax_ >= 32 ? 0xffffffffu : ((1u << jmax_) - 1u);
-    // bank rows 0 .. D-1 of the slice the next column pass works on, requested at the end of the current one
-    v4f pb[gfft_depth(L)];
+    // this wave's quarter of the bank rows of the slice(s) the next column pass works on (rows wave L/4 .. of every lane's slice),
+    // requested during the current pass; `stage` is where the four quarters meet (LDS, the region of T)
+    constexpr int DQ = gfft_depth(L);
+    v4f pb[DQ];
     unsigned pf_voff = 0xffffffffu;
-    auto col_voff = [&](int sl) { return ((unsigned)(sl < 0 ? 0 : sl) * (unsigned)(L * L) + (unsigned)ckx) * 16u; };
+    auto col_voff = [&](int sl) { return (((unsigned)(sl < 0 ? 0 : sl) * (unsigned)L + (unsigned)(wave * DQ)) * (unsigned)L + (unsigned)ckx) * 16u; };
+    float4 *stage = (float4 *)T;                                     // [G][L][L]
+    float4 *st_w = stage + (size_t)(cg * L + wave * DQ) * L + ckx;   // where this lane puts its rows
+    const float4 *st_r = stage + (size_t)cg * L * L + ckx;           // this lane's column of its slice
 
 #ifdef PPM_GFFT_STAMPS
     unsigned long long st_acc[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, st_t = __builtin_amdgcn_s_memtime();
@@ -287,17 +287,30 @@ __global__ void __launch_bounds__(256) k_gfft(GfftP P) {
         const int c_sl = slice_of(cg, c_eh, c_hit), r_sl = slice_of(rg, r_eh, r_hit);
 
         for (int c = 0; c < P.nchunk; c++) {
-            GF_STAMP(7);
             const int c0 = c * RC;                                   // first T row (slot) of this chunk
             // ================= column pass
-            if (half || ce == 0) {
-                v2f y[L];
+            const bool col_on = half || ce == 0;
+            v2f y[L];
+            {   // the slice, staged: this wave's rows go to LDS (T is idle: the row pass of the last slice has finished)
                 const unsigned voff = col_voff(c_sl);
                 if (pf_voff != voff) gfft_prefetch<L>(pb, bank, voff);          // first pass, after the top-K step, or a lane whose slice changed
-                if (ch == 0) { if (ce == 0) gfft_col_products<L, 0, 0>(y, pb, bank, voff, wl); else gfft_col_products<L, 1, 0>(y, pb, bank, voff, wl); }
-                else {
-                    if (ce == 0) gfft_col_products<L, 0, 1>(y, pb, bank, voff, wl); else gfft_col_products<L, 1, 1>(y, pb, bank, voff, wl);
-                    GF_STAMP(0);
+                static_for<0, DQ>([&](auto ic) { constexpr int i = decltype(ic)::value; st_w[i * L] = make_float4(pb[i].x, pb[i].y, pb[i].z, pb[i].w); });
+            }
+            lds_barrier();
+            GF_STAMP(7);
+            if (col_on) {
+                if (ch == 0) { if (ce == 0) gfft_col_products<L, 0, 0>(y, st_r, wl); else gfft_col_products<L, 1, 0>(y, st_r, wl); }
+                else { if (ce == 0) gfft_col_products<L, 0, 1>(y, st_r, wl); else gfft_col_products<L, 1, 1>(y, st_r, wl); }
+            }
+            GF_STAMP(0);
+            lds_barrier();                                           // every wave has read the staged slice: T may be written again
+            {   // the next column pass: the same slice again (next row chunk) or the next slices of the grid
+                const int nsl = (c + 1 < P.nchunk) ? c_sl : (it + 1 < npass0 ? min((it + 1) * G + cg, nslices - 1) : c_sl);
+                pf_voff = col_voff(nsl);
+                gfft_prefetch<L>(pb, bank, pf_voff);
+            }
+            if (col_on) {
+                if (ch != 0) {
                     // the decimation twiddles w^n of the odd rows; table entries two statements ahead
                     v4f wq[3][2];
                     auto fetch = [&](auto jc) { constexpr int j = decltype(jc)::value; wq[j % 3][0] = *(const v4f *)(twl + 8 * j); wq[j % 3][1] = *(const v4f *)(twl + 8 * j + 4); };
@@ -312,11 +325,6 @@ __global__ void __launch_bounds__(256) k_gfft(GfftP P) {
                     });
                 }
                 GF_STAMP(6);
-                {   // the next column pass: the same slice again (next row chunk) or the next slices of the grid
-                    const int nsl = (c + 1 < P.nchunk) ? c_sl : (it + 1 < npass0 ? min((it + 1) * G + cg, nslices - 1) : c_sl);
-                    pf_voff = col_voff(nsl);
-                    gfft_prefetch<L>(pb, bank, pf_voff);
-                }
                 fft_inreg<L>(y, twb);
                 GF_STAMP(1);
                 // output f of the L-point transform is row sy = 2 f + h (mod Ns) of the image: rows 0 .. RSy sit in slots 0 .. RSy,

@@ -429,7 +429,7 @@ static bool gfft_plan(const Geom &gm, GfftPlan &pl) {
     if (RC > 2 * L) RC = 2 * L;
     pl.RC = RC; pl.nchunk = (NR + RC - 1) / RC;
     pl.RC = (NR + pl.nchunk - 1) / pl.nchunk;        // even chunks
-    pl.t_bytes = (size_t)pl.RC * row;
+    pl.t_bytes = std::max((size_t)pl.RC * row, (size_t)G * L * L * sizeof(float4));        // T doubles as the staging area of the bank slice(s) of a pass
     const size_t topk = (size_t)gm.n_orient * sizeof(float);
     pl.topk_lds = 0;
     if (topk <= pl.t_bytes) pl.topk_lds = 1;
