@@ -211,7 +211,7 @@ struct ppm_ref {
     // (GBs: allocating and freeing them on every call cost ~20 ms of a 120 ms call)
     DevBuf<float2> s_f, s_g, s_F; DevBuf<float> s_vols;
     // the band's sample list (built and sorted on the host: ~25 ms at 192^3 / 452 k samples) is kept while the band-pass settings stay
-    struct { bool valid = false; float key[5] = { 0, 0, 0, 0, 0 }; int S = 0; std::vector<int> shell_off; DevBuf<uint32_t> samples; DevBuf<float> bandw; DevBuf<float2> Fw; bool fw_valid = false; float wkey[4] = { 0, 0, 0, 0 }; } s_plan;    // Fw: the window's transform at the samples
+    struct { bool valid = false; float key[5] = { 0, 0, 0, 0, 0 }; int S = 0; std::vector<int> shell_off; DevBuf<uint32_t> samples, pos; DevBuf<float> bandw; DevBuf<float2> Fw; bool fw_valid = false; float wkey[4] = { 0, 0, 0, 0 }; } s_plan;    // Fw: the window's transform at the samples
     DevBuf<float2> band, Il, Wp, bank, twN;
     DevBuf<float2> spill;            // k_prep outside the scratch-free path: the half spectrum between the row and the column phase, [n][N][W]
     DevBuf<float4> rowtw;            // k_global's row-pair twiddles for this reference's current search grid
@@ -676,7 +676,7 @@ void ppm_reference_destroy(ppm_ref_t *r) {
     if (r->cube) (void)hipFree(r->cube);
     r->rows_in.release(); r->rows_out.release(); r->dir_theta.release(); r->dir_phi.release();
     r->images.release(); r->wring.release(); r->cw.release(); r->C2.release(); r->nP.release(); r->nI.release();
-    r->s_f.release(); r->s_g.release(); r->s_F.release(); r->s_vols.release(); r->s_plan.samples.release(); r->s_plan.bandw.release(); r->s_plan.Fw.release();
+    r->s_f.release(); r->s_g.release(); r->s_F.release(); r->s_vols.release(); r->s_plan.samples.release(); r->s_plan.pos.release(); r->s_plan.bandw.release(); r->s_plan.Fw.release();
     r->c_Il.release(); r->c_band.release(); r->c_cw.release(); r->c_img.release(); r->c_wring.release(); r->c_rows.release(); r->c_N.release(); r->c_p.release(); r->c_tl.release();
     r->c_delta.release(); r->c_s0.release(); r->c_g0.release(); r->c_out.release(); r->c_eval.release(); r->c_rp.release(); r->c_rt.release(); r->c_slot.release(); r->c_states.release(); r->c_uoff.release(); r->c_mean.release(); r->c_active.release(); r->c_tmean.release(); r->c_acc.release(); r->c_dtrial.release(); r->c_fpm.release(); r->c_delta_t.release(); r->cc.release(); r->mats.release(); r->ddef.release();
     r->band.release(); r->spill.release(); r->Il.release(); r->Wp.release(); r->bank.release(); r->twN.release(); r->rowtw.release(); r->sh.release(); r->samples.release();
@@ -2009,6 +2009,18 @@ static int sva_align_impl(ppm_ref_t *ref, ppm_accum_t *avg, const ppm_sva_cfg *c
         if (int rc = ref->s_plan.bandw.ensure(S)) return rc;
         HIPCHK(hipMemcpyAsync(ref->s_plan.samples.p, samples.data(), (size_t)S * sizeof(uint32_t), hipMemcpyHostToDevice, cur_stream()));
         HIPCHK(hipMemcpyAsync(ref->s_plan.bandw.p, bandw.data(), (size_t)S * sizeof(float), hipMemcpyHostToDevice, cur_stream()));
+        {   // where a coefficient (kx, kyi, kzi) of the pruned transform sits in the sample list (k_sva_yz16's z pass emits the samples itself)
+            const int KYp = std::min(N, 2 * R + 1);
+            std::vector<unsigned> pos((size_t)KX * KYp * KYp, 0x7fffffffu);
+            for (int i = 0; i < S; i++) {
+                int kx, ky, kz; sva_unpack(samples[i], kx, ky, kz);
+                if (kx >= KX) continue;
+                const int kyi = ky >= 0 ? ky : ky + KYp, kzi = kz >= 0 ? kz : kz + KYp;
+                pos[((size_t)kx * KYp + kyi) * KYp + kzi] = (unsigned)i | (((kx + ky + kz) & 1) ? 0x80000000u : 0u);
+            }
+            if (int rc = ref->s_plan.pos.ensure(pos.size())) return rc;
+            HIPCHK(hipMemcpyAsync(ref->s_plan.pos.p, pos.data(), pos.size() * sizeof(unsigned), hipMemcpyHostToDevice, cur_stream()));
+        }
         HIPCHK(hipStreamSynchronize(cur_stream()));        // the host vectors go out of use here
         std::memcpy(ref->s_plan.key, plan_key, sizeof(plan_key)); ref->s_plan.S = S; ref->s_plan.shell_off = shell_off; ref->s_plan.valid = true;
     }
@@ -2019,6 +2031,7 @@ static int sva_align_impl(ppm_ref_t *ref, ppm_accum_t *avg, const ppm_sva_cfg *c
     // box sizes that are multiples of 16 take the two-step transforms (k_sva_x16 / k_sva_yz16): a second work array B[kx][kyi][z]
     const bool fast16 = N % 16 == 0 && getenv("PPM_SVA_GENERIC_FFT") == nullptr;
     const int KY = std::min(N, 2 * R + 1);
+    const bool sva_fold = !(getenv("PPM_SVA_FOLD") && atoi(getenv("PPM_SVA_FOLD")) == 0);      // 0: the z pass writes B back and k_sva_gather16 picks the samples (A/B, tests)
     DevTmp<double> d_spart;                              // per-block partial sums of the two-step x pass
     if (fast16) {
         if (int rc = ref->s_g.ensure((size_t)NB * KX * KY * N)) return rc;
@@ -2109,10 +2122,16 @@ static int sva_align_impl(ppm_ref_t *ref, ppm_accum_t *avg, const ppm_sva_cfg *c
                         hipLaunchKernelGGL(k_sva_x16, dim3((unsigned)(X.nlines / L16)), dim3(256), lds, cur_stream(), X);
                         if (mode == 1) hipLaunchKernelGGL(k_sva_stats_sum, dim3(mv), dim3(64), 0, cur_stream(), stats_, (int)(NN2 / L16), (double *)gstats);
                         SvaYZ16P Y; Y.A = d_f.p; Y.B = ref->s_g.p; Y.tw = X.tw; Y.n = N; Y.L = L16; Y.KX = KX; Y.KY = KY; Y.R = R; Y.in_place = 0; Y.nlines = 0;
+                        Y.pos = nullptr; Y.F = nullptr; Y.S = S; Y.stats = nullptr; Y.Fw = nullptr;
                         hipLaunchKernelGGL(k_sva_yz16, dim3((unsigned)((long)mv * KX * (N / L16))), dim3(256), lds, cur_stream(), Y);
                         Y.in_place = 1; Y.nlines = (long)mv * KX * KY;
-                        hipLaunchKernelGGL(k_sva_yz16, dim3((unsigned)((Y.nlines + L16 - 1) / L16)), dim3(256), lds, cur_stream(), Y);
-                        hipLaunchKernelGGL(k_sva_gather16, dim3((unsigned)((S + 255) / 256), mv), dim3(256), 0, cur_stream(), ref->s_g.p, d_samples.p, S, N, KX, KY, F_, gstats, Fw_);
+                        if (sva_fold) {         // the z pass emits the band's samples itself
+                            Y.pos = ref->s_plan.pos.p; Y.F = F_; Y.stats = gstats; Y.Fw = Fw_;
+                            hipLaunchKernelGGL(k_sva_yz16, dim3((unsigned)((Y.nlines + L16 - 1) / L16)), dim3(256), lds, cur_stream(), Y);
+                        } else {
+                            hipLaunchKernelGGL(k_sva_yz16, dim3((unsigned)((Y.nlines + L16 - 1) / L16)), dim3(256), lds, cur_stream(), Y);
+                            hipLaunchKernelGGL(k_sva_gather16, dim3((unsigned)((S + 255) / 256), mv), dim3(256), 0, cur_stream(), ref->s_g.p, d_samples.p, S, N, KX, KY, F_, gstats, Fw_);
+                        }
                     };
                     const float wkey[4] = { W.w[0], W.w[1], W.w[2], W.sigma };
                     if (!ref->s_plan.fw_valid || std::memcmp(wkey, ref->s_plan.wkey, sizeof(wkey)) != 0) {     // the window's own transform, once per window
@@ -2363,6 +2382,7 @@ static int sva_insert_device(ppm_accum_t *a, const ppm_sva_cfg *cfg, const float
                 hipLaunchKernelGGL(k_sva_x16, dim3((unsigned)(X.nlines / L16)), dim3(256), lds, cur_stream(), X);
                 hipLaunchKernelGGL(k_sva_stats_sum, dim3(m), dim3(64), 0, cur_stream(), d_spart.p, (int)(NN2 / L16), d_stats.p);
                 SvaYZ16P Y; Y.A = a->s_f.p; Y.B = a->s_g.p; Y.tw = X.tw; Y.n = N; Y.L = L16; Y.KX = KX; Y.KY = KY; Y.R = N / 2; Y.in_place = 0; Y.nlines = 0;
+                Y.pos = nullptr; Y.F = nullptr; Y.S = 0; Y.stats = nullptr; Y.Fw = nullptr;
                 hipLaunchKernelGGL(k_sva_yz16, dim3((unsigned)((long)m * KX * (N / L16))), dim3(256), lds, cur_stream(), Y);
                 Y.in_place = 1; Y.nlines = (long)m * KX * KY;
                 hipLaunchKernelGGL(k_sva_yz16, dim3((unsigned)((Y.nlines + L16 - 1) / L16)), dim3(256), lds, cur_stream(), Y);

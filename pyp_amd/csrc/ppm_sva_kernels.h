@@ -253,7 +253,11 @@ __global__ void __launch_bounds__(64) k_sva_stats_sum(const double *__restrict__
 }
 
 // y pass: block = L lines z0 .. z0 + L - 1 of one (sub-volume, kx); z pass (in_place): block = L consecutive lines of B
-struct SvaYZ16P { const float2 *A; float2 *B; const float2 *tw; int n, L, KX, KY, R, in_place; long nlines; };
+// z pass with `pos` set (round 5): the band's samples leave the pass directly — pos[(kx KY + kyi) KY + kzi] is the sample's place in the
+// list (bit 31: the sign (-1)^(kx+ky+kz) of the origin shift; 0x7fffffff: not in the band), F the sub-volumes' sample arrays — instead of
+// going back into B for k_sva_gather16 to pick them out (33 MB of scattered reads per 192^3 sub-volume)
+struct SvaYZ16P { const float2 *A; float2 *B; const float2 *tw; int n, L, KX, KY, R, in_place; long nlines;
+                  const unsigned *pos; float2 *F; int S; const double *stats; const float2 *Fw; };
 
 __global__ void __launch_bounds__(256) k_sva_yz16(SvaYZ16P P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -278,7 +282,27 @@ __global__ void __launch_bounds__(256) k_sva_yz16(SvaYZ16P P) {
             }
         }
         __syncthreads();
-        fft16m_any<false>(buf, nl, n, LS, tw_s, tid, need, [&](int line, int k, float2 val) { base[(long)line * n + k] = val; });
+        if (P.pos) {
+            const long per = (long)KX * KY;
+            const double n3 = (double)n * n * n;
+            fft16m_any<false>(buf, nl, n, LS, tw_s, tid, need, [&](int line, int k, float2 val) {
+                const long gl = l0 + line, v = gl / per, r = gl - v * per;
+                const int kzi = (!prune || k <= R) ? k : k - n + KY;
+                const unsigned u = P.pos[r * KY + kzi];
+                if (u == 0x7fffffffu) return;
+                const unsigned i = u & 0x7fffffffu;
+                const float sg = (u >> 31) ? -1.f : 1.f;
+                float2 o = make_float2(val.x * sg, val.y * sg);
+                if (P.stats) {
+                    const double mu = P.stats[2 * v] / n3, var = P.stats[2 * v + 1] / n3 - mu * mu, sd = var > 0 ? sqrt(var) : 1.0;
+                    const float fmu = (float)mu, finv = (float)(1.0 / sd);
+                    const float2 w = P.Fw[i];
+                    o = make_float2((o.x - fmu * w.x) * finv, (o.y - fmu * w.y) * finv);
+                }
+                P.F[(size_t)v * P.S + i] = o;
+            });
+        } else
+            fft16m_any<false>(buf, nl, n, LS, tw_s, tid, need, [&](int line, int k, float2 val) { base[(long)line * n + k] = val; });
     } else {
         const int zblocks = n / P.L;
         const int zb = blockIdx.x % zblocks, kx = (blockIdx.x / zblocks) % KX;

@@ -232,6 +232,11 @@ def test_gpu_two_step_transforms_equal_the_staged_ones(n, monkeypatch):
         monkeypatch.delenv("PPM_SVA_GENERIC_FFT", raising=False)
         assert np.abs(fsc - ssc).max() < 2e-5, (n, kw)
         assert synth.pose_angle_error(fast, slow).max() < 0.02 and np.abs(fast[:, 9:] - slow[:, 9:]).max() < 0.02, (n, kw)
+        # the z pass emits the band's samples itself (round 5); PPM_SVA_FOLD=0 writes the array back and lets k_sva_gather16 pick them: the same numbers
+        monkeypatch.setenv("PPM_SVA_FOLD", "0")
+        two, tsc = g.sva_align(c, vols.numpy(), wedges, start)
+        monkeypatch.delenv("PPM_SVA_FOLD", raising=False)
+        assert np.array_equal(two, fast) and np.array_equal(tsc, fsc), (n, kw)
         g.close()
 
 
