@@ -46,6 +46,7 @@ static int fft_size_ok(int n) {
     while (n % 2 == 0) n /= 2;
     while (n % 3 == 0) n /= 3;
     while (n % 5 == 0) n /= 5;
+    while (n % 7 == 0) n /= 7;
     return n == 1;
 }
 
@@ -58,6 +59,7 @@ static fplan_t *fft_plan(int n) {
     while (m % 2 == 0) { p->fac[p->nfac++] = 2; m /= 2; }
     while (m % 3 == 0) { p->fac[p->nfac++] = 3; m /= 3; }
     while (m % 5 == 0) { p->fac[p->nfac++] = 5; m /= 5; }
+    while (m % 7 == 0) { p->fac[p->nfac++] = 7; m /= 7; }
     p->c = (double *)malloc(sizeof(double) * n); p->s = (double *)malloc(sizeof(double) * n);
     for (int k = 0; k < n; k++) { p->c[k] = cos(2.0 * ORC_PI * k / n); p->s[k] = sin(2.0 * ORC_PI * k / n); }
     /* position of input sample i: P_m(i) = (i mod r_m) L_{m-1} + P_{m-1}(i div r_m) */
@@ -87,7 +89,7 @@ static void fft1d(cpx *x, int n, int stride, int inverse) {
     for (int st = 0; st < p->nfac; st++) {
         const int r = p->fac[st], L = Lp * r, tws = n / L, rs = n / r;
         for (int blk = 0; blk < n; blk += L) for (int j = 0; j < Lp; j++) {
-            double xr[5], xi[5];
+            double xr[7], xi[7];
             for (int q = 0; q < r; q++) {
                 double vr = br[blk + q * Lp + j], vi = bi[blk + q * Lp + j];
                 int t = q * j * tws;                         /* < n */

@@ -76,7 +76,7 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
-// FFT plan of one length n = prod fac[] (factors 4, 2, 3, 5): tw[k] = (cos 2 pi k/n, sin 2 pi k/n), k < n;
+// FFT plan of one length n = prod fac[] (factors 4, 2, 3, 5, 7): tw[k] = (cos 2 pi k/n, sin 2 pi k/n), k < n;
 // perm[i] = LDS position of input sample i (digit-reversed staging), both in global memory.
 struct FftPlan { int n, nfac; int fac[12]; const float2 *tw; const unsigned short *perm; };
 
@@ -104,9 +104,9 @@ __device__ inline void lds_fft(float2 *buf, const FftPlan &pl, int nlines, int l
         for (int i = tid; i < nlines * m; i += nthr) {
             const int line = fast_div(i, m, inv_m), t = i - line * m, blk = fast_div(t, Lp, inv_Lp), j = t - blk * Lp;
             float2 *p = buf + line * lstride + blk * L + j;
-            float2 x[5];
+            float2 x[7];
 #pragma unroll
-            for (int q = 0; q < 5; q++) {
+            for (int q = 0; q < 7; q++) {
                 if (q < r) {
                     float2 v = p[q * Lp];
                     if (q > 0) { float2 w = tw[q * j * tws]; w.y *= sgn; v = cmul(v, w); }
@@ -126,7 +126,7 @@ __device__ inline void lds_fft(float2 *buf, const FftPlan &pl, int nlines, int l
                 const float c = 0.8660254037844386f * sgn;           // (sgn i sqrt(3)/2) d
                 float2 jd = make_float2(-c * d.y, c * d.x);
                 p[0] = cadd(x[0], sm); p[Lp] = cadd(h, jd); p[2 * Lp] = csub(h, jd);
-            } else {
+            } else if (r == 5) {
                 const float c1 = 0.30901699437494745f, c2 = -0.8090169943749475f, s1 = 0.9510565162951535f, s2 = 0.5877852522924731f;
                 float2 a1 = cadd(x[1], x[4]), a2 = cadd(x[2], x[3]), b1 = csub(x[1], x[4]), b2 = csub(x[2], x[3]);
                 float2 t1 = make_float2(x[0].x + c1 * a1.x + c2 * a2.x, x[0].y + c1 * a1.y + c2 * a2.y);
@@ -137,6 +137,24 @@ __device__ inline void lds_fft(float2 *buf, const FftPlan &pl, int nlines, int l
                 p[0] = make_float2(x[0].x + a1.x + a2.x, x[0].y + a1.y + a2.y);
                 p[Lp] = cadd(t1, j1); p[4 * Lp] = csub(t1, j1);
                 p[2 * Lp] = cadd(t2, j2); p[3 * Lp] = csub(t2, j2);
+            } else {
+                // r == 7: X[p] = t_p + (sgn i) u_p, X[7 - p] = t_p - (sgn i) u_p with t_p = x0 + sum_k cos(2 pi p k / 7) a_k,
+                // u_p = sum_k sin(2 pi p k / 7) b_k over the pairs a_k = x[k] + x[7 - k], b_k = x[k] - x[7 - k]
+                const float c1 = 0.6234898018587336f, c2 = -0.2225209339563144f, c3 = -0.9009688679024191f;
+                const float s1 = 0.7818314824680298f, s2 = 0.9749279121818236f, s3 = 0.4338837391175581f;
+                float2 a1 = cadd(x[1], x[6]), a2 = cadd(x[2], x[5]), a3 = cadd(x[3], x[4]);
+                float2 b1 = csub(x[1], x[6]), b2 = csub(x[2], x[5]), b3 = csub(x[3], x[4]);
+                float2 t1 = make_float2(x[0].x + c1 * a1.x + c2 * a2.x + c3 * a3.x, x[0].y + c1 * a1.y + c2 * a2.y + c3 * a3.y);
+                float2 t2 = make_float2(x[0].x + c2 * a1.x + c3 * a2.x + c1 * a3.x, x[0].y + c2 * a1.y + c3 * a2.y + c1 * a3.y);
+                float2 t3 = make_float2(x[0].x + c3 * a1.x + c1 * a2.x + c2 * a3.x, x[0].y + c3 * a1.y + c1 * a2.y + c2 * a3.y);
+                float2 u1 = make_float2(s1 * b1.x + s2 * b2.x + s3 * b3.x, s1 * b1.y + s2 * b2.y + s3 * b3.y);
+                float2 u2 = make_float2(s2 * b1.x - s3 * b2.x - s1 * b3.x, s2 * b1.y - s3 * b2.y - s1 * b3.y);
+                float2 u3 = make_float2(s3 * b1.x - s1 * b2.x + s2 * b3.x, s3 * b1.y - s1 * b2.y + s2 * b3.y);
+                float2 j1 = make_float2(-sgn * u1.y, sgn * u1.x), j2 = make_float2(-sgn * u2.y, sgn * u2.x), j3 = make_float2(-sgn * u3.y, sgn * u3.x);
+                p[0] = make_float2(x[0].x + a1.x + a2.x + a3.x, x[0].y + a1.y + a2.y + a3.y);
+                p[Lp] = cadd(t1, j1); p[6 * Lp] = csub(t1, j1);
+                p[2 * Lp] = cadd(t2, j2); p[5 * Lp] = csub(t2, j2);
+                p[3 * Lp] = cadd(t3, j3); p[4 * Lp] = csub(t3, j3);
             }
         }
         Lp = L;

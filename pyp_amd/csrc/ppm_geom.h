@@ -46,15 +46,16 @@ inline void sym_limits(const char *sym, double &phi_max, double &theta_max) {
     else if (t == 'O') { phi_max = 90.0; theta_max = 90.0; }
 }
 
-// box sizes the FFTs handle: even, 32..512, prime factors 2, 3, 5 only
+// box sizes the FFTs handle: even, 32..512, prime factors 2, 3, 5, 7 only
 inline bool box_ok(int n) {
     if (n < 32 || n > 512 || n % 2) return false;
     while (n % 2 == 0) n /= 2;
     while (n % 3 == 0) n /= 3;
     while (n % 5 == 0) n /= 5;
+    while (n % 7 == 0) n /= 7;
     return n == 1;
 }
-// factors (4s first, then 2, 3, 5) and the digit-reversal staging permutation of an FFT length
+// factors (4s first, then 2, 3, 5, 7) and the digit-reversal staging permutation of an FFT length
 inline void fft_factors(int n, std::vector<int> &fac, std::vector<unsigned short> &perm) {
     fac.clear();
     int m = n;
@@ -62,6 +63,7 @@ inline void fft_factors(int n, std::vector<int> &fac, std::vector<unsigned short
     while (m % 2 == 0) { fac.push_back(2); m /= 2; }
     while (m % 3 == 0) { fac.push_back(3); m /= 3; }
     while (m % 5 == 0) { fac.push_back(5); m /= 5; }
+    while (m % 7 == 0) { fac.push_back(7); m /= 7; }
     perm.resize(n);
     for (int i = 0; i < n; i++) {
         int pos = 0, rem = i, L = n;
@@ -78,7 +80,7 @@ inline int n_phi_at(double theta_deg, double dstep, double phi_max = 360.0) {
 inline bool geom_init(Geom &g, const ppm_refine_cfg &c, std::string &err) {
     g = Geom();
     g.N = c.box; g.a = c.pixel_size;
-    if (!box_ok(g.N)) { err = "box size must be even, 32..512, with prime factors 2, 3 and 5 only"; return false; }
+    if (!box_ok(g.N)) { err = "box size must be even, 32..512, with prime factors 2, 3, 5 and 7 only"; return false; }
     if (!(g.a > 0) || !(c.res_high > 0)) { err = "pixel size and high-resolution limit must be positive"; return false; }
     double na = g.N * g.a;
     g.r_hi = na / c.res_high; if (g.r_hi > g.N / 2) g.r_hi = g.N / 2;

@@ -121,7 +121,7 @@ int ensure_plan(int n) {
     std::vector<int> fac; std::vector<unsigned short> perm;
     fft_factors(n, fac, perm);
     int prod = 1; for (int f : fac) prod *= f;
-    if (prod != n || fac.size() > 12) return fail(-22, "FFT length must have prime factors 2, 3 and 5 only");
+    if (prod != n || fac.size() > 12) return fail(-22, "FFT length must have prime factors 2, 3, 5 and 7 only");
     std::vector<float2> t(n);
     for (int k = 0; k < n; k++) t[k] = make_float2((float)std::cos(2.0 * kPi * k / n), (float)std::sin(2.0 * kPi * k / n));
     float2 *dtw = nullptr; unsigned short *dperm = nullptr;
@@ -625,7 +625,7 @@ int ppm_device_sync(void) { if (cur_stream()) HIPCHK(hipStreamSynchronize(cur_st
 // ------------------------------------------------------------------------------ reference
 ppm_ref_t *ppm_reference_create_weighted(const float *vol, int n, float max_band_px, int pad, const float *ring_weight, int n_weight) {
     if (!g.inited) { fail(-1, "ppm_init has not been called"); return nullptr; }
-    if (!vol || !box_ok(n) || !(max_band_px > 0)) { fail(-22, "reference box must be even, 32..512, with prime factors 2, 3, 5, and the band positive"); return nullptr; }
+    if (!vol || !box_ok(n) || !(max_band_px > 0)) { fail(-22, "reference box must be even, 32..512, with prime factors 2, 3, 5, 7, and the band positive"); return nullptr; }
     if ((pad != 1 && pad != 2 && pad != 4) || n * pad > 512) { fail(-22, "padding factor must be 1, 2 or 4 with padded box <= 512"); return nullptr; }
     if (max_band_px > n / 2) max_band_px = (float)(n / 2);
     const int np = n * pad;
@@ -1150,7 +1150,7 @@ size_t ppm_accum_floats(int box) { return (size_t)2 * box * box * (box / 2 + 1) 
 
 ppm_accum_t *ppm_accum_create(int box, float pixel_size, const char *symmetry, void *ext) {
     if (!g.inited) { fail(-1, "ppm_init has not been called"); return nullptr; }
-    if (!box_ok(box) || !(pixel_size > 0)) { fail(-22, "box must be even, 32..512, with prime factors 2, 3, 5, and the pixel size positive"); return nullptr; }
+    if (!box_ok(box) || !(pixel_size > 0)) { fail(-22, "box must be even, 32..512, with prime factors 2, 3, 5, 7, and the pixel size positive"); return nullptr; }
     std::unique_ptr<ppm_accum, void (*)(ppm_accum_t *)> guard(new ppm_accum(), ppm_accum_destroy);      // freed on every error return
     ppm_accum *a = guard.get();
     HIPCHKP(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
@@ -1904,7 +1904,7 @@ static int sva_align_impl(ppm_ref_t *ref, ppm_accum_t *avg, const ppm_sva_cfg *c
     const Trace trace_("ppm_sva_align");
     auto mark = [&](const char *what) { trace_.mark(what); };
     const int N = cfg->box;
-    if (!box_ok(N) || N != ref->N) return fail(-22, "sub-volume box differs from the reference box (even, 32..512, prime factors 2, 3, 5)");
+    if (!box_ok(N) || N != ref->N) return fail(-22, "sub-volume box differs from the reference box (even, 32..512, prime factors 2, 3, 5, 7)");
     if (ref->pad != 1) return fail(-22, "sub-tomogram alignment needs a reference prepared with padding 1");
     const double rband = sva_band_radius(*cfg);
     if (rband > ref->B) return fail(-22, "low-pass limit exceeds the band the reference was prepared for");
@@ -2344,7 +2344,7 @@ extern "C" int ppm_sva_align_average(ppm_ref_t *ref, ppm_accum_t *acc, const ppm
 static int sva_insert_device(ppm_accum_t *a, const ppm_sva_cfg *cfg, const float *d_vols, int n_vol, const float *wedges, const double *poses,
                              const long *index, long index_base) {
     const int N = cfg->box;
-    if (!box_ok(N) || N != a->N) return fail(-22, "sub-volume box differs from the accumulator's box (even, 32..512, prime factors 2, 3, 5)");
+    if (!box_ok(N) || N != a->N) return fail(-22, "sub-volume box differs from the accumulator's box (even, 32..512, prime factors 2, 3, 5, 7)");
     if (a->nsym != 1) return fail(-22, "sub-tomogram averaging needs a C1 accumulator");
     const size_t n3 = (size_t)N * N * N;
     const int KX = N / 2 + 1, KY = N, NB = std::min(n_vol, kSvaInsBatch);
@@ -2421,7 +2421,7 @@ extern "C" int ppm_sva_insert(ppm_accum_t *a, const ppm_sva_cfg *cfg, const void
     if (n_vol <= 0) return 0;
     if (volumes_on_device) return sva_insert_device(a, cfg, (const float *)volumes, n_vol, wedges, poses, index, 0);
     const int N = cfg->box;
-    if (!box_ok(N) || N != a->N) return fail(-22, "sub-volume box differs from the accumulator's box (even, 32..512, prime factors 2, 3, 5)");
+    if (!box_ok(N) || N != a->N) return fail(-22, "sub-volume box differs from the accumulator's box (even, 32..512, prime factors 2, 3, 5, 7)");
     const size_t n3 = (size_t)N * N * N;
     const int NB = std::min(n_vol, kSvaInsBatch);
     if (int rc = a->s_vols.ensure((size_t)NB * n3)) return rc;

@@ -321,7 +321,8 @@ def test_two_live_references_with_different_search_grids(H, O):
 
 @pytest.mark.parametrize("n,px,m,step", [(64, 2.0, 24, 15.0), (128, 1.5, 8, 15.0), (64, 2.0, 6, 20.0), (32, 3.0, 6, 30.0),
                                           (96, 1.5, 6, 15.0), (80, 2.0, 6, 15.0), (48, 3.0, 6, 20.0),    # 2^5 3, 2^4 5, 2^4 3: mixed-radix FFT
-                                          (90, 2.0, 6, 20.0)])             # 2 3^2 5: not a multiple of 4 (4-byte row fetches)
+                                          (90, 2.0, 6, 20.0),              # 2 3^2 5: not a multiple of 4 (4-byte row fetches)
+                                          (56, 2.0, 6, 20.0), (112, 1.5, 4, 20.0), (98, 2.0, 4, 24.0)])   # 2^3 7, 2^4 7, 2 7^2: radix-7 stages (boxes 224 / 336 / 448)
 def test_full_refinement_matches_oracle(H, O, n, px, m, step):
     vol, imgs, rows = dataset(n, m, px, 0.1)
     g, o = H.Reference(vol, n / 2), O.Reference(vol, n / 2)
@@ -583,8 +584,9 @@ def test_dose_weighted_insertion_matches_oracle(H, O):
     assert np.linalg.norm(plain.download() - acc) / np.linalg.norm(acc) > 0.05        # the weighting is not a no-op
 
 
-def test_insertion_non_power_of_two_box(H, O):
-    n, px, m = 96, 1.5, 16
+@pytest.mark.parametrize("n", [96, 112])
+def test_insertion_non_power_of_two_box(H, O, n):
+    px, m = 1.5, 16
     vol, imgs, rows = dataset(n, m, px, 0.2)
     rc = ReconCfg(box=n, pixel_size=px, res_limit=2 * px, normalize=1, split_by_pind=0, mask_radius=0.4 * n * px)
     acc = np.zeros(O.accum_floats(n), dtype=np.float32)

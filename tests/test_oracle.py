@@ -144,16 +144,16 @@ def test_symmetry_restricted_grid_finds_an_equivalent_pose():
 
 def test_mixed_radix_fft_matches_numpy():
     rng = np.random.default_rng(3)
-    for n in (32, 48, 80, 96, 120, 160, 192, 240, 256, 320, 384, 480, 512):
+    for n in (14, 32, 48, 56, 80, 96, 112, 120, 160, 192, 224, 240, 256, 320, 336, 384, 448, 480, 490, 512):
         x = (rng.normal(size=n) + 1j * rng.normal(size=n)).astype(np.complex64)
         assert np.abs(oracle.fft1d(x) - np.fft.fft(x)).max() < 2e-5 * np.sqrt(n)
         assert np.abs(oracle.fft1d(x, True) - np.fft.ifft(x) * n).max() < 2e-5 * np.sqrt(n)
     with pytest.raises(ValueError):
-        oracle.fft1d(np.zeros(56, np.complex64))            # 7 is not a supported factor
+        oracle.fft1d(np.zeros(88, np.complex64))            # 11 is not a supported factor
 
 
 def test_non_power_of_two_boxes_recover_poses():
-    for n in (48, 96):
+    for n in (48, 56, 96):
         vol, stack, rows = synth.make_dataset(n, 6, pixel=PX, snr=0)
         ref = oracle.Reference(vol, n / 2)
         c = RefineCfg.make(box=n, pixel_size=PX, mask_radius=0.4 * n * PX, res_high=PX * n / (0.375 * n), res_search=PX * n / (0.16 * n),

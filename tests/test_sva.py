@@ -215,9 +215,9 @@ def test_sva_align_executable_refines_a_table(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [32, 48, 80, 96])
+@pytest.mark.parametrize("n", [32, 48, 80, 96, 112])
 def test_gpu_two_step_transforms_equal_the_staged_ones(n, monkeypatch):
-    """Boxes that are multiples of 16 go through k_sva_x16 / k_sva_yz16 (N = 16 M, M = 2, 3, 5, 6 here; other layout of the work arrays); PPM_SVA_GENERIC_FFT=1 forces the staged line transforms every other box takes.
+    """Boxes that are multiples of 16 go through k_sva_x16 / k_sva_yz16 (N = 16 M, M = 2, 3, 5, 6, 7 here; other layout of the work arrays); PPM_SVA_GENERIC_FFT=1 forces the staged line transforms every other box takes.
     Same scores and poses to rounding."""
     from pyp_amd import host
     vol, vols, poses, wedges = synth.make_subtomograms(n, 5, snr=0.5, wedge=(-50.0, 62.0))
