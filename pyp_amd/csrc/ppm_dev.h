@@ -27,6 +27,19 @@ template <int CTRL> __device__ __forceinline__ float dpp_mov(float x) {
     return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), CTRL, 0xf, 0xf, false));
 }
 template <int CTRL> __device__ __forceinline__ int dpp_mov(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, false); }
+// Inclusive scans over the 64 lanes with DPP only (no LDS round trips): row shifts by 1, 2, 4, 8, then the last lane of row 0 / 2 broadcast
+// into the next row and that of the lower half into the upper half (row_bcast15 / row_bcast31, GFX9); lanes without a source keep 0.
+template <int CTRL, int ROWS> __device__ __forceinline__ int dpp_from(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, ROWS, 0xf, false); }
+__device__ __forceinline__ int wave_scan_add(int v) {
+    v += dpp_from<0x111, 0xf>(v); v += dpp_from<0x112, 0xf>(v); v += dpp_from<0x114, 0xf>(v); v += dpp_from<0x118, 0xf>(v);
+    v += dpp_from<0x142, 0xa>(v); v += dpp_from<0x143, 0xc>(v);
+    return v;
+}
+__device__ __forceinline__ int wave_scan_max0(int v) {          // values >= 0
+    v = max(v, dpp_from<0x111, 0xf>(v)); v = max(v, dpp_from<0x112, 0xf>(v)); v = max(v, dpp_from<0x114, 0xf>(v)); v = max(v, dpp_from<0x118, 0xf>(v));
+    v = max(v, dpp_from<0x142, 0xa>(v)); v = max(v, dpp_from<0x143, 0xc>(v));
+    return v;
+}
 // rows 1 and 3 of `a` trade places with rows 0 and 2 of `b` (M = 16), or the upper half of `a` with the lower half of `b`
 // (M = 32); afterwards lanes with (lane & M) == 0 hold both halves of their `a` pair, the others those of their `b` pair
 template <int M> __device__ __forceinline__ void lane_swap(float &a, float &b) {

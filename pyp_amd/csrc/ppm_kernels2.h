@@ -673,12 +673,22 @@ __global__ void k_insert_params(const double *rows, PartIns *pp, CullEnt *cull, 
 // 31-bit integer relative to the largest possible value of the chunk (max |band| x max weight, found on the device
 // beforehand), then summed exactly: the LDS part of the sum does not depend on the order of the adds.
 constexpr int CULL_CAP = 4096;
+// Diagnostic build (-DPPM_INS_STAMPS): cycles per phase (s_memtime), summed over all waves of a launch, and event counts
+#ifdef PPM_INS_STAMPS
+__device__ unsigned long long g_ins_stamps[24];
+#define INS_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_t; st_t = t_; } while (0)
+#define INS_COUNT(i, v) do { st_acc[i] += (unsigned long long)(v); } while (0)
+#else
+#define INS_STAMP(i) do { } while (0)
+#define INS_COUNT(i, v) do { } while (0)
+#endif
 template <int BE, int NW>
 __global__ void __launch_bounds__(NW * 64) k_insert_bricks(InsertBrickP P) {
     extern __shared__ long long brick[];           // [BE+1][BE+1][BE+1][3] with padded row / plane strides SY, SZ (in 8-byte cells):
     constexpr int BH = BE + 1, SY = BH * 3 + 1, SZ = BH * SY + 3;   // odd strides spread the 8 taps of neighbouring samples over the banks
                                                        // (unpadded, 3/4 of the LDS atomic cycles were bank conflicts)
     __shared__ unsigned queue_s[NW][128];
+    __shared__ unsigned deal_s[NW][64];
     __shared__ int cut_list[CULL_CAP];
     __shared__ int n_cut, cut_head;
     // value scale 2^(30-e) with bound < 2^e, so |tap| < 2^30; likewise for the weight channel
@@ -692,16 +702,22 @@ __global__ void __launch_bounds__(NW * 64) k_insert_bricks(InsertBrickP P) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int N = P.N, B = P.B, W = P.W;
+    const float invN = 1.0f / (float)N;
     const int h = blockIdx.y;
     const BrickItem it = P.items[blockIdx.x];
     // voxel COORDINATES covered by this brick: x in [x_lo, x_lo+BE), y, z likewise (stored index = coordinate + N/2)
     const int x_lo = it.bx * BE, y_lo = it.by * BE - N / 2, z_lo = it.bz * BE - N / 2;
     const int p_lo = (int)((long)P.n_img * it.s / it.S), p_hi = (int)((long)P.n_img * (it.s + 1) / it.S);
+#ifdef PPM_INS_STAMPS
+    unsigned long long st_acc[24] = { 0 }, st_t = __builtin_amdgcn_s_memtime();
+#endif
     for (int i = tid; i < BH * SZ; i += NW * 64) brick[i] = 0ll;
     __syncthreads();
+    INS_STAMP(0);
     // sample positions Q whose floor() lies in [lo, lo+BE-1] belong to the brick:  lo <= Q < lo+BE
     const float cx = x_lo + 0.5f * BE, cy = y_lo + 0.5f * BE, cz = z_lo + 0.5f * BE, hh = 0.5f * BE;
     unsigned *queue = queue_s[wave];
+    volatile unsigned *deal = deal_s[wave];
     int qn = 0;
     bool touched = false;
     const int e_hi = p_hi * P.nsym;
@@ -724,7 +740,9 @@ __global__ void __launch_bounds__(NW * 64) k_insert_bricks(InsertBrickP P) {
             if (cut) cut_list[base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = e;
         }
     }
+    INS_STAMP(1);
     __syncthreads();
+    INS_STAMP(2);
     const int nc = n_cut;
     for (;;) {                                           // WORK
         int ci = 0;
@@ -757,7 +775,7 @@ __global__ void __launch_bounds__(NW * 64) k_insert_bricks(InsertBrickP P) {
             const float cv = ctf_eval_fast(q.ctf, kx, ky);
             float w = q.w0 * (q.wexp != 0.f ? expf(q.wexp * k2) : 1.f);
             if (q.dexp != 0.f) w *= expf(q.dexp * fminf(k2, q.dcap2));
-            float rev = (kx * q.sx + ky * q.sy) / (float)N; rev -= floorf(rev);
+            float rev = (kx * q.sx + ky * q.sy) * invN; rev -= floorf(rev);
             const float sn = __sinf(6.283185307179586f * rev), cs = __cosf(6.283185307179586f * rev);
             const float2 iv = P.band[((size_t)p * P.H + (ky + B)) * W + kx];
             const float vr = sv * w * cv * (iv.x * cs - iv.y * sn), vw = sw * w * cv * cv;
@@ -780,6 +798,7 @@ __global__ void __launch_bounds__(NW * 64) k_insert_bricks(InsertBrickP P) {
         // candidate rectangle of (kx, ky) = (col0 . Q, col1 . Q) over the box, for Q = +P (sgn +1) and Q = -P (sgn -1)
         const float ea = (fabsf(a0) + fabsf(b0) + fabsf(c0)) * hh, eb = (fabsf(a1) + fabsf(b1) + fabsf(c1)) * hh;
         const float ka = a0 * cx + b0 * cy + c0 * cz, kb = a1 * cx + b1 * cy + c1 * cz;
+        INS_STAMP(3); INS_COUNT(12, 1);
 #pragma unroll 1
         for (int sgn = 1; sgn >= -1; sgn -= 2) {
             int kx0 = (int)floorf(sgn * ka - ea) - 1, kx1 = (int)ceilf(sgn * ka + ea) + 1;
@@ -809,19 +828,27 @@ __global__ void __launch_bounds__(NW * 64) k_insert_bricks(InsertBrickP P) {
                 }
             }
             const int cnt = hi >= lo ? hi - lo + 1 : 0;
-            int incl = cnt;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
+            const int incl = wave_scan_add(cnt);
             const int total = __builtin_amdgcn_readlane(incl, 63);
-            const int base = lo - (incl - cnt);                   // kx of candidate j in this row = base + j
+            const int start = incl - cnt, base = lo - start;      // kx of candidate j in this row = base + j
+            // rows are dealt out over the lanes through a 64-entry LDS line: every row with candidates marks the lane of its first one
+            // with (row + 1, base), a running maximum along the lanes (DPP) carries the mark to the row's other candidates
+            const unsigned mark = ((unsigned)(lane + 1) << 16) | (unsigned)((base + 32768) & 0xffff);
+            int carry = 0;
+            INS_STAMP(4); INS_COUNT(13, total);
 #pragma unroll 1
             for (int j0 = 0; j0 < total; j0 += 64) {
                 const int j = j0 + lane;
-                int r = 0;                                        // smallest row with incl[r] > j
-#pragma unroll
-                for (int st = 32; st >= 1; st >>= 1) { const int v = __shfl(incl, r + st - 1, 64); if (v <= j) r += st; }
-                r = r > 63 ? 63 : r;
-                const int kx = __shfl(base, r, 64) + j, ky = ky0 + r;
+                deal[lane] = 0u;
+                if (cnt > 0 && (unsigned)(start - j0) < 64u) deal[start - j0] = mark;
+                __builtin_amdgcn_wave_barrier();
+                int mk = (int)deal[lane];
+                if (lane == 0 && mk == 0) mk = carry;             // the row that began in an earlier group of 64
+                mk = wave_scan_max0(mk);
+                carry = __builtin_amdgcn_readlane(mk, 63);
+                __builtin_amdgcn_wave_barrier();
+                const int r = (mk >> 16) - 1;
+                const int kx = (mk & 0xffff) - 32768 + j, ky = ky0 + (r < 0 ? 0 : r);
                 const float k2 = (float)(kx * kx + ky * ky);
                 float X = pos(a0, a1, kx, ky), Y = pos(b0, b1, kx, ky), Z = pos(c0, c1, kx, ky);
                 const bool refl = X < 0.f;
@@ -833,24 +860,34 @@ __global__ void __launch_bounds__(NW * 64) k_insert_bricks(InsertBrickP P) {
                 if (m == 0ull) continue;
                 if (hit) queue[qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (unsigned)kx | ((unsigned)(ky + 512) << 16);
                 qn += __popcll(m);
+                INS_COUNT(14, __popcll(m));
                 __builtin_amdgcn_wave_barrier();
+                INS_STAMP(5);
                 if (qn >= 64) {
                     qn -= 64;
                     evaluate(queue[qn + lane], true);
                     __builtin_amdgcn_wave_barrier();
+                    INS_STAMP(6); INS_COUNT(15, 1);
                 }
                 touched = true;
             }
+            INS_STAMP(5);
         }
         if (qn > 0) {              // the queue never crosses a (particle, operator): the rotation above is wave-uniform
             evaluate(queue[lane], lane < qn);
             __builtin_amdgcn_wave_barrier();
             qn = 0;
+            INS_STAMP(7); INS_COUNT(16, 1);
         }
     }
+    INS_STAMP(3);
     __syncthreads();
+    INS_STAMP(8);
     }
     const int any = __syncthreads_or(touched ? 1 : 0);
+#ifdef PPM_INS_STAMPS
+    if (!any) { if (lane == 0) for (int i = 0; i < 24; i++) if (st_acc[i]) atomicAdd(&g_ins_stamps[i], st_acc[i]); return; }
+#endif
     if (!any) return;
     const size_t NX = N / 2 + 1;
     float *A = P.acc + (size_t)h * N * N * NX * 3;
@@ -864,7 +901,13 @@ __global__ void __launch_bounds__(NW * 64) k_insert_bricks(InsertBrickP P) {
         const float v = (float)((double)vq / (double)(i % 3 == 2 ? sw : sv));
         atomicAdd(o, v);                 // halo cells belong to the neighbours' boxes: no voxel has a sole owner
     }
+    INS_STAMP(9);
+#ifdef PPM_INS_STAMPS
+    if (lane == 0) for (int i = 0; i < 24; i++) if (st_acc[i]) atomicAdd(&g_ins_stamps[i], st_acc[i]);
+#endif
 }
+#undef INS_STAMP
+#undef INS_COUNT
 
 // ---------------------------------------------------------------------------------- matching projections
 // refine3d answers 8 / 43 (frealign.py:3929-3931, refine_fmatch): the reference projected at a row's pose, times the row's CTF,

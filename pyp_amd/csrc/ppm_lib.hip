@@ -1246,6 +1246,20 @@ int ppm_insert_batch(ppm_accum_t *a, const ppm_recon_cfg *cfg, const void *image
             else hipLaunchKernelGGL((k_insert_bricks<8, 4>), grid, dim3(256), 9 * (9 * 28 + 3) * sizeof(long long), cur_stream(), IP);
         }
         HIPCHK(hipGetLastError());
+#ifdef PPM_INS_STAMPS
+        {   // diagnostic build: cycles per phase summed over the waves of this launch (ppm_kernels2.h)
+            unsigned long long st[24], z[24] = { 0 };
+            HIPCHK(hipStreamSynchronize(cur_stream()));
+            HIPCHK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_ins_stamps), sizeof(st)));
+            HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_ins_stamps), z, sizeof(z)));
+            const char *names[10] = { "zero brick", "cull", "wait after cull", "cut set-up", "row intervals + prefix", "deal-out + test", "evaluate 64", "evaluate tail", "wait at round end", "write-back" };
+            double tot = 0; for (int i = 0; i < 10; i++) tot += (double)st[i];
+            fprintf(stderr, "k_insert_bricks stamps, %d particles, %d items:", nb, a->n_items);
+            for (int i = 0; i < 10; i++) fprintf(stderr, " | %s %.1f%%", names[i], 100.0 * (double)st[i] / tot);
+            fprintf(stderr, " || wave-cycles per particle %.0f, cuts per particle %.1f, candidates per cut %.1f, hits per cut %.1f, full evaluations per cut %.2f, tails per cut %.2f\n",
+                    tot / nb, (double)st[12] / nb, (double)st[13] / (double)st[12], (double)st[14] / (double)st[12], (double)st[15] / (double)st[12], (double)st[16] / (double)st[12]);
+        }
+#endif
         if (!images_on_device && c0 + CH < n_img) {
             const int nn = std::min(CH, n_img - (c0 + CH));
             HIPCHK(hipMemcpyAsync(a->images.p + (size_t)((ci + 1) & 1) * CH * NN, (const float *)images + (size_t)(c0 + CH) * NN,
