@@ -182,16 +182,20 @@ def pmc_traffic(summary, kernel, particles_per_launch):
 
 def pmc_traffic_sum(summary, kernels):
     """HBM-side bytes per profiled unit summed over several kernels (2 x FETCH_SIZE + WRITE_SIZE, KB; all their dispatches)."""
-    tot, meta_ = 0.0, None
+    tot, meta_, seen = 0.0, None, []
     for kname in kernels:
         e, meta = pmc_entry(summary, kname, merge=True)
-        if not e or "FETCH_SIZE" not in e or "WRITE_SIZE" not in e or not meta.get("particles"):
+        if not e:                           # a kernel the profiled build did not launch (k_sva_gather16 since the z pass emits the samples)
+            continue
+        if "FETCH_SIZE" not in e or "WRITE_SIZE" not in e or not meta.get("particles"):
             return None, "no FETCH_SIZE / WRITE_SIZE summary for %s under profiles/%s" % (kname, summary)
         tot += (2.0 * e["FETCH_SIZE"]["sum"] + e["WRITE_SIZE"]["sum"]) * 1024.0 / meta["particles"]
-        meta_ = meta
+        meta_ = meta; seen.append(kname)
+    if not seen:
+        return None, "none of %s under profiles/%s" % (" / ".join(kernels), summary)
     had, now = meta_.get("kernels_sha16", "?"), kernels_sha16()
     return tot, "profiles/%s (%d units, 2 x FETCH_SIZE + WRITE_SIZE, KB, summed over %s; kernel sources %s%s)" % (
-        summary, meta_["particles"], " + ".join(kernels), had, " = the timed ones" if had == now else ", the timed ones are " + now)
+        summary, meta_["particles"], " + ".join(seen), had, " = the timed ones" if had == now else ", the timed ones are " + now)
 
 
 def pmc_valu(summary, kernel, slices_per_particle):
@@ -822,7 +826,13 @@ def reconstruct_bench(ctx):
                               "unit": "G lane-atomics/s", "frac": round(lane_atomics / ms_i / peak_at, 4), "us_per_particle": round(ms_i * 1e6, 3),
                               "model": "24 ds_add_u64 per in-band sample (8 taps x re, im, weight), S = %d samples per particle" % S,
                               "peak_note": "derived: one 64-lane ds_add_u64 per 7.7 cycles and CU (measured, scripts/micro/lds_atomic_bench) x 256 CUs x 2.4 GHz; the "
-                                           "kernel's vector instructions (568 lane-instructions per sample) run beside them, so neither pipe is the whole bound"}
+                                           "kernel's vector instructions run beside them, so neither pipe is the whole bound"}
+        e_pmc, m_pmc = pmc_entry(pmc_latest("reconstruct"), "k_insert_bricks")
+        if e_pmc and m_pmc.get("particles") and "SQ_INSTS_VALU" in e_pmc:
+            roof["lds_atomic"]["counters"] = {"source": "profiles/" + pmc_latest("reconstruct"),
+                                              "valu_lane_instructions_per_sample": round(64.0 * e_pmc["SQ_INSTS_VALU"]["sum"] / m_pmc["particles"] / S, 1)}
+            if "SQ_LDS_BANK_CONFLICT" in e_pmc and e_pmc.get("SQ_LDS_IDX_ACTIVE", {}).get("sum"):
+                roof["lds_atomic"]["counters"]["lds_conflict_share"] = round(e_pmc["SQ_LDS_BANK_CONFLICT"]["sum"] / e_pmc["SQ_LDS_IDX_ACTIVE"]["sum"], 3)
     acc.set_counts(counts[0], counts[1])
     h1, h2, fl, stats = acc.finalize(FinalCfg(molecular_mass_kda=500.0, inner_radius=0.0, outer_radius=0.45 * N * px, mask_falloff=0.0))
     acc.close()

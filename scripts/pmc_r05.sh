@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-4 PMC summaries of the CURRENT kernels (one counter group per rocprofv3 run, --kernel-trace only; FETCH_SIZE and
+# Round-5 PMC summaries of the CURRENT kernels (one counter group per rocprofv3 run, --kernel-trace only; FETCH_SIZE and
 # WRITE_SIZE in separate passes as MI355X_MICROARCH.md prescribes).  Raw CSVs stay under /tmp; the per-kernel summaries
 # (with the library's sha and the unit count in "_meta") go to gpurun_out/ and are then copied to profiles/.
 #   usage: scripts/pmc_r05.sh <refine|refine0|reconstruct|sva|csp> <units> <out.json>     (refine0: search range 0 = the mask radius, k_gfft)
@@ -16,8 +16,8 @@ case "$W" in
   reconstruct) ARGS="--workload reconstruct --recon-particles $N --steps 1 --warmup 0 --no-cpu --no-dropin"; TCC="TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum";;
   sva)         ARGS="--workload sva --sva-volumes $N --steps 1 --warmup 0 --no-cpu --no-side"; TCC="TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum";;
   csp)         ARGS="--workload csp --csp-particles $N --steps 1 --warmup 0 --no-cpu --no-side"; TCC="TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum"; UNITS=$((N * 41));;
-  refine0)     ARGS="--workload refine --search-range 0 --particles $N --steps 1 --warmup 0 --no-cpu --no-dropin"; TCC="TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum";;
-  *)           ARGS="--workload refine --particles $N --steps 1 --warmup 0 --no-cpu --no-dropin"; TCC="TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum";;
+  refine0)     ARGS="--workload refine --search-range 0 --particles $N --steps 1 --warmup 0 --no-cpu --no-dropin --no-side"; TCC="TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum";;
+  *)           ARGS="--workload refine --particles $N --steps 1 --warmup 0 --no-cpu --no-dropin --no-side"; TCC="TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum";;
 esac
 # vector L1 of the gather kernels (k_local, k_csp_eval, k_sva_eval): lines looked up, requests sent on to L2, texture-addresser busy
 TCP="TA_BUSY_avr TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum"
