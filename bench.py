@@ -260,7 +260,8 @@ def gfft_model(band, search_range_px, box, mask_radius_px):
     col = 4 * L * (L * 14 + L * 3 + fft)
     row = 2 * (2 * RS + 1) * ((L // 2 - 1) * 18 + fft + 4 * L)
     return {"flops_per_slice": float(col + row), "Ns": Ns, "L": L, "RS": RS, "fft_flops": fft,
-            "l1_bytes_per_slice": 4.0 * L * L * 16.0, "lds_bytes_per_slice": 4.0 * L * L * 16.0 + 2.0 * (2 * RS + 1) * (L + 2) * 8.0 * 2}
+            "l1_bytes_per_slice": L * L * 16.0,     # the slice is staged through LDS once per block (a quarter per wave)
+            "lds_bytes_per_slice": (1.0 + 4.0) * L * L * 16.0 + 4.0 * L * L * 16.0 + 2.0 * (2 * RS + 1) * (L + 2) * 8.0 * 2}   # staging write + four waves' reads, W reads, T written and read
 
 
 def default_search_bench(a, ref, stack, start_rows, truth, vol, px, cpu):
@@ -298,6 +299,8 @@ def default_search_bench(a, ref, stack, start_rows, truth, vol, px, cpu):
         ppl = npart / launches
         tf = ppl * nsl * mdl["flops_per_slice"] / (ms_g * 1e-3) / 1e12
         l1 = ppl * nsl * mdl["l1_bytes_per_slice"] / (ms_g * 1e-3) / 1e9
+        gf_traffic, gf_src = (pmc_traffic(pmc_latest("refine0"), "k_gfft<%d" % int(np.log2(mdl["Ns"])), ppl) if key.startswith("mask_radius")
+                              else (None, "counters are taken for the 256^2 / 15 deg / r = 64 case only (profiles/r05_pmc_refine0.json)"))
         k = min(npart, 2000)
         ang = synth.angular_error_deg(got[:k], truth[:k])
         blk = {"value": round(npart / dt, 1), "unit": "particles/s", "particles": npart, "wall_s": round(dt, 3),
@@ -305,11 +308,15 @@ def default_search_bench(a, ref, stack, start_rows, truth, vol, px, cpu):
                           "search_grid_points": mdl["Ns"], "window_steps_each_side": mdl["RS"], "shifts_per_orientation": (2 * mdl["RS"] + 1) ** 2},
                "kernels_us_per_particle": {k2: round(v["ms"] * 1e3 / npart, 3) for k2, v in prof.items() if v["launches"]},
                "roofline": {"bound": "valu_fp32", "kernel": "k_gfft", "achieved": round(tf, 2), "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_VALU_TFLOPS, 4),
-                            "traffic": None, "avg_launch_ms": round(ms_g, 3), "particles_per_launch": round(ppl, 1),
+                            "traffic": gf_traffic, "traffic_source": gf_src, "avg_launch_ms": round(ms_g, 3), "particles_per_launch": round(ppl, 1),
                             "flops_per_stored_slice_and_particle": mdl["flops_per_slice"],
                             "flop_model": "column pass 4 L x (17 L + T) + row pass 2 (2 RS + 1) x (9 L + T - 18 + 4 L) with T = %d flop per %d-point transform (gfft_model)" % (mdl["fft_flops"], mdl["L"]),
                             "l1_path": {"GBps": round(l1, 1), "peak": PEAK_L1_GBPS, "frac": round(l1 / PEAK_L1_GBPS, 4),
-                                        "note": "bank rows pulled through the vector L1 by the four waves of a block (4 x the slice); peak derived: 64 B/clk/CU x 256 CUs x 2.4 GHz"}},
+                                        "note": "bank rows pulled through the vector L1: the slice once per block (each wave stages a quarter into LDS; four times the slice before the staging); "
+                                                "peak derived: 64 B/clk/CU x 256 CUs x 2.4 GHz"},
+                            "lds_path": {"GBps": round(ppl * nsl * mdl["lds_bytes_per_slice"] / (ms_g * 1e-3) / 1e9, 1), "peak": round(256 * 128 * 2.4, 1),
+                                         "frac": round(ppl * nsl * mdl["lds_bytes_per_slice"] / (ms_g * 1e-3) / 1e9 / (256 * 128 * 2.4), 4),
+                                         "note": "LDS bytes of a pass (slice staged and read by four waves, W table reads, image T written and read); peak derived: 128 B/clk/CU x 256 CUs x 2.4 GHz"}},
                "accuracy_vs_truth": {"median_deg": round(float(np.median(ang)), 3), "frac_within_2deg": round(float((ang < 2).mean()), 3)}}
         if cpu and key.startswith("mask_radius"):
             # the same particles through the oracle's zero-filled inverse transform (ccf_mode 0), all host cores
@@ -1321,7 +1328,7 @@ def sva_bench(ctx):
                       "sub_volumes_per_gpu": nv, "parallelism": "row-sharded x%d, no collective" % world},
            "device_ms_per_sub_volume": {"pre_processing": round(ms_prep, 3), "search": round(prof["local"]["ms"] / (nv * a.steps), 3)},
            "roofline": sva_eval_roofline(prof, lc_sva, nv, a.steps, wedges),
-           "roofline_pre_processing": {"bound": "hbm", "kernel": "sub-volume pre-processing (k_sva_x16 + k_sva_stats_sum + two k_sva_yz16 passes + k_sva_gather16)",
+           "roofline_pre_processing": {"bound": "hbm", "kernel": "sub-volume pre-processing (k_sva_x16 + k_sva_stats_sum + two k_sva_yz16 passes; k_sva_gather16 only with PPM_SVA_FOLD=0)",
                         "achieved": round(4.0 * n3 / (ms_prep * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                         "frac": round(4.0 * n3 / (ms_prep * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4), "traffic": pre_traffic, "traffic_source": pre_src,
                         "traffic_over_algorithmic": None if pre_traffic is None else round(pre_traffic / (4.0 * n3), 2),
