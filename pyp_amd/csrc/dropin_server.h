@@ -69,6 +69,62 @@ inline int connect_server(int dev) {
     if (connect(fd, (sockaddr *)&ad, sizeof ad) != 0) { close(fd); return -1; }
     return fd;
 }
+// What a request carries besides its input: the CLIENT's file-creation mask and its PPM_* settings (PPM_IO_THREADS, the kernels' knobs),
+// one "name=value" per line — a call served by the resident process behaves like the one-shot run the client would have made, whoever
+// started the server.  The server's own settings (cache size, idle limit, lock directory, device) are not the caller's to change.
+inline bool server_owned_setting(const std::string &name) {
+    return name.compare(0, 15, "PPM_STACK_CACHE") == 0 || name == "PPM_LOCK_DIR" || name == "PPM_DEVICE";
+}
+inline std::string client_settings() {
+    const mode_t m = umask(0); umask(m);
+    std::string s = "umask=" + std::to_string((unsigned)m) + "\n";
+    for (char **e = environ; e && *e; e++) {
+        const std::string kv = *e;
+        const size_t eq = kv.find('=');
+        if (eq == std::string::npos || kv.compare(0, 4, "PPM_") != 0 || kv.find('\n') != std::string::npos) continue;
+        if (!server_owned_setting(kv.substr(0, eq))) s += kv + "\n";
+    }
+    return s;
+}
+// applied by the server for the duration of one request, undone afterwards (requests are served one at a time)
+struct RequestSettings {
+    mode_t old_mask = 0; bool mask_set = false;
+    std::vector<std::pair<std::string, std::pair<bool, std::string>>> saved;       // name -> (was set, old value)
+    explicit RequestSettings(const std::string &text) {
+        // PPM_* settings of the server's own environment the client does not have are unset for this request
+        std::vector<std::string> mine;
+        for (char **e = environ; e && *e; e++) {
+            const std::string kv = *e; const size_t eq = kv.find('=');
+            if (eq != std::string::npos && kv.compare(0, 4, "PPM_") == 0 && !server_owned_setting(kv.substr(0, eq))) mine.push_back(kv.substr(0, eq));
+        }
+        std::vector<std::pair<std::string, std::string>> want;
+        size_t p0 = 0;
+        while (p0 < text.size()) {
+            size_t p1 = text.find('\n', p0); if (p1 == std::string::npos) p1 = text.size();
+            const std::string kv = text.substr(p0, p1 - p0); p0 = p1 + 1;
+            const size_t eq = kv.find('=');
+            if (eq == std::string::npos) continue;
+            const std::string k = kv.substr(0, eq), v = kv.substr(eq + 1);
+            if (k == "umask") { old_mask = umask((mode_t)(strtoul(v.c_str(), nullptr, 10) & 0777)); mask_set = true; }
+            else if (k.compare(0, 4, "PPM_") == 0 && !server_owned_setting(k)) want.emplace_back(k, v);
+        }
+        for (const auto &k : mine) {
+            bool keep = false; for (const auto &w : want) keep = keep || w.first == k;
+            if (!keep) { saved.push_back({ k, { true, getenv(k.c_str()) } }); unsetenv(k.c_str()); }
+        }
+        for (const auto &w : want) {
+            const char *o = getenv(w.first.c_str());
+            saved.push_back({ w.first, { o != nullptr, o ? o : "" } });
+            setenv(w.first.c_str(), w.second.c_str(), 1);
+        }
+    }
+    ~RequestSettings() {
+        for (auto it = saved.rbegin(); it != saved.rend(); ++it) {
+            if (it->second.first) setenv(it->first.c_str(), it->second.second.c_str(), 1); else unsetenv(it->first.c_str());
+        }
+        if (mask_set) umask(old_mask);
+    }
+};
 // one request / reply; false = no server could be reached (the caller runs the call itself)
 inline bool server_call(int dev, int prog, const std::string &input, int &status, std::string &text) {
     int fd = connect_server(dev);
@@ -76,7 +132,7 @@ inline bool server_call(int dev, int prog, const std::string &input, int &status
     char cwd[4096];
     if (!getcwd(cwd, sizeof cwd)) { close(fd); return false; }
     const uint32_t p = (uint32_t)prog;
-    bool ok = write_all(fd, "PPMS", 4) && write_all(fd, &p, 4) && send_blob(fd, cwd) && send_blob(fd, input);
+    bool ok = write_all(fd, "PPMS", 4) && write_all(fd, &p, 4) && send_blob(fd, cwd) && send_blob(fd, input) && send_blob(fd, client_settings());
     int32_t st = 1;
     ok = ok && read_all(fd, &st, 4) && recv_blob(fd, text);
     close(fd);

@@ -75,8 +75,8 @@ int main(int argc, char **argv) {
         const int fd = accept(ls, nullptr, nullptr);
         if (fd < 0) continue;
         { timeval tv; tv.tv_sec = 10; tv.tv_usec = 0; setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv); }      // a client that connects and stays silent does not block the others
-        char magic[4]; uint32_t prog = 0; std::string cwd, input;
-        if (!read_all(fd, magic, 4) || memcmp(magic, "PPMS", 4) != 0 || !read_all(fd, &prog, 4) || !recv_blob(fd, cwd) || !recv_blob(fd, input)) { close(fd); continue; }
+        char magic[4]; uint32_t prog = 0; std::string cwd, input, settings;
+        if (!read_all(fd, magic, 4) || memcmp(magic, "PPMS", 4) != 0 || !read_all(fd, &prog, 4) || !recv_blob(fd, cwd) || !recv_blob(fd, input) || !recv_blob(fd, settings)) { close(fd); continue; }
         std::string text; Out out; out.sink = &text;
         int32_t status = 0;
         bool leave = false;
@@ -91,6 +91,7 @@ int main(int argc, char **argv) {
             if (chdir(cwd.c_str()) != 0) { status = 1; out.print("ERROR: ppm_server: cannot enter %s\n", cwd.c_str()); }
             else {
                 const int lockfd = gpu_lock(dev);               // one-shot processes of the node wait their turn on the same lock
+                RequestSettings as_the_client(settings);        // the caller's umask and PPM_* settings, for this request only
                 try {
                     if (!inited) { if (ppm_init(dev) != 0) throw Fail{ ppm_last_error() }; inited = true; }
                     status = prog == kProgRecon ? serve_reconstruct3d(cache, input, out) : serve_refine3d(cache, input, out);

@@ -614,6 +614,13 @@ def test_resident_server_keeps_the_stack_and_the_reference_between_calls(project
         fc, fo = (np.frombuffer(open(d / f"s_{t}_map1_n1.mrc", "rb").read(), "<f4", offset=24) for t in ("c", "one"))
         fc2, fo2 = (np.frombuffer(open(d / f"s_{t}_map2_n1.mrc", "rb").read(), "<f4", offset=24) for t in ("c", "one"))
         assert not (np.allclose(fc, fo) and np.allclose(fc2, fo2))
+        # a request carries its client's umask (and PPM_* settings): files are created as the one-shot run of that client would create them
+        old = os.umask(0o027)
+        try:
+            assert run("reconstruct3d", rec("m"), d, "s_m.log") == 0
+        finally:
+            os.umask(old)
+        assert (os.stat(d / "s_m_map1_n1.mrc").st_mode & 0o777) == 0o640 and (os.stat(d / "s_a_map1_n1.mrc").st_mode & 0o777) == (0o666 & ~old)
         # errors come back through the server with the contract of the executables
         bad = rec("bad").replace("s_used.cistem", "s_missing.cistem")
         assert run("reconstruct3d", bad, d, "s_bad.log") != 0 and "ERROR" in open(d / "s_bad.log").read() and not (d / "s_bad_map1_n1.mrc").exists()
