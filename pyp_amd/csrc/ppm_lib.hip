@@ -109,7 +109,9 @@ struct Trace {
     explicit Trace(const char *w) : who(w), on(getenv("PPM_TRACE") != nullptr), t0(std::chrono::steady_clock::now()) {}
     void mark(const char *what) const {
         if (!on) return;
+        const double host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         (void)hipStreamSynchronize(cur_stream());
+        fprintf(stderr, "%s: %8.2f ms  (host reached this mark)\n", who, host_ms);
         fprintf(stderr, "%s: %8.2f ms  %s\n", who, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), what);
     }
 };
