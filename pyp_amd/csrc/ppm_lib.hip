@@ -1201,7 +1201,15 @@ int ppm_insert_batch(ppm_accum_t *a, const ppm_recon_cfg *cfg, const void *image
     Geom gm; std::string err;
     if (!geom_init(gm, rc, err)) return fail(-22, err);
     const size_t NN = (size_t)gm.N * gm.N, HW = (size_t)gm.H * gm.W;
-    const size_t chunk_gb = getenv("PPM_INSERT_GB") ? (size_t)std::max(1, atoi(getenv("PPM_INSERT_GB"))) : 8;
+    // particles per k_prep / k_insert_bricks launch: 16 GB of images + band spectra (32 k particles at 256^2) where the device has them to
+    // spare, 8 GB otherwise; swept on the 500 k x 256^2 reconstruction (scripts/sweep_insert2.sh): 4 / 8 / 16 / 24 / 32 / 48 GB -> 1.44 / 1.51 /
+    // 1.55 / 1.54 / 1.54 / 1.54 M particles/s
+    size_t chunk_gb = 8;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b >= ((size_t)128 << 30) && free_b >= ((size_t)64 << 30)) chunk_gb = 16;
+    }
+    if (getenv("PPM_INSERT_GB")) chunk_gb = (size_t)std::max(1, atoi(getenv("PPM_INSERT_GB")));
     int CH = (int)std::min<size_t>((size_t)n_img, std::max<size_t>(32, (chunk_gb << 30) / (NN * 4 + HW * 8)));
     CH = std::min(CH, 32768);
     if (const char *e = std::getenv("PPM_CHUNK")) { int v = std::atoi(e); if (v > 0) CH = std::min(CH, v); }   // tests: force several chunks
