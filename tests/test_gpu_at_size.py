@@ -21,11 +21,11 @@ def _sva_cfg(n):      # the settings of bench.py's `sva` block = the 3DAVG refin
     return SvaCfg.make(n, window=(0.33 * n, 0.33 * n, 0.33 * n), window_sigma=4.0, highpass=(0.05, 0.01), lowpass=(0.125, 0.05), tol_angle=10.0, tol_shift=10.0)
 
 
-def test_sva_align_at_192_matches_oracle_on_four_sub_volumes():
+def test_sva_align_at_192_matches_oracle_on_twelve_sub_volumes():
     from oracle import oracle as O
     from pyp_amd import host
     n = 192
-    vol, vols, poses, wedges = synth.make_subtomograms(n, 4, snr=0.1, device="cuda")
+    vol, vols, poses, wedges = synth.make_subtomograms(n, 12, snr=0.1, device="cuda")
     cfg = _sva_cfg(n)
     start = synth.perturb_poses(poses, 3.0, 2.0)
     want, wsc, _ = O.sva_align(O.Reference(vol, n / 2), cfg, vols.cpu().numpy(), wedges, start)

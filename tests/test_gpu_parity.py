@@ -728,9 +728,9 @@ def test_accumulator_sum_is_linear(H, O):
 
 
 def test_baseline_size_256_matches_oracle(H, O):
-    """BASELINE.json configs[1] geometry (256^2 box, 15 deg, band 64 px, 20 hits) on a handful of particles against the
-    oracle itself (about a minute of CPU work on the GPU box's cores)."""
-    n, px, m = 256, 1.0, 6
+    """BASELINE.json configs[1] geometry (256^2 box, 15 deg, band 64 px, 20 hits) on 32 particles against the oracle itself (OpenMP over
+    the particles on the GPU box's cores; bench.py's parity_vs_oracle does the same on 256 particles of the timed stack)."""
+    n, px, m = 256, 1.0, 32
     vol, stack, rows = synth.make_dataset(n, m, pixel=px, snr=0.05)
     imgs = stack.numpy()
     c = RefineCfg.make(box=n, pixel_size=px, mask_radius=0.32 * n * px, res_high=4.0, res_search=4.0, search_range_x=6.0,
