@@ -126,7 +126,7 @@ def test_pyp_default_search_at_256_matches_oracle_mode_0(H, O):
     """BASELINE.json configs[1] geometry as PYP calls it: 256^2, 15 degrees, band 64 px, search range 0 = mask radius (82 pixels = 41
     steps of the 128-point grid: 83 x 83 shifts per orientation).  Grid points and shifts against the oracle's zero-filled inverse
     transform, then the whole default call (20 hits refined, best continued at the full band)."""
-    n, px, m = 256, 1.0, 4
+    n, px, m = 256, 1.0, 16
     vol, stack, rows = synth.make_dataset(n, m, pixel=px, snr=0.05)
     imgs = stack.numpy()
     base = dict(box=n, pixel_size=px, mask_radius=0.32 * n * px, res_high=4.0, res_search=4.0, search_range_x=0.0, search_range_y=0.0, res_signed_cc=30.0)
