@@ -196,3 +196,61 @@ def test_csp_refine_at_384_box_matches_oracle():
     gr, gp, gt = g.csp_refine(cfg, ct, imgs, rows3, parts, t2)
     assert np.abs(wt[:, 4:6] - gt[:, 4:6]).max() < 0.1 and np.abs(wt[:, 2:4] - gt[:, 2:4]).max() < 0.5
     assert synth.angular_error_deg(wr, gr).max() < 0.1 and synth.shift_error_px(wr, gr, px).max() < 0.5
+
+
+def test_insertion_at_256_weight_total_and_linearity_on_20000_particles():
+    """Size-independent properties of the Fourier insertion at BASELINE's box, on a sample far beyond what the oracle finishes in seconds
+    (20 000 random 256^2 images in device memory, two chunks): (1) every in-band sample of every particle is inserted exactly once - the
+    total of the weight channel equals sum over particles and samples of CTF^2 (the eight trilinear weights of a sample add up to one), computed here in
+    float64 from the rows; (2) the half maps split by the parity of the position; (3) linearity in the images:
+    insert(I1 + I2) = insert(I1) + insert(I2) with the normalisation off."""
+    import torch
+    from pyp_amd import host
+    from pyp_amd.abi import ReconCfg
+    n, px, m, kv, cs_mm, amp = 256, 1.0, 20000, 300.0, 2.7, 0.07
+    rng = np.random.default_rng(21)
+    C = cistem.COL
+    rows = cistem.default_rows(m, px, kv, cs_mm, amp)
+    rows[:, C["PSI"]], rows[:, C["PHI"]] = rng.uniform(0, 360, m), rng.uniform(0, 360, m)
+    rows[:, C["THETA"]] = np.degrees(np.arccos(rng.uniform(-1, 1, m)))
+    rows[:, C["X_SHIFT"]], rows[:, C["Y_SHIFT"]] = rng.normal(0, 2, m), rng.normal(0, 2, m)
+    df1 = rng.uniform(8000, 24000, m)
+    rows[:, C["DEFOCUS_1"]], rows[:, C["DEFOCUS_2"]], rows[:, C["DEFOCUS_ANGLE"]] = df1, df1 + rng.uniform(-300, 300, m), rng.uniform(0, 180, m)
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    i1 = torch.randn((m, n, n), generator=g, device="cuda", dtype=torch.float32)
+    i2 = torch.randn((m, n, n), generator=g, device="cuda", dtype=torch.float32)
+    r_band = 0.4 * n                                                                   # taps stay inside the accumulator's box
+    rc = ReconCfg(box=n, pixel_size=px, res_limit=px * n / r_band, normalize=0, split_by_pind=0, mask_radius=0.0)
+    accs = []
+    for imgs in (i1, i2, i1 + i2):
+        a = host.Accumulator(n, px, "C1")
+        a.insert(rc, imgs, rows)
+        accs.append((a.download().reshape(2, -1, 3).astype(np.float64), a.counts()))
+        a.close()
+    del i1, i2
+    (a1, c1), (a2, c2), (a12, c12) = accs
+    assert c1 == c2 == c12 == [m // 2, m // 2]                                         # positions 1 .. m: odd / even
+    # (1) total weight = sum of CTF^2 over the in-band samples kx >= 0 (both signs of ky on the kx = 0 column, the origin left out)
+    kx, ky = np.meshgrid(np.arange(0, 128), np.arange(-127, 128))
+    k2 = (kx * kx + ky * ky).astype(np.float64)
+    band = (k2 < r_band * r_band) & (k2 > 0)
+    kx, ky, k2 = kx[band].astype(np.float64), ky[band].astype(np.float64), k2[band]
+    lam = 12.2639 / np.sqrt(kv * 1e3 + 0.97845e-6 * (kv * 1e3) ** 2)
+    extra = np.arctan(amp / np.sqrt(1.0 - amp * amp))
+    s2 = k2 / (n * px) ** 2
+    c2, s2p = (kx * kx - ky * ky) / k2, 2 * kx * ky / k2
+    want = 0.0
+    for b0 in range(0, m, 500):
+        r = rows[b0:b0 + 500]
+        ast = np.radians(r[:, C["DEFOCUS_ANGLE"]])[:, None]
+        dsum, ddif = (r[:, C["DEFOCUS_1"]] + r[:, C["DEFOCUS_2"]])[:, None], (r[:, C["DEFOCUS_1"]] - r[:, C["DEFOCUS_2"]])[:, None]
+        df = 0.5 * (dsum + ddif * (c2 * np.cos(2 * ast) + s2p * np.sin(2 * ast)))
+        chi = np.pi * lam * s2 * (df - 0.5 * cs_mm * 1e7 * lam * lam * s2) + extra
+        want += float((np.sin(chi) ** 2).sum())
+    got = a1[:, :, 2].sum()
+    assert abs(got - want) < 2e-6 * want, (got, want)                                  # measured: 4e-8
+    # the weights do not depend on the images (float adds of the bricks' halo cells arrive in any order: equal to rounding, not to the bit)
+    assert abs(a2[:, :, 2].sum() - want) < 2e-5 * want and np.abs(a1[:, :, 2] - a2[:, :, 2]).max() <= 1e-5 * a1[:, :, 2].max()
+    # (3) linearity of the two value channels
+    lin = a1[:, :, :2] + a2[:, :, :2]
+    assert np.linalg.norm(a12[:, :, :2] - lin) < 2e-5 * np.linalg.norm(lin)
