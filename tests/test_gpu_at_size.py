@@ -254,3 +254,29 @@ def test_insertion_at_256_weight_total_and_linearity_on_20000_particles():
     # (3) linearity of the two value channels
     lin = a1[:, :, :2] + a2[:, :, :2]
     assert np.linalg.norm(a12[:, :, :2] - lin) < 2e-5 * np.linalg.norm(lin)
+
+
+@pytest.mark.parametrize("search_range,m", [(6.0, 4096), (0.0, 1024)])
+def test_global_search_at_256_is_equivariant_under_a_half_turn(search_range, m):
+    """Size-independent property of the grid search at BASELINE's box (256^2, 15 deg, band 64 px, +-6 px), no oracle needed: an image turned
+    by 180 degrees about the box centre is found at psi + 180 degrees with the shifts negated and the same score.  That is exactly what the
+    search's pairing rests on (one stored slice serves psi as W conj(P) and psi + 180 as W P), here checked from the outside on 4 096
+    particles through k_global and on 1 024 through k_gfft (PYP's default window, search range 0 = the mask radius: +-41 steps); the rare
+    particle whose two best grid points tie to rounding is allowed for."""
+    from pyp_amd import host
+    n, px = 256, 1.0
+    vol, stack, rows = synth.make_dataset(n, m, pixel=px, snr=0.05, device="cuda", unique=256)
+    turned = stack.flip(1, 2).roll((1, 1), (1, 2)).contiguous()                       # pixel i -> N - i (mod N): the box centre N/2 stays
+    c = RefineCfg.make(box=n, pixel_size=px, mask_radius=0.32 * n * px, res_high=4.0, res_search=4.0, search_range_x=search_range, search_range_y=search_range,
+                       res_signed_cc=30.0, local_refine=0, iters_hit=-1)              # the grid point itself, no refinement
+    g = host.Reference(vol, n / 2)
+    a = g.refine(c, stack, rows)
+    b = g.refine(c, turned, rows)
+    g.close()
+    C = cistem.COL
+    dpsi = (b[:, C["PSI"]] - a[:, C["PSI"]]) % 360.0
+    same = (np.abs(dpsi - 180.0) < 1e-6) & (np.abs(a[:, C["THETA"]] - b[:, C["THETA"]]) < 1e-6) & (np.abs(a[:, C["PHI"]] - b[:, C["PHI"]]) < 1e-6) & \
+           (np.abs(a[:, C["X_SHIFT"]] + b[:, C["X_SHIFT"]]) < 1e-6) & (np.abs(a[:, C["Y_SHIFT"]] + b[:, C["Y_SHIFT"]]) < 1e-6)
+    assert same.mean() > 0.995, same.mean()
+    assert np.abs(a[same, C["SCORE"]] - b[same, C["SCORE"]]).max() < 0.01             # SCORE is 100 x cc
+    assert np.abs(a[~same, C["SCORE"]] - b[~same, C["SCORE"]]).max(initial=0.0) < 0.05   # ties to rounding, not different answers
