@@ -157,3 +157,21 @@ def test_rows_of_the_window_in_several_chunks(H, O, monkeypatch):
     b = g.refine(c, imgs, rows)
     same_grid_point_and_shift(a, b, px, 2.0)
     assert np.array_equal(a[:, 14], b[:, 14])
+
+
+def test_both_search_kernels_agree_at_256_on_256_particles(H, monkeypatch):
+    """PYP's default window (+-41 steps of the 128-point grid) at 256^2 / 15 deg / band 64 on 256 particles through the two independent
+    kernels: k_gfft (one pruned 2-D transform per orientation) and k_global (25 overlapping register tiles of +-8 steps, merged): the same
+    grid orientation and integer shift for every particle, scores to rounding."""
+    n, px, m = 256, 1.0, 256
+    vol, stack, rows = synth.make_dataset(n, m, pixel=px, snr=0.05, device="cuda", unique=64)
+    c = RefineCfg.make(box=n, pixel_size=px, mask_radius=0.32 * n * px, res_high=4.0, res_search=4.0, search_range_x=0.0, search_range_y=0.0,
+                       res_signed_cc=30.0, local_refine=0, iters_hit=-1)
+    g = H.Reference(vol, n / 2)
+    monkeypatch.setenv("PPM_GLOBAL_PATH", "tiles")
+    a = g.refine(c, stack, rows)
+    monkeypatch.setenv("PPM_GLOBAL_PATH", "fft")
+    b = g.refine(c, stack, rows)
+    monkeypatch.delenv("PPM_GLOBAL_PATH")
+    g.close()
+    same_grid_point_and_shift(a, b, px, 2.0)
