@@ -170,7 +170,7 @@ __device__ __forceinline__ void sweep_plan(SweepPlan &plan, const SweepCtx &C, c
     for (int i = tid; i < nslots * nw * nr; i += nthr) ringA[i] = 0.f;
     if (tid < kMaxCand * nw) sumB[tid] = 0.f;
     if (tid < ng * 6) (&plan.ms[0][0])[tid] = (&plan.m[0][0])[tid] * C.cv.scale;
-    if (tid >= 64 && tid < 64 + ng) { const int g = tid - 64, q0 = plan.slot0[g]; for (int v = 0; v < plan.nv[g]; v++) plan.bsl[q0 + v] = q0; }
+    { const int g = nthr > 64 ? tid - 64 : tid; if (g >= 0 && g < ng) { const int q0 = plan.slot0[g]; for (int v = 0; v < plan.nv[g]; v++) plan.bsl[q0 + v] = q0; } }
     __syncthreads();
     float *const myA = ringA + wave * nr, *const myB = sumB + wave;
     const int q_same = plan.q_same, strideA = nw * nr;
@@ -254,7 +254,9 @@ __device__ __forceinline__ void sweep_plan(SweepPlan &plan, const SweepCtx &C, c
     if (lane == 0) sumC[wave] = accC;
     __syncthreads();
     {   // 8 lanes per slot: lane j takes the rings j, j + 8, ...; waves and lanes are combined in a fixed order
-        const int slot = tid >> 3, j = tid & 7;
+        const int j = tid & 7;
+        for (int slot0_ = 0; slot0_ < nslots; slot0_ += nthr >> 3) {          // one trip with 128 or 256 threads (<= 13 slots), two with 64
+        const int slot = slot0_ + (tid >> 3);
         double sa = 0;
         if (slot < nslots)
             for (int b = j; b < nr; b += 8) {
@@ -270,6 +272,7 @@ __device__ __forceinline__ void sweep_plan(SweepPlan &plan, const SweepCtx &C, c
             for (int w = 1; w < nw; w++) { fb += sumB[bs * nw + w]; fc += sumC[w]; }
             const double sb = fb, sc = fc;
             score[slot] = (sb > 0 && sc > 0) ? sa / sqrt(sb * sc) : 0.0;
+        }
         }
     }
     __syncthreads();

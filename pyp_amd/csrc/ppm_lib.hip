@@ -965,6 +965,7 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
     LP.tabR = cube_tab_radius(gm.B, cv.scale);
     // tap addresses from LDS tables (ppm_dev.h) unless the tables would crowd the ring sums out of a CU (PPM_LOCAL_TABLES=0: arithmetic)
     const bool local_tab = !(getenv("PPM_LOCAL_TABLES") && atoi(getenv("PPM_LOCAL_TABLES")) == 0) && cube_tab_bytes(LP.tabR) <= 16 * 1024;
+    const int final_threads = (getenv("PPM_LOCAL_FINAL_THREADS") && atoi(getenv("PPM_LOCAL_FINAL_THREADS")) == 128) ? 128 : 256;      // A/B knob
     auto launch_local = [&](unsigned grid, int threads) {
         const size_t ring = ring_lds_bytes8(threads / 64, kMaxCand, LP.nr);
         const bool tab = local_tab && ring + cube_tab_bytes(LP.tabR) + 2048 <= (size_t)64 * 1024;      // with the kernel's static LDS inside the 64 KB a launch may ask for (box 512 at the full band: arithmetic)
@@ -1073,8 +1074,10 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
                 LP.nr = std::min(nrings, (int)std::ceil(gm.r_s) + 1);
                 fill_schedule(0.5 * gm.dstep, gm.step, 0, Tb, gm.r_s, (double)K);
                 ProfScope ps(PPM_K_LOCAL);
-                // 128-thread blocks for the hit stage (<= ~800 samples per sweep: two waves waste less on the serial steps), 256 below
-                launch_local((unsigned)(nb * K), 128);
+                // small blocks for the hit stage: one wave up to 1 024 samples per sweep (no cross-wave steps, 64-sample granularity: k_local
+                // 83.9 -> 80.9 ms per 28 672 particles against two waves, 93.2 with four; scripts/ab_hit_threads.sh), two waves above; 256 threads below
+                const int hit_threads = getenv("PPM_LOCAL_HIT_THREADS") ? atoi(getenv("PPM_LOCAL_HIT_THREADS")) : (LP.S_it[0] <= 1024 ? 64 : 128);
+                launch_local((unsigned)(nb * K), hit_threads == 64 || hit_threads == 256 ? hit_threads : 128);
             }
             {
                 ProfScope ps(PPM_K_TOPK);
@@ -1085,7 +1088,7 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
                 fill_schedule(0.5 * gm.dstep / (double)(1 << Tb), gm.step / (double)(1 << Tb), Tb, LP.T, gm.r_hi, 1.0);
                 sample_evals += std::floor(kPi * gm.r_hi * gm.r_hi / 2);
                 ProfScope ps(PPM_K_LOCAL);
-                launch_local((unsigned)nb, 256);
+                launch_local((unsigned)nb, final_threads);
             }
         } else {
             double ha0 = cfg->local_angle_step > 0 ? cfg->local_angle_step : 2.5, hs0 = cfg->local_shift_step > 0 ? cfg->local_shift_step : 2.0;
@@ -1095,7 +1098,7 @@ int ppm_refine_batch(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const void *imag
             fill_schedule(ha0, hs0, 0, LP.T, gm.r_hi, 1.0);
             sample_evals += std::floor(kPi * gm.r_hi * gm.r_hi / 2);
             ProfScope ps(PPM_K_LOCAL);
-            launch_local((unsigned)nb, 256);
+            launch_local((unsigned)nb, final_threads);
         }
         const float *d_ddef = nullptr;
         if (ndef > 0) {                                 // defocus offsets at the final pose
@@ -1743,6 +1746,11 @@ extern "C" int ppm_csp_refine(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const p
     EP.cv.cube = ref->cube; EP.cv.NBX = ref->NBX; EP.cv.NBY = ref->NBY; EP.cv.LB = ref->LB; EP.cv.off = ref->B + 1; EP.cv.scale = (float)ref->pad;
     EP.samples = ref->samples.p; EP.Il = Il.p; EP.cw = cw.p; EP.S_pad = S_pad; EP.N = gm.N; EP.nr = nrings;
     EP.tabR = cube_tab_radius(gm.B, EP.cv.scale);
+    // threads per block of k_csp_eval by the samples of a sweep (PPM_CSP_THREADS = 64 / 128 / 256 forces one)
+    auto csp_threads = [](int S_used) {
+        if (const char *e = getenv("PPM_CSP_THREADS")) { const int v = atoi(e); if (v == 64 || v == 128 || v == 256) return v; }
+        return 256;
+    };
     const int csp_bpc = getenv("PPM_CSP_BLOCKS_PER_CU") ? atoi(getenv("PPM_CSP_BLOCKS_PER_CU")) : 0;      // blocks of k_csp_eval per CU through the LDS request (0: what registers and LDS allow)
     const bool csp_tab = !(getenv("PPM_LOCAL_TABLES") && atoi(getenv("PPM_LOCAL_TABLES")) == 0) && cube_tab_bytes(EP.tabR) <= 16 * 1024 &&
                          ring_lds_bytes8(4, kMaxCand, nrings) + cube_tab_bytes(EP.tabR) + 2048 <= (size_t)64 * 1024;
@@ -1775,10 +1783,11 @@ extern "C" int ppm_csp_refine(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const p
         {
             ProfScope ps(PPM_K_LOCAL);
             {
-                size_t lds = ring_lds_bytes8(4, kMaxCand, nrings) + (csp_tab ? cube_tab_bytes(EP.tabR) : 0);
+                const int thr = csp_threads(EP.S_used);
+                size_t lds = ring_lds_bytes8(thr / 64, kMaxCand, nrings) + (csp_tab ? cube_tab_bytes(EP.tabR) : 0);
                 if (csp_bpc > 0 && csp_bpc < 8) lds = std::min((size_t)63 * 1024, std::max(lds, (size_t)(160 * 1024 / (csp_bpc + 1) + 1024) & ~(size_t)1023));
-                if (csp_tab) hipLaunchKernelGGL(k_csp_eval<true>, dim3((unsigned)rows_list.size()), dim3(256), lds, cur_stream(), EP);
-                else hipLaunchKernelGGL(k_csp_eval<false>, dim3((unsigned)rows_list.size()), dim3(256), lds, cur_stream(), EP);
+                if (csp_tab) hipLaunchKernelGGL(k_csp_eval<true>, dim3((unsigned)rows_list.size()), dim3(thr), lds, cur_stream(), EP);
+                else hipLaunchKernelGGL(k_csp_eval<false>, dim3((unsigned)rows_list.size()), dim3(thr), lds, cur_stream(), EP);
             }
         }
         if (means) {
@@ -1831,10 +1840,11 @@ extern "C" int ppm_csp_refine(ppm_ref_t *ref, const ppm_refine_cfg *cfg, const p
             acct_gathers += (double)eval_rows.size() * EP.S_used * (nc > 1 ? 1 + nrot_c : 1); acct_sweeps++;
             {
                 ProfScope ps(PPM_K_LOCAL);
-                size_t lds = ring_lds_bytes8(4, kMaxCand, nrings) + (csp_tab ? cube_tab_bytes(EP.tabR) : 0);
+                const int thr = csp_threads(EP.S_used);
+                size_t lds = ring_lds_bytes8(thr / 64, kMaxCand, nrings) + (csp_tab ? cube_tab_bytes(EP.tabR) : 0);
                 if (csp_bpc > 0 && csp_bpc < 8) lds = std::min((size_t)63 * 1024, std::max(lds, (size_t)(160 * 1024 / (csp_bpc + 1) + 1024) & ~(size_t)1023));
-                if (csp_tab) hipLaunchKernelGGL(k_csp_eval<true>, dim3((unsigned)eval_rows.size()), dim3(256), lds, cur_stream(), EP);
-                else hipLaunchKernelGGL(k_csp_eval<false>, dim3((unsigned)eval_rows.size()), dim3(256), lds, cur_stream(), EP);
+                if (csp_tab) hipLaunchKernelGGL(k_csp_eval<true>, dim3((unsigned)eval_rows.size()), dim3(thr), lds, cur_stream(), EP);
+                else hipLaunchKernelGGL(k_csp_eval<false>, dim3((unsigned)eval_rows.size()), dim3(thr), lds, cur_stream(), EP);
             }
             const int nm = na * nc;
             hipLaunchKernelGGL(k_csp_unit_means, dim3((nm + 255) / 256), dim3(256), 0, cur_stream(), d_out.p, ref->c_uoff.p, na, nc, means);
